@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by IMPORTING THE REAL REFERENCE (/root/reference).
+
+Runs only in the build container (the reference never travels to the GPU box;
+only these small data fixtures do).  Usage:  python oracle/gen_golden.py
+
+What is produced (all inputs/weights are regenerated from oracle/seeded.py by
+the tests, so only expected outputs are stored):
+
+  loss_cases.npz      reference BCEandDiceLoss / nn.CrossEntropyLoss values + grads
+  snunet_small.npz    SNUNet_ECAM(c, 3, base_channel=8) B=2 32x32: eval logits, train
+                      logits, loss, per-parameter grad stats + selected full grads, BN
+                      running stats after one step, 3-step Adam loss sequence
+  snunet_full.npz     SNUNet_ECAM(2, 3, 32) 224x224: eval logits (B=1) subsample +
+                      full argmax mask; train step (B=2) loss + grad norms
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+
+from oracle.seeded import seeded_fill_, seeded_labels, seeded_tensor  # noqa: E402
+
+from models.snunet import SNUNet_ECAM  # noqa: E402  (reference)
+from utilities.bce_and_dice import BCEandDiceLoss  # noqa: E402  (reference)
+
+OUT = os.path.join(ROOT, "tests", "golden")
+CLASS_WEIGHTS = [0.3715753140309927, 14.009780283125977, 8.20405370357821]  # utilities.py:393-397
+FULL_GRAD_KEYS = [
+    "conv0_0.conv1.weight", "conv0_0.conv1.bias", "conv0_0.bn1.weight", "conv0_0.bn2.bias",
+    "conv1_0.conv2.weight", "conv4_0.bn2.weight", "Up1_0.up.weight", "Up4_0.up.bias",
+    "conv0_4.conv1.weight", "conv2_2.conv1.bias", "ca.fc1.weight", "ca.fc2.weight",
+    "ca1.fc1.weight", "ca1.fc2.weight", "conv_final.weight", "conv_final.bias",
+]
+
+
+def sar_like(name, shape):
+    """Normalised-backscatter-like inputs: randn clipped to the VV/VH range of
+    SURVEY.md §8(d) (after clamp 0.15 + normalise)."""
+    return seeded_tensor(name, shape).mul_(1.0).clamp_(-2.23, 5.75)
+
+
+def gen_loss():
+    out = {}
+    # KAT-loss-1
+    kat_logits = torch.tensor([[[[1, -.5], [.25, 2]], [[0, .5], [-1, .5]], [[-1, 1.5], [.75, -2]]]], dtype=torch.float32)
+    kat_lbl = torch.tensor([[[0, 2], [3, 1]]], dtype=torch.int64)
+    cases = {"kat": (kat_logits, kat_lbl)}
+    cases["rand"] = (seeded_tensor("loss.rand.logits", (2, 3, 16, 16)) * 2.0, seeded_labels("loss.rand.labels", (2, 16, 16)))
+    cases["big"] = (seeded_tensor("loss.big.logits", (3, 3, 64, 48)) * 4.0, seeded_labels("loss.big.labels", (3, 64, 48), p_invalid=0.3))
+    for cname, (x, t) in cases.items():
+        for wname, w in (("unit", [1.0, 1.0, 1.0]), ("cw", CLASS_WEIGHTS)):
+            crit = BCEandDiceLoss(weights=w, ignore_index=3, use_softmax=True)
+            xx = x.clone().requires_grad_(True)
+            dice = crit.dice(xx, t)
+            ce = crit.bce(xx, t)
+            total = crit(xx, t)
+            total.backward()
+            out[f"{cname}.{wname}.dice"] = dice.detach().numpy()
+            out[f"{cname}.{wname}.ce"] = ce.detach().numpy()
+            out[f"{cname}.{wname}.total"] = total.detach().numpy()
+            out[f"{cname}.{wname}.grad"] = xx.grad.numpy().copy()
+            # plain (weighted) cross entropy = create_loss 'cross_entropy' train mode
+            xx2 = x.clone().requires_grad_(True)
+            ce2 = torch.nn.CrossEntropyLoss(weight=torch.tensor(w), ignore_index=3)(xx2, t)
+            ce2.backward()
+            out[f"{cname}.{wname}.ce_only"] = ce2.detach().numpy()
+            out[f"{cname}.{wname}.ce_only_grad"] = xx2.grad.numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "loss_cases.npz"), **out)
+    print("loss_cases.npz", {k: float(v) for k, v in out.items() if v.ndim == 0 and k.startswith("kat")})
+
+
+def _ref_model(c, bc):
+    m = SNUNet_ECAM(c, 3, base_channel=bc)
+    seeded_fill_(m.state_dict())
+    return m
+
+
+def _grad_stats(model):
+    stats, full = {}, {}
+    for k, p in model.named_parameters():
+        g = p.grad.detach().double()
+        stats[k] = np.array([float(g.norm()), float(g.sum()), float(g.abs().max())])
+        if k in FULL_GRAD_KEYS:
+            full[k] = p.grad.detach().numpy().copy()
+    return stats, full
+
+
+def gen_snunet_small():
+    out = {}
+    for c in (2, 3):
+        tag = f"c{c}"
+        B, H, W, bc = 2, 32, 32, 8
+        xA = sar_like(f"small.{tag}.xA", (B, c, H, W))
+        xB = sar_like(f"small.{tag}.xB", (B, c, H, W))
+        lbl = seeded_labels(f"small.{tag}.lbl", (B, H, W))
+        model = _ref_model(c, bc)
+        model.eval()
+        with torch.no_grad():
+            out[f"{tag}.eval_logits"] = model(xA, xB).numpy().copy()
+        # --- one train step, ce+dice with class weights, Adam lr 1e-3
+        model = _ref_model(c, bc)
+        model.train()
+        crit = BCEandDiceLoss(weights=CLASS_WEIGHTS, ignore_index=3, use_softmax=True)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+        losses = []
+        for step in range(3):
+            opt.zero_grad()
+            logits = model(xA, xB)
+            loss = crit(logits, lbl)
+            loss.backward()
+            if step == 0:
+                out[f"{tag}.train_logits"] = logits.detach().numpy().copy()
+                stats, full = _grad_stats(model)
+                for k, v in stats.items():
+                    out[f"{tag}.gstat.{k}"] = v
+                for k, v in full.items():
+                    out[f"{tag}.grad.{k}"] = v
+            opt.step()
+            losses.append(float(loss))
+            if step == 0:
+                sd = model.state_dict()
+                for k in ("conv0_0.bn1", "conv0_0.bn2", "conv4_0.bn1", "conv0_4.bn2", "conv2_1.bn1"):
+                    out[f"{tag}.bn.{k}.running_mean"] = sd[f"{k}.running_mean"].numpy().copy()
+                    out[f"{tag}.bn.{k}.running_var"] = sd[f"{k}.running_var"].numpy().copy()
+                    out[f"{tag}.bn.{k}.num_batches_tracked"] = sd[f"{k}.num_batches_tracked"].numpy().copy()
+                for k in ("conv0_0.conv1.weight", "conv_final.weight", "ca.fc1.weight"):
+                    out[f"{tag}.param1.{k}"] = sd[k].numpy().copy()
+        out[f"{tag}.losses"] = np.array(losses)
+        sd = model.state_dict()
+        out[f"{tag}.param3_sums"] = np.array([float(sd[k].double().sum()) for k in sd if sd[k].dtype.is_floating_point])
+        print("snunet_small", tag, losses)
+    np.savez_compressed(os.path.join(OUT, "snunet_small.npz"), **out)
+
+
+def gen_snunet_full():
+    out = {}
+    c, bc, H, W = 2, 32, 224, 224
+    xA = sar_like("full.xA", (1, c, H, W))
+    xB = sar_like("full.xB", (1, c, H, W))
+    model = _ref_model(c, bc)
+    model.eval()
+    with torch.no_grad():
+        logits = model(xA, xB)
+    out["eval_logits_sub"] = logits[:, :, ::8, ::8].numpy().copy()
+    out["eval_argmax"] = logits.argmax(1).numpy().astype(np.uint8)
+    top2 = logits.topk(2, dim=1).values
+    out["eval_margin"] = (top2[:, 0] - top2[:, 1]).numpy().astype(np.float16)
+    out["eval_logits_absmax"] = np.array(float(logits.abs().max()))
+    # train step, B=2
+    xA = sar_like("full.train.xA", (2, c, H, W))
+    xB = sar_like("full.train.xB", (2, c, H, W))
+    lbl = seeded_labels("full.train.lbl", (2, H, W))
+    model = _ref_model(c, bc)
+    model.train()
+    crit = BCEandDiceLoss(weights=[1.0, 1.0, 1.0], ignore_index=3, use_softmax=True)
+    logits = model(xA, xB)
+    loss = crit(logits, lbl)
+    loss.backward()
+    out["train_logits_sub"] = logits[:, :, ::8, ::8].detach().numpy().copy()
+    out["train_loss"] = np.array(float(loss))
+    stats, full = _grad_stats(model)
+    for k, v in stats.items():
+        out[f"gstat.{k}"] = v
+    for k in ("conv0_0.conv1.weight", "conv_final.weight", "ca.fc1.weight", "ca1.fc2.weight", "Up1_3.up.bias"):
+        out[f"grad.{k}"] = full[k] if k in full else dict(model.named_parameters())[k].grad.numpy().copy()
+    print("snunet_full loss", float(loss))
+    np.savez_compressed(os.path.join(OUT, "snunet_full.npz"), **out)
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    os.makedirs(OUT, exist_ok=True)
+    gen_loss()
+    gen_snunet_small()
+    gen_snunet_full()
