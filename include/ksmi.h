@@ -1,0 +1,252 @@
+/* libksmi — C-ABI of the MI355X-native (gfx950) Kuro Siwo training hot path.
+ *
+ * The reference (Orion-AI-Lab/KuroSiwo) is pure Python on torch.nn and has no FFI
+ * layer; each entry point below replaces the ATen/cuDNN op(s) behind one row of
+ * SURVEY.md §8(a) and cites the reference file:line whose computation it takes over.
+ * A reference-side binding (ctypes stub) for every group is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain pointers + sizes, no torch types; every pointer is DEVICE memory owned by
+ *     the caller (PyTorch allocator); kernels never allocate or free.
+ *   - every launch goes to the `stream` argument (hipStream_t passed as void*).
+ *   - return 0 on success, a positive hipError_t, or a negative KSMI_E_* code;
+ *     ksmi_last_error() returns a thread-local message.  Launches are asynchronous.
+ *   - dtype codes: KSMI_F32 = 0 (parity mode), KSMI_BF16 = 1 (performance mode).
+ *     Activations are NHWC in `dtype`; parameters, gradients, statistics are fp32.
+ *   - boundary tensors keep the reference layout: images NCHW fp32, labels int64
+ *     [B,H,W], logits NCHW fp32.
+ */
+#ifndef KSMI_H
+#define KSMI_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KSMI_ABI_VERSION 1
+#define KSMI_F32 0
+#define KSMI_BF16 1
+#define KSMI_E_ARG (-1)
+#define KSMI_E_UNSUPPORTED (-2)
+#define KSMI_MAX_SRC 6
+#define KSMI_MAX_CHUNKS 72
+
+int ksmi_abi_version(void);
+const char* ksmi_last_error(void);
+/* bytes of K per packed k-chunk / elements per chunk for a dtype (32 bf16, 16 fp32) */
+int ksmi_chunk_elems(int dtype);
+
+/* ---------------------------------------------------------------------------------
+ * Implicit-GEMM convolution family (MFMA).  Replaces nn.Conv2d / nn.ConvTranspose2d
+ * forward + input-gradient + weight-gradient:
+ *   models/snunet.py:15-17 (3x3 convs), :41 (ConvTranspose2d k2 s2), :132-146
+ *   (torch.cat => "virtual concat": up to 6 NHWC sources read in place).
+ * ------------------------------------------------------------------------------- */
+typedef struct ksmi_src {
+  const void* ptr;     /* NHWC activations, `dtype` */
+  const float* scale;  /* optional per-channel affine applied on load: v*scale[c]+shift[c] */
+  const float* shift;  /*   (indexed by channel within this source's used range)          */
+  int32_t C;           /* channel count of the tensor (pixel stride)                        */
+  int32_t c_off;       /* first channel used                                                */
+  int32_t c_len;       /* number of channels used (multiple of 8)                           */
+  int32_t relu;        /* apply max(0,.) after the affine                                   */
+} ksmi_src;
+
+typedef struct ksmi_dst {
+  void* ptr;           /* NHWC activations, `dtype` */
+  int32_t C;           /* channel count of the tensor                                       */
+  int32_t c_off;       /* first channel written                                             */
+  int32_t n_begin;     /* first GEMM column mapped to this segment (segments ascending)     */
+  int32_t n_len;       /* number of columns                                                 */
+  int32_t accumulate;  /* 1: dst += result                                                  */
+  int32_t pad_;
+} ksmi_dst;
+
+typedef struct ksmi_conv_desc {
+  ksmi_src src[KSMI_MAX_SRC];
+  ksmi_dst dst[KSMI_MAX_SRC];
+  int32_t nsrc, ndst;
+  const void* wpk;      /* packed weights (ksmi_pack_weights), `dtype` */
+  const float* bias;    /* [N] fp32 or NULL */
+  float* stats;         /* NULL or [grid_m][2][Npad] partial (sum, sumsq) of the fp32 results  */
+  /* optional ReLU/BatchNorm-backward epilogue (dgrad of conv2 in conv_block_nested,
+   * models/snunet.py:19-29): result *= (m*m_scale+m_shift > 0) with m read from mask_src;
+   * stats then holds (sum r, sum r*xhat), xhat = (m - m_mean)*m_rstd.                   */
+  const void* mask_src; /* NHWC `dtype`, N channels */
+  const float* m_mean; const float* m_rstd; const float* m_scale; const float* m_shift;
+  int32_t B, Hin, Win, Hout, Wout;
+  int32_t KH, KW, stride, pad;   /* supported: 3x3 s1 p1, 1x1 s1 p0, 2x2 s2 p0 */
+  int32_t TH, TW;                /* output patch per workgroup, TH*TW <= 256 */
+  int32_t N, Npad;               /* GEMM columns (output channels), padded to 16 */
+  int32_t nchunks;
+  int32_t ps_cout;               /* >0: pixel-shuffle store for ConvTranspose2d(k2,s2): N = 4*ps_cout,
+                                    column j=(dy*2+dx)*ps_cout+n -> out[b,2y+dy,2x+dx,n] */
+  uint16_t chunk_c0[KSMI_MAX_CHUNKS];  /* channel offset (within the source's used range) per k-chunk */
+  uint8_t chunk_src[KSMI_MAX_CHUNKS];  /* source index per k-chunk */
+} ksmi_conv_desc;
+
+/* number of M-tiles (= rows of `stats`) a descriptor launches */
+int ksmi_conv_grid_m(const ksmi_conv_desc* d);
+int ksmi_conv_forward(const ksmi_conv_desc* d, int dtype, void* stream);
+
+/* Weight packing fp32 parameter -> `dtype` [nchunks][taps][Npad][chunk_elems].
+ * element (chunk, tap, j, kk) = w[ k*sK + (j % n_mod)*sN + (j / n_mod)*sD + tap'*sT ],
+ * k = k_off[chunk] + kk (zero if kk >= k_len[chunk]); tap' = taps-1-tap if flip. */
+typedef struct ksmi_pack_desc {
+  const float* w; void* out;
+  int32_t nchunks, taps, N, Npad, n_mod;
+  int64_t sK, sN, sD, sT;
+  int32_t flip;
+  int32_t k_off[KSMI_MAX_CHUNKS];
+  int32_t k_len[KSMI_MAX_CHUNKS];
+} ksmi_pack_desc;
+int ksmi_pack_weights(const ksmi_pack_desc* d, int dtype, void* stream);
+
+/* Weight gradient: G[tap][k][n] = sum_pixels X[p*stride+tap-pad][k] * dY[p][n], X = virtual
+ * concat (with the same optional affine+ReLU on load), reduced over all pixels with a
+ * split over M-tiles, then written as fp32 to grad[k*gK + n*gN + tap*gT] (+= if accumulate). */
+typedef struct ksmi_wgrad_desc {
+  ksmi_src src[KSMI_MAX_SRC];
+  int32_t nsrc;
+  const void* dy; int32_t dyC; int32_t dy_c_off;   /* NHWC `dtype` */
+  int32_t B, Hin, Win, Hout, Wout;
+  int32_t KH, KW, stride, pad;
+  int32_t TH, TW;
+  int32_t N;                 /* columns (channels of dY used), multiple of 8 */
+  int32_t nchunks;
+  int32_t nsplit;            /* number of partial slabs (workgroups along the pixel axis) */
+  float* partial;            /* workspace [nsplit][taps][nchunks*chunk_elems][Npad16] fp32 */
+  float* grad; int64_t gK, gN, gT; int32_t accumulate;
+  int32_t k_off[KSMI_MAX_CHUNKS];  /* first K index (row of grad) of each chunk */
+  int32_t k_len[KSMI_MAX_CHUNKS];
+  uint16_t chunk_c0[KSMI_MAX_CHUNKS];
+  uint8_t chunk_src[KSMI_MAX_CHUNKS];
+} ksmi_wgrad_desc;
+size_t ksmi_conv_wgrad_workspace(const ksmi_wgrad_desc* d, int dtype);
+int ksmi_conv_wgrad(const ksmi_wgrad_desc* d, int dtype, void* stream);
+
+/* First-layer 3x3 conv on the raw image (NCHW fp32, Cin <= 8 -> Cout = 32*k):
+ * models/snunet.py:75 conv0_0.conv1.  Forward writes NHWC `dtype` + BN partial stats;
+ * wgrad writes fp32 dW (OIHW) and db. */
+int ksmi_conv_first_forward(const float* x_nchw, const float* w, const float* bias, void* out, float* stats,
+                            int B, int Cin, int H, int W, int Cout, int dtype, void* stream);
+int ksmi_conv_first_stats_rows(int B, int H, int W);
+int ksmi_conv_first_wgrad(const float* x_nchw, const void* dy, float* dw, float* workspace, size_t ws_bytes,
+                          int B, int Cin, int H, int W, int Cout, int accumulate, int dtype, void* stream);
+size_t ksmi_conv_first_wgrad_workspace(int B, int Cin, int H, int W, int Cout);
+
+/* ---------------------------------------------------------------------------------
+ * BatchNorm2d (train: batch statistics) + the conv_block_nested glue,
+ * models/snunet.py:16,18,19-29 (nn.BatchNorm2d defaults eps 1e-5, momentum 0.1).
+ * ------------------------------------------------------------------------------- */
+/* partial [rows][2][Cpad] (sum, sumsq) -> mean, rstd, scale=gamma*rstd, shift=beta-mean*scale;
+ * updates running_mean/var (unbiased var) and num_batches_tracked (int64) when training.
+ * training==0: scale/shift from the running statistics. */
+int ksmi_bn_finalize(const float* partial, int rows, int Cpad, int C, double count,
+                     const float* gamma, const float* beta, float* running_mean, float* running_var,
+                     int64_t* num_batches_tracked, float momentum, float eps, int training,
+                     float* mean, float* rstd, float* scale, float* shift, void* stream);
+/* out = relu(z*scale + shift + identity)   (snunet.py:27-28) */
+int ksmi_bn_add_relu(const void* z, const void* identity, const float* scale, const float* shift, void* out,
+                     int64_t npix, int C, int dtype, void* stream);
+/* backward of out = relu(bn2(z) + i):  g = dout*(out>0) (written in place of dout);
+ * pass 1 accumulates partial[rows][2][C] = (sum g, sum g*zhat). */
+int ksmi_bnrelu_bwd_reduce(const void* dout, const void* out, const void* z, const float* mean, const float* rstd,
+                           float* partial, int rows, int64_t npix, int C, int dtype, void* stream);
+/* sums[K][C] = sum over rows of partial[row][k][Cstride] (fp64 accumulate); optionally
+ * dgamma (+)= sums[1], dbeta (+)= sums[0] */
+int ksmi_reduce_rows(const float* partial, int rows, int K, int Cstride, int C, float* sums,
+                     float* dgamma, float* dbeta, int accumulate, void* stream);
+/* pass 2: g = dout*(out>0) -> dout (in place); dz = gamma*rstd*(g - s0/n - zhat*s1/n) */
+int ksmi_bnrelu_bwd_apply(void* dout_g, const void* out, const void* z, const float* mean, const float* rstd,
+                          const float* gamma, const float* sums, void* dz, double count,
+                          int64_t npix, int C, int dtype, void* stream);
+/* di = g + gamma*rstd*(r - t0/n - xhat*t1/n), xhat=(i-mean)*rstd; written over r; also
+ * partial[rows][1][C] = sum di (conv1 bias gradient). */
+int ksmi_bn_bwd_apply_add(void* r_di, const void* g, const void* i, const float* mean, const float* rstd,
+                          const float* gamma, const float* sums, float* partial, int rows, double count,
+                          int64_t npix, int C, int dtype, void* stream);
+/* partial[rows][1][C] = per-channel sum of x (bias gradients) */
+int ksmi_channel_sum(const void* x, float* partial, int rows, int64_t npix, int C, int dtype, void* stream);
+
+/* nn.MaxPool2d(2,2)  models/snunet.py:73 ; backward routes to the first maximum */
+int ksmi_maxpool2x2_forward(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream);
+int ksmi_maxpool2x2_backward(const void* x, const void* dy, void* dx, int accumulate,
+                             int B, int H, int W, int C, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * ECAM head: models/snunet.py:49-62 (ChannelAttention), :146-151 (fusion + conv_final).
+ * x[4] = x0_1..x0_4, NHWC `dtype`, C channels each (C = base_channel).
+ * ------------------------------------------------------------------------------- */
+/* pooled[B][5C] avg, [B][5C] max (first 4C: cat(x0_1..4), last C: their sum), argmax idx */
+int ksmi_ecam_pool(const void* const x[4], float* avg, float* mx, int32_t* argmax,
+                   float* workspace, int B, int HW, int C, int dtype, void* stream);
+size_t ksmi_ecam_pool_workspace(int B, int HW, int C);
+/* ca[B][4C] and ca1[B][C] = sigmoid(fc2(relu(fc1(avg))) + fc2(relu(fc1(max)))) */
+int ksmi_ecam_mlp(const float* avg, const float* mx, const float* ca_fc1, const float* ca_fc2,
+                  const float* ca1_fc1, const float* ca1_fc2, float* ca, float* ca1,
+                  float* hidden /* [B][2][(4C/16)+(C/4)] saved for backward */, int B, int C, void* stream);
+/* logits[b,k,p] = bias[k] + sum_c Wf[k][c] * ca[b,c]*(x[c/C][b,p,c%C] + ca1[b,c%C])  (NCHW fp32 out) */
+int ksmi_ecam_final_forward(const void* const x[4], const float* ca, const float* ca1, const float* wf,
+                            const float* bias, float* logits, int B, int HW, int C, int ncls, int dtype, void* stream);
+/* backward, phase A: reductions dca[B][4C], dca1[B][C], dWf[ncls][4C], dbias[ncls] (partials in ws) */
+int ksmi_ecam_final_backward_reduce(const void* const x[4], const float* dlogits, const float* ca, const float* ca1,
+                                    const float* wf, float* dca, float* dca1, float* dwf, float* dbias,
+                                    float* workspace, int B, int HW, int C, int ncls, int dtype, void* stream);
+size_t ksmi_ecam_bwd_workspace(int B, int HW, int C, int ncls);
+/* MLP backward: dca,dca1 -> davg[B][5C], dmax[B][5C], and fc weight grads (+=) */
+int ksmi_ecam_mlp_backward(const float* avg, const float* mx, const float* hidden, const float* ca, const float* ca1,
+                           const float* dca, const float* dca1, const float* ca_fc1, const float* ca_fc2,
+                           const float* ca1_fc1, const float* ca1_fc2, float* davg, float* dmax,
+                           float* g_ca_fc1, float* g_ca_fc2, float* g_ca1_fc1, float* g_ca1_fc2,
+                           float* workspace, int B, int C, void* stream);
+size_t ksmi_ecam_mlp_bwd_workspace(int B, int C);
+/* phase B: dx[j][b,p,c] = ca*dout' + davg terms/HW, plus the max-pool scatter at argmax */
+int ksmi_ecam_final_backward_dx(void* const dx[4], const float* dlogits, const float* ca, const float* wf,
+                                const float* davg, const float* dmax, const int32_t* argmax,
+                                int B, int HW, int C, int ncls, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * Loss: utilities/bce_and_dice.py:18-24 + utilities/dice.py:93-137 (softmax CE + softmax
+ * Dice, ignore_index 3) and nn.CrossEntropyLoss alone (utilities/utilities.py:307-347).
+ * logits NCHW fp32 [B,3,H,W], labels int64 [B,H,W].  out[0..2] = total, ce, dice.
+ * ------------------------------------------------------------------------------- */
+size_t ksmi_loss_workspace(int B, int HW);
+int ksmi_ce_dice_forward(const float* logits, const int64_t* labels, const float* class_w, int with_dice,
+                         float* out3, float* workspace, int B, int HW, int ignore_index, void* stream);
+/* dlogits = grad_scale * d total / d logits ; must follow ksmi_ce_dice_forward on the same workspace */
+int ksmi_ce_dice_backward(const float* logits, const int64_t* labels, const float* class_w, int with_dice,
+                          const float* workspace, const float* grad_scale /* device scalar or NULL (=1) */,
+                          float* dlogits, int B, int HW, int ignore_index, void* stream);
+
+/* Metrics: predictions = argmax(1) (lowest index on ties), cm[4][4] int64 += counts of
+ * (target,pred) over target != ignore_index.  training/change_detection_trainer.py:152,184-189;
+ * utilities/utilities.py:228-265. */
+int ksmi_argmax_confusion(const float* logits, const int64_t* labels, int64_t* pred /* or NULL */, int64_t* cm,
+                          int B, int C, int HW, int ignore_index, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * Optimisers: torch.optim.Adam(lr) / SGD(momentum, weight_decay) as used at
+ * training/change_detection_trainer.py:45-66.  Flat fp32 buffers (parameter arena).
+ * step_count: device int64 scalar incremented by the kernel (graph-replay safe).
+ * ------------------------------------------------------------------------------- */
+int ksmi_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int64_t* step_count,
+                   float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale, void* stream);
+int ksmi_sgd_step(float* p, const float* g, float* mom, int64_t n, int64_t* step_count,
+                  float lr, float momentum, float weight_decay, float grad_scale, void* stream);
+
+/* plumbing */
+int ksmi_fill_zero(void* p, size_t bytes, void* stream);
+/* NCHW fp32 -> NHWC dtype and back (tests / debugging only) */
+int ksmi_nchw_to_nhwc(const float* x, void* y, int B, int C, int HW, int dtype, void* stream);
+int ksmi_nhwc_to_nchw(const void* x, float* y, int B, int C, int HW, int dtype, void* stream);
+/* self-tests of the MFMA fragment conventions (used by tests/test_gpu_selftest.py) */
+int ksmi_selftest_mma(const void* a, const void* b, float* c, int dtype, void* stream);
+int ksmi_selftest_tr16(const uint16_t* in256, uint16_t* out256, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KSMI_H */

@@ -1,0 +1,144 @@
+"""ctypes binding of libksmi.so (the C-ABI declared in include/ksmi.h).
+
+The product path has NO fallback: if the shared library is missing or a symbol is
+absent, importing this module raises.  Struct layouts mirror include/ksmi.h 1:1.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libksmi.so")
+
+KSMI_F32, KSMI_BF16 = 0, 1
+MAX_SRC, MAX_CHUNKS = 6, 72
+ABI_VERSION = 1
+
+
+class KsmiError(RuntimeError):
+    pass
+
+
+class Src(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p),
+                ("C", C.c_int32), ("c_off", C.c_int32), ("c_len", C.c_int32), ("relu", C.c_int32)]
+
+
+class Dst(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("C", C.c_int32), ("c_off", C.c_int32), ("n_begin", C.c_int32),
+                ("n_len", C.c_int32), ("accumulate", C.c_int32), ("pad_", C.c_int32)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("src", Src * MAX_SRC), ("dst", Dst * MAX_SRC), ("nsrc", C.c_int32), ("ndst", C.c_int32),
+                ("wpk", C.c_void_p), ("bias", C.c_void_p), ("stats", C.c_void_p),
+                ("mask_src", C.c_void_p), ("m_mean", C.c_void_p), ("m_rstd", C.c_void_p),
+                ("m_scale", C.c_void_p), ("m_shift", C.c_void_p),
+                ("B", C.c_int32), ("Hin", C.c_int32), ("Win", C.c_int32), ("Hout", C.c_int32), ("Wout", C.c_int32),
+                ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
+                ("TH", C.c_int32), ("TW", C.c_int32), ("N", C.c_int32), ("Npad", C.c_int32),
+                ("nchunks", C.c_int32), ("ps_cout", C.c_int32),
+                ("chunk_c0", C.c_uint16 * MAX_CHUNKS), ("chunk_src", C.c_uint8 * MAX_CHUNKS)]
+
+
+class PackDesc(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("out", C.c_void_p),
+                ("nchunks", C.c_int32), ("taps", C.c_int32), ("N", C.c_int32), ("Npad", C.c_int32), ("n_mod", C.c_int32),
+                ("sK", C.c_int64), ("sN", C.c_int64), ("sD", C.c_int64), ("sT", C.c_int64),
+                ("flip", C.c_int32),
+                ("k_off", C.c_int32 * MAX_CHUNKS), ("k_len", C.c_int32 * MAX_CHUNKS)]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [("src", Src * MAX_SRC), ("nsrc", C.c_int32),
+                ("dy", C.c_void_p), ("dyC", C.c_int32), ("dy_c_off", C.c_int32),
+                ("B", C.c_int32), ("Hin", C.c_int32), ("Win", C.c_int32), ("Hout", C.c_int32), ("Wout", C.c_int32),
+                ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
+                ("TH", C.c_int32), ("TW", C.c_int32), ("N", C.c_int32), ("nchunks", C.c_int32), ("nsplit", C.c_int32),
+                ("partial", C.c_void_p), ("grad", C.c_void_p),
+                ("gK", C.c_int64), ("gN", C.c_int64), ("gT", C.c_int64), ("accumulate", C.c_int32),
+                ("k_off", C.c_int32 * MAX_CHUNKS), ("k_len", C.c_int32 * MAX_CHUNKS),
+                ("chunk_c0", C.c_uint16 * MAX_CHUNKS), ("chunk_src", C.c_uint8 * MAX_CHUNKS)]
+
+
+_vp, _i, _i64, _f, _d, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_size_t
+_P4 = C.c_void_p * 4
+
+# name -> (restype, argtypes).  Every symbol of include/ksmi.h is listed; load fails if one is missing.
+SIGNATURES = {
+    "ksmi_abi_version": (_i, []),
+    "ksmi_last_error": (C.c_char_p, []),
+    "ksmi_chunk_elems": (_i, [_i]),
+    "ksmi_conv_grid_m": (_i, [C.POINTER(ConvDesc)]),
+    "ksmi_conv_forward": (_i, [C.POINTER(ConvDesc), _i, _vp]),
+    "ksmi_pack_weights": (_i, [C.POINTER(PackDesc), _i, _vp]),
+    "ksmi_conv_wgrad_workspace": (_sz, [C.POINTER(WgradDesc), _i]),
+    "ksmi_conv_wgrad": (_i, [C.POINTER(WgradDesc), _i, _vp]),
+    "ksmi_conv_first_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "ksmi_conv_first_stats_rows": (_i, [_i, _i, _i]),
+    "ksmi_conv_first_wgrad": (_i, [_vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "ksmi_conv_first_wgrad_workspace": (_sz, [_i, _i, _i, _i, _i]),
+    "ksmi_bn_finalize": (_i, [_vp, _i, _i, _i, _d, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _vp]),
+    "ksmi_bn_add_relu": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp]),
+    "ksmi_bnrelu_bwd_reduce": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp]),
+    "ksmi_reduce_rows": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp]),
+    "ksmi_bnrelu_bwd_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _i64, _i, _i, _vp]),
+    "ksmi_bn_bwd_apply_add": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _d, _i64, _i, _i, _vp]),
+    "ksmi_channel_sum": (_i, [_vp, _vp, _i, _i64, _i, _i, _vp]),
+    "ksmi_maxpool2x2_forward": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "ksmi_maxpool2x2_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "ksmi_ecam_pool": (_i, [_P4, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "ksmi_ecam_pool_workspace": (_sz, [_i, _i, _i]),
+    "ksmi_ecam_mlp": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "ksmi_ecam_final_forward": (_i, [_P4, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "ksmi_ecam_final_backward_reduce": (_i, [_P4, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "ksmi_ecam_bwd_workspace": (_sz, [_i, _i, _i, _i]),
+    "ksmi_ecam_mlp_backward": (_i, [_vp] * 18 + [_i, _i, _vp]),
+    "ksmi_ecam_mlp_bwd_workspace": (_sz, [_i, _i]),
+    "ksmi_ecam_final_backward_dx": (_i, [_P4, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "ksmi_loss_workspace": (_sz, [_i, _i]),
+    "ksmi_ce_dice_forward": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp]),
+    "ksmi_ce_dice_backward": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "ksmi_argmax_confusion": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "ksmi_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _f, _f, _f, _f, _f, _f, _vp]),
+    "ksmi_sgd_step": (_i, [_vp, _vp, _vp, _i64, _vp, _f, _f, _f, _f, _vp]),
+    "ksmi_fill_zero": (_i, [_vp, _sz, _vp]),
+    "ksmi_nchw_to_nhwc": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "ksmi_nhwc_to_nchw": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "ksmi_selftest_mma": (_i, [_vp, _vp, _vp, _i, _vp]),
+    "ksmi_selftest_tr16": (_i, [_vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen libksmi.so and bind every declared symbol.  Raises KsmiError on any problem."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise KsmiError(
+            f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "
+            "Build it with `python -c 'import __graft_entry__ as g; g.build()'` or `make -C kurosiwo_amd/csrc`.")
+    try:
+        import torch  # noqa: F401  (libamdhip64 is resolved from the torch process first)
+    except Exception:  # pragma: no cover
+        pass
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise KsmiError(f"libksmi.so does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.ksmi_abi_version() != ABI_VERSION:
+        raise KsmiError(f"libksmi ABI {lib.ksmi_abi_version()} != binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().ksmi_last_error()
+        raise KsmiError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,739 @@
+// HBM-bound kernels of the SNUNet train step: BatchNorm glue of conv_block_nested,
+// max-pool, first-layer conv, bias/channel reductions, optimiser, layout helpers.
+// All activations NHWC in T (fp32 / bf16), accessed as 16-byte vectors; all
+// statistics, parameters and gradients fp32 (reductions finish in fp64).
+#include "common.h"
+#include "../../include/ksmi.h"
+#include "errors.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+// A block of 256 threads walks pixels [p0, p1) of an NHWC tensor with CV = C/VEC
+// channel-vectors per pixel.  Thread t owns channel-vector cv = t % CV and pixel lane
+// pl = t / CV (NPL = 256 / CV lanes); threads beyond NPL*CV idle.
+struct ChanWalk {
+  int cv, pl, npl, active;
+  __device__ ChanWalk(int CV) {
+    npl = kThreads / CV; if (npl < 1) npl = 1;
+    active = (int)threadIdx.x < npl * CV && CV <= kThreads;
+    cv = threadIdx.x % CV; pl = threadIdx.x / CV;
+  }
+};
+
+// Reduce per-thread accumulators val[K*VEC] (K quantities x VEC channels) over the pixel
+// lanes of the block and write partial[(row*K + k)*C + c].
+template <int K, int VEC>
+__device__ void block_channel_reduce(const float* val, const ChanWalk& w, int CV, int C, float* partial, int row) {
+  __shared__ float red[kThreads * 2];
+  for (int k = 0; k < K; ++k) {
+    for (int j0 = 0; j0 < VEC; j0 += 2) {
+      __syncthreads();
+      red[threadIdx.x * 2 + 0] = w.active ? val[k * VEC + j0] : 0.f;
+      red[threadIdx.x * 2 + 1] = w.active ? val[k * VEC + j0 + 1] : 0.f;
+      __syncthreads();
+      if ((int)threadIdx.x < CV * 2) {
+        const int cv = threadIdx.x >> 1, jj = threadIdx.x & 1;
+        float s = 0.f;
+        for (int pl = 0; pl < w.npl; ++pl) s += red[(pl * CV + cv) * 2 + jj];
+        partial[((size_t)row * K + k) * C + cv * VEC + j0 + jj] = s;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// BatchNorm finalize
+// ------------------------------------------------------------------------------------------------
+__global__ void bn_finalize_kernel(const float* partial, int rows, int Cpad, int C, double count,
+                                   const float* gamma, const float* beta, float* rmean, float* rvar,
+                                   int64_t* nbt, float momentum, float eps, int training,
+                                   float* mean_o, float* rstd_o, float* scale_o, float* shift_o) {
+  __shared__ double red[2][16][17];
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  if (!training) {
+    if (threadIdx.x < 16 && c < C) {
+      const float rs = 1.0f / sqrtf(rvar[c] + eps);
+      const float sc = gamma[c] * rs;
+      mean_o[c] = rmean[c]; rstd_o[c] = rs; scale_o[c] = sc; shift_o[c] = beta[c] - rmean[c] * sc;
+    }
+    return;
+  }
+  double s = 0.0, q = 0.0;
+  if (c < C)
+    for (int r = rl; r < rows; r += 16) {
+      s += (double)partial[((size_t)r * 2 + 0) * Cpad + c];
+      q += (double)partial[((size_t)r * 2 + 1) * Cpad + c];
+    }
+  red[0][rl][cl] = s; red[1][rl][cl] = q;
+  __syncthreads();
+  if (threadIdx.x < 16 && c < C) {
+    s = 0.0; q = 0.0;
+    for (int r = 0; r < 16; ++r) { s += red[0][r][cl]; q += red[1][r][cl]; }
+    const double mean = s / count;
+    double var = q / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rs = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = gamma[c] * rs;
+    mean_o[c] = (float)mean; rstd_o[c] = rs; scale_o[c] = sc; shift_o[c] = beta[c] - (float)mean * sc;
+    const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+    rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
+    rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
+}
+
+// sums[k][c] = sum_rows partial[row][k][c]; optional accumulate into dgamma (k=1) / dbeta (k=0)
+__global__ void reduce_rows_kernel(const float* partial, int rows, int K, int Cstride, int C, float* sums,
+                                   float* dgamma, float* dbeta, int accumulate) {
+  __shared__ double red[16][17];
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  for (int k = 0; k < K; ++k) {
+    double s = 0.0;
+    if (c < C)
+      for (int r = rl; r < rows; r += 16) s += (double)partial[((size_t)r * K + k) * Cstride + c];
+    __syncthreads();
+    red[rl][cl] = s;
+    __syncthreads();
+    if (threadIdx.x < 16 && c < C) {
+      s = 0.0;
+      for (int r = 0; r < 16; ++r) s += red[r][cl];
+      const float f = (float)s;
+      if (sums) sums[k * C + c] = f;
+      float* tgt = (k == 0) ? dbeta : (k == 1 ? dgamma : nullptr);
+      if (tgt) tgt[c] = accumulate ? tgt[c] + f : f;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// elementwise glue
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void bn_add_relu_kernel(const T* z, const T* idn, const float* scale, const float* shift, T* out,
+                                   int64_t nvec, int CV) {
+  constexpr int VEC = ElemTraits<T>::kVec;
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(v % CV) * VEC;
+    float a[VEC], b[VEC];
+    vec_unpack<T>(*(const u32x4*)(z + v * VEC), a);
+    vec_unpack<T>(*(const u32x4*)(idn + v * VEC), b);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) a[j] = fmaxf(a[j] * scale[c + j] + shift[c + j] + b[j], 0.f);
+    *(u32x4*)(out + v * VEC) = vec_pack<T>(a);
+  }
+}
+
+// pass 1 of block backward: partial[row][0] = sum g, partial[row][1] = sum g*zhat, g = dout*(out>0)
+template <typename T>
+__global__ void bnrelu_bwd_reduce_kernel(const T* dout, const T* out, const T* z, const float* mean, const float* rstd,
+                                         float* partial, int64_t npix, int C) {
+  constexpr int VEC = ElemTraits<T>::kVec;
+  const int CV = C / VEC;
+  ChanWalk w(CV);
+  float acc[2 * VEC];
+#pragma unroll
+  for (int j = 0; j < 2 * VEC; ++j) acc[j] = 0.f;
+  if (w.active) {
+    float mu[VEC], rs[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { mu[j] = mean[w.cv * VEC + j]; rs[j] = rstd[w.cv * VEC + j]; }
+    const int64_t per = (npix + gridDim.x - 1) / gridDim.x;
+    const int64_t p0 = per * blockIdx.x, p1 = min(npix, p0 + per);
+    for (int64_t p = p0 + w.pl; p < p1; p += w.npl) {
+      const int64_t off = p * C + w.cv * VEC;
+      float g[VEC], o[VEC], zz[VEC];
+      vec_unpack<T>(*(const u32x4*)(dout + off), g);
+      vec_unpack<T>(*(const u32x4*)(out + off), o);
+      vec_unpack<T>(*(const u32x4*)(z + off), zz);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const float gg = o[j] > 0.f ? g[j] : 0.f;
+        acc[j] += gg; acc[VEC + j] += gg * (zz[j] - mu[j]) * rs[j];
+      }
+    }
+  }
+  block_channel_reduce<2, VEC>(acc, w, CV, C, partial, blockIdx.x);
+}
+
+// pass 2: g -> dout (in place), dz = gamma*rstd*(g - s0/n - zhat*s1/n)
+template <typename T>
+__global__ void bnrelu_bwd_apply_kernel(T* dout, const T* out, const T* z, const float* mean, const float* rstd,
+                                        const float* gamma, const float* sums, T* dz, float inv_n, int64_t nvec, int CV, int C) {
+  constexpr int VEC = ElemTraits<T>::kVec;
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(v % CV) * VEC;
+    float g[VEC], o[VEC], zz[VEC];
+    vec_unpack<T>(*(const u32x4*)(dout + v * VEC), g);
+    vec_unpack<T>(*(const u32x4*)(out + v * VEC), o);
+    vec_unpack<T>(*(const u32x4*)(z + v * VEC), zz);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const float gg = o[j] > 0.f ? g[j] : 0.f;
+      const float zh = (zz[j] - mean[c + j]) * rstd[c + j];
+      g[j] = gg;
+      zz[j] = gamma[c + j] * rstd[c + j] * (gg - sums[c + j] * inv_n - zh * sums[C + c + j] * inv_n);
+    }
+    *(u32x4*)(dout + v * VEC) = vec_pack<T>(g);
+    *(u32x4*)(dz + v * VEC) = vec_pack<T>(zz);
+  }
+}
+
+// di = g + gamma*rstd*(r - t0/n - xhat*t1/n) written over r ; partial[row][0][c] = sum di
+template <typename T>
+__global__ void bn_bwd_apply_add_kernel(T* r, const T* g, const T* iv, const float* mean, const float* rstd,
+                                        const float* gamma, const float* sums, float* partial, float inv_n,
+                                        int64_t npix, int C) {
+  constexpr int VEC = ElemTraits<T>::kVec;
+  const int CV = C / VEC;
+  ChanWalk w(CV);
+  float acc[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+  if (w.active) {
+    float mu[VEC], rs[VEC], k0[VEC], k1[VEC], gr[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const int c = w.cv * VEC + j;
+      mu[j] = mean[c]; rs[j] = rstd[c]; gr[j] = gamma[c] * rstd[c];
+      k0[j] = sums[c] * inv_n; k1[j] = sums[C + c] * inv_n;
+    }
+    const int64_t per = (npix + gridDim.x - 1) / gridDim.x;
+    const int64_t p0 = per * blockIdx.x, p1 = min(npix, p0 + per);
+    for (int64_t p = p0 + w.pl; p < p1; p += w.npl) {
+      const int64_t off = p * C + w.cv * VEC;
+      float rr[VEC], gg[VEC], ii[VEC];
+      vec_unpack<T>(*(const u32x4*)(r + off), rr);
+      vec_unpack<T>(*(const u32x4*)(g + off), gg);
+      vec_unpack<T>(*(const u32x4*)(iv + off), ii);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const float xh = (ii[j] - mu[j]) * rs[j];
+        const float di = gg[j] + gr[j] * (rr[j] - k0[j] - xh * k1[j]);
+        rr[j] = di;
+      }
+      const u32x4 pk = vec_pack<T>(rr);
+      *(u32x4*)(r + off) = pk;
+      vec_unpack<T>(pk, rr);                 // bias gradient sums what the next kernels will read
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) acc[j] += rr[j];
+    }
+  }
+  block_channel_reduce<1, VEC>(acc, w, CV, C, partial, blockIdx.x);
+}
+
+template <typename T>
+__global__ void channel_sum_kernel(const T* x, float* partial, int64_t npix, int C) {
+  constexpr int VEC = ElemTraits<T>::kVec;
+  const int CV = C / VEC;
+  ChanWalk w(CV);
+  float acc[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+  if (w.active) {
+    const int64_t per = (npix + gridDim.x - 1) / gridDim.x;
+    const int64_t p0 = per * blockIdx.x, p1 = min(npix, p0 + per);
+    for (int64_t p = p0 + w.pl; p < p1; p += w.npl) {
+      float xx[VEC];
+      vec_unpack<T>(*(const u32x4*)(x + p * C + w.cv * VEC), xx);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) acc[j] += xx[j];
+    }
+  }
+  block_channel_reduce<1, VEC>(acc, w, CV, C, partial, blockIdx.x);
+}
+
+// ------------------------------------------------------------------------------------------------
+// max pool 2x2 stride 2
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void maxpool_fwd_kernel(const T* x, T* y, int B, int H, int W, int C) {
+  constexpr int VEC = ElemTraits<T>::kVec;
+  const int CV = C / VEC, Ho = H / 2, Wo = W / 2;
+  const int64_t n = (int64_t)B * Ho * Wo * CV;
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (int64_t)gridDim.x * blockDim.x) {
+    const int cv = v % CV; int64_t r = v / CV;
+    const int ox = r % Wo; r /= Wo;
+    const int oy = r % Ho; const int b = r / Ho;
+    const T* base = x + (((int64_t)b * H + 2 * oy) * W + 2 * ox) * C + cv * VEC;
+    float m[VEC], t[VEC];
+    vec_unpack<T>(*(const u32x4*)base, m);
+    vec_unpack<T>(*(const u32x4*)(base + C), t);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) m[j] = t[j] > m[j] ? t[j] : m[j];
+    vec_unpack<T>(*(const u32x4*)(base + (int64_t)W * C), t);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) m[j] = t[j] > m[j] ? t[j] : m[j];
+    vec_unpack<T>(*(const u32x4*)(base + (int64_t)W * C + C), t);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) m[j] = t[j] > m[j] ? t[j] : m[j];
+    *(u32x4*)(y + v * VEC) = vec_pack<T>(m);
+  }
+}
+
+template <typename T>
+__global__ void maxpool_bwd_kernel(const T* x, const T* dy, T* dx, int accumulate, int B, int H, int W, int C) {
+  constexpr int VEC = ElemTraits<T>::kVec;
+  const int CV = C / VEC, Ho = H / 2, Wo = W / 2;
+  const int64_t n = (int64_t)B * Ho * Wo * CV;
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (int64_t)gridDim.x * blockDim.x) {
+    const int cv = v % CV; int64_t r = v / CV;
+    const int ox = r % Wo; r /= Wo;
+    const int oy = r % Ho; const int b = r / Ho;
+    const int64_t o00 = (((int64_t)b * H + 2 * oy) * W + 2 * ox) * C + cv * VEC;
+    const int64_t offs[4] = {o00, o00 + C, o00 + (int64_t)W * C, o00 + (int64_t)W * C + C};
+    float xv[4][VEC], g[VEC];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) vec_unpack<T>(*(const u32x4*)(x + offs[k]), xv[k]);
+    vec_unpack<T>(*(const u32x4*)(dy + v * VEC), g);
+    int am[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      float m = xv[0][j]; am[j] = 0;
+#pragma unroll
+      for (int k = 1; k < 4; ++k) if (xv[k][j] > m) { m = xv[k][j]; am[j] = k; }   // first maximum wins
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float o[VEC];
+      if (accumulate) vec_unpack<T>(*(const u32x4*)(dx + offs[k]), o);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const float gg = am[j] == k ? g[j] : 0.f;
+        o[j] = accumulate ? o[j] + gg : gg;
+      }
+      *(u32x4*)(dx + offs[k]) = vec_pack<T>(o);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// first-layer conv (raw image NCHW fp32, Cin <= 8) -> NHWC T, + BN partial stats
+// one 16x16 output patch per block, one pixel per thread
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void conv_first_fwd_kernel(const float* x, const float* w, const float* bias, T* out,
+                                                             float* stats, int B, int Cin, int H, int W, int Cout) {
+  constexpr int VEC = ElemTraits<T>::kVec;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* xs = (float*)smem;                       // [Cin][18][18]
+  float* ws = xs + Cin * 324;                     // [Cout][Cin*9]
+  float* red = ws + Cout * Cin * 9;               // [4][2][Cout]
+  const int tilesX = (W + 15) / 16, tilesY = (H + 15) / 16;
+  int bm = blockIdx.x;
+  const int tx = bm % tilesX; bm /= tilesX;
+  const int ty = bm % tilesY; const int b = bm / tilesY;
+  const int tid = threadIdx.x, lx = tid & 15, ly = tid >> 4;
+  for (int i = tid; i < Cin * 324; i += 256) {
+    const int c = i / 324, r = i - c * 324, hy = r / 18, hx = r - hy * 18;
+    const int iy = ty * 16 - 1 + hy, ix = tx * 16 - 1 + hx;
+    xs[i] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? x[(((int64_t)b * Cin + c) * H + iy) * W + ix] : 0.f;
+  }
+  for (int i = tid; i < Cout * Cin * 9; i += 256) ws[i] = w[i];
+  __syncthreads();
+  const int oy = ty * 16 + ly, ox = tx * 16 + lx;
+  const bool ok = oy < H && ox < W;
+  float xin[8 * 9];
+  for (int c = 0; c < Cin; ++c)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) xin[c * 9 + t] = xs[c * 324 + (ly + t / 3) * 18 + lx + t % 3];
+  const int lane = tid & 63, wave = tid >> 6;
+  for (int n0 = 0; n0 < Cout; n0 += VEC) {
+    float o[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      float a = bias ? bias[n0 + j] : 0.f;
+      const float* wr = ws + (n0 + j) * Cin * 9;
+      for (int k = 0; k < Cin * 9; ++k) a += xin[k] * wr[k];
+      o[j] = a;
+    }
+    if (ok) *(u32x4*)(out + (((int64_t)b * H + oy) * W + ox) * Cout + n0) = vec_pack<T>(o);
+    if (stats) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const float v = ok ? o[j] : 0.f;
+        const float s = wave_sum(v), q = wave_sum(v * v);
+        if (lane == 0) { red[(wave * 2 + 0) * Cout + n0 + j] = s; red[(wave * 2 + 1) * Cout + n0 + j] = q; }
+      }
+    }
+  }
+  if (stats) {
+    __syncthreads();
+    for (int i = tid; i < 2 * Cout; i += 256) {
+      const int which = i / Cout, n = i - which * Cout;
+      stats[((size_t)blockIdx.x * 2 + which) * Cout + n] =
+          red[(0 * 2 + which) * Cout + n] + red[(1 * 2 + which) * Cout + n] + red[(2 * 2 + which) * Cout + n] + red[(3 * 2 + which) * Cout + n];
+    }
+  }
+}
+
+// first-layer weight gradient: partial[blk][n][c*9+t] = sum over the block's patches
+template <typename T>
+__global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float* x, const T* dy, float* partial,
+                                                               int B, int Cin, int H, int W, int Cout) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* xs = (float*)smem;                       // [Cin][18][18]
+  float* dys = xs + Cin * 324;                    // [256][Cout+1]
+  const int tilesX = (W + 15) / 16, tilesY = (H + 15) / 16;
+  const int patches = B * tilesX * tilesY;
+  const int tid = threadIdx.x;
+  const int KT = Cin * 9;
+  const int n = tid % Cout, grp = tid / Cout, ngrp = 256 / Cout;   // Cout in {8,16,32,64,128,256}
+  constexpr int MAXK = 12;                        // ceil(72 / ngrp) for Cout<=32 ; guarded below
+  float acc[MAXK];
+#pragma unroll
+  for (int j = 0; j < MAXK; ++j) acc[j] = 0.f;
+  const int ldy = Cout + 1;
+  for (int patch = blockIdx.x; patch < patches; patch += gridDim.x) {
+    int bm = patch;
+    const int tx = bm % tilesX; bm /= tilesX;
+    const int ty = bm % tilesY; const int b = bm / tilesY;
+    __syncthreads();
+    for (int i = tid; i < Cin * 324; i += 256) {
+      const int c = i / 324, r = i - c * 324, hy = r / 18, hx = r - hy * 18;
+      const int iy = ty * 16 - 1 + hy, ix = tx * 16 - 1 + hx;
+      xs[i] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? x[(((int64_t)b * Cin + c) * H + iy) * W + ix] : 0.f;
+    }
+    for (int i = tid; i < 256 * Cout; i += 256) {
+      const int p = i / Cout, nn = i - p * Cout;
+      const int oy = ty * 16 + (p >> 4), ox = tx * 16 + (p & 15);
+      dys[p * ldy + nn] = (oy < H && ox < W) ? ElemTraits<T>::ld(dy + (((int64_t)b * H + oy) * W + ox) * Cout + nn) : 0.f;
+    }
+    __syncthreads();
+    for (int p = 0; p < 256; ++p) {
+      const float g = dys[p * ldy + n];
+      const int ly = p >> 4, lx = p & 15;
+#pragma unroll
+      for (int j = 0; j < MAXK; ++j) {
+        const int k = grp + j * ngrp;
+        if (k < KT) {
+          const int c = k / 9, t = k - c * 9;
+          acc[j] += g * xs[c * 324 + (ly + t / 3) * 18 + lx + t % 3];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < MAXK; ++j) {
+    const int k = grp + j * ngrp;
+    if (k < KT) partial[((size_t)blockIdx.x * Cout + n) * KT + k] = acc[j];
+  }
+}
+
+__global__ void sum_rows_flat_kernel(const float* partial, int rows, int64_t n, float* out, int accumulate) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    double s = 0.0;
+    for (int r = 0; r < rows; ++r) s += (double)partial[(size_t)r * n + i];
+    out[i] = accumulate ? out[i] + (float)s : (float)s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// optimisers (flat fp32 arena)
+// ------------------------------------------------------------------------------------------------
+__global__ void step_increment_kernel(int64_t* step) { if (threadIdx.x == 0 && blockIdx.x == 0) *step += 1; }
+
+__global__ void adam_kernel(float* p, const float* g, float* m, float* v, int64_t n, const int64_t* step,
+                            float lr, float b1, float b2, float eps, float wd, float gscale) {
+  const double t = (double)*step;
+  const float bc1 = (float)(1.0 - pow((double)b1, t));
+  const float bc2s = (float)sqrt(1.0 - pow((double)b2, t));
+  const float step_size = lr / bc1;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float gi = g[i] * gscale;
+    const float pi = p[i];
+    if (wd != 0.f) gi += wd * pi;
+    const float mi = m[i] + (gi - m[i]) * (1.f - b1);
+    const float vi = v[i] * b2 + gi * gi * (1.f - b2);
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / bc2s + eps;
+    p[i] = pi - step_size * (mi / denom);
+  }
+}
+
+__global__ void sgd_kernel(float* p, const float* g, float* mom, int64_t n, const int64_t* step,
+                           float lr, float mu, float wd, float gscale) {
+  const bool first = *step <= 1;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float gi = g[i] * gscale;
+    const float pi = p[i];
+    if (wd != 0.f) gi += wd * pi;
+    if (mu != 0.f) {
+      const float b = first ? gi : mom[i] * mu + gi;
+      mom[i] = b; gi = b;
+    }
+    p[i] = pi - lr * gi;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// layout helpers (tests only)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* x, T* y, int B, int C, int HW) {
+  const int64_t n = (int64_t)B * C * HW;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = i % C; int64_t r = i / C; const int p = r % HW; const int b = r / HW;
+    ElemTraits<T>::st(y + i, x[((int64_t)b * C + c) * HW + p]);
+  }
+}
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* x, float* y, int B, int C, int HW) {
+  const int64_t n = (int64_t)B * C * HW;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int p = i % HW; int64_t r = i / HW; const int c = r % C; const int b = r / C;
+    y[i] = ElemTraits<T>::ld(x + ((int64_t)b * HW + p) * C + c);
+  }
+}
+
+// MFMA fragment convention self-test: c[16][16] = a[16][KC] * b[16][KC]^T
+template <typename T>
+__global__ void selftest_mma_kernel(const T* a, const T* b, float* c) {
+  constexpr int VEC = ElemTraits<T>::kVec;
+  const int lane = threadIdx.x, g = lane >> 4, l15 = lane & 15;
+  const u32x4 av = *(const u32x4*)(a + l15 * VEC * 4 + g * VEC);
+  const u32x4 bv = *(const u32x4*)(b + l15 * VEC * 4 + g * VEC);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  mma16<T>(acc, av, bv);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) c[(g * 4 + r) * 16 + l15] = acc[r];
+}
+
+__global__ void selftest_tr16_kernel(const uint16_t* in, uint16_t* out) {
+  __shared__ __attribute__((aligned(16))) uint16_t buf[256];
+  const int lane = threadIdx.x;
+  for (int i = lane; i < 256; i += 64) buf[i] = in[i];
+  __syncthreads();
+  const unsigned addr = (unsigned)(uintptr_t)buf + lane * 8;
+  s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(uintptr_t)addr);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) out[lane * 4 + j] = (uint16_t)v[j];
+}
+
+int grid_for(int64_t n, int cap = 2048) {
+  int64_t b = (n + kThreads - 1) / kThreads;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+bool chan_ok(int C, int dtype) {
+  const int vec = dtype == KSMI_BF16 ? 8 : 4;
+  return C % vec == 0 && C / vec <= kThreads / 2;
+}
+
+}  // namespace
+
+#define KSMI_DT(dtype, EXPR_BF16, EXPR_F32)                                  \
+  do {                                                                       \
+    if ((dtype) == KSMI_BF16) { EXPR_BF16; }                                 \
+    else if ((dtype) == KSMI_F32) { EXPR_F32; }                              \
+    else return ksmi_fail(KSMI_E_ARG, "bad dtype");                          \
+  } while (0)
+
+extern "C" {
+
+int ksmi_bn_finalize(const float* partial, int rows, int Cpad, int C, double count, const float* gamma, const float* beta,
+                     float* running_mean, float* running_var, int64_t* nbt, float momentum, float eps, int training,
+                     float* mean, float* rstd, float* scale, float* shift, void* stream) {
+  if (C < 1 || (training && (!partial || rows < 1))) return ksmi_fail(KSMI_E_ARG, "bn_finalize: bad args");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, partial, rows, Cpad, C, count,
+                     gamma, beta, running_mean, running_var, nbt, momentum, eps, training, mean, rstd, scale, shift);
+  return ksmi_check_launch("bn_finalize");
+}
+
+int ksmi_reduce_rows(const float* partial, int rows, int K, int Cstride, int C, float* sums, float* dgamma, float* dbeta,
+                     int accumulate, void* stream) {
+  if (rows < 1 || K < 1 || C < 1 || Cstride < C) return ksmi_fail(KSMI_E_ARG, "reduce_rows: bad args");
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, partial, rows, K, Cstride, C, sums,
+                     dgamma, dbeta, accumulate);
+  return ksmi_check_launch("reduce_rows");
+}
+
+int ksmi_bn_add_relu(const void* z, const void* identity, const float* scale, const float* shift, void* out, int64_t npix,
+                     int C, int dtype, void* stream) {
+  if (!chan_ok(C, dtype)) return ksmi_fail(KSMI_E_ARG, "bn_add_relu: C must be a multiple of the 16-byte vector");
+  const int vec = dtype == KSMI_BF16 ? 8 : 4;
+  const int64_t nvec = npix * C / vec;
+  KSMI_DT(dtype,
+          hipLaunchKernelGGL(bn_add_relu_kernel<bf16_t>, dim3(grid_for(nvec, 8192)), dim3(256), 0, (hipStream_t)stream,
+                             (const bf16_t*)z, (const bf16_t*)identity, scale, shift, (bf16_t*)out, nvec, C / vec),
+          hipLaunchKernelGGL(bn_add_relu_kernel<float>, dim3(grid_for(nvec, 8192)), dim3(256), 0, (hipStream_t)stream,
+                             (const float*)z, (const float*)identity, scale, shift, (float*)out, nvec, C / vec));
+  return ksmi_check_launch("bn_add_relu");
+}
+
+int ksmi_bnrelu_bwd_reduce(const void* dout, const void* out, const void* z, const float* mean, const float* rstd,
+                           float* partial, int rows, int64_t npix, int C, int dtype, void* stream) {
+  if (!chan_ok(C, dtype) || rows < 1) return ksmi_fail(KSMI_E_ARG, "bnrelu_bwd_reduce: bad args");
+  KSMI_DT(dtype,
+          hipLaunchKernelGGL(bnrelu_bwd_reduce_kernel<bf16_t>, dim3(rows), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dout,
+                             (const bf16_t*)out, (const bf16_t*)z, mean, rstd, partial, npix, C),
+          hipLaunchKernelGGL(bnrelu_bwd_reduce_kernel<float>, dim3(rows), dim3(256), 0, (hipStream_t)stream, (const float*)dout,
+                             (const float*)out, (const float*)z, mean, rstd, partial, npix, C));
+  return ksmi_check_launch("bnrelu_bwd_reduce");
+}
+
+int ksmi_bnrelu_bwd_apply(void* dout_g, const void* out, const void* z, const float* mean, const float* rstd,
+                          const float* gamma, const float* sums, void* dz, double count, int64_t npix, int C, int dtype,
+                          void* stream) {
+  if (!chan_ok(C, dtype)) return ksmi_fail(KSMI_E_ARG, "bnrelu_bwd_apply: bad C");
+  const int vec = dtype == KSMI_BF16 ? 8 : 4;
+  const int64_t nvec = npix * C / vec;
+  const float inv_n = (float)(1.0 / count);
+  KSMI_DT(dtype,
+          hipLaunchKernelGGL(bnrelu_bwd_apply_kernel<bf16_t>, dim3(grid_for(nvec, 8192)), dim3(256), 0, (hipStream_t)stream,
+                             (bf16_t*)dout_g, (const bf16_t*)out, (const bf16_t*)z, mean, rstd, gamma, sums, (bf16_t*)dz, inv_n, nvec,
+                             C / vec, C),
+          hipLaunchKernelGGL(bnrelu_bwd_apply_kernel<float>, dim3(grid_for(nvec, 8192)), dim3(256), 0, (hipStream_t)stream,
+                             (float*)dout_g, (const float*)out, (const float*)z, mean, rstd, gamma, sums, (float*)dz, inv_n, nvec,
+                             C / vec, C));
+  return ksmi_check_launch("bnrelu_bwd_apply");
+}
+
+int ksmi_bn_bwd_apply_add(void* r_di, const void* g, const void* i, const float* mean, const float* rstd, const float* gamma,
+                          const float* sums, float* partial, int rows, double count, int64_t npix, int C, int dtype,
+                          void* stream) {
+  if (!chan_ok(C, dtype) || rows < 1) return ksmi_fail(KSMI_E_ARG, "bn_bwd_apply_add: bad args");
+  const float inv_n = (float)(1.0 / count);
+  KSMI_DT(dtype,
+          hipLaunchKernelGGL(bn_bwd_apply_add_kernel<bf16_t>, dim3(rows), dim3(256), 0, (hipStream_t)stream, (bf16_t*)r_di,
+                             (const bf16_t*)g, (const bf16_t*)i, mean, rstd, gamma, sums, partial, inv_n, npix, C),
+          hipLaunchKernelGGL(bn_bwd_apply_add_kernel<float>, dim3(rows), dim3(256), 0, (hipStream_t)stream, (float*)r_di,
+                             (const float*)g, (const float*)i, mean, rstd, gamma, sums, partial, inv_n, npix, C));
+  return ksmi_check_launch("bn_bwd_apply_add");
+}
+
+int ksmi_channel_sum(const void* x, float* partial, int rows, int64_t npix, int C, int dtype, void* stream) {
+  if (!chan_ok(C, dtype) || rows < 1) return ksmi_fail(KSMI_E_ARG, "channel_sum: bad args");
+  KSMI_DT(dtype,
+          hipLaunchKernelGGL(channel_sum_kernel<bf16_t>, dim3(rows), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, partial, npix, C),
+          hipLaunchKernelGGL(channel_sum_kernel<float>, dim3(rows), dim3(256), 0, (hipStream_t)stream, (const float*)x, partial, npix, C));
+  return ksmi_check_launch("channel_sum");
+}
+
+int ksmi_maxpool2x2_forward(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream) {
+  if (!chan_ok(C, dtype) || (H & 1) || (W & 1)) return ksmi_fail(KSMI_E_ARG, "maxpool: even H,W and vector-multiple C required");
+  const int vec = dtype == KSMI_BF16 ? 8 : 4;
+  const int64_t n = (int64_t)B * (H / 2) * (W / 2) * (C / vec);
+  KSMI_DT(dtype,
+          hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(grid_for(n, 8192)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, B, H, W, C),
+          hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(grid_for(n, 8192)), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, B, H, W, C));
+  return ksmi_check_launch("maxpool_fwd");
+}
+
+int ksmi_maxpool2x2_backward(const void* x, const void* dy, void* dx, int accumulate, int B, int H, int W, int C, int dtype,
+                             void* stream) {
+  if (!chan_ok(C, dtype) || (H & 1) || (W & 1)) return ksmi_fail(KSMI_E_ARG, "maxpool: even H,W and vector-multiple C required");
+  const int vec = dtype == KSMI_BF16 ? 8 : 4;
+  const int64_t n = (int64_t)B * (H / 2) * (W / 2) * (C / vec);
+  KSMI_DT(dtype,
+          hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(grid_for(n, 8192)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, accumulate, B, H, W, C),
+          hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(grid_for(n, 8192)), dim3(256), 0, (hipStream_t)stream, (const float*)x, (const float*)dy, (float*)dx, accumulate, B, H, W, C));
+  return ksmi_check_launch("maxpool_bwd");
+}
+
+int ksmi_conv_first_stats_rows(int B, int H, int W) { return B * ((H + 15) / 16) * ((W + 15) / 16); }
+
+int ksmi_conv_first_forward(const float* x, const float* w, const float* bias, void* out, float* stats, int B, int Cin, int H,
+                            int W, int Cout, int dtype, void* stream) {
+  const int vec = dtype == KSMI_BF16 ? 8 : 4;
+  if (Cin < 1 || Cin > 8 || Cout % vec || Cout > 256) return ksmi_fail(KSMI_E_ARG, "conv_first: Cin<=8, Cout multiple of vector, <=256");
+  const int grid = ksmi_conv_first_stats_rows(B, H, W);
+  const size_t lds = (size_t)(Cin * 324 + Cout * Cin * 9 + 8 * Cout) * sizeof(float);
+  KSMI_DT(dtype,
+          hipLaunchKernelGGL(conv_first_fwd_kernel<bf16_t>, dim3(grid), dim3(256), lds, (hipStream_t)stream, x, w, bias, (bf16_t*)out, stats, B, Cin, H, W, Cout),
+          hipLaunchKernelGGL(conv_first_fwd_kernel<float>, dim3(grid), dim3(256), lds, (hipStream_t)stream, x, w, bias, (float*)out, stats, B, Cin, H, W, Cout));
+  return ksmi_check_launch("conv_first_fwd");
+}
+
+static int conv_first_wgrad_blocks(int B, int H, int W) {
+  const int patches = B * ((H + 15) / 16) * ((W + 15) / 16);
+  return patches < 512 ? patches : 512;
+}
+
+size_t ksmi_conv_first_wgrad_workspace(int B, int Cin, int H, int W, int Cout) {
+  return (size_t)conv_first_wgrad_blocks(B, H, W) * Cout * Cin * 9 * sizeof(float);
+}
+
+int ksmi_conv_first_wgrad(const float* x, const void* dy, float* dw, float* workspace, size_t ws_bytes, int B, int Cin, int H,
+                          int W, int Cout, int accumulate, int dtype, void* stream) {
+  if (Cin < 1 || Cin > 8 || 256 % Cout || (Cin * 9 + 256 / Cout - 1) / (256 / Cout) > 12)
+    return ksmi_fail(KSMI_E_ARG, "conv_first_wgrad: unsupported Cin/Cout");
+  if (ws_bytes < ksmi_conv_first_wgrad_workspace(B, Cin, H, W, Cout)) return ksmi_fail(KSMI_E_ARG, "conv_first_wgrad: workspace too small");
+  const int blocks = conv_first_wgrad_blocks(B, H, W);
+  const size_t lds = (size_t)(Cin * 324 + 256 * (Cout + 1)) * sizeof(float);
+  KSMI_DT(dtype,
+          {
+            auto k = conv_first_wgrad_kernel<bf16_t>;
+            if (lds > 65536) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(k, dim3(blocks), dim3(256), lds, (hipStream_t)stream, x, (const bf16_t*)dy, workspace, B, Cin, H, W, Cout);
+          },
+          {
+            auto k = conv_first_wgrad_kernel<float>;
+            if (lds > 65536) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(k, dim3(blocks), dim3(256), lds, (hipStream_t)stream, x, (const float*)dy, workspace, B, Cin, H, W, Cout);
+          });
+  int rc = ksmi_check_launch("conv_first_wgrad");
+  if (rc) return rc;
+  const int64_t n = (int64_t)Cout * Cin * 9;
+  hipLaunchKernelGGL(sum_rows_flat_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, workspace, blocks, n, dw, accumulate);
+  return ksmi_check_launch("conv_first_wgrad_reduce");
+}
+
+int ksmi_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int64_t* step_count, float lr, float beta1,
+                   float beta2, float eps, float weight_decay, float grad_scale, void* stream) {
+  if (!p || !g || !m || !v || !step_count || n < 0) return ksmi_fail(KSMI_E_ARG, "adam: bad args");
+  hipLaunchKernelGGL(step_increment_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step_count);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 4096)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, step_count, lr, beta1,
+                     beta2, eps, weight_decay, grad_scale);
+  return ksmi_check_launch("adam");
+}
+
+int ksmi_sgd_step(float* p, const float* g, float* mom, int64_t n, int64_t* step_count, float lr, float momentum,
+                  float weight_decay, float grad_scale, void* stream) {
+  if (!p || !g || !step_count || (momentum != 0.f && !mom)) return ksmi_fail(KSMI_E_ARG, "sgd: bad args");
+  hipLaunchKernelGGL(step_increment_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step_count);
+  hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n, 4096)), dim3(256), 0, (hipStream_t)stream, p, g, mom, n, step_count, lr, momentum,
+                     weight_decay, grad_scale);
+  return ksmi_check_launch("sgd");
+}
+
+int ksmi_fill_zero(void* p, size_t bytes, void* stream) {
+  hipError_t e = hipMemsetAsync(p, 0, bytes, (hipStream_t)stream);
+  if (e != hipSuccess) return ksmi_fail((int)e, hipGetErrorString(e));
+  return 0;
+}
+
+int ksmi_nchw_to_nhwc(const float* x, void* y, int B, int C, int HW, int dtype, void* stream) {
+  const int64_t n = (int64_t)B * C * HW;
+  KSMI_DT(dtype,
+          hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, dim3(grid_for(n, 8192)), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)y, B, C, HW),
+          hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(grid_for(n, 8192)), dim3(256), 0, (hipStream_t)stream, x, (float*)y, B, C, HW));
+  return ksmi_check_launch("nchw_to_nhwc");
+}
+
+int ksmi_nhwc_to_nchw(const void* x, float* y, int B, int C, int HW, int dtype, void* stream) {
+  const int64_t n = (int64_t)B * C * HW;
+  KSMI_DT(dtype,
+          hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, dim3(grid_for(n, 8192)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, y, B, C, HW),
+          hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(grid_for(n, 8192)), dim3(256), 0, (hipStream_t)stream, (const float*)x, y, B, C, HW));
+  return ksmi_check_launch("nhwc_to_nchw");
+}
+
+int ksmi_selftest_mma(const void* a, const void* b, float* c, int dtype, void* stream) {
+  KSMI_DT(dtype,
+          hipLaunchKernelGGL(selftest_mma_kernel<bf16_t>, dim3(1), dim3(64), 0, (hipStream_t)stream, (const bf16_t*)a, (const bf16_t*)b, c),
+          hipLaunchKernelGGL(selftest_mma_kernel<float>, dim3(1), dim3(64), 0, (hipStream_t)stream, (const float*)a, (const float*)b, c));
+  return ksmi_check_launch("selftest_mma");
+}
+
+int ksmi_selftest_tr16(const uint16_t* in256, uint16_t* out256, void* stream) {
+  hipLaunchKernelGGL(selftest_tr16_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, in256, out256);
+  return ksmi_check_launch("selftest_tr16");
+}
+
+}  // extern "C"

@@ -1,0 +1,586 @@
+// Implicit-GEMM convolution family for gfx950 (MFMA 16x16, LDS-staged halo tiles,
+// virtual concat).  See include/ksmi.h for the C-ABI and DESIGN.md for the tiling.
+//
+//   M = output pixels of one TH x TW patch (<= 256, 4 waves x 4 M-fragments x 16)
+//   N = output channels (BN = 16*NT per workgroup)
+//   K = taps x channels; channels walk the virtual-concat sources in 64-byte chunks
+//       (32 bf16 / 16 fp32), one halo tile + one weight slab in LDS per chunk.
+#include "common.h"
+#include "../../include/ksmi.h"
+#include "errors.h"
+
+namespace {
+
+// LDS swizzle of the 16-byte k-group slot inside a 64-byte row (conflict-free
+// ds_read_b128 for 16 consecutive rows; derivation in DESIGN.md §LDS).
+__device__ __forceinline__ int swz(int row) { return (0 - (row >> 2)) & 3; }
+
+template <typename T, int NT, int KH, int KW>
+__global__ __launch_bounds__(256) void igemm_fwd_kernel(const ksmi_conv_desc d) {
+  constexpr int TAPS = KH * KW;
+  constexpr int BN = NT * 16;
+  constexpr int VEC = ElemTraits<T>::kVec;   // elements per 16 B
+  constexpr int KC = VEC * 4;                // elements per 64-byte chunk
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, l15 = lane & 15;
+
+  const int tilesX = (d.Wout + d.TW - 1) / d.TW, tilesY = (d.Hout + d.TH - 1) / d.TH;
+  int bm = blockIdx.x;
+  const int tx = bm % tilesX; bm /= tilesX;
+  const int ty = bm % tilesY; const int b = bm / tilesY;
+  const int oy0 = ty * d.TH, ox0 = tx * d.TW;
+  const int n0 = blockIdx.y * BN;
+  const int S = d.stride;
+  const int HH = (d.TH - 1) * S + KH, HW = (d.TW - 1) * S + KW;
+  const int HP = HH * HW;
+  const int P = d.TH * d.TW;
+  unsigned char* lds_halo = smem;
+  unsigned char* lds_w = smem + ((HP * 64 + 255) & ~255);
+
+  // ---- per-thread halo slots (independent of the chunk) ---------------------------
+  constexpr int MAXSLOT = 8;                   // HP*4 <= 2048 vectors
+  int slot_goff[MAXSLOT];                      // pixel index in the image, or -1 (zero fill)
+  int slot_lds[MAXSLOT];
+  const int nvec = HP * 4;
+#pragma unroll
+  for (int s = 0; s < MAXSLOT; ++s) {
+    const int v = tid + s * 256;
+    slot_goff[s] = -2; slot_lds[s] = 0;
+    if (v < nvec) {
+      const int pix = v >> 2, q = v & 3;
+      const int hy = pix / HW, hx = pix - hy * HW;
+      const int iy = oy0 * S - d.pad + hy, ix = ox0 * S - d.pad + hx;
+      slot_goff[s] = (iy >= 0 && iy < d.Hin && ix >= 0 && ix < d.Win) ? ((b * d.Hin + iy) * d.Win + ix) : -1;
+      slot_lds[s] = pix * 64 + ((q ^ swz(pix)) << 4);
+    }
+  }
+  const int myq = tid & 3;                     // 256 % 4 == 0: a thread always owns k-group myq
+
+  // ---- per-lane A addresses (pixel -> halo position), per tap -------------------------
+  int a_addr[4][TAPS];
+  bool pvalid[4];
+#pragma unroll
+  for (int mf = 0; mf < 4; ++mf) {
+    int p = wave * 64 + mf * 16 + l15;
+    pvalid[mf] = p < P;
+    if (p >= P) p = 0;
+    const int ly = p / d.TW, lx = p - ly * d.TW;
+    const int base = ly * S * HW + lx * S;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {
+      const int ap = base + (t / KW) * HW + (t % KW);
+      a_addr[mf][t] = ap * 64 + ((g ^ swz(ap)) << 4);
+    }
+  }
+  int b_addr[NT];
+#pragma unroll
+  for (int nf = 0; nf < NT; ++nf) {
+    const int n = nf * 16 + l15;
+    b_addr[nf] = n * 64 + ((g ^ swz(n)) << 4);
+  }
+
+  f32x4 acc[4][NT];
+#pragma unroll
+  for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+    for (int nf = 0; nf < NT; ++nf) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const T* wpk = (const T*)d.wpk;
+
+  for (int ch = 0; ch < d.nchunks; ++ch) {
+    const ksmi_src& sr = d.src[d.chunk_src[ch]];
+    const int c0 = d.chunk_c0[ch];
+    __syncthreads();
+    // ---- stage halo: global -> regs -> (affine, relu) -> LDS ---------------------------
+    {
+      const int cq = c0 + myq * VEC;           // first channel of my vector (within used range)
+      const bool cvalid = cq < sr.c_len;
+      float sc[VEC], sh[VEC];
+      const bool aff = sr.scale != nullptr;
+      if (aff && cvalid) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { sc[j] = sr.scale[cq + j]; sh[j] = sr.shift[cq + j]; }
+      }
+      const T* sp = (const T*)sr.ptr + sr.c_off + cq;
+#pragma unroll
+      for (int s = 0; s < MAXSLOT; ++s) {
+        if (slot_goff[s] == -2) break;
+        u32x4 v = (u32x4){0u, 0u, 0u, 0u};
+        if (slot_goff[s] >= 0 && cvalid) {
+          v = *(const u32x4*)(sp + (size_t)slot_goff[s] * sr.C);
+          if (aff) {
+            float f[VEC];
+            vec_unpack<T>(v, f);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+              f[j] = f[j] * sc[j] + sh[j];
+              if (sr.relu) f[j] = fmaxf(f[j], 0.f);
+            }
+            v = vec_pack<T>(f);
+          }
+        }
+        *(u32x4*)(lds_halo + slot_lds[s]) = v;
+      }
+    }
+    // ---- stage weights [TAPS][BN][KC] ---------------------------------------------------
+    {
+      const T* wsrc = wpk + (size_t)ch * TAPS * d.Npad * KC;
+      for (int v = tid; v < TAPS * BN * 4; v += 256) {
+        const int row = v >> 2, q = v & 3;
+        const int t = row / BN, n = row - t * BN;
+        u32x4 w = (u32x4){0u, 0u, 0u, 0u};
+        if (n0 + n < d.Npad) w = *(const u32x4*)(wsrc + ((size_t)t * d.Npad + n0 + n) * KC + q * VEC);
+        *(u32x4*)(lds_w + row * 64 + ((q ^ swz(n)) << 4)) = w;
+      }
+    }
+    __syncthreads();
+    // ---- MFMA ------------------------------------------------------------------------------
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {
+      u32x4 a[4], bb[NT];
+#pragma unroll
+      for (int mf = 0; mf < 4; ++mf) a[mf] = *(const u32x4*)(lds_halo + a_addr[mf][t]);
+#pragma unroll
+      for (int nf = 0; nf < NT; ++nf) bb[nf] = *(const u32x4*)(lds_w + t * BN * 64 + b_addr[nf]);
+#pragma unroll
+      for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+        for (int nf = 0; nf < NT; ++nf) mma16<T>(acc[mf][nf], a[mf], bb[nf]);
+    }
+  }
+
+  // ---- epilogue ---------------------------------------------------------------------------------
+  // C layout: col n = l15, row (pixel within fragment) = g*4 + r.
+  float s_sum[NT], s_sq[NT];
+#pragma unroll
+  for (int nf = 0; nf < NT; ++nf) { s_sum[nf] = 0.f; s_sq[nf] = 0.f; }
+
+#pragma unroll
+  for (int nf = 0; nf < NT; ++nf) {
+    const int n = n0 + nf * 16 + l15;
+    const bool nvalid = n < d.N;
+    const float bias = (d.bias && nvalid) ? d.bias[d.ps_cout > 0 ? n % d.ps_cout : n] : 0.f;
+    // destination segment of this 16-column fragment
+    int si = 0;
+    for (int k = 1; k < d.ndst; ++k) if (n >= d.dst[k].n_begin) si = k;
+    const ksmi_dst& ds = d.dst[si];
+    float mm = 0.f, mr = 0.f, mg = 0.f, mb = 0.f;
+    if (d.mask_src && nvalid) { mm = d.m_mean[n]; mr = d.m_rstd[n]; mg = d.m_scale[n]; mb = d.m_shift[n]; }
+#pragma unroll
+    for (int mf = 0; mf < 4; ++mf) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int p = wave * 64 + mf * 16 + g * 4 + r;
+        const int ly = p / d.TW, lx = p - ly * d.TW;
+        const int oy = oy0 + ly, ox = ox0 + lx;
+        const bool ok = nvalid && p < P && oy < d.Hout && ox < d.Wout;
+        if (!ok) continue;
+        float v = acc[mf][nf][r] + bias;
+        const size_t opix = ((size_t)b * d.Hout + oy) * d.Wout + ox;
+        if (d.mask_src) {
+          const float m = ElemTraits<T>::ld((const T*)d.mask_src + opix * d.N + n);
+          const float xh = (m - mm) * mr;
+          if (!(m * mg + mb > 0.f)) v = 0.f;
+          s_sum[nf] += v; s_sq[nf] += v * xh;
+        } else {
+          s_sum[nf] += v; s_sq[nf] += v * v;
+        }
+        T* dp;
+        if (d.ps_cout > 0) {
+          const int dd = n / d.ps_cout, nn = n - dd * d.ps_cout;
+          const size_t op2 = ((size_t)b * (2 * d.Hout) + (2 * oy + (dd >> 1))) * (2 * d.Wout) + (2 * ox + (dd & 1));
+          dp = (T*)ds.ptr + op2 * ds.C + ds.c_off + nn;
+        } else {
+          dp = (T*)ds.ptr + opix * ds.C + ds.c_off + (n - ds.n_begin);
+        }
+        if (ds.accumulate) v += ElemTraits<T>::ld(dp);
+        ElemTraits<T>::st(dp, v);
+      }
+    }
+  }
+  if (d.stats) {
+    float* red = (float*)smem;                 // [4 waves][2][BN]
+    __syncthreads();
+#pragma unroll
+    for (int nf = 0; nf < NT; ++nf) {
+      float a = s_sum[nf], q = s_sq[nf];
+      a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+      q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+      if (g == 0) { red[(wave * 2 + 0) * BN + nf * 16 + l15] = a; red[(wave * 2 + 1) * BN + nf * 16 + l15] = q; }
+    }
+    __syncthreads();
+    if (tid < 2 * BN) {
+      const int which = tid / BN, n = tid - which * BN;
+      const float v = red[(0 * 2 + which) * BN + n] + red[(1 * 2 + which) * BN + n] + red[(2 * 2 + which) * BN + n] + red[(3 * 2 + which) * BN + n];
+      if (n0 + n < d.Npad) d.stats[((size_t)blockIdx.x * 2 + which) * d.Npad + n0 + n] = v;
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+// weight packing
+// -------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void pack_weights_kernel(const ksmi_pack_desc d) {
+  constexpr int KC = ElemTraits<T>::kVec * 4;
+  const size_t total = (size_t)d.nchunks * d.taps * d.Npad * KC;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int kk = i % KC; size_t r = i / KC;
+    const int j = r % d.Npad; r /= d.Npad;
+    const int tap = r % d.taps; const int ch = r / d.taps;
+    float v = 0.f;
+    if (j < d.N && kk < d.k_len[ch]) {
+      const int64_t k = d.k_off[ch] + kk;
+      const int tp = d.flip ? (d.taps - 1 - tap) : tap;
+      v = d.w[k * d.sK + (int64_t)(j % d.n_mod) * d.sN + (int64_t)(j / d.n_mod) * d.sD + tp * d.sT];
+    }
+    ElemTraits<T>::st((T*)d.out + i, v);
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+// weight gradient: per (pixel-split, chunk, N-tile) workgroup accumulates
+//   G[tap][kc][n] = sum_p X[p*S + tap - pad][kc] * dY[p][n]  over its patches.
+// MFMA rows = channels of the chunk, cols = n, K = pixels; both operands are read
+// "transposed" from LDS (ds_read_b64_tr_b16 for bf16, scalar ds_read_b32 for fp32).
+// -------------------------------------------------------------------------------------------------
+template <typename T> struct TrRead;
+template <> struct TrRead<bf16_t> {
+  // rows = 8 consecutive k (pixels) of k-group g; returns the lane's 8 bf16 at column col0+l15.
+  // rowaddr(j) gives the LDS byte address of pixel-row (g*8+j), already including col0*2.
+  template <typename F> __device__ static __forceinline__ u32x4 read(F rowaddr, int l15) {
+    const int jr = l15 >> 2, q = l15 & 3;
+    const unsigned a0 = rowaddr(jr) + q * 8, a1 = rowaddr(4 + jr) + q * 8;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(uintptr_t)a0);
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(uintptr_t)a1);
+    u32x4 r;
+    r[0] = (uint16_t)lo[0] | ((uint32_t)(uint16_t)lo[1] << 16);
+    r[1] = (uint16_t)lo[2] | ((uint32_t)(uint16_t)lo[3] << 16);
+    r[2] = (uint16_t)hi[0] | ((uint32_t)(uint16_t)hi[1] << 16);
+    r[3] = (uint16_t)hi[2] | ((uint32_t)(uint16_t)hi[3] << 16);
+    return r;
+  }
+};
+
+template <typename T, int NT, int KH, int KW>
+__global__ __launch_bounds__(256) void igemm_wgrad_kernel(const ksmi_wgrad_desc d, int patches_total, int patches_per_split) {
+  constexpr int TAPS = KH * KW;
+  constexpr int BN = NT * 16;
+  constexpr int VEC = ElemTraits<T>::kVec;
+  constexpr int KC = VEC * 4;
+  constexpr int CF = KC / 16;                  // channel fragments per chunk (2 bf16, 1 fp32)
+  constexpr int KSTEP = KC;                    // pixels per MFMA k-step (32 bf16 / 16 fp32)
+  constexpr int TPW = (TAPS + 3) / 4;          // taps per wave
+  constexpr int ES = sizeof(T);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, l15 = lane & 15;
+  const int split = blockIdx.x, ch = blockIdx.y, n0 = blockIdx.z * BN;
+  const int S = d.stride;
+  const int HH = (d.TH - 1) * S + KH, HW = (d.TW - 1) * S + KW;
+  const int HP = HH * HW;
+  const int P = d.TH * d.TW;
+  const int Ppad = (P + KSTEP - 1) / KSTEP * KSTEP;
+  const int tilesX = (d.Wout + d.TW - 1) / d.TW, tilesY = (d.Hout + d.TH - 1) / d.TH;
+  // LDS: X halo [HP][KC] (64 B rows, unswizzled) ; dY tile [Ppad][BN] (BN*ES bytes per row)
+  unsigned char* lds_x = smem;
+  unsigned char* lds_dy = smem + ((HP * 64 + 255) & ~255);
+  const int dyrow = BN * ES;
+
+  const ksmi_src& sr = d.src[d.chunk_src[ch]];
+  const int c0 = d.chunk_c0[ch];
+  const int myq = tid & 3;
+  const int cq = c0 + myq * VEC;
+  const bool cvalid = cq < sr.c_len;
+  float sc[VEC], sh[VEC];
+  const bool aff = sr.scale != nullptr;
+  if (aff && cvalid) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { sc[j] = sr.scale[cq + j]; sh[j] = sr.shift[cq + j]; }
+  }
+
+  f32x4 acc[TPW][CF][NT];
+#pragma unroll
+  for (int a = 0; a < TPW; ++a)
+#pragma unroll
+    for (int c = 0; c < CF; ++c)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[a][c][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int p_begin = split * patches_per_split;
+  const int p_end = min(patches_total, p_begin + patches_per_split);
+  for (int patch = p_begin; patch < p_end; ++patch) {
+    int bm = patch;
+    const int tx = bm % tilesX; bm /= tilesX;
+    const int ty = bm % tilesY; const int b = bm / tilesY;
+    const int oy0 = ty * d.TH, ox0 = tx * d.TW;
+    __syncthreads();
+    // ---- stage X halo -------------------------------------------------------------------
+    {
+      const T* sp = (const T*)sr.ptr + sr.c_off + cq;
+      for (int v = tid; v < HP * 4; v += 256) {
+        const int pix = v >> 2;
+        const int hy = pix / HW, hx = pix - hy * HW;
+        const int iy = oy0 * S - d.pad + hy, ix = ox0 * S - d.pad + hx;
+        u32x4 x = (u32x4){0u, 0u, 0u, 0u};
+        if (cvalid && iy >= 0 && iy < d.Hin && ix >= 0 && ix < d.Win) {
+          x = *(const u32x4*)(sp + ((size_t)(b * d.Hin + iy) * d.Win + ix) * sr.C);
+          if (aff) {
+            float f[VEC];
+            vec_unpack<T>(x, f);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+              f[j] = f[j] * sc[j] + sh[j];
+              if (sr.relu) f[j] = fmaxf(f[j], 0.f);
+            }
+            x = vec_pack<T>(f);
+          }
+        }
+        *(u32x4*)(lds_x + pix * 64 + myq * 16) = x;
+      }
+    }
+    // ---- stage dY tile [Ppad][BN] (zero rows for invalid pixels) ------------------------------
+    {
+      constexpr int VPR = BN / VEC;            // 16-byte vectors per row
+      const T* dyp = (const T*)d.dy + d.dy_c_off + n0;
+      for (int v = tid; v < Ppad * VPR; v += 256) {
+        const int p = v / VPR, q = v - p * VPR;
+        const int ly = p / d.TW, lx = p - ly * d.TW;
+        const int oy = oy0 + ly, ox = ox0 + lx;
+        u32x4 x = (u32x4){0u, 0u, 0u, 0u};
+        if (p < P && oy < d.Hout && ox < d.Wout && n0 + q * VEC < d.N)
+          x = *(const u32x4*)(dyp + ((size_t)(b * d.Hout + oy) * d.Wout + ox) * d.dyC + q * VEC);
+        *(u32x4*)(lds_dy + p * dyrow + q * 16) = x;
+      }
+    }
+    __syncthreads();
+    // ---- MFMA over pixel k-steps --------------------------------------------------------------
+    for (int ks = 0; ks < Ppad; ks += KSTEP) {
+      u32x4 bfrag[NT];
+      if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int nf = 0; nf < NT; ++nf) {
+          auto rowaddr = [&](int j) -> unsigned {
+            return (unsigned)(uintptr_t)(lds_dy) + (ks + g * 8 + j) * dyrow + nf * 32;
+          };
+          bfrag[nf] = TrRead<bf16_t>::read(rowaddr, l15);
+        }
+      } else {
+#pragma unroll
+        for (int nf = 0; nf < NT; ++nf)
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+            bfrag[nf][s] = *(const uint32_t*)(lds_dy + (ks + g * 4 + s) * dyrow + (nf * 16 + l15) * 4);
+      }
+#pragma unroll
+      for (int a = 0; a < TPW; ++a) {
+        const int t = wave + a * 4;
+        if (t >= TAPS) break;
+        const int toff = (t / KW) * HW + (t % KW);
+#pragma unroll
+        for (int cf = 0; cf < CF; ++cf) {
+          u32x4 afrag;
+          if constexpr (sizeof(T) == 2) {
+            auto rowaddr = [&](int j) -> unsigned {
+              int p = ks + g * 8 + j; if (p >= P) p = 0;      // dY rows >= P are zero
+              const int ly = p / d.TW, lx = p - ly * d.TW;
+              return (unsigned)(uintptr_t)(lds_x) + (ly * S * HW + lx * S + toff) * 64 + cf * 32;
+            };
+            afrag = TrRead<bf16_t>::read(rowaddr, l15);
+          } else {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+              int p = ks + g * 4 + s; if (p >= P) p = 0;
+              const int ly = p / d.TW, lx = p - ly * d.TW;
+              afrag[s] = *(const uint32_t*)(lds_x + (ly * S * HW + lx * S + toff) * 64 + l15 * 4);
+            }
+          }
+#pragma unroll
+          for (int nf = 0; nf < NT; ++nf) mma16<T>(acc[a][cf][nf], afrag, bfrag[nf]);
+        }
+      }
+    }
+  }
+  // ---- write partial slab [split][tap][chunk*KC + kc][Npad] ------------------------------------
+  const int Npad = (d.N + 15) & ~15;
+  const int Ktot = d.nchunks * KC;
+#pragma unroll
+  for (int a = 0; a < TPW; ++a) {
+    const int t = wave + a * 4;
+    if (t >= TAPS) break;
+#pragma unroll
+    for (int cf = 0; cf < CF; ++cf)
+#pragma unroll
+      for (int nf = 0; nf < NT; ++nf) {
+        const int n = n0 + nf * 16 + l15;
+        if (n >= Npad) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int kc = cf * 16 + g * 4 + r;
+          d.partial[(((size_t)split * TAPS + t) * Ktot + ch * KC + kc) * Npad + n] = acc[a][cf][nf][r];
+        }
+      }
+  }
+}
+
+// sum the split slabs (fp32, fixed order => deterministic) and scatter into the fp32 gradient
+__global__ void wgrad_reduce_kernel(const ksmi_wgrad_desc d, int taps, int KC) {
+  const int Npad = (d.N + 15) & ~15;
+  const int Ktot = d.nchunks * KC;
+  const size_t total = (size_t)taps * Ktot * Npad;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int n = i % Npad; size_t r = i / Npad;
+    const int krow = r % Ktot; const int t = r / Ktot;
+    const int ch = krow / KC, kc = krow - ch * KC;
+    if (n >= d.N || kc >= d.k_len[ch]) continue;
+    float s = 0.f;
+    for (int sp = 0; sp < d.nsplit; ++sp) s += d.partial[(size_t)sp * total + i];
+    const int64_t k = d.k_off[ch] + kc;
+    float* gp = d.grad + k * d.gK + (int64_t)n * d.gN + (int64_t)t * d.gT;
+    *gp = d.accumulate ? (*gp + s) : s;
+  }
+}
+
+template <typename T>
+int launch_fwd(const ksmi_conv_desc* d, hipStream_t st) {
+  const int taps = d->KH * d->KW;
+  const int tilesX = (d->Wout + d->TW - 1) / d->TW, tilesY = (d->Hout + d->TH - 1) / d->TH;
+  const int gm = d->B * tilesX * tilesY;
+  const int HH = (d->TH - 1) * d->stride + d->KH, HW = (d->TW - 1) * d->stride + d->KW;
+  const int HP = HH * HW;
+  if (d->TH * d->TW > 256 || HP * 4 > 2048) return ksmi_fail(KSMI_E_ARG, "conv: patch too large (TH*TW<=256, halo<=512 px)");
+  int nt = d->Npad >= 128 ? 8 : (d->Npad >= 64 ? 4 : (d->Npad >= 32 ? 2 : 1));
+  if (sizeof(T) == 4 && nt > 4) nt = 4;        // fp32: keep LDS <= 160 KB
+  const int bn = nt * 16;
+  const dim3 grid(gm, (d->Npad + bn - 1) / bn);
+  size_t lds = ((HP * 64 + 255) & ~255) + (size_t)taps * bn * 64;
+  const size_t red = 4 * 2 * bn * sizeof(float);
+  if (lds < red) lds = red;
+#define KSMI_LAUNCH_FWD(NT_, KH_, KW_)                                                              \
+  do {                                                                                              \
+    auto kfn = igemm_fwd_kernel<T, NT_, KH_, KW_>;                                                  \
+    if (lds > 65536) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, *d);                                          \
+  } while (0)
+#define KSMI_DISPATCH_NT(KH_, KW_)                                                                  \
+  switch (nt) {                                                                                     \
+    case 1: KSMI_LAUNCH_FWD(1, KH_, KW_); break;                                                    \
+    case 2: KSMI_LAUNCH_FWD(2, KH_, KW_); break;                                                    \
+    case 4: KSMI_LAUNCH_FWD(4, KH_, KW_); break;                                                    \
+    default: KSMI_LAUNCH_FWD(8, KH_, KW_); break;                                                   \
+  }
+  if (d->KH == 3 && d->KW == 3) { KSMI_DISPATCH_NT(3, 3) }
+  else if (d->KH == 1 && d->KW == 1) { KSMI_DISPATCH_NT(1, 1) }
+  else if (d->KH == 2 && d->KW == 2) { KSMI_DISPATCH_NT(2, 2) }
+  else return ksmi_fail(KSMI_E_UNSUPPORTED, "conv: kernel size not supported");
+#undef KSMI_DISPATCH_NT
+#undef KSMI_LAUNCH_FWD
+  return ksmi_check_launch("igemm_fwd");
+}
+
+struct WgradGeom { int taps, kc, nt, bn, patches, pps, nsplit, ntiles, npad; size_t lds; };
+
+template <typename T>
+WgradGeom wgrad_geom(const ksmi_wgrad_desc* d) {
+  WgradGeom g;
+  g.taps = d->KH * d->KW;
+  g.kc = ElemTraits<T>::kVec * 4;
+  g.npad = (d->N + 15) & ~15;
+  g.nt = g.npad >= 64 ? 4 : (g.npad >= 32 ? 2 : 1);
+  g.bn = g.nt * 16;
+  g.ntiles = (g.npad + g.bn - 1) / g.bn;
+  const int tilesX = (d->Wout + d->TW - 1) / d->TW, tilesY = (d->Hout + d->TH - 1) / d->TH;
+  g.patches = d->B * tilesX * tilesY;
+  // aim at ~1024 workgroups in total; at most 256 splits
+  int want = 1024 / (d->nchunks * g.ntiles);
+  if (want < 1) want = 1;
+  if (want > 256) want = 256;
+  if (want > g.patches) want = g.patches;
+  g.pps = (g.patches + want - 1) / want;
+  g.nsplit = (g.patches + g.pps - 1) / g.pps;
+  const int HH = (d->TH - 1) * d->stride + d->KH, HW = (d->TW - 1) * d->stride + d->KW;
+  const int P = d->TH * d->TW, Ppad = (P + g.kc - 1) / g.kc * g.kc;
+  g.lds = ((HH * HW * 64 + 255) & ~255) + (size_t)Ppad * g.bn * sizeof(T);
+  return g;
+}
+
+template <typename T>
+int launch_wgrad(const ksmi_wgrad_desc* d, hipStream_t st) {
+  WgradGeom g = wgrad_geom<T>(d);
+  if (d->TH * d->TW > 256) return ksmi_fail(KSMI_E_ARG, "wgrad: patch too large");
+  if (d->nsplit != g.nsplit) return ksmi_fail(KSMI_E_ARG, "wgrad: nsplit does not match ksmi_conv_wgrad_workspace geometry");
+  const dim3 grid(g.nsplit, d->nchunks, g.ntiles);
+#define KSMI_LAUNCH_WG(NT_, KH_, KW_)                                                               \
+  do {                                                                                              \
+    auto kfn = igemm_wgrad_kernel<T, NT_, KH_, KW_>;                                                \
+    if (g.lds > 65536) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds); \
+    hipLaunchKernelGGL(kfn, grid, dim3(256), g.lds, st, *d, g.patches, g.pps);                      \
+  } while (0)
+#define KSMI_DISPATCH_WNT(KH_, KW_)                                                                 \
+  switch (g.nt) {                                                                                   \
+    case 1: KSMI_LAUNCH_WG(1, KH_, KW_); break;                                                     \
+    case 2: KSMI_LAUNCH_WG(2, KH_, KW_); break;                                                     \
+    default: KSMI_LAUNCH_WG(4, KH_, KW_); break;                                                    \
+  }
+  if (d->KH == 3 && d->KW == 3) { KSMI_DISPATCH_WNT(3, 3) }
+  else if (d->KH == 1 && d->KW == 1) { KSMI_DISPATCH_WNT(1, 1) }
+  else if (d->KH == 2 && d->KW == 2) { KSMI_DISPATCH_WNT(2, 2) }
+  else return ksmi_fail(KSMI_E_UNSUPPORTED, "wgrad: kernel size not supported");
+#undef KSMI_DISPATCH_WNT
+#undef KSMI_LAUNCH_WG
+  int rc = ksmi_check_launch("igemm_wgrad");
+  if (rc) return rc;
+  const size_t total = (size_t)g.taps * d->nchunks * g.kc * g.npad;
+  int blocks = (int)((total + 255) / 256); if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, *d, g.taps, g.kc);
+  return ksmi_check_launch("wgrad_reduce");
+}
+
+}  // namespace
+
+extern "C" {
+
+int ksmi_chunk_elems(int dtype) { return dtype == KSMI_BF16 ? 32 : 16; }
+
+int ksmi_conv_grid_m(const ksmi_conv_desc* d) {
+  const int tilesX = (d->Wout + d->TW - 1) / d->TW, tilesY = (d->Hout + d->TH - 1) / d->TH;
+  return d->B * tilesX * tilesY;
+}
+
+int ksmi_conv_forward(const ksmi_conv_desc* d, int dtype, void* stream) {
+  if (!d || d->nsrc < 1 || d->nsrc > KSMI_MAX_SRC || d->ndst < 1 || d->ndst > KSMI_MAX_SRC || d->nchunks < 1 ||
+      d->nchunks > KSMI_MAX_CHUNKS)
+    return ksmi_fail(KSMI_E_ARG, "conv: bad descriptor");
+  if (dtype == KSMI_BF16) return launch_fwd<bf16_t>(d, (hipStream_t)stream);
+  if (dtype == KSMI_F32) return launch_fwd<float>(d, (hipStream_t)stream);
+  return ksmi_fail(KSMI_E_ARG, "conv: bad dtype");
+}
+
+int ksmi_pack_weights(const ksmi_pack_desc* d, int dtype, void* stream) {
+  if (!d || d->nchunks < 1 || d->nchunks > KSMI_MAX_CHUNKS) return ksmi_fail(KSMI_E_ARG, "pack: bad descriptor");
+  const int kc = ksmi_chunk_elems(dtype);
+  const size_t total = (size_t)d->nchunks * d->taps * d->Npad * kc;
+  int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
+  if (dtype == KSMI_BF16) hipLaunchKernelGGL(pack_weights_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *d);
+  else hipLaunchKernelGGL(pack_weights_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *d);
+  return ksmi_check_launch("pack_weights");
+}
+
+size_t ksmi_conv_wgrad_workspace(const ksmi_wgrad_desc* d, int dtype) {
+  WgradGeom g = dtype == KSMI_BF16 ? wgrad_geom<bf16_t>(d) : wgrad_geom<float>(d);
+  // caller reads nsplit back through the returned size: bytes = nsplit * slab
+  return (size_t)g.nsplit * g.taps * d->nchunks * g.kc * g.npad * sizeof(float);
+}
+
+int ksmi_conv_wgrad(const ksmi_wgrad_desc* d, int dtype, void* stream) {
+  if (!d || d->nsrc < 1 || d->nsrc > KSMI_MAX_SRC || d->nchunks < 1 || d->nchunks > KSMI_MAX_CHUNKS)
+    return ksmi_fail(KSMI_E_ARG, "wgrad: bad descriptor");
+  if (dtype == KSMI_BF16) return launch_wgrad<bf16_t>(d, (hipStream_t)stream);
+  if (dtype == KSMI_F32) return launch_wgrad<float>(d, (hipStream_t)stream);
+  return ksmi_fail(KSMI_E_ARG, "wgrad: bad dtype");
+}
+
+}  // extern "C"

@@ -1,0 +1,195 @@
+"""Host-side plumbing shared by the plans: device buffers (PyTorch allocator), stream
+handles, descriptor builders for the implicit-GEMM family, and launch lists.
+
+PyTorch is used here only for device memory and streams; all math is in libksmi.so.
+"""
+import ctypes as C
+import functools
+
+import torch
+
+from . import _lib
+from ._lib import KSMI_BF16, KSMI_F32, ConvDesc, Dst, PackDesc, Src, WgradDesc, check
+
+DT = {torch.float32: KSMI_F32, torch.bfloat16: KSMI_BF16}
+
+
+def require_gpu(t):
+    if not t.is_cuda:
+        raise _lib.KsmiError("kurosiwo_amd runs on an MI355X (HIP) device only: got a CPU tensor. "
+                             "There is no CPU fallback; use the reference repo for CPU runs.")
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def chunk_elems(dtype):
+    return 32 if dtype == torch.bfloat16 else 16
+
+
+def vec_elems(dtype):
+    return 8 if dtype == torch.bfloat16 else 4
+
+
+class Act:
+    """An NHWC activation (+ its gradient buffer) inside a plan."""
+
+    def __init__(self, name, B, H, W, Cch, dtype, device, needs_grad=True):
+        self.name, self.B, self.H, self.W, self.C = name, B, H, W, Cch
+        self.t = torch.empty((B, H, W, Cch), dtype=dtype, device=device)
+        self.g = None
+        self.needs_grad = needs_grad
+        self.ginit = False        # has some backward op already written self.g (plan-build-time tracking)
+        self.dtype, self.device = dtype, device
+
+    def grad(self):
+        if self.g is None:
+            self.g = torch.empty_like(self.t)
+        return self.g
+
+    def take_acc_flag(self):
+        """accumulate flag for the next backward writer (first writer overwrites)."""
+        acc = 1 if self.ginit else 0
+        self.ginit = True
+        return acc
+
+
+class SrcSpec:
+    def __init__(self, tensor, Cch, c_off=0, c_len=None, scale=None, shift=None, relu=0):
+        self.tensor, self.C, self.c_off = tensor, Cch, c_off
+        self.c_len = Cch - c_off if c_len is None else c_len
+        self.scale, self.shift, self.relu = scale, shift, relu
+
+
+@functools.lru_cache(maxsize=None)
+def choose_patch(H, W, stride=1, KH=3, KW=3, max_pix=256, max_halo=512):
+    """Pick the output patch (TH, TW) of a workgroup: maximise useful pixels per 256-row
+    M-tile, then minimise halo area."""
+    best = None
+    for tw in range(1, min(W, 256) + 1):
+        for th in range(1, min(H, max_pix // tw) + 1):
+            hp = ((th - 1) * stride + KH) * ((tw - 1) * stride + KW)
+            if hp > max_halo:
+                continue
+            tiles = -(-H // th) * -(-W // tw)
+            mfrag = -(-(th * tw) // 64) * 64      # waves work in 64-pixel quanta
+            cost = tiles * max(mfrag, 64) * (1.0 + 0.15 * hp / (th * tw))
+            key = (cost, hp)
+            if best is None or key < best[0]:
+                best = (key, th, tw)
+    return best[1], best[2]
+
+
+def _chunk_table(srcs, kc):
+    """[(src_idx, c0, k_global, k_len)] walking the virtual concat in kc-element chunks."""
+    table, kbase = [], 0
+    for si, s in enumerate(srcs):
+        for c0 in range(0, s.c_len, kc):
+            table.append((si, c0, kbase + c0, min(kc, s.c_len - c0)))
+        kbase += s.c_len
+    if len(table) > _lib.MAX_CHUNKS:
+        raise _lib.KsmiError(f"too many k-chunks ({len(table)} > {_lib.MAX_CHUNKS})")
+    return table, kbase
+
+
+def _fill_srcs(desc, srcs):
+    desc.nsrc = len(srcs)
+    for i, s in enumerate(srcs):
+        d = desc.src[i]
+        d.ptr = s.tensor.data_ptr()
+        d.scale = s.scale.data_ptr() if s.scale is not None else None
+        d.shift = s.shift.data_ptr() if s.shift is not None else None
+        d.C, d.c_off, d.c_len, d.relu = s.C, s.c_off, s.c_len, s.relu
+
+
+class Launches:
+    """A flat list of prepared C-ABI calls (fn, args) executed in order on the current stream."""
+
+    def __init__(self):
+        self.calls = []
+        self.keep = []       # keep descriptors / tensors alive
+
+    def add(self, name, *args):
+        fn = getattr(_lib.load(), name)
+        self.calls.append((fn, args, name))
+
+    def run(self):
+        st = stream_ptr()
+        for fn, args, name in self.calls:
+            rc = fn(*args, st)
+            if rc != 0:
+                check(rc, name)
+
+
+def make_pack(w, out, table, taps, N, Npad, n_mod, sK, sN, sD, sT, flip):
+    d = PackDesc()
+    d.w, d.out = w.data_ptr(), out.data_ptr()
+    d.nchunks, d.taps, d.N, d.Npad, d.n_mod = len(table), taps, N, Npad, n_mod
+    d.sK, d.sN, d.sD, d.sT, d.flip = sK, sN, sD, sT, flip
+    for i, (_, _, kg, kl) in enumerate(table):
+        d.k_off[i], d.k_len[i] = kg, kl
+    return d
+
+
+def make_conv(srcs, dsts, wpk, bias, stats, B, Hin, Win, Hout, Wout, KH, KW, stride, pad, N, dtype,
+              mask=None, ps_cout=0, max_pix=256):
+    """dsts: list of (tensor, C, c_off, n_begin, n_len, accumulate).  mask: (tensor, mean, rstd, scale, shift)."""
+    kc = chunk_elems(dtype)
+    table, _ = _chunk_table(srcs, kc)
+    d = ConvDesc()
+    _fill_srcs(d, srcs)
+    d.ndst = len(dsts)
+    for i, (t, Cc, c_off, nb, nl, acc) in enumerate(dsts):
+        q = d.dst[i]
+        q.ptr, q.C, q.c_off, q.n_begin, q.n_len, q.accumulate = t.data_ptr(), Cc, c_off, nb, nl, acc
+    d.wpk = wpk.data_ptr()
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.stats = stats.data_ptr() if stats is not None else None
+    if mask is not None:
+        d.mask_src, d.m_mean, d.m_rstd, d.m_scale, d.m_shift = [x.data_ptr() for x in mask]
+    d.B, d.Hin, d.Win, d.Hout, d.Wout = B, Hin, Win, Hout, Wout
+    d.KH, d.KW, d.stride, d.pad = KH, KW, stride, pad
+    mp = max_pix if stride == 1 else min(max_pix, 128)
+    d.TH, d.TW = choose_patch(Hout, Wout, stride, KH, KW, mp)
+    d.N, d.Npad = N, (N + 15) // 16 * 16
+    d.nchunks = len(table)
+    d.ps_cout = ps_cout
+    for i, (si, c0, _, _) in enumerate(table):
+        d.chunk_src[i], d.chunk_c0[i] = si, c0
+    return d, table
+
+
+def conv_grid_m(d):
+    return _lib.load().ksmi_conv_grid_m(C.byref(d))
+
+
+def packed_weight_numel(table, taps, Npad, dtype):
+    return len(table) * taps * Npad * chunk_elems(dtype)
+
+
+def make_wgrad(srcs, dy, dyC, dy_c_off, N, grad, gK, gN, gT, accumulate, B, Hin, Win, Hout, Wout,
+               KH, KW, stride, pad, dtype):
+    kc = chunk_elems(dtype)
+    table, _ = _chunk_table(srcs, kc)
+    d = WgradDesc()
+    _fill_srcs(d, srcs)
+    d.dy, d.dyC, d.dy_c_off = dy.data_ptr(), dyC, dy_c_off
+    d.B, d.Hin, d.Win, d.Hout, d.Wout = B, Hin, Win, Hout, Wout
+    d.KH, d.KW, d.stride, d.pad = KH, KW, stride, pad
+    mp = 256 if stride == 1 else 128
+    d.TH, d.TW = choose_patch(Hout, Wout, stride, KH, KW, mp)
+    d.N, d.nchunks = N, len(table)
+    d.grad, d.gK, d.gN, d.gT, d.accumulate = grad.data_ptr(), gK, gN, gT, accumulate
+    for i, (si, c0, kg, kl) in enumerate(table):
+        d.chunk_src[i], d.chunk_c0[i], d.k_off[i], d.k_len[i] = si, c0, kg, kl
+    lib = _lib.load()
+    ws = lib.ksmi_conv_wgrad_workspace(C.byref(d), DT[dtype])
+    npad = (N + 15) // 16 * 16
+    slab = (KH * KW) * len(table) * kc * npad * 4
+    d.nsplit = ws // slab
+    return d, ws

@@ -1,0 +1,376 @@
+"""Static launch plan of one SNUNet-ECAM forward/backward at a fixed (B, H, W, dtype, mode).
+
+The plan owns every NHWC activation / gradient buffer and a flat list of prepared C-ABI
+calls; running it is a loop of ctypes calls on the current HIP stream (no allocation, no
+host sync), so a whole train step can be captured into one HIP graph.
+
+Reference computation: /root/reference/models/snunet.py:118-153 (forward graph),
+:11-29 (conv_block_nested), :32-46 (up), :49-62 + :146-151 (ECAM head).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .runtime import DT, Act, SrcSpec, conv_grid_m, make_conv, make_pack, make_wgrad, packed_weight_numel, stream_ptr
+from .snunet import BN_EPS, BN_MOMENTUM
+
+
+class LaunchList:
+    """(name, argfn) pairs; argfn() is evaluated once, after all scratch buffers exist."""
+
+    def __init__(self):
+        self.pending, self.calls = [], []
+
+    def add(self, name, argfn):
+        self.pending.append((name, argfn))
+
+    def resolve(self, lib):
+        self.calls = [(getattr(lib, name), tuple(argfn()), name) for name, argfn in self.pending]
+
+    def run(self):
+        st = stream_ptr()
+        for fn, args, name in self.calls:
+            rc = fn(*args, st)
+            if rc != 0:
+                _lib.check(rc, name)
+
+
+class _Saved:
+    """saved statistics of one BatchNorm call: rows = mean, rstd, scale, shift"""
+
+    def __init__(self, Cch, device):
+        self.t = torch.zeros((4, Cch), dtype=torch.float32, device=device)
+        self.mean, self.rstd, self.scale, self.shift = (self.t[i].data_ptr() for i in range(4))
+        self.scale_t, self.shift_t = self.t[2], self.t[3]
+
+
+class SNUNetPlan:
+    def __init__(self, model, B, H, W, dtype, training, with_backward):
+        self.m, self.B, self.H, self.W, self.dtype = model, B, H, W, dtype
+        self.training, self.with_backward = training, with_backward
+        self.dev = model.flat_params.device
+        self.dt = DT[dtype]
+        self.lib = _lib.load()
+        self.packs, self.fwd, self.bwd = LaunchList(), LaunchList(), LaunchList()
+        self.keep = []
+        self._pinit = set()
+        self._need, self._bufs, self._later = {}, {}, []
+        n, c = model.base_channel, model.in_channels
+        self.n = n
+        f = [n, 2 * n, 4 * n, 8 * n, 16 * n]
+        self.xA = torch.empty((B, c, H, W), dtype=torch.float32, device=self.dev)
+        self.xB = torch.empty_like(self.xA)
+        self.logits = torch.empty((B, 3, H, W), dtype=torch.float32, device=self.dev)
+        self.dlogits = torch.empty_like(self.logits) if with_backward else None
+        self.bwd_builders = []
+
+        def A(name, lvl, ch):
+            return Act(name, B, H >> lvl, W >> lvl, ch, dtype, self.dev)
+
+        # ---- forward graph (snunet.py:118-153) -----------------------------------------------
+        x0_0A = self._block("conv0_0", "A", [self.xA], A("x0_0A", 0, f[0]), first=True)
+        x1_0A = self._block("conv1_0", "A", [self._pool(x0_0A, "p0A")], A("x1_0A", 1, f[1]))
+        x2_0A = self._block("conv2_0", "A", [self._pool(x1_0A, "p1A")], A("x2_0A", 2, f[2]))
+        x3_0A = self._block("conv3_0", "A", [self._pool(x2_0A, "p2A")], A("x3_0A", 3, f[3]))
+        x0_0B = self._block("conv0_0", "B", [self.xB], A("x0_0B", 0, f[0]), first=True)
+        x1_0B = self._block("conv1_0", "B", [self._pool(x0_0B, "p0B")], A("x1_0B", 1, f[1]))
+        x2_0B = self._block("conv2_0", "B", [self._pool(x1_0B, "p1B")], A("x2_0B", 2, f[2]))
+        x3_0B = self._block("conv3_0", "B", [self._pool(x2_0B, "p2B")], A("x3_0B", 3, f[3]))
+        x4_0B = self._block("conv4_0", "B", [self._pool(x3_0B, "p3B")], A("x4_0B", 4, f[4]))
+
+        x0_1 = self._block("conv0_1", "", [x0_0A, x0_0B, self._up("Up1_0", x1_0B)], A("x0_1", 0, f[0]))
+        x1_1 = self._block("conv1_1", "", [x1_0A, x1_0B, self._up("Up2_0", x2_0B)], A("x1_1", 1, f[1]))
+        x0_2 = self._block("conv0_2", "", [x0_0A, x0_0B, x0_1, self._up("Up1_1", x1_1)], A("x0_2", 0, f[0]))
+        x2_1 = self._block("conv2_1", "", [x2_0A, x2_0B, self._up("Up3_0", x3_0B)], A("x2_1", 2, f[2]))
+        x1_2 = self._block("conv1_2", "", [x1_0A, x1_0B, x1_1, self._up("Up2_1", x2_1)], A("x1_2", 1, f[1]))
+        x0_3 = self._block("conv0_3", "", [x0_0A, x0_0B, x0_1, x0_2, self._up("Up1_2", x1_2)], A("x0_3", 0, f[0]))
+        x3_1 = self._block("conv3_1", "", [x3_0A, x3_0B, self._up("Up4_0", x4_0B)], A("x3_1", 3, f[3]))
+        x2_2 = self._block("conv2_2", "", [x2_0A, x2_0B, x2_1, self._up("Up3_1", x3_1)], A("x2_2", 2, f[2]))
+        x1_3 = self._block("conv1_3", "", [x1_0A, x1_0B, x1_1, x1_2, self._up("Up2_2", x2_2)], A("x1_3", 1, f[1]))
+        x0_4 = self._block("conv0_4", "", [x0_0A, x0_0B, x0_1, x0_2, x0_3, self._up("Up1_3", x1_3)], A("x0_4", 0, f[0]))
+        self._head([x0_1, x0_2, x0_3, x0_4])
+        self.acts = {a.name: a for a in (x0_0A, x0_0B, x1_0A, x1_0B, x3_0B, x4_0B, x0_1, x1_1, x0_2, x0_3, x0_4, x1_3, x3_1)}
+
+        if with_backward:
+            for build in reversed(self.bwd_builders):
+                build()
+        # scratch allocation, descriptor patching, argument resolution
+        for name, nbytes in self._need.items():
+            self._bufs[name] = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.dev)
+        for fn in self._later:
+            fn()
+        for ll in (self.packs, self.fwd, self.bwd):
+            ll.resolve(self.lib)
+
+    # ---------------------------------------------------------------- helpers
+    def need(self, name, nbytes):
+        self._need[name] = max(self._need.get(name, 0), int(nbytes))
+
+    def scr(self, name):
+        return self._bufs[name].data_ptr()
+
+    def patch(self, desc, field, name):
+        self._later.append(lambda: setattr(desc, field, self.scr(name)))
+
+    def _acc_param(self, key):
+        acc = 1 if key in self._pinit else 0
+        self._pinit.add(key)
+        return acc
+
+    def _packed(self, key, table, taps, N, n_mod, sK, sN, sD, sT, flip):
+        Npad = (N + 15) // 16 * 16
+        out = torch.empty(packed_weight_numel(table, taps, Npad, self.dtype), dtype=self.dtype, device=self.dev)
+        d = make_pack(self.m._p(key), out, table, taps, N, Npad, n_mod, sK, sN, sD, sT, flip)
+        self.keep += [d, out]
+        self.packs.add("ksmi_pack_weights", lambda: (C.byref(d), self.dt))
+        return out
+
+    def _rows(self, npix):
+        return max(1, min(512, npix // 256))
+
+    def _conv(self, ll, d):
+        self.keep.append(d)
+        ll.add("ksmi_conv_forward", lambda: (C.byref(d), self.dt))
+
+    def _wgrad(self, d, ws):
+        self.keep.append(d)
+        self.need("wgrad", ws)
+        self.patch(d, "partial", "wgrad")
+        self.bwd.add("ksmi_conv_wgrad", lambda: (C.byref(d), self.dt))
+
+    # ---------------------------------------------------------------- nn.MaxPool2d(2,2)  (snunet.py:73)
+    def _pool(self, x, name):
+        y = Act(name, x.B, x.H // 2, x.W // 2, x.C, self.dtype, self.dev)
+        self.fwd.add("ksmi_maxpool2x2_forward", lambda: (x.t.data_ptr(), y.t.data_ptr(), x.B, x.H, x.W, x.C, self.dt))
+
+        def build_bwd():
+            acc = x.take_acc_flag()
+            gy, gx = y.grad(), x.grad()
+            self.bwd.add("ksmi_maxpool2x2_backward", lambda: (x.t.data_ptr(), gy.data_ptr(), gx.data_ptr(), acc,
+                                                              x.B, x.H, x.W, x.C, self.dt))
+        self.bwd_builders.append(build_bwd)
+        return y
+
+    # ---------------------------------------------------------------- up = ConvTranspose2d(k2,s2)  (snunet.py:32-46)
+    def _up(self, name, x):
+        Cc, B, H, W = x.C, x.B, x.H, x.W
+        y = Act(name, B, 2 * H, 2 * W, Cc, self.dtype, self.dev)
+        wkey, bkey = f"{name}.up.weight", f"{name}.up.bias"
+        d, table = make_conv([SrcSpec(x.t, Cc)], [(y.t, Cc, 0, 0, 4 * Cc, 0)], x.t, self.m._p(bkey), None,
+                             B, H, W, H, W, 1, 1, 1, 0, 4 * Cc, self.dtype, ps_cout=Cc)
+        # Wt[c][n][dy][dx]: GEMM column j = d*C + n, k = c
+        wpk = self._packed(wkey, table, 1, 4 * Cc, Cc, Cc * 4, 4, 1, 0, 0)
+        d.wpk = wpk.data_ptr()
+        self._conv(self.fwd, d)
+
+        def build_bwd():
+            gy = y.grad()
+            s2 = [SrcSpec(gy, Cc)]
+            acc = x.take_acc_flag()
+            # input gradient = 2x2 stride-2 conv over dUp: K = n, N = c
+            d2, t2 = make_conv(s2, [(x.grad(), Cc, 0, 0, Cc, acc)], gy, None, None,
+                               B, 2 * H, 2 * W, H, W, 2, 2, 2, 0, Cc, self.dtype)
+            w2 = self._packed(wkey, t2, 4, Cc, Cc, 4, Cc * 4, 0, 1, 0)
+            d2.wpk = w2.data_ptr()
+            self._conv(self.bwd, d2)
+            # weight gradient: G[tap d][k = n][col = c] -> grad[c*(4C) + n*4 + d]
+            dw, ws = make_wgrad(s2, x.t, Cc, 0, Cc, self.m._g(wkey), 4, Cc * 4, 1, self._acc_param(wkey),
+                                B, 2 * H, 2 * W, H, W, 2, 2, 2, 0, self.dtype)
+            self._wgrad(dw, ws)
+            # bias gradient
+            npix = B * 4 * H * W
+            rows = self._rows(npix)
+            self.need("red", rows * Cc * 4)
+            a_b = self._acc_param(bkey)
+            gb = self.m._g(bkey).data_ptr()
+            self.bwd.add("ksmi_channel_sum", lambda: (gy.data_ptr(), self.scr("red"), rows, npix, Cc, self.dt))
+            self.bwd.add("ksmi_reduce_rows", lambda: (self.scr("red"), rows, 1, Cc, Cc, None, None, gb, a_b))
+        self.bwd_builders.append(build_bwd)
+        return y
+
+    # ---------------------------------------------------------------- conv_block_nested  (snunet.py:11-29)
+    def _block(self, name, branch, sources, out, first=False):
+        m, B, H, W, Cc = self.m, out.B, out.H, out.W, out.C
+        npix = B * H * W
+        dtype, dt, training = self.dtype, self.dt, self.training
+        i_act = Act(f"{name}{branch}.i", B, H, W, Cc, dtype, self.dev)
+        z_act = Act(f"{name}{branch}.z", B, H, W, Cc, dtype, self.dev)
+        sv1, sv2 = _Saved(Cc, self.dev), _Saved(Cc, self.dev)
+        self.keep += [i_act, z_act, sv1, sv2]
+        P = lambda s: m._p(f"{name}.{s}").data_ptr()
+        G = lambda s: m._g(f"{name}.{s}").data_ptr()
+        Bf = lambda s: m._b(f"{name}.{s}").data_ptr()
+        Npad = (Cc + 15) // 16 * 16
+        stats = (lambda: self.scr("stats")) if training else (lambda: None)
+
+        # ---- conv1 ----------------------------------------------------------------------
+        if first:
+            x_img = sources[0]
+            cin = x_img.shape[1]
+            rows1, cpad1, Ktot = self.lib.ksmi_conv_first_stats_rows(B, H, W), Cc, cin
+            self.need("stats", rows1 * 2 * Cc * 4)
+            self.fwd.add("ksmi_conv_first_forward", lambda: (x_img.data_ptr(), P("conv1.weight"), P("conv1.bias"),
+                                                             i_act.t.data_ptr(), stats(), B, cin, H, W, Cc, dt))
+        else:
+            srcs = [SrcSpec(a.t, a.C) for a in sources]
+            Ktot = sum(a.C for a in sources)
+            d1, t1 = make_conv(srcs, [(i_act.t, Cc, 0, 0, Cc, 0)], i_act.t, m._p(f"{name}.conv1.bias"), None,
+                               B, H, W, H, W, 3, 3, 1, 1, Cc, dtype)
+            w1 = self._packed(f"{name}.conv1.weight", t1, 9, Cc, Cc, 9, Ktot * 9, 0, 1, 0)
+            d1.wpk = w1.data_ptr()
+            rows1, cpad1 = conv_grid_m(d1), Npad
+            if training:
+                self.need("stats", rows1 * 2 * Npad * 4)
+                self.patch(d1, "stats", "stats")
+            self._conv(self.fwd, d1)
+
+        def bn_fin(bn, sv, rows, cpad):
+            nbt = m._c(f"{name}.{bn}.num_batches_tracked").data_ptr()
+            self.fwd.add("ksmi_bn_finalize", lambda: (stats(), rows, cpad, Cc, float(npix), P(f"{bn}.weight"), P(f"{bn}.bias"),
+                                                      Bf(f"{bn}.running_mean"), Bf(f"{bn}.running_var"), nbt,
+                                                      BN_MOMENTUM, BN_EPS, 1 if training else 0,
+                                                      sv.mean, sv.rstd, sv.scale, sv.shift))
+        bn_fin("bn1", sv1, rows1, cpad1)
+
+        # ---- conv2 (BN1-apply + ReLU fused into the operand load) ---------------------------
+        src2 = [SrcSpec(i_act.t, Cc, scale=sv1.scale_t, shift=sv1.shift_t, relu=1)]
+        d2, t2 = make_conv(src2, [(z_act.t, Cc, 0, 0, Cc, 0)], z_act.t, m._p(f"{name}.conv2.bias"), None,
+                           B, H, W, H, W, 3, 3, 1, 1, Cc, dtype)
+        w2 = self._packed(f"{name}.conv2.weight", t2, 9, Cc, Cc, 9, Cc * 9, 0, 1, 0)
+        d2.wpk = w2.data_ptr()
+        rows2 = conv_grid_m(d2)
+        if training:
+            self.need("stats", rows2 * 2 * Npad * 4)
+            self.patch(d2, "stats", "stats")
+        self._conv(self.fwd, d2)
+        bn_fin("bn2", sv2, rows2, Npad)
+        self.fwd.add("ksmi_bn_add_relu", lambda: (z_act.t.data_ptr(), i_act.t.data_ptr(), sv2.scale, sv2.shift,
+                                                  out.t.data_ptr(), npix, Cc, dt))
+
+        # ---- backward ----------------------------------------------------------------------------
+        def build_bwd():
+            rows = self._rows(npix)
+            self.need("red", rows * 2 * Cc * 4)
+            sums1 = torch.zeros((2, Cc), dtype=torch.float32, device=self.dev)
+            sums2 = torch.zeros((2, Cc), dtype=torch.float32, device=self.dev)
+            dz = torch.empty_like(z_act.t)     # grad wrt conv2 output
+            r = torch.empty_like(i_act.t)      # relu-masked dgrad of conv2, then di (grad wrt conv1 output)
+            self.keep += [sums1, sums2, dz, r]
+            gout = out.grad().data_ptr()
+            s1p, s2p = sums1.data_ptr(), sums2.data_ptr()
+            a_bn2 = self._acc_param(f"{name}.bn2")
+            self.bwd.add("ksmi_bnrelu_bwd_reduce", lambda: (gout, out.t.data_ptr(), z_act.t.data_ptr(), sv2.mean, sv2.rstd,
+                                                            self.scr("red"), rows, npix, Cc, dt))
+            self.bwd.add("ksmi_reduce_rows", lambda: (self.scr("red"), rows, 2, Cc, Cc, s2p, G("bn2.weight"), G("bn2.bias"), a_bn2))
+            self.bwd.add("ksmi_bnrelu_bwd_apply", lambda: (gout, out.t.data_ptr(), z_act.t.data_ptr(), sv2.mean, sv2.rstd,
+                                                           P("bn2.weight"), s2p, dz.data_ptr(), float(npix), npix, Cc, dt))
+            a_c2b = self._acc_param(f"{name}.conv2.bias")
+            self.bwd.add("ksmi_channel_sum", lambda: (dz.data_ptr(), self.scr("red"), rows, npix, Cc, dt))
+            self.bwd.add("ksmi_reduce_rows", lambda: (self.scr("red"), rows, 1, Cc, Cc, None, None, G("conv2.bias"), a_c2b))
+            # dgrad of conv2 with fused ReLU mask + BN1-backward statistics in the epilogue
+            dg2, tg2 = make_conv([SrcSpec(dz, Cc)], [(r, Cc, 0, 0, Cc, 0)], dz, None, None, B, H, W, H, W, 3, 3, 1, 1, Cc, dtype,
+                                 mask=(i_act.t, sv1.t[0], sv1.t[1], sv1.t[2], sv1.t[3]))
+            wg2 = self._packed(f"{name}.conv2.weight", tg2, 9, Cc, Cc, Cc * 9, 9, 0, 1, 1)
+            dg2.wpk = wg2.data_ptr()
+            rows_g = conv_grid_m(dg2)
+            self.need("stats", rows_g * 2 * Npad * 4)
+            self.patch(dg2, "stats", "stats")
+            self._conv(self.bwd, dg2)
+            a_bn1 = self._acc_param(f"{name}.bn1")
+            self.bwd.add("ksmi_reduce_rows", lambda: (self.scr("stats"), rows_g, 2, Npad, Cc, s1p, G("bn1.weight"), G("bn1.bias"), a_bn1))
+            # weight gradient of conv2: X = relu(bn1(i)) recomputed on load, dY = dz
+            dw2, ws2 = make_wgrad(src2, dz, Cc, 0, Cc, m._g(f"{name}.conv2.weight"), 9, Cc * 9, 1,
+                                  self._acc_param(f"{name}.conv2.weight"), B, H, W, H, W, 3, 3, 1, 1, dtype)
+            self._wgrad(dw2, ws2)
+            # di = g + BN1 backward (over r, in place); conv1 bias gradient
+            a_c1b = self._acc_param(f"{name}.conv1.bias")
+            self.bwd.add("ksmi_bn_bwd_apply_add", lambda: (r.data_ptr(), gout, i_act.t.data_ptr(), sv1.mean, sv1.rstd,
+                                                           P("bn1.weight"), s1p, self.scr("red"), rows, float(npix), npix, Cc, dt))
+            self.bwd.add("ksmi_reduce_rows", lambda: (self.scr("red"), rows, 1, Cc, Cc, None, None, G("conv1.bias"), a_c1b))
+            a_w1 = self._acc_param(f"{name}.conv1.weight")
+            if first:
+                x_img = sources[0]
+                cin = x_img.shape[1]
+                wsz = self.lib.ksmi_conv_first_wgrad_workspace(B, cin, H, W, Cc)
+                self.need("wgrad", wsz)
+                self.bwd.add("ksmi_conv_first_wgrad", lambda: (x_img.data_ptr(), r.data_ptr(), G("conv1.weight"), self.scr("wgrad"),
+                                                               wsz, B, cin, H, W, Cc, a_w1, dt))
+            else:
+                srcs = [SrcSpec(a.t, a.C) for a in sources]
+                dsts, nb = [], 0
+                for a in sources:       # one pass over di, GEMM columns split across the concat sources
+                    dsts.append((a.grad(), a.C, 0, nb, a.C, a.take_acc_flag()))
+                    nb += a.C
+                dg1, tg1 = make_conv([SrcSpec(r, Cc)], dsts, r, None, None, B, H, W, H, W, 3, 3, 1, 1, Ktot, dtype)
+                wg1 = self._packed(f"{name}.conv1.weight", tg1, 9, Ktot, Ktot, Ktot * 9, 9, 0, 1, 1)
+                dg1.wpk = wg1.data_ptr()
+                self._conv(self.bwd, dg1)
+                dw1, ws1 = make_wgrad(srcs, r, Cc, 0, Cc, m._g(f"{name}.conv1.weight"), 9, Ktot * 9, 1, a_w1,
+                                      B, H, W, H, W, 3, 3, 1, 1, dtype)
+                self._wgrad(dw1, ws1)
+        self.bwd_builders.append(build_bwd)
+        return out
+
+    # ---------------------------------------------------------------- ECAM head  (snunet.py:49-62,146-151)
+    def _head(self, xs):
+        m, B, n = self.m, self.B, self.n
+        HW = self.H * self.W
+        dev, dt = self.dev, self.dt
+        f32 = dict(dtype=torch.float32, device=dev)
+        avg, mx = torch.zeros((B, 5 * n), **f32), torch.zeros((B, 5 * n), **f32)
+        argmax = torch.zeros((B, 5 * n), dtype=torch.int32, device=dev)
+        ca, ca1 = torch.zeros((B, 4 * n), **f32), torch.zeros((B, n), **f32)
+        hidden = torch.zeros((B, 2, 4 * n // 16 + n // 4), **f32)
+        xarr = (C.c_void_p * 4)(*[a.t.data_ptr() for a in xs])
+        ws_pool = torch.empty(self.lib.ksmi_ecam_pool_workspace(B, HW, n), dtype=torch.uint8, device=dev)
+        self.keep += [avg, mx, argmax, ca, ca1, hidden, xarr, ws_pool]
+        self.head = dict(avg=avg, mx=mx, argmax=argmax, ca=ca, ca1=ca1)
+        P = lambda key: m._p(key).data_ptr()
+        G = lambda key: m._g(key).data_ptr()
+        self.fwd.add("ksmi_ecam_pool", lambda: (xarr, avg.data_ptr(), mx.data_ptr(), argmax.data_ptr(), ws_pool.data_ptr(), B, HW, n, dt))
+        self.fwd.add("ksmi_ecam_mlp", lambda: (avg.data_ptr(), mx.data_ptr(), P("ca.fc1.weight"), P("ca.fc2.weight"),
+                                               P("ca1.fc1.weight"), P("ca1.fc2.weight"), ca.data_ptr(), ca1.data_ptr(),
+                                               hidden.data_ptr(), B, n))
+        self.fwd.add("ksmi_ecam_final_forward", lambda: (xarr, ca.data_ptr(), ca1.data_ptr(), P("conv_final.weight"),
+                                                         P("conv_final.bias"), self.logits.data_ptr(), B, HW, n, 3, dt))
+
+        def build_bwd():
+            dca, dca1 = torch.zeros((B, 4 * n), **f32), torch.zeros((B, n), **f32)
+            davg, dmax = torch.zeros((B, 5 * n), **f32), torch.zeros((B, 5 * n), **f32)
+            ws_b = torch.empty(self.lib.ksmi_ecam_bwd_workspace(B, HW, n, 3), dtype=torch.uint8, device=dev)
+            ws_m = torch.empty(self.lib.ksmi_ecam_mlp_bwd_workspace(B, n), dtype=torch.uint8, device=dev)
+            garr = (C.c_void_p * 4)(*[a.grad().data_ptr() for a in xs])
+            for a in xs:
+                a.take_acc_flag()
+            for key in ("conv_final.weight", "conv_final.bias", "ca.fc1.weight", "ca.fc2.weight", "ca1.fc1.weight", "ca1.fc2.weight"):
+                self._acc_param(key)
+            self.keep += [dca, dca1, davg, dmax, ws_b, ws_m, garr]
+            dl = self.dlogits.data_ptr()
+            self.bwd.add("ksmi_ecam_final_backward_reduce", lambda: (
+                xarr, dl, ca.data_ptr(), ca1.data_ptr(), P("conv_final.weight"), dca.data_ptr(), dca1.data_ptr(),
+                G("conv_final.weight"), G("conv_final.bias"), ws_b.data_ptr(), B, HW, n, 3, dt))
+            self.bwd.add("ksmi_ecam_mlp_backward", lambda: (
+                avg.data_ptr(), mx.data_ptr(), hidden.data_ptr(), ca.data_ptr(), ca1.data_ptr(), dca.data_ptr(), dca1.data_ptr(),
+                P("ca.fc1.weight"), P("ca.fc2.weight"), P("ca1.fc1.weight"), P("ca1.fc2.weight"), davg.data_ptr(), dmax.data_ptr(),
+                G("ca.fc1.weight"), G("ca.fc2.weight"), G("ca1.fc1.weight"), G("ca1.fc2.weight"), ws_m.data_ptr(), B, n))
+            self.bwd.add("ksmi_ecam_final_backward_dx", lambda: (
+                garr, dl, ca.data_ptr(), P("conv_final.weight"), davg.data_ptr(), dmax.data_ptr(), argmax.data_ptr(), B, HW, n, 3, dt))
+        self.bwd_builders.append(build_bwd)
+
+    # ---------------------------------------------------------------- execution
+    def run_forward(self, xA, xB):
+        if xA.data_ptr() != self.xA.data_ptr():
+            self.xA.copy_(xA)
+        if xB.data_ptr() != self.xB.data_ptr():
+            self.xB.copy_(xB)
+        self.packs.run()
+        self.fwd.run()
+        return self.logits
+
+    def run_backward(self, dlogits=None):
+        if not self.with_backward:
+            raise _lib.KsmiError("plan was built without backward")
+        if dlogits is not None and dlogits.data_ptr() != self.dlogits.data_ptr():
+            self.dlogits.copy_(dlogits)
+        self.bwd.run()

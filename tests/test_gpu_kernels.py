@@ -1,0 +1,188 @@
+"""GPU parity tests of the individual HIP kernels (through the C-ABI) against the CPU oracle
+/ stock torch-CPU fp32 ops on the same seeded inputs."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import loss_ref, metrics_ref
+from oracle.seeded import seeded_labels, seeded_tensor
+
+CLASS_WEIGHTS = [0.3715753140309927, 14.009780283125977, 8.20405370357821]
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from kurosiwo_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def _tol(dtype):
+    return 2e-5 if dtype == torch.float32 else 2.5e-2
+
+
+# ------------------------------------------------------------------ MFMA conventions
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_selftest_mma(dev, dtype):
+    from kurosiwo_amd import _lib
+    from kurosiwo_amd.runtime import DT, stream_ptr
+    kc = 32 if dtype == torch.bfloat16 else 16
+    a = seeded_tensor("mma.a", (16, kc)).to(dtype)
+    b = seeded_tensor("mma.b", (16, kc)).to(dtype)       # asymmetric B (guide §3)
+    c = torch.zeros((16, 16), dtype=torch.float32, device=dev)
+    ad, bd = a.to(dev), b.to(dev)
+    _lib.check(_lib.load().ksmi_selftest_mma(ad.data_ptr(), bd.data_ptr(), c.data_ptr(), DT[dtype], stream_ptr()))
+    ref = a.float() @ b.float().t()
+    assert (c.cpu() - ref).abs().max() < 1e-4 * ref.abs().max()
+
+
+def test_selftest_tr16(dev):
+    from kurosiwo_amd import _lib
+    from kurosiwo_amd.runtime import stream_ptr
+    inp = torch.arange(256, dtype=torch.int16, device=dev)
+    out = torch.zeros(256, dtype=torch.int16, device=dev)
+    _lib.check(_lib.load().ksmi_selftest_tr16(inp.data_ptr(), out.data_ptr(), stream_ptr()))
+    got = out.cpu().numpy().reshape(64, 4)
+    lane = np.arange(64)[:, None]
+    j = np.arange(4)[None, :]
+    exp = (lane & 15) + j * 16 + (lane >> 4) * 64
+    assert (got == exp).all(), got[:20]
+
+
+# ------------------------------------------------------------------ loss / metrics / optimiser
+@pytest.mark.parametrize("shape,scale,pinv", [((1, 3, 2, 2), 1.0, 0.25), ((2, 3, 16, 16), 2.0, 0.05), ((3, 3, 224, 224), 4.0, 0.3)])
+@pytest.mark.parametrize("with_dice", [True, False])
+def test_loss_forward_backward(dev, shape, scale, pinv, with_dice):
+    from kurosiwo_amd.loss import BCEandDiceLoss, CrossEntropyLoss
+    x = seeded_tensor("kl.logits" + str(shape), shape) * scale
+    t = seeded_labels("kl.labels" + str(shape), (shape[0],) + shape[2:], p_invalid=pinv)
+    t[0, 0, 0] = 1
+    crit = BCEandDiceLoss(CLASS_WEIGHTS, 3, True) if with_dice else CrossEntropyLoss(CLASS_WEIGHTS, 3)
+    xd = x.to(dev).requires_grad_(True)
+    loss = crit(xd, t.to(dev))
+    (2.5 * loss).backward()
+    r = loss_ref.ce_dice_forward(x.numpy(), t.numpy(), CLASS_WEIGHTS, with_dice=with_dice, with_grad=True)
+    assert abs(float(loss) - r["total"]) < 2e-5 * max(1.0, abs(r["total"]))
+    g = xd.grad.cpu().numpy() / 2.5
+    assert np.abs(g - r["grad"]).max() < 2e-5 * np.abs(r["grad"]).max() + 1e-9
+
+
+def test_loss_golden_kat(dev, golden_dir):
+    import os
+    from kurosiwo_amd.loss import BCEandDiceLoss
+    gold = np.load(os.path.join(golden_dir, "loss_cases.npz"))
+    x = torch.tensor([[[[1, -.5], [.25, 2]], [[0, .5], [-1, .5]], [[-1, 1.5], [.75, -2]]]], dtype=torch.float32)
+    t = torch.tensor([[[0, 2], [3, 1]]], dtype=torch.int64)
+    xd = x.to(dev).requires_grad_(True)
+    crit = BCEandDiceLoss([1.0, 1.0, 1.0], 3, True)
+    loss = crit(xd, t.to(dev))
+    loss.backward()
+    assert abs(float(loss) - float(gold["kat.unit.total"])) < 2e-6
+    assert np.abs(xd.grad.cpu().numpy() - gold["kat.unit.grad"]).max() < 2e-7
+
+
+def test_argmax_confusion(dev):
+    from kurosiwo_amd.metrics import ConfusionMetrics
+    x = seeded_tensor("cm.logits", (3, 3, 64, 48))
+    x[0, :, :4, :4] = 0.5                      # ties -> lowest index
+    t = seeded_labels("cm.labels", (3, 64, 48), p_invalid=0.2)
+    cmx = ConfusionMetrics(dev)
+    pred = cmx.update(x.to(dev), t.to(dev), return_predictions=True)
+    cmx.update(x.to(dev), t.to(dev))
+    ref_pred = metrics_ref.argmax_lowest_index(x.numpy())
+    assert (pred.cpu().numpy() == ref_pred).all()
+    ref_cm = metrics_ref.confusion_matrix(ref_pred, t.numpy())
+    assert (cmx.cm.cpu().numpy() == 2 * ref_cm).all()
+    got, ref = cmx.compute(), metrics_ref.metrics_from_cm(2 * ref_cm)
+    for k in ("accuracy", "precision", "recall", "f1", "iou"):
+        assert np.abs(got[k].numpy() - ref[k]).max() < 1e-12
+    assert abs(float(got["miou"]) - ref["miou"]) < 1e-12
+
+
+# ------------------------------------------------------------------ convolution family
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cfg", [
+    dict(B=2, H=32, W=32, cs=[32], N=32),
+    dict(B=1, H=48, W=32, cs=[32, 32, 64], N=32),
+    dict(B=2, H=16, W=16, cs=[64, 64, 128], N=64),
+    dict(B=3, H=8, W=8, cs=[16, 8], N=24),
+    dict(B=2, H=2, W=2, cs=[256], N=256),
+    dict(B=1, H=14, W=14, cs=[128], N=128),
+])
+def test_conv3x3_forward_dgrad_wgrad(dev, dtype, cfg):
+    from kurosiwo_amd import functional as Fk
+    B, H, W, cs, N = cfg["B"], cfg["H"], cfg["W"], cfg["cs"], cfg["N"]
+    tag = f"conv{B}{H}{W}{cs}{N}"
+    xs = [seeded_tensor(f"{tag}.x{i}", (B, c, H, W)) for i, c in enumerate(cs)]
+    K = sum(cs)
+    w = seeded_tensor(tag + ".w", (N, K, 3, 3)) * (2.0 / (K * 9)) ** 0.5
+    bias = seeded_tensor(tag + ".b", (N,)) * 0.1
+    dy = seeded_tensor(tag + ".dy", (B, N, H, W))
+    q = (lambda t: t.to(dtype).float())          # quantise the operands the way the kernel sees them
+    xq = [q(x) for x in xs]
+    wq, dyq = q(w), q(dy)
+    xc = torch.cat(xq, 1).requires_grad_(True)
+    wr = wq.clone().requires_grad_(True)
+    y_ref = F.conv2d(xc, wr, bias, padding=1)
+    y_ref.backward(dyq)
+    xd = [Fk.to_nhwc(x.to(dev), dtype) for x in xs]
+    y, stats = Fk.conv3x3(xd, w.to(dev), bias.to(dev), want_stats=True)
+    tol = _tol(dtype)
+    yn = Fk.to_nchw(y).cpu()
+    assert (yn - y_ref.detach()).abs().max() < tol * y_ref.abs().max()
+    s = stats.sum(0).cpu()
+    assert (s[0, :N] - y_ref.detach().sum((0, 2, 3))).abs().max() < 1e-3 * max(1.0, float(y_ref.abs().sum((0, 2, 3)).max()))
+    assert (s[1, :N] - (y_ref.detach() ** 2).sum((0, 2, 3))).abs().max() < 1e-3 * float((y_ref.detach() ** 2).sum((0, 2, 3)).max())
+    dyd = Fk.to_nhwc(dy.to(dev), dtype)
+    dxs = Fk.conv3x3_dgrad(dyd, w.to(dev), cs)
+    dx = torch.cat([Fk.to_nchw(t).cpu() for t in dxs], 1)
+    assert (dx - xc.grad).abs().max() < tol * xc.grad.abs().max()
+    dw = Fk.conv3x3_wgrad(xd, dyd).cpu()
+    assert (dw - wr.grad).abs().max() < tol * wr.grad.abs().max()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv3x3_fused_affine_relu_operand(dev, dtype):
+    from kurosiwo_amd import functional as Fk
+    B, H, W, Cc, N = 2, 24, 40, 32, 32
+    x = seeded_tensor("aff.x", (B, Cc, H, W))
+    w = seeded_tensor("aff.w", (N, Cc, 3, 3)) * 0.1
+    sc, sh = 1.0 + 0.3 * seeded_tensor("aff.sc", (Cc,)), 0.2 * seeded_tensor("aff.sh", (Cc,))
+    dy = seeded_tensor("aff.dy", (B, N, H, W))
+    q = (lambda t: t.to(dtype).float())
+    xa = q(torch.relu(q(x) * sc[None, :, None, None] + sh[None, :, None, None]))
+    wr = q(w).requires_grad_(True)
+    y_ref = F.conv2d(xa, wr, None, padding=1)       # zero padding applies AFTER the affine+relu
+    y_ref.backward(q(dy))
+    xd = Fk.to_nhwc(x.to(dev), dtype)
+    aff = (sc.to(dev), sh.to(dev), 1)
+    y, _ = Fk.conv3x3([xd], w.to(dev), None, affine=aff)
+    assert (Fk.to_nchw(y).cpu() - y_ref.detach()).abs().max() < _tol(dtype) * y_ref.abs().max()
+    dw = Fk.conv3x3_wgrad([xd], Fk.to_nhwc(dy.to(dev), dtype), affine=aff).cpu()
+    assert (dw - wr.grad).abs().max() < _tol(dtype) * wr.grad.abs().max()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 16, 16, 64), (1, 7, 5, 32), (2, 1, 1, 256)])
+def test_deconv2x2(dev, dtype, shape):
+    from kurosiwo_amd import functional as Fk
+    B, H, W, Cc = shape
+    x = seeded_tensor("dc.x" + str(shape), (B, Cc, H, W))
+    w = seeded_tensor("dc.w" + str(shape), (Cc, Cc, 2, 2)) * (1.0 / Cc) ** 0.5
+    b = seeded_tensor("dc.b" + str(shape), (Cc,)) * 0.1
+    dy = seeded_tensor("dc.dy" + str(shape), (B, Cc, 2 * H, 2 * W))
+    q = (lambda t: t.to(dtype).float())
+    xr, wr = q(x).requires_grad_(True), q(w).requires_grad_(True)
+    y_ref = F.conv_transpose2d(xr, wr, b, stride=2)
+    y_ref.backward(q(dy))
+    xd = Fk.to_nhwc(x.to(dev), dtype)
+    y = Fk.deconv2x2(xd, w.to(dev), b.to(dev))
+    tol = _tol(dtype)
+    assert (Fk.to_nchw(y).cpu() - y_ref.detach()).abs().max() < tol * y_ref.abs().max()
+    dx, dw = Fk.deconv2x2_backward(xd, Fk.to_nhwc(dy.to(dev), dtype), w.to(dev))
+    assert (Fk.to_nchw(dx).cpu() - xr.grad).abs().max() < tol * xr.grad.abs().max()
+    assert (dw.cpu() - wr.grad).abs().max() < tol * wr.grad.abs().max()

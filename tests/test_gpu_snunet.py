@@ -1,0 +1,157 @@
+"""GPU parity of the whole SNUNet-ECAM train step (HIP kernels through the C-ABI) against the
+CPU oracle, plus the committed golden vectors of the real reference at full size."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import snunet_ref as R
+from oracle.seeded import seeded_fill_, seeded_labels, seeded_tensor
+
+CLASS_WEIGHTS = [0.3715753140309927, 14.009780283125977, 8.20405370357821]
+
+
+def sar_like(name, shape):
+    return seeded_tensor(name, shape).clamp_(-2.23, 5.75)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _model(c, bc, precision, sd, dev):
+    from kurosiwo_amd.snunet import SNUNet_ECAM
+    m = SNUNet_ECAM(c, 3, base_channel=bc, precision=precision)
+    m.load_state_dict({k: v.clone() for k, v in sd.items()})
+    return m.to(dev)
+
+
+@pytest.mark.parametrize("c,bc,B,H,W", [(2, 16, 2, 32, 32), (3, 16, 1, 48, 32), (2, 32, 2, 64, 64)])
+def test_fp32_eval_logits(dev, c, bc, B, H, W):
+    tag = f"ev{c}{bc}{B}{H}{W}"
+    xA, xB = sar_like(tag + "A", (B, c, H, W)), sar_like(tag + "B", (B, c, H, W))
+    sd = seeded_fill_(R.new_state_dict(c, 3, bc))
+    with torch.no_grad():
+        ref = R.snunet_forward(sd, xA, xB, training=False)
+    m = _model(c, bc, "fp32", sd, dev).eval()
+    with torch.no_grad():
+        out = m(xA.to(dev), xB.to(dev)).cpu()
+    rel = float((out - ref).abs().max() / ref.abs().max())
+    assert rel < 1e-3, rel           # north-star: 1e-3 rel on logits (measured ~1e-6)
+    assert rel < 5e-5, rel
+
+
+@pytest.mark.parametrize("c,bc,B,H,W", [(2, 16, 2, 32, 32), (3, 16, 2, 32, 48)])
+def test_fp32_train_step_matches_oracle(dev, c, bc, B, H, W):
+    from kurosiwo_amd.loss import BCEandDiceLoss
+    from kurosiwo_amd.optim import FusedAdam
+    tag = f"tr{c}{bc}{B}{H}{W}"
+    xA, xB = sar_like(tag + "A", (B, c, H, W)), sar_like(tag + "B", (B, c, H, W))
+    lbl = seeded_labels(tag + "L", (B, H, W))
+    sd = seeded_fill_(R.new_state_dict(c, 3, bc))
+    m = _model(c, bc, "fp32", sd, dev).train()
+    crit = BCEandDiceLoss(CLASS_WEIGHTS, 3, True)
+    opt = FusedAdam(m.parameters(), lr=1e-3)
+    ref_opt = R.AdamRef(sd, lr=1e-3)
+    for step in range(3):
+        opt.zero_grad()
+        logits = m(xA.to(dev), xB.to(dev))
+        loss = crit(logits, lbl.to(dev))
+        loss.backward()
+        grads = {k: p.grad.detach().cpu().clone() for k, p in m.named_parameters()}
+        opt.step()
+        ref_loss, ref_logits, ref_grads = R.train_step(sd, ref_opt, xA, xB, lbl, CLASS_WEIGHTS, True)
+        tol = 1e-4 * (10 ** step)        # trajectories drift apart slowly
+        assert float((logits.detach().cpu() - ref_logits).abs().max() / ref_logits.abs().max()) < tol
+        assert abs(float(loss) - ref_loss) < tol * max(1.0, abs(ref_loss))
+        if step == 0:
+            worst = 0.0
+            for k, g in ref_grads.items():
+                denom = float(g.abs().max())
+                err = float((grads[k] - g).abs().max())
+                if denom > 1e-6:
+                    worst = max(worst, err / denom)
+                    assert err < 2e-3 * denom + 1e-6, (k, err, denom)
+                else:
+                    assert err < 1e-5, (k, err)
+            print("worst relative grad error", worst)
+            msd = m.state_dict()
+            for k in sd:
+                if k.endswith(("running_mean", "running_var")):
+                    assert (msd[k].cpu() - sd[k]).abs().max() < 1e-4, k
+                if k.endswith("num_batches_tracked"):
+                    assert int(msd[k]) == int(sd[k]), k
+    msd = m.state_dict()
+    for k in R.param_keys(sd):
+        assert (msd[k].cpu() - sd[k]).abs().max() < 2e-3 * max(1e-2, float(sd[k].abs().max())), k
+
+
+def test_fp32_full_size_golden(dev, golden_dir):
+    """224x224 tile, base_channel 32: logits + argmax mask of the REAL reference (golden file)."""
+    gold = np.load(os.path.join(golden_dir, "snunet_full.npz"))
+    xA, xB = sar_like("full.xA", (1, 2, 224, 224)), sar_like("full.xB", (1, 2, 224, 224))
+    sd = seeded_fill_(R.new_state_dict(2, 3, 32))
+    m = _model(2, 32, "fp32", sd, dev).eval()
+    with torch.no_grad():
+        logits = m(xA.to(dev), xB.to(dev)).cpu()
+    scale = float(gold["eval_logits_absmax"])
+    rel = float(np.abs(logits[:, :, ::8, ::8].numpy() - gold["eval_logits_sub"]).max() / scale)
+    assert rel < 1e-3, rel
+    am = logits.argmax(1).numpy().astype(np.uint8)
+    margin = gold["eval_margin"].astype(np.float32)
+    decisive = margin > 1e-3 * scale
+    mism = int((am != gold["eval_argmax"]).sum())
+    assert (am[decisive] == gold["eval_argmax"][decisive]).all()
+    print(f"full-size: logits rel err {rel:.2e}; argmax mismatches {mism} of {am.size} (all inside the {1e-3 * scale:.1e} margin)")
+
+
+def test_fp32_full_size_train_golden(dev, golden_dir):
+    from kurosiwo_amd.loss import BCEandDiceLoss
+    gold = np.load(os.path.join(golden_dir, "snunet_full.npz"))
+    xA, xB = sar_like("full.train.xA", (2, 2, 224, 224)), sar_like("full.train.xB", (2, 2, 224, 224))
+    lbl = seeded_labels("full.train.lbl", (2, 224, 224))
+    sd = seeded_fill_(R.new_state_dict(2, 3, 32))
+    m = _model(2, 32, "fp32", sd, dev).train()
+    logits = m(xA.to(dev), xB.to(dev))
+    loss = BCEandDiceLoss([1.0, 1.0, 1.0], 3, True)(logits, lbl.to(dev))
+    loss.backward()
+    ref = gold["train_logits_sub"]
+    assert np.abs(logits.detach().cpu()[:, :, ::8, ::8].numpy() - ref).max() < 1e-3 * np.abs(ref).max()
+    assert abs(float(loss) - float(gold["train_loss"])) < 1e-4 * float(gold["train_loss"])
+    for k, p in m.named_parameters():
+        st = gold[f"gstat.{k}"]
+        nrm = float(p.grad.double().norm())
+        assert abs(nrm - st[0]) < 5e-3 * st[0] + 1e-6, (k, nrm, st[0])
+    for k in ("conv0_0.conv1.weight", "conv_final.weight", "ca.fc1.weight", "ca1.fc2.weight", "Up1_3.up.bias"):
+        g = dict(m.named_parameters())[k].grad.cpu().numpy()
+        assert np.abs(g - gold[f"grad.{k}"]).max() < 5e-3 * np.abs(gold[f"grad.{k}"]).max() + 1e-7, k
+
+
+@pytest.mark.parametrize("c,bc,B,H,W", [(2, 32, 2, 64, 64)])
+def test_bf16_train_step_close_to_oracle(dev, c, bc, B, H, W):
+    from kurosiwo_amd.loss import BCEandDiceLoss
+    tag = f"bf{c}{bc}{B}{H}{W}"
+    xA, xB = sar_like(tag + "A", (B, c, H, W)), sar_like(tag + "B", (B, c, H, W))
+    lbl = seeded_labels(tag + "L", (B, H, W))
+    sd = seeded_fill_(R.new_state_dict(c, 3, bc))
+    m = _model(c, bc, "bf16", sd, dev).train()
+    logits = m(xA.to(dev), xB.to(dev))
+    loss = BCEandDiceLoss(CLASS_WEIGHTS, 3, True)(logits, lbl.to(dev))
+    loss.backward()
+    ref_opt = R.AdamRef(sd, lr=0.0)
+    ref_loss, ref_logits, ref_grads = R.train_step(sd, ref_opt, xA, xB, lbl, CLASS_WEIGHTS, True)
+    rel = float((logits.detach().cpu() - ref_logits).abs().max() / ref_logits.abs().max())
+    assert rel < 0.1, rel
+    assert abs(float(loss) - ref_loss) < 0.05 * abs(ref_loss)
+    cos = []
+    for k, p in m.named_parameters():
+        g, r = p.grad.cpu().flatten().double(), ref_grads[k].flatten().double()
+        if float(r.norm()) > 1e-6:
+            cos.append(float((g @ r) / (g.norm() * r.norm() + 1e-30)))
+    assert np.median(cos) > 0.98, np.median(cos)
+    print(f"bf16: logits rel err {rel:.3e}, median grad cosine {np.median(cos):.4f}, min {min(cos):.4f}")
