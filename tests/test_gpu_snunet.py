@@ -74,11 +74,16 @@ def test_fp32_train_step_matches_oracle(dev, c, bc, B, H, W):
             for k, g in ref_grads.items():
                 denom = float(g.abs().max())
                 err = float((grads[k] - g).abs().max())
-                if denom > 1e-6:
-                    worst = max(worst, err / denom)
-                    assert err < 2e-3 * denom + 1e-6, (k, err, denom)
-                else:
-                    assert err < 1e-5, (k, err)
+                if k.endswith("conv2.bias") or denom <= 1e-6:
+                    # conv2 is followed by train-mode BatchNorm: its bias gradient is analytically 0 and
+                    # both sides only hold rounding noise (reference ~1e-6, HIP ~1e-8)
+                    assert err < 2e-5, (k, err)
+                    continue
+                worst = max(worst, err / denom)
+                # a single ReLU-mask flip at |pre-activation| ~ 1e-7 moves a per-channel sum over only
+                # B*H*W = 2k pixels by ~0.5 %: vectors get 1e-2, weight tensors 2e-3
+                rtol = 2e-3 if g.dim() == 4 else 1e-2
+                assert err < rtol * denom + 1e-6, (k, err, denom)
             print("worst relative grad error", worst)
             msd = m.state_dict()
             for k in sd:
@@ -88,6 +93,8 @@ def test_fp32_train_step_matches_oracle(dev, c, bc, B, H, W):
                     assert int(msd[k]) == int(sd[k]), k
     msd = m.state_dict()
     for k in R.param_keys(sd):
+        if k.endswith("conv2.bias"):
+            continue     # zero-gradient parameter: Adam turns rounding noise into +-lr steps on BOTH sides
         assert (msd[k].cpu() - sd[k]).abs().max() < 2e-3 * max(1e-2, float(sd[k].abs().max())), k
 
 
@@ -126,6 +133,9 @@ def test_fp32_full_size_train_golden(dev, golden_dir):
     for k, p in m.named_parameters():
         st = gold[f"gstat.{k}"]
         nrm = float(p.grad.double().norm())
+        if k.endswith("conv2.bias"):
+            assert nrm < 1e-4 and st[0] < 1e-4, (k, nrm, st[0])      # analytically zero (BN follows)
+            continue
         assert abs(nrm - st[0]) < 5e-3 * st[0] + 1e-6, (k, nrm, st[0])
     for k in ("conv0_0.conv1.weight", "conv_final.weight", "ca.fc1.weight", "ca1.fc2.weight", "Up1_3.up.bias"):
         g = dict(m.named_parameters())[k].grad.cpu().numpy()
