@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""Headline benchmark: SAR tiles/sec of one SNUNet-ECAM change-detection TRAIN STEP
+(forward + CE+Dice loss + backward + Adam [+ gradient all-reduce]) on 224x224 tiles.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[1]): SNUNet-ECAM, 2 dates x 2-ch GRD (VV,VH) 224x224, per-GPU
+batch 32, bf16 activations / fp32 parameters+accumulation, synthetic tiles, random-init weights.
+Weak scaling: every rank processes its own 32 tiles per step; value = total tiles / max-over-ranks time.
+
+Prints ONE JSON line (rank 0) with the driver's contract plus `roofline` (dominant kernel class,
+HIP-event timed inside the timed region) and `cpu_baseline` (CPU oracle port on host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_BF16_PEAK_TF = 2500.0   # dense bf16
+
+
+class KernelTimer:
+    """HIP events around selected launches on the stream they are launched on (torch's current
+    stream == the stream handed to the C-ABI)."""
+
+    def __init__(self, kinds=None):
+        self.kinds = kinds          # None = every launch
+        self.rec = []               # (kind, meta, ev0, ev1)
+        self._cur = None
+
+    def wants(self, kind):
+        return self.kinds is None or kind in self.kinds
+
+    def begin(self, kind, meta=None):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        self._cur = (kind, meta or {"bytes": 0, "flops": 0}, e0)
+
+    def end(self):
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        self.rec.append(self._cur + (e1,))
+        self._cur = None
+
+    def summary(self):
+        out = {}
+        for kind, meta, e0, e1 in self.rec:
+            d = out.setdefault(kind, {"ms": 0.0, "n": 0, "bytes": 0, "flops": 0})
+            d["ms"] += e0.elapsed_time(e1)
+            d["n"] += 1
+            d["bytes"] += meta.get("bytes", 0)
+            d["flops"] += meta.get("flops", 0)
+        return out
+
+
+def cpu_baseline(budget_s=20.0):
+    """The CPU oracle (port of the reference's train step, pinned to it by tests/golden) on the
+    host cores: SNUNet-ECAM c=2 bc=32, bs=4, fp32, ce+dice, Adam; 1 warm-up + timed steps."""
+    from oracle import snunet_ref as R
+    from oracle.seeded import seeded_fill_
+    from kurosiwo_amd.synthetic import cd_inputs, make_batch
+    B = 4
+    batch = make_batch(B, seed=424242)
+    (xA, xB), mask = cd_inputs(batch)
+    sd = seeded_fill_(R.new_state_dict(2, 3, 32))
+    opt = R.AdamRef(sd, lr=1e-3)
+    R.train_step(sd, opt, xA, xB, mask)          # warm-up
+    t0, n = time.time(), 0
+    while True:
+        R.train_step(sd, opt, xA, xB, mask)
+        n += 1
+        if time.time() - t0 > budget_s or n >= 8:
+            break
+    dt = time.time() - t0
+    return {"value": round(B * n / dt, 3), "unit": "tiles/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} timed train steps of SNUNet-ECAM(2,3,32) bs={B} 224x224 fp32 ce+dice Adam (oracle/snunet_ref.py), {dt:.1f}s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--base-channel", type=int, default=32)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--time-all", action="store_true", help="HIP-event time every kernel class (diagnostic)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from kurosiwo_amd.snunet import SNUNet_ECAM
+    from kurosiwo_amd.synthetic import cd_inputs, make_batch
+    from kurosiwo_amd.trainer import CDTrainStep
+
+    B, H, W = args.batch, 224, 224
+    torch.manual_seed(999)                      # same init on every rank (reference default seed, main.py:36)
+    model = SNUNet_ECAM(2, 3, base_channel=args.base_channel, precision=args.precision).to(dev).train()
+    step = CDTrainStep(model, B, H, W, loss_function="ce+dice", lr=1e-3, bucket_mb=8.0)
+    batch = make_batch(B, H, W, seed=999 + rank)
+    (xA, xB), mask = cd_inputs(batch, ("pre_event_1", "post_event"))
+    xA, xB, mask = xA.to(dev), xB.to(dev), mask.to(dev)
+    step.set_batch(xA, xB, mask)                # inputs resident in HBM before the timed region
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- warm-up (first step also picks the dominant kernel class with every launch timed) ------
+    calib = KernelTimer(None)
+    step.timer = calib
+    step.run()
+    torch.cuda.synchronize()
+    cs = calib.summary()
+    dominant = max((k for k in cs if k.startswith("igemm")), key=lambda k: cs[k]["ms"])
+    step.timer = None
+    for _ in range(max(args.warmup - 1, 0)):
+        step.run()
+    # ---- timed region ----------------------------------------------------------------------------
+    timer = KernelTimer(None if args.time_all else {dominant})
+    step.timer = timer
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step.run()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax)
+    loss = step.loss_out.cpu().tolist()
+
+    if rank == 0:
+        ts = timer.summary()
+        d = ts[dominant]
+        avg_ms = d["ms"] / d["n"]
+        ach_gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+        ach_tf = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        step_flops = sum(c[3]["flops"] for c in step.plan.fwd.calls + step.plan.bwd.calls)
+        step_bytes = sum(c[3]["bytes"] for c in step.plan.fwd.calls + step.plan.bwd.calls)
+        res = {
+            "metric": "SAR tiles/sec (224x224, SNUNet-ECAM change-detection train step)",
+            "value": round(B * world * args.steps / dt, 2), "unit": "tiles/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1]: SNUNet-ECAM CD, 2 dates x 2-ch GRD 224x224, "
+                                   f"per-GPU batch {B}, ce+dice loss, Adam lr 1e-3, fwd+loss+bwd+optimizer"
+                                   + ("+RCCL all-reduce" if world > 1 else ""),
+                       "global_batch": B * world, "base_channel": args.base_channel, "parallelism": f"dp{world}",
+                       "loss_last": [round(x, 5) for x in loss]},
+            "roofline": {"kernel": dominant, "bound": "hbm", "achieved": round(ach_gbs, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(ach_gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                         "launches_timed": d["n"], "avg_launch_ms": round(avg_ms, 4),
+                         "share_of_step": round(d["ms"] / (dt * 1e3), 3),
+                         "tflops": round(ach_tf, 1), "mfma_frac": round(ach_tf / MFMA_BF16_PEAK_TF, 4),
+                         "step_algorithmic_GB": round(step_bytes / 1e9, 3), "step_GFLOP": round(step_flops / 1e9, 1),
+                         "step_hbm_frac": round(step_bytes / dt * args.steps / 1e9 / HBM_PEAK_GBS, 4),
+                         "step_mfma_frac": round(step_flops / dt * args.steps / 1e12 / MFMA_BF16_PEAK_TF, 4)},
+        }
+        if args.time_all:
+            tot = sum(v["ms"] for v in ts.values())
+            res["kernels"] = {k: {"ms_per_step": round(v["ms"] / args.steps, 3), "launches": v["n"] // args.steps,
+                                  "GBs": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1),
+                                  "TFs": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 1)}
+                              for k, v in sorted(ts.items(), key=lambda kv: -kv[1]["ms"])}
+            res["kernels_total_ms_per_step"] = round(tot / args.steps, 3)
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,51 @@
+"""Data parallelism for the flat gradient arena: one process per GPU,
+`torch.distributed` (backend "nccl" == RCCL over xGMI on ROCm; "gloo" for the CPU tests).
+
+The backward pass is a static launch list, so gradient readiness is known at plan-build time:
+the arena is cut into contiguous buckets and each bucket's all-reduce(SUM) is issued right after
+the last launch that writes into it.  ProcessGroupNCCL runs the collective on its own HIP stream
+(it waits on the launching stream's event), i.e. the reduction overlaps the remaining backward
+kernels; the optimiser waits for the handles and folds the 1/world average into its kernel.
+"""
+import torch
+import torch.distributed as dist
+
+
+def make_buckets(ready_index, offsets, numels, total, bucket_elems):
+    """ready_index[key] = index of the last backward launch writing parameter `key`.
+    Returns [(start, end, after_launch)] covering [0, total) in arena order."""
+    keys = sorted(offsets, key=lambda k: offsets[k])
+    buckets, start, after = [], 0, -1
+    for i, k in enumerate(keys):
+        after = max(after, ready_index.get(k, -1))
+        end = offsets[keys[i + 1]] if i + 1 < len(keys) else total
+        if end - start >= bucket_elems or i + 1 == len(keys):
+            buckets.append((start, end, after))
+            start, after = end, -1
+    return buckets
+
+
+class BucketedAllReduce:
+    def __init__(self, flat_grads, buckets, group=None):
+        self.flat, self.group = flat_grads, group
+        self.buckets = buckets
+        self.by_launch = {}
+        for b in buckets:
+            self.by_launch.setdefault(b[2], []).append(b)
+        self.handles = []
+        self.issued = []
+
+    def world(self):
+        return dist.get_world_size(self.group) if dist.is_initialized() else 1
+
+    def after_launch(self, idx):
+        for (s, e, _) in self.by_launch.get(idx, ()):
+            self.issued.append((s, e))
+            if self.world() > 1:
+                self.handles.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def wait(self):
+        for h in self.handles:
+            h.wait()
+        self.handles = []
+        self.issued = []

@@ -17,23 +17,31 @@ from .snunet import BN_EPS, BN_MOMENTUM
 
 
 class LaunchList:
-    """(name, argfn) pairs; argfn() is evaluated once, after all scratch buffers exist."""
+    """(name, argfn, meta) triples; argfn() is evaluated once, after all scratch buffers exist.
+    meta = {"kind": kernel class, "bytes": algorithmic HBM bytes, "flops": 2*MAC} for the roofline."""
 
     def __init__(self):
         self.pending, self.calls = [], []
 
-    def add(self, name, argfn):
-        self.pending.append((name, argfn))
+    def add(self, name, argfn, meta=None):
+        self.pending.append((name, argfn, meta or {"kind": name[5:], "bytes": 0, "flops": 0}))
 
     def resolve(self, lib):
-        self.calls = [(getattr(lib, name), tuple(argfn()), name) for name, argfn in self.pending]
+        self.calls = [(getattr(lib, name), tuple(argfn()), name, meta) for name, argfn, meta in self.pending]
 
-    def run(self):
+    def run(self, timer=None, hook=None):
         st = stream_ptr()
-        for fn, args, name in self.calls:
+        for idx, (fn, args, name, meta) in enumerate(self.calls):
+            timed = timer is not None and timer.wants(meta["kind"])
+            if timed:
+                timer.begin(meta["kind"], meta)
             rc = fn(*args, st)
+            if timed:
+                timer.end()
             if rc != 0:
                 _lib.check(rc, name)
+            if hook is not None:
+                hook(idx)
 
 
 class _Saved:
@@ -55,6 +63,7 @@ class SNUNetPlan:
         self.packs, self.fwd, self.bwd = LaunchList(), LaunchList(), LaunchList()
         self.keep = []
         self._pinit = set()
+        self.param_ready = {}      # parameter key -> index of the last backward launch writing its gradient
         self._need, self._bufs, self._later = {}, {}, []
         n, c = model.base_channel, model.in_channels
         self.n = n
@@ -129,15 +138,38 @@ class SNUNetPlan:
     def _rows(self, npix):
         return max(1, min(512, npix // 256))
 
-    def _conv(self, ll, d):
-        self.keep.append(d)
-        ll.add("ksmi_conv_forward", lambda: (C.byref(d), self.dt))
+    def _mark(self, *keys):
+        """the launch just appended to self.bwd is (so far) the last writer of these gradients"""
+        for k in keys:
+            self.param_ready[k] = len(self.bwd.pending) - 1
 
-    def _wgrad(self, d, ws):
+    def _es(self):
+        return 2 if self.dtype == torch.bfloat16 else 4
+
+    def _conv(self, ll, d, tag="fwd"):
+        self.keep.append(d)
+        taps, es = d.KH * d.KW, self._es()
+        ktot = sum(d.src[i].c_len for i in range(d.nsrc))
+        pin, pout = d.B * d.Hin * d.Win, d.B * d.Hout * d.Wout
+        elems = pin * ktot + sum(pout * d.dst[i].n_len * (2 if d.dst[i].accumulate else 1) for i in range(d.ndst))
+        if d.mask_src:
+            elems += pout * d.N
+        nt = 8 if d.Npad >= 128 else (4 if d.Npad >= 64 else (2 if d.Npad >= 32 else 1))
+        meta = {"kind": f"igemm_{tag}<{d.KH}x{d.KW}s{d.stride},BN{16 * nt}>", "bytes": elems * es + taps * ktot * d.N * es,
+                "flops": 2 * pout * d.N * ktot * taps}
+        ll.add("ksmi_conv_forward", lambda: (C.byref(d), self.dt), meta)
+
+    def _wgrad(self, d, ws, *keys):
         self.keep.append(d)
         self.need("wgrad", ws)
         self.patch(d, "partial", "wgrad")
-        self.bwd.add("ksmi_conv_wgrad", lambda: (C.byref(d), self.dt))
+        taps, es = d.KH * d.KW, self._es()
+        ktot = sum(d.src[i].c_len for i in range(d.nsrc))
+        pin, pout = d.B * d.Hin * d.Win, d.B * d.Hout * d.Wout
+        meta = {"kind": f"igemm_wgrad<{d.KH}x{d.KW}s{d.stride}>", "bytes": (pin * ktot + pout * d.N) * es + taps * ktot * d.N * 4,
+                "flops": 2 * pout * d.N * ktot * taps}
+        self.bwd.add("ksmi_conv_wgrad", lambda: (C.byref(d), self.dt), meta)
+        self._mark(*keys)
 
     # ---------------------------------------------------------------- nn.MaxPool2d(2,2)  (snunet.py:73)
     def _pool(self, x, name):
@@ -173,11 +205,11 @@ class SNUNetPlan:
                                B, 2 * H, 2 * W, H, W, 2, 2, 2, 0, Cc, self.dtype)
             w2 = self._packed(wkey, t2, 4, Cc, Cc, 4, Cc * 4, 0, 1, 0)
             d2.wpk = w2.data_ptr()
-            self._conv(self.bwd, d2)
+            self._conv(self.bwd, d2, "dgrad")
             # weight gradient: G[tap d][k = n][col = c] -> grad[c*(4C) + n*4 + d]
             dw, ws = make_wgrad(s2, x.t, Cc, 0, Cc, self.m._g(wkey), 4, Cc * 4, 1, self._acc_param(wkey),
                                 B, 2 * H, 2 * W, H, W, 2, 2, 2, 0, self.dtype)
-            self._wgrad(dw, ws)
+            self._wgrad(dw, ws, wkey)
             # bias gradient
             npix = B * 4 * H * W
             rows = self._rows(npix)
@@ -186,6 +218,7 @@ class SNUNetPlan:
             gb = self.m._g(bkey).data_ptr()
             self.bwd.add("ksmi_channel_sum", lambda: (gy.data_ptr(), self.scr("red"), rows, npix, Cc, self.dt))
             self.bwd.add("ksmi_reduce_rows", lambda: (self.scr("red"), rows, 1, Cc, Cc, None, None, gb, a_b))
+            self._mark(bkey)
         self.bwd_builders.append(build_bwd)
         return y
 
@@ -263,11 +296,13 @@ class SNUNetPlan:
             self.bwd.add("ksmi_bnrelu_bwd_reduce", lambda: (gout, out.t.data_ptr(), z_act.t.data_ptr(), sv2.mean, sv2.rstd,
                                                             self.scr("red"), rows, npix, Cc, dt))
             self.bwd.add("ksmi_reduce_rows", lambda: (self.scr("red"), rows, 2, Cc, Cc, s2p, G("bn2.weight"), G("bn2.bias"), a_bn2))
+            self._mark(f"{name}.bn2.weight", f"{name}.bn2.bias")
             self.bwd.add("ksmi_bnrelu_bwd_apply", lambda: (gout, out.t.data_ptr(), z_act.t.data_ptr(), sv2.mean, sv2.rstd,
                                                            P("bn2.weight"), s2p, dz.data_ptr(), float(npix), npix, Cc, dt))
             a_c2b = self._acc_param(f"{name}.conv2.bias")
             self.bwd.add("ksmi_channel_sum", lambda: (dz.data_ptr(), self.scr("red"), rows, npix, Cc, dt))
             self.bwd.add("ksmi_reduce_rows", lambda: (self.scr("red"), rows, 1, Cc, Cc, None, None, G("conv2.bias"), a_c2b))
+            self._mark(f"{name}.conv2.bias")
             # dgrad of conv2 with fused ReLU mask + BN1-backward statistics in the epilogue
             dg2, tg2 = make_conv([SrcSpec(dz, Cc)], [(r, Cc, 0, 0, Cc, 0)], dz, None, None, B, H, W, H, W, 3, 3, 1, 1, Cc, dtype,
                                  mask=(i_act.t, sv1.t[0], sv1.t[1], sv1.t[2], sv1.t[3]))
@@ -276,18 +311,20 @@ class SNUNetPlan:
             rows_g = conv_grid_m(dg2)
             self.need("stats", rows_g * 2 * Npad * 4)
             self.patch(dg2, "stats", "stats")
-            self._conv(self.bwd, dg2)
+            self._conv(self.bwd, dg2, "dgrad")
             a_bn1 = self._acc_param(f"{name}.bn1")
             self.bwd.add("ksmi_reduce_rows", lambda: (self.scr("stats"), rows_g, 2, Npad, Cc, s1p, G("bn1.weight"), G("bn1.bias"), a_bn1))
+            self._mark(f"{name}.bn1.weight", f"{name}.bn1.bias")
             # weight gradient of conv2: X = relu(bn1(i)) recomputed on load, dY = dz
             dw2, ws2 = make_wgrad(src2, dz, Cc, 0, Cc, m._g(f"{name}.conv2.weight"), 9, Cc * 9, 1,
                                   self._acc_param(f"{name}.conv2.weight"), B, H, W, H, W, 3, 3, 1, 1, dtype)
-            self._wgrad(dw2, ws2)
+            self._wgrad(dw2, ws2, f"{name}.conv2.weight")
             # di = g + BN1 backward (over r, in place); conv1 bias gradient
             a_c1b = self._acc_param(f"{name}.conv1.bias")
             self.bwd.add("ksmi_bn_bwd_apply_add", lambda: (r.data_ptr(), gout, i_act.t.data_ptr(), sv1.mean, sv1.rstd,
                                                            P("bn1.weight"), s1p, self.scr("red"), rows, float(npix), npix, Cc, dt))
             self.bwd.add("ksmi_reduce_rows", lambda: (self.scr("red"), rows, 1, Cc, Cc, None, None, G("conv1.bias"), a_c1b))
+            self._mark(f"{name}.conv1.bias")
             a_w1 = self._acc_param(f"{name}.conv1.weight")
             if first:
                 x_img = sources[0]
@@ -296,6 +333,7 @@ class SNUNetPlan:
                 self.need("wgrad", wsz)
                 self.bwd.add("ksmi_conv_first_wgrad", lambda: (x_img.data_ptr(), r.data_ptr(), G("conv1.weight"), self.scr("wgrad"),
                                                                wsz, B, cin, H, W, Cc, a_w1, dt))
+                self._mark(f"{name}.conv1.weight")
             else:
                 srcs = [SrcSpec(a.t, a.C) for a in sources]
                 dsts, nb = [], 0
@@ -305,10 +343,10 @@ class SNUNetPlan:
                 dg1, tg1 = make_conv([SrcSpec(r, Cc)], dsts, r, None, None, B, H, W, H, W, 3, 3, 1, 1, Ktot, dtype)
                 wg1 = self._packed(f"{name}.conv1.weight", tg1, 9, Ktot, Ktot, Ktot * 9, 9, 0, 1, 1)
                 dg1.wpk = wg1.data_ptr()
-                self._conv(self.bwd, dg1)
+                self._conv(self.bwd, dg1, "dgrad")
                 dw1, ws1 = make_wgrad(srcs, r, Cc, 0, Cc, m._g(f"{name}.conv1.weight"), 9, Ktot * 9, 1, a_w1,
                                       B, H, W, H, W, 3, 3, 1, 1, dtype)
-                self._wgrad(dw1, ws1)
+                self._wgrad(dw1, ws1, f"{name}.conv1.weight")
         self.bwd_builders.append(build_bwd)
         return out
 
@@ -350,10 +388,12 @@ class SNUNetPlan:
             self.bwd.add("ksmi_ecam_final_backward_reduce", lambda: (
                 xarr, dl, ca.data_ptr(), ca1.data_ptr(), P("conv_final.weight"), dca.data_ptr(), dca1.data_ptr(),
                 G("conv_final.weight"), G("conv_final.bias"), ws_b.data_ptr(), B, HW, n, 3, dt))
+            self._mark("conv_final.weight", "conv_final.bias")
             self.bwd.add("ksmi_ecam_mlp_backward", lambda: (
                 avg.data_ptr(), mx.data_ptr(), hidden.data_ptr(), ca.data_ptr(), ca1.data_ptr(), dca.data_ptr(), dca1.data_ptr(),
                 P("ca.fc1.weight"), P("ca.fc2.weight"), P("ca1.fc1.weight"), P("ca1.fc2.weight"), davg.data_ptr(), dmax.data_ptr(),
                 G("ca.fc1.weight"), G("ca.fc2.weight"), G("ca1.fc1.weight"), G("ca1.fc2.weight"), ws_m.data_ptr(), B, n))
+            self._mark("ca.fc1.weight", "ca.fc2.weight", "ca1.fc1.weight", "ca1.fc2.weight")
             self.bwd.add("ksmi_ecam_final_backward_dx", lambda: (
                 garr, dl, ca.data_ptr(), P("conv_final.weight"), davg.data_ptr(), dmax.data_ptr(), argmax.data_ptr(), B, HW, n, 3, dt))
         self.bwd_builders.append(build_bwd)

@@ -1,0 +1,85 @@
+"""CPU, world_size 2, gloo: the data-parallel gradient path of kurosiwo_amd/dp.py (bucket
+construction from launch-readiness indices, overlapped all-reduce issue order, SUM semantics).
+The same code runs over RCCL ("nccl") on the GPUs; only the backend differs."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from kurosiwo_amd.dp import BucketedAllReduce, make_buckets
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_make_buckets_cover_arena_in_order():
+    offsets = {"a": 0, "b": 100, "c": 300, "d": 1000}
+    ready = {"a": 9, "b": 7, "c": 3, "d": 1}
+    b = make_buckets(ready, offsets, None, 1200, 250)
+    assert b[0][0] == 0 and b[-1][1] == 1200
+    for (s0, e0, _), (s1, e1, _) in zip(b, b[1:]):
+        assert e0 == s1
+    assert b == [(0, 300, 9), (300, 1000, 3), (1000, 1200, 1)]
+    assert make_buckets(ready, offsets, None, 1200, 10 ** 9) == [(0, 1200, 9)]
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n = 1200
+    flat = torch.zeros(n)
+    offsets = {"a": 0, "b": 100, "c": 300, "d": 1000}
+    ready = {"a": 9, "b": 7, "c": 3, "d": 1}          # backward finishes the arena tail first
+    red = BucketedAllReduce(flat, make_buckets(ready, offsets, None, n, 250))
+    order = []
+    for launch in range(10):                          # the "backward launch list"
+        if launch == 1:
+            flat[1000:1200] = rank + 1.0
+        if launch == 3:
+            flat[300:1000] = 10.0 * (rank + 1)
+        if launch == 7:
+            flat[100:300] = 100.0 * (rank + 1)
+        if launch == 9:
+            flat[0:100] = -1.0 * (rank + 1)
+        before = len(red.issued)
+        red.after_launch(launch)
+        order += [(launch, s, e) for (s, e) in red.issued[before:]]
+    red.wait()
+    tot = sum(r + 1.0 for r in range(world))
+    ok = (torch.allclose(flat[1000:], torch.full((200,), tot)) and torch.allclose(flat[300:1000], torch.full((700,), 10 * tot))
+          and torch.allclose(flat[100:300], torch.full((200,), 100 * tot)) and torch.allclose(flat[:100], torch.full((100,), -tot)))
+    q.put((rank, ok, order))
+    dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, order in res:
+        assert ok, rank
+        assert order == [(1, 1000, 1200), (3, 300, 1000), (9, 0, 300)], order
+
+
+def test_single_process_is_a_noop():
+    flat = torch.arange(10.0)
+    red = BucketedAllReduce(flat, [(0, 10, 0)])
+    red.after_launch(0)
+    red.wait()
+    assert torch.equal(flat, torch.arange(10.0))
