@@ -50,7 +50,7 @@ __global__ void bn_finalize_kernel(const float* partial, int rows, int Cpad, int
                                    const float* gamma, const float* beta, float* rmean, float* rvar,
                                    int64_t* nbt, float momentum, float eps, int training,
                                    float* mean_o, float* rstd_o, float* scale_o, float* shift_o) {
-  __shared__ double red[2][16][17];
+  __shared__ double red[2][64][17];
   const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
   const int c = blockIdx.x * 16 + cl;
   if (!training) {
@@ -63,7 +63,7 @@ __global__ void bn_finalize_kernel(const float* partial, int rows, int Cpad, int
   }
   double s = 0.0, q = 0.0;
   if (c < C)
-    for (int r = rl; r < rows; r += 16) {
+    for (int r = rl; r < rows; r += 64) {
       s += (double)partial[((size_t)r * 2 + 0) * Cpad + c];
       q += (double)partial[((size_t)r * 2 + 1) * Cpad + c];
     }
@@ -71,7 +71,7 @@ __global__ void bn_finalize_kernel(const float* partial, int rows, int Cpad, int
   __syncthreads();
   if (threadIdx.x < 16 && c < C) {
     s = 0.0; q = 0.0;
-    for (int r = 0; r < 16; ++r) { s += red[0][r][cl]; q += red[1][r][cl]; }
+    for (int r = 0; r < 64; ++r) { s += red[0][r][cl]; q += red[1][r][cl]; }
     const double mean = s / count;
     double var = q / count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -88,19 +88,19 @@ __global__ void bn_finalize_kernel(const float* partial, int rows, int Cpad, int
 // sums[k][c] = sum_rows partial[row][k][c]; optional accumulate into dgamma (k=1) / dbeta (k=0)
 __global__ void reduce_rows_kernel(const float* partial, int rows, int K, int Cstride, int C, float* sums,
                                    float* dgamma, float* dbeta, int accumulate) {
-  __shared__ double red[16][17];
+  __shared__ double red[64][17];
   const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
   const int c = blockIdx.x * 16 + cl;
   for (int k = 0; k < K; ++k) {
     double s = 0.0;
     if (c < C)
-      for (int r = rl; r < rows; r += 16) s += (double)partial[((size_t)r * K + k) * Cstride + c];
+      for (int r = rl; r < rows; r += 64) s += (double)partial[((size_t)r * K + k) * Cstride + c];
     __syncthreads();
     red[rl][cl] = s;
     __syncthreads();
     if (threadIdx.x < 16 && c < C) {
       s = 0.0;
-      for (int r = 0; r < 16; ++r) s += red[r][cl];
+      for (int r = 0; r < 64; ++r) s += red[r][cl];
       const float f = (float)s;
       if (sums) sums[k * C + c] = f;
       float* tgt = (k == 0) ? dbeta : (k == 1 ? dgamma : nullptr);
@@ -314,30 +314,31 @@ __global__ void maxpool_bwd_kernel(const T* x, const T* dy, T* dx, int accumulat
 // first-layer conv (raw image NCHW fp32, Cin <= 8) -> NHWC T, + BN partial stats
 // one 16x16 output patch per block, one pixel per thread
 // ------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void conv_first_fwd_kernel(const float* x, const float* w, const float* bias, T* out,
-                                                             float* stats, int B, int Cin, int H, int W, int Cout) {
+template <typename T, int CIN>
+__global__ __launch_bounds__(256) void conv_first_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, T* out, float* stats, int B,
+                                                             int H, int W, int Cout) {
   constexpr int VEC = ElemTraits<T>::kVec;
+  constexpr int KT = CIN * 9;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* xs = (float*)smem;                       // [Cin][18][18]
-  float* ws = xs + Cin * 324;                     // [Cout][Cin*9]
-  float* red = ws + Cout * Cin * 9;               // [4][2][Cout]
+  float* xs = (float*)smem;                       // [CIN][18][18]
+  float* red = xs + CIN * 324;                    // [4][2][Cout]
   const int tilesX = (W + 15) / 16, tilesY = (H + 15) / 16;
   int bm = blockIdx.x;
   const int tx = bm % tilesX; bm /= tilesX;
   const int ty = bm % tilesY; const int b = bm / tilesY;
   const int tid = threadIdx.x, lx = tid & 15, ly = tid >> 4;
-  for (int i = tid; i < Cin * 324; i += 256) {
+  for (int i = tid; i < CIN * 324; i += 256) {
     const int c = i / 324, r = i - c * 324, hy = r / 18, hx = r - hy * 18;
     const int iy = ty * 16 - 1 + hy, ix = tx * 16 - 1 + hx;
-    xs[i] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? x[(((int64_t)b * Cin + c) * H + iy) * W + ix] : 0.f;
+    xs[i] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? x[(((int64_t)b * CIN + c) * H + iy) * W + ix] : 0.f;
   }
-  for (int i = tid; i < Cout * Cin * 9; i += 256) ws[i] = w[i];
   __syncthreads();
   const int oy = ty * 16 + ly, ox = tx * 16 + lx;
   const bool ok = oy < H && ox < W;
-  float xin[8 * 9];
-  for (int c = 0; c < Cin; ++c)
+  float xin[KT];
+#pragma unroll
+  for (int c = 0; c < CIN; ++c)
 #pragma unroll
     for (int t = 0; t < 9; ++t) xin[c * 9 + t] = xs[c * 324 + (ly + t / 3) * 18 + lx + t % 3];
   const int lane = tid & 63, wave = tid >> 6;
@@ -345,9 +346,10 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const float* x, con
     float o[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
-      float a = bias ? bias[n0 + j] : 0.f;
-      const float* wr = ws + (n0 + j) * Cin * 9;
-      for (int k = 0; k < Cin * 9; ++k) a += xin[k] * wr[k];
+      float a = bias ? bias[n0 + j] : 0.f;         // uniform addresses -> scalar loads
+      const float* wr = w + (n0 + j) * KT;
+#pragma unroll
+      for (int k = 0; k < KT; ++k) a += xin[k] * wr[k];
       o[j] = a;
     }
     if (ok) *(u32x4*)(out + (((int64_t)b * H + oy) * W + ox) * Cout + n0) = vec_pack<T>(o);
@@ -540,7 +542,7 @@ int ksmi_bn_finalize(const float* partial, int rows, int Cpad, int C, double cou
                      float* running_mean, float* running_var, int64_t* nbt, float momentum, float eps, int training,
                      float* mean, float* rstd, float* scale, float* shift, void* stream) {
   if (C < 1 || (training && (!partial || rows < 1))) return ksmi_fail(KSMI_E_ARG, "bn_finalize: bad args");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, partial, rows, Cpad, C, count,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, (hipStream_t)stream, partial, rows, Cpad, C, count,
                      gamma, beta, running_mean, running_var, nbt, momentum, eps, training, mean, rstd, scale, shift);
   return ksmi_check_launch("bn_finalize");
 }
@@ -548,7 +550,7 @@ int ksmi_bn_finalize(const float* partial, int rows, int Cpad, int C, double cou
 int ksmi_reduce_rows(const float* partial, int rows, int K, int Cstride, int C, float* sums, float* dgamma, float* dbeta,
                      int accumulate, void* stream) {
   if (rows < 1 || K < 1 || C < 1 || Cstride < C) return ksmi_fail(KSMI_E_ARG, "reduce_rows: bad args");
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, partial, rows, K, Cstride, C, sums,
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3((C + 15) / 16), dim3(1024), 0, (hipStream_t)stream, partial, rows, K, Cstride, C, sums,
                      dgamma, dbeta, accumulate);
   return ksmi_check_launch("reduce_rows");
 }
@@ -643,10 +645,16 @@ int ksmi_conv_first_forward(const float* x, const float* w, const float* bias, v
   const int vec = dtype == KSMI_BF16 ? 8 : 4;
   if (Cin < 1 || Cin > 8 || Cout % vec || Cout > 256) return ksmi_fail(KSMI_E_ARG, "conv_first: Cin<=8, Cout multiple of vector, <=256");
   const int grid = ksmi_conv_first_stats_rows(B, H, W);
-  const size_t lds = (size_t)(Cin * 324 + Cout * Cin * 9 + 8 * Cout) * sizeof(float);
-  KSMI_DT(dtype,
-          hipLaunchKernelGGL(conv_first_fwd_kernel<bf16_t>, dim3(grid), dim3(256), lds, (hipStream_t)stream, x, w, bias, (bf16_t*)out, stats, B, Cin, H, W, Cout),
-          hipLaunchKernelGGL(conv_first_fwd_kernel<float>, dim3(grid), dim3(256), lds, (hipStream_t)stream, x, w, bias, (float*)out, stats, B, Cin, H, W, Cout));
+  const size_t lds = (size_t)(Cin * 324 + 8 * Cout) * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+#define KSMI_CF(CIN_)                                                                                                     \
+  case CIN_:                                                                                                              \
+    if (dtype == KSMI_BF16) hipLaunchKernelGGL((conv_first_fwd_kernel<bf16_t, CIN_>), dim3(grid), dim3(256), lds, st, x, w, bias, (bf16_t*)out, stats, B, H, W, Cout); \
+    else hipLaunchKernelGGL((conv_first_fwd_kernel<float, CIN_>), dim3(grid), dim3(256), lds, st, x, w, bias, (float*)out, stats, B, H, W, Cout);                    \
+    break;
+  if (dtype != KSMI_BF16 && dtype != KSMI_F32) return ksmi_fail(KSMI_E_ARG, "bad dtype");
+  switch (Cin) { KSMI_CF(1) KSMI_CF(2) KSMI_CF(3) KSMI_CF(4) KSMI_CF(5) KSMI_CF(6) KSMI_CF(7) KSMI_CF(8) }
+#undef KSMI_CF
   return ksmi_check_launch("conv_first_fwd");
 }
 

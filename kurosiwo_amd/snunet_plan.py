@@ -154,7 +154,7 @@ class SNUNetPlan:
         elems = pin * ktot + sum(pout * d.dst[i].n_len * (2 if d.dst[i].accumulate else 1) for i in range(d.ndst))
         if d.mask_src:
             elems += pout * d.N
-        nt = 8 if d.Npad >= 128 else (4 if d.Npad >= 64 else (2 if d.Npad >= 32 else 1))
+        nt = 4 if d.Npad >= 64 else (2 if d.Npad >= 32 else 1)
         meta = {"kind": f"igemm_{tag}<{d.KH}x{d.KW}s{d.stride},BN{16 * nt}>", "bytes": elems * es + taps * ktot * d.N * es,
                 "flops": 2 * pout * d.N * ktot * taps}
         ll.add("ksmi_conv_forward", lambda: (C.byref(d), self.dt), meta)

@@ -95,7 +95,12 @@ def test_fp32_train_step_matches_oracle(dev, c, bc, B, H, W):
     for k in R.param_keys(sd):
         if k.endswith("conv2.bias"):
             continue     # zero-gradient parameter: Adam turns rounding noise into +-lr steps on BOTH sides
-        assert (msd[k].cpu() - sd[k]).abs().max() < 2e-3 * max(1e-2, float(sd[k].abs().max())), k
+        # Adam normalises every element's update to ~lr regardless of |g|: an element whose gradient is
+        # rounding noise (dead ReLU channel, ...) may step +-lr in opposite directions on the two sides.
+        # So: hard bound 2*lr*steps on every element, and >= 99 % of the elements within 1e-4.
+        diff = (msd[k].cpu() - sd[k]).abs()
+        assert float(diff.max()) <= 2 * 1e-3 * 3 + 1e-6, k
+        assert float((diff > 1e-4).float().mean()) < 0.01, (k, float((diff > 1e-4).float().mean()))
 
 
 def test_fp32_full_size_golden(dev, golden_dir):
