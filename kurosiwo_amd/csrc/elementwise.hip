@@ -25,9 +25,11 @@ struct ChanWalk {
 // Reduce per-thread accumulators val[K*VEC] (K quantities x VEC channels) over the pixel
 // lanes of the block and write partial[(row*K + k)*C + c].
 template <int K, int VEC>
-__device__ void block_channel_reduce(const float* val, const ChanWalk& w, int CV, int C, float* partial, int row) {
+__device__ __forceinline__ void block_channel_reduce(const float* val, const ChanWalk& w, int CV, int C, float* partial, int row) {
   __shared__ float red[kThreads * 2];
+#pragma unroll
   for (int k = 0; k < K; ++k) {
+#pragma unroll
     for (int j0 = 0; j0 < VEC; j0 += 2) {
       __syncthreads();
       red[threadIdx.x * 2 + 0] = w.active ? val[k * VEC + j0] : 0.f;

@@ -58,7 +58,9 @@ __global__ __launch_bounds__(256) void ecam_pool_kernel(const T* x0, const T* x1
   // reduce over pixel lanes through LDS
   __shared__ float rs[kThreads], rm[kThreads];
   __shared__ int ri[kThreads];
+#pragma unroll
   for (int k = 0; k < 5; ++k)
+#pragma unroll
     for (int j = 0; j < VEC; ++j) {
       __syncthreads();
       rs[threadIdx.x] = active ? s[k][j] : 0.f;
@@ -195,7 +197,9 @@ __global__ __launch_bounds__(256) void ecam_bwd_reduce_kernel(const T* x0, const
       }
     }
   __shared__ float red[kThreads];
+#pragma unroll
   for (int k = 0; k < NCLS; ++k) {
+#pragma unroll
     for (int j = 0; j < VEC; ++j) {
       __syncthreads();
       red[threadIdx.x] = active ? g[k][j] : 0.f;

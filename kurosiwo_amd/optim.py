@@ -4,7 +4,8 @@ torch.optim.Adam(lr) / SGD(momentum, weight_decay) as constructed at
 
 One HIP kernel updates the whole model (12 M parameters = one 48 MB pass) instead of a
 236-tensor foreach loop.  The step counter lives on the device so a captured HIP graph
-can be replayed.
+can be replayed.  They are real torch.optim.Optimizer subclasses (param_groups, lr schedulers,
+state_dict work); `step()` serves the autograd path, `step_arena()` the fused train step.
 """
 import torch
 
@@ -14,7 +15,7 @@ from .runtime import stream_ptr
 
 def _arena_of(params):
     """(base_ptr, numel) if the tensors tile one contiguous fp32 buffer in order, else None."""
-    params = [p for p in params]
+    params = list(params)
     if not params:
         return None
     base = params[0].data_ptr()
@@ -27,51 +28,60 @@ def _arena_of(params):
 
 
 class _FlatOptimizer(torch.optim.Optimizer):
-    def _flat_state(self, group, names):
-        st = self.state.setdefault("flat%d" % id(group), {})
-        ps = group["params"]
+    _names = ()
+
+    def flat_state(self, n, device):
+        st = self.state.setdefault("flat", {})
+        if st.get("n") != n:
+            st["n"] = n
+            for nm in self._names:
+                st[nm] = torch.zeros(n, dtype=torch.float32, device=device)
+            st["step"] = torch.zeros(1, dtype=torch.int64, device=device)
+        return st
+
+    def _arenas(self):
+        if len(self.param_groups) != 1:
+            raise _lib.KsmiError("fused optimiser: exactly one param group is supported")
+        ps = self.param_groups[0]["params"]
         ar = _arena_of(ps)
         if ar is None:
             raise _lib.KsmiError("fused optimiser: parameters must be views of one flat fp32 arena "
                                  "(pass model.parameters() of a kurosiwo_amd model)")
-        if "n" not in st or st["n"] != ar[1] or st["base"] != ar[0]:
-            dev = ps[0].device
-            st["base"], st["n"] = ar
-            for nm in names:
-                st[nm] = torch.zeros(ar[1], dtype=torch.float32, device=dev)
-            st["step"] = torch.zeros(1, dtype=torch.int64, device=dev)
         gr = _arena_of([p.grad for p in ps]) if all(p.grad is not None for p in ps) else None
         if gr is None or gr[1] != ar[1]:
             raise _lib.KsmiError("fused optimiser: gradients are not a flat arena (run backward through the HIP model first)")
-        return st, ar, gr
+        return ar, gr, ps[0].device
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        ar, gr, dev = self._arenas()
+        self.step_arena(ar[0], gr[0], ar[1], dev)
+        return loss
 
 
 class FusedAdam(_FlatOptimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=1.0):
-        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, grad_scale=grad_scale))
+    _names = ("exp_avg", "exp_avg_sq")
 
-    @torch.no_grad()
-    def step(self, closure=None):
-        loss = closure() if closure is not None else None
-        lib = _lib.load()
-        for g in self.param_groups:
-            st, ar, gr = self._flat_state(g, ("exp_avg", "exp_avg_sq"))
-            _lib.check(lib.ksmi_adam_step(ar[0], gr[0], st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), ar[1],
-                                          st["step"].data_ptr(), g["lr"], g["betas"][0], g["betas"][1], g["eps"],
-                                          g["weight_decay"], g["grad_scale"], stream_ptr()), "adam_step")
-        return loss
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+
+    def step_arena(self, p_ptr, g_ptr, n, device, grad_scale=1.0):
+        g = self.param_groups[0]
+        st = self.flat_state(n, device)
+        _lib.check(_lib.load().ksmi_adam_step(p_ptr, g_ptr, st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), n,
+                                              st["step"].data_ptr(), g["lr"], g["betas"][0], g["betas"][1], g["eps"],
+                                              g["weight_decay"], grad_scale, stream_ptr()), "adam_step")
 
 
 class FusedSGD(_FlatOptimizer):
-    def __init__(self, params, lr, momentum=0.0, weight_decay=0.0, grad_scale=1.0):
-        super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay, grad_scale=grad_scale))
+    _names = ("momentum_buffer",)
 
-    @torch.no_grad()
-    def step(self, closure=None):
-        loss = closure() if closure is not None else None
-        lib = _lib.load()
-        for g in self.param_groups:
-            st, ar, gr = self._flat_state(g, ("momentum_buffer",))
-            _lib.check(lib.ksmi_sgd_step(ar[0], gr[0], st["momentum_buffer"].data_ptr(), ar[1], st["step"].data_ptr(),
-                                         g["lr"], g["momentum"], g["weight_decay"], g["grad_scale"], stream_ptr()), "sgd_step")
-        return loss
+    def __init__(self, params, lr, momentum=0.0, weight_decay=0.0):
+        super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
+
+    def step_arena(self, p_ptr, g_ptr, n, device, grad_scale=1.0):
+        g = self.param_groups[0]
+        st = self.flat_state(n, device)
+        _lib.check(_lib.load().ksmi_sgd_step(p_ptr, g_ptr, st["momentum_buffer"].data_ptr(), n, st["step"].data_ptr(),
+                                             g["lr"], g["momentum"], g["weight_decay"], grad_scale, stream_ptr()), "sgd_step")

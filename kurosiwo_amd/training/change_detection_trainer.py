@@ -1,0 +1,137 @@
+"""Change-detection trainer with the reference's entry points and return contract
+(/root/reference/training/change_detection_trainer.py: train_change_detection :18-322,
+eval_change_detection :325-791), on the fused HIP train step.
+
+Kept: batch-tuple unpacking, input assembly from configs['inputs'] (+dem), Adam/SGD choice, per-epoch
+LR schedule step, checkpoint dict format + best_segmentation.{pt,txt}, metric definitions and the
+`(100*acc[4], 100*meanF1[:3], 100*mIoU)` return value, per-AOI / water-only metrics.
+Changed on purpose: no per-step host syncs -- losses and the 4x4 confusion
+matrix accumulate on the device and are read once per logging interval; wandb / kornia image
+panels are dropped.
+"""
+from pathlib import Path
+
+import torch
+
+from ..config import init_lr_scheduler
+from ..loss import create_loss
+from ..metrics import ConfusionMetrics, metrics_from_cm
+from ..optim import FusedAdam, FusedSGD
+from ..synthetic import cd_inputs
+from ..trainer import CDTrainStep
+
+CLASS_LABELS = {0: "No water", 1: "Permanent Waters", 2: "Floods", 3: "Invalid pixels"}
+
+
+def _make_optimizer(model, configs, model_configs):
+    if configs["method"] in ("bit-cd", "hfa-net") or model_configs.get("optimizer") == "sgd":
+        return FusedSGD(model.parameters(), lr=model_configs["learning_rate"], momentum=model_configs.get("momentum", 0.0),
+                        weight_decay=model_configs.get("weight_decay", 0.0))
+    if model_configs["optimizer"] == "adam":
+        # the reference ignores betas / weight_decay of the method json for Adam (cd_trainer:52-54)
+        return FusedAdam(model.parameters(), lr=model_configs["learning_rate"])
+    if model_configs["optimizer"] == "adamw":
+        raise NotImplementedError("adamw is unused by the in-scope methods")
+    raise NotImplementedError(model_configs["optimizer"])
+
+
+def _print_metrics(prefix, m, loss):
+    print(f"{prefix} loss {loss:.5f} | mIoU {100 * float(m['miou']):.2f} | "
+          + " | ".join(f"{CLASS_LABELS[c]}: acc {100 * float(m['accuracy'][c]):.2f} F1 {100 * float(m['f1'][c]):.2f} "
+                       f"IoU {100 * float(m['iou'][c]):.2f}" for c in range(3)))
+
+
+def train_change_detection(model, train_loader, val_loader, test_loader, configs, model_configs):
+    assert len(configs["inputs"]) == 2, f'Model {model_configs["method"]} requires exactly 2 input images.'
+    dev = torch.device(configs["device"])
+    model.to(dev)
+    optimizer = _make_optimizer(model, configs, model_configs)
+    lr_scheduler = init_lr_scheduler(optimizer, configs, model_configs, steps=len(train_loader))
+    metrics = ConfusionMetrics(dev)
+    best_val, loss_val = 0.0, float("nan")
+    step = None
+    print(f'===== checkpoint_path: {configs["checkpoint_path"]} ====')
+    for epoch in range(0, configs["epochs"]):
+        model.train()
+        metrics.reset()
+        loss_acc = torch.zeros(3, dtype=torch.float32, device=dev)
+        nb = 0
+        for index, batch in enumerate(train_loader):
+            (xA, xB), mask = cd_inputs(batch, configs["inputs"], bool(configs["dem"]))
+            if step is None or step.B != xA.shape[0]:
+                step = CDTrainStep(model, xA.shape[0], xA.shape[2], xA.shape[3], configs["loss_function"],
+                                   configs.get("class_weights", [1.0, 1.0, 1.0]) if configs["loss_function"] != "cross_entropy"
+                                   or True else [1.0, 1.0, 1.0], optimizer=optimizer)
+            step.step(xA.to(dev, non_blocking=True), xB.to(dev, non_blocking=True), mask.to(dev, non_blocking=True))
+            metrics.update(step.plan.logits, step.labels)
+            loss_acc += step.loss_out
+            nb += 1
+            if configs.get("on_screen_prints") and (index + 1) % configs["print_frequency"] == 0:
+                _print_metrics(f"[{epoch}:{index + 1}]", metrics.compute(), float(loss_acc[0]) / nb)
+        loss_val = float(loss_acc[0]) / max(nb, 1)
+        _print_metrics(f"Epoch {epoch} train", metrics.compute(), loss_val)
+        if (epoch + 1) % configs.get("train_save_checkpoint_freq", 1) == 0:
+            torch.save({"epoch": epoch, "model_state_dict": model.state_dict(), "optimizer_state_dict": optimizer.state_dict(),
+                        "lr_scheduler_state_dict": lr_scheduler.state_dict(), "loss": loss_val},
+                       Path(configs["checkpoint_path"]) / f"checkpoint_epoch={epoch}.pt")
+        lr_scheduler.step()
+        val_acc, val_score, miou = eval_change_detection(model, val_loader, settype="Validation", configs=configs,
+                                                         model_configs=model_configs)
+        if miou > best_val:
+            print(f"New best validation mIoU: {miou}")
+            print(f'Saving model to: {configs["checkpoint_path"]}/best_segmentation.pt')
+            best_val = miou
+            torch.save({"epoch": epoch, "model_state_dict": model.state_dict(), "optimizer_state_dict": optimizer.state_dict(),
+                        "lr_scheduler_state_dict": lr_scheduler.state_dict(), "loss": loss_val},
+                       Path(configs["checkpoint_path"]) / "best_segmentation.pt")
+            with open(Path(configs["checkpoint_path"]) / "best_segmentation.txt", "w") as f:
+                f.write(f"{epoch}\n")
+                f.write(f"{miou}")
+
+
+def eval_change_detection(model, loader, settype, configs=None, model_configs=None):
+    dev = torch.device(configs["device"])
+    metrics = ConfusionMetrics(dev)
+    per_aoi = {a: ConfusionMetrics(dev) for a in getattr(loader.dataset, "activations", [])} if configs.get("log_AOI_metrics") else {}
+    per_zone = {z: ConfusionMetrics(dev) for z in (1, 2, 3)} if configs.get("log_zone_metrics") else {}
+    criterion = create_loss(configs, mode="val")
+    model.to(dev)
+    model.eval()
+    total_loss = torch.zeros((), dtype=torch.float32, device=dev)
+    nsamples = 0
+    with torch.no_grad():
+        for batch in loader:
+            (xA, xB), mask = cd_inputs(batch, configs["inputs"], bool(configs["dem"]))
+            xA, xB, mask = xA.to(dev), xB.to(dev), mask.to(dev)
+            clz, activ = batch[-2], batch[-1]
+            output = model(xA, xB)
+            if configs["method"] == "changeformer":
+                output = output[-1]
+            total_loss += criterion(output, mask) * xA.size(0)
+            nsamples += xA.size(0)
+            metrics.update(output, mask)
+            for group, key in ((per_aoi, activ), (per_zone, clz)):
+                if group:
+                    for i in range(xA.size(0)):
+                        k = int(key[i])
+                        if k in group:
+                            group[k].update(output[i:i + 1], mask[i:i + 1])
+    m = metrics.compute()
+    loss = float(total_loss) / max(nsamples, 1)
+    _print_metrics(f"{settype}", m, loss)
+    if configs.get("evaluate_water"):
+        cm = metrics.cm.cpu().double()
+        # water-only F1: classes {1,2} merged (cd_trainer:414-419)
+        w = torch.zeros((4, 4), dtype=torch.float64)
+        w[0, 0] = cm[0, 0]
+        w[0, 1] = cm[0, 1] + cm[0, 2]
+        w[1, 0] = cm[1, 0] + cm[2, 0]
+        w[1, 1] = cm[1:3, 1:3].sum()
+        wm = metrics_from_cm(w)
+        print(f'{settype} water-only F1: no-water {100 * float(wm["f1"][0]):.2f} water {100 * float(wm["f1"][1]):.2f}')
+    for name, group in (("AOI", per_aoi), ("climate zone", per_zone)):
+        for k, cmx in group.items():
+            if int(cmx.cm.sum()) > 0:
+                gm = cmx.compute()
+                print(f"{settype} {name} {k}: mIoU {100 * float(gm['miou']):.2f}")
+    return 100 * m["accuracy"], 100 * m["f1"][:3].mean(), 100 * m["miou"]

@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Entry point with the reference's CLI (/root/reference/main.py:29-36) and dispatch (:83-195)
+for the tasks/methods that have a HIP implementation (this round: task "cd", method "snunet").
+
+  python main.py --method snunet --inputs pre_event_1 post_event [--dem] [--slope] [--batch_size N] [--seed S]
+"""
+import argparse
+import pprint
+import random
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from kurosiwo_amd.config import create_checkpoint_directory, load_json5, update_config
+from kurosiwo_amd.data import prepare_loaders
+from kurosiwo_amd.model_utilities import initialize_cd_model
+from kurosiwo_amd.training.change_detection_trainer import eval_change_detection, train_change_detection
+
+parser = argparse.ArgumentParser()
+parser.add_argument("--method", default=None)
+parser.add_argument("--backbone", default=None)
+parser.add_argument("--dem", action="store_true", default=False)
+parser.add_argument("--slope", action="store_true", default=False)
+parser.add_argument("--batch_size", default=None)
+parser.add_argument("--inputs", nargs="+", default=None)
+parser.add_argument("--seed", type=int, default=999)
+
+
+def main(argv=None):
+    args = parser.parse_args(argv)
+    np.random.seed(args.seed)
+    random.seed(args.seed)
+    torch.manual_seed(args.seed)
+    configs = load_json5("configs/config.json")
+    if args.method is not None:
+        configs["method"] = args.method
+    name = configs["method"].lower()
+    model_configs = load_json5(f'configs/method/{name}/{name.replace("-", "_")}.json')
+    if args.backbone is not None:
+        model_configs["backbone"] = args.backbone
+    configs.update(model_configs)
+    configs = update_config(configs, args)          # (the reference drops --dem without --inputs: main.py:66-69 bug, not kept)
+    if name in ("snunet", "changeformer", "siam-conc", "siam-diff", "bit-cd", "hfa-net", "adhr-cdnet"):
+        configs["task"] = "cd"
+        configs["num_channels"] = len(configs["channels"]) + (1 if configs["dem"] else 0)
+    configs["checkpoint_path"] = create_checkpoint_directory(configs, model_configs)
+    if args.batch_size is not None:
+        configs["batch_size"] = int(args.batch_size)
+    pprint.pprint(configs)
+    train_loader, val_loader, test_loader = prepare_loaders(configs)
+    if configs["task"] == "cd":
+        if not configs["test"]:
+            model = initialize_cd_model(configs, model_configs, "train")
+            train_change_detection(model, train_loader, val_loader, test_loader, configs=configs, model_configs=model_configs)
+        model = initialize_cd_model(configs, model_configs, "test")
+        ckpt_path = Path(configs["checkpoint_path"]) / "best_segmentation.pt"
+        print(f"Loading model from: {ckpt_path}")
+        checkpoint = torch.load(ckpt_path, map_location=configs["device"])
+        model.load_state_dict(checkpoint["model_state_dict"])
+        test_acc, test_score, miou = eval_change_detection(model, test_loader, settype="Test", configs=configs,
+                                                           model_configs=model_configs)
+        print(f"Test mIoU: {miou}")
+        return float(miou)
+    raise SystemExit(f'task {configs["task"]!r} is not implemented by this build yet (SURVEY.md §8: next rows)')
+
+
+if __name__ == "__main__":
+    main()

@@ -170,3 +170,20 @@ def test_bf16_train_step_close_to_oracle(dev, c, bc, B, H, W):
             cos.append(float((g @ r) / (g.norm() * r.norm() + 1e-30)))
     assert np.median(cos) > 0.98, np.median(cos)
     print(f"bf16: logits rel err {rel:.3e}, median grad cosine {np.median(cos):.4f}, min {min(cos):.4f}")
+
+
+def test_main_entry_end_to_end_tiny(dev, tmp_path, monkeypatch):
+    """main.py with the reference's flags on a tiny synthetic set: train 1 epoch, checkpoint, reload, test."""
+    import shutil
+    import main as entry
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    shutil.copytree(os.path.join(root, "configs"), tmp_path / "configs")
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv("KSMI_SYNTHETIC_TILES", "8,4,4")
+    miou = entry.main(["--method", "snunet", "--inputs", "pre_event_1", "post_event", "--batch_size", "4"])
+    assert 0.0 <= miou <= 100.0
+    ck = list((tmp_path / "checkpoints" / "snunet").glob("*/best_segmentation.pt"))
+    assert ck, "best checkpoint missing"
+    d = torch.load(ck[0], map_location="cpu")
+    assert set(d) == {"epoch", "model_state_dict", "optimizer_state_dict", "lr_scheduler_state_dict", "loss"}
+    assert len(d["model_state_dict"]) == 236

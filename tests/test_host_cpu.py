@@ -1,0 +1,96 @@
+"""CPU: host-side mirror of the reference's operator surface (config derivation table of
+SURVEY.md §8(c), JSON5 loader, synthetic batch contract, checkpoint directory naming, metrics
+oracle hand cases)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from kurosiwo_amd.config import create_checkpoint_directory, load_json5, update_config
+from kurosiwo_amd.synthetic import cd_inputs, make_batch
+from oracle import metrics_ref
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class Args:
+    def __init__(self, inputs=None, dem=False, slope=False):
+        self.inputs, self.dem, self.slope = inputs, dem, slope
+
+
+def _cfg(task, **kw):
+    c = load_json5(os.path.join(ROOT, "configs/config.json"))
+    c.update(load_json5(os.path.join(ROOT, "configs/method/snunet/snunet.json")))
+    c["task"] = task
+    c = update_config(c, Args(**kw), root=ROOT)
+    return c
+
+
+def test_num_channels_table():
+    # cd/GRD 2, cd/GRD+dem 3, seg 3-date GRD 6, seg 3-date+dem 7 (utilities.py:377-390)
+    assert _cfg("cd", inputs=["pre_event_1", "post_event"])["num_channels"] == 2
+    assert _cfg("cd", inputs=["pre_event_1", "post_event"], dem=True)["num_channels"] == 3
+    assert _cfg("segmentation")["num_channels"] == 6
+    assert _cfg("segmentation", inputs=["pre_event_1", "pre_event_2", "post_event"], dem=True)["num_channels"] == 7
+    c = _cfg("cd", inputs=["pre_event_1", "post_event"])
+    assert c["class_weights"] == [1.0, 1.0, 1.0] and c["device"] == "cuda:0" and c["inputs"] == ["pre_event_1", "post_event"]
+
+
+def test_json5_loader_handles_comments_and_trailing_commas(tmp_path):
+    p = tmp_path / "c.json"
+    p.write_text('{\n "a": 1, // comment with "quotes"\n "url": "http://x//y", // keep\n "l": [1,2,],\n}\n')
+    assert load_json5(p) == {"a": 1, "url": "http://x//y", "l": [1, 2]}
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/configs"), reason="reference not mounted")
+def test_json5_loader_reads_reference_config_files():
+    c = load_json5("/root/reference/configs/config.json")
+    assert c["num_classes"] == 3 and c["task"] == "segmentation"
+    d = load_json5("/root/reference/configs/train/data_config.json")
+    mine = load_json5(os.path.join(ROOT, "configs/train/data_config.json"))
+    for k in ("data_mean", "data_std", "dem_mean", "dem_std", "clamp_input", "inputs", "channels", "train_acts", "val_acts", "test_acts"):
+        assert d[k] == mine[k], k
+    s = load_json5("/root/reference/configs/method/snunet/snunet.json")
+    m = load_json5(os.path.join(ROOT, "configs/method/snunet/snunet.json"))
+    assert s == {k: m[k] for k in s}
+
+
+def test_synthetic_batch_contract():
+    b = make_batch(3, 32, 32, seed=5)
+    assert len(b) == 12
+    assert b[2].shape == (3, 2, 32, 32) and b[3].shape == (3, 32, 32) and b[3].dtype == torch.int64
+    assert isinstance(b[0], list) and b[0][0].dtype == torch.float64 and b[0][0].shape == (3,)
+    assert set(b[3].unique().tolist()) <= {0, 1, 2, 3}
+    vv = b[2][:, 0]
+    assert float(vv.min()) >= -2.24 and float(vv.max()) <= 1.29          # SURVEY.md §8(d) value range
+    bd = make_batch(2, 32, 32, seed=5, dem=True)
+    assert len(bd) == 13 and bd[10].shape == (2, 1, 32, 32)
+    (xA, xB), mask = cd_inputs(bd, ("pre_event_1", "post_event"), dem=True)
+    assert xA.shape == (2, 3, 32, 32) and torch.equal(xB[:, :2], bd[2])
+    b2 = make_batch(3, 32, 32, seed=5)
+    assert torch.equal(b[2], b2[2]) and torch.equal(b[3], b2[3])
+
+
+def test_checkpoint_directory_naming(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    p = create_checkpoint_directory({"task": "cd", "method": "SNUNet", "track": "RandomEvents"}, {})
+    assert p.startswith("checkpoints/snunet/RandomEvents_") and os.path.isdir(p)
+
+
+def test_metrics_oracle_hand_cases():
+    # hand-computed confusion-matrix cases (torchmetrics semantics; parity unpinned by import)
+    pred = np.array([0, 1, 2, 2, 1, 0, 0, 3])
+    tgt = np.array([0, 1, 2, 1, 3, 2, 0, 0])
+    cm = metrics_ref.confusion_matrix(pred, tgt)
+    assert cm.sum() == 7 and cm[3].sum() == 0          # target==3 dropped
+    assert cm[0, 0] == 2 and cm[0, 3] == 1 and cm[1, 1] == 1 and cm[1, 2] == 1 and cm[2, 2] == 1 and cm[2, 0] == 1
+    m = metrics_ref.metrics_from_cm(cm)
+    assert np.allclose(m["recall"], [2 / 3, 1 / 2, 1 / 2, 0.0])
+    assert np.allclose(m["precision"], [2 / 3, 1.0, 1 / 2, 0.0])
+    assert np.allclose(m["iou"], [2 / 4, 1 / 2, 1 / 3, 0.0])
+    assert abs(m["miou"] - (0.5 + 0.5 + 1 / 3) / 3) < 1e-12
+    from kurosiwo_amd.metrics import metrics_from_cm
+    mm = metrics_from_cm(torch.tensor(cm))
+    for k in ("accuracy", "precision", "recall", "f1", "iou"):
+        assert np.allclose(mm[k].numpy(), m[k])
