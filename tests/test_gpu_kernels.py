@@ -186,3 +186,22 @@ def test_deconv2x2(dev, dtype, shape):
     dx, dw = Fk.deconv2x2_backward(xd, Fk.to_nhwc(dy.to(dev), dtype), w.to(dev))
     assert (Fk.to_nchw(dx).cpu() - xr.grad).abs().max() < tol * xr.grad.abs().max()
     assert (dw.cpu() - wr.grad).abs().max() < tol * wr.grad.abs().max()
+
+
+def test_adam_and_sgd_match_reference_formulas(dev):
+    """ksmi_adam_step / ksmi_sgd_step on a flat arena vs torch.optim.Adam / SGD (CPU) over 4 steps."""
+    from kurosiwo_amd.optim import FusedAdam, FusedSGD
+    n = 10007
+    p0 = seeded_tensor("opt.p", (n,))
+    grads = [seeded_tensor(f"opt.g{i}", (n,)) * (10.0 ** (-i)) for i in range(4)]
+    for kind in ("adam", "sgd"):
+        pr = p0.clone().requires_grad_(True)
+        ref = torch.optim.Adam([pr], lr=1e-3) if kind == "adam" else torch.optim.SGD([pr], lr=6e-4, momentum=0.99, weight_decay=1e-5)
+        pd = torch.nn.Parameter(p0.clone().to(dev))
+        opt = FusedAdam([pd], lr=1e-3) if kind == "adam" else FusedSGD([pd], lr=6e-4, momentum=0.99, weight_decay=1e-5)
+        for g in grads:
+            pr.grad = g.clone()
+            ref.step()
+            pd.grad = g.clone().to(dev)
+            opt.step()
+        assert (pd.detach().cpu() - pr.detach()).abs().max() < 2e-6, kind
