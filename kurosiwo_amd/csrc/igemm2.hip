@@ -1,0 +1,249 @@
+// Implicit-GEMM convolution, software-pipelined variant (the default when every concat source
+// is a whole number of 64-byte k-chunks).
+//
+// Per k-chunk a workgroup needs a halo tile (HP pixels x 64 B) and a weight slab (taps x BN x 64 B).
+// Both LDS images are double-buffered and filled by LDS-DMA (`global_load_lds_dwordx4`): lane i of a
+// wave instruction lands at base + 16*i, so the image is lane-linear and the bank swizzle is applied
+// on the per-lane SOURCE address (cdna_hip_programming.md rule 21).  Zero padding comes for free:
+// out-of-image halo positions are never written (exec-masked lanes) and the buffers are zeroed once.
+// One barrier per chunk; the DMA of chunk c+1 is in flight while the MFMAs of chunk c run.
+// With a fused BN-apply+ReLU operand (AFF) the halo goes through registers instead (transform,
+// ds_write); the weights still use DMA.
+#include "common.h"
+#include "../../include/ksmi.h"
+#include "errors.h"
+#include "igemm_epilogue.h"
+
+namespace {
+
+template <typename T, int NT, int KH, int KW, bool AFF>
+__global__ __launch_bounds__(256) void igemm2_fwd_kernel(const ksmi_conv_desc d) {
+  constexpr int TAPS = KH * KW;
+  constexpr int BN = NT * 16;
+  constexpr int VEC = ElemTraits<T>::kVec;
+  constexpr int KC = VEC * 4;
+  constexpr int WVEC = TAPS * BN * 4;                       // 16-byte vectors of one weight slab
+  constexpr int WITER = (WVEC + 255) / 256;
+  constexpr int MAXSLOT = 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, l15 = lane & 15;
+
+  const int tilesX = (d.Wout + d.TW - 1) / d.TW, tilesY = (d.Hout + d.TH - 1) / d.TH;
+  int bm = blockIdx.x;
+  const int tx = bm % tilesX; bm /= tilesX;
+  const int ty = bm % tilesY; const int b = bm / tilesY;
+  const int oy0 = ty * d.TH, ox0 = tx * d.TW;
+  const int n0 = blockIdx.y * BN;
+  const int S = d.stride;
+  const int HH = (d.TH - 1) * S + KH, HW = (d.TW - 1) * S + KW;
+  const int HP = HH * HW;
+  const int P = d.TH * d.TW;
+  const int HPB = (HP * 64 + 1023) & ~1023;                 // halo bytes, whole wave-instructions (1 KiB)
+  const int BUFB = HPB + TAPS * BN * 64;                    // one stage
+  const int nslot = HPB / 4096 + ((HPB % 4096) ? 1 : 0);    // 256 lanes x 16 B per slot-iteration
+
+  // ---- zero both halo images once (padding positions are never written afterwards) -----------
+  for (int v = tid; v < HPB / 16; v += 256) {
+    *(u32x4*)(smem + v * 16) = (u32x4){0u, 0u, 0u, 0u};
+    *(u32x4*)(smem + BUFB + v * 16) = (u32x4){0u, 0u, 0u, 0u};
+  }
+
+  // ---- per-thread halo slots: LDS position v = s*256 + tid <-> (pixel v>>2, slot v&3) -----------
+  int slot_goff[MAXSLOT];                                   // pixel index in the image, or -1
+  int slot_q[MAXSLOT];                                      // k-group fetched into this LDS slot (DMA path)
+  int slot_lds[MAXSLOT];                                    // register path: where k-group myq of the pixel goes
+#pragma unroll
+  for (int s = 0; s < MAXSLOT; ++s) {
+    const int v = tid + s * 256;
+    slot_goff[s] = -1; slot_q[s] = 0; slot_lds[s] = 0;
+    if (v < HP * 4) {
+      const int pix = v >> 2, sl = v & 3;
+      const int hy = pix / HW, hx = pix - hy * HW;
+      const int iy = oy0 * S - d.pad + hy, ix = ox0 * S - d.pad + hx;
+      if (iy >= 0 && iy < d.Hin && ix >= 0 && ix < d.Win) slot_goff[s] = (b * d.Hin + iy) * d.Win + ix;
+      slot_q[s] = sl ^ swz(pix);
+      slot_lds[s] = pix * 64 + ((sl ^ swz(pix)) << 4);     // (register path: thread owns k-group sl)
+    }
+  }
+  const int myq = tid & 3;
+
+  // ---- per-lane fragment addresses ---------------------------------------------------------------
+  int a_addr[4][TAPS];
+#pragma unroll
+  for (int mf = 0; mf < 4; ++mf) {
+    int p = wave * 64 + mf * 16 + l15;
+    if (p >= P) p = 0;
+    const int ly = p / d.TW, lx = p - ly * d.TW;
+    const int base = ly * S * HW + lx * S;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {
+      const int ap = base + (t / KW) * HW + (t % KW);
+      a_addr[mf][t] = ap * 64 + ((g ^ swz(ap)) << 4);
+    }
+  }
+  int b_addr[NT];
+#pragma unroll
+  for (int nf = 0; nf < NT; ++nf) {
+    const int n = nf * 16 + l15;
+    b_addr[nf] = n * 64 + ((g ^ swz(n)) << 4);
+  }
+  // weight DMA: vector v = i*256 + tid -> row (tap*BN + n), slot; source k-group = slot ^ swz(n)
+  int w_src[WITER];                                         // element offset inside one chunk's slab, or -1
+#pragma unroll
+  for (int i = 0; i < WITER; ++i) {
+    const int v = i * 256 + tid;
+    const int row = v >> 2, sl = v & 3;
+    const int t = row / BN, n = row - t * BN;
+    w_src[i] = (v < WVEC && n0 + n < d.Npad) ? ((t * d.Npad + n0 + n) * KC + ((sl ^ swz(n)) * VEC)) : -1;
+  }
+
+  f32x4 acc[4][NT];
+#pragma unroll
+  for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+    for (int nf = 0; nf < NT; ++nf) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const T* wpk = (const T*)d.wpk;
+  u32x4 hreg[AFF ? MAXSLOT : 1];
+
+  auto issue_weights = [&](int ch, int buf) {
+    const T* wsrc = wpk + (size_t)ch * TAPS * d.Npad * KC;
+    unsigned char* wdst = smem + buf * BUFB + HPB;
+#pragma unroll
+    for (int i = 0; i < WITER; ++i) {
+      if (w_src[i] >= 0)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + w_src[i]),
+                                         (__attribute__((address_space(3))) void*)(wdst + (i * 256 + wave * 64) * 16), 16, 0, 0);
+    }
+  };
+  auto issue_halo_dma = [&](int ch, int buf) {
+    const ksmi_src& sr = d.src[d.chunk_src[ch]];
+    const T* sp = (const T*)sr.ptr + sr.c_off + d.chunk_c0[ch];
+    unsigned char* hdst = smem + buf * BUFB;
+#pragma unroll
+    for (int s = 0; s < MAXSLOT; ++s) {
+      if (s < nslot && slot_goff[s] >= 0)
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(sp + (size_t)slot_goff[s] * sr.C + slot_q[s] * VEC),
+            (__attribute__((address_space(3))) void*)(hdst + (s * 256 + wave * 64) * 16), 16, 0, 0);
+    }
+  };
+  auto load_halo_regs = [&](int ch) {                      // AFF: thread owns k-group myq of its slot pixels
+    const ksmi_src& sr = d.src[d.chunk_src[ch]];
+    const T* sp = (const T*)sr.ptr + sr.c_off + d.chunk_c0[ch] + myq * VEC;
+#pragma unroll
+    for (int s = 0; s < MAXSLOT; ++s)
+      if (s < nslot && slot_goff[s] >= 0) hreg[AFF ? s : 0] = *(const u32x4*)(sp + (size_t)slot_goff[s] * sr.C);
+  };
+  auto store_halo_regs = [&](int ch, int buf) {
+    const ksmi_src& sr = d.src[d.chunk_src[ch]];
+    const int cq = d.chunk_c0[ch] + myq * VEC;
+    float sc[VEC], sh[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { sc[j] = sr.scale[cq + j]; sh[j] = sr.shift[cq + j]; }
+    unsigned char* hdst = smem + buf * BUFB;
+#pragma unroll
+    for (int s = 0; s < MAXSLOT; ++s)
+      if (s < nslot && slot_goff[s] >= 0) {
+        float f[VEC];
+        vec_unpack<T>(hreg[AFF ? s : 0], f);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          f[j] = f[j] * sc[j] + sh[j];
+          if (sr.relu) f[j] = fmaxf(f[j], 0.f);
+        }
+        *(u32x4*)(hdst + slot_lds[s]) = vec_pack<T>(f);
+      }
+  };
+
+  __syncthreads();                                          // zero fill visible before any DMA lands
+  // ---- prologue: stage chunk 0 ---------------------------------------------------------------------
+  issue_weights(0, 0);
+  if constexpr (AFF) { load_halo_regs(0); store_halo_regs(0, 0); }
+  else issue_halo_dma(0, 0);
+
+  for (int ch = 0; ch < d.nchunks; ++ch) {
+    const int buf = ch & 1;
+    __syncthreads();                                        // chunk ch landed (vmcnt(0) before the barrier); buf^1 is free
+    const bool more = ch + 1 < d.nchunks;
+    if (more) {
+      issue_weights(ch + 1, buf ^ 1);
+      if constexpr (AFF) load_halo_regs(ch + 1);
+      else issue_halo_dma(ch + 1, buf ^ 1);
+    }
+    const unsigned char* lds_halo = smem + buf * BUFB;
+    const unsigned char* lds_w = lds_halo + HPB;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {
+      u32x4 a[4], bb[NT];
+#pragma unroll
+      for (int mf = 0; mf < 4; ++mf) a[mf] = *(const u32x4*)(lds_halo + a_addr[mf][t]);
+#pragma unroll
+      for (int nf = 0; nf < NT; ++nf) bb[nf] = *(const u32x4*)(lds_w + t * BN * 64 + b_addr[nf]);
+#pragma unroll
+      for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+        for (int nf = 0; nf < NT; ++nf) mma16<T>(acc[mf][nf], a[mf], bb[nf]);
+    }
+    if constexpr (AFF) { if (more) store_halo_regs(ch + 1, buf ^ 1); }
+  }
+  igemm_epilogue<T, NT>(d, acc, smem, tid, wave, g, l15, b, oy0, ox0, n0, P);
+}
+
+template <typename T>
+int launch2(const ksmi_conv_desc* d, hipStream_t st) {
+  const int taps = d->KH * d->KW;
+  const int tilesX = (d->Wout + d->TW - 1) / d->TW, tilesY = (d->Hout + d->TH - 1) / d->TH;
+  const int gm = d->B * tilesX * tilesY;
+  const int HH = (d->TH - 1) * d->stride + d->KH, HW = (d->TW - 1) * d->stride + d->KW;
+  const int HP = HH * HW;
+  if (d->TH * d->TW > 256 || HP * 4 > 2048) return ksmi_fail(KSMI_E_ARG, "conv: patch too large (TH*TW<=256, halo<=512 px)");
+  const int nt = d->Npad >= 64 ? 4 : (d->Npad >= 32 ? 2 : 1);
+  const int bn = nt * 16;
+  const dim3 grid(gm, (d->Npad + bn - 1) / bn);
+  const size_t hpb = ((size_t)HP * 64 + 1023) & ~(size_t)1023;
+  size_t lds = 2 * (hpb + (size_t)taps * bn * 64);
+  const size_t tile = (size_t)d->TH * d->TW * (bn * sizeof(T) + 16);
+  if (lds < tile) lds = tile;
+  const bool aff = d->src[0].scale != nullptr;
+#define KSMI_L2(NT_, KH_, KW_, AFF_)                                                                \
+  do {                                                                                              \
+    auto kfn = igemm2_fwd_kernel<T, NT_, KH_, KW_, AFF_>;                                           \
+    if (lds > 65536) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, *d);                                          \
+  } while (0)
+#define KSMI_D2(KH_, KW_)                                                                           \
+  switch (nt) {                                                                                     \
+    case 1: if (aff) KSMI_L2(1, KH_, KW_, true); else KSMI_L2(1, KH_, KW_, false); break;           \
+    case 2: if (aff) KSMI_L2(2, KH_, KW_, true); else KSMI_L2(2, KH_, KW_, false); break;           \
+    default: if (aff) KSMI_L2(4, KH_, KW_, true); else KSMI_L2(4, KH_, KW_, false); break;          \
+  }
+  if (d->KH == 3 && d->KW == 3) { KSMI_D2(3, 3) }
+  else if (d->KH == 1 && d->KW == 1) { KSMI_D2(1, 1) }
+  else if (d->KH == 2 && d->KW == 2) { KSMI_D2(2, 2) }
+  else return ksmi_fail(KSMI_E_UNSUPPORTED, "conv: kernel size not supported");
+#undef KSMI_D2
+#undef KSMI_L2
+  return ksmi_check_launch("igemm2_fwd");
+}
+
+}  // namespace
+
+// eligibility: every source is a whole number of k-chunks and only source 0 may carry an affine
+bool ksmi_igemm2_eligible(const ksmi_conv_desc* d, int dtype) {
+  const int kc = dtype == KSMI_BF16 ? 32 : 16;
+  for (int i = 0; i < d->nsrc; ++i) {
+    if (d->src[i].c_len % kc) return false;
+    if (i > 0 && d->src[i].scale) return false;
+  }
+  if (d->src[0].scale && d->nsrc != 1) return false;
+  return true;
+}
+
+int ksmi_igemm2_launch(const ksmi_conv_desc* d, int dtype, hipStream_t st) {
+  if (dtype == KSMI_BF16) return launch2<bf16_t>(d, st);
+  return launch2<float>(d, st);
+}
