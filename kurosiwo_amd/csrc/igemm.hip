@@ -89,8 +89,8 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const ksmi_conv_desc d) 
   const T* wpk = (const T*)d.wpk;
 
   for (int ch = 0; ch < d.nchunks; ++ch) {
-    const ksmi_src& sr = d.src[d.chunk_src[ch]];
-    const int c0 = d.chunk_c0[ch];
+    const ksmi_src& sr = d.src[chunk_src_of(d, ch)];
+    const int c0 = chunk_c0_of(d, ch);
     __syncthreads();
     // ---- stage halo: global -> regs -> (affine, relu) -> LDS ---------------------------
     {

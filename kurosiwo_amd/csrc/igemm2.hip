@@ -9,6 +9,7 @@
 // One barrier per chunk; the DMA of chunk c+1 is in flight while the MFMAs of chunk c run.
 // With a fused BN-apply+ReLU operand (AFF) the halo goes through registers instead (transform,
 // ds_write); the weights still use DMA.
+#include <stdlib.h>
 #include "common.h"
 #include "../../include/ksmi.h"
 #include "errors.h"
@@ -44,6 +45,7 @@ __global__ __launch_bounds__(256) void igemm2_fwd_kernel(const ksmi_conv_desc d)
   const int HPB = (HP * 64 + 1023) & ~1023;                 // halo bytes, whole wave-instructions (1 KiB)
   const int BUFB = HPB + TAPS * BN * 64;                    // one stage
   const int nslot = HPB / 4096 + ((HPB % 4096) ? 1 : 0);    // 256 lanes x 16 B per slot-iteration
+  const FastDiv dHW(HW), dTW(d.TW);
 
   // ---- zero both halo images once (padding positions are never written afterwards) -----------
   for (int v = tid; v < HPB / 16; v += 256) {
@@ -61,7 +63,7 @@ __global__ __launch_bounds__(256) void igemm2_fwd_kernel(const ksmi_conv_desc d)
     slot_goff[s] = -1; slot_q[s] = 0; slot_lds[s] = 0;
     if (v < HP * 4) {
       const int pix = v >> 2, sl = v & 3;
-      const int hy = pix / HW, hx = pix - hy * HW;
+      const int hy = dHW.div(pix), hx = pix - hy * HW;
       const int iy = oy0 * S - d.pad + hy, ix = ox0 * S - d.pad + hx;
       if (iy >= 0 && iy < d.Hin && ix >= 0 && ix < d.Win) slot_goff[s] = (b * d.Hin + iy) * d.Win + ix;
       slot_q[s] = sl ^ swz(pix);
@@ -76,7 +78,7 @@ __global__ __launch_bounds__(256) void igemm2_fwd_kernel(const ksmi_conv_desc d)
   for (int mf = 0; mf < 4; ++mf) {
     int p = wave * 64 + mf * 16 + l15;
     if (p >= P) p = 0;
-    const int ly = p / d.TW, lx = p - ly * d.TW;
+    const int ly = dTW.div(p), lx = p - ly * d.TW;
     const int base = ly * S * HW + lx * S;
 #pragma unroll
     for (int t = 0; t < TAPS; ++t) {
@@ -120,8 +122,8 @@ __global__ __launch_bounds__(256) void igemm2_fwd_kernel(const ksmi_conv_desc d)
     }
   };
   auto issue_halo_dma = [&](int ch, int buf) {
-    const ksmi_src& sr = d.src[d.chunk_src[ch]];
-    const T* sp = (const T*)sr.ptr + sr.c_off + d.chunk_c0[ch];
+    const ksmi_src& sr = d.src[chunk_src_of(d, ch)];
+    const T* sp = (const T*)sr.ptr + sr.c_off + chunk_c0_of(d, ch);
     unsigned char* hdst = smem + buf * BUFB;
 #pragma unroll
     for (int s = 0; s < MAXSLOT; ++s) {
@@ -132,15 +134,15 @@ __global__ __launch_bounds__(256) void igemm2_fwd_kernel(const ksmi_conv_desc d)
     }
   };
   auto load_halo_regs = [&](int ch) {                      // AFF: thread owns k-group myq of its slot pixels
-    const ksmi_src& sr = d.src[d.chunk_src[ch]];
-    const T* sp = (const T*)sr.ptr + sr.c_off + d.chunk_c0[ch] + myq * VEC;
+    const ksmi_src& sr = d.src[chunk_src_of(d, ch)];
+    const T* sp = (const T*)sr.ptr + sr.c_off + chunk_c0_of(d, ch) + myq * VEC;
 #pragma unroll
     for (int s = 0; s < MAXSLOT; ++s)
       if (s < nslot && slot_goff[s] >= 0) hreg[AFF ? s : 0] = *(const u32x4*)(sp + (size_t)slot_goff[s] * sr.C);
   };
   auto store_halo_regs = [&](int ch, int buf) {
-    const ksmi_src& sr = d.src[d.chunk_src[ch]];
-    const int cq = d.chunk_c0[ch] + myq * VEC;
+    const ksmi_src& sr = d.src[chunk_src_of(d, ch)];
+    const int cq = chunk_c0_of(d, ch) + myq * VEC;
     float sc[VEC], sh[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) { sc[j] = sr.scale[cq + j]; sh[j] = sr.shift[cq + j]; }
@@ -165,32 +167,45 @@ __global__ __launch_bounds__(256) void igemm2_fwd_kernel(const ksmi_conv_desc d)
   if constexpr (AFF) { load_halo_regs(0); store_halo_regs(0, 0); }
   else issue_halo_dma(0, 0);
 
+  const int dbg = d.dst[KSMI_MAX_SRC - 1].pad_;            // profiling switches (KSMI_DBG): 1 no MFMA, 2 no DMA, 4 no epilogue
   for (int ch = 0; ch < d.nchunks; ++ch) {
     const int buf = ch & 1;
     __syncthreads();                                        // chunk ch landed (vmcnt(0) before the barrier); buf^1 is free
     const bool more = ch + 1 < d.nchunks;
-    if (more) {
+    if (more && !(dbg & 2)) {
       issue_weights(ch + 1, buf ^ 1);
       if constexpr (AFF) load_halo_regs(ch + 1);
       else issue_halo_dma(ch + 1, buf ^ 1);
     }
     const unsigned char* lds_halo = smem + buf * BUFB;
     const unsigned char* lds_w = lds_halo + HPB;
+    if (!(dbg & 1)) {
+    // fragments of tap t+1 are fetched from LDS while the MFMAs of tap t issue (one wave per SIMD:
+    // nothing else hides the LDS latency)
+    u32x4 fa[2][4], fb[2][NT];
+#pragma unroll
+    for (int mf = 0; mf < 4; ++mf) fa[0][mf] = *(const u32x4*)(lds_halo + a_addr[mf][0]);
+#pragma unroll
+    for (int nf = 0; nf < NT; ++nf) fb[0][nf] = *(const u32x4*)(lds_w + b_addr[nf]);
 #pragma unroll
     for (int t = 0; t < TAPS; ++t) {
-      u32x4 a[4], bb[NT];
+      constexpr int dummy = 0; (void)dummy;
+      const int cur = t & 1, nxt = cur ^ 1;
+      if (t + 1 < TAPS) {
 #pragma unroll
-      for (int mf = 0; mf < 4; ++mf) a[mf] = *(const u32x4*)(lds_halo + a_addr[mf][t]);
+        for (int mf = 0; mf < 4; ++mf) fa[nxt][mf] = *(const u32x4*)(lds_halo + a_addr[mf][t + 1]);
 #pragma unroll
-      for (int nf = 0; nf < NT; ++nf) bb[nf] = *(const u32x4*)(lds_w + t * BN * 64 + b_addr[nf]);
+        for (int nf = 0; nf < NT; ++nf) fb[nxt][nf] = *(const u32x4*)(lds_w + (t + 1) * BN * 64 + b_addr[nf]);
+      }
 #pragma unroll
       for (int mf = 0; mf < 4; ++mf)
 #pragma unroll
-        for (int nf = 0; nf < NT; ++nf) mma16<T>(acc[mf][nf], a[mf], bb[nf]);
+        for (int nf = 0; nf < NT; ++nf) mma16<T>(acc[mf][nf], fb[cur][nf], fa[cur][mf]);   // D = W * X^T (see epilogue)
+    }
     }
     if constexpr (AFF) { if (more) store_halo_regs(ch + 1, buf ^ 1); }
   }
-  igemm_epilogue<T, NT>(d, acc, smem, tid, wave, g, l15, b, oy0, ox0, n0, P);
+  if (!(dbg & 4)) igemm_epilogue_direct<T, NT>(d, acc, smem, tid, wave, g, l15, b, oy0, ox0, n0, P);
 }
 
 template <typename T>
@@ -206,8 +221,6 @@ int launch2(const ksmi_conv_desc* d, hipStream_t st) {
   const dim3 grid(gm, (d->Npad + bn - 1) / bn);
   const size_t hpb = ((size_t)HP * 64 + 1023) & ~(size_t)1023;
   size_t lds = 2 * (hpb + (size_t)taps * bn * 64);
-  const size_t tile = (size_t)d->TH * d->TW * (bn * sizeof(T) + 16);
-  if (lds < tile) lds = tile;
   const bool aff = d->src[0].scale != nullptr;
 #define KSMI_L2(NT_, KH_, KW_, AFF_)                                                                \
   do {                                                                                              \
@@ -243,7 +256,11 @@ bool ksmi_igemm2_eligible(const ksmi_conv_desc* d, int dtype) {
   return true;
 }
 
-int ksmi_igemm2_launch(const ksmi_conv_desc* d, int dtype, hipStream_t st) {
+int ksmi_igemm2_launch(const ksmi_conv_desc* d0, int dtype, hipStream_t st) {
+  static const int dbg = getenv("KSMI_DBG") ? atoi(getenv("KSMI_DBG")) : 0;
+  ksmi_conv_desc dd = *d0;
+  dd.dst[KSMI_MAX_SRC - 1].pad_ = dbg;
+  const ksmi_conv_desc* d = &dd;
   if (dtype == KSMI_BF16) return launch2<bf16_t>(d, st);
   return launch2<float>(d, st);
 }

@@ -7,11 +7,31 @@
 // ds_read_b128 for 16 consecutive rows; derivation in DESIGN.md §LDS).
 __device__ __forceinline__ int swz(int row) { return (0 - (row >> 2)) & 3; }
 
+// Exact unsigned division by a runtime constant with one v_mul_hi_u32: q = umulhi(p, floor(2^32/d)+1)
+// (exact for p*d < 2^32; all uses have p <= 2048, d <= 512).  d == 1 is handled by the caller's struct.
+struct FastDiv {
+  uint32_t magic; int d;
+  __device__ __forceinline__ explicit FastDiv(int dd) : magic(dd > 1 ? (uint32_t)(4294967296.0 / (double)dd) + 1u : 0u), d(dd) {}
+  __device__ __forceinline__ int div(int p) const { return d > 1 ? (int)__umulhi((uint32_t)p, magic) : p; }
+};
+
+// k-chunk table lookups as 32-bit scalar loads: a dynamically indexed uint8/uint16 kernarg array is
+// fetched with global_load_ubyte/ushort (VMEM), and hipcc then waits vmcnt(0) -- draining every LDS-DMA
+// in flight -- before the value can be used.  A uniform dword index keeps it on the scalar path.
+__device__ __forceinline__ int chunk_c0_of(const ksmi_conv_desc& d, int ch) {
+  const uint32_t w = ((const uint32_t*)d.chunk_c0)[ch >> 1];
+  return (ch & 1) ? (int)(w >> 16) : (int)(w & 0xffffu);
+}
+__device__ __forceinline__ int chunk_src_of(const ksmi_conv_desc& d, int ch) {
+  return (int)((((const uint32_t*)d.chunk_src)[ch >> 2] >> ((ch & 3) * 8)) & 0xffu);
+}
+
 template <typename T, int NT>
 __device__ __forceinline__ void igemm_epilogue(const ksmi_conv_desc& d, f32x4 (&acc)[4][NT], unsigned char* smem, int tid,
                                                int wave, int g, int l15, int b, int oy0, int ox0, int n0, int P) {
   constexpr int BN = NT * 16;
   constexpr int VEC = ElemTraits<T>::kVec;
+  const FastDiv dTW(d.TW);
   // ---- epilogue ---------------------------------------------------------------------------------
   // phase 1: accumulators (+bias) -> LDS tile [P][BN] in T (C layout: col n = l15, row = g*4 + r);
   //          plain BatchNorm statistics (sum, sumsq) straight from the fp32 registers.
@@ -27,7 +47,7 @@ __device__ __forceinline__ void igemm_epilogue(const ksmi_conv_desc& d, f32x4 (&
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int p = wave * 64 + mf * 16 + g * 4 + r;
-      const int ly = p / d.TW, lx = p - ly * d.TW;
+      const int ly = dTW.div(p), lx = p - ly * d.TW;
       rvalid[mf][r] = p < P && (oy0 + ly) < d.Hout && (ox0 + lx) < d.Wout;
     }
   __syncthreads();                                       // every wave is done reading halo / weights
@@ -69,7 +89,7 @@ __device__ __forceinline__ void igemm_epilogue(const ksmi_conv_desc& d, f32x4 (&
       }
     }
     for (int p = tid / VPR; p < P; p += 256 / VPR) {
-      const int ly = p / d.TW, lx = p - ly * d.TW;
+      const int ly = dTW.div(p), lx = p - ly * d.TW;
       const int oy = oy0 + ly, ox = ox0 + lx;
       if (oy >= d.Hout || ox >= d.Wout) continue;
       float v[VEC];
@@ -156,6 +176,149 @@ __device__ __forceinline__ void igemm_epilogue(const ksmi_conv_desc& d, f32x4 (&
         const float v = red[(0 * 2 + which) * BN + n] + red[(1 * 2 + which) * BN + n] + red[(2 * 2 + which) * BN + n] + red[(3 * 2 + which) * BN + n];
         if (n0 + n < d.Npad) d.stats[((size_t)blockIdx.x * 2 + which) * d.Npad + n0 + n] = v;
       }
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+// Direct epilogue for the swapped-operand MFMA (D = W * X^T): acc[mf][nf][r] holds
+//   out[pixel = wave*64 + mf*16 + l15][n = n0 + nf*16 + g*4 + r]
+// i.e. every lane owns 4 CONSECUTIVE channels of a pixel -> one 8-byte (bf16) / 16-byte (fp32) global
+// access per (mf, nf), no LDS staging and no barrier.  Same features as igemm_epilogue.
+// -------------------------------------------------------------------------------------------------
+template <typename T> struct Quad;   // 4 consecutive elements of T as one vector access
+template <> struct Quad<float> {
+  __device__ static __forceinline__ void ld(const float* p, float* f) { const f32x4 v = *(const f32x4*)p; f[0] = v[0]; f[1] = v[1]; f[2] = v[2]; f[3] = v[3]; }
+  __device__ static __forceinline__ void st(float* p, const float* f) { *(f32x4*)p = (f32x4){f[0], f[1], f[2], f[3]}; }
+};
+template <> struct Quad<bf16_t> {
+  __device__ static __forceinline__ void ld(const bf16_t* p, float* f) {
+    const uint2 v = *(const uint2*)p;
+    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+  }
+  __device__ static __forceinline__ void st(bf16_t* p, const float* f) {
+    uint2 v;
+    v.x = (uint32_t)f32_to_bf16(f[0]) | ((uint32_t)f32_to_bf16(f[1]) << 16);
+    v.y = (uint32_t)f32_to_bf16(f[2]) | ((uint32_t)f32_to_bf16(f[3]) << 16);
+    *(uint2*)p = v;
+  }
+};
+
+template <typename T, int NT>
+__device__ __forceinline__ void igemm_epilogue_direct(const ksmi_conv_desc& d, f32x4 (&acc)[4][NT], unsigned char* smem, int tid,
+                                                      int wave, int g, int l15, int b, int oy0, int ox0, int n0, int P) {
+  constexpr int BN = NT * 16;
+  const FastDiv dTW(d.TW);
+  size_t opix[4];
+  bool pv[4];
+  int oyv[4], oxv[4];
+#pragma unroll
+  for (int mf = 0; mf < 4; ++mf) {
+    const int p = wave * 64 + mf * 16 + l15;
+    const int ly = dTW.div(p), lx = p - ly * d.TW;
+    oyv[mf] = oy0 + ly; oxv[mf] = ox0 + lx;
+    pv[mf] = p < P && oyv[mf] < d.Hout && oxv[mf] < d.Wout;
+    opix[mf] = ((size_t)b * d.Hout + oyv[mf]) * d.Wout + oxv[mf];
+  }
+  float ssum[NT][4], ssq[NT][4];
+#pragma unroll
+  for (int nf = 0; nf < NT; ++nf) {
+    const int n4 = n0 + nf * 16 + g * 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { ssum[nf][r] = 0.f; ssq[nf][r] = 0.f; }
+    if (n4 >= d.N) continue;
+    const int nval = min(4, d.N - n4);
+    int si = 0;
+    for (int k = 1; k < d.ndst; ++k) if (n4 >= d.dst[k].n_begin) si = k;
+    const ksmi_dst& ds = d.dst[si];
+    const bool vec_ok = nval == 4 && ((ds.C | ds.c_off | (n4 - ds.n_begin) | d.N) & 3) == 0 && (d.ps_cout & 3) == 0;
+    float bias[4] = {0.f, 0.f, 0.f, 0.f};
+    if (d.bias)
+      for (int r = 0; r < nval; ++r) bias[r] = d.bias[d.ps_cout > 0 ? (n4 + r) % d.ps_cout : (n4 + r)];
+    float mm[4], mr[4], mg[4], mb[4];
+    if (d.mask_src)
+      for (int r = 0; r < 4; ++r) {
+        const int n = min(n4 + r, d.N - 1);
+        mm[r] = d.m_mean[n]; mr[r] = d.m_rstd[n]; mg[r] = d.m_scale[n]; mb[r] = d.m_shift[n];
+      }
+    int dd = 0, nn = n4 - ds.n_begin;
+    if (d.ps_cout > 0) { dd = n4 / d.ps_cout; nn = n4 - dd * d.ps_cout; }
+#pragma unroll
+    for (int mf = 0; mf < 4; ++mf) {
+      if (!pv[mf]) continue;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[mf][nf][r] + bias[r];
+      if (d.mask_src) {
+        float m[4] = {0.f, 0.f, 0.f, 0.f};
+        const T* mp = (const T*)d.mask_src + opix[mf] * d.N + n4;
+        if (vec_ok) Quad<T>::ld(mp, m);
+        else for (int r = 0; r < nval; ++r) m[r] = ElemTraits<T>::ld(mp + r);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float xh = (m[r] - mm[r]) * mr[r];
+          if (!(m[r] * mg[r] + mb[r] > 0.f)) v[r] = 0.f;
+          if (r < nval) { ssum[nf][r] += v[r]; ssq[nf][r] += v[r] * xh; }
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (r < nval) { ssum[nf][r] += v[r]; ssq[nf][r] += v[r] * v[r]; }
+      }
+      T* dp;
+      if (d.ps_cout > 0) {
+        const size_t op2 = ((size_t)b * (2 * d.Hout) + (2 * oyv[mf] + (dd >> 1))) * (2 * d.Wout) + (2 * oxv[mf] + (dd & 1));
+        dp = (T*)ds.ptr + op2 * ds.C + ds.c_off + nn;
+      } else {
+        dp = (T*)ds.ptr + opix[mf] * ds.C + ds.c_off + nn;
+      }
+      if (vec_ok) {
+        if (ds.accumulate) {
+          float o[4];
+          Quad<T>::ld(dp, o);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += o[r];
+        }
+        Quad<T>::st(dp, v);
+      } else {
+        for (int r = 0; r < nval; ++r) {
+          const int n = n4 + r;
+          int sj = 0;
+          for (int k = 1; k < d.ndst; ++k) if (n >= d.dst[k].n_begin) sj = k;
+          const ksmi_dst& dj = d.dst[sj];
+          T* q;
+          if (d.ps_cout > 0) {
+            const int d2 = n / d.ps_cout, n2 = n - d2 * d.ps_cout;
+            const size_t op2 = ((size_t)b * (2 * d.Hout) + (2 * oyv[mf] + (d2 >> 1))) * (2 * d.Wout) + (2 * oxv[mf] + (d2 & 1));
+            q = (T*)dj.ptr + op2 * dj.C + dj.c_off + n2;
+          } else {
+            q = (T*)dj.ptr + opix[mf] * dj.C + dj.c_off + (n - dj.n_begin);
+          }
+          float o = v[r];
+          if (dj.accumulate) o += ElemTraits<T>::ld(q);
+          ElemTraits<T>::st(q, o);
+        }
+      }
+    }
+  }
+  if (d.stats) {
+    // reduce over the 16 pixel lanes (l15) of each k-group, then over the 4 waves through LDS
+    __syncthreads();                                     // (all waves are past their last LDS reads)
+    float* red = (float*)smem;                           // [4 waves][2][BN]
+#pragma unroll
+    for (int nf = 0; nf < NT; ++nf)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float a = ssum[nf][r], q = ssq[nf][r];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); q += __shfl_xor(q, o, 64); }
+        if (l15 == 0) { red[(wave * 2 + 0) * BN + nf * 16 + g * 4 + r] = a; red[(wave * 2 + 1) * BN + nf * 16 + g * 4 + r] = q; }
+      }
+    __syncthreads();
+    if (tid < 2 * BN) {
+      const int which = tid / BN, n = tid - which * BN;
+      const float v = red[(0 * 2 + which) * BN + n] + red[(1 * 2 + which) * BN + n] + red[(2 * 2 + which) * BN + n] + red[(3 * 2 + which) * BN + n];
+      if (n0 + n < d.Npad) d.stats[((size_t)blockIdx.x * 2 + which) * d.Npad + n0 + n] = v;
     }
   }
 }

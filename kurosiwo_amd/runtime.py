@@ -70,6 +70,10 @@ class SrcSpec:
 def choose_patch(H, W, stride=1, KH=3, KW=3, max_pix=256, max_halo=512):
     """Pick the output patch (TH, TW) of a workgroup: maximise useful pixels per 256-row
     M-tile, then minimise halo area."""
+    import os
+    if os.environ.get("KSMI_PATCH"):                      # experiment override "TH,TW"
+        th, tw = (int(v) for v in os.environ["KSMI_PATCH"].split(","))
+        return min(th, H), min(tw, W)
     best = None
     for tw in range(1, min(W, 256) + 1):
         for th in range(1, min(H, max_pix // tw) + 1):
@@ -77,8 +81,8 @@ def choose_patch(H, W, stride=1, KH=3, KW=3, max_pix=256, max_halo=512):
             if hp > max_halo:
                 continue
             tiles = -(-H // th) * -(-W // tw)
-            mfrag = -(-(th * tw) // 64) * 64      # waves work in 64-pixel quanta
-            cost = tiles * max(mfrag, 64) * (1.0 + 0.15 * hp / (th * tw))
+            # a workgroup always issues the MFMAs of a full 256-row M tile (4 waves x 4 fragments x 16)
+            cost = tiles * 256 * (1.0 + 0.15 * hp / 256.0)
             key = (cost, hp)
             if best is None or key < best[0]:
                 best = (key, th, tw)
