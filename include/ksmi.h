@@ -133,6 +133,9 @@ int ksmi_conv_wgrad(const ksmi_wgrad_desc* d, int dtype, void* stream);
 int ksmi_conv_first_forward(const float* x_nchw, const float* w, const float* bias, void* out, float* stats,
                             int B, int Cin, int H, int W, int Cout, int dtype, void* stream);
 int ksmi_conv_first_stats_rows(int B, int H, int W);
+/* im2col of the raw image: out[b,y,x,c*9+t] (NHWC `dtype`, Kpad channels, zero padded); the first conv and its
+ * weight gradient then run on the MFMA implicit-GEMM kernels as a 1x1 conv (k = c*9+t = OIHW flattening). */
+int ksmi_im2col3x3(const float* x_nchw, void* out, int B, int Cin, int H, int W, int Kpad, int dtype, void* stream);
 int ksmi_conv_first_wgrad(const float* x_nchw, const void* dy, float* dw, float* workspace, size_t ws_bytes,
                           int B, int Cin, int H, int W, int Cout, int accumulate, int dtype, void* stream);
 size_t ksmi_conv_first_wgrad_workspace(int B, int Cin, int H, int W, int Cout);

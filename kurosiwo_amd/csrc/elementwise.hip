@@ -374,6 +374,42 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const float* __rest
   }
 }
 
+// im2col of the raw image for the first 3x3 conv: out[b,y,x, c*9 + t] = x[b,c,y+t/3-1,x+t%3-1] (zero padded,
+// channels >= Cin*9 zero).  The first conv and its weight gradient then run on the MFMA implicit-GEMM kernels
+// as a 1x1 convolution over these Kpad "channels" (k = c*9 + t matches the OIHW flattening of the weight).
+template <typename T>
+__global__ __launch_bounds__(256) void im2col3x3_kernel(const float* __restrict__ x, T* out, int B, int Cin, int H, int W, int Kpad) {
+  constexpr int VEC = ElemTraits<T>::kVec;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* xs = (float*)smem;                       // [Cin][18][18]
+  const int tilesX = (W + 15) / 16, tilesY = (H + 15) / 16;
+  int bm = blockIdx.x;
+  const int tx = bm % tilesX; bm /= tilesX;
+  const int ty = bm % tilesY; const int b = bm / tilesY;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < Cin * 324; i += 256) {
+    const int c = i / 324, r = i - c * 324, hy = r / 18, hx = r - hy * 18;
+    const int iy = ty * 16 - 1 + hy, ix = tx * 16 - 1 + hx;
+    xs[i] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? x[(((int64_t)b * Cin + c) * H + iy) * W + ix] : 0.f;
+  }
+  __syncthreads();
+  const int KV = Kpad / VEC;                      // vectors per pixel
+  for (int v = tid; v < 256 * KV; v += 256) {
+    const int p = v / KV, q = v - p * KV;
+    const int ly = p >> 4, lx = p & 15;
+    const int oy = ty * 16 + ly, ox = tx * 16 + lx;
+    if (oy >= H || ox >= W) continue;
+    float f[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const int k = q * VEC + j;
+      const int c = k / 9, t = k - c * 9;
+      f[j] = c < Cin ? xs[c * 324 + (ly + t / 3) * 18 + lx + t % 3] : 0.f;
+    }
+    *(u32x4*)(out + (((int64_t)b * H + oy) * W + ox) * Kpad + q * VEC) = vec_pack<T>(f);
+  }
+}
+
 // first-layer weight gradient: partial[blk][n][c*9+t] = sum over the block's patches
 template <typename T>
 __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float* x, const T* dy, float* partial,
@@ -692,6 +728,17 @@ int ksmi_conv_first_wgrad(const float* x, const void* dy, float* dw, float* work
   const int64_t n = (int64_t)Cout * Cin * 9;
   hipLaunchKernelGGL(sum_rows_flat_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, workspace, blocks, n, dw, accumulate);
   return ksmi_check_launch("conv_first_wgrad_reduce");
+}
+
+int ksmi_im2col3x3(const float* x_nchw, void* out, int B, int Cin, int H, int W, int Kpad, int dtype, void* stream) {
+  const int vec = dtype == KSMI_BF16 ? 8 : 4;
+  if (Cin < 1 || Cin * 9 > Kpad || Kpad % vec || Cin > 32) return ksmi_fail(KSMI_E_ARG, "im2col3x3: need Cin*9 <= Kpad, Kpad multiple of the vector");
+  const int grid = B * ((H + 15) / 16) * ((W + 15) / 16);
+  const size_t lds = (size_t)Cin * 324 * sizeof(float);
+  KSMI_DT(dtype,
+          hipLaunchKernelGGL(im2col3x3_kernel<bf16_t>, dim3(grid), dim3(256), lds, (hipStream_t)stream, x_nchw, (bf16_t*)out, B, Cin, H, W, Kpad),
+          hipLaunchKernelGGL(im2col3x3_kernel<float>, dim3(grid), dim3(256), lds, (hipStream_t)stream, x_nchw, (float*)out, B, Cin, H, W, Kpad));
+  return ksmi_check_launch("im2col3x3");
 }
 
 int ksmi_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int64_t* step_count, float lr, float beta1,

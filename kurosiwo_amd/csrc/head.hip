@@ -7,7 +7,7 @@
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kPoolSplit = 64;       // pixel splits per image for the global pools
+constexpr int kPoolSplit = 16;       // pixel splits per image for the global pools
 constexpr int kBwdSplit = 64;
 
 // ------------------------------------------------------------------------------------------------

@@ -219,6 +219,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const ksmi_wgrad_desc 
   const int P = d.TH * d.TW;
   const int Ppad = (P + KSTEP - 1) / KSTEP * KSTEP;
   const int tilesX = (d.Wout + d.TW - 1) / d.TW, tilesY = (d.Hout + d.TH - 1) / d.TH;
+  const FastDiv dTW(d.TW), dHW(HW);
   // LDS: X halo [HP][KC] (64 B rows, unswizzled) ; dY tile [Ppad][BN] (BN*ES bytes per row)
   unsigned char* lds_x = smem;
   unsigned char* lds_dy = smem + ((HP * 64 + 255) & ~255);
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const ksmi_wgrad_desc 
       const T* sp = (const T*)sr.ptr + sr.c_off + cq;
       for (int v = tid; v < HP * 4; v += 256) {
         const int pix = v >> 2;
-        const int hy = pix / HW, hx = pix - hy * HW;
+        const int hy = dHW.div(pix), hx = pix - hy * HW;
         const int iy = oy0 * S - d.pad + hy, ix = ox0 * S - d.pad + hx;
         u32x4 x = (u32x4){0u, 0u, 0u, 0u};
         if (cvalid && iy >= 0 && iy < d.Hin && ix >= 0 && ix < d.Win) {
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const ksmi_wgrad_desc 
       const T* dyp = (const T*)d.dy + d.dy_c_off + n0;
       for (int v = tid; v < Ppad * VPR; v += 256) {
         const int p = v / VPR, q = v - p * VPR;
-        const int ly = p / d.TW, lx = p - ly * d.TW;
+        const int ly = dTW.div(p), lx = p - ly * d.TW;
         const int oy = oy0 + ly, ox = ox0 + lx;
         u32x4 x = (u32x4){0u, 0u, 0u, 0u};
         if (p < P && oy < d.Hout && ox < d.Wout && n0 + q * VEC < d.N)
@@ -320,7 +321,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const ksmi_wgrad_desc 
           if constexpr (sizeof(T) == 2) {
             auto rowaddr = [&](int j) -> unsigned {
               int p = ks + g * 8 + j; if (p >= P) p = 0;      // dY rows >= P are zero
-              const int ly = p / d.TW, lx = p - ly * d.TW;
+              const int ly = dTW.div(p), lx = p - ly * d.TW;
               return (unsigned)(uintptr_t)(lds_x) + (ly * S * HW + lx * S + toff) * 64 + cf * 32;
             };
             afrag = TrRead<bf16_t>::read(rowaddr, l15);
@@ -328,7 +329,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const ksmi_wgrad_desc 
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
               int p = ks + g * 4 + s; if (p >= P) p = 0;
-              const int ly = p / d.TW, lx = p - ly * d.TW;
+              const int ly = dTW.div(p), lx = p - ly * d.TW;
               afrag[s] = *(const uint32_t*)(lds_x + (ly * S * HW + lx * S + toff) * 64 + l15 * 4);
             }
           }

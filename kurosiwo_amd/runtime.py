@@ -45,6 +45,7 @@ class Act:
         self.g = None
         self.needs_grad = needs_grad
         self.ginit = False        # has some backward op already written self.g (plan-build-time tracking)
+        self.consumers = []       # (di tensor, C_di, conv weight key, channel offset in that conv's K, Ktot) of 3x3 convs reading this
         self.dtype, self.device = dtype, device
 
     def grad(self):
