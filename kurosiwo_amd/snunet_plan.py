@@ -274,26 +274,22 @@ class SNUNetPlan:
 
         # ---- conv1 ----------------------------------------------------------------------
         if first:
-            # raw NCHW image -> im2col [B,H,W,Kpad] (k = c*9+t) -> 1x1 implicit GEMM on the MFMA path
+            # forward: direct fp32 conv on the raw NCHW image (exact fp32 operands even in bf16 mode: quantising
+            # the input image to bf16 costs ~2 points of gradient cosine downstream).  For the weight gradient
+            # the image is also laid out as im2col [B,H,W,Kpad] (k = c*9+t) so dW runs on the MFMA wgrad kernel.
             x_img = sources[0]
             cin = x_img.shape[1]
             kc = 32 if dtype == torch.bfloat16 else 16
             Kpad = -(-(cin * 9) // kc) * kc
-            col = torch.empty((B, H, W, Kpad), dtype=dtype, device=self.dev)
-            self.keep.append(col)
-            self.fwd.add("ksmi_im2col3x3", lambda: (x_img.data_ptr(), col.data_ptr(), B, cin, H, W, Kpad, dt))
-            Ktot = cin
-            src1 = [SrcSpec(col, Kpad)]
-            d1, t1 = make_conv(src1, [(i_act.t, Cc, 0, 0, Cc, 0)], i_act.t, m._p(f"{name}.conv1.bias"), None,
-                               B, H, W, H, W, 1, 1, 1, 0, Cc, dtype)
-            t1w = [(si, c0, kg, max(0, min(kl, cin * 9 - kg))) for (si, c0, kg, kl) in t1]   # k >= Cin*9 is padding
-            w1 = self._packed(f"{name}.conv1.weight", t1w, 1, Cc, Cc, 1, cin * 9, 0, 0, 0)
-            d1.wpk = w1.data_ptr()
-            rows1, cpad1 = conv_grid_m(d1), Npad
-            if training:
-                self.need("stats", rows1 * 2 * Npad * 4)
-                self.patch(d1, "stats", "stats")
-            self._conv(self.fwd, d1)
+            rows1, cpad1, Ktot = self.lib.ksmi_conv_first_stats_rows(B, H, W), Cc, cin
+            self.need("stats", rows1 * 2 * Cc * 4)
+            self.fwd.add("ksmi_conv_first_forward", lambda: (x_img.data_ptr(), P("conv1.weight"), P("conv1.bias"),
+                                                             i_act.t.data_ptr(), stats(), B, cin, H, W, Cc, dt))
+            if self.with_backward:
+                col = torch.empty((B, H, W, Kpad), dtype=dtype, device=self.dev)
+                self.keep.append(col)
+                self.fwd.add("ksmi_im2col3x3", lambda: (x_img.data_ptr(), col.data_ptr(), B, cin, H, W, Kpad, dt))
+                src1 = [SrcSpec(col, Kpad)]
         else:
             srcs = [SrcSpec(a.t, a.C) for a in sources]
             Ktot = sum(a.C for a in sources)
