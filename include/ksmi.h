@@ -103,6 +103,8 @@ typedef struct ksmi_pack_desc {
   int32_t k_len[KSMI_MAX_CHUNKS];
 } ksmi_pack_desc;
 int ksmi_pack_weights(const ksmi_pack_desc* d, int dtype, void* stream);
+/* n descriptors stored in DEVICE memory, packed by one launch (a model plan re-packs every conv each step) */
+int ksmi_pack_weights_batched(const ksmi_pack_desc* descs_device, int n, int dtype, void* stream);
 
 /* Weight gradient: G[tap][k][n] = sum_pixels X[p*stride+tap-pad][k] * dY[p][n], X = virtual
  * concat (with the same optional affine+ReLU on load), reduced over all pixels with a
@@ -144,7 +146,8 @@ size_t ksmi_conv_first_wgrad_workspace(int B, int Cin, int H, int W, int Cout);
  * BatchNorm2d (train: batch statistics) + the conv_block_nested glue,
  * models/snunet.py:16,18,19-29 (nn.BatchNorm2d defaults eps 1e-5, momentum 0.1).
  * ------------------------------------------------------------------------------- */
-/* partial [rows][2][Cpad] (sum, sumsq) -> mean, rstd, scale=gamma*rstd, shift=beta-mean*scale;
+/* NOTE: `partial` of ksmi_bn_finalize / ksmi_reduce_rows is scratch: long row lists are folded IN PLACE first.
+ * partial [rows][2][Cpad] (sum, sumsq) -> mean, rstd, scale=gamma*rstd, shift=beta-mean*scale;
  * updates running_mean/var (unbiased var) and num_batches_tracked (int64) when training.
  * training==0: scale/shift from the running statistics. */
 int ksmi_bn_finalize(const float* partial, int rows, int Cpad, int C, double count,

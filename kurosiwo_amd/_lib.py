@@ -71,6 +71,7 @@ SIGNATURES = {
     "ksmi_conv_grid_m": (_i, [C.POINTER(ConvDesc)]),
     "ksmi_conv_forward": (_i, [C.POINTER(ConvDesc), _i, _vp]),
     "ksmi_pack_weights": (_i, [C.POINTER(PackDesc), _i, _vp]),
+    "ksmi_pack_weights_batched": (_i, [_vp, _i, _i, _vp]),
     "ksmi_conv_wgrad_workspace": (_sz, [C.POINTER(WgradDesc), _i]),
     "ksmi_conv_wgrad": (_i, [C.POINTER(WgradDesc), _i, _vp]),
     "ksmi_conv_first_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

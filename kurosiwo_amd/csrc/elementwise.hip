@@ -87,6 +87,34 @@ __global__ void bn_finalize_kernel(const float* partial, int rows, int Cpad, int
   if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
 }
 
+// Stage 1 of long row reductions, IN PLACE: block (channel group, r) folds rows r, r+R, r+2R, ... into row r
+// (fp64 accumulate), so the latency-bound finalize kernels below only walk R rows instead of thousands.
+__global__ void rows_fold_kernel(float* partial, int rows, int K, int Cstride, int C, int R) {
+  __shared__ double red[16][17];
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl, r0 = blockIdx.y;
+  for (int k = 0; k < K; ++k) {
+    double s = 0.0;
+    if (c < C)
+      for (int r = r0 + R * rl; r < rows; r += R * 16) s += (double)partial[((size_t)r * K + k) * Cstride + c];
+    __syncthreads();
+    red[rl][cl] = s;
+    __syncthreads();
+    if (threadIdx.x < 16 && c < C) {
+      s = 0.0;
+      for (int r = 0; r < 16; ++r) s += red[r][cl];
+      partial[((size_t)r0 * K + k) * Cstride + c] = (float)s;
+    }
+  }
+}
+
+static int fold_rows(float* partial, int rows, int K, int Cstride, int C, hipStream_t st) {
+  constexpr int R = 32;
+  if (rows <= 4 * R) return rows;
+  hipLaunchKernelGGL(rows_fold_kernel, dim3((C + 15) / 16, R), dim3(256), 0, st, partial, rows, K, Cstride, C, R);
+  return R;
+}
+
 // sums[k][c] = sum_rows partial[row][k][c]; optional accumulate into dgamma (k=1) / dbeta (k=0)
 __global__ void reduce_rows_kernel(const float* partial, int rows, int K, int Cstride, int C, float* sums,
                                    float* dgamma, float* dbeta, int accumulate) {
@@ -580,6 +608,7 @@ int ksmi_bn_finalize(const float* partial, int rows, int Cpad, int C, double cou
                      float* running_mean, float* running_var, int64_t* nbt, float momentum, float eps, int training,
                      float* mean, float* rstd, float* scale, float* shift, void* stream) {
   if (C < 1 || (training && (!partial || rows < 1))) return ksmi_fail(KSMI_E_ARG, "bn_finalize: bad args");
+  if (training) rows = fold_rows((float*)partial, rows, 2, Cpad, C, (hipStream_t)stream);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, (hipStream_t)stream, partial, rows, Cpad, C, count,
                      gamma, beta, running_mean, running_var, nbt, momentum, eps, training, mean, rstd, scale, shift);
   return ksmi_check_launch("bn_finalize");
@@ -588,6 +617,7 @@ int ksmi_bn_finalize(const float* partial, int rows, int Cpad, int C, double cou
 int ksmi_reduce_rows(const float* partial, int rows, int K, int Cstride, int C, float* sums, float* dgamma, float* dbeta,
                      int accumulate, void* stream) {
   if (rows < 1 || K < 1 || C < 1 || Cstride < C) return ksmi_fail(KSMI_E_ARG, "reduce_rows: bad args");
+  rows = fold_rows((float*)partial, rows, K, Cstride, C, (hipStream_t)stream);
   hipLaunchKernelGGL(reduce_rows_kernel, dim3((C + 15) / 16), dim3(1024), 0, (hipStream_t)stream, partial, rows, K, Cstride, C, sums,
                      dgamma, dbeta, accumulate);
   return ksmi_check_launch("reduce_rows");

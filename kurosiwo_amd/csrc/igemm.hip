@@ -174,6 +174,29 @@ __global__ void pack_weights_kernel(const ksmi_pack_desc d) {
   }
 }
 
+// all packs of a plan in ONE launch: descs live in device memory, blockIdx.y selects the descriptor
+template <typename T>
+__global__ void pack_weights_batched_kernel(const ksmi_pack_desc* descs) {
+  constexpr int KC = ElemTraits<T>::kVec * 4;
+  const ksmi_pack_desc& d = descs[blockIdx.y];
+  const int nchunks = d.nchunks, taps = d.taps, Npad = d.Npad, N = d.N, n_mod = d.n_mod, flip = d.flip;
+  const int64_t sK = d.sK, sN = d.sN, sD = d.sD, sT = d.sT;
+  const float* w = d.w; T* out = (T*)d.out;
+  const size_t total = (size_t)nchunks * taps * Npad * KC;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int kk = i % KC; size_t r = i / KC;
+    const int j = r % Npad; r /= Npad;
+    const int tap = r % taps; const int ch = r / taps;
+    float v = 0.f;
+    if (j < N && kk < d.k_len[ch]) {
+      const int64_t k = d.k_off[ch] + kk;
+      const int tp = flip ? (taps - 1 - tap) : tap;
+      v = w[k * sK + (int64_t)(j % n_mod) * sN + (int64_t)(j / n_mod) * sD + tp * sT];
+    }
+    ElemTraits<T>::st(out + i, v);
+  }
+}
+
 // -------------------------------------------------------------------------------------------------
 // weight gradient: per (pixel-split, chunk, N-tile) workgroup accumulates
 //   G[tap][kc][n] = sum_p X[p*S + tap - pad][kc] * dY[p][n]  over its patches.
@@ -198,6 +221,21 @@ template <> struct TrRead<bf16_t> {
   }
 };
 
+// LDS images of the weight-gradient kernel, swizzled at 32-byte granules (= one 16-column fragment row) so that
+// the 2 x 32 lanes of a ds_read_b64_tr_b16 (4 rows x 32 B per 16-lane group; rows p..p+3 and p+8..p+11) land on
+// 8 distinct 32-byte bank groups (unswizzled: 2-way on the X tile, 4-way on the dY tile; rocprofv3 showed
+// SQ_LDS_BANK_CONFLICT = 58 % of SQ_LDS_IDX_ACTIVE):
+//   X halo tile [halo pixel][64 B]        granule' = granule ^ ((hp >> 3) & 1)
+//   dY tile     [pixel row][GR * 32 B]    granule' = granule ^ f(row),  f = (row>>1 & 1) | (row>>3 & 1) << 1   (row & 7 for GR = 8)
+__device__ __forceinline__ int wg_x_off(int hp, int byte) {
+  return hp * 64 + ((((byte >> 5) ^ (hp >> 3)) & 1) << 5) + (byte & 31);
+}
+template <int GR>
+__device__ __forceinline__ int wg_dy_off(int row, int byte) {
+  const int f = GR >= 8 ? (row & 7) : ((((row >> 1) & 1) | (((row >> 3) & 1) << 1)) & (GR - 1));
+  return row * (GR * 32) + ((((byte >> 5) ^ f) & (GR - 1)) << 5) + (byte & 31);
+}
+
 template <typename T, int NT, int KH, int KW>
 __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const ksmi_wgrad_desc d, int patches_total, int patches_per_split) {
   constexpr int TAPS = KH * KW;
@@ -208,6 +246,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const ksmi_wgrad_desc 
   constexpr int KSTEP = KC;                    // pixels per MFMA k-step (32 bf16 / 16 fp32)
   constexpr int TPW = (TAPS + 3) / 4;          // taps per wave
   constexpr int ES = sizeof(T);
+  constexpr int GR = (BN * ES / 32) > 0 ? (BN * ES / 32) : 1;   // 32-byte granules per dY row
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -274,7 +313,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const ksmi_wgrad_desc 
             x = vec_pack<T>(f);
           }
         }
-        *(u32x4*)(lds_x + pix * 64 + myq * 16) = x;
+        *(u32x4*)(lds_x + wg_x_off(pix, myq * 16)) = x;
       }
     }
     // ---- stage dY tile [Ppad][BN] (zero rows for invalid pixels) ------------------------------
@@ -288,7 +327,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const ksmi_wgrad_desc 
         u32x4 x = (u32x4){0u, 0u, 0u, 0u};
         if (p < P && oy < d.Hout && ox < d.Wout && n0 + q * VEC < d.N)
           x = *(const u32x4*)(dyp + ((size_t)(b * d.Hout + oy) * d.Wout + ox) * d.dyC + q * VEC);
-        *(u32x4*)(lds_dy + p * dyrow + q * 16) = x;
+        *(u32x4*)(lds_dy + wg_dy_off<GR>(p, q * 16)) = x;
       }
     }
     __syncthreads();
@@ -299,7 +338,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const ksmi_wgrad_desc 
 #pragma unroll
         for (int nf = 0; nf < NT; ++nf) {
           auto rowaddr = [&](int j) -> unsigned {
-            return (unsigned)(uintptr_t)(lds_dy) + (ks + g * 8 + j) * dyrow + nf * 32;
+            return (unsigned)(uintptr_t)(lds_dy) + wg_dy_off<GR>(ks + g * 8 + j, nf * 32);
           };
           bfrag[nf] = TrRead<bf16_t>::read(rowaddr, l15);
         }
@@ -308,7 +347,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const ksmi_wgrad_desc 
         for (int nf = 0; nf < NT; ++nf)
 #pragma unroll
           for (int s = 0; s < 4; ++s)
-            bfrag[nf][s] = *(const uint32_t*)(lds_dy + (ks + g * 4 + s) * dyrow + (nf * 16 + l15) * 4);
+            bfrag[nf][s] = *(const uint32_t*)(lds_dy + wg_dy_off<GR>(ks + g * 4 + s, (nf * 16 + l15) * 4));
       }
 #pragma unroll
       for (int a = 0; a < TPW; ++a) {
@@ -322,7 +361,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const ksmi_wgrad_desc 
             auto rowaddr = [&](int j) -> unsigned {
               int p = ks + g * 8 + j; if (p >= P) p = 0;      // dY rows >= P are zero
               const int ly = dTW.div(p), lx = p - ly * d.TW;
-              return (unsigned)(uintptr_t)(lds_x) + (ly * S * HW + lx * S + toff) * 64 + cf * 32;
+              return (unsigned)(uintptr_t)(lds_x) + wg_x_off(ly * S * HW + lx * S + toff, cf * 32);
             };
             afrag = TrRead<bf16_t>::read(rowaddr, l15);
           } else {
@@ -330,7 +369,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const ksmi_wgrad_desc 
             for (int s = 0; s < 4; ++s) {
               int p = ks + g * 4 + s; if (p >= P) p = 0;
               const int ly = dTW.div(p), lx = p - ly * d.TW;
-              afrag[s] = *(const uint32_t*)(lds_x + (ly * S * HW + lx * S + toff) * 64 + l15 * 4);
+              afrag[s] = *(const uint32_t*)(lds_x + wg_x_off(ly * S * HW + lx * S + toff, l15 * 4));
             }
           }
 #pragma unroll
@@ -506,6 +545,15 @@ int ksmi_pack_weights(const ksmi_pack_desc* d, int dtype, void* stream) {
   if (dtype == KSMI_BF16) hipLaunchKernelGGL(pack_weights_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *d);
   else hipLaunchKernelGGL(pack_weights_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *d);
   return ksmi_check_launch("pack_weights");
+}
+
+int ksmi_pack_weights_batched(const ksmi_pack_desc* descs_device, int n, int dtype, void* stream) {
+  if (!descs_device || n < 1) return ksmi_fail(KSMI_E_ARG, "pack_batched: bad args");
+  const dim3 grid(48, n);
+  if (dtype == KSMI_BF16) hipLaunchKernelGGL(pack_weights_batched_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, descs_device);
+  else if (dtype == KSMI_F32) hipLaunchKernelGGL(pack_weights_batched_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, descs_device);
+  else return ksmi_fail(KSMI_E_ARG, "pack_batched: bad dtype");
+  return ksmi_check_launch("pack_weights_batched");
 }
 
 size_t ksmi_conv_wgrad_workspace(const ksmi_wgrad_desc* d, int dtype) {

@@ -63,6 +63,7 @@ class SNUNetPlan:
         self.packs, self.fwd, self.bwd = LaunchList(), LaunchList(), LaunchList()
         self.keep = []
         self._pinit = set()
+        self._pack_descs = []      # every weight-pack descriptor of the plan -> ONE batched launch per step
         self.param_ready = {}      # parameter key -> index of the last backward launch writing its gradient
         self._need, self._bufs, self._later = {}, {}, []
         n, c = model.base_channel, model.in_channels
@@ -104,6 +105,15 @@ class SNUNetPlan:
         if with_backward:
             for build in reversed(self.bwd_builders):
                 build()
+        # all weight packs of the step as one launch over a device-resident descriptor table
+        if self._pack_descs:
+            import ctypes
+            n = len(self._pack_descs)
+            arr = (_lib.PackDesc * n)(*self._pack_descs)
+            raw = bytes(ctypes.string_at(ctypes.addressof(arr), ctypes.sizeof(arr)))
+            table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.dev)
+            self.keep.append(table)
+            self.packs.add("ksmi_pack_weights_batched", lambda: (table.data_ptr(), n, self.dt))
         # scratch allocation, descriptor patching, argument resolution
         for name, nbytes in self._need.items():
             self._bufs[name] = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.dev)
@@ -132,7 +142,7 @@ class SNUNetPlan:
         out = torch.empty(packed_weight_numel(table, taps, Npad, self.dtype), dtype=self.dtype, device=self.dev)
         d = make_pack(self.m._p(key), out, table, taps, N, Npad, n_mod, sK, sN, sD, sT, flip)
         self.keep += [d, out]
-        self.packs.add("ksmi_pack_weights", lambda: (C.byref(d), self.dt))
+        self._pack_descs.append(d)
         return out
 
     def _rows(self, npix):
@@ -198,7 +208,7 @@ class SNUNetPlan:
             out = wpk[ch0 * slab:(ch0 + nch) * slab]
             pd = make_pack(wview, out, tj, 9, Cc, Npad, Cc, ktot * 9, 9, 0, 1, 1)
             self.keep += [pd, wview, out]
-            self.packs.add("ksmi_pack_weights", lambda pd=pd: (C.byref(pd), self.dt))
+            self._pack_descs.append(pd)
             ch0 += nch
         d.wpk = wpk.data_ptr()
         self.keep.append(wpk)
