@@ -187,6 +187,15 @@ def main():
                                   "TFs": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 1)}
                               for k, v in sorted(ts.items(), key=lambda kv: -kv[1]["ms"])}
             res["kernels_total_ms_per_step"] = round(tot / args.steps, 3)
+        if os.environ.get("BENCH_DETAIL"):
+            det = {}
+            for kind, meta, e0, e1 in timer.rec:
+                if os.environ["BENCH_DETAIL"] in kind:
+                    dd = det.setdefault((kind, meta.get("tag", "")), [0.0, 0, meta])
+                    dd[0] += e0.elapsed_time(e1); dd[1] += 1
+            for (kind, tag), (ms, n, meta) in sorted(det.items(), key=lambda kv: -kv[1][0]):
+                print(f"DETAIL {kind:28s} {tag:48s} {ms / args.steps:7.3f} ms/step x{n // args.steps} "
+                      f"{meta['flops'] * n / ms / 1e9:7.1f} TF/s {meta['bytes'] * n / ms / 1e6:7.1f} GB/s", file=sys.stderr)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res), flush=True)

@@ -216,7 +216,9 @@ int launch2(const ksmi_conv_desc* d, hipStream_t st) {
   const int HH = (d->TH - 1) * d->stride + d->KH, HW = (d->TW - 1) * d->stride + d->KW;
   const int HP = HH * HW;
   if (d->TH * d->TW > 256 || HP * 4 > 2048) return ksmi_fail(KSMI_E_ARG, "conv: patch too large (TH*TW<=256, halo<=512 px)");
-  const int nt = d->Npad >= 64 ? 4 : (d->Npad >= 32 ? 2 : 1);
+  static const int nt_cap = getenv("KSMI_NT_CAP") ? atoi(getenv("KSMI_NT_CAP")) : 2;      // BN=32: 80 KB of LDS = 2 workgroups per CU beats the BN=64 tile (1 per CU) by 15-35 %
+  int nt = d->Npad >= 64 ? 4 : (d->Npad >= 32 ? 2 : 1);
+  if (nt > nt_cap) nt = nt_cap;
   const int bn = nt * 16;
   const dim3 grid(gm, (d->Npad + bn - 1) / bn);
   const size_t hpb = ((size_t)HP * 64 + 1023) & ~(size_t)1023;

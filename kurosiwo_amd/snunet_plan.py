@@ -164,9 +164,10 @@ class SNUNetPlan:
         elems = pin * ktot + sum(pout * d.dst[i].n_len * (2 if d.dst[i].accumulate else 1) for i in range(d.ndst))
         if d.mask_src:
             elems += pout * d.N
-        nt = 4 if d.Npad >= 64 else (2 if d.Npad >= 32 else 1)
+        nt = 2 if d.Npad >= 32 else 1
         meta = {"kind": f"igemm_{tag}<{d.KH}x{d.KW}s{d.stride},BN{16 * nt}>", "bytes": elems * es + taps * ktot * d.N * es,
                 "flops": 2 * pout * d.N * ktot * taps}
+        meta["tag"] = f"K={ktot} N={d.N} {d.Hout}x{d.Wout} nsrc={d.nsrc}"
         ll.add("ksmi_conv_forward", lambda: (C.byref(d), self.dt), meta)
 
     def _wgrad(self, d, ws, *keys):
@@ -178,6 +179,7 @@ class SNUNetPlan:
         pin, pout = d.B * d.Hin * d.Win, d.B * d.Hout * d.Wout
         meta = {"kind": f"igemm_wgrad<{d.KH}x{d.KW}s{d.stride}>", "bytes": (pin * ktot + pout * d.N) * es + taps * ktot * d.N * 4,
                 "flops": 2 * pout * d.N * ktot * taps}
+        meta["tag"] = f"{keys[0] if keys else '?'} K={ktot} N={d.N} {d.Hout}x{d.Wout}"
         self.bwd.add("ksmi_conv_wgrad", lambda: (C.byref(d), self.dt), meta)
         self._mark(*keys)
 
