@@ -17,8 +17,16 @@
 
 namespace {
 
+struct Igemm2Args {            // kernel argument: the public descriptor + launcher-computed constants
+  ksmi_conv_desc d;
+  uint32_t m_tw, m_hw, m_tx, m_ty;   // fastdiv magics of TW, halo width, tilesX, tilesY
+  int dbg;
+};
+
 template <typename T, int NT, int KH, int KW, bool AFF>
-__global__ __launch_bounds__(256) void igemm2_fwd_kernel(const ksmi_conv_desc d) {
+__global__ __launch_bounds__(256) void igemm2_fwd_kernel(const Igemm2Args ka) {
+  const ksmi_conv_desc& d = ka.d;
+  const long long tm0 = __builtin_readcyclecounter();
   constexpr int TAPS = KH * KW;
   constexpr int BN = NT * 16;
   constexpr int VEC = ElemTraits<T>::kVec;
@@ -33,9 +41,11 @@ __global__ __launch_bounds__(256) void igemm2_fwd_kernel(const ksmi_conv_desc d)
   const int g = lane >> 4, l15 = lane & 15;
 
   const int tilesX = (d.Wout + d.TW - 1) / d.TW, tilesY = (d.Hout + d.TH - 1) / d.TH;
-  int bm = blockIdx.x;
-  const int tx = bm % tilesX; bm /= tilesX;
-  const int ty = bm % tilesY; const int b = bm / tilesY;
+  const FastDiv dTX(tilesX, ka.m_tx), dTY(tilesY, ka.m_ty);
+  const int q1 = dTX.div(blockIdx.x);
+  const int tx = blockIdx.x - q1 * tilesX;
+  const int b = dTY.div(q1);
+  const int ty = q1 - b * tilesY;
   const int oy0 = ty * d.TH, ox0 = tx * d.TW;
   const int n0 = blockIdx.y * BN;
   const int S = d.stride;
@@ -45,13 +55,7 @@ __global__ __launch_bounds__(256) void igemm2_fwd_kernel(const ksmi_conv_desc d)
   const int HPB = (HP * 64 + 1023) & ~1023;                 // halo bytes, whole wave-instructions (1 KiB)
   const int BUFB = HPB + TAPS * BN * 64;                    // one stage
   const int nslot = HPB / 4096 + ((HPB % 4096) ? 1 : 0);    // 256 lanes x 16 B per slot-iteration
-  const FastDiv dHW(HW), dTW(d.TW);
-
-  // ---- zero both halo images once (padding positions are never written afterwards) -----------
-  for (int v = tid; v < HPB / 16; v += 256) {
-    *(u32x4*)(smem + v * 16) = (u32x4){0u, 0u, 0u, 0u};
-    *(u32x4*)(smem + BUFB + v * 16) = (u32x4){0u, 0u, 0u, 0u};
-  }
+  const FastDiv dHW(HW, ka.m_hw), dTW(d.TW, ka.m_tw);
 
   // ---- per-thread halo slots: LDS position v = s*256 + tid <-> (pixel v>>2, slot v&3) -----------
   int slot_goff[MAXSLOT];                                   // pixel index in the image, or -1
@@ -71,6 +75,16 @@ __global__ __launch_bounds__(256) void igemm2_fwd_kernel(const ksmi_conv_desc d)
     }
   }
   const int myq = tid & 3;
+  // padding positions are never written by the DMA: zero them once (both stages; interior patches have none)
+  const bool two_stage = d.nchunks > 1;
+#pragma unroll
+  for (int s = 0; s < MAXSLOT; ++s) {
+    if (tid + s * 256 < HP * 4 && slot_goff[s] < 0) {
+      const int off = AFF ? slot_lds[s] : (s * 256 + tid) * 16;
+      *(u32x4*)(smem + off) = (u32x4){0u, 0u, 0u, 0u};
+      if (two_stage) *(u32x4*)(smem + BUFB + off) = (u32x4){0u, 0u, 0u, 0u};
+    }
+  }
 
   // ---- per-lane fragment addresses ---------------------------------------------------------------
   int a_addr[4][TAPS];
@@ -161,13 +175,14 @@ __global__ __launch_bounds__(256) void igemm2_fwd_kernel(const ksmi_conv_desc d)
       }
   };
 
+  const long long tm1 = __builtin_readcyclecounter();
   __syncthreads();                                          // zero fill visible before any DMA lands
   // ---- prologue: stage chunk 0 ---------------------------------------------------------------------
   issue_weights(0, 0);
   if constexpr (AFF) { load_halo_regs(0); store_halo_regs(0, 0); }
   else issue_halo_dma(0, 0);
 
-  const int dbg = d.dst[KSMI_MAX_SRC - 1].pad_;            // profiling switches (KSMI_DBG): 1 no MFMA, 2 no DMA, 4 no epilogue
+  const int dbg = ka.dbg;            // profiling switches (KSMI_DBG): 1 no MFMA, 2 no DMA, 4 no epilogue
   for (int ch = 0; ch < d.nchunks; ++ch) {
     const int buf = ch & 1;
     __syncthreads();                                        // chunk ch landed (vmcnt(0) before the barrier); buf^1 is free
@@ -205,11 +220,18 @@ __global__ __launch_bounds__(256) void igemm2_fwd_kernel(const ksmi_conv_desc d)
     }
     if constexpr (AFF) { if (more) store_halo_regs(ch + 1, buf ^ 1); }
   }
-  if (!(dbg & 4)) igemm_epilogue_direct<T, NT>(d, acc, smem, tid, wave, g, l15, b, oy0, ox0, n0, P);
+  const long long tm2 = __builtin_readcyclecounter();
+  if (!(dbg & 4)) igemm_epilogue_direct<T, NT>(d, acc, smem, tid, wave, g, l15, b, oy0, ox0, n0, P, ka.m_tw);
+  if ((dbg & 8) && d.stats && tid == 0 && blockIdx.y == 0) {   // per-block phase timestamps (profiling only; clobbers stats)
+    __builtin_amdgcn_s_waitcnt(0);
+    const long long tm3 = __builtin_readcyclecounter();
+    long long* o = (long long*)d.stats + (size_t)blockIdx.x * 4;
+    o[0] = tm0; o[1] = tm1; o[2] = tm2; o[3] = tm3;
+  }
 }
 
 template <typename T>
-int launch2(const ksmi_conv_desc* d, hipStream_t st) {
+int launch2(const ksmi_conv_desc* d, int dbg, hipStream_t st) {
   const int taps = d->KH * d->KW;
   const int tilesX = (d->Wout + d->TW - 1) / d->TW, tilesY = (d->Hout + d->TH - 1) / d->TH;
   const int gm = d->B * tilesX * tilesY;
@@ -222,13 +244,19 @@ int launch2(const ksmi_conv_desc* d, hipStream_t st) {
   const int bn = nt * 16;
   const dim3 grid(gm, (d->Npad + bn - 1) / bn);
   const size_t hpb = ((size_t)HP * 64 + 1023) & ~(size_t)1023;
-  size_t lds = 2 * (hpb + (size_t)taps * bn * 64);
+  // single-chunk convolutions (K <= 32 bf16 channels) need one stage only: 40 KB -> 3-4 workgroups per CU
+  size_t lds = (d->nchunks > 1 ? 2 : 1) * (hpb + (size_t)taps * bn * 64);
+  if (lds < 4 * 2 * bn * sizeof(float)) lds = 4 * 2 * bn * sizeof(float);
   const bool aff = d->src[0].scale != nullptr;
+  Igemm2Args ka;
+  ka.d = *d;
+  ka.m_tw = fastdiv_magic(d->TW); ka.m_hw = fastdiv_magic(HW); ka.m_tx = fastdiv_magic(tilesX); ka.m_ty = fastdiv_magic(tilesY);
+  ka.dbg = dbg;
 #define KSMI_L2(NT_, KH_, KW_, AFF_)                                                                \
   do {                                                                                              \
     auto kfn = igemm2_fwd_kernel<T, NT_, KH_, KW_, AFF_>;                                           \
     if (lds > 65536) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, *d);                                          \
+    hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, ka);                                          \
   } while (0)
 #define KSMI_D2(KH_, KW_)                                                                           \
   switch (nt) {                                                                                     \
@@ -260,9 +288,6 @@ bool ksmi_igemm2_eligible(const ksmi_conv_desc* d, int dtype) {
 
 int ksmi_igemm2_launch(const ksmi_conv_desc* d0, int dtype, hipStream_t st) {
   static const int dbg = getenv("KSMI_DBG") ? atoi(getenv("KSMI_DBG")) : 0;
-  ksmi_conv_desc dd = *d0;
-  dd.dst[KSMI_MAX_SRC - 1].pad_ = dbg;
-  const ksmi_conv_desc* d = &dd;
-  if (dtype == KSMI_BF16) return launch2<bf16_t>(d, st);
-  return launch2<float>(d, st);
+  if (dtype == KSMI_BF16) return launch2<bf16_t>(d0, dbg, st);
+  return launch2<float>(d0, dbg, st);
 }

@@ -9,9 +9,11 @@ __device__ __forceinline__ int swz(int row) { return (0 - (row >> 2)) & 3; }
 
 // Exact unsigned division by a runtime constant with one v_mul_hi_u32: q = umulhi(p, floor(2^32/d)+1)
 // (exact for p*d < 2^32; all uses have p <= 2048, d <= 512).  d == 1 is handled by the caller's struct.
+__host__ __device__ inline uint32_t fastdiv_magic(int dd) { return dd > 1 ? (uint32_t)(0x100000000ull / (uint64_t)dd) + 1u : 0u; }
 struct FastDiv {
   uint32_t magic; int d;
   __device__ __forceinline__ explicit FastDiv(int dd) : magic(dd > 1 ? (uint32_t)(4294967296.0 / (double)dd) + 1u : 0u), d(dd) {}
+  __device__ __forceinline__ FastDiv(int dd, uint32_t host_magic) : magic(host_magic), d(dd) {}   // magic from the launcher
   __device__ __forceinline__ int div(int p) const { return d > 1 ? (int)__umulhi((uint32_t)p, magic) : p; }
 };
 
@@ -207,9 +209,10 @@ template <> struct Quad<bf16_t> {
 
 template <typename T, int NT>
 __device__ __forceinline__ void igemm_epilogue_direct(const ksmi_conv_desc& d, f32x4 (&acc)[4][NT], unsigned char* smem, int tid,
-                                                      int wave, int g, int l15, int b, int oy0, int ox0, int n0, int P) {
+                                                      int wave, int g, int l15, int b, int oy0, int ox0, int n0, int P,
+                                                      uint32_t magic_tw = 0xffffffffu) {
   constexpr int BN = NT * 16;
-  const FastDiv dTW(d.TW);
+  const FastDiv dTW = magic_tw != 0xffffffffu ? FastDiv(d.TW, magic_tw) : FastDiv(d.TW);
   size_t opix[4];
   bool pv[4];
   int oyv[4], oxv[4];
