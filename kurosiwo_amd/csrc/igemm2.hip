@@ -21,6 +21,7 @@ struct Igemm2Args {            // kernel argument: the public descriptor + launc
   ksmi_conv_desc d;
   uint32_t m_tw, m_hw, m_tx, m_ty;   // fastdiv magics of TW, halo width, tilesX, tilesY
   int dbg;
+  int stages;                        // LDS stages: 2 = double-buffered k-chunks, 1 = single
 };
 
 template <typename T, int NT, int KH, int KW, bool AFF>
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(256) void igemm2_fwd_kernel(const Igemm2Args ka) {
   }
   const int myq = tid & 3;
   // padding positions are never written by the DMA: zero them once (both stages; interior patches have none)
-  const bool two_stage = d.nchunks > 1;
+  const bool two_stage = ka.stages > 1;
 #pragma unroll
   for (int s = 0; s < MAXSLOT; ++s) {
     if (tid + s * 256 < HP * 4 && slot_goff[s] < 0) {
@@ -184,13 +185,14 @@ __global__ __launch_bounds__(256) void igemm2_fwd_kernel(const Igemm2Args ka) {
 
   const int dbg = ka.dbg;            // profiling switches (KSMI_DBG): 1 no MFMA, 2 no DMA, 4 no epilogue
   for (int ch = 0; ch < d.nchunks; ++ch) {
-    const int buf = ch & 1;
-    __syncthreads();                                        // chunk ch landed (vmcnt(0) before the barrier); buf^1 is free
+    const int buf = two_stage ? (ch & 1) : 0;
+    const int nbuf = two_stage ? (buf ^ 1) : 0;
+    __syncthreads();                                        // chunk ch landed (vmcnt(0) before the barrier); the other stage is free
     const bool more = ch + 1 < d.nchunks;
-    if (more && !(dbg & 2)) {
-      issue_weights(ch + 1, buf ^ 1);
+    if (two_stage && more && !(dbg & 2)) {
+      issue_weights(ch + 1, nbuf);
       if constexpr (AFF) load_halo_regs(ch + 1);
-      else issue_halo_dma(ch + 1, buf ^ 1);
+      else issue_halo_dma(ch + 1, nbuf);
     }
     const unsigned char* lds_halo = smem + buf * BUFB;
     const unsigned char* lds_w = lds_halo + HPB;
@@ -218,7 +220,15 @@ __global__ __launch_bounds__(256) void igemm2_fwd_kernel(const Igemm2Args ka) {
         for (int nf = 0; nf < NT; ++nf) mma16<T>(acc[mf][nf], fb[cur][nf], fa[cur][mf]);   // D = W * X^T (see epilogue)
     }
     }
-    if constexpr (AFF) { if (more) store_halo_regs(ch + 1, buf ^ 1); }
+    if (two_stage) {
+      if constexpr (AFF) { if (more) store_halo_regs(ch + 1, nbuf); }
+    } else if (more) {
+      // single stage (40 KB: more workgroups per CU instead of intra-workgroup overlap): refill after the MFMAs
+      __syncthreads();
+      issue_weights(ch + 1, 0);
+      if constexpr (AFF) { load_halo_regs(ch + 1); store_halo_regs(ch + 1, 0); }
+      else issue_halo_dma(ch + 1, 0);
+    }
   }
   const long long tm2 = __builtin_readcyclecounter();
   if (!(dbg & 4)) igemm_epilogue_direct<T, NT>(d, acc, smem, tid, wave, g, l15, b, oy0, ox0, n0, P, ka.m_tw);
@@ -245,13 +255,16 @@ int launch2(const ksmi_conv_desc* d, int dbg, hipStream_t st) {
   const dim3 grid(gm, (d->Npad + bn - 1) / bn);
   const size_t hpb = ((size_t)HP * 64 + 1023) & ~(size_t)1023;
   // single-chunk convolutions (K <= 32 bf16 channels) need one stage only: 40 KB -> 3-4 workgroups per CU
-  size_t lds = (d->nchunks > 1 ? 2 : 1) * (hpb + (size_t)taps * bn * 64);
+  static const int stage_cap = getenv("KSMI_STAGES") ? atoi(getenv("KSMI_STAGES")) : 2;
+  const int stages = (d->nchunks > 1 && stage_cap > 1) ? 2 : 1;
+  size_t lds = stages * (hpb + (size_t)taps * bn * 64);
   if (lds < 4 * 2 * bn * sizeof(float)) lds = 4 * 2 * bn * sizeof(float);
   const bool aff = d->src[0].scale != nullptr;
   Igemm2Args ka;
   ka.d = *d;
   ka.m_tw = fastdiv_magic(d->TW); ka.m_hw = fastdiv_magic(HW); ka.m_tx = fastdiv_magic(tilesX); ka.m_ty = fastdiv_magic(tilesY);
   ka.dbg = dbg;
+  ka.stages = stages;
 #define KSMI_L2(NT_, KH_, KW_, AFF_)                                                                \
   do {                                                                                              \
     auto kfn = igemm2_fwd_kernel<T, NT_, KH_, KW_, AFF_>;                                           \
