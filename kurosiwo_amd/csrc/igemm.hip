@@ -400,21 +400,29 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const ksmi_wgrad_desc 
   }
 }
 
-// sum the split slabs (fp32, fixed order => deterministic) and scatter into the fp32 gradient
+// sum the split slabs (fp32, fixed summation tree => deterministic) and scatter into the fp32 gradient.
+// 8 lanes cooperate on one element (slabs sp = lane8, lane8+8, ...; two independent accumulators each, then a
+// 3-step shuffle tree): the serial version (one thread walks up to 256 slabs) cost 44 us per launch.
 __global__ void wgrad_reduce_kernel(const ksmi_wgrad_desc d, int taps, int KC) {
   const int Npad = (d.N + 15) & ~15;
   const int Ktot = d.nchunks * KC;
   const size_t total = (size_t)taps * Ktot * Npad;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+  const int l8 = threadIdx.x & 7;
+  for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3; i < total; i += ((size_t)gridDim.x * blockDim.x) >> 3) {
     const int n = i % Npad; size_t r = i / Npad;
     const int krow = r % Ktot; const int t = r / Ktot;
     const int ch = krow / KC, kc = krow - ch * KC;
-    if (n >= d.N || kc >= d.k_len[ch]) continue;
-    float s = 0.f;
-    for (int sp = 0; sp < d.nsplit; ++sp) s += d.partial[(size_t)sp * total + i];
-    const int64_t k = d.k_off[ch] + kc;
-    float* gp = d.grad + k * d.gK + (int64_t)n * d.gN + (int64_t)t * d.gT;
-    *gp = d.accumulate ? (*gp + s) : s;
+    float s0 = 0.f, s1 = 0.f;
+    int sp = l8;
+    for (; sp + 8 < d.nsplit; sp += 16) { s0 += d.partial[(size_t)sp * total + i]; s1 += d.partial[(size_t)(sp + 8) * total + i]; }
+    if (sp < d.nsplit) s0 += d.partial[(size_t)sp * total + i];
+    float s = s0 + s1;
+    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+    if (l8 == 0 && n < d.N && kc < d.k_len[ch]) {
+      const int64_t k = d.k_off[ch] + kc;
+      float* gp = d.grad + k * d.gK + (int64_t)n * d.gN + (int64_t)t * d.gT;
+      *gp = d.accumulate ? (*gp + s) : s;
+    }
   }
 }
 
@@ -510,7 +518,7 @@ int launch_wgrad(const ksmi_wgrad_desc* d, hipStream_t st) {
   int rc = ksmi_check_launch("igemm_wgrad");
   if (rc) return rc;
   const size_t total = (size_t)g.taps * d->nchunks * g.kc * g.npad;
-  int blocks = (int)((total + 255) / 256); if (blocks > 2048) blocks = 2048;
+  int blocks = (int)((total * 8 + 255) / 256); if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, *d, g.taps, g.kc);
   return ksmi_check_launch("wgrad_reduce");
 }
