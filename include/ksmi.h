@@ -243,6 +243,37 @@ int ksmi_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int6
 int ksmi_sgd_step(float* p, const float* g, float* mom, int64_t n, int64_t* step_count,
                   float lr, float momentum, float weight_decay, float grad_scale, void* stream);
 
+/* ---------------------------------------------------------------------------------
+ * Token-sequence ops of the FloodViT path: models/vision_transformer.py (lucidrains-style ViT) and the
+ * FinetunerSegmentation / Decoder head, models/model_utilities.py:22-94.  Activations are [rows][C] `dtype`
+ * (= NHWC with H*W tokens); the Linear layers run on ksmi_conv_forward / ksmi_conv_wgrad as 1x1 convolutions.
+ * ------------------------------------------------------------------------------- */
+/* nn.LayerNorm(C) (vision_transformer.py:22,43,72,124,126; eps 1e-5); mean/rstd [rows] saved for backward */
+int ksmi_layernorm_forward(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                           int rows, int C, float eps, int dtype, void* stream);
+/* dx (+)= LN backward; partial[blocks][2][C] = (sum dy, sum dy*xhat) per block -> ksmi_reduce_rows gives dbeta, dgamma */
+int ksmi_layernorm_bwd_blocks(int rows);
+int ksmi_layernorm_backward(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                            void* dx, int accumulate, float* partial, int rows, int C, int dtype, void* stream);
+/* nn.GELU() exact-erf (vision_transformer.py:24), elementwise helpers */
+int ksmi_gelu_forward(const void* x, void* y, int64_t n, int dtype, void* stream);
+int ksmi_gelu_backward(const void* dy, const void* x, void* dx, int64_t n, int dtype, void* stream);
+int ksmi_add(const void* a, const void* b, void* out, int64_t n, int dtype, void* stream);
+int ksmi_relu_backward(const void* dy, const void* x, void* dx, int64_t n, int dtype, void* stream);
+/* Rearrange("b c (h p1) (w p2) -> b (h w) (p1 p2 c)") of the NCHW fp32 image (vision_transformer.py:122) */
+int ksmi_patchify(const float* x_nchw, void* out, int B, int Cin, int H, int W, int P, int dtype, void* stream);
+/* x0 = cat(cls, emb) + pos_embedding (vision_transformer.py:143-145) and its backward (dcls, dpos fp32 "=") */
+int ksmi_vit_embed_forward(const void* emb, const float* cls, const float* pos, void* x0, int B, int N1, int C, int dtype, void* stream);
+int ksmi_vit_embed_backward(const void* dx0, void* demb, float* dcls, float* dpos, int B, int N1, int C, int dtype, void* stream);
+/* softmax(q k^T * scale) v per head (vision_transformer.py:52-63); qkv [B*N][3*H*D] in "(3 h d)" order, out [B*N][H*D],
+ * lse [B][H][N] saved for backward; dqkv written ("=").  D must be 64. */
+int ksmi_attention_forward(const void* qkv, void* out, float* lse, int B, int N, int H, int D, float scale, int dtype, void* stream);
+int ksmi_attention_backward(const void* qkv, const void* out, const float* lse, const void* dout, void* dqkv,
+                            int B, int N, int H, int D, float scale, int dtype, void* stream);
+/* [relu ->] nn.Upsample(scale_factor=2) nearest (model_utilities.py:36-41) */
+int ksmi_upsample2_forward(const void* x, void* y, int B, int H, int W, int C, int relu, int dtype, void* stream);
+int ksmi_upsample2_backward(const void* dy, const void* x_pre, void* dx, int B, int H, int W, int C, int relu, int dtype, void* stream);
+
 /* plumbing */
 int ksmi_fill_zero(void* p, size_t bytes, void* stream);
 /* NCHW fp32 -> NHWC dtype and back (tests / debugging only) */

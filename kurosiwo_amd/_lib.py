@@ -103,6 +103,20 @@ SIGNATURES = {
     "ksmi_argmax_confusion": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ksmi_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _f, _f, _f, _f, _f, _f, _vp]),
     "ksmi_sgd_step": (_i, [_vp, _vp, _vp, _i64, _vp, _f, _f, _f, _f, _vp]),
+    "ksmi_layernorm_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp]),
+    "ksmi_layernorm_bwd_blocks": (_i, [_i]),
+    "ksmi_layernorm_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp]),
+    "ksmi_gelu_forward": (_i, [_vp, _vp, _i64, _i, _vp]),
+    "ksmi_gelu_backward": (_i, [_vp, _vp, _vp, _i64, _i, _vp]),
+    "ksmi_add": (_i, [_vp, _vp, _vp, _i64, _i, _vp]),
+    "ksmi_relu_backward": (_i, [_vp, _vp, _vp, _i64, _i, _vp]),
+    "ksmi_patchify": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "ksmi_vit_embed_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "ksmi_vit_embed_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "ksmi_attention_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
+    "ksmi_attention_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
+    "ksmi_upsample2_forward": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "ksmi_upsample2_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ksmi_fill_zero": (_i, [_vp, _sz, _vp]),
     "ksmi_nchw_to_nhwc": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "ksmi_nhwc_to_nchw": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),

@@ -1,0 +1,555 @@
+// Token-sequence kernels of the FloodViT path (rows V1-V4 of SURVEY.md §8(a)); activations are
+// [rows = B*N tokens][C] in T (bf16 / fp32), i.e. the same memory as NHWC with H*W = N.
+// The token GEMMs (to_qkv, to_out, FFN) run on the implicit-GEMM kernels as 1x1 convolutions.
+//
+// Round-1 note: attention here is a straightforward VALU kernel (N = 197 keys live in LDS, one query row
+// per lane, online softmax); it is ~5 % of the ViT FLOPs.  The MFMA flash-style version is a later step.
+#include "common.h"
+#include "../../include/ksmi.h"
+#include "errors.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm over the last dim: one wave per row (vision_transformer.py:22,43,72,124,126; eps 1e-5)
+// ------------------------------------------------------------------------------------------------
+template <typename T, int MAXV>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* x, const float* gamma, const float* beta, T* y,
+                                                            float* mean, float* rstd, int rows, int C, float eps) {
+  constexpr int VEC = ElemTraits<T>::kVec;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= rows) return;
+  const int nv = C / VEC;
+  float v[MAXV][VEC];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int q = lane + i * 64;
+    if (q < nv) {
+      vec_unpack<T>(*(const u32x4*)(x + (size_t)row * C + q * VEC), v[i]);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) s += v[i][j];
+    }
+  }
+  const float mu = wave_sum(s) / (float)C;
+  float q2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i)
+    if (lane + i * 64 < nv) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) { const float dlt = v[i][j] - mu; q2 += dlt * dlt; }
+    }
+  const float rs = 1.0f / sqrtf(wave_sum(q2) / (float)C + eps);
+  if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int q = lane + i * 64;
+    if (q < nv) {
+      float o[VEC];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) o[j] = (v[i][j] - mu) * rs * gamma[q * VEC + j] + beta[q * VEC + j];
+      *(u32x4*)(y + (size_t)row * C + q * VEC) = vec_pack<T>(o);
+    }
+  }
+}
+
+// dx = rstd*(g*dy - mean(g*dy) - xhat*mean(g*dy*xhat)); partial[blk][0][c] = sum dy, [1][c] = sum dy*xhat
+template <typename T, int MAXV>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dy, const T* x, const float* mean, const float* rstd,
+                                                            const float* gamma, T* dx, int accumulate, float* partial,
+                                                            int rows, int C, int rows_per_block) {
+  constexpr int VEC = ElemTraits<T>::kVec;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nv = C / VEC;
+  float gsum[MAXV][VEC], bsum[MAXV][VEC], gam[MAXV][VEC];
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i)
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      gsum[i][j] = 0.f; bsum[i][j] = 0.f;
+      const int q = lane + i * 64;
+      gam[i][j] = q < nv ? gamma[q * VEC + j] : 0.f;
+    }
+  const int r0 = blockIdx.x * rows_per_block;
+  const int r1 = min(rows, r0 + rows_per_block);
+  for (int row = r0 + wave; row < r1; row += 4) {
+    const float mu = mean[row], rs = rstd[row];
+    float g[MAXV][VEC], xh[MAXV][VEC];
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int q = lane + i * 64;
+      if (q < nv) {
+        float xv[VEC];
+        vec_unpack<T>(*(const u32x4*)(dy + (size_t)row * C + q * VEC), g[i]);
+        vec_unpack<T>(*(const u32x4*)(x + (size_t)row * C + q * VEC), xv);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          xh[i][j] = (xv[j] - mu) * rs;
+          bsum[i][j] += g[i][j]; gsum[i][j] += g[i][j] * xh[i][j];
+          const float gg = g[i][j] * gam[i][j];
+          a += gg; b += gg * xh[i][j];
+        }
+      }
+    }
+    a = wave_sum(a) / (float)C; b = wave_sum(b) / (float)C;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int q = lane + i * 64;
+      if (q < nv) {
+        float o[VEC];
+        T* dp = dx + (size_t)row * C + q * VEC;
+        if (accumulate) vec_unpack<T>(*(const u32x4*)dp, o);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          const float d = rs * (g[i][j] * gam[i][j] - a - xh[i][j] * b);
+          o[j] = accumulate ? o[j] + d : d;
+        }
+        *(u32x4*)dp = vec_pack<T>(o);
+      }
+    }
+  }
+  // combine the 4 waves through LDS, write partial[blk][2][C]
+  extern __shared__ float red[];                 // [2][C]
+  for (int ph = 0; ph < 4; ++ph) {
+    __syncthreads();
+    if (wave == ph) {
+#pragma unroll
+      for (int i = 0; i < MAXV; ++i) {
+        const int q = lane + i * 64;
+        if (q < nv)
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) {
+            const int c = q * VEC + j;
+            if (ph == 0) { red[c] = bsum[i][j]; red[C + c] = gsum[i][j]; }
+            else { red[c] += bsum[i][j]; red[C + c] += gsum[i][j]; }
+          }
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += kThreads) partial[(size_t)blockIdx.x * 2 * C + i] = red[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// GELU (exact erf form, nn.GELU default; vision_transformer.py:24), residual add
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_df(float x) {
+  return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);
+}
+template <typename T, int MODE>   // 0: y = gelu(x) ; 1: dx = dy*gelu'(x) ; 2: out = a + b ; 3: relu bwd: dx = dy*(x>0)
+__global__ void eltwise_kernel(const T* a, const T* b, T* out, int64_t nvec) {
+  constexpr int VEC = ElemTraits<T>::kVec;
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * blockDim.x) {
+    float x[VEC], y[VEC];
+    vec_unpack<T>(*(const u32x4*)(a + v * VEC), x);
+    if (MODE >= 1) vec_unpack<T>(*(const u32x4*)(b + v * VEC), y);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      if (MODE == 0) x[j] = gelu_f(x[j]);
+      else if (MODE == 1) x[j] = x[j] * gelu_df(y[j]);        // a = dy, b = x
+      else if (MODE == 2) x[j] = x[j] + y[j];
+      else x[j] = y[j] > 0.f ? x[j] : 0.f;                    // a = dy, b = x
+    }
+    *(u32x4*)(out + v * VEC) = vec_pack<T>(x);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// patchify: "b c (h p1) (w p2) -> b (h w) (p1 p2 c)"  (vision_transformer.py:122); image NCHW fp32
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void patchify_kernel(const float* x, T* out, int B, int Cin, int H, int W, int P) {
+  const int gh = H / P, gw = W / P, D = P * P * Cin;
+  const int64_t total = (int64_t)B * gh * gw * D;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int k = i % D; int64_t r = i / D;
+    const int pw = r % gw; r /= gw;
+    const int ph = r % gh; const int b = r / gh;
+    const int c = k % Cin; const int pp = k / Cin;
+    const int p2 = pp % P, p1 = pp / P;
+    ElemTraits<T>::st(out + i, x[(((int64_t)b * Cin + c) * H + ph * P + p1) * W + pw * P + p2]);
+  }
+}
+
+// x0[b,0,:] = cls + pos[0] ; x0[b,1+i,:] = emb[b,i,:] + pos[1+i]   (vision_transformer.py:143-145)
+template <typename T>
+__global__ void vit_embed_fwd_kernel(const T* emb, const float* cls, const float* pos, T* x0, int B, int N1, int C) {
+  const int64_t total = (int64_t)B * N1 * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = i % C; int64_t r = i / C;
+    const int n = r % N1; const int b = r / N1;
+    const float v = n == 0 ? cls[c] : ElemTraits<T>::ld(emb + ((int64_t)b * (N1 - 1) + n - 1) * C + c);
+    ElemTraits<T>::st(x0 + i, v + pos[(int64_t)n * C + c]);
+  }
+}
+// dpos[n,c] = sum_b dx0[b,n,c] ; dcls[c] = sum_b dx0[b,0,c] ; demb[b,i,c] = dx0[b,1+i,c]
+template <typename T>
+__global__ void vit_embed_bwd_kernel(const T* dx0, T* demb, float* dcls, float* dpos, int B, int N1, int C) {
+  const int64_t total = (int64_t)N1 * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = i % C; const int n = i / C;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) {
+      const float v = ElemTraits<T>::ld(dx0 + ((int64_t)b * N1 + n) * C + c);
+      s += v;
+      if (n > 0 && demb) ElemTraits<T>::st(demb + ((int64_t)b * (N1 - 1) + n - 1) * C + c, v);
+    }
+    dpos[i] = s;
+    if (n == 0) dcls[c] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// multi-head attention, softmax(q k^T * scale) v   (vision_transformer.py:52-63); qkv [B*N][3*H*D]
+// with the reference's "(3 h d)" channel order; out [B*N][H*D]; lse [B][H][N] (log-sum-exp of the scaled scores)
+// ------------------------------------------------------------------------------------------------
+// helpers on LDS rows of D elements (vector reads: every lane reads the SAME row -> LDS broadcast)
+template <typename T, int D>
+__device__ __forceinline__ float row_dot(const T* row, const float* a) {
+  constexpr int VEC = ElemTraits<T>::kVec;
+  float s = 0.f;
+#pragma unroll
+  for (int v = 0; v < D / VEC; ++v) {
+    float f[VEC];
+    vec_unpack<T>(*(const u32x4*)(row + v * VEC), f);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) s += a[v * VEC + j] * f[j];
+  }
+  return s;
+}
+template <typename T, int D>
+__device__ __forceinline__ void row_axpy(float* acc, float w, const T* row) {
+  constexpr int VEC = ElemTraits<T>::kVec;
+#pragma unroll
+  for (int v = 0; v < D / VEC; ++v) {
+    float f[VEC];
+    vec_unpack<T>(*(const u32x4*)(row + v * VEC), f);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[v * VEC + j] += w * f[j];
+  }
+}
+template <typename T, int D>
+__device__ __forceinline__ void row_load(float* dst, const T* row, float mul) {
+  constexpr int VEC = ElemTraits<T>::kVec;
+#pragma unroll
+  for (int v = 0; v < D / VEC; ++v) {
+    float f[VEC];
+    vec_unpack<T>(*(const u32x4*)(row + v * VEC), f);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) dst[v * VEC + j] = f[j] * mul;
+  }
+}
+template <typename T, int D>
+__device__ __forceinline__ void row_store(T* row, const float* src, float mul) {
+  constexpr int VEC = ElemTraits<T>::kVec;
+#pragma unroll
+  for (int v = 0; v < D / VEC; ++v) {
+    float f[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) f[j] = src[v * VEC + j] * mul;
+    *(u32x4*)(row + v * VEC) = vec_pack<T>(f);
+  }
+}
+// cooperative copy of the [N][D] slice (head h, part 0/1/2 = q/k/v) of qkv into LDS
+template <typename T, int D>
+__device__ __forceinline__ void stage_rows(T* dst, const T* src, int N, int row_stride) {
+  constexpr int VEC = ElemTraits<T>::kVec;
+  constexpr int VPR = D / VEC;
+  for (int i = threadIdx.x; i < N * VPR; i += kThreads) {
+    const int j = i / VPR, v = i - j * VPR;
+    *(u32x4*)(dst + j * D + v * VEC) = *(const u32x4*)(src + (size_t)j * row_stride + v * VEC);
+  }
+}
+
+template <typename T, int D>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const T* qkv, T* out, float* lse, int N, int H, float scale) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  T* ks = (T*)smem;                    // [N][D]
+  T* vs = ks + (size_t)N * D;          // [N][D]
+  const int b = blockIdx.y, h = blockIdx.x;
+  const int C3 = 3 * H * D;
+  const T* base = qkv + (size_t)b * N * C3;
+  stage_rows<T, D>(ks, base + (H + h) * D, N, C3);
+  stage_rows<T, D>(vs, base + (2 * H + h) * D, N, C3);
+  __syncthreads();
+  for (int q = threadIdx.x; q < N; q += kThreads) {
+    float qr[D], o[D];
+    row_load<T, D>(qr, base + (size_t)q * C3 + h * D, scale);
+#pragma unroll
+    for (int dd = 0; dd < D; ++dd) o[dd] = 0.f;
+    float m = -INFINITY, l = 0.f;
+    for (int j = 0; j < N; ++j) {
+      const float s = row_dot<T, D>(ks + j * D, qr);
+      const float mn = fmaxf(m, s);
+      const float corr = expf(m - mn), p = expf(s - mn);
+      l = l * corr + p;
+#pragma unroll
+      for (int dd = 0; dd < D; ++dd) o[dd] *= corr;
+      row_axpy<T, D>(o, p, vs + j * D);
+      m = mn;
+    }
+    row_store<T, D>(out + ((size_t)b * N + q) * (H * D) + h * D, o, 1.0f / l);
+    lse[((size_t)b * H + h) * N + q] = m + logf(l);
+  }
+}
+
+// backward, p recomputed from lse.  pass A (lane = query row): dq ; pass B1 (lane = key row): dv ; pass B2: dk.
+template <typename T, int D>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const T* qkv, const T* out, const float* lse, const T* dout, T* dqkv,
+                                                       int N, int H, float scale) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  T* qs = (T*)smem;                    // [N][D]
+  T* ks = qs + (size_t)N * D;
+  T* vs = ks + (size_t)N * D;
+  T* dos = vs + (size_t)N * D;         // [N][D]
+  float* dl = (float*)(dos + (size_t)N * D);   // [N] D_q = sum_d dO*O
+  float* ls = dl + N;                  // [N] lse
+  const int b = blockIdx.y, h = blockIdx.x;
+  const int C3 = 3 * H * D, C1 = H * D;
+  const T* base = qkv + (size_t)b * N * C3;
+  T* dbase = dqkv + (size_t)b * N * C3;
+  stage_rows<T, D>(qs, base + h * D, N, C3);
+  stage_rows<T, D>(ks, base + (H + h) * D, N, C3);
+  stage_rows<T, D>(vs, base + (2 * H + h) * D, N, C3);
+  stage_rows<T, D>(dos, dout + (size_t)b * N * C1 + h * D, N, C1);
+  __syncthreads();
+  for (int q = threadIdx.x; q < N; q += kThreads) {
+    float orow[D];
+    row_load<T, D>(orow, out + ((size_t)b * N + q) * C1 + h * D, 1.f);
+    dl[q] = row_dot<T, D>(dos + q * D, orow);
+    ls[q] = lse[((size_t)b * H + h) * N + q];
+  }
+  __syncthreads();
+  // pass A: dq[q] = scale * sum_j p*(dp - D_q) * k[j]
+  for (int q = threadIdx.x; q < N; q += kThreads) {
+    float qr[D], dor[D], dq[D];
+    row_load<T, D>(qr, qs + q * D, scale);
+    row_load<T, D>(dor, dos + q * D, 1.f);
+#pragma unroll
+    for (int dd = 0; dd < D; ++dd) dq[dd] = 0.f;
+    const float Lq = ls[q], Dq = dl[q];
+    for (int j = 0; j < N; ++j) {
+      const float s = row_dot<T, D>(ks + j * D, qr);
+      const float dp = row_dot<T, D>(vs + j * D, dor);
+      row_axpy<T, D>(dq, expf(s - Lq) * (dp - Dq), ks + j * D);
+    }
+    row_store<T, D>(dbase + (size_t)q * C3 + h * D, dq, scale);
+  }
+  // pass B1: dv[j] = sum_q p[q][j] * dO[q]
+  for (int j = threadIdx.x; j < N; j += kThreads) {
+    float kr[D], dv[D];
+    row_load<T, D>(kr, ks + j * D, scale);
+#pragma unroll
+    for (int dd = 0; dd < D; ++dd) dv[dd] = 0.f;
+    for (int q = 0; q < N; ++q) row_axpy<T, D>(dv, expf(row_dot<T, D>(qs + q * D, kr) - ls[q]), dos + q * D);
+    row_store<T, D>(dbase + (size_t)j * C3 + (2 * H + h) * D, dv, 1.f);
+  }
+  // pass B2: dk[j] = scale * sum_q p*(dp - D_q) * q[q]
+  for (int j = threadIdx.x; j < N; j += kThreads) {
+    float kr[D], vr[D], dk[D];
+    row_load<T, D>(kr, ks + j * D, scale);
+    row_load<T, D>(vr, vs + j * D, 1.f);
+#pragma unroll
+    for (int dd = 0; dd < D; ++dd) dk[dd] = 0.f;
+    for (int q = 0; q < N; ++q) {
+      const float p = expf(row_dot<T, D>(qs + q * D, kr) - ls[q]);
+      const float dp = row_dot<T, D>(dos + q * D, vr);
+      row_axpy<T, D>(dk, p * (dp - dl[q]), qs + q * D);
+    }
+    row_store<T, D>(dbase + (size_t)j * C3 + (H + h) * D, dk, scale);
+  }
+}
+
+// nearest x2 upsample with optional ReLU on the way (model_utilities.py:36-41: relu -> nn.Upsample(scale_factor=2))
+template <typename T>
+__global__ void upsample2_fwd_kernel(const T* x, T* y, int B, int H, int W, int C, int relu) {
+  constexpr int VEC = ElemTraits<T>::kVec;
+  const int CV = C / VEC;
+  const int64_t n = (int64_t)B * 2 * H * 2 * W * CV;
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (int64_t)gridDim.x * blockDim.x) {
+    const int cv = v % CV; int64_t r = v / CV;
+    const int ox = r % (2 * W); r /= 2 * W;
+    const int oy = r % (2 * H); const int b = r / (2 * H);
+    float f[VEC];
+    vec_unpack<T>(*(const u32x4*)(x + (((int64_t)b * H + oy / 2) * W + ox / 2) * C + cv * VEC), f);
+    if (relu) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) f[j] = fmaxf(f[j], 0.f);
+    }
+    *(u32x4*)(y + v * VEC) = vec_pack<T>(f);
+  }
+}
+// dx[b,y,x,c] = (x_pre > 0 if relu) * sum of the 4 dy positions
+template <typename T>
+__global__ void upsample2_bwd_kernel(const T* dy, const T* xpre, T* dx, int B, int H, int W, int C, int relu) {
+  constexpr int VEC = ElemTraits<T>::kVec;
+  const int CV = C / VEC;
+  const int64_t n = (int64_t)B * H * W * CV;
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (int64_t)gridDim.x * blockDim.x) {
+    const int cv = v % CV; int64_t r = v / CV;
+    const int ix = r % W; r /= W;
+    const int iy = r % H; const int b = r / H;
+    float s[VEC], t[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) s[j] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      vec_unpack<T>(*(const u32x4*)(dy + (((int64_t)b * 2 * H + 2 * iy + (k >> 1)) * 2 * W + 2 * ix + (k & 1)) * C + cv * VEC), t);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) s[j] += t[j];
+    }
+    if (relu) {
+      vec_unpack<T>(*(const u32x4*)(xpre + v * VEC), t);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) if (!(t[j] > 0.f)) s[j] = 0.f;
+    }
+    *(u32x4*)(dx + v * VEC) = vec_pack<T>(s);
+  }
+}
+
+template <typename T>
+void attn_fwd_launch(dim3 grid, size_t lds, hipStream_t st, const void* qkv, void* out, float* lse, int N, int H, float scale) {
+  auto k = attn_fwd_kernel<T, 64>;
+  if (lds > 65536) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(k, grid, dim3(256), lds, st, (const T*)qkv, (T*)out, lse, N, H, scale);
+}
+template <typename T>
+void attn_bwd_launch(dim3 grid, size_t lds, hipStream_t st, const void* qkv, const void* out, const float* lse, const void* dout,
+                     void* dqkv, int N, int H, float scale) {
+  auto k = attn_bwd_kernel<T, 64>;
+  if (lds > 65536) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(k, grid, dim3(256), lds, st, (const T*)qkv, (const T*)out, lse, (const T*)dout, (T*)dqkv, N, H, scale);
+}
+
+int grid_for(int64_t n, int cap = 8192) {
+  int64_t b = (n + kThreads - 1) / kThreads;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+#define KSMI_DT(dtype, EXPR_BF16, EXPR_F32)                                  \
+  do {                                                                       \
+    if ((dtype) == KSMI_BF16) { EXPR_BF16; }                                 \
+    else if ((dtype) == KSMI_F32) { EXPR_F32; }                              \
+    else return ksmi_fail(KSMI_E_ARG, "bad dtype");                          \
+  } while (0)
+
+extern "C" {
+
+int ksmi_layernorm_forward(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                           int rows, int C, float eps, int dtype, void* stream) {
+  const int vec = dtype == KSMI_BF16 ? 8 : 4;
+  if (C % vec || C / vec > 64 * 8) return ksmi_fail(KSMI_E_ARG, "layernorm: C must be a multiple of the vector and <= 512 vectors");
+  const dim3 grid((rows + 3) / 4);
+  KSMI_DT(dtype,
+          hipLaunchKernelGGL((layernorm_fwd_kernel<bf16_t, 8>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, rows, C, eps),
+          hipLaunchKernelGGL((layernorm_fwd_kernel<float, 8>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, gamma, beta, (float*)y, mean, rstd, rows, C, eps));
+  return ksmi_check_launch("layernorm_fwd");
+}
+
+int ksmi_layernorm_bwd_blocks(int rows) { int b = (rows + 31) / 32; return b > 512 ? 512 : (b < 1 ? 1 : b); }
+
+int ksmi_layernorm_backward(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma, void* dx,
+                            int accumulate, float* partial, int rows, int C, int dtype, void* stream) {
+  const int vec = dtype == KSMI_BF16 ? 8 : 4;
+  if (C % vec || C / vec > 64 * 8) return ksmi_fail(KSMI_E_ARG, "layernorm_bwd: unsupported C");
+  const int nblk = ksmi_layernorm_bwd_blocks(rows);
+  const int rpb = (rows + nblk - 1) / nblk;
+  const size_t lds = (size_t)2 * C * sizeof(float);
+  KSMI_DT(dtype,
+          hipLaunchKernelGGL((layernorm_bwd_kernel<bf16_t, 8>), dim3(nblk), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x, mean, rstd, gamma, (bf16_t*)dx, accumulate, partial, rows, C, rpb),
+          hipLaunchKernelGGL((layernorm_bwd_kernel<float, 8>), dim3(nblk), dim3(256), lds, (hipStream_t)stream, (const float*)dy, (const float*)x, mean, rstd, gamma, (float*)dx, accumulate, partial, rows, C, rpb));
+  return ksmi_check_launch("layernorm_bwd");
+}
+
+#define KSMI_ELT(MODE_, a_, b_, out_, n_, what_)                                                                       \
+  const int vec = dtype == KSMI_BF16 ? 8 : 4;                                                                          \
+  if ((n_) % vec) return ksmi_fail(KSMI_E_ARG, what_ ": element count must be a multiple of the 16-byte vector");      \
+  const int64_t nvec = (n_) / vec;                                                                                     \
+  KSMI_DT(dtype,                                                                                                        \
+          hipLaunchKernelGGL((eltwise_kernel<bf16_t, MODE_>), dim3(grid_for(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)(a_), (const bf16_t*)(b_), (bf16_t*)(out_), nvec), \
+          hipLaunchKernelGGL((eltwise_kernel<float, MODE_>), dim3(grid_for(nvec)), dim3(256), 0, (hipStream_t)stream, (const float*)(a_), (const float*)(b_), (float*)(out_), nvec)); \
+  return ksmi_check_launch(what_);
+
+int ksmi_gelu_forward(const void* x, void* y, int64_t n, int dtype, void* stream) { KSMI_ELT(0, x, x, y, n, "gelu_fwd") }
+int ksmi_gelu_backward(const void* dy, const void* x, void* dx, int64_t n, int dtype, void* stream) { KSMI_ELT(1, dy, x, dx, n, "gelu_bwd") }
+int ksmi_add(const void* a, const void* b, void* out, int64_t n, int dtype, void* stream) { KSMI_ELT(2, a, b, out, n, "add") }
+int ksmi_relu_backward(const void* dy, const void* x, void* dx, int64_t n, int dtype, void* stream) { KSMI_ELT(3, dy, x, dx, n, "relu_bwd") }
+
+int ksmi_patchify(const float* x_nchw, void* out, int B, int Cin, int H, int W, int P, int dtype, void* stream) {
+  if (H % P || W % P) return ksmi_fail(KSMI_E_ARG, "patchify: image not divisible by the patch size");
+  const int64_t n = (int64_t)B * Cin * H * W;
+  KSMI_DT(dtype,
+          hipLaunchKernelGGL(patchify_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x_nchw, (bf16_t*)out, B, Cin, H, W, P),
+          hipLaunchKernelGGL(patchify_kernel<float>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x_nchw, (float*)out, B, Cin, H, W, P));
+  return ksmi_check_launch("patchify");
+}
+
+int ksmi_vit_embed_forward(const void* emb, const float* cls, const float* pos, void* x0, int B, int N1, int C, int dtype, void* stream) {
+  const int64_t n = (int64_t)B * N1 * C;
+  KSMI_DT(dtype,
+          hipLaunchKernelGGL(vit_embed_fwd_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)emb, cls, pos, (bf16_t*)x0, B, N1, C),
+          hipLaunchKernelGGL(vit_embed_fwd_kernel<float>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const float*)emb, cls, pos, (float*)x0, B, N1, C));
+  return ksmi_check_launch("vit_embed_fwd");
+}
+
+int ksmi_vit_embed_backward(const void* dx0, void* demb, float* dcls, float* dpos, int B, int N1, int C, int dtype, void* stream) {
+  const int64_t n = (int64_t)N1 * C;
+  KSMI_DT(dtype,
+          hipLaunchKernelGGL(vit_embed_bwd_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dx0, (bf16_t*)demb, dcls, dpos, B, N1, C),
+          hipLaunchKernelGGL(vit_embed_bwd_kernel<float>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const float*)dx0, (float*)demb, dcls, dpos, B, N1, C));
+  return ksmi_check_launch("vit_embed_bwd");
+}
+
+int ksmi_attention_forward(const void* qkv, void* out, float* lse, int B, int N, int H, int D, float scale, int dtype, void* stream) {
+  if (D != 64) return ksmi_fail(KSMI_E_UNSUPPORTED, "attention: dim_head must be 64");
+  const size_t es = dtype == KSMI_BF16 ? 2 : 4;
+  const size_t lds = 2 * (size_t)N * D * es;
+  if (lds > 160 * 1024) return ksmi_fail(KSMI_E_UNSUPPORTED, "attention: sequence too long for the LDS-resident kernel");
+  const dim3 grid(H, B);
+  KSMI_DT(dtype, attn_fwd_launch<bf16_t>(grid, lds, (hipStream_t)stream, qkv, out, lse, N, H, scale),
+          attn_fwd_launch<float>(grid, lds, (hipStream_t)stream, qkv, out, lse, N, H, scale));
+  return ksmi_check_launch("attention_fwd");
+}
+
+int ksmi_attention_backward(const void* qkv, const void* out, const float* lse, const void* dout, void* dqkv, int B, int N, int H,
+                            int D, float scale, int dtype, void* stream) {
+  if (D != 64) return ksmi_fail(KSMI_E_UNSUPPORTED, "attention: dim_head must be 64");
+  const size_t es = dtype == KSMI_BF16 ? 2 : 4;
+  const size_t lds = 4 * (size_t)N * D * es + 2 * (size_t)N * sizeof(float);
+  if (lds > 160 * 1024) return ksmi_fail(KSMI_E_UNSUPPORTED, "attention_bwd: sequence too long for the LDS-resident kernel");
+  const dim3 grid(H, B);
+  KSMI_DT(dtype, attn_bwd_launch<bf16_t>(grid, lds, (hipStream_t)stream, qkv, out, lse, dout, dqkv, N, H, scale),
+          attn_bwd_launch<float>(grid, lds, (hipStream_t)stream, qkv, out, lse, dout, dqkv, N, H, scale));
+  return ksmi_check_launch("attention_bwd");
+}
+
+int ksmi_upsample2_forward(const void* x, void* y, int B, int H, int W, int C, int relu, int dtype, void* stream) {
+  const int vec = dtype == KSMI_BF16 ? 8 : 4;
+  if (C % vec) return ksmi_fail(KSMI_E_ARG, "upsample2: C must be a multiple of the vector");
+  const int64_t n = (int64_t)B * 4 * H * W * (C / vec);
+  KSMI_DT(dtype,
+          hipLaunchKernelGGL(upsample2_fwd_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, B, H, W, C, relu),
+          hipLaunchKernelGGL(upsample2_fwd_kernel<float>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, B, H, W, C, relu));
+  return ksmi_check_launch("upsample2_fwd");
+}
+
+int ksmi_upsample2_backward(const void* dy, const void* x_pre, void* dx, int B, int H, int W, int C, int relu, int dtype, void* stream) {
+  const int vec = dtype == KSMI_BF16 ? 8 : 4;
+  if (C % vec) return ksmi_fail(KSMI_E_ARG, "upsample2: C must be a multiple of the vector");
+  const int64_t n = (int64_t)B * H * W * (C / vec);
+  KSMI_DT(dtype,
+          hipLaunchKernelGGL(upsample2_bwd_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x_pre, (bf16_t*)dx, B, H, W, C, relu),
+          hipLaunchKernelGGL(upsample2_bwd_kernel<float>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const float*)dy, (const float*)x_pre, (float*)dx, B, H, W, C, relu));
+  return ksmi_check_launch("upsample2_bwd");
+}
+
+}  // extern "C"

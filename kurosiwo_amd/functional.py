@@ -118,3 +118,100 @@ def deconv2x2_backward(x, dy, weight):
     dw.partial = wsb.data_ptr()
     _lib.check(_lib.load().ksmi_conv_wgrad(C.byref(dw), DT[dtype], stream_ptr()), "deconv_wgrad")
     return dx, grad
+
+
+# ---------------------------------------------------------------------------------------------------
+# token ops (FloodViT path): x is [rows, C] in the activation dtype
+# ---------------------------------------------------------------------------------------------------
+def linear(x, weight, bias=None, out=None, accumulate=0):
+    """y[rows, N] (+)= x[rows, Cin] @ weight[N, Cin]^T + bias  — a 1x1 implicit GEMM over a rows x 1 'image'."""
+    dtype = x.dtype
+    rows, Cin = x.shape
+    N = weight.shape[0]
+    if out is None:
+        out = torch.empty((rows, N), dtype=dtype, device=x.device)
+    d, table = make_conv([SrcSpec(x, Cin)], [(out, N, 0, 0, N, accumulate)], out, bias, None, 1, rows, 1, rows, 1, 1, 1, 1, 0, N, dtype)
+    wpk = _pack(weight.contiguous(), table, 1, N, N, 1, Cin, 0, 0, 0, dtype)
+    d.wpk = wpk.data_ptr()
+    _lib.check(_lib.load().ksmi_conv_forward(C.byref(d), DT[dtype], stream_ptr()), "linear")
+    return out
+
+
+def linear_dgrad(dy, weight, out=None, accumulate=0):
+    """dx[rows, Cin] (+)= dy[rows, N] @ weight[N, Cin]."""
+    dtype = dy.dtype
+    rows, N = dy.shape
+    Cin = weight.shape[1]
+    if out is None:
+        out = torch.empty((rows, Cin), dtype=dtype, device=dy.device)
+    d, table = make_conv([SrcSpec(dy, N)], [(out, Cin, 0, 0, Cin, accumulate)], out, None, None, 1, rows, 1, rows, 1, 1, 1, 1, 0, Cin, dtype)
+    wpk = _pack(weight.contiguous(), table, 1, Cin, Cin, Cin, 1, 0, 0, 0, dtype)
+    d.wpk = wpk.data_ptr()
+    _lib.check(_lib.load().ksmi_conv_forward(C.byref(d), DT[dtype], stream_ptr()), "linear_dgrad")
+    return out
+
+
+def linear_wgrad(x, dy):
+    """dW[N, Cin] = dy^T @ x (fp32)."""
+    dtype = x.dtype
+    rows, Cin = x.shape
+    N = dy.shape[1]
+    grad = torch.zeros((N, Cin), dtype=torch.float32, device=x.device)
+    d, ws = make_wgrad([SrcSpec(x, Cin)], dy, N, 0, N, grad, 1, Cin, 0, 0, 1, rows, 1, rows, 1, 1, 1, 1, 0, dtype)
+    wsb = torch.empty(max(ws, 16), dtype=torch.uint8, device=x.device)
+    d.partial = wsb.data_ptr()
+    _lib.check(_lib.load().ksmi_conv_wgrad(C.byref(d), DT[dtype], stream_ptr()), "linear_wgrad")
+    return grad
+
+
+def layernorm(x, gamma, beta, eps=1e-5):
+    rows, Cc = x.shape
+    lib = _lib.load()
+    y = torch.empty_like(x)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    _lib.check(lib.ksmi_layernorm_forward(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), mean.data_ptr(),
+                                          rstd.data_ptr(), rows, Cc, eps, DT[x.dtype], stream_ptr()), "layernorm_forward")
+    return y, mean, rstd
+
+
+def layernorm_backward(dy, x, mean, rstd, gamma):
+    rows, Cc = x.shape
+    lib = _lib.load()
+    dx = torch.empty_like(x)
+    nblk = lib.ksmi_layernorm_bwd_blocks(rows)
+    partial = torch.empty((nblk, 2, Cc), dtype=torch.float32, device=x.device)
+    _lib.check(lib.ksmi_layernorm_backward(dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
+                                           dx.data_ptr(), 0, partial.data_ptr(), rows, Cc, DT[x.dtype], stream_ptr()), "layernorm_backward")
+    dgamma = torch.empty(Cc, dtype=torch.float32, device=x.device)
+    dbeta = torch.empty(Cc, dtype=torch.float32, device=x.device)
+    _lib.check(lib.ksmi_reduce_rows(partial.data_ptr(), nblk, 2, Cc, Cc, None, dgamma.data_ptr(), dbeta.data_ptr(), 0, stream_ptr()), "reduce_rows")
+    return dx, dgamma, dbeta
+
+
+def gelu(x):
+    y = torch.empty_like(x)
+    _lib.check(_lib.load().ksmi_gelu_forward(x.data_ptr(), y.data_ptr(), x.numel(), DT[x.dtype], stream_ptr()), "gelu")
+    return y
+
+
+def gelu_backward(dy, x):
+    dx = torch.empty_like(x)
+    _lib.check(_lib.load().ksmi_gelu_backward(dy.data_ptr(), x.data_ptr(), dx.data_ptr(), x.numel(), DT[x.dtype], stream_ptr()), "gelu_bwd")
+    return dx
+
+
+def attention(qkv, B, N, H, D=64):
+    """qkv [B*N, 3*H*D] -> (out [B*N, H*D], lse [B,H,N])."""
+    out = torch.empty((B * N, H * D), dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
+    _lib.check(_lib.load().ksmi_attention_forward(qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), B, N, H, D, D ** -0.5,
+                                                  DT[qkv.dtype], stream_ptr()), "attention_forward")
+    return out, lse
+
+
+def attention_backward(qkv, out, lse, dout, B, N, H, D=64):
+    dqkv = torch.empty_like(qkv)
+    _lib.check(_lib.load().ksmi_attention_backward(qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), dout.data_ptr(), dqkv.data_ptr(),
+                                                   B, N, H, D, D ** -0.5, DT[qkv.dtype], stream_ptr()), "attention_backward")
+    return dqkv

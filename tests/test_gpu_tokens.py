@@ -1,0 +1,107 @@
+"""GPU parity of the token-sequence kernels of the FloodViT path (through the C-ABI) against stock
+torch-CPU fp32 ops on the same seeded inputs (rows V1-V4 of SURVEY.md §8(a))."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle.seeded import seeded_tensor
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _tol(dtype):
+    return 3e-5 if dtype == torch.float32 else 3e-2
+
+
+def q(t, dtype):
+    return t.to(dtype).float()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,cin,n", [(394, 1024, 3072), (197, 1536, 1024), (300, 2048, 1024), (64, 64, 48)])
+def test_linear_forward_dgrad_wgrad(dev, dtype, rows, cin, n):
+    from kurosiwo_amd import functional as Fk
+    tag = f"lin{rows}{cin}{n}"
+    x = seeded_tensor(tag + "x", (rows, cin))
+    w = seeded_tensor(tag + "w", (n, cin)) * cin ** -0.5
+    b = seeded_tensor(tag + "b", (n,)) * 0.1
+    dy = seeded_tensor(tag + "dy", (rows, n))
+    xr, wr = q(x, dtype).requires_grad_(True), q(w, dtype).requires_grad_(True)
+    y_ref = F.linear(xr, wr, b)
+    y_ref.backward(q(dy, dtype))
+    xd, dyd = x.to(dev).to(dtype), dy.to(dev).to(dtype)
+    y = Fk.linear(xd, w.to(dev), b.to(dev))
+    tol = _tol(dtype)
+    assert (y.float().cpu() - y_ref.detach()).abs().max() < tol * y_ref.abs().max()
+    dx = Fk.linear_dgrad(dyd, w.to(dev))
+    assert (dx.float().cpu() - xr.grad).abs().max() < tol * xr.grad.abs().max()
+    dw = Fk.linear_wgrad(xd, dyd)
+    assert (dw.cpu() - wr.grad).abs().max() < tol * wr.grad.abs().max()
+    # residual form: out += x @ W^T
+    acc = Fk.linear(xd, w.to(dev), None, out=y.clone(), accumulate=1)
+    ref2 = q(y.float().cpu(), dtype) + F.linear(q(x, dtype), q(w, dtype))
+    assert (acc.float().cpu() - ref2).abs().max() < 2 * tol * ref2.abs().max()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,c", [(394, 1024), (197, 1536), (37, 64)])
+def test_layernorm(dev, dtype, rows, c):
+    from kurosiwo_amd import functional as Fk
+    tag = f"ln{rows}{c}"
+    x = seeded_tensor(tag + "x", (rows, c)) * 2 + 0.5
+    g = 1 + 0.2 * seeded_tensor(tag + "g", (c,))
+    b = 0.1 * seeded_tensor(tag + "b", (c,))
+    dy = seeded_tensor(tag + "dy", (rows, c))
+    xr, gr, br = q(x, dtype).requires_grad_(True), g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y_ref = F.layer_norm(xr, (c,), gr, br, 1e-5)
+    y_ref.backward(q(dy, dtype))
+    xd = x.to(dev).to(dtype)
+    y, mean, rstd = Fk.layernorm(xd, g.to(dev), b.to(dev))
+    tol = _tol(dtype)
+    assert (y.float().cpu() - y_ref.detach()).abs().max() < tol * y_ref.abs().max()
+    dx, dg, db = Fk.layernorm_backward(dy.to(dev).to(dtype), xd, mean, rstd, g.to(dev))
+    assert (dx.float().cpu() - xr.grad).abs().max() < tol * xr.grad.abs().max()
+    assert (dg.cpu() - gr.grad).abs().max() < 1e-3 * gr.grad.abs().max()
+    assert (db.cpu() - br.grad).abs().max() < 1e-3 * br.grad.abs().max()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gelu(dev, dtype):
+    from kurosiwo_amd import functional as Fk
+    x = seeded_tensor("gelu.x", (100, 64)) * 3
+    dy = seeded_tensor("gelu.dy", (100, 64))
+    xr = q(x, dtype).requires_grad_(True)
+    y_ref = F.gelu(xr)
+    y_ref.backward(q(dy, dtype))
+    xd = x.to(dev).to(dtype)
+    tol = _tol(dtype)
+    assert (Fk.gelu(xd).float().cpu() - y_ref.detach()).abs().max() < tol * y_ref.abs().max()
+    assert (Fk.gelu_backward(dy.to(dev).to(dtype), xd).float().cpu() - xr.grad).abs().max() < tol * xr.grad.abs().max()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,N,H", [(2, 197, 16), (1, 50, 2), (3, 300, 4)])
+def test_attention(dev, dtype, B, N, H):
+    from kurosiwo_amd import functional as Fk
+    D = 64
+    tag = f"att{B}{N}{H}"
+    qkv = seeded_tensor(tag + "qkv", (B * N, 3 * H * D))
+    dout = seeded_tensor(tag + "do", (B * N, H * D))
+    qr = q(qkv, dtype).requires_grad_(True)
+    t = qr.view(B, N, 3, H, D)
+    qq, kk, vv = (t[:, :, i].permute(0, 2, 1, 3) for i in range(3))           # b h n d  ("(3 h d)" chunk order)
+    attn = torch.softmax(qq @ kk.transpose(-1, -2) * D ** -0.5, dim=-1)
+    o_ref = (attn @ vv).permute(0, 2, 1, 3).reshape(B * N, H * D)
+    o_ref.backward(q(dout, dtype))
+    qd = qkv.to(dev).to(dtype)
+    out, lse = Fk.attention(qd, B, N, H)
+    tol = _tol(dtype)
+    assert (out.float().cpu() - o_ref.detach()).abs().max() < tol * o_ref.abs().max()
+    dqkv = Fk.attention_backward(qd, out, lse, dout.to(dev).to(dtype), B, N, H)
+    assert (dqkv.float().cpu() - qr.grad).abs().max() < tol * qr.grad.abs().max()
