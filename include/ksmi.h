@@ -31,7 +31,7 @@ extern "C" {
 #define KSMI_E_ARG (-1)
 #define KSMI_E_UNSUPPORTED (-2)
 #define KSMI_MAX_SRC 6
-#define KSMI_MAX_CHUNKS 72
+#define KSMI_MAX_CHUNKS 256
 
 int ksmi_abi_version(void);
 const char* ksmi_last_error(void);
@@ -77,7 +77,7 @@ typedef struct ksmi_conv_desc {
   const void* mask_src; /* NHWC `dtype`, N channels */
   const float* m_mean; const float* m_rstd; const float* m_scale; const float* m_shift;
   int32_t B, Hin, Win, Hout, Wout;
-  int32_t KH, KW, stride, pad;   /* supported: 3x3 s1 p1, 1x1 s1 p0, 2x2 s2 p0 */
+  int32_t KH, KW, stride, pad;   /* supported kernel sizes: 1x1, 2x2, 3x3, 4x4 (any stride/pad that keeps the halo <= 512 px) */
   int32_t TH, TW;                /* output patch per workgroup, TH*TW <= 256 */
   int32_t N, Npad;               /* GEMM columns (output channels), padded to 16 */
   int32_t nchunks;
@@ -85,6 +85,10 @@ typedef struct ksmi_conv_desc {
                                     column j=(dy*2+dx)*ps_cout+n -> out[b,2y+dy,2x+dx,n] */
   uint16_t chunk_c0[KSMI_MAX_CHUNKS];  /* channel offset (within the source's used range) per k-chunk */
   uint8_t chunk_src[KSMI_MAX_CHUNKS];  /* source index per k-chunk */
+  int32_t pad_x;                 /* left padding (pad = top padding); set pad_x = pad for the usual symmetric case */
+  /* strided output placement (phase convolutions of ConvTranspose2d k4 s2 p1): result pixel (oy,ox) is written to
+   * (oy*out_sy + out_oy, ox*out_sx + out_ox) of a [B, out_H, out_W, C] tensor; out_sy == 0 => dense [B,Hout,Wout,C] */
+  int32_t out_sy, out_sx, out_oy, out_ox, out_H, out_W;
 } ksmi_conv_desc;
 
 /* number of M-tiles (= rows of `stats`) a descriptor launches */
@@ -101,6 +105,8 @@ typedef struct ksmi_pack_desc {
   int32_t flip;
   int32_t k_off[KSMI_MAX_CHUNKS];
   int32_t k_len[KSMI_MAX_CHUNKS];
+  int32_t use_tap_map;            /* 1: tap' = tap_map[tap] (phase kernels of ConvTranspose2d k4 s2 p1) */
+  int32_t tap_map[16];
 } ksmi_pack_desc;
 int ksmi_pack_weights(const ksmi_pack_desc* d, int dtype, void* stream);
 /* n descriptors stored in DEVICE memory, packed by one launch (a model plan re-packs every conv each step) */

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libksmi.so")
 
 KSMI_F32, KSMI_BF16 = 0, 1
-MAX_SRC, MAX_CHUNKS = 6, 72
+MAX_SRC, MAX_CHUNKS = 6, 256
 ABI_VERSION = 1
 
 
@@ -37,7 +37,9 @@ class ConvDesc(C.Structure):
                 ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
                 ("TH", C.c_int32), ("TW", C.c_int32), ("N", C.c_int32), ("Npad", C.c_int32),
                 ("nchunks", C.c_int32), ("ps_cout", C.c_int32),
-                ("chunk_c0", C.c_uint16 * MAX_CHUNKS), ("chunk_src", C.c_uint8 * MAX_CHUNKS)]
+                ("chunk_c0", C.c_uint16 * MAX_CHUNKS), ("chunk_src", C.c_uint8 * MAX_CHUNKS),
+                ("pad_x", C.c_int32), ("out_sy", C.c_int32), ("out_sx", C.c_int32), ("out_oy", C.c_int32),
+                ("out_ox", C.c_int32), ("out_H", C.c_int32), ("out_W", C.c_int32)]
 
 
 class PackDesc(C.Structure):
@@ -45,7 +47,8 @@ class PackDesc(C.Structure):
                 ("nchunks", C.c_int32), ("taps", C.c_int32), ("N", C.c_int32), ("Npad", C.c_int32), ("n_mod", C.c_int32),
                 ("sK", C.c_int64), ("sN", C.c_int64), ("sD", C.c_int64), ("sT", C.c_int64),
                 ("flip", C.c_int32),
-                ("k_off", C.c_int32 * MAX_CHUNKS), ("k_len", C.c_int32 * MAX_CHUNKS)]
+                ("k_off", C.c_int32 * MAX_CHUNKS), ("k_len", C.c_int32 * MAX_CHUNKS),
+                ("use_tap_map", C.c_int32), ("tap_map", C.c_int32 * 16)]
 
 
 class WgradDesc(C.Structure):

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const ksmi_conv_desc d) 
     if (v < nvec) {
       const int pix = v >> 2, q = v & 3;
       const int hy = pix / HW, hx = pix - hy * HW;
-      const int iy = oy0 * S - d.pad + hy, ix = ox0 * S - d.pad + hx;
+      const int iy = oy0 * S - d.pad + hy, ix = ox0 * S - d.pad_x + hx;
       slot_goff[s] = (iy >= 0 && iy < d.Hin && ix >= 0 && ix < d.Win) ? ((b * d.Hin + iy) * d.Win + ix) : -1;
       slot_lds[s] = pix * 64 + ((q ^ swz(pix)) << 4);
     }
@@ -167,7 +167,7 @@ __global__ void pack_weights_kernel(const ksmi_pack_desc d) {
     float v = 0.f;
     if (j < d.N && kk < d.k_len[ch]) {
       const int64_t k = d.k_off[ch] + kk;
-      const int tp = d.flip ? (d.taps - 1 - tap) : tap;
+      const int tp = d.use_tap_map ? d.tap_map[tap] : (d.flip ? (d.taps - 1 - tap) : tap);
       v = d.w[k * d.sK + (int64_t)(j % d.n_mod) * d.sN + (int64_t)(j / d.n_mod) * d.sD + tp * d.sT];
     }
     ElemTraits<T>::st((T*)d.out + i, v);
@@ -190,7 +190,7 @@ __global__ void pack_weights_batched_kernel(const ksmi_pack_desc* descs) {
     float v = 0.f;
     if (j < N && kk < d.k_len[ch]) {
       const int64_t k = d.k_off[ch] + kk;
-      const int tp = flip ? (taps - 1 - tap) : tap;
+      const int tp = d.use_tap_map ? d.tap_map[tap] : (flip ? (taps - 1 - tap) : tap);
       v = w[k * sK + (int64_t)(j % n_mod) * sN + (int64_t)(j / n_mod) * sD + tp * sT];
     }
     ElemTraits<T>::st(out + i, v);
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const ksmi_wgrad_desc 
       for (int v = tid; v < HP * 4; v += 256) {
         const int pix = v >> 2;
         const int hy = dHW.div(pix), hx = pix - hy * HW;
-        const int iy = oy0 * S - d.pad + hy, ix = ox0 * S - d.pad + hx;
+        const int iy = oy0 * S - d.pad + hy, ix = ox0 * S - d.pad_x + hx;
         u32x4 x = (u32x4){0u, 0u, 0u, 0u};
         if (cvalid && iy >= 0 && iy < d.Hin && ix >= 0 && ix < d.Win) {
           x = *(const u32x4*)(sp + ((size_t)(b * d.Hin + iy) * d.Win + ix) * sr.C);

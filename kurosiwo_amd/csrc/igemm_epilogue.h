@@ -28,6 +28,12 @@ __device__ __forceinline__ int chunk_src_of(const ksmi_conv_desc& d, int ch) {
   return (int)((((const uint32_t*)d.chunk_src)[ch >> 2] >> ((ch & 3) * 8)) & 0xffu);
 }
 
+// destination pixel index of result pixel (b, oy, ox): dense, or the strided placement of a phase convolution
+__device__ __forceinline__ size_t dst_pixel(const ksmi_conv_desc& d, int b, int oy, int ox) {
+  if (d.out_sy == 0) return ((size_t)b * d.Hout + oy) * d.Wout + ox;
+  return ((size_t)b * d.out_H + (oy * d.out_sy + d.out_oy)) * d.out_W + (ox * d.out_sx + d.out_ox);
+}
+
 template <typename T, int NT>
 __device__ __forceinline__ void igemm_epilogue(const ksmi_conv_desc& d, f32x4 (&acc)[4][NT], unsigned char* smem, int tid,
                                                int wave, int g, int l15, int b, int oy0, int ox0, int n0, int P) {
@@ -115,7 +121,7 @@ __device__ __forceinline__ void igemm_epilogue(const ksmi_conv_desc& d, f32x4 (&
         const size_t op2 = ((size_t)b * (2 * d.Hout) + (2 * oy + (dd >> 1))) * (2 * d.Wout) + (2 * ox + (dd & 1));
         dp = (T*)ds.ptr + op2 * ds.C + ds.c_off + nn;
       } else {
-        dp = (T*)ds.ptr + opix * ds.C + ds.c_off + (nq - ds.n_begin);
+        dp = (T*)ds.ptr + dst_pixel(d, b, oy, ox) * ds.C + ds.c_off + (nq - ds.n_begin);
       }
       if (vec_ok) {
         if (ds.accumulate) {
@@ -138,7 +144,7 @@ __device__ __forceinline__ void igemm_epilogue(const ksmi_conv_desc& d, f32x4 (&
             const size_t op2 = ((size_t)b * (2 * d.Hout) + (2 * oy + (dd >> 1))) * (2 * d.Wout) + (2 * ox + (dd & 1));
             q = (T*)dj.ptr + op2 * dj.C + dj.c_off + nn;
           } else {
-            q = (T*)dj.ptr + opix * dj.C + dj.c_off + (n - dj.n_begin);
+            q = (T*)dj.ptr + dst_pixel(d, b, oy, ox) * dj.C + dj.c_off + (n - dj.n_begin);
           }
           float o = v[j];
           if (dj.accumulate) o += ElemTraits<T>::ld(q);
@@ -273,7 +279,7 @@ __device__ __forceinline__ void igemm_epilogue_direct(const ksmi_conv_desc& d, f
         const size_t op2 = ((size_t)b * (2 * d.Hout) + (2 * oyv[mf] + (dd >> 1))) * (2 * d.Wout) + (2 * oxv[mf] + (dd & 1));
         dp = (T*)ds.ptr + op2 * ds.C + ds.c_off + nn;
       } else {
-        dp = (T*)ds.ptr + opix[mf] * ds.C + ds.c_off + nn;
+        dp = (T*)ds.ptr + dst_pixel(d, b, oyv[mf], oxv[mf]) * ds.C + ds.c_off + nn;
       }
       if (vec_ok) {
         if (ds.accumulate) {
@@ -295,7 +301,7 @@ __device__ __forceinline__ void igemm_epilogue_direct(const ksmi_conv_desc& d, f
             const size_t op2 = ((size_t)b * (2 * d.Hout) + (2 * oyv[mf] + (d2 >> 1))) * (2 * d.Wout) + (2 * oxv[mf] + (d2 & 1));
             q = (T*)dj.ptr + op2 * dj.C + dj.c_off + n2;
           } else {
-            q = (T*)dj.ptr + opix[mf] * dj.C + dj.c_off + (n - dj.n_begin);
+            q = (T*)dj.ptr + dst_pixel(d, b, oyv[mf], oxv[mf]) * dj.C + dj.c_off + (n - dj.n_begin);
           }
           float o = v[r];
           if (dj.accumulate) o += ElemTraits<T>::ld(q);

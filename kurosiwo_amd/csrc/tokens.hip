@@ -303,63 +303,65 @@ template <typename T, int D>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* qkv, const T* out, const float* lse, const T* dout, T* dqkv,
                                                        int N, int H, float scale) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  T* qs = (T*)smem;                    // [N][D]
-  T* ks = qs + (size_t)N * D;
-  T* vs = ks + (size_t)N * D;
-  T* dos = vs + (size_t)N * D;         // [N][D]
-  float* dl = (float*)(dos + (size_t)N * D);   // [N] D_q = sum_d dO*O
+  // two LDS matrices at a time: pass A keeps K,V resident (q / dO rows come from global memory), passes B1/B2
+  // keep Q,dO resident (k / v rows from global memory) -> 2*N*D elements instead of 4 (fp32 N=197 fits 160 KB)
+  T* m0 = (T*)smem;                    // [N][D]  K, then Q
+  T* m1 = m0 + (size_t)N * D;          // [N][D]  V, then dO
+  float* dl = (float*)(m1 + (size_t)N * D);    // [N] D_q = sum_d dO*O
   float* ls = dl + N;                  // [N] lse
   const int b = blockIdx.y, h = blockIdx.x;
   const int C3 = 3 * H * D, C1 = H * D;
   const T* base = qkv + (size_t)b * N * C3;
+  const T* dob = dout + (size_t)b * N * C1 + h * D;
   T* dbase = dqkv + (size_t)b * N * C3;
-  stage_rows<T, D>(qs, base + h * D, N, C3);
-  stage_rows<T, D>(ks, base + (H + h) * D, N, C3);
-  stage_rows<T, D>(vs, base + (2 * H + h) * D, N, C3);
-  stage_rows<T, D>(dos, dout + (size_t)b * N * C1 + h * D, N, C1);
-  __syncthreads();
+  stage_rows<T, D>(m0, base + (H + h) * D, N, C3);
+  stage_rows<T, D>(m1, base + (2 * H + h) * D, N, C3);
   for (int q = threadIdx.x; q < N; q += kThreads) {
     float orow[D];
     row_load<T, D>(orow, out + ((size_t)b * N + q) * C1 + h * D, 1.f);
-    dl[q] = row_dot<T, D>(dos + q * D, orow);
+    dl[q] = row_dot<T, D>(dob + (size_t)q * C1, orow);
     ls[q] = lse[((size_t)b * H + h) * N + q];
   }
   __syncthreads();
   // pass A: dq[q] = scale * sum_j p*(dp - D_q) * k[j]
   for (int q = threadIdx.x; q < N; q += kThreads) {
     float qr[D], dor[D], dq[D];
-    row_load<T, D>(qr, qs + q * D, scale);
-    row_load<T, D>(dor, dos + q * D, 1.f);
+    row_load<T, D>(qr, base + (size_t)q * C3 + h * D, scale);
+    row_load<T, D>(dor, dob + (size_t)q * C1, 1.f);
 #pragma unroll
     for (int dd = 0; dd < D; ++dd) dq[dd] = 0.f;
     const float Lq = ls[q], Dq = dl[q];
     for (int j = 0; j < N; ++j) {
-      const float s = row_dot<T, D>(ks + j * D, qr);
-      const float dp = row_dot<T, D>(vs + j * D, dor);
-      row_axpy<T, D>(dq, expf(s - Lq) * (dp - Dq), ks + j * D);
+      const float s = row_dot<T, D>(m0 + j * D, qr);
+      const float dp = row_dot<T, D>(m1 + j * D, dor);
+      row_axpy<T, D>(dq, expf(s - Lq) * (dp - Dq), m0 + j * D);
     }
     row_store<T, D>(dbase + (size_t)q * C3 + h * D, dq, scale);
   }
+  __syncthreads();
+  stage_rows<T, D>(m0, base + h * D, N, C3);          // Q
+  stage_rows<T, D>(m1, dob, N, C1);                    // dO
+  __syncthreads();
   // pass B1: dv[j] = sum_q p[q][j] * dO[q]
   for (int j = threadIdx.x; j < N; j += kThreads) {
     float kr[D], dv[D];
-    row_load<T, D>(kr, ks + j * D, scale);
+    row_load<T, D>(kr, base + (size_t)j * C3 + (H + h) * D, scale);
 #pragma unroll
     for (int dd = 0; dd < D; ++dd) dv[dd] = 0.f;
-    for (int q = 0; q < N; ++q) row_axpy<T, D>(dv, expf(row_dot<T, D>(qs + q * D, kr) - ls[q]), dos + q * D);
+    for (int q = 0; q < N; ++q) row_axpy<T, D>(dv, expf(row_dot<T, D>(m0 + q * D, kr) - ls[q]), m1 + q * D);
     row_store<T, D>(dbase + (size_t)j * C3 + (2 * H + h) * D, dv, 1.f);
   }
   // pass B2: dk[j] = scale * sum_q p*(dp - D_q) * q[q]
   for (int j = threadIdx.x; j < N; j += kThreads) {
     float kr[D], vr[D], dk[D];
-    row_load<T, D>(kr, ks + j * D, scale);
-    row_load<T, D>(vr, vs + j * D, 1.f);
+    row_load<T, D>(kr, base + (size_t)j * C3 + (H + h) * D, scale);
+    row_load<T, D>(vr, base + (size_t)j * C3 + (2 * H + h) * D, 1.f);
 #pragma unroll
     for (int dd = 0; dd < D; ++dd) dk[dd] = 0.f;
     for (int q = 0; q < N; ++q) {
-      const float p = expf(row_dot<T, D>(qs + q * D, kr) - ls[q]);
-      const float dp = row_dot<T, D>(dos + q * D, vr);
-      row_axpy<T, D>(dk, p * (dp - dl[q]), qs + q * D);
+      const float p = expf(row_dot<T, D>(m0 + q * D, kr) - ls[q]);
+      const float dp = row_dot<T, D>(m1 + q * D, vr);
+      row_axpy<T, D>(dk, p * (dp - dl[q]), m0 + q * D);
     }
     row_store<T, D>(dbase + (size_t)j * C3 + (H + h) * D, dk, scale);
   }
@@ -524,7 +526,7 @@ int ksmi_attention_backward(const void* qkv, const void* out, const float* lse, 
                             int D, float scale, int dtype, void* stream) {
   if (D != 64) return ksmi_fail(KSMI_E_UNSUPPORTED, "attention: dim_head must be 64");
   const size_t es = dtype == KSMI_BF16 ? 2 : 4;
-  const size_t lds = 4 * (size_t)N * D * es + 2 * (size_t)N * sizeof(float);
+  const size_t lds = 2 * (size_t)N * D * es + 2 * (size_t)N * sizeof(float);
   if (lds > 160 * 1024) return ksmi_fail(KSMI_E_UNSUPPORTED, "attention_bwd: sequence too long for the LDS-resident kernel");
   const dim3 grid(H, B);
   KSMI_DT(dtype, attn_bwd_launch<bf16_t>(grid, lds, (hipStream_t)stream, qkv, out, lse, dout, dqkv, N, H, scale),

@@ -131,18 +131,22 @@ class Launches:
                 check(rc, name)
 
 
-def make_pack(w, out, table, taps, N, Npad, n_mod, sK, sN, sD, sT, flip):
+def make_pack(w, out, table, taps, N, Npad, n_mod, sK, sN, sD, sT, flip, tap_map=None):
     d = PackDesc()
     d.w, d.out = w.data_ptr(), out.data_ptr()
     d.nchunks, d.taps, d.N, d.Npad, d.n_mod = len(table), taps, N, Npad, n_mod
     d.sK, d.sN, d.sD, d.sT, d.flip = sK, sN, sD, sT, flip
     for i, (_, _, kg, kl) in enumerate(table):
         d.k_off[i], d.k_len[i] = kg, kl
+    if tap_map is not None:
+        d.use_tap_map = 1
+        for i, t in enumerate(tap_map):
+            d.tap_map[i] = t
     return d
 
 
 def make_conv(srcs, dsts, wpk, bias, stats, B, Hin, Win, Hout, Wout, KH, KW, stride, pad, N, dtype,
-              mask=None, ps_cout=0, max_pix=256):
+              mask=None, ps_cout=0, max_pix=256, pad_x=None, out_map=None):
     """dsts: list of (tensor, C, c_off, n_begin, n_len, accumulate).  mask: (tensor, mean, rstd, scale, shift)."""
     kc = chunk_elems(dtype)
     table, _ = _chunk_table(srcs, kc)
@@ -159,6 +163,9 @@ def make_conv(srcs, dsts, wpk, bias, stats, B, Hin, Win, Hout, Wout, KH, KW, str
         d.mask_src, d.m_mean, d.m_rstd, d.m_scale, d.m_shift = [x.data_ptr() for x in mask]
     d.B, d.Hin, d.Win, d.Hout, d.Wout = B, Hin, Win, Hout, Wout
     d.KH, d.KW, d.stride, d.pad = KH, KW, stride, pad
+    d.pad_x = pad if pad_x is None else pad_x
+    if out_map is not None:          # (sy, sx, oy, ox, H, W)
+        d.out_sy, d.out_sx, d.out_oy, d.out_ox, d.out_H, d.out_W = out_map
     mp = max_pix if stride == 1 else min(max_pix, 128)
     d.TH, d.TW = choose_patch(Hout, Wout, stride, KH, KW, mp)
     d.N, d.Npad = N, (N + 15) // 16 * 16
