@@ -266,6 +266,12 @@ int ksmi_gelu_forward(const void* x, void* y, int64_t n, int dtype, void* stream
 int ksmi_gelu_backward(const void* dy, const void* x, void* dx, int64_t n, int dtype, void* stream);
 int ksmi_add(const void* a, const void* b, void* out, int64_t n, int dtype, void* stream);
 int ksmi_relu_backward(const void* dy, const void* x, void* dx, int64_t n, int dtype, void* stream);
+int ksmi_relu_forward(const void* x, void* y, int64_t n, int dtype, void* stream);   /* Decoder.relu, model_utilities.py:44 */
+/* x[:, 1:] (vision_transformer.py:150-151): backward=0 [B][N1][C] -> dense [B][N1-1][C]; backward=1 the adjoint (cls rows zero) */
+int ksmi_drop_cls(const void* x, void* y, int B, int N1, int C, int backward, int dtype, void* stream);
+/* head output NHWC [B][HW][Cs] (first C channels real) -> NCHW fp32 logits, and d(logits) back (pad channels zero) */
+int ksmi_logits_to_nchw(const void* x, float* y, int B, int C, int Cs, int64_t HW, int dtype, void* stream);
+int ksmi_dlogits_to_nhwc(const float* dy, void* dx, int B, int C, int Cs, int64_t HW, int dtype, void* stream);
 /* Rearrange("b c (h p1) (w p2) -> b (h w) (p1 p2 c)") of the NCHW fp32 image (vision_transformer.py:122) */
 int ksmi_patchify(const float* x_nchw, void* out, int B, int Cin, int H, int W, int P, int dtype, void* stream);
 /* x0 = cat(cls, emb) + pos_embedding (vision_transformer.py:143-145) and its backward (dcls, dpos fp32 "=") */

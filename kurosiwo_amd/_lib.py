@@ -113,6 +113,10 @@ SIGNATURES = {
     "ksmi_gelu_backward": (_i, [_vp, _vp, _vp, _i64, _i, _vp]),
     "ksmi_add": (_i, [_vp, _vp, _vp, _i64, _i, _vp]),
     "ksmi_relu_backward": (_i, [_vp, _vp, _vp, _i64, _i, _vp]),
+    "ksmi_relu_forward": (_i, [_vp, _vp, _i64, _i, _vp]),
+    "ksmi_drop_cls": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "ksmi_logits_to_nchw": (_i, [_vp, _vp, _i, _i, _i, _i64, _i, _vp]),
+    "ksmi_dlogits_to_nhwc": (_i, [_vp, _vp, _i, _i, _i, _i64, _i, _vp]),
     "ksmi_patchify": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ksmi_vit_embed_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ksmi_vit_embed_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

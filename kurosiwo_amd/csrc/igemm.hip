@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const ksmi_wgrad_desc 
       for (int v = tid; v < HP * 4; v += 256) {
         const int pix = v >> 2;
         const int hy = dHW.div(pix), hx = pix - hy * HW;
-        const int iy = oy0 * S - d.pad + hy, ix = ox0 * S - d.pad_x + hx;
+        const int iy = oy0 * S - d.pad + hy, ix = ox0 * S - d.pad + hx;
         u32x4 x = (u32x4){0u, 0u, 0u, 0u};
         if (cvalid && iy >= 0 && iy < d.Hin && ix >= 0 && ix < d.Win) {
           x = *(const u32x4*)(sp + ((size_t)(b * d.Hin + iy) * d.Win + ix) * sr.C);
@@ -459,6 +459,7 @@ int launch_fwd(const ksmi_conv_desc* d, hipStream_t st) {
   if (d->KH == 3 && d->KW == 3) { KSMI_DISPATCH_NT(3, 3) }
   else if (d->KH == 1 && d->KW == 1) { KSMI_DISPATCH_NT(1, 1) }
   else if (d->KH == 2 && d->KW == 2) { KSMI_DISPATCH_NT(2, 2) }
+  else if (d->KH == 4 && d->KW == 4) { KSMI_DISPATCH_NT(4, 4) }
   else return ksmi_fail(KSMI_E_UNSUPPORTED, "conv: kernel size not supported");
 #undef KSMI_DISPATCH_NT
 #undef KSMI_LAUNCH_FWD
@@ -512,6 +513,7 @@ int launch_wgrad(const ksmi_wgrad_desc* d, hipStream_t st) {
   if (d->KH == 3 && d->KW == 3) { KSMI_DISPATCH_WNT(3, 3) }
   else if (d->KH == 1 && d->KW == 1) { KSMI_DISPATCH_WNT(1, 1) }
   else if (d->KH == 2 && d->KW == 2) { KSMI_DISPATCH_WNT(2, 2) }
+  else if (d->KH == 4 && d->KW == 4) { KSMI_DISPATCH_WNT(4, 4) }
   else return ksmi_fail(KSMI_E_UNSUPPORTED, "wgrad: kernel size not supported");
 #undef KSMI_DISPATCH_WNT
 #undef KSMI_LAUNCH_WG

@@ -280,6 +280,7 @@ int launch2(const ksmi_conv_desc* d, int dbg, hipStream_t st) {
   if (d->KH == 3 && d->KW == 3) { KSMI_D2(3, 3) }
   else if (d->KH == 1 && d->KW == 1) { KSMI_D2(1, 1) }
   else if (d->KH == 2 && d->KW == 2) { KSMI_D2(2, 2) }
+  else if (d->KH == 4 && d->KW == 4) { KSMI_D2(4, 4) }
   else return ksmi_fail(KSMI_E_UNSUPPORTED, "conv: kernel size not supported");
 #undef KSMI_D2
 #undef KSMI_L2

@@ -141,16 +141,17 @@ __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erf
 __device__ __forceinline__ float gelu_df(float x) {
   return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);
 }
-template <typename T, int MODE>   // 0: y = gelu(x) ; 1: dx = dy*gelu'(x) ; 2: out = a + b ; 3: relu bwd: dx = dy*(x>0)
+template <typename T, int MODE>   // 0: y = gelu(x) ; 1: dx = dy*gelu'(x) ; 2: out = a + b ; 3: relu bwd: dx = dy*(x>0) ; 4: y = relu(x)
 __global__ void eltwise_kernel(const T* a, const T* b, T* out, int64_t nvec) {
   constexpr int VEC = ElemTraits<T>::kVec;
   for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * blockDim.x) {
     float x[VEC], y[VEC];
     vec_unpack<T>(*(const u32x4*)(a + v * VEC), x);
-    if (MODE >= 1) vec_unpack<T>(*(const u32x4*)(b + v * VEC), y);
+    if (MODE >= 1 && MODE <= 3) vec_unpack<T>(*(const u32x4*)(b + v * VEC), y);
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
       if (MODE == 0) x[j] = gelu_f(x[j]);
+      else if (MODE == 4) x[j] = fmaxf(x[j], 0.f);
       else if (MODE == 1) x[j] = x[j] * gelu_df(y[j]);        // a = dy, b = x
       else if (MODE == 2) x[j] = x[j] + y[j];
       else x[j] = y[j] > 0.f ? x[j] : 0.f;                    // a = dy, b = x
@@ -414,6 +415,41 @@ __global__ void upsample2_bwd_kernel(const T* dy, const T* xpre, T* dx, int B, i
   }
 }
 
+// x[:, 1:] of the token sequence (vision_transformer.py:150-151) as a dense [B][N1-1][C] image, and its adjoint
+template <typename T>
+__global__ void drop_cls_kernel(const T* x, T* y, int B, int N1, int C, int backward) {
+  constexpr int VEC = ElemTraits<T>::kVec;
+  const int CV = C / VEC;
+  const int64_t n = (int64_t)B * N1 * CV;                      // indexed over the [B][N1][C] side
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (int64_t)gridDim.x * blockDim.x) {
+    const int cv = v % CV; int64_t r = v / CV;
+    const int t = r % N1; const int b = r / N1;
+    const int64_t full = v * VEC, dense = (((int64_t)b * (N1 - 1) + (t - 1)) * CV + cv) * VEC;
+    if (!backward) { if (t > 0) *(u32x4*)(y + dense) = *(const u32x4*)(x + full); }
+    else *(u32x4*)(y + full) = t > 0 ? *(const u32x4*)(x + dense) : (u32x4){0u, 0u, 0u, 0u};
+  }
+}
+
+// logits NHWC [B][HW][Cs] (C real channels) <-> NCHW fp32 [B][C][HW]; the adjoint zero-fills the pad channels
+template <typename T>
+__global__ void logits_to_nchw_kernel(const T* x, float* y, int B, int C, int Cs, int64_t HW) {
+  const int64_t n = (int64_t)B * C * HW;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = i % HW; int64_t r = i / HW;
+    const int c = r % C; const int b = r / C;
+    y[i] = ElemTraits<T>::ld(x + ((int64_t)b * HW + p) * Cs + c);
+  }
+}
+template <typename T>
+__global__ void dlogits_to_nhwc_kernel(const float* dy, T* dx, int B, int C, int Cs, int64_t HW) {
+  const int64_t n = (int64_t)B * HW * Cs;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = i % Cs; int64_t r = i / Cs;
+    const int64_t p = r % HW; const int b = r / HW;
+    ElemTraits<T>::st(dx + i, c < C ? dy[((int64_t)b * C + c) * HW + p] : 0.f);
+  }
+}
+
 template <typename T>
 void attn_fwd_launch(dim3 grid, size_t lds, hipStream_t st, const void* qkv, void* out, float* lse, int N, int H, float scale) {
   auto k = attn_fwd_kernel<T, 64>;
@@ -485,6 +521,34 @@ int ksmi_gelu_forward(const void* x, void* y, int64_t n, int dtype, void* stream
 int ksmi_gelu_backward(const void* dy, const void* x, void* dx, int64_t n, int dtype, void* stream) { KSMI_ELT(1, dy, x, dx, n, "gelu_bwd") }
 int ksmi_add(const void* a, const void* b, void* out, int64_t n, int dtype, void* stream) { KSMI_ELT(2, a, b, out, n, "add") }
 int ksmi_relu_backward(const void* dy, const void* x, void* dx, int64_t n, int dtype, void* stream) { KSMI_ELT(3, dy, x, dx, n, "relu_bwd") }
+
+int ksmi_relu_forward(const void* x, void* y, int64_t n, int dtype, void* stream) { KSMI_ELT(4, x, x, y, n, "relu_fwd") }
+
+int ksmi_drop_cls(const void* x, void* y, int B, int N1, int C, int backward, int dtype, void* stream) {
+  const int vec = dtype == KSMI_BF16 ? 8 : 4;
+  if (C % vec || N1 < 2) return ksmi_fail(KSMI_E_ARG, "drop_cls: C must be a multiple of the vector, N1 >= 2");
+  const int64_t n = (int64_t)B * N1 * (C / vec);
+  KSMI_DT(dtype,
+          hipLaunchKernelGGL(drop_cls_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, B, N1, C, backward),
+          hipLaunchKernelGGL(drop_cls_kernel<float>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, B, N1, C, backward));
+  return ksmi_check_launch("drop_cls");
+}
+
+int ksmi_logits_to_nchw(const void* x, float* y, int B, int C, int Cs, int64_t HW, int dtype, void* stream) {
+  const int64_t n = (int64_t)B * C * HW;
+  KSMI_DT(dtype,
+          hipLaunchKernelGGL(logits_to_nchw_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, y, B, C, Cs, HW),
+          hipLaunchKernelGGL(logits_to_nchw_kernel<float>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const float*)x, y, B, C, Cs, HW));
+  return ksmi_check_launch("logits_to_nchw");
+}
+
+int ksmi_dlogits_to_nhwc(const float* dy, void* dx, int B, int C, int Cs, int64_t HW, int dtype, void* stream) {
+  const int64_t n = (int64_t)B * HW * Cs;
+  KSMI_DT(dtype,
+          hipLaunchKernelGGL(dlogits_to_nhwc_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, dy, (bf16_t*)dx, B, C, Cs, HW),
+          hipLaunchKernelGGL(dlogits_to_nhwc_kernel<float>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, dy, (float*)dx, B, C, Cs, HW));
+  return ksmi_check_launch("dlogits_to_nhwc");
+}
 
 int ksmi_patchify(const float* x_nchw, void* out, int B, int Cin, int H, int W, int P, int dtype, void* stream) {
   if (H % P || W % P) return ksmi_fail(KSMI_E_ARG, "patchify: image not divisible by the patch size");

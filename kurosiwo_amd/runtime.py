@@ -61,9 +61,11 @@ class Act:
 
 
 class SrcSpec:
-    def __init__(self, tensor, Cch, c_off=0, c_len=None, scale=None, shift=None, relu=0):
+    def __init__(self, tensor, Cch, c_off=0, c_len=None, scale=None, shift=None, relu=0, k_real=None):
         self.tensor, self.C, self.c_off = tensor, Cch, c_off
         self.c_len = Cch - c_off if c_len is None else c_len
+        # channels that exist in the weight (the rest of c_len are zero pad channels of the activation)
+        self.k_real = self.c_len if k_real is None else k_real
         self.scale, self.shift, self.relu = scale, shift, relu
 
 
@@ -95,8 +97,8 @@ def _chunk_table(srcs, kc):
     table, kbase = [], 0
     for si, s in enumerate(srcs):
         for c0 in range(0, s.c_len, kc):
-            table.append((si, c0, kbase + c0, min(kc, s.c_len - c0)))
-        kbase += s.c_len
+            table.append((si, c0, kbase + c0, max(0, min(kc, s.k_real - c0))))
+        kbase += s.k_real
     if len(table) > _lib.MAX_CHUNKS:
         raise _lib.KsmiError(f"too many k-chunks ({len(table)} > {_lib.MAX_CHUNKS})")
     return table, kbase

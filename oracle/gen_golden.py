@@ -13,6 +13,13 @@ the tests, so only expected outputs are stored):
                       running stats after one step, 3-step Adam loss sequence
   snunet_full.npz     SNUNet_ECAM(2, 3, 32) 224x224: eval logits (B=1) subsample +
                       full argmax mask; train step (B=2) loss + grad norms
+  floodvit_small.npz  FinetunerSegmentation(ViT(dim 1024, depth 2, heads 4, mlp 512, 6 ch), decoder head) B=2:
+                      encoder tokens + logits subsamples, weighted-CE loss, per-parameter grad stats, selected grads
+  floodvit_full.npz   the mae.json encoder (depth 24, heads 16, mlp 2048) B=1: logits subsample, argmax, loss, grad stats
+
+models/model_utilities.py imports every model family of the reference plus three packages that are not installed
+here (segmentation_models_pytorch, denoising_diffusion_pytorch, torchsummary, timm); they are irrelevant to the FloodViT
+classes and are replaced by empty placeholder modules for the duration of that import (SURVEY.md §2, row "Model factory").
 """
 import os
 import sys
@@ -175,10 +182,85 @@ def gen_snunet_full():
     np.savez_compressed(os.path.join(OUT, "snunet_full.npz"), **out)
 
 
+def _import_floodvit_reference():
+    import types
+    import models.upernet  # noqa: F401  (pulls in transformers before the placeholders exist)
+    for name, attrs in (("segmentation_models_pytorch", ()), ("denoising_diffusion_pytorch", ("GaussianDiffusion", "Unet")),
+                        ("torchsummary", ("summary",)), ("timm", ()), ("timm.models", ()),
+                        ("timm.models.layers", ("DropPath", "to_2tuple", "trunc_normal_"))):
+        if name not in sys.modules:
+            try:
+                __import__(name)
+            except ImportError:
+                import importlib.machinery
+                mod = types.ModuleType(name)
+                mod.__spec__ = importlib.machinery.ModuleSpec(name, None)
+                mod.__path__ = []
+                for a in attrs:
+                    setattr(mod, a, object)
+                sys.modules[name] = mod
+    from models.model_utilities import FinetunerSegmentation  # noqa: E402  (reference)
+    from models.vision_transformer import ViT  # noqa: E402  (reference)
+    return ViT, FinetunerSegmentation
+
+
+FLOODVIT_SMALL = dict(channels=6, image_size=224, patch_size=16, dim=1024, depth=2, heads=4, mlp_dim=512)
+FLOODVIT_FULL = dict(channels=6, image_size=224, patch_size=16, dim=1024, depth=24, heads=16, mlp_dim=2048)   # configs/method/mae/mae.json
+FLOODVIT_GRAD_KEYS = [
+    "model.cls_token", "model.to_patch_embedding.1.weight", "model.to_patch_embedding.2.bias", "model.to_patch_embedding.3.bias",
+    "model.transformer.norm.weight", "model.transformer.layers.0.0.norm.weight", "model.transformer.layers.0.0.to_out.0.bias",
+    "model.transformer.layers.1.1.net.1.bias", "model.transformer.layers.1.1.net.4.bias", "model.transformer.layers.0.1.net.0.bias",
+    "head.deconv1.bias", "head.deconv2.bias", "head.deconv3.weight", "head.deconv3.bias",
+]
+
+
+def _ref_floodvit(hp):
+    ViT, FinetunerSegmentation = _import_floodvit_reference()
+    enc = ViT(image_size=hp["image_size"], patch_size=hp["patch_size"], num_classes=1000, dim=hp["dim"], depth=hp["depth"],
+              heads=hp["heads"], mlp_dim=hp["mlp_dim"], channels=hp["channels"])
+    cfg = {"mlp": False, "decoder": True, "num_classes": 3, "image_size": 224, "finetuning_patch_size": hp["patch_size"]}
+    model = FinetunerSegmentation(encoder=enc, configs=cfg)
+    seeded_fill_(model.state_dict())
+    return model
+
+
+def gen_floodvit(tag, hp, B):
+    out = {}
+    x = sar_like(f"floodvit.{tag}.x", (B, hp["channels"], 224, 224))
+    lbl = seeded_labels(f"floodvit.{tag}.lbl", (B, 224, 224))
+    model = _ref_floodvit(hp)
+    model.train()
+    out["state_dict_keys"] = np.array(list(model.state_dict().keys()))
+    tokens = model.model(x)                                   # [B,196,1024] = ViT.forward with pool False
+    out["tokens_sub"] = tokens[:, ::7, ::16].detach().numpy().copy()
+    logits = model(x)
+    crit = torch.nn.CrossEntropyLoss(weight=torch.tensor(CLASS_WEIGHTS), ignore_index=3)    # create_loss 'cross_entropy' train mode
+    loss = crit(logits, lbl)
+    loss.backward()
+    out["logits_sub"] = logits[:, :, ::8, ::8].detach().numpy().copy()
+    out["argmax"] = logits.argmax(1).numpy().astype(np.uint8)
+    top2 = logits.topk(2, dim=1).values
+    out["margin"] = (top2[:, 0] - top2[:, 1]).detach().numpy().astype(np.float16)
+    out["loss"] = np.array(float(loss))
+    for k, p in model.named_parameters():
+        g = p.grad.detach().double()
+        out[f"gstat.{k}"] = np.array([float(g.norm()), float(g.sum()), float(g.abs().max())])
+        if k in FLOODVIT_GRAD_KEYS:
+            out[f"grad.{k}"] = p.grad.detach().numpy().copy()
+    print(f"floodvit_{tag} loss", float(loss), "logits absmax", float(logits.abs().max()))
+    np.savez_compressed(os.path.join(OUT, f"floodvit_{tag}.npz"), **out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
     os.makedirs(OUT, exist_ok=True)
-    gen_loss()
-    gen_snunet_small()
-    gen_snunet_full()
+    only = sys.argv[1:]
+    if not only or "loss" in only:
+        gen_loss()
+    if not only or "snunet" in only:
+        gen_snunet_small()
+        gen_snunet_full()
+    if not only or "floodvit" in only:
+        gen_floodvit("small", FLOODVIT_SMALL, 2)
+        gen_floodvit("full", FLOODVIT_FULL, 1)

@@ -30,6 +30,10 @@ def seeded_fill_(state_dict, salt: int = 0):
                 t.copy_(0.1 * torch.randn(t.shape, generator=g))
             elif key.endswith("running_var"):
                 t.copy_(1.0 + 0.2 * torch.rand(t.shape, generator=g))
+            elif key.endswith("pos_embedding") or key.endswith("cls_token"):  # ViT tokens (randn-init in the reference)
+                t.copy_(0.5 * torch.randn(t.shape, generator=g))
+            elif key.endswith("to_qkv.weight"):  # keep softmax logits O(1): q.k/8 ~ N(0, ~1)
+                t.copy_(math.sqrt(0.5 / t.shape[1]) * torch.randn(t.shape, generator=g))
             elif t.dim() >= 2:  # conv / deconv / linear weights
                 fan_in = t[0].numel() if t.dim() > 1 else t.numel()
                 # ConvTranspose2d weight is [Cin, Cout, kh, kw]: fan-in = Cin*... use dim 0

@@ -1,0 +1,132 @@
+"""GPU parity of the FloodViT path (kurosiwo_amd/floodvit.py) against the CPU oracle (oracle/vit_ref.py) and the golden
+vectors generated from the real reference (tests/golden/floodvit_*.npz)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+CLASS_WEIGHTS = [0.3715753140309927, 14.009780283125977, 8.20405370357821]
+SMALL = dict(channels=6, image_size=224, patch_size=16, dim=1024, depth=2, heads=4, mlp_dim=512)
+FULL = dict(channels=6, image_size=224, patch_size=16, dim=1024, depth=24, heads=16, mlp_dim=2048)
+CFG = {"mlp": False, "decoder": True, "num_classes": 3, "image_size": 224, "finetuning_patch_size": 16}
+
+
+def sar_like(name, shape):
+    from oracle.seeded import seeded_tensor
+    return seeded_tensor(name, shape).clamp_(-2.23, 5.75)
+
+
+def build(hp, precision):
+    from kurosiwo_amd.floodvit import FinetunerSegmentation, ViT
+    from oracle import vit_ref as V
+    from oracle.seeded import seeded_fill_
+    enc = ViT(image_size=hp["image_size"], patch_size=hp["patch_size"], num_classes=1000, dim=hp["dim"], depth=hp["depth"],
+              heads=hp["heads"], mlp_dim=hp["mlp_dim"], channels=hp["channels"])
+    model = FinetunerSegmentation(enc, CFG, precision=precision)
+    sd = seeded_fill_(V.new_state_dict(**hp))
+    assert list(model.state_dict().keys()) == list(sd.keys())
+    model.load_state_dict(sd)
+    return model.cuda().train(), sd
+
+
+def nhwc_tokens(t, B):
+    return t.float().cpu().reshape(B, -1, t.shape[-1])
+
+
+def to_nchw(t):
+    return t.float().cpu().permute(0, 3, 1, 2)
+
+
+def relerr(a, b):
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_small_forward_backward_vs_oracle_and_golden(golden_dir, precision):
+    from oracle import vit_ref as V
+    from oracle.seeded import seeded_labels
+    hp, B = SMALL, 2
+    gold = np.load(os.path.join(golden_dir, "floodvit_small.npz"))
+    model, sd = build(hp, precision)
+    x = sar_like("floodvit.small.x", (B, 6, 224, 224))
+    lbl = seeded_labels("floodvit.small.lbl", (B, 224, 224))
+    inter = {}
+    with torch.no_grad():
+        ref_logits = V.floodvit_forward(sd, x, hp["heads"], inter=inter)
+    logits = model(x.cuda())
+    plan = model.plan(B, True, True)
+    tol = 2e-4 if precision == "fp32" else 6e-2
+    errs = {}
+    for name in ("embed", "x0", "layer0", "layer1"):
+        errs[name] = relerr(nhwc_tokens(plan.named[name], B), inter[name])
+    errs["feat"] = relerr(to_nchw(plan.named["feat"].reshape(B, 14, 14, -1)), inter["feat"])
+    for name in ("d1", "u1"):
+        errs[name] = relerr(to_nchw(plan.named[name]), inter[name])
+    errs["d2"] = relerr(to_nchw(plan.named["d2"]), inter["d2"])
+    errs["logits"] = relerr(logits.detach().float().cpu(), ref_logits)
+    bad = {k: v for k, v in errs.items() if not v < tol}
+    assert not bad, f"{precision}: {errs}"
+    if precision == "fp32":
+        assert np.abs(logits.detach().cpu()[:, :, ::8, ::8].numpy() - gold["logits_sub"]).max() < 2e-3
+    # backward: weighted CE, as create_loss('cross_entropy') in train mode
+    loss = torch.nn.functional.cross_entropy(logits, lbl.cuda(), weight=torch.tensor(CLASS_WEIGHTS, device="cuda"), ignore_index=3)
+    loss.backward()
+    _, ref_loss, ref_grads = V.loss_and_grads(sd, x, lbl, hp["heads"], CLASS_WEIGHTS)
+    assert abs(float(loss) - ref_loss) < (1e-4 if precision == "fp32" else 3e-2)
+    assert abs(ref_loss - float(gold["loss"])) < 1e-5
+    worst = {}
+    for k, p in model.named_parameters():
+        g, r = p.grad.detach().float().cpu(), ref_grads[k]
+        if precision == "fp32":
+            e = float((g - r).abs().max() / (r.abs().max() + 1e-12))
+            if not e < 2e-3:
+                worst[k] = e
+            ref = gold[f"gstat.{k}"]
+            assert abs(float(g.double().norm()) - ref[0]) <= 2e-3 * ref[0] + 1e-7, k
+        else:
+            cos = float((g.double() * r.double()).sum() / (g.double().norm() * r.double().norm() + 1e-30))
+            if not cos > 0.98:
+                worst[k] = cos
+    assert not worst, f"{precision}: {worst}"
+
+
+def test_full_depth_forward_and_grad_norms_vs_golden(golden_dir):
+    from oracle.seeded import seeded_labels
+    hp, B = FULL, 1
+    gold = np.load(os.path.join(golden_dir, "floodvit_full.npz"))
+    model, _ = build(hp, "fp32")
+    x = sar_like("floodvit.full.x", (B, 6, 224, 224))
+    lbl = seeded_labels("floodvit.full.lbl", (B, 224, 224))
+    logits = model(x.cuda())
+    sub = logits.detach().cpu()[:, :, ::8, ::8].numpy()
+    assert np.abs(sub - gold["logits_sub"]).max() < 5e-3 * np.abs(gold["logits_sub"]).max()
+    am = logits.argmax(1).cpu().numpy().astype(np.uint8)
+    confident = gold["margin"].astype(np.float32) > 5e-2
+    assert (am == gold["argmax"])[confident].all()
+    loss = torch.nn.functional.cross_entropy(logits, lbl.cuda(), weight=torch.tensor(CLASS_WEIGHTS, device="cuda"), ignore_index=3)
+    loss.backward()
+    assert abs(float(loss) - float(gold["loss"])) < 1e-3
+    for k, p in model.named_parameters():
+        ref = gold[f"gstat.{k}"]
+        assert abs(float(p.grad.double().norm()) - ref[0]) <= 1e-2 * ref[0] + 1e-7, k
+        fk = f"grad.{k}"
+        if fk in gold:
+            assert np.abs(p.grad.cpu().numpy() - gold[fk]).max() <= 1e-2 * np.abs(gold[fk]).max() + 1e-8, k
+
+
+def test_linear_eval_freezes_encoder():
+    from kurosiwo_amd.floodvit import FinetunerSegmentation, ViT
+    hp = SMALL
+    enc = ViT(image_size=224, patch_size=16, num_classes=10, dim=1024, depth=1, heads=2, mlp_dim=128, channels=6)
+    model = FinetunerSegmentation(enc, dict(CFG, linear_eval=True), precision="fp32").cuda().train()
+    x = sar_like("floodvit.lin.x", (1, 6, 224, 224)).cuda()
+    out = model(x)
+    out.square().mean().backward()
+    for k, p in model.named_parameters():
+        if k.startswith("model."):
+            assert p.grad is None and not p.requires_grad
+        else:
+            assert p.grad is not None and float(p.grad.abs().sum()) > 0
