@@ -276,6 +276,37 @@ __global__ void channel_sum_kernel(const T* x, float* partial, int64_t npix, int
   block_channel_reduce<1, VEC>(acc, w, CV, C, partial, blockIdx.x);
 }
 
+// wide rows (token matrices, C up to several thousand): block (row slab, 64-vector channel group); thread = (pixel lane
+// t>>6, channel vector t&63) -> 1 KB contiguous per pixel row
+template <typename T>
+__global__ void channel_sum_wide_kernel(const T* x, float* partial, int64_t npix, int C) {
+  constexpr int VEC = ElemTraits<T>::kVec;
+  __shared__ float red[4][64][VEC + 1];
+  const int CV = C / VEC;
+  const int cv = blockIdx.y * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
+  float acc[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+  if (cv < CV) {
+    const int64_t per = (npix + gridDim.x - 1) / gridDim.x;
+    const int64_t p0 = per * blockIdx.x, p1 = min(npix, p0 + per);
+    for (int64_t p = p0 + pl; p < p1; p += 4) {
+      float xx[VEC];
+      vec_unpack<T>(*(const u32x4*)(x + p * C + cv * VEC), xx);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) acc[j] += xx[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) red[pl][threadIdx.x & 63][j] = acc[j];
+  __syncthreads();
+  if (pl == 0 && cv < CV) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j)
+      partial[(size_t)blockIdx.x * C + cv * VEC + j] = red[0][threadIdx.x][j] + red[1][threadIdx.x][j] + red[2][threadIdx.x][j] + red[3][threadIdx.x][j];
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // max pool 2x2 stride 2
 // ------------------------------------------------------------------------------------------------
@@ -678,7 +709,15 @@ int ksmi_bn_bwd_apply_add(void* r_di, const void* g, const void* i, const float*
 }
 
 int ksmi_channel_sum(const void* x, float* partial, int rows, int64_t npix, int C, int dtype, void* stream) {
-  if (!chan_ok(C, dtype) || rows < 1) return ksmi_fail(KSMI_E_ARG, "channel_sum: bad args");
+  const int vec_ = dtype == KSMI_BF16 ? 8 : 4;
+  if (C % vec_ || rows < 1) return ksmi_fail(KSMI_E_ARG, "channel_sum: bad args");
+  if (!chan_ok(C, dtype)) {
+    const dim3 grid(rows, (C / vec_ + 63) / 64);
+    KSMI_DT(dtype,
+            hipLaunchKernelGGL(channel_sum_wide_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, partial, npix, C),
+            hipLaunchKernelGGL(channel_sum_wide_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, partial, npix, C));
+    return ksmi_check_launch("channel_sum_wide");
+  }
   KSMI_DT(dtype,
           hipLaunchKernelGGL(channel_sum_kernel<bf16_t>, dim3(rows), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, partial, npix, C),
           hipLaunchKernelGGL(channel_sum_kernel<float>, dim3(rows), dim3(256), 0, (hipStream_t)stream, (const float*)x, partial, npix, C));

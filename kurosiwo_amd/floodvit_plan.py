@@ -253,7 +253,7 @@ class FloodViTPlan:
         X = self.buf(R, D)
         self.named.update(patches=P0, embed=E1, x0=X)
         cls, pos = m._p("model.cls_token").data_ptr(), m._p("model.pos_embedding").data_ptr()
-        self.fwd.add("ksmi_vit_embed_forward", lambda: (E1.data_ptr(), cls, pos, X.data_ptr(), B, self.N1, D, dt),
+        self.fwd.add("ksmi_vit_embed_forward", lambda X0=X: (E1.data_ptr(), cls, pos, X0.data_ptr(), B, self.N1, D, dt),
                      self._elt_meta("vit_embed", 2 * R * D))
 
         if self.with_backward:

@@ -103,8 +103,10 @@ def _decoder(sd, x):
     return F.conv_transpose2d(x, sd["head.deconv3.weight"], sd["head.deconv3.bias"], stride=2, padding=1)
 
 
-def floodvit_forward(sd, img, heads, patch_size=16, return_tokens=False, inter=None):
-    """`inter` (optional dict) receives the intermediate activations the GPU tests compare against."""
+def floodvit_forward(sd, img, heads, patch_size=16, return_tokens=False, inter=None, masks=None):
+    """`inter` (optional dict) receives the intermediate activations the GPU tests compare against.  `masks` (optional
+    {"d1": bool, "d2": bool}) replaces the two Decoder ReLUs by x * mask: a pre-activation within rounding distance of 0
+    may land on either side on another device, and the backward comparison must use the same active set."""
     depth = 1 + max(int(k.split(".")[3]) for k in sd if k.startswith("model.transformer.layers."))
     x = _patch_embed(sd, img, patch_size)
     B, n, D = x.shape
@@ -123,13 +125,14 @@ def floodvit_forward(sd, img, heads, patch_size=16, return_tokens=False, inter=N
         return x
     g = img.shape[2] // patch_size
     x = x.reshape(B, g, img.shape[3] // patch_size, D).permute(0, 3, 1, 2)
-    if inter is None:
+    if inter is None and masks is None:
         return _decoder(sd, x)
-    inter["feat"] = x
     d1 = F.conv_transpose2d(x, sd["head.deconv1.weight"], sd["head.deconv1.bias"], stride=2, padding=1)
-    u1 = F.interpolate(F.relu(d1), scale_factor=2)
-    d2 = F.relu(F.conv_transpose2d(u1, sd["head.deconv2.weight"], sd["head.deconv2.bias"], stride=2, padding=1))
-    inter.update(d1=d1, u1=u1, d2=d2)
+    u1 = F.interpolate(F.relu(d1) if masks is None else d1 * masks["d1"], scale_factor=2)
+    d2 = F.conv_transpose2d(u1, sd["head.deconv2.weight"], sd["head.deconv2.bias"], stride=2, padding=1)
+    d2 = F.relu(d2) if masks is None else d2 * masks["d2"]
+    if inter is not None:
+        inter.update(feat=x, d1=d1, u1=u1, d2=d2)
     return F.conv_transpose2d(d2, sd["head.deconv3.weight"], sd["head.deconv3.bias"], stride=2, padding=1)
 
 
@@ -139,9 +142,9 @@ def cross_entropy(logits, labels, weights=None):
     return F.cross_entropy(logits, labels, weight=w, ignore_index=3)
 
 
-def loss_and_grads(sd, img, labels, heads, weights=None):
+def loss_and_grads(sd, img, labels, heads, weights=None, masks=None):
     params = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items()}
-    logits = floodvit_forward(params, img, heads)
+    logits = floodvit_forward(params, img, heads, masks=masks)
     loss = cross_entropy(logits, labels, weights)
     loss.backward()
-    return logits.detach(), float(loss), {k: p.grad for k, p in params.items()}
+    return logits.detach(), float(loss.detach()), {k: p.grad for k, p in params.items()}

@@ -74,16 +74,21 @@ def test_small_forward_backward_vs_oracle_and_golden(golden_dir, precision):
     # backward: weighted CE, as create_loss('cross_entropy') in train mode
     loss = torch.nn.functional.cross_entropy(logits, lbl.cuda(), weight=torch.tensor(CLASS_WEIGHTS, device="cuda"), ignore_index=3)
     loss.backward()
-    _, ref_loss, ref_grads = V.loss_and_grads(sd, x, lbl, hp["heads"], CLASS_WEIGHTS)
+    # the oracle backward runs on the GPU's ReLU active set (see oracle/vit_ref.py: masks)
+    masks = {"d1": (to_nchw(plan.named["d1"]) > 0).float(), "d2": (to_nchw(plan.named["d2"]) > 0).float()}
+    _, ref_loss, ref_grads = V.loss_and_grads(sd, x, lbl, hp["heads"], CLASS_WEIGHTS, masks=masks)
     assert abs(float(loss) - ref_loss) < (1e-4 if precision == "fp32" else 3e-2)
-    assert abs(ref_loss - float(gold["loss"])) < 1e-5
+    if precision == "fp32":
+        assert abs(ref_loss - float(gold["loss"])) < 1e-5
     worst = {}
+    flips = {n: int(((to_nchw(plan.named[n]) > 0) != (inter[n] > 0)).sum()) for n in ("d1", "d2")}
     for k, p in model.named_parameters():
         g, r = p.grad.detach().float().cpu(), ref_grads[k]
         if precision == "fp32":
             e = float((g - r).abs().max() / (r.abs().max() + 1e-12))
-            if not e < 2e-3:
-                worst[k] = e
+            l2 = float((g - r).double().norm() / (r.double().norm() + 1e-30))
+            if not (l2 < 1e-3 and e < 2e-3):
+                worst[k] = (e, l2, flips)
             ref = gold[f"gstat.{k}"]
             assert abs(float(g.double().norm()) - ref[0]) <= 2e-3 * ref[0] + 1e-7, k
         else:
