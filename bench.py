@@ -90,7 +90,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--model", default="snunet", choices=["snunet", "floodvit"],
+                    help="snunet = BASELINE.json configs[1] (the headline); floodvit = configs[4] per-GPU shard (bs 16)")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (weak scaling); default 32 snunet / 16 floodvit")
     ap.add_argument("--base-channel", type=int, default=32)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--time-all", action="store_true", help="HIP-event time every kernel class (diagnostic)")
@@ -109,18 +111,32 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from kurosiwo_amd.snunet import SNUNet_ECAM
-    from kurosiwo_amd.synthetic import cd_inputs, make_batch
-    from kurosiwo_amd.trainer import CDTrainStep
+    from kurosiwo_amd.synthetic import cd_inputs, make_batch, seg_inputs
 
-    B, H, W = args.batch, 224, 224
+    B, H, W = args.batch or (32 if args.model == "snunet" else 16), 224, 224
     torch.manual_seed(999)                      # same init on every rank (reference default seed, main.py:36)
-    model = SNUNet_ECAM(2, 3, base_channel=args.base_channel, precision=args.precision).to(dev).train()
-    step = CDTrainStep(model, B, H, W, loss_function="ce+dice", lr=1e-3, bucket_mb=8.0)
     batch = make_batch(B, H, W, seed=999 + rank)
-    (xA, xB), mask = cd_inputs(batch, ("pre_event_1", "post_event"))
-    xA, xB, mask = xA.to(dev), xB.to(dev), mask.to(dev)
-    step.set_batch(xA, xB, mask)                # inputs resident in HBM before the timed region
+    if args.model == "snunet":
+        from kurosiwo_amd.snunet import SNUNet_ECAM
+        from kurosiwo_amd.trainer import CDTrainStep
+        model = SNUNet_ECAM(2, 3, base_channel=args.base_channel, precision=args.precision).to(dev).train()
+        step = CDTrainStep(model, B, H, W, loss_function="ce+dice", lr=1e-3, bucket_mb=8.0)
+        (xA, xB), mask = cd_inputs(batch, ("pre_event_1", "post_event"))
+        step.set_batch(xA.to(dev), xB.to(dev), mask.to(dev))          # inputs resident in HBM before the timed region
+        workload = ("BASELINE.json configs[1]: SNUNet-ECAM CD, 2 dates x 2-ch GRD 224x224, "
+                    f"per-GPU batch {B}, ce+dice loss, Adam lr 1e-3, fwd+loss+bwd+optimizer")
+        metric = "SAR tiles/sec (224x224, SNUNet-ECAM change-detection train step)"
+    else:
+        from kurosiwo_amd.floodvit import FinetunerSegmentation, ViT
+        from kurosiwo_amd.trainer import SegTrainStep
+        enc = ViT(image_size=224, patch_size=16, num_classes=1000, dim=1024, depth=24, heads=16, mlp_dim=2048, channels=6)
+        model = FinetunerSegmentation(enc, {"decoder": True, "num_classes": 3}, precision=args.precision).to(dev).train()
+        step = SegTrainStep(model, B, loss_function="cross_entropy", lr=1e-4, bucket_mb=32.0)
+        x, mask = seg_inputs(batch)                                   # [post, pre1, pre2] = 3 dates x 2 ch
+        step.set_batch(x.to(dev), mask.to(dev))
+        workload = ("BASELINE.json configs[4] per-GPU shard: FloodViT (ViT d1024 L24 h16 mlp2048, 6 ch) + Decoder head, "
+                    f"224x224, per-GPU batch {B}, weighted CE, Adam, fwd+loss+bwd+optimizer")
+        metric = "SAR tiles/sec (224x224, FloodViT segmentation train step)"
 
     def sync():
         if world > 1:
@@ -161,14 +177,12 @@ def main():
         step_flops = sum(c[3]["flops"] for c in step.plan.fwd.calls + step.plan.bwd.calls)
         step_bytes = sum(c[3]["bytes"] for c in step.plan.fwd.calls + step.plan.bwd.calls)
         res = {
-            "metric": "SAR tiles/sec (224x224, SNUNet-ECAM change-detection train step)",
+            "metric": metric,
             "value": round(B * world * args.steps / dt, 2), "unit": "tiles/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: SNUNet-ECAM CD, 2 dates x 2-ch GRD 224x224, "
-                                   f"per-GPU batch {B}, ce+dice loss, Adam lr 1e-3, fwd+loss+bwd+optimizer"
-                                   + ("+RCCL all-reduce" if world > 1 else ""),
+            "config": {"workload": workload + ("+RCCL all-reduce" if world > 1 else ""),
                        "global_batch": B * world, "base_channel": args.base_channel, "parallelism": f"dp{world}",
                        "loss_last": [round(x, 5) for x in loss]},
             "roofline": {"kernel": dominant, "bound": "hbm", "achieved": round(ach_gbs, 1), "peak": HBM_PEAK_GBS,
@@ -196,7 +210,7 @@ def main():
             for (kind, tag), (ms, n, meta) in sorted(det.items(), key=lambda kv: -kv[1][0]):
                 print(f"DETAIL {kind:28s} {tag:48s} {ms / args.steps:7.3f} ms/step x{n // args.steps} "
                       f"{meta['flops'] * n / ms / 1e9:7.1f} TF/s {meta['bytes'] * n / ms / 1e6:7.1f} GB/s", file=sys.stderr)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.model == "snunet":
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res), flush=True)
     if world > 1:

@@ -72,3 +72,24 @@ def cd_inputs(batch, inputs=("pre_event_1", "post_event"), dem=False):
         x = pick[name]
         xs.append(torch.cat((x, d), dim=1) if dem else x)
     return xs, mask
+
+
+def seg_inputs(batch, inputs=("pre_event_1", "pre_event_2", "post_event"), dem=False):
+    """The segmentation trainer's channel concat (training/segmentation_trainer.py:107-144):
+    [post, (dem), pre1 and/or pre2] -> (image, mask)."""
+    post, mask, pre1, pre2 = batch[2], batch[3], batch[6], batch[9]
+    parts = [post]
+    if dem:
+        parts.append(batch[10])
+    names = set(inputs)
+    if names == {"post_event"}:
+        pass
+    elif names == {"pre_event_1", "post_event"}:
+        parts.append(pre1)
+    elif names == {"pre_event_2", "post_event"}:
+        parts.append(pre2)
+    elif names == {"pre_event_1", "pre_event_2", "post_event"}:
+        parts += [pre1, pre2]
+    else:
+        raise ValueError('Invalid configuration for "inputs".')
+    return torch.cat(parts, dim=1), mask

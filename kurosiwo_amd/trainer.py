@@ -12,14 +12,16 @@ from .optim import FusedAdam
 from .runtime import stream_ptr
 
 
-class CDTrainStep:
-    def __init__(self, model, B, H, W, loss_function="ce+dice", class_weights=(1.0, 1.0, 1.0), optimizer=None, lr=1e-3,
+class _PlanTrainStep:
+    """zero_grad -> forward -> criterion -> backward (+ bucketed all-reduce) -> optimizer.step over a model plan."""
+
+    def __init__(self, model, plan, B, H, W, loss_function="ce+dice", class_weights=(1.0, 1.0, 1.0), optimizer=None, lr=1e-3,
                  bucket_mb=8.0, group=None):
         if loss_function not in ("ce+dice", "cross_entropy"):
             raise NotImplementedError(loss_function)
         self.model = model
         self.lib = _lib.load()
-        self.plan = model.plan(B, H, W, True, True)
+        self.plan = plan
         dev = self.plan.dev
         self.B, self.HW = B, H * W
         self.with_dice = 1 if loss_function == "ce+dice" else 0
@@ -35,10 +37,12 @@ class CDTrainStep:
         self.reducer = BucketedAllReduce(model.flat_grads, buckets, group)
         self.timer = None          # optional kernel timer (bench.py)
 
-    def set_batch(self, xA, xB, labels):
-        self.plan.xA.copy_(xA, non_blocking=True)
-        self.plan.xB.copy_(xB, non_blocking=True)
-        self.labels.copy_(labels, non_blocking=True)
+    def _set_inputs(self, *inputs):
+        raise NotImplementedError
+
+    def set_batch(self, *args):
+        self._set_inputs(*args[:-1])
+        self.labels.copy_(args[-1], non_blocking=True)
 
     def _timed(self, kind, fn):
         t = self.timer
@@ -68,7 +72,30 @@ class CDTrainStep:
         self._timed("optimizer", lambda: self.optimizer.step_arena(mf.flat_params.data_ptr(), mf.flat_grads.data_ptr(),
                                                                    mf.flat_params.numel(), p.dev, 1.0 / self.world))
 
-    def step(self, xA, xB, labels):
-        self.set_batch(xA, xB, labels)
+    def step(self, *args):
+        self.set_batch(*args)
         self.run()
         return self.loss_out      # device tensor [total, ce, dice]; no host sync here
+
+
+class CDTrainStep(_PlanTrainStep):
+    """change_detection_trainer.py:135-180 on SNUNet_ECAM: step(xA, xB, labels)."""
+
+    def __init__(self, model, B, H, W, loss_function="ce+dice", class_weights=(1.0, 1.0, 1.0), **kw):
+        super().__init__(model, model.plan(B, H, W, True, True), B, H, W, loss_function, class_weights, **kw)
+
+    def _set_inputs(self, xA, xB):
+        self.plan.xA.copy_(xA, non_blocking=True)
+        self.plan.xB.copy_(xB, non_blocking=True)
+
+
+class SegTrainStep(_PlanTrainStep):
+    """segmentation_trainer.py:54-171 on FinetunerSegmentation (FloodViT): step(x, labels) with x the channel concat
+    [post, (dem), pre1, pre2] (:107-147); default criterion = create_loss 'cross_entropy' with class weights."""
+
+    def __init__(self, model, B, loss_function="cross_entropy", class_weights=(1.0, 1.0, 1.0), **kw):
+        ih, iw = model.hp["image_size"]
+        super().__init__(model, model.plan(B, True, True), B, ih, iw, loss_function, class_weights, **kw)
+
+    def _set_inputs(self, x):
+        self.plan.x.copy_(x, non_blocking=True)
