@@ -19,3 +19,28 @@ def initialize_cd_model(configs, model_configs, phase="train"):
         model.load_state_dict(ck["model_state_dict"])
     print(model.__class__.__name__, f"({sum(p.numel() for p in model.parameters())} parameters, precision={model.precision})")
     return model
+
+
+def initialize_segmentation_model(config, model_configs):
+    """model_utilities.py:97-167 for the method with a HIP implementation: `finetune` = FloodViT
+    (FinetunerSegmentation over a pickled MAE-pretrained ViT encoder, :158-165).  Without `config["encoder"]` a
+    randomly initialised encoder of configs/method/mae/mae.json's size is used (no checkpoint can be fetched here)."""
+    from .floodvit import FinetunerSegmentation, ViT
+    if config["method"].lower() != "finetune":
+        raise _lib.KsmiError(f"segmentation method {config['method']!r} has no HIP implementation (in scope: finetune = FloodViT)")
+    if config.get("encoder"):
+        encoder = torch.load(config["encoder"], map_location="cpu", weights_only=False)
+    else:
+        mc = model_configs
+        encoder = ViT(image_size=mc.get("image_size", 224), patch_size=mc.get("patch_size", 16), num_classes=mc.get("num_classes", 1000),
+                      dim=mc.get("dim", 1024), depth=mc.get("depth", 24), heads=mc.get("heads", 16), mlp_dim=mc.get("mlp_dim", 2048),
+                      channels=config["num_channels"])
+    cfg = dict(config)
+    cfg.setdefault("decoder", True)
+    cfg.setdefault("mlp", False)
+    cfg.setdefault("linear_eval", False)
+    cfg.setdefault("finetuning_patch_size", 16)
+    model = FinetunerSegmentation(encoder=encoder, configs=cfg,
+                                  precision=config.get("precision", "bf16" if config.get("mixed_precision") else "fp32"))
+    print(model.__class__.__name__, f"({sum(p.numel() for p in model.parameters())} parameters, precision={model.precision})")
+    return model.to(config["device"])

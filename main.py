@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """Entry point with the reference's CLI (/root/reference/main.py:29-36) and dispatch (:83-195)
-for the tasks/methods that have a HIP implementation (this round: task "cd", method "snunet").
+for the tasks/methods that have a HIP implementation: task "cd" method "snunet", task "segmentation" method
+"finetune" (FloodViT).
 
   python main.py --method snunet --inputs pre_event_1 post_event [--dem] [--slope] [--batch_size N] [--seed S]
+  python main.py --method finetune --inputs pre_event_1 pre_event_2 post_event [--batch_size N]
 """
 import argparse
 import pprint
@@ -14,8 +16,9 @@ import torch
 
 from kurosiwo_amd.config import create_checkpoint_directory, load_json5, update_config
 from kurosiwo_amd.data import prepare_loaders
-from kurosiwo_amd.model_utilities import initialize_cd_model
+from kurosiwo_amd.model_utilities import initialize_cd_model, initialize_segmentation_model
 from kurosiwo_amd.training.change_detection_trainer import eval_change_detection, train_change_detection
+from kurosiwo_amd.training.segmentation_trainer import eval_semantic_segmentation, train_semantic_segmentation
 
 parser = argparse.ArgumentParser()
 parser.add_argument("--method", default=None)
@@ -44,6 +47,10 @@ def main(argv=None):
     if name in ("snunet", "changeformer", "siam-conc", "siam-diff", "bit-cd", "hfa-net", "adhr-cdnet"):
         configs["task"] = "cd"
         configs["num_channels"] = len(configs["channels"]) + (1 if configs["dem"] else 0)
+    else:
+        configs["task"] = "segmentation"
+        # utilities/utilities.py:381-384: channel concat of the selected dates (+ dem)
+        configs["num_channels"] = len(configs["channels"]) * len(configs["inputs"]) + (1 if configs["dem"] else 0)
     configs["checkpoint_path"] = create_checkpoint_directory(configs, model_configs)
     if args.batch_size is not None:
         configs["batch_size"] = int(args.batch_size)
@@ -62,7 +69,18 @@ def main(argv=None):
                                                            model_configs=model_configs)
         print(f"Test mIoU: {miou}")
         return float(miou)
-    raise SystemExit(f'task {configs["task"]!r} is not implemented by this build yet (SURVEY.md §8: next rows)')
+    if configs["task"] == "segmentation":
+        model = initialize_segmentation_model(configs, model_configs)
+        if not configs["test"]:
+            train_semantic_segmentation(model, train_loader, val_loader, test_loader, configs=configs, model_configs=model_configs)
+        ckpt_path = Path(configs["checkpoint_path"]) / "best_segmentation.pt"
+        print(f"Loading model from: {ckpt_path}")
+        model = torch.load(ckpt_path, map_location=configs["device"], weights_only=False)       # whole-module pickle (main.py:151)
+        test_acc, test_score, miou = eval_semantic_segmentation(model, test_loader, settype="Test", configs=configs,
+                                                                model_configs=model_configs)
+        print(f"Test Mean IOU: {miou}")
+        return float(miou)
+    raise SystemExit(f'task {configs["task"]!r} is not implemented by this build (SURVEY.md §8)')
 
 
 if __name__ == "__main__":

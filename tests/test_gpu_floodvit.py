@@ -135,3 +135,20 @@ def test_linear_eval_freezes_encoder():
             assert p.grad is None and not p.requires_grad
         else:
             assert p.grad is not None and float(p.grad.abs().sum()) > 0
+
+
+def test_main_entry_finetune_end_to_end_tiny(tmp_path, monkeypatch):
+    """main.py --method finetune (FloodViT) on a tiny synthetic set with a 2-layer encoder: train 1 epoch, pickle the best
+    module (segmentation_trainer.py:255), reload it (main.py:151), test."""
+    import re
+    import shutil
+    import main as entry
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    shutil.copytree(os.path.join(root, "configs"), tmp_path / "configs")
+    cfg = tmp_path / "configs" / "method" / "finetune" / "finetune.json"
+    cfg.write_text(re.sub(r'"depth": 24', '"depth": 2', re.sub(r'"mlp_dim": 2048', '"mlp_dim": 256', cfg.read_text())))
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv("KSMI_SYNTHETIC_TILES", "8,4,4")
+    miou = entry.main(["--method", "finetune", "--inputs", "pre_event_1", "pre_event_2", "post_event", "--batch_size", "4"])
+    assert 0.0 <= miou <= 100.0
+    assert (tmp_path / "checkpoints" / "vit" / "best_segmentation.pt").exists()
