@@ -89,6 +89,17 @@ typedef struct ksmi_conv_desc {
   /* strided output placement (phase convolutions of ConvTranspose2d k4 s2 p1): result pixel (oy,ox) is written to
    * (oy*out_sy + out_oy, ox*out_sx + out_ox) of a [B, out_H, out_W, C] tensor; out_sy == 0 => dense [B,Hout,Wout,C] */
   int32_t out_sy, out_sx, out_oy, out_ox, out_H, out_W;
+  /* single-source descriptors may exceed KSMI_MAX_CHUNKS: uniform_kc = chunk elements (ksmi_chunk_elems) means
+   * chunk ch starts at channel ch*uniform_kc of src[0] and the chunk tables are ignored; 0 = use the tables */
+  int32_t uniform_kc;
+  /* epilogue extras (igemm2 path): v = alpha*(acc + bias) [alpha == 0 means 1] ; v += resid[pixel][n] (dense
+   * [B,Hout,Wout,residC] `dtype`, ResidualBlock of models/changeformer.py:471-483) ; v = max(v, 0) if relu_out
+   * (conv -> ReLU -> BatchNorm ordering of conv_diff / make_prediction, changeformer.py:31-46: the BN statistics in
+   * `stats` are those of the ReLU output) */
+  float alpha;
+  int32_t relu_out;
+  int32_t residC;
+  const void* resid;
 } ksmi_conv_desc;
 
 /* number of M-tiles (= rows of `stats`) a descriptor launches */
@@ -107,6 +118,7 @@ typedef struct ksmi_pack_desc {
   int32_t k_len[KSMI_MAX_CHUNKS];
   int32_t use_tap_map;            /* 1: tap' = tap_map[tap] (phase kernels of ConvTranspose2d k4 s2 p1) */
   int32_t tap_map[16];
+  int32_t uniform_kc, k_total;    /* uniform_kc != 0: k_off = chunk*uniform_kc, k_len = min(uniform_kc, k_total - k_off); tables ignored */
 } ksmi_pack_desc;
 int ksmi_pack_weights(const ksmi_pack_desc* d, int dtype, void* stream);
 /* n descriptors stored in DEVICE memory, packed by one launch (a model plan re-packs every conv each step) */
@@ -131,6 +143,7 @@ typedef struct ksmi_wgrad_desc {
   int32_t k_len[KSMI_MAX_CHUNKS];
   uint16_t chunk_c0[KSMI_MAX_CHUNKS];
   uint8_t chunk_src[KSMI_MAX_CHUNKS];
+  int32_t uniform_kc, k_total;    /* same meaning as in the pack descriptor: single source, more than KSMI_MAX_CHUNKS chunks */
 } ksmi_wgrad_desc;
 size_t ksmi_conv_wgrad_workspace(const ksmi_wgrad_desc* d, int dtype);
 int ksmi_conv_wgrad(const ksmi_wgrad_desc* d, int dtype, void* stream);
@@ -285,6 +298,39 @@ int ksmi_attention_backward(const void* qkv, const void* out, const float* lse, 
 /* [relu ->] nn.Upsample(scale_factor=2) nearest (model_utilities.py:36-41) */
 int ksmi_upsample2_forward(const void* x, void* y, int B, int H, int W, int C, int relu, int dtype, void* stream);
 int ksmi_upsample2_backward(const void* dy, const void* x_pre, void* dx, int B, int H, int W, int C, int relu, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * ChangeFormerV6 glue (models/changeformer.py); the dense contractions run on ksmi_conv_forward / ksmi_conv_wgrad.
+ * ------------------------------------------------------------------------------- */
+/* out[b,oy,ox, c*KH*KW + ky*KW + kx] (Kpad columns, zero padded) from an NHWC `dtype` activation or (src_nchw_f32) the raw
+ * NCHW fp32 image: OverlapPatchEmbed.proj (:267) and Attention.sr (:166) become GEMMs against the OIHW-flattened weight */
+int ksmi_im2col(const void* x, void* out, int B, int Cin, int H, int W, int Ho, int Wo, int KH, int KW, int stride, int pad,
+                int Kpad, int src_nchw_f32, int dtype, void* stream);
+int ksmi_col2im(const void* dcol, void* dx, int B, int Cin, int H, int W, int Ho, int Wo, int KH, int KW, int stride, int pad,
+                int Kpad, int dtype, void* stream);
+/* Mlp.dwconv + act (:85-96,128-129): z = depthwise3x3(x) + b (w fp32 [C][9]), g = gelu(z); adjoint of the conv; weight/bias
+ * gradient partials partial[rows][10*C] (columns c*9+t, then 9C+c) for ksmi_reduce_rows */
+int ksmi_dwconv3x3_gelu_forward(const void* x, const float* w, const float* bias, void* z, void* g, int B, int H, int W, int C,
+                                int dtype, void* stream);
+int ksmi_dwconv3x3_backward_input(const void* dz, const float* w, void* dx, int B, int H, int W, int C, int dtype, void* stream);
+int ksmi_dwconv3x3_wgrad(const void* x, const void* dz, float* partial, int rows, int B, int H, int W, int C, int dtype, void* stream);
+/* Attention against the spatially reduced keys (:190-207): q [B*Nq][C], kv [B*Nk][2C] "(2 h d)", out [B*Nq][C]; Nk = 49,
+ * head dim C/H in {64, 80}.  backward writes dq, dkv ("=") using `workspace` (ksmi_sr_attention_bwd_workspace bytes). */
+int ksmi_sr_attention_forward(const void* q, const void* kv, void* out, int B, int Nq, int Nk, int H, int C, float scale, int dtype,
+                              void* stream);
+size_t ksmi_sr_attention_bwd_workspace(int B, int Nq, int Nk, int H, int C);
+int ksmi_sr_attention_backward(const void* q, const void* kv, const void* dout, void* dq, void* dkv, void* workspace, int B, int Nq,
+                               int Nk, int H, int C, float scale, int dtype, void* stream);
+/* F.interpolate(mode="bilinear", align_corners=False) (:581-608): y = [add +] resize(x); adjoint dx (+)= resize^T(dy) (upsampling) */
+int ksmi_bilinear_forward(const void* x, const void* add, void* y, int B, int Hi, int Wi, int Ho, int Wo, int C, int dtype, void* stream);
+int ksmi_bilinear_backward(const void* dy, void* dx, int accumulate, int B, int Hi, int Wi, int Ho, int Wo, int C, int dtype, void* stream);
+/* input gradient of y = BN(r), r = relu(v) or v (conv -> ReLU -> BN of conv_diff / make_prediction :31-46; linear_fuse :563-567):
+ * dv = gamma*rstd*(dy - sums[0]/n - rhat*sums[1]/n) [masked by r > 0] */
+int ksmi_bn_bwd_apply(const void* dy, const void* r, const float* mean, const float* rstd, const float* gamma, const float* sums,
+                      void* dv, int relu_mask, double count, int64_t npix, int C, int dtype, void* stream);
+/* head output NHWC [B][HW][Cs] -> NCHW fp32, act = 1: sigmoid (:635-639); adjoint (y = the forward's NCHW output) */
+int ksmi_out_to_nchw(const void* x, float* y, int B, int C, int Cs, int64_t HW, int act, int dtype, void* stream);
+int ksmi_dout_to_nhwc(const float* dy, const float* y, void* dx, int B, int C, int Cs, int64_t HW, int act, int dtype, void* stream);
 
 /* plumbing */
 int ksmi_fill_zero(void* p, size_t bytes, void* stream);

@@ -39,7 +39,9 @@ class ConvDesc(C.Structure):
                 ("nchunks", C.c_int32), ("ps_cout", C.c_int32),
                 ("chunk_c0", C.c_uint16 * MAX_CHUNKS), ("chunk_src", C.c_uint8 * MAX_CHUNKS),
                 ("pad_x", C.c_int32), ("out_sy", C.c_int32), ("out_sx", C.c_int32), ("out_oy", C.c_int32),
-                ("out_ox", C.c_int32), ("out_H", C.c_int32), ("out_W", C.c_int32)]
+                ("out_ox", C.c_int32), ("out_H", C.c_int32), ("out_W", C.c_int32),
+                ("uniform_kc", C.c_int32), ("alpha", C.c_float), ("relu_out", C.c_int32), ("residC", C.c_int32),
+                ("resid", C.c_void_p)]
 
 
 class PackDesc(C.Structure):
@@ -48,7 +50,7 @@ class PackDesc(C.Structure):
                 ("sK", C.c_int64), ("sN", C.c_int64), ("sD", C.c_int64), ("sT", C.c_int64),
                 ("flip", C.c_int32),
                 ("k_off", C.c_int32 * MAX_CHUNKS), ("k_len", C.c_int32 * MAX_CHUNKS),
-                ("use_tap_map", C.c_int32), ("tap_map", C.c_int32 * 16)]
+                ("use_tap_map", C.c_int32), ("tap_map", C.c_int32 * 16), ("uniform_kc", C.c_int32), ("k_total", C.c_int32)]
 
 
 class WgradDesc(C.Structure):
@@ -60,7 +62,8 @@ class WgradDesc(C.Structure):
                 ("partial", C.c_void_p), ("grad", C.c_void_p),
                 ("gK", C.c_int64), ("gN", C.c_int64), ("gT", C.c_int64), ("accumulate", C.c_int32),
                 ("k_off", C.c_int32 * MAX_CHUNKS), ("k_len", C.c_int32 * MAX_CHUNKS),
-                ("chunk_c0", C.c_uint16 * MAX_CHUNKS), ("chunk_src", C.c_uint8 * MAX_CHUNKS)]
+                ("chunk_c0", C.c_uint16 * MAX_CHUNKS), ("chunk_src", C.c_uint8 * MAX_CHUNKS),
+                ("uniform_kc", C.c_int32), ("k_total", C.c_int32)]
 
 
 _vp, _i, _i64, _f, _d, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_size_t
@@ -114,6 +117,19 @@ SIGNATURES = {
     "ksmi_add": (_i, [_vp, _vp, _vp, _i64, _i, _vp]),
     "ksmi_relu_backward": (_i, [_vp, _vp, _vp, _i64, _i, _vp]),
     "ksmi_relu_forward": (_i, [_vp, _vp, _i64, _i, _vp]),
+    "ksmi_im2col": (_i, [_vp, _vp] + [_i] * 11 + [_i, _i, _vp]),
+    "ksmi_col2im": (_i, [_vp, _vp] + [_i] * 11 + [_i, _vp]),
+    "ksmi_dwconv3x3_gelu_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "ksmi_dwconv3x3_backward_input": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "ksmi_dwconv3x3_wgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "ksmi_sr_attention_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, C.c_float, _i, _vp]),
+    "ksmi_sr_attention_bwd_workspace": (C.c_size_t, [_i, _i, _i, _i, _i]),
+    "ksmi_sr_attention_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, C.c_float, _i, _vp]),
+    "ksmi_bilinear_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "ksmi_bilinear_backward": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "ksmi_bn_bwd_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, C.c_double, _i64, _i, _i, _vp]),
+    "ksmi_out_to_nchw": (_i, [_vp, _vp, _i, _i, _i, _i64, _i, _i, _vp]),
+    "ksmi_dout_to_nhwc": (_i, [_vp, _vp, _vp, _i, _i, _i, _i64, _i, _i, _vp]),
     "ksmi_drop_cls": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ksmi_logits_to_nchw": (_i, [_vp, _vp, _i, _i, _i, _i64, _i, _vp]),
     "ksmi_dlogits_to_nhwc": (_i, [_vp, _vp, _i, _i, _i, _i64, _i, _vp]),

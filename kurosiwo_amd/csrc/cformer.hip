@@ -1,0 +1,674 @@
+// ChangeFormerV6 glue kernels (rows C1-C7 of SURVEY.md §8(a)); reference: models/changeformer.py.
+// Activations are NHWC / token-major [rows][C] in T (bf16 / fp32).  The dense contractions (patch-embed and
+// spatial-reduction convolutions via im2col, every nn.Linear, the 3x3 / 1x1 / transposed convolutions of the decoder)
+// run on the implicit-GEMM kernels; this file holds what surrounds them: im2col / col2im, the depth-wise 3x3 conv of
+// Mlp (:85-133), attention against the 49 spatially-reduced keys (:148-208), bilinear resize (:581-608), the
+// BatchNorm input gradient for the conv -> ReLU -> BN ordering (:31-46) and the sigmoid outputs (:635-639).
+#include "common.h"
+#include "../../include/ksmi.h"
+#include "errors.h"
+
+namespace {
+
+int grid_for(int64_t n, int cap = 8192) {
+  int64_t b = (n + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+// ------------------------------------------------------------------------------------------------
+// im2col: out[b,oy,ox, c*T + tap] (Kpad columns, zero padded), k = c*KH*KW + ky*KW + kx = OIHW flattening, so the
+// convolution weight is the GEMM operand as it lies in memory.  Source: NCHW fp32 image or NHWC T activation.
+// ------------------------------------------------------------------------------------------------
+template <typename T, bool NCHW>
+__global__ void im2col_kernel(const void* xin, T* out, int B, int Cin, int H, int W, int Ho, int Wo, int KH, int KW, int stride,
+                              int pad, int Kpad) {
+  const int taps = KH * KW, K = Cin * taps;
+  const int64_t n = (int64_t)B * Ho * Wo * Kpad;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int k = i % Kpad; int64_t r = i / Kpad;
+    const int ox = r % Wo; r /= Wo;
+    const int oy = r % Ho; const int b = r / Ho;
+    float v = 0.f;
+    if (k < K) {
+      const int c = k / taps, t = k - c * taps;
+      const int ky = t / KW, kx = t - ky * KW;
+      const int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
+      if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+        if (NCHW) v = ((const float*)xin)[(((int64_t)b * Cin + c) * H + iy) * W + ix];
+        else v = ElemTraits<T>::ld((const T*)xin + (((int64_t)b * H + iy) * W + ix) * Cin + c);
+      }
+    }
+    ElemTraits<T>::st(out + i, v);
+  }
+}
+
+// col2im (adjoint): dx[b,iy,ix,c] = sum over taps with (iy + pad - ky) % stride == 0 of dcol[b,oy,ox,c*T+tap]
+template <typename T>
+__global__ void col2im_kernel(const T* dcol, T* dx, int B, int Cin, int H, int W, int Ho, int Wo, int KH, int KW, int stride,
+                              int pad, int Kpad) {
+  const int taps = KH * KW;
+  const int64_t n = (int64_t)B * H * W * Cin;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = i % Cin; int64_t r = i / Cin;
+    const int ix = r % W; r /= W;
+    const int iy = r % H; const int b = r / H;
+    float s = 0.f;
+    for (int ky = 0; ky < KH; ++ky) {
+      const int ty = iy + pad - ky;
+      if (ty < 0 || ty % stride) continue;
+      const int oy = ty / stride;
+      if (oy >= Ho) continue;
+      for (int kx = 0; kx < KW; ++kx) {
+        const int tx = ix + pad - kx;
+        if (tx < 0 || tx % stride) continue;
+        const int ox = tx / stride;
+        if (ox >= Wo) continue;
+        s += ElemTraits<T>::ld(dcol + (((int64_t)b * Ho + oy) * Wo + ox) * Kpad + c * taps + ky * KW + kx);
+      }
+    }
+    ElemTraits<T>::st(dx + i, s);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// depth-wise 3x3 conv, pad 1 (DWConv, changeformer.py:85-96): z = dw(x) + b ; g = gelu(z) (exact erf).
+// MODE 0: forward (writes z and g) ; MODE 1: adjoint (flipped taps, no bias, writes z only)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+template <typename T, int MODE>
+__global__ void dwconv3x3_kernel(const T* x, const float* w, const float* bias, T* z, T* g, int B, int H, int W, int C) {
+  constexpr int VEC = ElemTraits<T>::kVec;
+  const int CV = C / VEC;
+  const int64_t n = (int64_t)B * H * W * CV;
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (int64_t)gridDim.x * blockDim.x) {
+    const int cv = v % CV; int64_t r = v / CV;
+    const int px = r % W; r /= W;
+    const int py = r % H; const int b = r / H;
+    const int c0 = cv * VEC;
+    float acc[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] = (MODE == 0 && bias) ? bias[c0 + j] : 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int dy = t / 3 - 1, dx = t % 3 - 1;
+      const int iy = py + dy, ix = px + dx;
+      if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+      float xx[VEC];
+      vec_unpack<T>(*(const u32x4*)(x + (((int64_t)b * H + iy) * W + ix) * C + c0), xx);
+      const int tw = MODE == 0 ? t : 8 - t;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) acc[j] += xx[j] * w[(c0 + j) * 9 + tw];
+    }
+    *(u32x4*)(z + v * VEC) = vec_pack<T>(acc);
+    if (MODE == 0) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) acc[j] = gelu_f(ElemTraits<T>::cvt(acc[j]));
+      *(u32x4*)(g + v * VEC) = vec_pack<T>(acc);
+    }
+  }
+}
+
+// weight/bias gradient partials: partial[row][c*9 + t] = sum_p x[p + off_t][c] * dz[p][c] ; partial[row][9C + c] = sum_p dz[p][c]
+// grid (rows, ceil(CV/64)); thread = (pixel lane t>>6, channel vector t&63)
+template <typename T>
+__global__ void dwconv3x3_wgrad_kernel(const T* x, const T* dz, float* partial, int B, int H, int W, int C) {
+  constexpr int VEC = ElemTraits<T>::kVec;
+  __shared__ float red[4][64][VEC + 1];
+  const int CV = C / VEC;
+  const int cvl = threadIdx.x & 63, cv = blockIdx.y * 64 + cvl, pl = threadIdx.x >> 6;
+  const int64_t npix = (int64_t)B * H * W;
+  const int64_t per = (npix + gridDim.x - 1) / gridDim.x;
+  const int64_t p0 = per * blockIdx.x, p1 = min(npix, p0 + per);
+  float acc[10][VEC];
+#pragma unroll
+  for (int t = 0; t < 10; ++t)
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[t][j] = 0.f;
+  if (cv < CV) {
+    for (int64_t p = p0 + pl; p < p1; p += 4) {
+      const int px = p % W; const int64_t r = p / W;
+      const int py = r % H;
+      float d[VEC];
+      vec_unpack<T>(*(const u32x4*)(dz + p * C + cv * VEC), d);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) acc[9][j] += d[j];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int iy = py + t / 3 - 1, ix = px + t % 3 - 1;
+        if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+        float xx[VEC];
+        vec_unpack<T>(*(const u32x4*)(x + (p + (int64_t)(t / 3 - 1) * W + (t % 3 - 1)) * C + cv * VEC), xx);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[t][j] += xx[j] * d[j];
+      }
+    }
+  }
+  float* prow = partial + (size_t)blockIdx.x * 10 * C;
+#pragma unroll
+  for (int t = 0; t < 10; ++t) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) red[pl][cvl][j] = acc[t][j];
+    __syncthreads();
+    if (pl == 0 && cv < CV) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const float s = red[0][cvl][j] + red[1][cvl][j] + red[2][cvl][j] + red[3][cvl][j];
+        const int c = cv * VEC + j;
+        if (t < 9) prow[c * 9 + t] = s; else prow[9 * C + c] = s;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Attention against NK spatially-reduced keys (changeformer.py:190-207): q [B*Nq][C], kv [B*NK][2C] in "(2 h d)" order,
+// out [B*Nq][C]; head h uses columns h*D..h*D+D.  One query row per thread, K and V of (b, h) live in LDS as fp32.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int D, int NK>
+__device__ __forceinline__ void load_kv(const T* kv, float* sK, float* sV, int b, int h, int C) {
+  for (int i = threadIdx.x; i < NK * D; i += blockDim.x) {
+    const int j = i / D, d = i - j * D;
+    const T* row = kv + ((int64_t)b * NK + j) * 2 * C + h * D + d;
+    sK[i] = ElemTraits<T>::ld(row);
+    sV[i] = ElemTraits<T>::ld(row + C);
+  }
+}
+
+template <typename T, int D, int NK>
+__global__ __launch_bounds__(256) void sr_attn_fwd_kernel(const T* q, const T* kv, T* out, int Nq, int C, float scale) {
+  __shared__ float sK[NK * D], sV[NK * D];
+  const int b = blockIdx.z, h = blockIdx.y;
+  load_kv<T, D, NK>(kv, sK, sV, b, h, C);
+  __syncthreads();
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Nq) return;
+  const T* qp = q + ((int64_t)b * Nq + i) * C + h * D;
+  float qr[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) qr[d] = ElemTraits<T>::ld(qp + d) * scale;
+  float s[NK];
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int j = 0; j < NK; ++j) {
+    float a = 0.f;
+#pragma unroll
+    for (int d = 0; d < D; ++d) a += qr[d] * sK[j * D + d];
+    s[j] = a;
+    mx = fmaxf(mx, a);
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < NK; ++j) { s[j] = __expf(s[j] - mx); sum += s[j]; }
+  const float inv = 1.f / sum;
+#pragma unroll
+  for (int d = 0; d < D; ++d) qr[d] = 0.f;
+#pragma unroll
+  for (int j = 0; j < NK; ++j) {
+    const float p = s[j] * inv;
+#pragma unroll
+    for (int d = 0; d < D; ++d) qr[d] += p * sV[j * D + d];
+  }
+  T* op = out + ((int64_t)b * Nq + i) * C + h * D;
+#pragma unroll
+  for (int d = 0; d < D; ++d) ElemTraits<T>::st(op + d, qr[d]);
+}
+
+// backward, pass A (one query per thread): dq ; P and dS (scale folded in) to scratch [B][H][Nq][NK] fp32
+template <typename T, int D, int NK>
+__global__ __launch_bounds__(256) void sr_attn_bwd_q_kernel(const T* q, const T* kv, const T* dout, T* dq, float* Pbuf, float* dSbuf,
+                                                            int Nq, int C, int H, float scale) {
+  __shared__ float sK[NK * D], sV[NK * D];
+  const int b = blockIdx.z, h = blockIdx.y;
+  load_kv<T, D, NK>(kv, sK, sV, b, h, C);
+  __syncthreads();
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Nq) return;
+  const T* qp = q + ((int64_t)b * Nq + i) * C + h * D;
+  const T* gp = dout + ((int64_t)b * Nq + i) * C + h * D;
+  float qr[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) qr[d] = ElemTraits<T>::ld(qp + d) * scale;
+  float s[NK];
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int j = 0; j < NK; ++j) {
+    float a = 0.f;
+#pragma unroll
+    for (int d = 0; d < D; ++d) a += qr[d] * sK[j * D + d];
+    s[j] = a;
+    mx = fmaxf(mx, a);
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < NK; ++j) { s[j] = __expf(s[j] - mx); sum += s[j]; }
+  const float inv = 1.f / sum;
+#pragma unroll
+  for (int d = 0; d < D; ++d) qr[d] = ElemTraits<T>::ld(gp + d);        // qr now holds dO
+  float dp[NK];
+  float delta = 0.f;
+#pragma unroll
+  for (int j = 0; j < NK; ++j) {
+    s[j] *= inv;
+    float a = 0.f;
+#pragma unroll
+    for (int d = 0; d < D; ++d) a += qr[d] * sV[j * D + d];
+    dp[j] = a;
+    delta += s[j] * a;
+  }
+  float* Pp = Pbuf + (((int64_t)b * H + h) * Nq + i) * NK;
+  float* Sp = dSbuf + (((int64_t)b * H + h) * Nq + i) * NK;
+#pragma unroll
+  for (int d = 0; d < D; ++d) qr[d] = 0.f;                              // qr now accumulates dq
+#pragma unroll
+  for (int j = 0; j < NK; ++j) {
+    const float ds = s[j] * (dp[j] - delta) * scale;
+    Pp[j] = s[j];
+    Sp[j] = ds;
+#pragma unroll
+    for (int d = 0; d < D; ++d) qr[d] += ds * sK[j * D + d];
+  }
+  T* op = dq + ((int64_t)b * Nq + i) * C + h * D;
+#pragma unroll
+  for (int d = 0; d < D; ++d) ElemTraits<T>::st(op + d, qr[d]);
+}
+
+// backward, pass B: partial[split][b][j][2C] : dK[j, h*D+d] = sum_i dS[i][j] q[i][d] ; dV[j, C + h*D+d] = sum_i P[i][j] dO[i][d]
+// grid (nsplit, H, B); 256 threads; queries staged 32 at a time in LDS
+template <typename T, int D, int NK>
+__global__ __launch_bounds__(256) void sr_attn_bwd_kv_kernel(const T* q, const T* dout, const float* Pbuf, const float* dSbuf,
+                                                             float* partial, int Nq, int C, int H, int B) {
+  constexpr int QT = 32;
+  __shared__ float sQ[QT * D], sG[QT * D], sP[QT * NK], sS[QT * NK];
+  const int b = blockIdx.z, h = blockIdx.y, split = blockIdx.x, nsplit = gridDim.x;
+  const int per = (Nq + nsplit - 1) / nsplit;
+  const int i0 = split * per, i1 = min(Nq, i0 + per);
+  constexpr int OUT = NK * D;                       // outputs per matrix
+  constexpr int PER_T = (OUT + 255) / 256;
+  float aK[PER_T], aV[PER_T];
+#pragma unroll
+  for (int k = 0; k < PER_T; ++k) { aK[k] = 0.f; aV[k] = 0.f; }
+  for (int base = i0; base < i1; base += QT) {
+    const int nq = min(QT, i1 - base);
+    __syncthreads();
+    for (int e = threadIdx.x; e < QT * D; e += 256) {
+      const int qi = e / D, d = e - qi * D;
+      const bool ok = qi < nq;
+      const int64_t row = ((int64_t)b * Nq + base + qi) * C + h * D + d;
+      sQ[e] = ok ? ElemTraits<T>::ld(q + row) : 0.f;
+      sG[e] = ok ? ElemTraits<T>::ld(dout + row) : 0.f;
+    }
+    for (int e = threadIdx.x; e < QT * NK; e += 256) {
+      const int qi = e / NK, j = e - qi * NK;
+      const bool ok = qi < nq;
+      const int64_t idx = (((int64_t)b * H + h) * Nq + base + qi) * NK + j;
+      sP[e] = ok ? Pbuf[idx] : 0.f;
+      sS[e] = ok ? dSbuf[idx] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PER_T; ++k) {
+      const int o = threadIdx.x + k * 256;
+      if (o < OUT) {
+        const int j = o / D, d = o - j * D;
+        float ak = 0.f, av = 0.f;
+#pragma unroll 8
+        for (int qi = 0; qi < QT; ++qi) {
+          ak += sS[qi * NK + j] * sQ[qi * D + d];
+          av += sP[qi * NK + j] * sG[qi * D + d];
+        }
+        aK[k] += ak; aV[k] += av;
+      }
+    }
+  }
+  float* pr = partial + ((size_t)split * B + b) * NK * 2 * C;
+#pragma unroll
+  for (int k = 0; k < PER_T; ++k) {
+    const int o = threadIdx.x + k * 256;
+    if (o < OUT) {
+      const int j = o / D, d = o - j * D;
+      pr[(size_t)j * 2 * C + h * D + d] = aK[k];
+      pr[(size_t)j * 2 * C + C + h * D + d] = aV[k];
+    }
+  }
+}
+
+// dkv[r][c] = sum_split partial[split][r][c]  (r over B*NK rows, c over 2C)
+template <typename T>
+__global__ void sum_splits_kernel(const float* partial, T* out, int64_t n, int nsplit) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += partial[(size_t)k * n + i];
+    ElemTraits<T>::st(out + i, s);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// bilinear resize, align_corners=False (F.interpolate semantics: src = max(0, (o+0.5)*in/out - 0.5))
+// forward: y = [add +] resize(x) ; backward (adjoint, gather form): dx (+)= resize^T(dy)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void bil_src(int o, float ratio, int in, int& i0, int& i1, float& l) {
+  float s = ((float)o + 0.5f) * ratio - 0.5f;
+  if (s < 0.f) s = 0.f;
+  i0 = (int)s;
+  if (i0 > in - 1) i0 = in - 1;
+  i1 = i0 < in - 1 ? i0 + 1 : i0;
+  l = s - (float)i0;
+}
+
+template <typename T>
+__global__ void bilinear_fwd_kernel(const T* x, const T* add, T* y, int B, int Hi, int Wi, int Ho, int Wo, int C) {
+  constexpr int VEC = ElemTraits<T>::kVec;
+  const int CV = C / VEC;
+  const float ry = (float)Hi / (float)Ho, rx = (float)Wi / (float)Wo;
+  const int64_t n = (int64_t)B * Ho * Wo * CV;
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (int64_t)gridDim.x * blockDim.x) {
+    const int cv = v % CV; int64_t r = v / CV;
+    const int ox = r % Wo; r /= Wo;
+    const int oy = r % Ho; const int b = r / Ho;
+    int y0, y1, x0, x1; float ly, lx;
+    bil_src(oy, ry, Hi, y0, y1, ly);
+    bil_src(ox, rx, Wi, x0, x1, lx);
+    float a[VEC], bb[VEC], c[VEC], d[VEC], o[VEC];
+    const T* base = x + (int64_t)b * Hi * Wi * C + cv * VEC;
+    vec_unpack<T>(*(const u32x4*)(base + ((int64_t)y0 * Wi + x0) * C), a);
+    vec_unpack<T>(*(const u32x4*)(base + ((int64_t)y0 * Wi + x1) * C), bb);
+    vec_unpack<T>(*(const u32x4*)(base + ((int64_t)y1 * Wi + x0) * C), c);
+    vec_unpack<T>(*(const u32x4*)(base + ((int64_t)y1 * Wi + x1) * C), d);
+    if (add) vec_unpack<T>(*(const u32x4*)(add + v * VEC), o);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const float top = a[j] + lx * (bb[j] - a[j]), bot = c[j] + lx * (d[j] - c[j]);
+      const float val = top + ly * (bot - top);
+      o[j] = add ? o[j] + val : val;
+    }
+    *(u32x4*)(y + v * VEC) = vec_pack<T>(o);
+  }
+}
+
+template <typename T>
+__global__ void bilinear_bwd_kernel(const T* dy, T* dx, int B, int Hi, int Wi, int Ho, int Wo, int C, int accumulate) {
+  constexpr int VEC = ElemTraits<T>::kVec;
+  const int CV = C / VEC;
+  const float ry = (float)Hi / (float)Ho, rx = (float)Wi / (float)Wo;
+  const int sy = (Ho + Hi - 1) / Hi, sx = (Wo + Wi - 1) / Wi;          // upscale factors (ceil)
+  const int64_t n = (int64_t)B * Hi * Wi * CV;
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (int64_t)gridDim.x * blockDim.x) {
+    const int cv = v % CV; int64_t r = v / CV;
+    const int ix = r % Wi; r /= Wi;
+    const int iy = r % Hi; const int b = r / Hi;
+    float s[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) s[j] = 0.f;
+    // output rows whose two taps can include iy: src in (iy-1, iy+1)  ->  o in [(iy-1)*s - s, (iy+1)*s + s]
+    const int oy_lo = max(0, (iy - 1) * sy - sy), oy_hi = min(Ho - 1, (iy + 2) * sy + sy);
+    const int ox_lo = max(0, (ix - 1) * sx - sx), ox_hi = min(Wo - 1, (ix + 2) * sx + sx);
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+      int y0, y1; float ly;
+      bil_src(oy, ry, Hi, y0, y1, ly);
+      float wy = 0.f;
+      if (y0 == iy) wy += 1.f - ly;
+      if (y1 == iy) wy += ly;
+      if (wy == 0.f) continue;
+      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+        int x0, x1; float lx;
+        bil_src(ox, rx, Wi, x0, x1, lx);
+        float wx = 0.f;
+        if (x0 == ix) wx += 1.f - lx;
+        if (x1 == ix) wx += lx;
+        if (wx == 0.f) continue;
+        float g[VEC];
+        vec_unpack<T>(*(const u32x4*)(dy + (((int64_t)b * Ho + oy) * Wo + ox) * C + cv * VEC), g);
+        const float w = wy * wx;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) s[j] += w * g[j];
+      }
+    }
+    if (accumulate) {
+      float o[VEC];
+      vec_unpack<T>(*(const u32x4*)(dx + v * VEC), o);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) s[j] += o[j];
+    }
+    *(u32x4*)(dx + v * VEC) = vec_pack<T>(s);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// BatchNorm input gradient for y = BN(r), r = relu(v) (or r = v): dv = gamma*rstd*(dy - s0/n - rhat*s1/n) [* (r > 0)]
+// sums[0][c] = sum dy, sums[1][c] = sum dy*rhat (from the consumer's dgrad epilogue + ksmi_reduce_rows)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void bn_bwd_apply_kernel(const T* dy, const T* r, const float* mean, const float* rstd, const float* gamma,
+                                    const float* sums, T* dv, int relu_mask, float inv_n, int64_t nvec, int CV, int C) {
+  constexpr int VEC = ElemTraits<T>::kVec;
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(v % CV) * VEC;
+    float g[VEC], rr[VEC];
+    vec_unpack<T>(*(const u32x4*)(dy + v * VEC), g);
+    vec_unpack<T>(*(const u32x4*)(r + v * VEC), rr);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const float rh = (rr[j] - mean[c + j]) * rstd[c + j];
+      float o = gamma[c + j] * rstd[c + j] * (g[j] - sums[c + j] * inv_n - rh * sums[C + c + j] * inv_n);
+      if (relu_mask && !(rr[j] > 0.f)) o = 0.f;
+      g[j] = o;
+    }
+    *(u32x4*)(dv + v * VEC) = vec_pack<T>(g);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// head output NHWC [B][HW][Cs] -> NCHW fp32 with optional sigmoid (changeformer.py:635-639) and its adjoint
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void out_to_nchw_kernel(const T* x, float* y, int B, int C, int Cs, int64_t HW, int act) {
+  const int64_t n = (int64_t)B * C * HW;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = i % HW; int64_t r = i / HW;
+    const int c = r % C; const int b = r / C;
+    float v = ElemTraits<T>::ld(x + ((int64_t)b * HW + p) * Cs + c);
+    if (act == 1) v = 1.f / (1.f + __expf(-v));
+    y[i] = v;
+  }
+}
+template <typename T>
+__global__ void dout_to_nhwc_kernel(const float* dy, const float* y, T* dx, int B, int C, int Cs, int64_t HW, int act) {
+  const int64_t n = (int64_t)B * HW * Cs;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = i % Cs; int64_t r = i / Cs;
+    const int64_t p = r % HW; const int b = r / HW;
+    float v = 0.f;
+    if (c < C) {
+      const int64_t j = ((int64_t)b * C + c) * HW + p;
+      v = dy[j];
+      if (act == 1) { const float s = y[j]; v *= s * (1.f - s); }
+    }
+    ElemTraits<T>::st(dx + i, v);
+  }
+}
+
+template <typename T, int D>
+int sr_attn_launch(int which, const void* q, const void* kv, const void* io, void* o2, float* Pb, float* Sb, float* partial,
+                   int B, int Nq, int H, int C, float scale, int nsplit, hipStream_t st) {
+  constexpr int NK = 49;
+  const dim3 grid((Nq + 255) / 256, H, B);
+  if (which == 0) hipLaunchKernelGGL((sr_attn_fwd_kernel<T, D, NK>), grid, dim3(256), 0, st, (const T*)q, (const T*)kv, (T*)o2, Nq, C, scale);
+  else if (which == 1)
+    hipLaunchKernelGGL((sr_attn_bwd_q_kernel<T, D, NK>), grid, dim3(256), 0, st, (const T*)q, (const T*)kv, (const T*)io, (T*)o2, Pb, Sb, Nq, C, H, scale);
+  else
+    hipLaunchKernelGGL((sr_attn_bwd_kv_kernel<T, D, NK>), dim3(nsplit, H, B), dim3(256), 0, st, (const T*)q, (const T*)io, Pb, Sb, partial, Nq, C, H, B);
+  return ksmi_check_launch("sr_attention");
+}
+
+int sr_attn_dispatch(int which, const void* q, const void* kv, const void* io, void* o2, float* Pb, float* Sb, float* partial,
+                     int B, int Nq, int Nk, int H, int C, float scale, int nsplit, int dtype, hipStream_t st) {
+  if (Nk != 49) return ksmi_fail(KSMI_E_UNSUPPORTED, "sr_attention: specialised for 49 keys (224x224 tiles: 7x7 after spatial reduction)");
+  if (H < 1 || C % H) return ksmi_fail(KSMI_E_ARG, "sr_attention: C must be divisible by heads");
+  const int D = C / H;
+  if (dtype != KSMI_BF16 && dtype != KSMI_F32) return ksmi_fail(KSMI_E_ARG, "bad dtype");
+  if (D == 64) return dtype == KSMI_BF16 ? sr_attn_launch<bf16_t, 64>(which, q, kv, io, o2, Pb, Sb, partial, B, Nq, H, C, scale, nsplit, st)
+                                         : sr_attn_launch<float, 64>(which, q, kv, io, o2, Pb, Sb, partial, B, Nq, H, C, scale, nsplit, st);
+  if (D == 80) return dtype == KSMI_BF16 ? sr_attn_launch<bf16_t, 80>(which, q, kv, io, o2, Pb, Sb, partial, B, Nq, H, C, scale, nsplit, st)
+                                         : sr_attn_launch<float, 80>(which, q, kv, io, o2, Pb, Sb, partial, B, Nq, H, C, scale, nsplit, st);
+  return ksmi_fail(KSMI_E_UNSUPPORTED, "sr_attention: head dim must be 64 or 80 (ChangeFormerV6 embed_dims / num_heads)");
+}
+
+}  // namespace
+
+#define KSMI_DT(dtype, EXPR_BF16, EXPR_F32)                                  \
+  do {                                                                       \
+    if ((dtype) == KSMI_BF16) { EXPR_BF16; }                                 \
+    else if ((dtype) == KSMI_F32) { EXPR_F32; }                              \
+    else return ksmi_fail(KSMI_E_ARG, "bad dtype");                          \
+  } while (0)
+
+extern "C" {
+
+int ksmi_im2col(const void* x, void* out, int B, int Cin, int H, int W, int Ho, int Wo, int KH, int KW, int stride, int pad,
+                int Kpad, int src_nchw_f32, int dtype, void* stream) {
+  if (Kpad < Cin * KH * KW) return ksmi_fail(KSMI_E_ARG, "im2col: Kpad < Cin*KH*KW");
+  const int64_t n = (int64_t)B * Ho * Wo * Kpad;
+  hipStream_t st = (hipStream_t)stream;
+  if (src_nchw_f32) {
+    KSMI_DT(dtype,
+            hipLaunchKernelGGL((im2col_kernel<bf16_t, true>), dim3(grid_for(n, 65536)), dim3(256), 0, st, x, (bf16_t*)out, B, Cin, H, W, Ho, Wo, KH, KW, stride, pad, Kpad),
+            hipLaunchKernelGGL((im2col_kernel<float, true>), dim3(grid_for(n, 65536)), dim3(256), 0, st, x, (float*)out, B, Cin, H, W, Ho, Wo, KH, KW, stride, pad, Kpad));
+  } else {
+    KSMI_DT(dtype,
+            hipLaunchKernelGGL((im2col_kernel<bf16_t, false>), dim3(grid_for(n, 65536)), dim3(256), 0, st, x, (bf16_t*)out, B, Cin, H, W, Ho, Wo, KH, KW, stride, pad, Kpad),
+            hipLaunchKernelGGL((im2col_kernel<float, false>), dim3(grid_for(n, 65536)), dim3(256), 0, st, x, (float*)out, B, Cin, H, W, Ho, Wo, KH, KW, stride, pad, Kpad));
+  }
+  return ksmi_check_launch("im2col");
+}
+
+int ksmi_col2im(const void* dcol, void* dx, int B, int Cin, int H, int W, int Ho, int Wo, int KH, int KW, int stride, int pad,
+                int Kpad, int dtype, void* stream) {
+  const int64_t n = (int64_t)B * H * W * Cin;
+  hipStream_t st = (hipStream_t)stream;
+  KSMI_DT(dtype,
+          hipLaunchKernelGGL(col2im_kernel<bf16_t>, dim3(grid_for(n, 65536)), dim3(256), 0, st, (const bf16_t*)dcol, (bf16_t*)dx, B, Cin, H, W, Ho, Wo, KH, KW, stride, pad, Kpad),
+          hipLaunchKernelGGL(col2im_kernel<float>, dim3(grid_for(n, 65536)), dim3(256), 0, st, (const float*)dcol, (float*)dx, B, Cin, H, W, Ho, Wo, KH, KW, stride, pad, Kpad));
+  return ksmi_check_launch("col2im");
+}
+
+int ksmi_dwconv3x3_gelu_forward(const void* x, const float* w, const float* bias, void* z, void* g, int B, int H, int W, int C,
+                                int dtype, void* stream) {
+  const int vec = dtype == KSMI_BF16 ? 8 : 4;
+  if (C % vec) return ksmi_fail(KSMI_E_ARG, "dwconv: C must be a multiple of the 16-byte vector");
+  const int64_t n = (int64_t)B * H * W * (C / vec);
+  hipStream_t st = (hipStream_t)stream;
+  KSMI_DT(dtype,
+          hipLaunchKernelGGL((dwconv3x3_kernel<bf16_t, 0>), dim3(grid_for(n, 65536)), dim3(256), 0, st, (const bf16_t*)x, w, bias, (bf16_t*)z, (bf16_t*)g, B, H, W, C),
+          hipLaunchKernelGGL((dwconv3x3_kernel<float, 0>), dim3(grid_for(n, 65536)), dim3(256), 0, st, (const float*)x, w, bias, (float*)z, (float*)g, B, H, W, C));
+  return ksmi_check_launch("dwconv3x3_gelu_fwd");
+}
+
+int ksmi_dwconv3x3_backward_input(const void* dz, const float* w, void* dx, int B, int H, int W, int C, int dtype, void* stream) {
+  const int vec = dtype == KSMI_BF16 ? 8 : 4;
+  if (C % vec) return ksmi_fail(KSMI_E_ARG, "dwconv: C must be a multiple of the 16-byte vector");
+  const int64_t n = (int64_t)B * H * W * (C / vec);
+  hipStream_t st = (hipStream_t)stream;
+  KSMI_DT(dtype,
+          hipLaunchKernelGGL((dwconv3x3_kernel<bf16_t, 1>), dim3(grid_for(n, 65536)), dim3(256), 0, st, (const bf16_t*)dz, w, (const float*)nullptr, (bf16_t*)dx, (bf16_t*)nullptr, B, H, W, C),
+          hipLaunchKernelGGL((dwconv3x3_kernel<float, 1>), dim3(grid_for(n, 65536)), dim3(256), 0, st, (const float*)dz, w, (const float*)nullptr, (float*)dx, (float*)nullptr, B, H, W, C));
+  return ksmi_check_launch("dwconv3x3_bwd_input");
+}
+
+int ksmi_dwconv3x3_wgrad(const void* x, const void* dz, float* partial, int rows, int B, int H, int W, int C, int dtype, void* stream) {
+  const int vec = dtype == KSMI_BF16 ? 8 : 4;
+  if (C % vec || rows < 1) return ksmi_fail(KSMI_E_ARG, "dwconv_wgrad: bad args");
+  const dim3 grid(rows, (C / vec + 63) / 64);
+  hipStream_t st = (hipStream_t)stream;
+  KSMI_DT(dtype,
+          hipLaunchKernelGGL(dwconv3x3_wgrad_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dz, partial, B, H, W, C),
+          hipLaunchKernelGGL(dwconv3x3_wgrad_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (const float*)dz, partial, B, H, W, C));
+  return ksmi_check_launch("dwconv3x3_wgrad");
+}
+
+int ksmi_sr_attention_forward(const void* q, const void* kv, void* out, int B, int Nq, int Nk, int H, int C, float scale, int dtype,
+                              void* stream) {
+  return sr_attn_dispatch(0, q, kv, nullptr, out, nullptr, nullptr, nullptr, B, Nq, Nk, H, C, scale, 1, dtype, (hipStream_t)stream);
+}
+
+int ksmi_sr_attention_splits(int Nq) { int s = (Nq + 255) / 256; return s < 1 ? 1 : (s > 16 ? 16 : s); }
+
+size_t ksmi_sr_attention_bwd_workspace(int B, int Nq, int Nk, int H, int C) {
+  const size_t ps = (size_t)B * H * Nq * Nk * sizeof(float);
+  return 2 * ps + (size_t)ksmi_sr_attention_splits(Nq) * B * Nk * 2 * C * sizeof(float);
+}
+
+int ksmi_sr_attention_backward(const void* q, const void* kv, const void* dout, void* dq, void* dkv, void* workspace, int B, int Nq,
+                               int Nk, int H, int C, float scale, int dtype, void* stream) {
+  const size_t ps = (size_t)B * H * Nq * Nk;
+  float* Pb = (float*)workspace;
+  float* Sb = Pb + ps;
+  float* partial = Sb + ps;
+  const int nsplit = ksmi_sr_attention_splits(Nq);
+  hipStream_t st = (hipStream_t)stream;
+  int rc = sr_attn_dispatch(1, q, kv, dout, dq, Pb, Sb, partial, B, Nq, Nk, H, C, scale, nsplit, dtype, st);
+  if (rc) return rc;
+  rc = sr_attn_dispatch(2, q, kv, dout, nullptr, Pb, Sb, partial, B, Nq, Nk, H, C, scale, nsplit, dtype, st);
+  if (rc) return rc;
+  const int64_t n = (int64_t)B * Nk * 2 * C;
+  KSMI_DT(dtype,
+          hipLaunchKernelGGL(sum_splits_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, st, partial, (bf16_t*)dkv, n, nsplit),
+          hipLaunchKernelGGL(sum_splits_kernel<float>, dim3(grid_for(n)), dim3(256), 0, st, partial, (float*)dkv, n, nsplit));
+  return ksmi_check_launch("sr_attention_sum");
+}
+
+int ksmi_bilinear_forward(const void* x, const void* add, void* y, int B, int Hi, int Wi, int Ho, int Wo, int C, int dtype, void* stream) {
+  const int vec = dtype == KSMI_BF16 ? 8 : 4;
+  if (C % vec) return ksmi_fail(KSMI_E_ARG, "bilinear: C must be a multiple of the 16-byte vector");
+  const int64_t n = (int64_t)B * Ho * Wo * (C / vec);
+  hipStream_t st = (hipStream_t)stream;
+  KSMI_DT(dtype,
+          hipLaunchKernelGGL(bilinear_fwd_kernel<bf16_t>, dim3(grid_for(n, 65536)), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)add, (bf16_t*)y, B, Hi, Wi, Ho, Wo, C),
+          hipLaunchKernelGGL(bilinear_fwd_kernel<float>, dim3(grid_for(n, 65536)), dim3(256), 0, st, (const float*)x, (const float*)add, (float*)y, B, Hi, Wi, Ho, Wo, C));
+  return ksmi_check_launch("bilinear_fwd");
+}
+
+int ksmi_bilinear_backward(const void* dy, void* dx, int accumulate, int B, int Hi, int Wi, int Ho, int Wo, int C, int dtype, void* stream) {
+  const int vec = dtype == KSMI_BF16 ? 8 : 4;
+  if (C % vec || Ho < Hi || Wo < Wi) return ksmi_fail(KSMI_E_ARG, "bilinear_bwd: upsampling only, C multiple of the vector");
+  const int64_t n = (int64_t)B * Hi * Wi * (C / vec);
+  hipStream_t st = (hipStream_t)stream;
+  KSMI_DT(dtype,
+          hipLaunchKernelGGL(bilinear_bwd_kernel<bf16_t>, dim3(grid_for(n, 65536)), dim3(256), 0, st, (const bf16_t*)dy, (bf16_t*)dx, B, Hi, Wi, Ho, Wo, C, accumulate),
+          hipLaunchKernelGGL(bilinear_bwd_kernel<float>, dim3(grid_for(n, 65536)), dim3(256), 0, st, (const float*)dy, (float*)dx, B, Hi, Wi, Ho, Wo, C, accumulate));
+  return ksmi_check_launch("bilinear_bwd");
+}
+
+int ksmi_bn_bwd_apply(const void* dy, const void* r, const float* mean, const float* rstd, const float* gamma, const float* sums,
+                      void* dv, int relu_mask, double count, int64_t npix, int C, int dtype, void* stream) {
+  const int vec = dtype == KSMI_BF16 ? 8 : 4;
+  if (C % vec) return ksmi_fail(KSMI_E_ARG, "bn_bwd_apply: C must be a multiple of the 16-byte vector");
+  const int64_t nvec = npix * (C / vec);
+  const float inv_n = (float)(1.0 / count);
+  hipStream_t st = (hipStream_t)stream;
+  KSMI_DT(dtype,
+          hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(grid_for(nvec, 65536)), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)r, mean, rstd, gamma, sums, (bf16_t*)dv, relu_mask, inv_n, nvec, C / vec, C),
+          hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid_for(nvec, 65536)), dim3(256), 0, st, (const float*)dy, (const float*)r, mean, rstd, gamma, sums, (float*)dv, relu_mask, inv_n, nvec, C / vec, C));
+  return ksmi_check_launch("bn_bwd_apply");
+}
+
+int ksmi_out_to_nchw(const void* x, float* y, int B, int C, int Cs, int64_t HW, int act, int dtype, void* stream) {
+  const int64_t n = (int64_t)B * C * HW;
+  hipStream_t st = (hipStream_t)stream;
+  KSMI_DT(dtype,
+          hipLaunchKernelGGL(out_to_nchw_kernel<bf16_t>, dim3(grid_for(n, 65536)), dim3(256), 0, st, (const bf16_t*)x, y, B, C, Cs, HW, act),
+          hipLaunchKernelGGL(out_to_nchw_kernel<float>, dim3(grid_for(n, 65536)), dim3(256), 0, st, (const float*)x, y, B, C, Cs, HW, act));
+  return ksmi_check_launch("out_to_nchw");
+}
+
+int ksmi_dout_to_nhwc(const float* dy, const float* y, void* dx, int B, int C, int Cs, int64_t HW, int act, int dtype, void* stream) {
+  const int64_t n = (int64_t)B * HW * Cs;
+  hipStream_t st = (hipStream_t)stream;
+  KSMI_DT(dtype,
+          hipLaunchKernelGGL(dout_to_nhwc_kernel<bf16_t>, dim3(grid_for(n, 65536)), dim3(256), 0, st, dy, y, (bf16_t*)dx, B, C, Cs, HW, act),
+          hipLaunchKernelGGL(dout_to_nhwc_kernel<float>, dim3(grid_for(n, 65536)), dim3(256), 0, st, dy, y, (float*)dx, B, C, Cs, HW, act));
+  return ksmi_check_launch("dout_to_nhwc");
+}
+
+}  // extern "C"

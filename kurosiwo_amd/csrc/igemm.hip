@@ -165,8 +165,10 @@ __global__ void pack_weights_kernel(const ksmi_pack_desc d) {
     const int j = r % d.Npad; r /= d.Npad;
     const int tap = r % d.taps; const int ch = r / d.taps;
     float v = 0.f;
-    if (j < d.N && kk < d.k_len[ch]) {
-      const int64_t k = d.k_off[ch] + kk;
+    const int koff = d.uniform_kc ? ch * d.uniform_kc : d.k_off[ch];
+    const int klen = d.uniform_kc ? min(d.uniform_kc, d.k_total - koff) : d.k_len[ch];
+    if (j < d.N && kk < klen) {
+      const int64_t k = koff + kk;
       const int tp = d.use_tap_map ? d.tap_map[tap] : (d.flip ? (d.taps - 1 - tap) : tap);
       v = d.w[k * d.sK + (int64_t)(j % d.n_mod) * d.sN + (int64_t)(j / d.n_mod) * d.sD + tp * d.sT];
     }
@@ -188,8 +190,10 @@ __global__ void pack_weights_batched_kernel(const ksmi_pack_desc* descs) {
     const int j = r % Npad; r /= Npad;
     const int tap = r % taps; const int ch = r / taps;
     float v = 0.f;
-    if (j < N && kk < d.k_len[ch]) {
-      const int64_t k = d.k_off[ch] + kk;
+    const int koff = d.uniform_kc ? ch * d.uniform_kc : d.k_off[ch];
+    const int klen = d.uniform_kc ? min(d.uniform_kc, d.k_total - koff) : d.k_len[ch];
+    if (j < N && kk < klen) {
+      const int64_t k = koff + kk;
       const int tp = d.use_tap_map ? d.tap_map[tap] : (flip ? (taps - 1 - tap) : tap);
       v = w[k * sK + (int64_t)(j % n_mod) * sN + (int64_t)(j / n_mod) * sD + tp * sT];
     }
@@ -264,8 +268,8 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const ksmi_wgrad_desc 
   unsigned char* lds_dy = smem + ((HP * 64 + 255) & ~255);
   const int dyrow = BN * ES;
 
-  const ksmi_src& sr = d.src[d.chunk_src[ch]];
-  const int c0 = d.chunk_c0[ch];
+  const ksmi_src& sr = d.src[d.uniform_kc ? 0 : d.chunk_src[ch]];
+  const int c0 = d.uniform_kc ? ch * d.uniform_kc : d.chunk_c0[ch];
   const int myq = tid & 3;
   const int cq = c0 + myq * VEC;
   const bool cvalid = cq < sr.c_len;
@@ -418,8 +422,10 @@ __global__ void wgrad_reduce_kernel(const ksmi_wgrad_desc d, int taps, int KC) {
     if (sp < d.nsplit) s0 += d.partial[(size_t)sp * total + i];
     float s = s0 + s1;
     s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
-    if (l8 == 0 && n < d.N && kc < d.k_len[ch]) {
-      const int64_t k = d.k_off[ch] + kc;
+    const int koff = d.uniform_kc ? ch * d.uniform_kc : d.k_off[ch];
+    const int klen = d.uniform_kc ? min(d.uniform_kc, d.k_total - koff) : d.k_len[ch];
+    if (l8 == 0 && n < d.N && kc < klen) {
+      const int64_t k = koff + kc;
       float* gp = d.grad + k * d.gK + (int64_t)n * d.gN + (int64_t)t * d.gT;
       *gp = d.accumulate ? (*gp + s) : s;
     }
@@ -538,17 +544,19 @@ int ksmi_conv_grid_m(const ksmi_conv_desc* d) {
 
 int ksmi_conv_forward(const ksmi_conv_desc* d, int dtype, void* stream) {
   if (!d || d->nsrc < 1 || d->nsrc > KSMI_MAX_SRC || d->ndst < 1 || d->ndst > KSMI_MAX_SRC || d->nchunks < 1 ||
-      d->nchunks > KSMI_MAX_CHUNKS)
+      (d->nchunks > KSMI_MAX_CHUNKS && !(d->uniform_kc && d->nsrc == 1)))
     return ksmi_fail(KSMI_E_ARG, "conv: bad descriptor");
   if (dtype != KSMI_BF16 && dtype != KSMI_F32) return ksmi_fail(KSMI_E_ARG, "conv: bad dtype");
   static const bool force_v1 = getenv("KSMI_IGEMM_V1") != nullptr;      // A/B switch for profiling
   if (!force_v1 && ksmi_igemm2_eligible(d, dtype)) return ksmi_igemm2_launch(d, dtype, (hipStream_t)stream);
+  if (d->alpha != 0.f || d->resid || d->relu_out || d->uniform_kc)
+    return ksmi_fail(KSMI_E_UNSUPPORTED, "conv: alpha/resid/relu_out/uniform chunks need whole-chunk sources (igemm2 path)");
   if (dtype == KSMI_BF16) return launch_fwd<bf16_t>(d, (hipStream_t)stream);
   return launch_fwd<float>(d, (hipStream_t)stream);
 }
 
 int ksmi_pack_weights(const ksmi_pack_desc* d, int dtype, void* stream) {
-  if (!d || d->nchunks < 1 || d->nchunks > KSMI_MAX_CHUNKS) return ksmi_fail(KSMI_E_ARG, "pack: bad descriptor");
+  if (!d || d->nchunks < 1 || (d->nchunks > KSMI_MAX_CHUNKS && !d->uniform_kc)) return ksmi_fail(KSMI_E_ARG, "pack: bad descriptor");
   const int kc = ksmi_chunk_elems(dtype);
   const size_t total = (size_t)d->nchunks * d->taps * d->Npad * kc;
   int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
@@ -573,7 +581,7 @@ size_t ksmi_conv_wgrad_workspace(const ksmi_wgrad_desc* d, int dtype) {
 }
 
 int ksmi_conv_wgrad(const ksmi_wgrad_desc* d, int dtype, void* stream) {
-  if (!d || d->nsrc < 1 || d->nsrc > KSMI_MAX_SRC || d->nchunks < 1 || d->nchunks > KSMI_MAX_CHUNKS)
+  if (!d || d->nsrc < 1 || d->nsrc > KSMI_MAX_SRC || d->nchunks < 1 || (d->nchunks > KSMI_MAX_CHUNKS && !(d->uniform_kc && d->nsrc == 1)))
     return ksmi_fail(KSMI_E_ARG, "wgrad: bad descriptor");
   if (dtype == KSMI_BF16) return launch_wgrad<bf16_t>(d, (hipStream_t)stream);
   if (dtype == KSMI_F32) return launch_wgrad<float>(d, (hipStream_t)stream);

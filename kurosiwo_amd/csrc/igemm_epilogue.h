@@ -21,10 +21,12 @@ struct FastDiv {
 // fetched with global_load_ubyte/ushort (VMEM), and hipcc then waits vmcnt(0) -- draining every LDS-DMA
 // in flight -- before the value can be used.  A uniform dword index keeps it on the scalar path.
 __device__ __forceinline__ int chunk_c0_of(const ksmi_conv_desc& d, int ch) {
+  if (d.uniform_kc) return ch * d.uniform_kc;
   const uint32_t w = ((const uint32_t*)d.chunk_c0)[ch >> 1];
   return (ch & 1) ? (int)(w >> 16) : (int)(w & 0xffffu);
 }
 __device__ __forceinline__ int chunk_src_of(const ksmi_conv_desc& d, int ch) {
+  if (d.uniform_kc) return 0;
   return (int)((((const uint32_t*)d.chunk_src)[ch >> 2] >> ((ch & 3) * 8)) & 0xffu);
 }
 
@@ -259,6 +261,22 @@ __device__ __forceinline__ void igemm_epilogue_direct(const ksmi_conv_desc& d, f
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = acc[mf][nf][r] + bias[r];
+      if (d.alpha != 0.f) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= d.alpha;
+      }
+      if (d.resid) {
+        float rs[4] = {0.f, 0.f, 0.f, 0.f};
+        const T* rp = (const T*)d.resid + opix[mf] * d.residC + n4;
+        if (vec_ok && (d.residC & 3) == 0) Quad<T>::ld(rp, rs);
+        else for (int r = 0; r < nval; ++r) rs[r] = ElemTraits<T>::ld(rp + r);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += rs[r];
+      }
+      if (d.relu_out) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+      }
       if (d.mask_src) {
         float m[4] = {0.f, 0.f, 0.f, 0.f};
         const T* mp = (const T*)d.mask_src + opix[mf] * d.N + n4;

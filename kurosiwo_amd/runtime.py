@@ -99,9 +99,17 @@ def _chunk_table(srcs, kc):
         for c0 in range(0, s.c_len, kc):
             table.append((si, c0, kbase + c0, max(0, min(kc, s.k_real - c0))))
         kbase += s.k_real
-    if len(table) > _lib.MAX_CHUNKS:
-        raise _lib.KsmiError(f"too many k-chunks ({len(table)} > {_lib.MAX_CHUNKS})")
+    if len(table) > _lib.MAX_CHUNKS and len(srcs) != 1:
+        raise _lib.KsmiError(f"too many k-chunks ({len(table)} > {_lib.MAX_CHUNKS}) for a multi-source descriptor")
     return table, kbase
+
+
+def _uniform(table, kc):
+    """Descriptors with more chunks than the tables hold use the computed (uniform) chunk walk of one source."""
+    if len(table) <= _lib.MAX_CHUNKS:
+        return 0, 0
+    assert all(t[0] == 0 and t[1] == i * kc and t[2] == i * kc for i, t in enumerate(table))
+    return kc, table[-1][2] + table[-1][3]
 
 
 def _fill_srcs(desc, srcs):
@@ -138,8 +146,12 @@ def make_pack(w, out, table, taps, N, Npad, n_mod, sK, sN, sD, sT, flip, tap_map
     d.w, d.out = w.data_ptr(), out.data_ptr()
     d.nchunks, d.taps, d.N, d.Npad, d.n_mod = len(table), taps, N, Npad, n_mod
     d.sK, d.sN, d.sD, d.sT, d.flip = sK, sN, sD, sT, flip
-    for i, (_, _, kg, kl) in enumerate(table):
-        d.k_off[i], d.k_len[i] = kg, kl
+    kc_u, ktot = _uniform(table, table[0][3] if len(table) == 1 else table[1][2] - table[0][2])
+    if kc_u:
+        d.uniform_kc, d.k_total = kc_u, ktot
+    else:
+        for i, (_, _, kg, kl) in enumerate(table):
+            d.k_off[i], d.k_len[i] = kg, kl
     if tap_map is not None:
         d.use_tap_map = 1
         for i, t in enumerate(tap_map):
@@ -148,8 +160,9 @@ def make_pack(w, out, table, taps, N, Npad, n_mod, sK, sN, sD, sT, flip, tap_map
 
 
 def make_conv(srcs, dsts, wpk, bias, stats, B, Hin, Win, Hout, Wout, KH, KW, stride, pad, N, dtype,
-              mask=None, ps_cout=0, max_pix=256, pad_x=None, out_map=None):
-    """dsts: list of (tensor, C, c_off, n_begin, n_len, accumulate).  mask: (tensor, mean, rstd, scale, shift)."""
+              mask=None, ps_cout=0, max_pix=256, pad_x=None, out_map=None, alpha=0.0, relu_out=0, resid=None):
+    """dsts: list of (tensor, C, c_off, n_begin, n_len, accumulate).  mask: (tensor, mean, rstd, scale, shift).
+    resid: (tensor, C) added after alpha scaling; relu_out: ReLU before statistics/store."""
     kc = chunk_elems(dtype)
     table, _ = _chunk_table(srcs, kc)
     d = ConvDesc()
@@ -166,6 +179,9 @@ def make_conv(srcs, dsts, wpk, bias, stats, B, Hin, Win, Hout, Wout, KH, KW, str
     d.B, d.Hin, d.Win, d.Hout, d.Wout = B, Hin, Win, Hout, Wout
     d.KH, d.KW, d.stride, d.pad = KH, KW, stride, pad
     d.pad_x = pad if pad_x is None else pad_x
+    d.alpha, d.relu_out = alpha, relu_out
+    if resid is not None:
+        d.resid, d.residC = resid[0].data_ptr(), resid[1]
     if out_map is not None:          # (sy, sx, oy, ox, H, W)
         d.out_sy, d.out_sx, d.out_oy, d.out_ox, d.out_H, d.out_W = out_map
     mp = max_pix if stride == 1 else min(max_pix, 128)
@@ -173,8 +189,11 @@ def make_conv(srcs, dsts, wpk, bias, stats, B, Hin, Win, Hout, Wout, KH, KW, str
     d.N, d.Npad = N, (N + 15) // 16 * 16
     d.nchunks = len(table)
     d.ps_cout = ps_cout
-    for i, (si, c0, _, _) in enumerate(table):
-        d.chunk_src[i], d.chunk_c0[i] = si, c0
+    if _uniform(table, kc)[0]:
+        d.uniform_kc = kc
+    else:
+        for i, (si, c0, _, _) in enumerate(table):
+            d.chunk_src[i], d.chunk_c0[i] = si, c0
     return d, table
 
 
@@ -199,8 +218,12 @@ def make_wgrad(srcs, dy, dyC, dy_c_off, N, grad, gK, gN, gT, accumulate, B, Hin,
     d.TH, d.TW = choose_patch(Hout, Wout, stride, KH, KW, mp)
     d.N, d.nchunks = N, len(table)
     d.grad, d.gK, d.gN, d.gT, d.accumulate = grad.data_ptr(), gK, gN, gT, accumulate
-    for i, (si, c0, kg, kl) in enumerate(table):
-        d.chunk_src[i], d.chunk_c0[i], d.k_off[i], d.k_len[i] = si, c0, kg, kl
+    kc_u, ktot = _uniform(table, kc)
+    if kc_u:
+        d.uniform_kc, d.k_total = kc_u, ktot
+    else:
+        for i, (si, c0, kg, kl) in enumerate(table):
+            d.chunk_src[i], d.chunk_c0[i], d.k_off[i], d.k_len[i] = si, c0, kg, kl
     lib = _lib.load()
     ws = lib.ksmi_conv_wgrad_workspace(C.byref(d), DT[dtype])
     npad = (N + 15) // 16 * 16

@@ -15,6 +15,8 @@ the tests, so only expected outputs are stored):
                       full argmax mask; train step (B=2) loss + grad norms
   floodvit_small.npz  FinetunerSegmentation(ViT(dim 1024, depth 2, heads 4, mlp 512, 6 ch), decoder head) B=2:
                       encoder tokens + logits subsamples, weighted-CE loss, per-parameter grad stats, selected grads
+  changeformer.npz    ChangeFormerV6(2, 3, decoder_softmax=True, embed_dim=256): state-dict inventory, eval outputs (B=1), train-mode
+                      (dropout / drop-path probabilities set to 0) outputs, ce+dice loss, grad stats, BN running statistics (B=2)
   floodvit_full.npz   the mae.json encoder (depth 24, heads 16, mlp 2048) B=1: logits subsample, argmax, loss, grad stats
 
 models/model_utilities.py imports every model family of the reference plus three packages that are not installed
@@ -251,6 +253,110 @@ def gen_floodvit(tag, hp, B):
     np.savez_compressed(os.path.join(OUT, f"floodvit_{tag}.npz"), **out)
 
 
+def _import_changeformer_reference():
+    """models/changeformer.py needs three helpers of timm (not installed): DropPath, to_2tuple, trunc_normal_.  The placeholders
+    below stand in for them during the import: weights are seeded-filled afterwards (initialisation is irrelevant) and every
+    stochastic layer is disabled for the vectors (eval mode, or p = 0), where timm's DropPath is the identity as well."""
+    import importlib.machinery
+    import types
+
+    class DropPath(torch.nn.Module):
+        def __init__(self, drop_prob=0.0):
+            super().__init__()
+            self.drop_prob = drop_prob
+
+        def forward(self, x):
+            assert not (self.training and self.drop_prob > 0), "golden vectors are generated with drop_path = 0"
+            return x
+    attrs = {"timm": {}, "timm.models": {}, "timm.models.layers": {
+        "DropPath": DropPath, "to_2tuple": lambda v: v if isinstance(v, tuple) else (v, v), "trunc_normal_": torch.nn.init.trunc_normal_}}
+    for name, a in attrs.items():
+        mod = types.ModuleType(name)
+        mod.__spec__ = importlib.machinery.ModuleSpec(name, None)
+        mod.__path__ = []
+        for k, v in a.items():
+            setattr(mod, k, v)
+        sys.modules[name] = mod
+    from models.changeformer import ChangeFormerV6  # noqa: E402  (reference)
+    return ChangeFormerV6
+
+
+CHANGEFORMER_GRAD_KEYS = [
+    "Tenc_x2.patch_embed1.proj.weight", "Tenc_x2.patch_embed1.norm.bias", "Tenc_x2.patch_embed3.proj.bias",
+    "Tenc_x2.block1.0.attn.q.bias", "Tenc_x2.block1.0.attn.sr.bias", "Tenc_x2.block1.2.attn.norm.weight",
+    "Tenc_x2.block2.1.attn.kv.bias", "Tenc_x2.block3.3.mlp.dwconv.dwconv.weight", "Tenc_x2.block3.0.mlp.dwconv.dwconv.bias",
+    "Tenc_x2.block4.2.mlp.fc2.bias", "Tenc_x2.block4.0.norm1.weight", "Tenc_x2.norm2.weight", "Tenc_x2.norm4.bias",
+    "TDec_x2.linear_c4.proj.bias", "TDec_x2.linear_c1.proj.weight", "TDec_x2.diff_c4.0.bias", "TDec_x2.diff_c1.2.weight",
+    "TDec_x2.diff_c2.2.bias", "TDec_x2.diff_c3.3.bias", "TDec_x2.linear_fuse.0.bias", "TDec_x2.linear_fuse.1.weight",
+    "TDec_x2.convd2x.conv2d.bias", "TDec_x2.dense_2x.0.conv2.conv2d.bias", "TDec_x2.dense_1x.0.conv1.conv2d.bias",
+    "TDec_x2.change_probability.conv2d.weight", "TDec_x2.change_probability.conv2d.bias",
+]
+
+
+def gen_changeformer():
+    ChangeFormerV6 = _import_changeformer_reference()
+    out = {}
+    c = 2
+
+    def ref_model():
+        m = ChangeFormerV6(input_nc=c, output_nc=3, decoder_softmax=True, embed_dim=256)   # model_utilities.py:198-204
+        seeded_fill_(m.state_dict())
+        return m
+    model = ref_model()
+    sd = model.state_dict()
+    out["state_dict_keys"] = np.array(list(sd.keys()))
+    out["state_dict_shapes"] = np.array([",".join(str(d) for d in v.shape) for v in sd.values()])
+    # ---- eval forward, B = 1
+    x1 = sar_like("changeformer.eval.x1", (1, c, 224, 224))
+    x2 = sar_like("changeformer.eval.x2", (1, c, 224, 224))
+    model.eval()
+    with torch.no_grad():
+        outs = model(x1, x2)
+        feats = model.Tenc_x2(x1)
+    for i, o in enumerate(outs[:4]):
+        out[f"eval.out{i}"] = o.numpy().copy()
+    out["eval.out4_sub"] = outs[4][:, :, ::8, ::8].numpy().copy()
+    out["eval.argmax"] = outs[4].argmax(1).numpy().astype(np.uint8)
+    top2 = outs[4].topk(2, dim=1).values
+    out["eval.margin"] = (top2[:, 0] - top2[:, 1]).numpy().astype(np.float16)
+    for i, f in enumerate(feats):
+        out[f"eval.feat{i + 1}_sub"] = f[:, ::4, ::2, ::2].numpy().copy()
+    # ---- train forward/backward, B = 2, stochastic layers off (p = 0)
+    x1 = sar_like("changeformer.train.x1", (2, c, 224, 224))
+    x2 = sar_like("changeformer.train.x2", (2, c, 224, 224))
+    lbl = seeded_labels("changeformer.train.lbl", (2, 224, 224))
+    model = ref_model()
+    model.train()
+    for mod in model.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+        if hasattr(mod, "drop_prob"):
+            mod.drop_prob = 0.0
+    crit = BCEandDiceLoss(weights=CLASS_WEIGHTS, ignore_index=3, use_softmax=True)
+    outs = model(x1, x2)
+    loss = crit(outs[-1], lbl)                      # change_detection_trainer.py:138-166 (multi_scale_train false)
+    loss.backward()
+    for i, o in enumerate(outs[:4]):
+        out[f"train.out{i}"] = o.detach().numpy().copy()
+    out["train.out4_sub"] = outs[4][:, :, ::8, ::8].detach().numpy().copy()
+    out["train.loss"] = np.array(float(loss.detach()))
+    for k, p in model.named_parameters():
+        if p.grad is None:
+            out[f"gstat.{k}"] = np.zeros(3)
+            continue
+        g = p.grad.detach().double()
+        out[f"gstat.{k}"] = np.array([float(g.norm()), float(g.sum()), float(g.abs().max())])
+        if k in CHANGEFORMER_GRAD_KEYS:
+            out[f"grad.{k}"] = p.grad.detach().numpy().copy()
+    sd = model.state_dict()
+    for k in ("TDec_x2.diff_c4.2", "TDec_x2.diff_c1.2", "TDec_x2.make_pred_c2.2", "TDec_x2.linear_fuse.1"):
+        out[f"bn.{k}.running_mean"] = sd[f"{k}.running_mean"].numpy().copy()
+        out[f"bn.{k}.running_var"] = sd[f"{k}.running_var"].numpy().copy()
+        out[f"bn.{k}.num_batches_tracked"] = sd[f"{k}.num_batches_tracked"].numpy().copy()
+    print("changeformer train loss", float(loss.detach()), "keys", len(sd))
+    np.savez_compressed(os.path.join(OUT, "changeformer.npz"), **out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -264,3 +370,5 @@ if __name__ == "__main__":
     if not only or "floodvit" in only:
         gen_floodvit("small", FLOODVIT_SMALL, 2)
         gen_floodvit("full", FLOODVIT_FULL, 1)
+    if not only or "changeformer" in only:
+        gen_changeformer()

@@ -1,0 +1,70 @@
+"""CPU: the ChangeFormerV6 oracle (oracle/changeformer_ref.py) against golden vectors produced by the real reference
+(models/changeformer.py imported in oracle/gen_golden.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import changeformer_ref as R
+from oracle.seeded import seeded_fill_, seeded_labels, seeded_tensor
+
+CLASS_WEIGHTS = [0.3715753140309927, 14.009780283125977, 8.20405370357821]
+
+
+def sar_like(name, shape):
+    return seeded_tensor(name, shape).clamp_(-2.23, 5.75)
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    return np.load(os.path.join(golden_dir, "changeformer.npz"))
+
+
+def test_state_dict_inventory(gold):
+    # 373 state-dict keys, 41 035 255 parameters (c = 2)
+    spec = R.changeformer_state_dict_spec(2, 3, 256)
+    assert list(spec.keys()) == list(gold["state_dict_keys"])
+    assert [",".join(str(d) for d in s) for s in spec.values()] == list(gold["state_dict_shapes"])
+    assert len(spec) == 373
+    assert sum(int(np.prod(s)) for k, s in spec.items() if not R.is_buffer(k)) == 41_035_255
+
+
+def test_eval_forward(gold):
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    sd = seeded_fill_(R.new_state_dict(2, 3, 256))
+    x1 = sar_like("changeformer.eval.x1", (1, 2, 224, 224))
+    x2 = sar_like("changeformer.eval.x2", (1, 2, 224, 224))
+    inter = {}
+    with torch.no_grad():
+        outs = R.changeformer_forward(sd, x1, x2, training=False, inter=inter)
+    assert [tuple(o.shape) for o in outs] == [(1, 3, 7, 7), (1, 3, 14, 14), (1, 3, 28, 28), (1, 3, 56, 56), (1, 3, 224, 224)]
+    for i in range(4):
+        assert np.abs(outs[i].numpy() - gold[f"eval.out{i}"]).max() < 1e-4
+        assert np.abs(inter[f"A.f{i + 1}"][:, ::4, ::2, ::2].numpy() - gold[f"eval.feat{i + 1}_sub"]).max() < 2e-3
+    assert np.abs(outs[4][:, :, ::8, ::8].numpy() - gold["eval.out4_sub"]).max() < 1e-4
+    confident = gold["eval.margin"].astype(np.float32) > 1e-3
+    assert (outs[4].argmax(1).numpy().astype(np.uint8) == gold["eval.argmax"])[confident].all()
+
+
+def test_train_step(gold):
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    sd = seeded_fill_(R.new_state_dict(2, 3, 256))
+    x1 = sar_like("changeformer.train.x1", (2, 2, 224, 224))
+    x2 = sar_like("changeformer.train.x2", (2, 2, 224, 224))
+    lbl = seeded_labels("changeformer.train.lbl", (2, 224, 224))
+    outs, loss, grads, new_stats = R.loss_and_grads(sd, x1, x2, lbl, CLASS_WEIGHTS, True)
+    for i in range(4):
+        assert np.abs(outs[i].numpy() - gold[f"train.out{i}"]).max() < 1e-4
+    assert np.abs(outs[4][:, :, ::8, ::8].numpy() - gold["train.out4_sub"]).max() < 1e-4
+    assert abs(loss - float(gold["train.loss"])) < 1e-5
+    for k, g in grads.items():
+        ref = gold[f"gstat.{k}"]
+        assert abs(float(g.double().norm()) - ref[0]) <= 2e-3 * ref[0] + 1e-7, k
+        fk = f"grad.{k}"
+        if fk in gold:
+            assert np.abs(g.numpy() - gold[fk]).max() <= 2e-3 * np.abs(gold[fk]).max() + 1e-8, k
+    for k in ("TDec_x2.diff_c4.2", "TDec_x2.diff_c1.2", "TDec_x2.make_pred_c2.2", "TDec_x2.linear_fuse.1"):
+        assert np.abs(new_stats[f"{k}.running_mean"].numpy() - gold[f"bn.{k}.running_mean"]).max() < 1e-4
+        assert np.abs(new_stats[f"{k}.running_var"].numpy() - gold[f"bn.{k}.running_var"]).max() < 1e-3 * max(1.0, float(gold[f"bn.{k}.running_var"].max()))
+        assert int(new_stats[f"{k}.num_batches_tracked"]) == int(gold[f"bn.{k}.num_batches_tracked"])
