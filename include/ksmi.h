@@ -306,7 +306,7 @@ int ksmi_upsample2_backward(const void* dy, const void* x_pre, void* dx, int B, 
  * NCHW fp32 image: OverlapPatchEmbed.proj (:267) and Attention.sr (:166) become GEMMs against the OIHW-flattened weight */
 int ksmi_im2col(const void* x, void* out, int B, int Cin, int H, int W, int Ho, int Wo, int KH, int KW, int stride, int pad,
                 int Kpad, int src_nchw_f32, int dtype, void* stream);
-int ksmi_col2im(const void* dcol, void* dx, int B, int Cin, int H, int W, int Ho, int Wo, int KH, int KW, int stride, int pad,
+int ksmi_col2im(const void* dcol, void* dx, int accumulate, int B, int Cin, int H, int W, int Ho, int Wo, int KH, int KW, int stride, int pad,
                 int Kpad, int dtype, void* stream);
 /* Mlp.dwconv + act (:85-96,128-129): z = depthwise3x3(x) + b (w fp32 [C][9]), g = gelu(z); adjoint of the conv; weight/bias
  * gradient partials partial[rows][10*C] (columns c*9+t, then 9C+c) for ksmi_reduce_rows */
@@ -328,6 +328,10 @@ int ksmi_bilinear_backward(const void* dy, void* dx, int accumulate, int B, int 
  * dv = gamma*rstd*(dy - sums[0]/n - rhat*sums[1]/n) [masked by r > 0] */
 int ksmi_bn_bwd_apply(const void* dy, const void* r, const float* mean, const float* rstd, const float* gamma, const float* sums,
                       void* dv, int relu_mask, double count, int64_t npix, int C, int dtype, void* stream);
+/* y = alpha * [relu](x*scale[c] + shift[c]) (scale = shift = NULL: plain scaled copy): the materialised BatchNorm output of
+ * linear_fuse (:563-567) and the 0.1 branch scale of ResidualBlock (:479-481) in the backward pass */
+int ksmi_affine(const void* x, const float* scale, const float* shift, void* y, int64_t npix, int C, int relu, float alpha, int dtype,
+                void* stream);
 /* head output NHWC [B][HW][Cs] -> NCHW fp32, act = 1: sigmoid (:635-639); adjoint (y = the forward's NCHW output) */
 int ksmi_out_to_nchw(const void* x, float* y, int B, int C, int Cs, int64_t HW, int act, int dtype, void* stream);
 int ksmi_dout_to_nhwc(const float* dy, const float* y, void* dx, int B, int C, int Cs, int64_t HW, int act, int dtype, void* stream);

@@ -118,7 +118,8 @@ SIGNATURES = {
     "ksmi_relu_backward": (_i, [_vp, _vp, _vp, _i64, _i, _vp]),
     "ksmi_relu_forward": (_i, [_vp, _vp, _i64, _i, _vp]),
     "ksmi_im2col": (_i, [_vp, _vp] + [_i] * 11 + [_i, _i, _vp]),
-    "ksmi_col2im": (_i, [_vp, _vp] + [_i] * 11 + [_i, _vp]),
+    "ksmi_col2im": (_i, [_vp, _vp, _i] + [_i] * 11 + [_i, _vp]),
+    "ksmi_affine": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, C.c_float, _i, _vp]),
     "ksmi_dwconv3x3_gelu_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ksmi_dwconv3x3_backward_input": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ksmi_dwconv3x3_wgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

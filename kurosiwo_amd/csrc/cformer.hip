@@ -45,7 +45,7 @@ __global__ void im2col_kernel(const void* xin, T* out, int B, int Cin, int H, in
 // col2im (adjoint): dx[b,iy,ix,c] = sum over taps with (iy + pad - ky) % stride == 0 of dcol[b,oy,ox,c*T+tap]
 template <typename T>
 __global__ void col2im_kernel(const T* dcol, T* dx, int B, int Cin, int H, int W, int Ho, int Wo, int KH, int KW, int stride,
-                              int pad, int Kpad) {
+                              int pad, int Kpad, int accumulate) {
   const int taps = KH * KW;
   const int64_t n = (int64_t)B * H * W * Cin;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -66,7 +66,27 @@ __global__ void col2im_kernel(const T* dcol, T* dx, int B, int Cin, int H, int W
         s += ElemTraits<T>::ld(dcol + (((int64_t)b * Ho + oy) * Wo + ox) * Kpad + c * taps + ky * KW + kx);
       }
     }
+    if (accumulate) s += ElemTraits<T>::ld(dx + i);
     ElemTraits<T>::st(dx + i, s);
+  }
+}
+
+// y = [relu](x * scale[c] + shift[c]) (scale/shift may be null = 1/0), times alpha: materialised BatchNorm output / scaled copy
+template <typename T>
+__global__ void affine_kernel(const T* x, const float* scale, const float* shift, T* y, int64_t nvec, int CV, int relu, float alpha) {
+  constexpr int VEC = ElemTraits<T>::kVec;
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(v % CV) * VEC;
+    float f[VEC];
+    vec_unpack<T>(*(const u32x4*)(x + v * VEC), f);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      float o = f[j];
+      if (scale) o = o * scale[c + j] + shift[c + j];
+      if (relu) o = fmaxf(o, 0.f);
+      f[j] = o * alpha;
+    }
+    *(u32x4*)(y + v * VEC) = vec_pack<T>(f);
   }
 }
 
@@ -543,13 +563,25 @@ int ksmi_im2col(const void* x, void* out, int B, int Cin, int H, int W, int Ho, 
   return ksmi_check_launch("im2col");
 }
 
-int ksmi_col2im(const void* dcol, void* dx, int B, int Cin, int H, int W, int Ho, int Wo, int KH, int KW, int stride, int pad,
+int ksmi_affine(const void* x, const float* scale, const float* shift, void* y, int64_t npix, int C, int relu, float alpha, int dtype,
+                void* stream) {
+  const int vec = dtype == KSMI_BF16 ? 8 : 4;
+  if (C % vec || (scale == nullptr) != (shift == nullptr)) return ksmi_fail(KSMI_E_ARG, "affine: bad args");
+  const int64_t nvec = npix * (C / vec);
+  hipStream_t st = (hipStream_t)stream;
+  KSMI_DT(dtype,
+          hipLaunchKernelGGL(affine_kernel<bf16_t>, dim3(grid_for(nvec, 65536)), dim3(256), 0, st, (const bf16_t*)x, scale, shift, (bf16_t*)y, nvec, C / vec, relu, alpha),
+          hipLaunchKernelGGL(affine_kernel<float>, dim3(grid_for(nvec, 65536)), dim3(256), 0, st, (const float*)x, scale, shift, (float*)y, nvec, C / vec, relu, alpha));
+  return ksmi_check_launch("affine");
+}
+
+int ksmi_col2im(const void* dcol, void* dx, int accumulate, int B, int Cin, int H, int W, int Ho, int Wo, int KH, int KW, int stride, int pad,
                 int Kpad, int dtype, void* stream) {
   const int64_t n = (int64_t)B * H * W * Cin;
   hipStream_t st = (hipStream_t)stream;
   KSMI_DT(dtype,
-          hipLaunchKernelGGL(col2im_kernel<bf16_t>, dim3(grid_for(n, 65536)), dim3(256), 0, st, (const bf16_t*)dcol, (bf16_t*)dx, B, Cin, H, W, Ho, Wo, KH, KW, stride, pad, Kpad),
-          hipLaunchKernelGGL(col2im_kernel<float>, dim3(grid_for(n, 65536)), dim3(256), 0, st, (const float*)dcol, (float*)dx, B, Cin, H, W, Ho, Wo, KH, KW, stride, pad, Kpad));
+          hipLaunchKernelGGL(col2im_kernel<bf16_t>, dim3(grid_for(n, 65536)), dim3(256), 0, st, (const bf16_t*)dcol, (bf16_t*)dx, B, Cin, H, W, Ho, Wo, KH, KW, stride, pad, Kpad, accumulate),
+          hipLaunchKernelGGL(col2im_kernel<float>, dim3(grid_for(n, 65536)), dim3(256), 0, st, (const float*)dcol, (float*)dx, B, Cin, H, W, Ho, Wo, KH, KW, stride, pad, Kpad, accumulate));
   return ksmi_check_launch("col2im");
 }
 

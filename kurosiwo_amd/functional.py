@@ -33,9 +33,9 @@ def _pack(weight, table, taps, N, n_mod, sK, sN, sD, sT, flip, dtype):
     return out
 
 
-def conv3x3(xs, weight, bias=None, affine=None, want_stats=False):
+def conv3x3(xs, weight, bias=None, affine=None, want_stats=False, alpha=0.0, relu_out=0, resid=None):
     """xs: list of NHWC tensors (virtual concat); weight [N, sum C, 3, 3] fp32; affine=(scale, shift, relu)
-    applies to a single source.  Returns (out NHWC, stats[rows,2,Npad] or None)."""
+    applies to a single source; out = [relu](alpha*(conv + bias) + resid).  Returns (out NHWC, stats[rows,2,Npad] or None)."""
     dtype = xs[0].dtype
     B, H, W, _ = xs[0].shape
     N = weight.shape[0]
@@ -44,7 +44,8 @@ def conv3x3(xs, weight, bias=None, affine=None, want_stats=False):
     if affine is not None:
         srcs[0].scale, srcs[0].shift, srcs[0].relu = affine
     out = torch.empty((B, H, W, N), dtype=dtype, device=xs[0].device)
-    d, table = make_conv(srcs, [(out, N, 0, 0, N, 0)], out, bias, None, B, H, W, H, W, 3, 3, 1, 1, N, dtype)
+    d, table = make_conv(srcs, [(out, N, 0, 0, N, 0)], out, bias, None, B, H, W, H, W, 3, 3, 1, 1, N, dtype,
+                         alpha=alpha, relu_out=relu_out, resid=None if resid is None else (resid, resid.shape[3]))
     wpk = _pack(weight.contiguous(), table, 9, N, N, 9, Ktot * 9, 0, 1, 0, dtype)
     d.wpk = wpk.data_ptr()
     stats = None
@@ -215,3 +216,91 @@ def attention_backward(qkv, out, lse, dout, B, N, H, D=64):
     _lib.check(_lib.load().ksmi_attention_backward(qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), dout.data_ptr(), dqkv.data_ptr(),
                                                    B, N, H, D, D ** -0.5, DT[qkv.dtype], stream_ptr()), "attention_backward")
     return dqkv
+
+
+# ---------------------------------------------------------------------------------------------------
+# ChangeFormer glue ops (cformer.hip)
+# ---------------------------------------------------------------------------------------------------
+def im2col(x, KH, KW, stride, pad, nchw_image=False, dtype=None):
+    """x NHWC (or the NCHW fp32 image) -> col [B, Ho, Wo, Kpad], k = c*KH*KW + tap."""
+    if nchw_image:
+        B, Cin, H, W = x.shape
+    else:
+        B, H, W, Cin = x.shape
+        dtype = x.dtype
+    Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+    kc = 32 if dtype == torch.bfloat16 else 16
+    Kpad = -(-(Cin * KH * KW) // kc) * kc
+    out = torch.empty((B, Ho, Wo, Kpad), dtype=dtype, device=x.device)
+    _lib.check(_lib.load().ksmi_im2col(x.data_ptr(), out.data_ptr(), B, Cin, H, W, Ho, Wo, KH, KW, stride, pad, Kpad,
+                                       1 if nchw_image else 0, DT[dtype], stream_ptr()), "im2col")
+    return out
+
+
+def col2im(dcol, Cin, H, W, KH, KW, stride, pad, out=None):
+    B, Ho, Wo, Kpad = dcol.shape
+    acc = 0 if out is None else 1
+    if out is None:
+        out = torch.empty((B, H, W, Cin), dtype=dcol.dtype, device=dcol.device)
+    _lib.check(_lib.load().ksmi_col2im(dcol.data_ptr(), out.data_ptr(), acc, B, Cin, H, W, Ho, Wo, KH, KW, stride, pad, Kpad,
+                                       DT[dcol.dtype], stream_ptr()), "col2im")
+    return out
+
+
+def dwconv3x3_gelu(x, weight, bias):
+    B, H, W, Cc = x.shape
+    z, g = torch.empty_like(x), torch.empty_like(x)
+    _lib.check(_lib.load().ksmi_dwconv3x3_gelu_forward(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), z.data_ptr(), g.data_ptr(),
+                                                       B, H, W, Cc, DT[x.dtype], stream_ptr()), "dwconv_fwd")
+    return z, g
+
+
+def dwconv3x3_backward(x, dz, weight):
+    """(dx, dweight [C,1,3,3], dbias [C]) of z = depthwise3x3(x) + b given dz."""
+    B, H, W, Cc = x.shape
+    lib = _lib.load()
+    dx = torch.empty_like(x)
+    _lib.check(lib.ksmi_dwconv3x3_backward_input(dz.data_ptr(), weight.data_ptr(), dx.data_ptr(), B, H, W, Cc, DT[x.dtype], stream_ptr()), "dwconv_bwd")
+    rows = max(1, min(256, B * H * W // 64))
+    partial = torch.empty((rows, 10 * Cc), dtype=torch.float32, device=x.device)
+    _lib.check(lib.ksmi_dwconv3x3_wgrad(x.data_ptr(), dz.data_ptr(), partial.data_ptr(), rows, B, H, W, Cc, DT[x.dtype], stream_ptr()), "dwconv_wgrad")
+    dw = torch.empty((Cc, 1, 3, 3), dtype=torch.float32, device=x.device)
+    db = torch.empty(Cc, dtype=torch.float32, device=x.device)
+    _lib.check(lib.ksmi_reduce_rows(partial.data_ptr(), rows, 1, 10 * Cc, 9 * Cc, None, None, dw.data_ptr(), 0, stream_ptr()), "reduce_rows")
+    _lib.check(lib.ksmi_reduce_rows(partial.data_ptr() + 9 * Cc * 4, rows, 1, 10 * Cc, Cc, None, None, db.data_ptr(), 0, stream_ptr()), "reduce_rows")
+    return dx, dw, db
+
+
+def sr_attention(q, kv, B, Nq, Nk, heads):
+    Cc = q.shape[1]
+    out = torch.empty_like(q)
+    _lib.check(_lib.load().ksmi_sr_attention_forward(q.data_ptr(), kv.data_ptr(), out.data_ptr(), B, Nq, Nk, heads, Cc,
+                                                     (Cc // heads) ** -0.5, DT[q.dtype], stream_ptr()), "sr_attention_fwd")
+    return out
+
+
+def sr_attention_backward(q, kv, dout, B, Nq, Nk, heads):
+    Cc = q.shape[1]
+    lib = _lib.load()
+    ws = torch.empty(lib.ksmi_sr_attention_bwd_workspace(B, Nq, Nk, heads, Cc), dtype=torch.uint8, device=q.device)
+    dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+    _lib.check(lib.ksmi_sr_attention_backward(q.data_ptr(), kv.data_ptr(), dout.data_ptr(), dq.data_ptr(), dkv.data_ptr(), ws.data_ptr(),
+                                              B, Nq, Nk, heads, Cc, (Cc // heads) ** -0.5, DT[q.dtype], stream_ptr()), "sr_attention_bwd")
+    return dq, dkv
+
+
+def bilinear(x, Ho, Wo, add=None):
+    B, Hi, Wi, Cc = x.shape
+    y = torch.empty((B, Ho, Wo, Cc), dtype=x.dtype, device=x.device)
+    _lib.check(_lib.load().ksmi_bilinear_forward(x.data_ptr(), None if add is None else add.data_ptr(), y.data_ptr(), B, Hi, Wi, Ho, Wo, Cc,
+                                                 DT[x.dtype], stream_ptr()), "bilinear_fwd")
+    return y
+
+
+def bilinear_backward(dy, Hi, Wi, out=None):
+    B, Ho, Wo, Cc = dy.shape
+    acc = 0 if out is None else 1
+    if out is None:
+        out = torch.empty((B, Hi, Wi, Cc), dtype=dy.dtype, device=dy.device)
+    _lib.check(_lib.load().ksmi_bilinear_backward(dy.data_ptr(), out.data_ptr(), acc, B, Hi, Wi, Ho, Wo, Cc, DT[dy.dtype], stream_ptr()), "bilinear_bwd")
+    return out
