@@ -23,9 +23,12 @@ def _numel(shape):
 
 
 class ArenaModule(nn.Module):
-    def _setup_arena(self, pspec):
-        """pspec: OrderedDict key -> shape, in the reference's registration order."""
+    def _setup_arena(self, pspec, bspec=None, ispec=None):
+        """pspec: OrderedDict key -> shape, in the reference's registration order; bspec: fp32 buffers (BatchNorm running
+        statistics); ispec: int64 counters (num_batches_tracked)."""
         self._pspec = OrderedDict(pspec)
+        self._bspec = OrderedDict(bspec or {})
+        self._ispec = OrderedDict(ispec or {})
         self._plans = {}
         self._anchor = None
         self._build_arenas(torch.device("cpu"))
@@ -56,6 +59,21 @@ class ArenaModule(nn.Module):
                 h._parameters[parts[-1]].data = view
             else:
                 h.register_parameter(parts[-1], nn.Parameter(view))
+        boffs, o = OrderedDict(), 0
+        for k, shp in self._bspec.items():
+            boffs[k] = o
+            o += -(-max(_numel(shp), 1) // 4) * 4
+        self._boff = boffs
+        self.flat_buffers = torch.zeros(max(o, 1), dtype=torch.float32, device=device)
+        self._ioff = OrderedDict((k, i) for i, k in enumerate(self._ispec))
+        self.flat_counters = torch.zeros(max(len(self._ispec), 1), dtype=torch.int64, device=device)
+        for key in list(self._bspec) + list(self._ispec):
+            parts = key.split(".")
+            h = self._holder(parts[:-1])
+            view = self._b(key).view(self._bspec[key]) if key in self._bspec else self._c(key).view(())
+            if old is not None:
+                view.copy_(old[key])
+            h._buffers[parts[-1]] = view
         self._plans = {}
 
     def _param_obj(self, key):
@@ -73,9 +91,28 @@ class ArenaModule(nn.Module):
                 return False
         return True
 
+    def _b(self, key):
+        return self.flat_buffers[self._boff[key]:self._boff[key] + _numel(self._bspec[key])]
+
+    def _c(self, key):
+        return self.flat_counters[self._ioff[key]:self._ioff[key] + 1]
+
+    def _buffer_obj(self, key):
+        parts = key.split(".")
+        mod = self
+        for part in parts[:-1]:
+            mod = mod._modules[part]
+        return mod._buffers[parts[-1]]
+
     def _ensure_arena(self):
-        if not self._arena_ok():
+        ok = self._arena_ok()
+        if ok and self._bspec:
+            k0 = next(iter(self._bspec))
+            b = self._buffer_obj(k0)
+            ok = b.device == self.flat_buffers.device and b.data_ptr() == self.flat_buffers.data_ptr() + 4 * self._boff[k0]
+        if not ok:
             old = {k: self._param_obj(k).detach().clone() for k in self._pspec}
+            old.update({k: self._buffer_obj(k).detach().clone() for k in list(self._bspec) + list(self._ispec)})
             self._build_arenas(self._param_obj(next(iter(self._pspec))).device, old)
 
     def _p(self, key):

@@ -1,0 +1,210 @@
+"""Shared machinery of the static launch plans (FloodViT, ChangeFormer): scratch bookkeeping, weight packing, the
+launch-list wrappers around ksmi_conv_forward / ksmi_conv_wgrad for nn.Linear, nn.LayerNorm and ConvTranspose2d(k4,s2,p1)."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .runtime import DT, SrcSpec, make_conv, make_pack, make_wgrad, packed_weight_numel
+from .snunet_plan import LaunchList
+
+LN_EPS = 1e-5
+
+
+class PlanBase:
+    def _init_base(self, model, dtype, with_backward):
+        self.m, self.dtype, self.with_backward = model, dtype, with_backward
+        self.dev = model.flat_params.device
+        self.dt = DT[dtype]
+        self.lib = _lib.load()
+        self.packs, self.fwd, self.bwd = LaunchList(), LaunchList(), LaunchList()
+        self.keep, self._pack_descs, self._pinit = [], [], set()
+        self.param_ready = {}
+        self.named = {}            # debug/test access to intermediate activations
+        self._need, self._bufs, self._later = {}, {}, []
+
+    def _finish(self):
+        if self._pack_descs:
+            n = len(self._pack_descs)
+            arr = (_lib.PackDesc * n)(*self._pack_descs)
+            raw = bytes(C.string_at(C.addressof(arr), C.sizeof(arr)))
+            table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.dev)
+            self.keep.append(table)
+            self.packs.add("ksmi_pack_weights_batched", lambda: (table.data_ptr(), n, self.dt),
+                           {"kind": "pack_weights", "bytes": 0, "flops": 0})
+        for name, nbytes in self._need.items():
+            self._bufs[name] = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.dev)
+        for fn in self._later:
+            fn()
+        for ll in (self.packs, self.fwd, self.bwd):
+            ll.resolve(self.lib)
+
+    # ---------------------------------------------------------------- small helpers
+    def need(self, name, nbytes):
+        self._need[name] = max(self._need.get(name, 0), int(nbytes))
+
+    def scr(self, name):
+        return self._bufs[name].data_ptr()
+
+    def buf(self, *shape):
+        t = torch.zeros(shape, dtype=self.dtype, device=self.dev)
+        self.keep.append(t)
+        return t
+
+    def fbuf(self, *shape):
+        t = torch.zeros(shape, dtype=torch.float32, device=self.dev)
+        self.keep.append(t)
+        return t
+
+    def _es(self):
+        return 2 if self.dtype == torch.bfloat16 else 4
+
+    def _acc_param(self, key):
+        acc = 1 if key in self._pinit else 0
+        self._pinit.add(key)
+        return acc
+
+    def _mark(self, *keys):
+        for k in keys:
+            self.param_ready[k] = len(self.bwd.pending) - 1
+
+    def _packed(self, key, table, taps, N, n_mod, sK, sN, sD, sT, flip=0, tap_map=None):
+        Npad = (N + 15) // 16 * 16
+        out = torch.empty(packed_weight_numel(table, taps, Npad, self.dtype), dtype=self.dtype, device=self.dev)
+        d = make_pack(self.m._p(key), out, table, taps, N, Npad, n_mod, sK, sN, sD, sT, flip, tap_map)
+        self.keep += [d, out]
+        self._pack_descs.append(d)
+        return out
+
+    def _conv(self, ll, d, tag, name=""):
+        self.keep.append(d)
+        taps, es = d.KH * d.KW, self._es()
+        ktot = sum(d.src[i].c_len for i in range(d.nsrc))
+        pin, pout = d.B * d.Hin * d.Win, d.B * d.Hout * d.Wout
+        elems = pin * ktot + sum(pout * d.dst[i].n_len * (2 if d.dst[i].accumulate else 1) for i in range(d.ndst))
+        if d.mask_src:
+            elems += pout * d.N
+        meta = {"kind": f"igemm_{tag}<{d.KH}x{d.KW}s{d.stride}>", "bytes": elems * es + taps * ktot * d.N * es,
+                "flops": 2 * pout * d.N * ktot * taps, "tag": f"{name} K={ktot} N={d.N} M={pout}"}
+        ll.add("ksmi_conv_forward", lambda: (C.byref(d), self.dt), meta)
+
+    def _wgrad(self, d, ws, key):
+        self.keep.append(d)
+        self.need("wgrad", ws)
+        self._later.append(lambda: setattr(d, "partial", self.scr("wgrad")))
+        taps, es = d.KH * d.KW, self._es()
+        ktot = sum(d.src[i].c_len for i in range(d.nsrc))
+        pin, pout = d.B * d.Hin * d.Win, d.B * d.Hout * d.Wout
+        meta = {"kind": f"igemm_wgrad<{d.KH}x{d.KW}s{d.stride}>", "bytes": (pin * ktot + pout * d.N) * es + taps * ktot * d.N * 4,
+                "flops": 2 * pout * d.N * ktot * taps, "tag": f"{key} K={ktot} N={d.N} M={pout}"}
+        self.bwd.add("ksmi_conv_wgrad", lambda: (C.byref(d), self.dt), meta)
+        self._mark(key)
+
+    def _elt_meta(self, kind, nelem_rw):
+        return {"kind": kind, "bytes": int(nelem_rw) * self._es(), "flops": 0}
+
+    # ---------------------------------------------------------------- nn.Linear on token rows
+    def _linear(self, name, x, Cin, wkey, bkey, out, N, rows, resid=None, k_real=None):
+        """out[rows, N] = x[rows, Cin] @ W[N, k_real]^T + b [+ resid]; columns of x beyond k_real (default Cin) are zero padding."""
+        kr = Cin if k_real is None else k_real
+        d, table = make_conv([SrcSpec(x, Cin, k_real=kr)], [(out, N, 0, 0, N, 0)], out, self.m._p(bkey) if bkey else None, None,
+                             1, rows, 1, rows, 1, 1, 1, 1, 0, N, self.dtype, resid=None if resid is None else (resid, N))
+        d.wpk = self._packed(wkey, table, 1, N, N, 1, kr, 0, 0).data_ptr()
+        self._conv(self.fwd, d, "linear", name)
+
+    def _bias_grad(self, dy, rows, N, bkey):
+        r = max(1, min(512, rows // 64))
+        self.need("red", r * N * 4)
+        acc = self._acc_param(bkey)
+        gb = self.m._g(bkey).data_ptr()
+        self.bwd.add("ksmi_channel_sum", lambda: (dy.data_ptr(), self.scr("red"), r, rows, N, self.dt),
+                     self._elt_meta("channel_sum", rows * N))
+        self.bwd.add("ksmi_reduce_rows", lambda: (self.scr("red"), r, 1, N, N, None, None, gb, acc))
+        self._mark(bkey)
+
+    def _linear_bwd(self, name, x, Cin, wkey, bkey, dy, N, rows, dx, want_w=True, dx_acc=0, k_real=None):
+        """dx (+)= dy @ W (skipped if dx is None) ; dW = dy^T x ; db = colsum(dy)"""
+        kr = Cin if k_real is None else k_real
+        if dx is not None:
+            d, table = make_conv([SrcSpec(dy, N)], [(dx, Cin, 0, 0, Cin, dx_acc)], dx, None, None,
+                                 1, rows, 1, rows, 1, 1, 1, 1, 0, Cin, self.dtype)
+            d.wpk = self._packed(wkey, table, 1, Cin, Cin, Cin, 1, 0, 0).data_ptr()
+            self._conv(self.bwd, d, "linear_dgrad", name)
+        if want_w:
+            dw, ws = make_wgrad([SrcSpec(x, Cin, k_real=kr)], dy, N, 0, N, self.m._g(wkey), 1, kr, 0, self._acc_param(wkey),
+                                1, rows, 1, rows, 1, 1, 1, 1, 0, self.dtype)
+            self._wgrad(dw, ws, wkey)
+            if bkey:
+                self._bias_grad(dy, rows, N, bkey)
+
+    # ---------------------------------------------------------------- nn.LayerNorm
+    def _ln(self, x, wkey, bkey, y, rows, Cc, eps=LN_EPS):
+        st = self.fbuf(2, rows)
+        g, b = self.m._p(wkey).data_ptr(), self.m._p(bkey).data_ptr()
+        self.fwd.add("ksmi_layernorm_forward", lambda: (x.data_ptr(), g, b, y.data_ptr(), st[0].data_ptr(), st[1].data_ptr(),
+                                                        rows, Cc, eps, self.dt), self._elt_meta("layernorm_fwd", 2 * rows * Cc))
+        return st
+
+    def _ln_bwd(self, dy, x, st, wkey, bkey, dx, accumulate, rows, Cc, want_w=True):
+        nblk = self.lib.ksmi_layernorm_bwd_blocks(rows)
+        self.need("lnp", nblk * 2 * Cc * 4)
+        g = self.m._p(wkey).data_ptr()
+        self.bwd.add("ksmi_layernorm_backward", lambda: (dy.data_ptr(), x.data_ptr(), st[0].data_ptr(), st[1].data_ptr(), g,
+                                                         dx.data_ptr(), accumulate, self.scr("lnp"), rows, Cc, self.dt),
+                     self._elt_meta("layernorm_bwd", (3 + accumulate) * rows * Cc))
+        if want_w:
+            a1, a2 = self._acc_param(wkey), self._acc_param(bkey)
+            assert a1 == a2
+            gw, gb = self.m._g(wkey).data_ptr(), self.m._g(bkey).data_ptr()
+            self.bwd.add("ksmi_reduce_rows", lambda: (self.scr("lnp"), nblk, 2, Cc, Cc, None, gw, gb, a1))
+            self._mark(wkey, bkey)
+
+    # ---------------------------------------------------------------- ConvTranspose2d(k4, s2, p1)
+    def _deconv(self, name, x, Cin, N, H, W, out, outC, prefix="head.", suffix="", B=None):
+        """out[B,2H,2W,outC][..., :N] = ConvTranspose2d(x) + bias as 4 phase convolutions with 2x2 taps:
+        out[2m+py] = sum_a x[m - pad + a] * W[ky],  pad = 1 - py,  ky = (3 - 2a) if py == 0 else (2 - 2a)."""
+        wkey, bkey = f"{prefix}{name}{suffix}.weight", f"{prefix}{name}{suffix}.bias"
+        B = self.B if B is None else B
+        for py in range(2):
+            for px in range(2):
+                tap_map = []
+                for a in range(2):
+                    for b in range(2):
+                        ky = 3 - 2 * a if py == 0 else 2 - 2 * a
+                        kx = 3 - 2 * b if px == 0 else 2 - 2 * b
+                        tap_map.append(ky * 4 + kx)
+                d, table = make_conv([SrcSpec(x, Cin)], [(out, outC, 0, 0, N, 0)], out, self.m._p(bkey), None,
+                                     B, H, W, H, W, 2, 2, 1, 1 - py, N, self.dtype, pad_x=1 - px,
+                                     out_map=(2, 2, py, px, 2 * H, 2 * W))
+                # Wt[c][n][ky][kx]: k = c, column = n
+                d.wpk = self._packed(wkey, table, 4, N, N, N * 16, 16, 0, 1, 0, tap_map).data_ptr()
+                self._conv(self.fwd, d, "deconv_phase", f"{name}.p{py}{px}")
+
+    def _deconv_bwd(self, name, x, Cin, N, H, W, dout, doutC, dx, mask=None, prefix="head.", suffix="", B=None, stats=None):
+        """dout [B,2H,2W,doutC] (first N channels real).  dx[B,H,W,Cin] = 4x4 stride-2 conv of dout (optionally
+        ReLU-masked by `mask`), dW via the stride-2 weight-gradient GEMM, db = channel sums."""
+        wkey, bkey = f"{prefix}{name}{suffix}.weight", f"{prefix}{name}{suffix}.bias"
+        B = self.B if B is None else B
+        src = [SrcSpec(dout, doutC, 0, doutC, k_real=N)]
+        if dx is not None:
+            mk = None
+            if mask is not None:
+                mk = (mask, self.const[0], self.const[1], self.const[1], self.const[0])
+            d, table = make_conv(src, [(dx, Cin, 0, 0, Cin, 0)], dx, None, None, B, 2 * H, 2 * W, H, W, 4, 4, 2, 1, Cin,
+                                 self.dtype, mask=mk)
+            d.wpk = self._packed(wkey, table, 16, Cin, Cin, 16, N * 16, 0, 1, 0).data_ptr()
+            self._conv(self.bwd, d, "deconv_dgrad", name)
+        dw, ws = make_wgrad(src, x, Cin, 0, Cin, self.m._g(wkey), 16, N * 16, 1, self._acc_param(wkey),
+                            B, 2 * H, 2 * W, H, W, 4, 4, 2, 1, self.dtype)
+        self._wgrad(dw, ws, wkey)
+        # bias gradient over the real channels only
+        rows = B * 4 * H * W
+        r = max(1, min(512, rows // 256))
+        self.need("red", r * doutC * 4)
+        acc = self._acc_param(bkey)
+        gb = self.m._g(bkey).data_ptr()
+        self.bwd.add("ksmi_channel_sum", lambda: (dout.data_ptr(), self.scr("red"), r, rows, doutC, self.dt),
+                     self._elt_meta("channel_sum", rows * doutC))
+        self.bwd.add("ksmi_reduce_rows", lambda: (self.scr("red"), r, 1, doutC, N, None, None, gb, acc))
+        self._mark(bkey)
+

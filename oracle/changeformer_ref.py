@@ -190,10 +190,19 @@ def encoder_features(sd, x, inter=None):
     return outs
 
 
-def _conv_diff(sd, key, x, training, new_stats):
-    x = F.relu(F.conv2d(x, sd[f"{key}.0.weight"], sd[f"{key}.0.bias"], padding=1))
+def _relu(x, masks, name):
+    """ReLU, or x * mask when the caller pins the active set (GPU parity tests: a pre-activation within rounding distance of
+    0 may land on either side on another device and the backward comparison must use the same active set)."""
+    if masks is None or name not in masks:
+        return F.relu(x)
+    return x * masks[name]
+
+
+def _conv_diff(sd, key, x, training, new_stats, masks=None):
+    name = key.split(".")[-1]
+    x = _relu(F.conv2d(x, sd[f"{key}.0.weight"], sd[f"{key}.0.bias"], padding=1), masks, f"{name}.0")
     x = _bn(sd, f"{key}.2", x, training, new_stats)
-    return F.relu(F.conv2d(x, sd[f"{key}.3.weight"], sd[f"{key}.3.bias"], padding=1))
+    return _relu(F.conv2d(x, sd[f"{key}.3.weight"], sd[f"{key}.3.bias"], padding=1), masks, f"{name}.3")
 
 
 def _make_pred(sd, key, x, training, new_stats):
@@ -202,13 +211,13 @@ def _make_pred(sd, key, x, training, new_stats):
     return F.conv2d(x, sd[f"{key}.3.weight"], sd[f"{key}.3.bias"], padding=1)
 
 
-def _res_block(sd, key, x):
-    out = F.relu(F.conv2d(x, sd[f"{key}.conv1.conv2d.weight"], sd[f"{key}.conv1.conv2d.bias"], padding=1))
+def _res_block(sd, key, x, masks=None):
+    out = _relu(F.conv2d(x, sd[f"{key}.conv1.conv2d.weight"], sd[f"{key}.conv1.conv2d.bias"], padding=1), masks, key.split(".")[1])
     out = F.conv2d(out, sd[f"{key}.conv2.conv2d.weight"], sd[f"{key}.conv2.conv2d.bias"], padding=1) * 0.1
     return out + x
 
 
-def decoder(sd, f1, f2, training=False, new_stats=None, decoder_softmax=True, inter=None):
+def decoder(sd, f1, f2, training=False, new_stats=None, decoder_softmax=True, inter=None, masks=None):
     D = "TDec_x2"
     size1 = f1[0].shape[2:]
     outputs, ups, prev = [], [], None
@@ -219,7 +228,7 @@ def decoder(sd, f1, f2, training=False, new_stats=None, decoder_softmax=True, in
         def lin(t):
             y = F.linear(t.flatten(2).transpose(1, 2), sd[f"{D}.linear_c{i}.proj.weight"], sd[f"{D}.linear_c{i}.proj.bias"])
             return y.permute(0, 2, 1).reshape(n, -1, h, w)
-        c = _conv_diff(sd, f"{D}.diff_c{i}", torch.cat((lin(a), lin(b)), dim=1), training, new_stats)
+        c = _conv_diff(sd, f"{D}.diff_c{i}", torch.cat((lin(a), lin(b)), dim=1), training, new_stats, masks)
         if prev is not None:
             c = c + F.interpolate(prev, scale_factor=2, mode="bilinear")
         outputs.append(_make_pred(sd, f"{D}.make_pred_c{i}", c, training, new_stats))
@@ -232,18 +241,18 @@ def decoder(sd, f1, f2, training=False, new_stats=None, decoder_softmax=True, in
     if inter is not None:
         inter["fuse"] = x
     x = F.conv_transpose2d(x, sd[f"{D}.convd2x.conv2d.weight"], sd[f"{D}.convd2x.conv2d.bias"], stride=2, padding=1)
-    x = _res_block(sd, f"{D}.dense_2x.0", x)
+    x = _res_block(sd, f"{D}.dense_2x.0", x, masks)
     if inter is not None:
         inter["dense_2x"] = x
     x = F.conv_transpose2d(x, sd[f"{D}.convd1x.conv2d.weight"], sd[f"{D}.convd1x.conv2d.bias"], stride=2, padding=1)
-    x = _res_block(sd, f"{D}.dense_1x.0", x)
+    x = _res_block(sd, f"{D}.dense_1x.0", x, masks)
     if inter is not None:
         inter["dense_1x"] = x
     outputs.append(F.conv2d(x, sd[f"{D}.change_probability.conv2d.weight"], sd[f"{D}.change_probability.conv2d.bias"], padding=1))
     return [torch.sigmoid(o) for o in outputs] if decoder_softmax else outputs
 
 
-def changeformer_forward(sd, x1, x2, training=False, new_stats=None, decoder_softmax=True, inter=None):
+def changeformer_forward(sd, x1, x2, training=False, new_stats=None, decoder_softmax=True, inter=None, masks=None):
     """Returns the list of 5 outputs [(B,3,7,7), (B,3,14,14), (B,3,28,28), (B,3,56,56), (B,3,224,224)] (for 224x224 input)."""
     i1 = {} if inter is not None else None
     i2 = {} if inter is not None else None
@@ -253,15 +262,15 @@ def changeformer_forward(sd, x1, x2, training=False, new_stats=None, decoder_sof
         inter.update({f"B.{k}": v for k, v in i2.items()})
         for i in range(4):
             inter[f"A.f{i + 1}"], inter[f"B.f{i + 1}"] = f1[i], f2[i]
-    return decoder(sd, f1, f2, training, new_stats, decoder_softmax, inter)
+    return decoder(sd, f1, f2, training, new_stats, decoder_softmax, inter, masks)
 
 
-def loss_and_grads(sd, x1, x2, labels, weights=(1.0, 1.0, 1.0), with_dice=True):
+def loss_and_grads(sd, x1, x2, labels, weights=(1.0, 1.0, 1.0), with_dice=True, masks=None):
     """One train-mode forward/backward with the reference's CD criterion on output[-1] (cd_trainer:138-166)."""
     from .snunet_ref import torch_ce_dice
     params = {k: (v.detach().clone().requires_grad_(True) if not is_buffer(k) else v) for k, v in sd.items()}
     new_stats = {}
-    outs = changeformer_forward(params, x1, x2, training=True, new_stats=new_stats)
+    outs = changeformer_forward(params, x1, x2, training=True, new_stats=new_stats, masks=masks)
     loss = torch_ce_dice(outs[-1], labels, weights, with_dice)
     total = loss[0] if isinstance(loss, (tuple, list)) else loss
     total.backward()

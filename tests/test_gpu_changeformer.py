@@ -1,0 +1,153 @@
+"""GPU parity of the ChangeFormerV6 path (kurosiwo_amd/changeformer.py) against the CPU oracle (oracle/changeformer_ref.py)
+and the golden vectors generated from the real reference (tests/golden/changeformer.npz)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+CLASS_WEIGHTS = [0.3715753140309927, 14.009780283125977, 8.20405370357821]
+
+
+def sar_like(name, shape):
+    from oracle.seeded import seeded_tensor
+    return seeded_tensor(name, shape).clamp_(-2.23, 5.75)
+
+
+def build(precision):
+    from kurosiwo_amd.changeformer import ChangeFormerV6
+    from oracle import changeformer_ref as R
+    from oracle.seeded import seeded_fill_
+    model = ChangeFormerV6(2, 3, decoder_softmax=True, embed_dim=256, precision=precision)
+    sd = seeded_fill_(R.new_state_dict(2, 3, 256))
+    assert list(model.state_dict().keys()) == list(sd.keys())
+    model.load_state_dict(sd)
+    return model.cuda(), sd
+
+
+def relerr(a, b):
+    return float((a.float() - b.float()).abs().max() / (b.float().abs().max() + 1e-12))
+
+
+def tok(t, B):          # [2B*hw, C] tokens -> date-1 half as [B, hw, C]
+    t = t.float().cpu()
+    return t.reshape(2 * B, -1, t.shape[-1])[:B]
+
+
+def nchw(t, B, h, w):
+    return t.float().cpu().reshape(B, h, w, -1).permute(0, 3, 1, 2)
+
+
+def compare_intermediates(plan, inter, B, tol):
+    errs = {}
+    for st in range(4):
+        errs[f"pe{st + 1}"] = relerr(tok(plan.named[f"pe{st + 1}"], B), inter[f"A.pe{st + 1}"])
+        last = f"s{st + 1}b{[3, 3, 4, 3][st] - 1}"
+        errs[last] = relerr(tok(plan.named[last], B), inter[f"A.{last}"])
+        h = 56 >> st
+        errs[f"f{st + 1}"] = relerr(nchw(plan.named[f"f{st + 1}"][:B * h * h], B, h, h), inter[f"A.f{st + 1}"])
+        errs[f"fB{st + 1}"] = relerr(nchw(plan.named[f"f{st + 1}"][B * h * h:], B, h, h), inter[f"B.f{st + 1}"])
+    for i, h in ((4, 7), (3, 14), (2, 28), (1, 56)):
+        errs[f"c{i}"] = relerr(nchw(plan.named[f"c{i}"], B, h, h), inter[f"c{i}"])
+    errs["fuse"] = relerr(nchw(plan.named["fuse"], B, 56, 56), inter["fuse"])
+    errs["dense_2x"] = relerr(nchw(plan.named["dense_2x"], B, 112, 112), inter["dense_2x"])
+    errs["dense_1x"] = relerr(nchw(plan.named["dense_1x"], B, 224, 224), inter["dense_1x"])
+    bad = {k: v for k, v in errs.items() if not v < tol}
+    assert not bad, errs
+
+
+def test_eval_forward_vs_oracle_and_golden(golden_dir):
+    from oracle import changeformer_ref as R
+    gold = np.load(os.path.join(golden_dir, "changeformer.npz"))
+    model, sd = build("fp32")
+    model.eval()
+    x1 = sar_like("changeformer.eval.x1", (1, 2, 224, 224))
+    x2 = sar_like("changeformer.eval.x2", (1, 2, 224, 224))
+    inter = {}
+    with torch.no_grad():
+        ref = R.changeformer_forward(sd, x1, x2, training=False, inter=inter)
+        outs = model(x1.cuda(), x2.cuda())
+    compare_intermediates(model.plan(1, 224, 224, False, False), inter, 1, 5e-4)
+    assert [tuple(o.shape) for o in outs] == [(1, 3, 7, 7), (1, 3, 14, 14), (1, 3, 28, 28), (1, 3, 56, 56), (1, 3, 224, 224)]
+    for i in range(5):
+        assert float((outs[i].cpu() - ref[i]).abs().max()) < 1e-3            # north_star: 1e-3 on the outputs (sigmoid maps)
+    for i in range(4):
+        assert np.abs(outs[i].cpu().numpy() - gold[f"eval.out{i}"]).max() < 1e-3
+    assert np.abs(outs[4].cpu()[:, :, ::8, ::8].numpy() - gold["eval.out4_sub"]).max() < 1e-3
+    confident = gold["eval.margin"].astype(np.float32) > 2e-3
+    assert (outs[4].argmax(1).cpu().numpy().astype(np.uint8) == gold["eval.argmax"])[confident].all()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_train_forward_backward_vs_oracle(golden_dir, precision):
+    from oracle import changeformer_ref as R
+    from oracle.seeded import seeded_labels
+    gold = np.load(os.path.join(golden_dir, "changeformer.npz"))
+    B = 2
+    model, sd = build(precision)
+    model.train()
+    x1 = sar_like("changeformer.train.x1", (B, 2, 224, 224))
+    x2 = sar_like("changeformer.train.x2", (B, 2, 224, 224))
+    lbl = seeded_labels("changeformer.train.lbl", (B, 224, 224))
+    outs = model(x1.cuda(), x2.cuda())
+    plan = model.plan(B, 224, 224, True, True)
+    inter = {}
+    with torch.no_grad():
+        ref = R.changeformer_forward(sd, x1, x2, training=True, inter=inter)
+    compare_intermediates(plan, inter, B, 5e-4 if precision == "fp32" else 0.15)
+    for i in range(5):
+        err = (outs[i].detach().cpu() - ref[i]).abs()
+        if precision == "fp32":
+            assert float(err.max()) < 1e-3, i
+        else:       # bf16 storage through 13 blocks + BatchNorm over as few as 98 pixels: bound the mean, sanity-bound the max
+            assert float(err.mean()) < 2e-2 and float(err.max()) < 0.25, (i, float(err.mean()), float(err.max()))
+    if precision == "fp32":
+        assert np.abs(outs[4].detach().cpu()[:, :, ::8, ::8].numpy() - gold["train.out4_sub"]).max() < 1e-3
+    # BatchNorm running statistics after the step
+    msd = model.state_dict()
+    for k in ("TDec_x2.diff_c4.2", "TDec_x2.diff_c1.2", "TDec_x2.make_pred_c2.2", "TDec_x2.linear_fuse.1"):
+        rt = 1e-3 if precision == "fp32" else 5e-2
+        assert np.abs(msd[f"{k}.running_mean"].cpu().numpy() - gold[f"bn.{k}.running_mean"]).max() < rt * max(1.0, np.abs(gold[f"bn.{k}.running_mean"]).max())
+        assert np.abs(msd[f"{k}.running_var"].cpu().numpy() - gold[f"bn.{k}.running_var"]).max() < rt * max(1.0, float(gold[f"bn.{k}.running_var"].max()))
+        assert int(msd[f"{k}.num_batches_tracked"]) == 1
+    # backward on output[-1] with the reference's CD criterion; the oracle uses the GPU's ReLU active sets
+    from kurosiwo_amd.loss import BCEandDiceLoss
+    crit = BCEandDiceLoss(weights=CLASS_WEIGHTS, ignore_index=3, use_softmax=True)
+    loss = crit(outs[-1], lbl.cuda())
+    loss.backward()
+    masks = {}
+    for i, h in ((4, 7), (3, 14), (2, 28), (1, 56)):
+        sc = plan.scales[i]
+        masks[f"diff_c{i}.0"] = (nchw(sc["r1"], B, h, h) > 0).float()
+        masks[f"diff_c{i}.3"] = (nchw(sc["r2"], B, h, h) > 0).float()
+    masks["dense_2x"] = (nchw(plan.dec["Ra"], B, 112, 112) > 0).float()
+    masks["dense_1x"] = (nchw(plan.dec["Rb"], B, 224, 224) > 0).float()
+    _, ref_loss, ref_grads, _ = R.loss_and_grads(sd, x1, x2, lbl, CLASS_WEIGHTS, True, masks=masks)
+    assert abs(float(loss) - ref_loss) < (2e-4 if precision == "fp32" else 3e-2)
+    if precision == "fp32":
+        assert abs(float(loss) - float(gold["train.loss"])) < 2e-4
+    worst, coss = {}, []
+    for k, p in model.named_parameters():
+        g, r = p.grad.detach().float().cpu(), ref_grads[k]
+        if float(r.abs().max()) == 0.0:
+            assert float(g.abs().max()) == 0.0, k
+            continue
+        if k == "TDec_x2.linear_fuse.0.bias":
+            # a conv bias followed directly by BatchNorm has an analytically zero gradient: both sides hold rounding noise
+            assert float(g.abs().max()) < (1e-5 if precision == "fp32" else 1e-2), k
+            continue
+        if precision == "fp32":
+            e = float((g - r).abs().max() / (r.abs().max() + 1e-12))
+            l2 = float((g - r).double().norm() / (r.double().norm() + 1e-30))
+            if not (l2 < 2e-3 and e < 5e-3):
+                worst[k] = (e, l2)
+        else:
+            cos = float((g.double() * r.double()).sum() / (g.double().norm() * r.double().norm() + 1e-30))
+            coss.append(cos)
+            if not cos > 0.94:
+                worst[k] = cos
+    if coss:
+        assert float(np.median(coss)) > 0.99, float(np.median(coss))
+    assert not worst, f"{precision}: {len(worst)} params: {dict(list(worst.items())[:12])}"
