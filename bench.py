@@ -90,9 +90,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--model", default="snunet", choices=["snunet", "floodvit"],
-                    help="snunet = BASELINE.json configs[1] (the headline); floodvit = configs[4] per-GPU shard (bs 16)")
-    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (weak scaling); default 32 snunet / 16 floodvit")
+    ap.add_argument("--model", default="snunet", choices=["snunet", "floodvit", "changeformer"],
+                    help="snunet = BASELINE.json configs[1] (the headline); changeformer = configs[3] (bs 32); "
+                         "floodvit = configs[4] per-GPU shard (bs 16)")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (weak scaling); default 32 snunet/changeformer, 16 floodvit")
     ap.add_argument("--base-channel", type=int, default=32)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--time-all", action="store_true", help="HIP-event time every kernel class (diagnostic)")
@@ -113,7 +114,7 @@ def main():
 
     from kurosiwo_amd.synthetic import cd_inputs, make_batch, seg_inputs
 
-    B, H, W = args.batch or (32 if args.model == "snunet" else 16), 224, 224
+    B, H, W = args.batch or (16 if args.model == "floodvit" else 32), 224, 224
     torch.manual_seed(999)                      # same init on every rank (reference default seed, main.py:36)
     batch = make_batch(B, H, W, seed=999 + rank)
     if args.model == "snunet":
@@ -126,6 +127,18 @@ def main():
         workload = ("BASELINE.json configs[1]: SNUNet-ECAM CD, 2 dates x 2-ch GRD 224x224, "
                     f"per-GPU batch {B}, ce+dice loss, Adam lr 1e-3, fwd+loss+bwd+optimizer")
         metric = "SAR tiles/sec (224x224, SNUNet-ECAM change-detection train step)"
+    elif args.model == "changeformer":
+        from kurosiwo_amd.changeformer import ChangeFormerV6
+        from kurosiwo_amd.optim import FusedSGD
+        from kurosiwo_amd.trainer import CDTrainStep
+        model = ChangeFormerV6(input_nc=2, output_nc=3, decoder_softmax=True, embed_dim=256, precision=args.precision).to(dev).train()
+        opt = FusedSGD(model.parameters(), lr=6e-4, momentum=0.99, weight_decay=1e-5)      # configs/method/changeformer/changeformer.json
+        step = CDTrainStep(model, B, H, W, loss_function="ce+dice", optimizer=opt, bucket_mb=16.0)
+        (xA, xB), mask = cd_inputs(batch, ("pre_event_1", "post_event"))
+        step.set_batch(xA.to(dev), xB.to(dev), mask.to(dev))
+        workload = ("BASELINE.json configs[3]: ChangeFormerV6 CD (embed 256), 2 dates x 2-ch 224x224, "
+                    f"per-GPU batch {B}, ce+dice on the sigmoid map, SGD(0.99, wd 1e-5), fwd+loss+bwd+optimizer")
+        metric = "SAR tiles/sec (224x224, ChangeFormerV6 change-detection train step)"
     else:
         from kurosiwo_amd.floodvit import FinetunerSegmentation, ViT
         from kurosiwo_amd.trainer import SegTrainStep

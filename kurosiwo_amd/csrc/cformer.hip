@@ -196,50 +196,69 @@ __device__ __forceinline__ void load_kv(const T* kv, float* sK, float* sV, int b
   }
 }
 
+// dot product of a register vector with a row of an LDS matrix (16-byte broadcast reads)
+template <int D>
+__device__ __forceinline__ float dot_row(const float* qr, const float* row) {
+  float a = 0.f;
+#pragma unroll
+  for (int d = 0; d < D; d += 4) {
+    const f32x4 k4 = *(const f32x4*)(row + d);
+    a += qr[d] * k4[0] + qr[d + 1] * k4[1] + qr[d + 2] * k4[2] + qr[d + 3] * k4[3];
+  }
+  return a;
+}
+template <int D>
+__device__ __forceinline__ void axpy_row(float* o, float p, const float* row) {
+#pragma unroll
+  for (int d = 0; d < D; d += 4) {
+    const f32x4 v4 = *(const f32x4*)(row + d);
+    o[d] += p * v4[0]; o[d + 1] += p * v4[1]; o[d + 2] += p * v4[2]; o[d + 3] += p * v4[3];
+  }
+}
+
+// forward: one query per thread, keys walked with an online softmax (no per-key register arrays: the fully unrolled
+// 49 x D version spilled kilobytes of scratch per thread)
 template <typename T, int D, int NK>
 __global__ __launch_bounds__(256) void sr_attn_fwd_kernel(const T* q, const T* kv, T* out, int Nq, int C, float scale) {
-  __shared__ float sK[NK * D], sV[NK * D];
+  __shared__ __attribute__((aligned(16))) float sK[NK * D];
+  __shared__ __attribute__((aligned(16))) float sV[NK * D];
   const int b = blockIdx.z, h = blockIdx.y;
   load_kv<T, D, NK>(kv, sK, sV, b, h, C);
   __syncthreads();
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= Nq) return;
   const T* qp = q + ((int64_t)b * Nq + i) * C + h * D;
-  float qr[D];
+  float qr[D], o[D];
 #pragma unroll
-  for (int d = 0; d < D; ++d) qr[d] = ElemTraits<T>::ld(qp + d) * scale;
-  float s[NK];
-  float mx = -3.0e38f;
-#pragma unroll
+  for (int d = 0; d < D; ++d) { qr[d] = ElemTraits<T>::ld(qp + d) * scale; o[d] = 0.f; }
+  float m = -3.0e38f, l = 0.f;
+#pragma unroll 1
   for (int j = 0; j < NK; ++j) {
-    float a = 0.f;
+    const float a = dot_row<D>(qr, sK + j * D);
+    if (a > m) {
+      const float c = __expf(m - a);
+      l *= c;
 #pragma unroll
-    for (int d = 0; d < D; ++d) a += qr[d] * sK[j * D + d];
-    s[j] = a;
-    mx = fmaxf(mx, a);
+      for (int d = 0; d < D; ++d) o[d] *= c;
+      m = a;
+    }
+    const float p = __expf(a - m);
+    l += p;
+    axpy_row<D>(o, p, sV + j * D);
   }
-  float sum = 0.f;
-#pragma unroll
-  for (int j = 0; j < NK; ++j) { s[j] = __expf(s[j] - mx); sum += s[j]; }
-  const float inv = 1.f / sum;
-#pragma unroll
-  for (int d = 0; d < D; ++d) qr[d] = 0.f;
-#pragma unroll
-  for (int j = 0; j < NK; ++j) {
-    const float p = s[j] * inv;
-#pragma unroll
-    for (int d = 0; d < D; ++d) qr[d] += p * sV[j * D + d];
-  }
+  const float inv = 1.f / l;
   T* op = out + ((int64_t)b * Nq + i) * C + h * D;
 #pragma unroll
-  for (int d = 0; d < D; ++d) ElemTraits<T>::st(op + d, qr[d]);
+  for (int d = 0; d < D; ++d) ElemTraits<T>::st(op + d, o[d] * inv);
 }
 
-// backward, pass A (one query per thread): dq ; P and dS (scale folded in) to scratch [B][H][Nq][NK] fp32
+// backward, pass A (one query per thread): dq ; P and dS (scale folded in) to scratch [B][H][Nq][NK] fp32.
+// Three walks over the keys: (1) softmax max / sum, (2) P, dP (parked in the scratch rows) and delta, (3) dS and dq.
 template <typename T, int D, int NK>
 __global__ __launch_bounds__(256) void sr_attn_bwd_q_kernel(const T* q, const T* kv, const T* dout, T* dq, float* Pbuf, float* dSbuf,
                                                             int Nq, int C, int H, float scale) {
-  __shared__ float sK[NK * D], sV[NK * D];
+  __shared__ __attribute__((aligned(16))) float sK[NK * D];
+  __shared__ __attribute__((aligned(16))) float sV[NK * D];
   const int b = blockIdx.z, h = blockIdx.y;
   load_kv<T, D, NK>(kv, sK, sV, b, h, C);
   __syncthreads();
@@ -247,51 +266,42 @@ __global__ __launch_bounds__(256) void sr_attn_bwd_q_kernel(const T* q, const T*
   if (i >= Nq) return;
   const T* qp = q + ((int64_t)b * Nq + i) * C + h * D;
   const T* gp = dout + ((int64_t)b * Nq + i) * C + h * D;
-  float qr[D];
-#pragma unroll
-  for (int d = 0; d < D; ++d) qr[d] = ElemTraits<T>::ld(qp + d) * scale;
-  float s[NK];
-  float mx = -3.0e38f;
-#pragma unroll
-  for (int j = 0; j < NK; ++j) {
-    float a = 0.f;
-#pragma unroll
-    for (int d = 0; d < D; ++d) a += qr[d] * sK[j * D + d];
-    s[j] = a;
-    mx = fmaxf(mx, a);
-  }
-  float sum = 0.f;
-#pragma unroll
-  for (int j = 0; j < NK; ++j) { s[j] = __expf(s[j] - mx); sum += s[j]; }
-  const float inv = 1.f / sum;
-#pragma unroll
-  for (int d = 0; d < D; ++d) qr[d] = ElemTraits<T>::ld(gp + d);        // qr now holds dO
-  float dp[NK];
-  float delta = 0.f;
-#pragma unroll
-  for (int j = 0; j < NK; ++j) {
-    s[j] *= inv;
-    float a = 0.f;
-#pragma unroll
-    for (int d = 0; d < D; ++d) a += qr[d] * sV[j * D + d];
-    dp[j] = a;
-    delta += s[j] * a;
-  }
   float* Pp = Pbuf + (((int64_t)b * H + h) * Nq + i) * NK;
   float* Sp = dSbuf + (((int64_t)b * H + h) * Nq + i) * NK;
+  float qr[D], gr[D];
 #pragma unroll
-  for (int d = 0; d < D; ++d) qr[d] = 0.f;                              // qr now accumulates dq
-#pragma unroll
+  for (int d = 0; d < D; ++d) { qr[d] = ElemTraits<T>::ld(qp + d) * scale; gr[d] = ElemTraits<T>::ld(gp + d); }
+  float m = -3.0e38f;
+#pragma unroll 1
   for (int j = 0; j < NK; ++j) {
-    const float ds = s[j] * (dp[j] - delta) * scale;
-    Pp[j] = s[j];
-    Sp[j] = ds;
+    const float a = dot_row<D>(qr, sK + j * D);
+    Pp[j] = a;
+    m = fmaxf(m, a);
+  }
+  float l = 0.f;
+#pragma unroll 1
+  for (int j = 0; j < NK; ++j) l += __expf(Pp[j] - m);
+  const float inv = 1.f / l;
+  float delta = 0.f;
+#pragma unroll 1
+  for (int j = 0; j < NK; ++j) {
+    const float p = __expf(Pp[j] - m) * inv;
+    const float dp = dot_row<D>(gr, sV + j * D);
+    Pp[j] = p;
+    Sp[j] = dp;
+    delta += p * dp;
+  }
 #pragma unroll
-    for (int d = 0; d < D; ++d) qr[d] += ds * sK[j * D + d];
+  for (int d = 0; d < D; ++d) gr[d] = 0.f;                              // gr now accumulates dq
+#pragma unroll 1
+  for (int j = 0; j < NK; ++j) {
+    const float ds = Pp[j] * (Sp[j] - delta) * scale;
+    Sp[j] = ds;
+    axpy_row<D>(gr, ds, sK + j * D);
   }
   T* op = dq + ((int64_t)b * Nq + i) * C + h * D;
 #pragma unroll
-  for (int d = 0; d < D; ++d) ElemTraits<T>::st(op + d, qr[d]);
+  for (int d = 0; d < D; ++d) ElemTraits<T>::st(op + d, gr[d]);
 }
 
 // backward, pass B: partial[split][b][j][2C] : dK[j, h*D+d] = sum_i dS[i][j] q[i][d] ; dV[j, C + h*D+d] = sum_i P[i][j] dO[i][d]

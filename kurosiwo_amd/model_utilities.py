@@ -10,9 +10,15 @@ def initialize_cd_model(configs, model_configs, phase="train"):
     if method == "snunet":
         model = SNUNet_ECAM(configs["num_channels"], configs["num_classes"], base_channel=model_configs["base_channel"],
                             precision=configs.get("precision", "bf16" if configs.get("mixed_precision") else "fp32"))
+    elif method == "changeformer":
+        from .changeformer import ChangeFormerV6
+        if model_configs.get("multi_scale_train") or model_configs.get("multi_scale_infer"):
+            raise NotImplementedError("changeformer: multi_scale_train / multi_scale_infer (only output[-1] is used, the reference default)")
+        model = ChangeFormerV6(embed_dim=model_configs["embed_dim"], input_nc=configs["num_channels"], output_nc=configs["num_classes"],
+                               decoder_softmax=model_configs["decoder_softmax"],
+                               precision=configs.get("precision", "bf16" if configs.get("mixed_precision") else "fp32"))
     else:
-        raise _lib.KsmiError(f"method {method!r} has no HIP implementation yet (in scope this round: snunet; "
-                             "changeformer / FloodViT are the next rows of SURVEY.md §8)")
+        raise _lib.KsmiError(f"method {method!r} has no HIP implementation (change-detection methods in scope: snunet, changeformer)")
     model = model.to(configs["device"])
     if configs.get("resume_checkpoint"):
         ck = torch.load(configs["resume_checkpoint"], map_location=configs["device"])

@@ -151,3 +151,19 @@ def test_train_forward_backward_vs_oracle(golden_dir, precision):
     if coss:
         assert float(np.median(coss)) > 0.99, float(np.median(coss))
     assert not worst, f"{precision}: {len(worst)} params: {dict(list(worst.items())[:12])}"
+
+
+def test_main_entry_changeformer_end_to_end_tiny(tmp_path, monkeypatch):
+    """main.py --method changeformer on a tiny synthetic set: SGD(momentum .99, wd 1e-5) epoch, checkpoint, reload, test."""
+    import shutil
+    import main as entry
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    shutil.copytree(os.path.join(root, "configs"), tmp_path / "configs")
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv("KSMI_SYNTHETIC_TILES", "8,4,4")
+    miou = entry.main(["--method", "changeformer", "--inputs", "pre_event_1", "post_event", "--batch_size", "4"])
+    assert 0.0 <= miou <= 100.0
+    ck = list((tmp_path / "checkpoints" / "changeformer").glob("*/best_segmentation.pt"))
+    assert ck, "best checkpoint missing"
+    d = torch.load(ck[0], map_location="cpu")
+    assert len(d["model_state_dict"]) == 373
