@@ -249,6 +249,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const ksmi_wgrad_desc 
   constexpr int CF = KC / 16;                  // channel fragments per chunk (2 bf16, 1 fp32)
   constexpr int KSTEP = KC;                    // pixels per MFMA k-step (32 bf16 / 16 fp32)
   constexpr int TPW = (TAPS + 3) / 4;          // taps per wave
+  constexpr bool SPLITK = TAPS == 1;
   constexpr int ES = sizeof(T);
   constexpr int GR = (BN * ES / 32) > 0 ? (BN * ES / 32) : 1;   // 32-byte granules per dY row
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -336,7 +337,10 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const ksmi_wgrad_desc 
     }
     __syncthreads();
     // ---- MFMA over pixel k-steps --------------------------------------------------------------
+    // 1x1 (token GEMM) case: a single tap would keep one wave busy, so the four waves split the pixel k-steps instead
+    // and their accumulators are summed through LDS after the patch loop (SPLITK)
     for (int ks = 0; ks < Ppad; ks += KSTEP) {
+      if (SPLITK && (((ks / KSTEP) & 3) != wave)) continue;
       u32x4 bfrag[NT];
       if constexpr (sizeof(T) == 2) {
 #pragma unroll
@@ -355,7 +359,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const ksmi_wgrad_desc 
       }
 #pragma unroll
       for (int a = 0; a < TPW; ++a) {
-        const int t = wave + a * 4;
+        const int t = SPLITK ? 0 : wave + a * 4;
         if (t >= TAPS) break;
         const int toff = (t / KW) * HW + (t % KW);
 #pragma unroll
@@ -381,6 +385,29 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const ksmi_wgrad_desc 
         }
       }
     }
+  }
+  if (SPLITK) {
+    __syncthreads();
+    float* red = (float*)smem;                       // [4 waves][CF][NT][4 regs][64 lanes]
+#pragma unroll
+    for (int cf = 0; cf < CF; ++cf)
+#pragma unroll
+      for (int nf = 0; nf < NT; ++nf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[(((wave * CF + cf) * NT + nf) * 4 + r) * 64 + lane] = acc[0][cf][nf][r];
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int cf = 0; cf < CF; ++cf)
+#pragma unroll
+      for (int nf = 0; nf < NT; ++nf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float sacc = 0.f;
+#pragma unroll
+          for (int w = 0; w < 4; ++w) sacc += red[(((w * CF + cf) * NT + nf) * 4 + r) * 64 + lane];
+          acc[0][cf][nf][r] = sacc;
+        }
   }
   // ---- write partial slab [split][tap][chunk*KC + kc][Npad] ------------------------------------
   const int Npad = (d.N + 15) & ~15;
@@ -472,7 +499,111 @@ int launch_fwd(const ksmi_conv_desc* d, hipStream_t st) {
   return ksmi_check_launch("igemm_fwd");
 }
 
-struct WgradGeom { int taps, kc, nt, bn, patches, pps, nsplit, ntiles, npad; size_t lds; };
+
+// -------------------------------------------------------------------------------------------------
+// Token-GEMM weight gradient (1x1, stride 1, one dense bf16 source): dW^T[cin][n] = sum_rows X[row][cin] * dY[row][n].
+// The generic kernel above gives every workgroup a 32 x 64 output tile (21 flop per staged byte); here a workgroup owns a
+// 128 x 128 tile (2 x 2 waves of 64 x 64 = 4 x 4 MFMA tiles each) and streams its row slab in steps of 32 rows through a
+// double-buffered LDS image (64 flop per byte), global -> register prefetch one step ahead.  Same partial-slab layout and
+// reduce kernel as the generic path.
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gemm_tn_wgrad_kernel(const ksmi_wgrad_desc d, int rows_total, int rows_per_split, int K) {
+  constexpr int TM = 128, TN = 128, RS = 32;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (RS * TM * 2 + RS * TN * 2)];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, l15 = lane & 15;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int k0 = blockIdx.x * TM, n0 = blockIdx.y * TN, split = blockIdx.z;
+  const ksmi_src& sr = d.src[0];
+  const bf16_t* xp = (const bf16_t*)sr.ptr + sr.c_off;
+  const bf16_t* yp = (const bf16_t*)d.dy + d.dy_c_off;
+  const int r_begin = split * rows_per_split;
+  const int r_end = min(rows_total, r_begin + rows_per_split);
+  const int nsteps = (max(r_end - r_begin, 0) + RS - 1) / RS;
+  // staging slots: 512 16-byte vectors per tile, 2 per thread: v = tid + i*256 -> row v>>4, vector v&15
+  u32x4 rx[2], ry[2];
+  auto gload = [&](int step) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int v = tid + i * 256, r = v >> 4, q = v & 15;
+      const int row = r_begin + step * RS + r;
+      const bool rok = row < r_end;
+      rx[i] = (rok && k0 + q * 8 < sr.c_len) ? *(const u32x4*)(xp + (size_t)row * sr.C + k0 + q * 8) : (u32x4){0u, 0u, 0u, 0u};
+      ry[i] = (rok && n0 + q * 8 < d.N) ? *(const u32x4*)(yp + (size_t)row * d.dyC + n0 + q * 8) : (u32x4){0u, 0u, 0u, 0u};
+    }
+  };
+  auto lstore = [&](int buf) {
+    unsigned char* bx = smem + buf * (RS * TM * 2 + RS * TN * 2);
+    unsigned char* by = bx + RS * TM * 2;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int v = tid + i * 256, r = v >> 4, q = v & 15;
+      *(u32x4*)(bx + wg_dy_off<8>(r, q * 16)) = rx[i];
+      *(u32x4*)(by + wg_dy_off<8>(r, q * 16)) = ry[i];
+    }
+  };
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (nsteps > 0) { gload(0); lstore(0); }
+  __syncthreads();
+  for (int s = 0; s < nsteps; ++s) {
+    const bool more = s + 1 < nsteps;
+    if (more) gload(s + 1);
+    const unsigned bx = (unsigned)(uintptr_t)(smem + (s & 1) * (RS * TM * 2 + RS * TN * 2));
+    const unsigned by = bx + RS * TM * 2;
+    u32x4 af[4], bf[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      auto ra = [&](int j) -> unsigned { return bx + wg_dy_off<8>(g * 8 + j, (wm * 64 + t * 16) * 2); };
+      auto rb = [&](int j) -> unsigned { return by + wg_dy_off<8>(g * 8 + j, (wn * 64 + t * 16) * 2); };
+      af[t] = TrRead<bf16_t>::read(ra, l15);
+      bf[t] = TrRead<bf16_t>::read(rb, l15);
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) mma16<bf16_t>(acc[a][b], af[a], bf[b]);
+    if (more) lstore((s + 1) & 1);
+    __syncthreads();
+  }
+  // partial[split][0][krow][Npad]: krow = cin, same as the generic kernel (row = (lane>>4)*4 + r, col = lane&15)
+  const int Npad = (d.N + 15) & ~15;
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int n = n0 + wn * 64 + b * 16 + l15;
+      if (n >= Npad) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int krow = k0 + wm * 64 + a * 16 + g * 4 + r;
+        if (krow < K) d.partial[((size_t)split * K + krow) * Npad + n] = acc[a][b][r];
+      }
+    }
+}
+
+// eligibility of the token-GEMM path and its split geometry
+static bool gemm_tn_eligible(const ksmi_wgrad_desc* d, int es) {
+  return es == 2 && d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && d->nsrc == 1 && d->src[0].scale == nullptr &&
+         d->Hin == d->Hout && d->Win == d->Wout && (d->src[0].c_len % 8) == 0 && (d->N % 8) == 0 && d->N >= 64 && d->src[0].c_len >= 64 &&
+         getenv("KSMI_WGRAD_GENERIC") == nullptr;
+}
+static void gemm_tn_geom(const ksmi_wgrad_desc* d, int kc, int& nsplit, int& rps, int& tk, int& tn) {
+  const int rows = d->B * d->Hout * d->Wout;
+  const int K = d->nchunks * kc;
+  tk = (K + 127) / 128; tn = (((d->N + 15) & ~15) + 127) / 128;
+  int want = 768 / (tk * tn);
+  if (want < 1) want = 1;
+  if (want > 256) want = 256;
+  rps = ((rows + want - 1) / want + 31) & ~31;
+  if (rps < 32) rps = 32;
+  nsplit = (rows + rps - 1) / rps;
+}
+
+struct WgradGeom { int taps, kc, nt, bn, patches, pps, nsplit, ntiles, npad; size_t lds; bool tn; int rps, tk, tnn; };
 
 template <typename T>
 WgradGeom wgrad_geom(const ksmi_wgrad_desc* d) {
@@ -495,6 +626,9 @@ WgradGeom wgrad_geom(const ksmi_wgrad_desc* d) {
   const int HH = (d->TH - 1) * d->stride + d->KH, HW = (d->TW - 1) * d->stride + d->KW;
   const int P = d->TH * d->TW, Ppad = (P + g.kc - 1) / g.kc * g.kc;
   g.lds = ((HH * HW * 64 + 255) & ~255) + (size_t)Ppad * g.bn * sizeof(T);
+  if (g.taps == 1 && g.lds < (size_t)(g.kc / 16) * g.nt * 4096) g.lds = (size_t)(g.kc / 16) * g.nt * 4096;   // split-k reduction buffer
+  g.tn = gemm_tn_eligible(d, (int)sizeof(T));
+  if (g.tn) gemm_tn_geom(d, g.kc, g.nsplit, g.rps, g.tk, g.tnn);
   return g;
 }
 
@@ -503,6 +637,15 @@ int launch_wgrad(const ksmi_wgrad_desc* d, hipStream_t st) {
   WgradGeom g = wgrad_geom<T>(d);
   if (d->TH * d->TW > 256) return ksmi_fail(KSMI_E_ARG, "wgrad: patch too large");
   if (d->nsplit != g.nsplit) return ksmi_fail(KSMI_E_ARG, "wgrad: nsplit does not match ksmi_conv_wgrad_workspace geometry");
+  if (g.tn) {
+    hipLaunchKernelGGL(gemm_tn_wgrad_kernel, dim3(g.tk, g.tnn, g.nsplit), dim3(256), 0, st, *d, d->B * d->Hout * d->Wout, g.rps, d->nchunks * g.kc);
+    int rc0 = ksmi_check_launch("gemm_tn_wgrad");
+    if (rc0) return rc0;
+    const size_t total0 = (size_t)d->nchunks * g.kc * g.npad;
+    int blocks0 = (int)((total0 * 8 + 255) / 256); if (blocks0 > 4096) blocks0 = 4096;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks0), dim3(256), 0, st, *d, 1, g.kc);
+    return ksmi_check_launch("wgrad_reduce");
+  }
   const dim3 grid(g.nsplit, d->nchunks, g.ntiles);
 #define KSMI_LAUNCH_WG(NT_, KH_, KW_)                                                               \
   do {                                                                                              \
