@@ -31,7 +31,7 @@ extern "C" {
 #define KSMI_E_ARG (-1)
 #define KSMI_E_UNSUPPORTED (-2)
 #define KSMI_MAX_SRC 6
-#define KSMI_MAX_CHUNKS 256
+#define KSMI_MAX_CHUNKS 72
 
 int ksmi_abi_version(void);
 const char* ksmi_last_error(void);

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libksmi.so")
 
 KSMI_F32, KSMI_BF16 = 0, 1
-MAX_SRC, MAX_CHUNKS = 6, 256
+MAX_SRC, MAX_CHUNKS = 6, 72
 ABI_VERSION = 1
 
 

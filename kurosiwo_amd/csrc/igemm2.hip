@@ -24,7 +24,7 @@ struct Igemm2Args {            // kernel argument: the public descriptor + launc
   int stages;                        // LDS stages: 2 = double-buffered k-chunks, 1 = single
 };
 
-template <typename T, int NT, int KH, int KW, bool AFF>
+template <typename T, int NT, int KH, int KW, bool AFF, bool EX>
 __global__ __launch_bounds__(256) void igemm2_fwd_kernel(const Igemm2Args ka) {
   const ksmi_conv_desc& d = ka.d;
   const long long tm0 = __builtin_readcyclecounter();
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void igemm2_fwd_kernel(const Igemm2Args ka) {
     }
   }
   const long long tm2 = __builtin_readcyclecounter();
-  if (!(dbg & 4)) igemm_epilogue_direct<T, NT>(d, acc, smem, tid, wave, g, l15, b, oy0, ox0, n0, P, ka.m_tw);
+  if (!(dbg & 4)) igemm_epilogue_direct<T, NT, EX>(d, acc, smem, tid, wave, g, l15, b, oy0, ox0, n0, P, ka.m_tw);
   if ((dbg & 8) && d.stats && tid == 0 && blockIdx.y == 0) {   // per-block phase timestamps (profiling only; clobbers stats)
     __builtin_amdgcn_s_waitcnt(0);
     const long long tm3 = __builtin_readcyclecounter();
@@ -260,17 +260,21 @@ int launch2(const ksmi_conv_desc* d, int dbg, hipStream_t st) {
   size_t lds = stages * (hpb + (size_t)taps * bn * 64);
   if (lds < 4 * 2 * bn * sizeof(float)) lds = 4 * 2 * bn * sizeof(float);
   const bool aff = d->src[0].scale != nullptr;
+  // epilogue extras (scale, residual, ReLU, strided placement) compile into a separate kernel: the common path stays lean
+  const bool extras = d->alpha != 0.f || d->resid != nullptr || d->relu_out != 0 || d->out_sy != 0;
   Igemm2Args ka;
   ka.d = *d;
   ka.m_tw = fastdiv_magic(d->TW); ka.m_hw = fastdiv_magic(HW); ka.m_tx = fastdiv_magic(tilesX); ka.m_ty = fastdiv_magic(tilesY);
   ka.dbg = dbg;
   ka.stages = stages;
-#define KSMI_L2(NT_, KH_, KW_, AFF_)                                                                \
+#define KSMI_L2X(NT_, KH_, KW_, AFF_, EX_)                                                          \
   do {                                                                                              \
-    auto kfn = igemm2_fwd_kernel<T, NT_, KH_, KW_, AFF_>;                                           \
+    auto kfn = igemm2_fwd_kernel<T, NT_, KH_, KW_, AFF_, EX_>;                                      \
     if (lds > 65536) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, ka);                                          \
   } while (0)
+#define KSMI_L2(NT_, KH_, KW_, AFF_)                                                                \
+  do { if (extras) KSMI_L2X(NT_, KH_, KW_, AFF_, true); else KSMI_L2X(NT_, KH_, KW_, AFF_, false); } while (0)
 #define KSMI_D2(KH_, KW_)                                                                           \
   switch (nt) {                                                                                     \
     case 1: if (aff) KSMI_L2(1, KH_, KW_, true); else KSMI_L2(1, KH_, KW_, false); break;           \
@@ -284,6 +288,7 @@ int launch2(const ksmi_conv_desc* d, int dbg, hipStream_t st) {
   else return ksmi_fail(KSMI_E_UNSUPPORTED, "conv: kernel size not supported");
 #undef KSMI_D2
 #undef KSMI_L2
+#undef KSMI_L2X
   return ksmi_check_launch("igemm2_fwd");
 }
 

@@ -215,7 +215,7 @@ template <> struct Quad<bf16_t> {
   }
 };
 
-template <typename T, int NT>
+template <typename T, int NT, bool EX = true>
 __device__ __forceinline__ void igemm_epilogue_direct(const ksmi_conv_desc& d, f32x4 (&acc)[4][NT], unsigned char* smem, int tid,
                                                       int wave, int g, int l15, int b, int oy0, int ox0, int n0, int P,
                                                       uint32_t magic_tw = 0xffffffffu) {
@@ -261,11 +261,11 @@ __device__ __forceinline__ void igemm_epilogue_direct(const ksmi_conv_desc& d, f
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = acc[mf][nf][r] + bias[r];
-      if (d.alpha != 0.f) {
+      if (EX && d.alpha != 0.f) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] *= d.alpha;
       }
-      if (d.resid) {
+      if (EX && d.resid) {
         float rs[4] = {0.f, 0.f, 0.f, 0.f};
         const T* rp = (const T*)d.resid + opix[mf] * d.residC + n4;
         if (vec_ok && (d.residC & 3) == 0) Quad<T>::ld(rp, rs);
@@ -273,7 +273,7 @@ __device__ __forceinline__ void igemm_epilogue_direct(const ksmi_conv_desc& d, f
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] += rs[r];
       }
-      if (d.relu_out) {
+      if (EX && d.relu_out) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
       }
@@ -297,7 +297,7 @@ __device__ __forceinline__ void igemm_epilogue_direct(const ksmi_conv_desc& d, f
         const size_t op2 = ((size_t)b * (2 * d.Hout) + (2 * oyv[mf] + (dd >> 1))) * (2 * d.Wout) + (2 * oxv[mf] + (dd & 1));
         dp = (T*)ds.ptr + op2 * ds.C + ds.c_off + nn;
       } else {
-        dp = (T*)ds.ptr + dst_pixel(d, b, oyv[mf], oxv[mf]) * ds.C + ds.c_off + nn;
+        dp = (T*)ds.ptr + (EX ? dst_pixel(d, b, oyv[mf], oxv[mf]) : opix[mf]) * ds.C + ds.c_off + nn;
       }
       if (vec_ok) {
         if (ds.accumulate) {
@@ -319,7 +319,7 @@ __device__ __forceinline__ void igemm_epilogue_direct(const ksmi_conv_desc& d, f
             const size_t op2 = ((size_t)b * (2 * d.Hout) + (2 * oyv[mf] + (d2 >> 1))) * (2 * d.Wout) + (2 * oxv[mf] + (d2 & 1));
             q = (T*)dj.ptr + op2 * dj.C + dj.c_off + n2;
           } else {
-            q = (T*)dj.ptr + dst_pixel(d, b, oyv[mf], oxv[mf]) * dj.C + dj.c_off + (n - dj.n_begin);
+            q = (T*)dj.ptr + (EX ? dst_pixel(d, b, oyv[mf], oxv[mf]) : opix[mf]) * dj.C + dj.c_off + (n - dj.n_begin);
           }
           float o = v[r];
           if (dj.accumulate) o += ElemTraits<T>::ld(q);

