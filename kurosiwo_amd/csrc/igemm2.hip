@@ -114,7 +114,9 @@ __global__ __launch_bounds__(256) void igemm2_fwd_kernel(const Igemm2Args ka) {
     const int v = i * 256 + tid;
     const int row = v >> 2, sl = v & 3;
     const int t = row / BN, n = row - t * BN;
-    w_src[i] = (v < WVEC && n0 + n < d.Npad) ? ((t * d.Npad + n0 + n) * KC + ((sl ^ swz(n)) * VEC)) : -1;
+    // LDS row n = nf*16 + g*4 + r of the A operand holds output channel g*4*NT + nf*4 + r (epilogue: igemm_epilogue.h, epi_col)
+    const int nsrc_ = ((n >> 2) & 3) * 4 * NT + (n >> 4) * 4 + (n & 3);
+    w_src[i] = (v < WVEC && n0 + nsrc_ < d.Npad) ? ((t * d.Npad + n0 + nsrc_) * KC + ((sl ^ swz(n)) * VEC)) : -1;
   }
 
   f32x4 acc[4][NT];
@@ -233,10 +235,11 @@ __global__ __launch_bounds__(256) void igemm2_fwd_kernel(const Igemm2Args ka) {
   const long long tm2 = __builtin_readcyclecounter();
   if (!(dbg & 4)) igemm_epilogue_direct<T, NT, EX>(d, acc, smem, tid, wave, g, l15, b, oy0, ox0, n0, P, ka.m_tw);
   if ((dbg & 8) && d.stats && tid == 0 && blockIdx.y == 0) {   // per-block phase timestamps (profiling only; clobbers stats)
+    const long long tm3a = __builtin_readcyclecounter();      // epilogue instructions issued
     __builtin_amdgcn_s_waitcnt(0);
-    const long long tm3 = __builtin_readcyclecounter();
-    long long* o = (long long*)d.stats + (size_t)blockIdx.x * 4;
-    o[0] = tm0; o[1] = tm1; o[2] = tm2; o[3] = tm3;
+    const long long tm3 = __builtin_readcyclecounter();       // ... and its stores acknowledged
+    long long* o = (long long*)d.stats + (size_t)blockIdx.x * 8;
+    o[0] = tm0; o[1] = tm1; o[2] = tm2; o[3] = tm3; o[4] = tm3a;
   }
 }
 

@@ -215,6 +215,21 @@ template <> struct Quad<bf16_t> {
   }
 };
 
+// sum over the 16 lanes of a DPP row (lane & 15), result in every lane: quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, false));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, false));
+  return v;
+}
+
+// Channel ownership of the direct epilogue.  The weight slab is staged with its rows permuted (igemm2.hip: row nf*16 + g*4 + r of
+// the MFMA A operand holds output channel g*4*NT + nf*4 + r of the tile), so lane (g, l15) owns the 4*NT CONSECUTIVE channels
+// n0 + g*4*NT .. of pixel l15: one 16-byte store per pixel for bf16 NT = 2 (a wave instruction covers 16 whole 64-byte pixel rows
+// instead of 16 half rows).
+template <int NT> __device__ __forceinline__ int epi_col(int nf, int g) { return g * 4 * NT + nf * 4; }
+
 template <typename T, int NT, bool EX = true>
 __device__ __forceinline__ void igemm_epilogue_direct(const ksmi_conv_desc& d, f32x4 (&acc)[4][NT], unsigned char* smem, int tid,
                                                       int wave, int g, int l15, int b, int oy0, int ox0, int n0, int P,
@@ -232,96 +247,116 @@ __device__ __forceinline__ void igemm_epilogue_direct(const ksmi_conv_desc& d, f
     pv[mf] = p < P && oyv[mf] < d.Hout && oxv[mf] < d.Wout;
     opix[mf] = ((size_t)b * d.Hout + oyv[mf]) * d.Wout + oxv[mf];
   }
-  float ssum[NT][4], ssq[NT][4];
+  // ---- per-nf column setup ---------------------------------------------------------------------------
+  float ssum[NT][4], ssq[NT][4], bias[NT][4];
+  int n4v[NT], nval[NT], si[NT], ddv[NT], nnv[NT];
+  bool vok[NT];
 #pragma unroll
   for (int nf = 0; nf < NT; ++nf) {
-    const int n4 = n0 + nf * 16 + g * 4;
+    const int n4 = n0 + epi_col<NT>(nf, g);
+    n4v[nf] = n4;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { ssum[nf][r] = 0.f; ssq[nf][r] = 0.f; }
-    if (n4 >= d.N) continue;
-    const int nval = min(4, d.N - n4);
-    int si = 0;
-    for (int k = 1; k < d.ndst; ++k) if (n4 >= d.dst[k].n_begin) si = k;
-    const ksmi_dst& ds = d.dst[si];
-    const bool vec_ok = nval == 4 && ((ds.C | ds.c_off | (n4 - ds.n_begin) | d.N) & 3) == 0 && (d.ps_cout & 3) == 0;
-    float bias[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < 4; ++r) { ssum[nf][r] = 0.f; ssq[nf][r] = 0.f; bias[nf][r] = 0.f; }
+    nval[nf] = n4 >= d.N ? 0 : min(4, d.N - n4);
+    int k0 = 0;
+    for (int k = 1; k < d.ndst; ++k) if (n4 >= d.dst[k].n_begin) k0 = k;
+    si[nf] = k0;
+    const ksmi_dst& ds = d.dst[k0];
+    vok[nf] = nval[nf] == 4 && ((ds.C | ds.c_off | (n4 - ds.n_begin) | d.N) & 3) == 0 && (d.ps_cout & 3) == 0;
     if (d.bias)
-      for (int r = 0; r < nval; ++r) bias[r] = d.bias[d.ps_cout > 0 ? (n4 + r) % d.ps_cout : (n4 + r)];
-    float mm[4], mr[4], mg[4], mb[4];
-    if (d.mask_src)
-      for (int r = 0; r < 4; ++r) {
-        const int n = min(n4 + r, d.N - 1);
-        mm[r] = d.m_mean[n]; mr[r] = d.m_rstd[n]; mg[r] = d.m_scale[n]; mb[r] = d.m_shift[n];
-      }
-    int dd = 0, nn = n4 - ds.n_begin;
-    if (d.ps_cout > 0) { dd = n4 / d.ps_cout; nn = n4 - dd * d.ps_cout; }
+      for (int r = 0; r < nval[nf]; ++r) bias[nf][r] = d.bias[d.ps_cout > 0 ? (n4 + r) % d.ps_cout : (n4 + r)];
+    ddv[nf] = 0; nnv[nf] = n4 - ds.n_begin;
+    if (d.ps_cout > 0) { ddv[nf] = n4 / d.ps_cout; nnv[nf] = n4 - ddv[nf] * d.ps_cout; }
+  }
+  // 16-byte combined store of the lane's 8 consecutive bf16 channels (NT = 2): same destination, 8-element alignment
+  bool wide = false;
+  if constexpr (NT == 2 && sizeof(T) == 2) {
+    const ksmi_dst& ds = d.dst[si[0]];
+    wide = vok[0] && vok[1] && si[0] == si[1] && ddv[0] == ddv[1] && (((ds.C | ds.c_off | nnv[0]) & 7) == 0) && !ds.accumulate;
+  }
 #pragma unroll
-    for (int mf = 0; mf < 4; ++mf) {
-      if (!pv[mf]) continue;
-      float v[4];
+  for (int mf = 0; mf < 4; ++mf) {
+    if (!pv[mf]) continue;
+    float v[NT][4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = acc[mf][nf][r] + bias[r];
+    for (int nf = 0; nf < NT; ++nf) {
+      const int n4 = n4v[nf];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[nf][r] = acc[mf][nf][r] + bias[nf][r];
+      if (nval[nf] == 0) continue;
       if (EX && d.alpha != 0.f) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] *= d.alpha;
+        for (int r = 0; r < 4; ++r) v[nf][r] *= d.alpha;
       }
       if (EX && d.resid) {
         float rs[4] = {0.f, 0.f, 0.f, 0.f};
         const T* rp = (const T*)d.resid + opix[mf] * d.residC + n4;
-        if (vec_ok && (d.residC & 3) == 0) Quad<T>::ld(rp, rs);
-        else for (int r = 0; r < nval; ++r) rs[r] = ElemTraits<T>::ld(rp + r);
+        if (vok[nf] && (d.residC & 3) == 0) Quad<T>::ld(rp, rs);
+        else for (int r = 0; r < nval[nf]; ++r) rs[r] = ElemTraits<T>::ld(rp + r);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += rs[r];
+        for (int r = 0; r < 4; ++r) v[nf][r] += rs[r];
       }
       if (EX && d.relu_out) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        for (int r = 0; r < 4; ++r) v[nf][r] = fmaxf(v[nf][r], 0.f);
       }
       if (d.mask_src) {
         float m[4] = {0.f, 0.f, 0.f, 0.f};
         const T* mp = (const T*)d.mask_src + opix[mf] * d.N + n4;
-        if (vec_ok) Quad<T>::ld(mp, m);
-        else for (int r = 0; r < nval; ++r) m[r] = ElemTraits<T>::ld(mp + r);
+        if (vok[nf]) Quad<T>::ld(mp, m);
+        else for (int r = 0; r < nval[nf]; ++r) m[r] = ElemTraits<T>::ld(mp + r);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float xh = (m[r] - mm[r]) * mr[r];
-          if (!(m[r] * mg[r] + mb[r] > 0.f)) v[r] = 0.f;
-          if (r < nval) { ssum[nf][r] += v[r]; ssq[nf][r] += v[r] * xh; }
+          const int n = min(n4 + r, d.N - 1);
+          const float xh = (m[r] - d.m_mean[n]) * d.m_rstd[n];
+          if (!(m[r] * d.m_scale[n] + d.m_shift[n] > 0.f)) v[nf][r] = 0.f;
+          if (r < nval[nf]) { ssum[nf][r] += v[nf][r]; ssq[nf][r] += v[nf][r] * xh; }
         }
       } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) if (r < nval) { ssum[nf][r] += v[r]; ssq[nf][r] += v[r] * v[r]; }
+        for (int r = 0; r < 4; ++r) if (r < nval[nf]) { ssum[nf][r] += v[nf][r]; ssq[nf][r] += v[nf][r] * v[nf][r]; }
       }
-      T* dp;
+    }
+    // ---- stores -----------------------------------------------------------------------------------
+    auto dst_of = [&](const ksmi_dst& ds, int dd, int nn) -> T* {
       if (d.ps_cout > 0) {
         const size_t op2 = ((size_t)b * (2 * d.Hout) + (2 * oyv[mf] + (dd >> 1))) * (2 * d.Wout) + (2 * oxv[mf] + (dd & 1));
-        dp = (T*)ds.ptr + op2 * ds.C + ds.c_off + nn;
-      } else {
-        dp = (T*)ds.ptr + (EX ? dst_pixel(d, b, oyv[mf], oxv[mf]) : opix[mf]) * ds.C + ds.c_off + nn;
+        return (T*)ds.ptr + op2 * ds.C + ds.c_off + nn;
       }
-      if (vec_ok) {
+      return (T*)ds.ptr + (EX ? dst_pixel(d, b, oyv[mf], oxv[mf]) : opix[mf]) * ds.C + ds.c_off + nn;
+    };
+    if constexpr (NT == 2 && sizeof(T) == 2) {
+      if (wide) {
+        float f[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { f[r] = v[0][r]; f[4 + r] = v[1][r]; }
+        *(u32x4*)dst_of(d.dst[si[0]], ddv[0], nnv[0]) = vec_pack<T>(f);
+        continue;
+      }
+    }
+#pragma unroll
+    for (int nf = 0; nf < NT; ++nf) {
+      if (nval[nf] == 0) continue;
+      const ksmi_dst& ds = d.dst[si[nf]];
+      if (vok[nf]) {
+        T* dp = dst_of(ds, ddv[nf], nnv[nf]);
         if (ds.accumulate) {
           float o[4];
           Quad<T>::ld(dp, o);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] += o[r];
+          for (int r = 0; r < 4; ++r) v[nf][r] += o[r];
         }
-        Quad<T>::st(dp, v);
+        Quad<T>::st(dp, v[nf]);
       } else {
-        for (int r = 0; r < nval; ++r) {
-          const int n = n4 + r;
+        for (int r = 0; r < nval[nf]; ++r) {
+          const int n = n4v[nf] + r;
           int sj = 0;
           for (int k = 1; k < d.ndst; ++k) if (n >= d.dst[k].n_begin) sj = k;
           const ksmi_dst& dj = d.dst[sj];
-          T* q;
-          if (d.ps_cout > 0) {
-            const int d2 = n / d.ps_cout, n2 = n - d2 * d.ps_cout;
-            const size_t op2 = ((size_t)b * (2 * d.Hout) + (2 * oyv[mf] + (d2 >> 1))) * (2 * d.Wout) + (2 * oxv[mf] + (d2 & 1));
-            q = (T*)dj.ptr + op2 * dj.C + dj.c_off + n2;
-          } else {
-            q = (T*)dj.ptr + (EX ? dst_pixel(d, b, oyv[mf], oxv[mf]) : opix[mf]) * dj.C + dj.c_off + (n - dj.n_begin);
-          }
-          float o = v[r];
+          int d2 = 0, n2 = n - dj.n_begin;
+          if (d.ps_cout > 0) { d2 = n / d.ps_cout; n2 = n - d2 * d.ps_cout; }
+          T* q = dst_of(dj, d2, n2);
+          float o = v[nf][r];
           if (dj.accumulate) o += ElemTraits<T>::ld(q);
           ElemTraits<T>::st(q, o);
         }
@@ -329,17 +364,16 @@ __device__ __forceinline__ void igemm_epilogue_direct(const ksmi_conv_desc& d, f
     }
   }
   if (d.stats) {
-    // reduce over the 16 pixel lanes (l15) of each k-group, then over the 4 waves through LDS
+    // reduce over the 16 pixel lanes (l15) of each k-group with DPP row operations, then over the 4 waves through LDS
     __syncthreads();                                     // (all waves are past their last LDS reads)
     float* red = (float*)smem;                           // [4 waves][2][BN]
 #pragma unroll
     for (int nf = 0; nf < NT; ++nf)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float a = ssum[nf][r], q = ssq[nf][r];
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); q += __shfl_xor(q, o, 64); }
-        if (l15 == 0) { red[(wave * 2 + 0) * BN + nf * 16 + g * 4 + r] = a; red[(wave * 2 + 1) * BN + nf * 16 + g * 4 + r] = q; }
+        const float a = row16_sum(ssum[nf][r]), q = row16_sum(ssq[nf][r]);
+        const int col = epi_col<NT>(nf, g) + r;
+        if (l15 == 0) { red[(wave * 2 + 0) * BN + col] = a; red[(wave * 2 + 1) * BN + col] = q; }
       }
     __syncthreads();
     if (tid < 2 * BN) {

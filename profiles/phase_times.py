@@ -12,9 +12,10 @@ for name, H, cs, N in [("L0 conv0_4", 224, [32] * 5 + [64], 32), ("L0 K=32", 224
     for _ in range(2):
         y, st = Fk.conv3x3(xs, w, None, want_stats=True)
     torch.cuda.synchronize()
-    t = st.view(torch.int64).reshape(-1)[: st.shape[0] * 4].reshape(-1, 4).cpu()
+    t = st.view(torch.int64).reshape(-1)[: st.shape[0] * 8].reshape(-1, 8).cpu()
     t = t[t[:, 0] > 0]
     pro, loop, epi = (t[:, 1] - t[:, 0]).float(), (t[:, 2] - t[:, 1]).float(), (t[:, 3] - t[:, 2]).float()
+    issue = (t[:, 4] - t[:, 2]).float()
     span = float(t[:, 3].max() - t[:, 0].min())
-    print(f"{name}: blocks {len(t)} prologue {pro.median():.0f} loop {loop.median():.0f} epilogue {epi.median():.0f} cycles (median); "
+    print(f"{name}: blocks {len(t)} prologue {pro.median():.0f} loop {loop.median():.0f} epilogue {epi.median():.0f} (issue {issue.median():.0f}) cycles (median); "
           f"kernel span {span:.0f} ticks; sum/block {float((t[:,3]-t[:,0]).float().median()):.0f}")
