@@ -291,9 +291,11 @@ int ksmi_patchify(const float* x_nchw, void* out, int B, int Cin, int H, int W, 
 int ksmi_vit_embed_forward(const void* emb, const float* cls, const float* pos, void* x0, int B, int N1, int C, int dtype, void* stream);
 int ksmi_vit_embed_backward(const void* dx0, void* demb, float* dcls, float* dpos, int B, int N1, int C, int dtype, void* stream);
 /* softmax(q k^T * scale) v per head (vision_transformer.py:52-63); qkv [B*N][3*H*D] in "(3 h d)" order, out [B*N][H*D],
- * lse [B][H][N] saved for backward; dqkv written ("=").  D must be 64. */
+ * lse [B][H][N] saved for backward; dqkv written ("=").  D must be 64.  bf16: MFMA flash-style kernels (csrc/attn_mfma.hip),
+ * the backward needs `workspace` (ksmi_attention_bwd_workspace bytes); fp32 (parity mode): VALU kernels. */
 int ksmi_attention_forward(const void* qkv, void* out, float* lse, int B, int N, int H, int D, float scale, int dtype, void* stream);
-int ksmi_attention_backward(const void* qkv, const void* out, const float* lse, const void* dout, void* dqkv,
+size_t ksmi_attention_bwd_workspace(int B, int N, int H, int D, int dtype);
+int ksmi_attention_backward(const void* qkv, const void* out, const float* lse, const void* dout, void* dqkv, void* workspace,
                             int B, int N, int H, int D, float scale, int dtype, void* stream);
 /* [relu ->] nn.Upsample(scale_factor=2) nearest (model_utilities.py:36-41) */
 int ksmi_upsample2_forward(const void* x, void* y, int B, int H, int W, int C, int relu, int dtype, void* stream);
@@ -315,12 +317,13 @@ int ksmi_dwconv3x3_gelu_forward(const void* x, const float* w, const float* bias
 int ksmi_dwconv3x3_backward_input(const void* dz, const float* w, void* dx, int B, int H, int W, int C, int dtype, void* stream);
 int ksmi_dwconv3x3_wgrad(const void* x, const void* dz, float* partial, int rows, int B, int H, int W, int C, int dtype, void* stream);
 /* Attention against the spatially reduced keys (:190-207): q [B*Nq][C], kv [B*Nk][2C] "(2 h d)", out [B*Nq][C]; Nk = 49,
- * head dim C/H in {64, 80}.  backward writes dq, dkv ("=") using `workspace` (ksmi_sr_attention_bwd_workspace bytes). */
+ * head dim C/H in {64, 80}.  backward (out = the forward's output) writes dq, dkv ("=") using `workspace`
+ * (ksmi_sr_attention_bwd_workspace bytes).  bf16 runs on the MFMA kernels of csrc/attn_mfma.hip. */
 int ksmi_sr_attention_forward(const void* q, const void* kv, void* out, int B, int Nq, int Nk, int H, int C, float scale, int dtype,
                               void* stream);
 size_t ksmi_sr_attention_bwd_workspace(int B, int Nq, int Nk, int H, int C);
-int ksmi_sr_attention_backward(const void* q, const void* kv, const void* dout, void* dq, void* dkv, void* workspace, int B, int Nq,
-                               int Nk, int H, int C, float scale, int dtype, void* stream);
+int ksmi_sr_attention_backward(const void* q, const void* kv, const void* out, const void* dout, void* dq, void* dkv, void* workspace, int B,
+                               int Nq, int Nk, int H, int C, float scale, int dtype, void* stream);
 /* F.interpolate(mode="bilinear", align_corners=False) (:581-608): y = [add +] resize(x); adjoint dx (+)= resize^T(dy) (upsampling) */
 int ksmi_bilinear_forward(const void* x, const void* add, void* y, int B, int Hi, int Wi, int Ho, int Wo, int C, int dtype, void* stream);
 int ksmi_bilinear_backward(const void* dy, void* dx, int accumulate, int B, int Hi, int Wi, int Ho, int Wo, int C, int dtype, void* stream);

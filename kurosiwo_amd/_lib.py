@@ -125,7 +125,8 @@ SIGNATURES = {
     "ksmi_dwconv3x3_wgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ksmi_sr_attention_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, C.c_float, _i, _vp]),
     "ksmi_sr_attention_bwd_workspace": (C.c_size_t, [_i, _i, _i, _i, _i]),
-    "ksmi_sr_attention_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, C.c_float, _i, _vp]),
+    "ksmi_sr_attention_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, C.c_float, _i, _vp]),
+    "ksmi_attention_bwd_workspace": (C.c_size_t, [_i, _i, _i, _i, _i]),
     "ksmi_bilinear_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "ksmi_bilinear_backward": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "ksmi_bn_bwd_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, C.c_double, _i64, _i, _i, _vp]),
@@ -138,7 +139,7 @@ SIGNATURES = {
     "ksmi_vit_embed_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ksmi_vit_embed_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ksmi_attention_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
-    "ksmi_attention_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
+    "ksmi_attention_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
     "ksmi_upsample2_forward": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ksmi_upsample2_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ksmi_fill_zero": (_i, [_vp, _sz, _vp]),

@@ -411,8 +411,8 @@ class ChangeFormerPlan(PlanBase):
             self._ln_bwd(tC, rec["t_mid"], rec["st2"], f"{k}.norm2.weight", f"{k}.norm2.bias", gt, 1, R, Cc)
             # Attention
             self._linear_bwd(f"{k}.proj", rec["att"], Cc, f"{k}.attn.proj.weight", f"{k}.attn.proj.bias", gt, Cc, R, tC)
-            self.bwd.add("ksmi_sr_attention_backward", lambda q=rec["q"], kv=rec["kv"], scale=rec["scale"]: (
-                q.data_ptr(), kv.data_ptr(), tC.data_ptr(), tq.data_ptr(), tkv.data_ptr(), self.scr("attn"), B2, Hs * Ws, 49, heads, Cc, scale, dt),
+            self.bwd.add("ksmi_sr_attention_backward", lambda q=rec["q"], kv=rec["kv"], att=rec["att"], scale=rec["scale"]: (
+                q.data_ptr(), kv.data_ptr(), att.data_ptr(), tC.data_ptr(), tq.data_ptr(), tkv.data_ptr(), self.scr("attn"), B2, Hs * Ws, 49, heads, Cc, scale, dt),
                 {"kind": "sr_attention_bwd", "bytes": (6 * R * Cc + 4 * Rk * Cc) * self._es(), "flops": 5 * rec["aflops"] // 2})
             dh = self.buf(R, Cc) if False else rec["h2"]         # h2 is dead here (fc1 wgrad done): reuse as d(norm1 output)
             if sr > 1:

@@ -629,20 +629,35 @@ int ksmi_dwconv3x3_wgrad(const void* x, const void* dz, float* partial, int rows
   return ksmi_check_launch("dwconv3x3_wgrad");
 }
 
+static bool sr_mfma(int dtype, int Nk, int C, int H) {
+  static const bool valu = getenv("KSMI_ATTN_VALU") != nullptr;
+  return dtype == KSMI_BF16 && Nk <= 64 && H > 0 && (C / H == 64 || C / H == 80) && !valu;
+}
+
 int ksmi_sr_attention_forward(const void* q, const void* kv, void* out, int B, int Nq, int Nk, int H, int C, float scale, int dtype,
                               void* stream) {
+  if (sr_mfma(dtype, Nk, C, H)) return ksmi_attn_mfma_sr(0, q, kv, out, nullptr, nullptr, nullptr, nullptr, nullptr, B, Nq, Nk, H, C, scale, stream);
   return sr_attn_dispatch(0, q, kv, nullptr, out, nullptr, nullptr, nullptr, B, Nq, Nk, H, C, scale, 1, dtype, (hipStream_t)stream);
 }
 
+size_t ksmi_sr_attention_bwd_workspace_valu(int B, int Nq, int Nk, int H, int C);
 int ksmi_sr_attention_splits(int Nq) { int s = (Nq + 255) / 256; return s < 1 ? 1 : (s > 16 ? 16 : s); }
 
 size_t ksmi_sr_attention_bwd_workspace(int B, int Nq, int Nk, int H, int C) {
+  const size_t mf = H > 0 ? ksmi_attn_mfma_workspace(B, Nq, Nk, H, C / H) : 0;
+  const size_t vl = ksmi_sr_attention_bwd_workspace_valu(B, Nq, Nk, H, C);
+  return mf > vl ? mf : vl;
+}
+
+size_t ksmi_sr_attention_bwd_workspace_valu(int B, int Nq, int Nk, int H, int C) {
   const size_t ps = (size_t)B * H * Nq * Nk * sizeof(float);
   return 2 * ps + (size_t)ksmi_sr_attention_splits(Nq) * B * Nk * 2 * C * sizeof(float);
 }
 
-int ksmi_sr_attention_backward(const void* q, const void* kv, const void* dout, void* dq, void* dkv, void* workspace, int B, int Nq,
-                               int Nk, int H, int C, float scale, int dtype, void* stream) {
+int ksmi_sr_attention_backward(const void* q, const void* kv, const void* out, const void* dout, void* dq, void* dkv, void* workspace, int B,
+                               int Nq, int Nk, int H, int C, float scale, int dtype, void* stream) {
+  if (sr_mfma(dtype, Nk, C, H))
+    return ksmi_attn_mfma_sr(1, q, kv, (void*)out, nullptr, dout, dq, dkv, workspace, B, Nq, Nk, H, C, scale, stream);
   const size_t ps = (size_t)B * H * Nq * Nk;
   float* Pb = (float*)workspace;
   float* Sb = Pb + ps;

@@ -8,3 +8,11 @@ int ksmi_check_launch(const char* what);           // hipGetLastError() -> 0 or 
 struct ksmi_conv_desc;
 bool ksmi_igemm2_eligible(const ksmi_conv_desc* d, int dtype);
 int ksmi_igemm2_launch(const ksmi_conv_desc* d, int dtype, hipStream_t st);
+
+// attn_mfma.hip: MFMA attention (bf16)
+int ksmi_attn_mfma_qsplit(int B, int Nq, int Nk, int H);
+size_t ksmi_attn_mfma_workspace(int B, int Nq, int Nk, int H, int D);
+int ksmi_attn_mfma_vit(int backward, const void* qkv, void* out, float* lse, const void* dout, void* dqkv, void* workspace, int B, int N,
+                       int H, float scale, void* stream);
+int ksmi_attn_mfma_sr(int backward, const void* q, const void* kv, void* out, float* lse, const void* dout, void* dq, void* dkv,
+                      void* workspace, int B, int Nq, int Nk, int H, int C, float scale, void* stream);

@@ -577,6 +577,8 @@ int ksmi_vit_embed_backward(const void* dx0, void* demb, float* dcls, float* dpo
 
 int ksmi_attention_forward(const void* qkv, void* out, float* lse, int B, int N, int H, int D, float scale, int dtype, void* stream) {
   if (D != 64) return ksmi_fail(KSMI_E_UNSUPPORTED, "attention: dim_head must be 64");
+  static const bool valu = getenv("KSMI_ATTN_VALU") != nullptr;       // A/B switch
+  if (dtype == KSMI_BF16 && N <= 208 && !valu) return ksmi_attn_mfma_vit(0, qkv, out, lse, nullptr, nullptr, nullptr, B, N, H, scale, stream);
   const size_t es = dtype == KSMI_BF16 ? 2 : 4;
   const size_t lds = 2 * (size_t)N * D * es;
   if (lds > 160 * 1024) return ksmi_fail(KSMI_E_UNSUPPORTED, "attention: sequence too long for the LDS-resident kernel");
@@ -586,9 +588,18 @@ int ksmi_attention_forward(const void* qkv, void* out, float* lse, int B, int N,
   return ksmi_check_launch("attention_fwd");
 }
 
-int ksmi_attention_backward(const void* qkv, const void* out, const float* lse, const void* dout, void* dqkv, int B, int N, int H,
-                            int D, float scale, int dtype, void* stream) {
+size_t ksmi_attention_bwd_workspace(int B, int N, int H, int D, int dtype) {
+  return dtype == KSMI_BF16 ? ksmi_attn_mfma_workspace(B, N, N, H, D) : 256;
+}
+
+int ksmi_attention_backward(const void* qkv, const void* out, const float* lse, const void* dout, void* dqkv, void* workspace, int B, int N,
+                            int H, int D, float scale, int dtype, void* stream) {
   if (D != 64) return ksmi_fail(KSMI_E_UNSUPPORTED, "attention: dim_head must be 64");
+  static const bool valu = getenv("KSMI_ATTN_VALU") != nullptr;
+  if (dtype == KSMI_BF16 && N <= 208 && !valu) {
+    if (!workspace) return ksmi_fail(KSMI_E_ARG, "attention_bwd: workspace required (ksmi_attention_bwd_workspace)");
+    return ksmi_attn_mfma_vit(1, qkv, (void*)out, (float*)lse, dout, dqkv, workspace, B, N, H, scale, stream);
+  }
   const size_t es = dtype == KSMI_BF16 ? 2 : 4;
   const size_t lds = 2 * (size_t)N * D * es + 2 * (size_t)N * sizeof(float);
   if (lds > 160 * 1024) return ksmi_fail(KSMI_E_UNSUPPORTED, "attention_bwd: sequence too long for the LDS-resident kernel");

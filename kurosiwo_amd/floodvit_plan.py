@@ -120,8 +120,9 @@ class FloodViTPlan(PlanBase):
                 self._ln_bwd(tD, x_mid, st2, f"{f}.net.0.weight", f"{f}.net.0.bias", gx, 1, R, D)
                 # Attention: x_mid = x_in + Wo attn(Wqkv LN(x_in)) + bo
                 self._linear_bwd(f"L{li}.to_out", att, I, f"{a}.to_out.0.weight", f"{a}.to_out.0.bias", gx, D, R, tI)
+                self.need("attn", self.lib.ksmi_attention_bwd_workspace(B, self.N1, self.heads, 64, dt))
                 self.bwd.add("ksmi_attention_backward", lambda: (qkv.data_ptr(), att.data_ptr(), lse.data_ptr(), tI.data_ptr(),
-                                                                 tQ.data_ptr(), B, self.N1, self.heads, 64, scale, dt),
+                                                                 tQ.data_ptr(), self.scr("attn"), B, self.N1, self.heads, 64, scale, dt),
                              {"kind": "attention_bwd", "bytes": 8 * R * I * self._es(), "flops": 5 * aflops // 2})
                 self._linear_bwd(f"L{li}.to_qkv", h1, D, f"{a}.to_qkv.weight", None, tQ, 3 * I, R, tD)
                 self._ln_bwd(tD, x_in, st1, f"{a}.norm.weight", f"{a}.norm.bias", gx, 1, R, D)

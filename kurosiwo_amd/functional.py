@@ -213,8 +213,9 @@ def attention(qkv, B, N, H, D=64):
 
 def attention_backward(qkv, out, lse, dout, B, N, H, D=64):
     dqkv = torch.empty_like(qkv)
+    ws = torch.empty(_lib.load().ksmi_attention_bwd_workspace(B, N, H, D, DT[qkv.dtype]), dtype=torch.uint8, device=qkv.device)
     _lib.check(_lib.load().ksmi_attention_backward(qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), dout.data_ptr(), dqkv.data_ptr(),
-                                                   B, N, H, D, D ** -0.5, DT[qkv.dtype], stream_ptr()), "attention_backward")
+                                                   ws.data_ptr(), B, N, H, D, D ** -0.5, DT[qkv.dtype], stream_ptr()), "attention_backward")
     return dqkv
 
 
@@ -279,12 +280,12 @@ def sr_attention(q, kv, B, Nq, Nk, heads):
     return out
 
 
-def sr_attention_backward(q, kv, dout, B, Nq, Nk, heads):
+def sr_attention_backward(q, kv, out, dout, B, Nq, Nk, heads):
     Cc = q.shape[1]
     lib = _lib.load()
     ws = torch.empty(lib.ksmi_sr_attention_bwd_workspace(B, Nq, Nk, heads, Cc), dtype=torch.uint8, device=q.device)
     dq, dkv = torch.empty_like(q), torch.empty_like(kv)
-    _lib.check(lib.ksmi_sr_attention_backward(q.data_ptr(), kv.data_ptr(), dout.data_ptr(), dq.data_ptr(), dkv.data_ptr(), ws.data_ptr(),
+    _lib.check(lib.ksmi_sr_attention_backward(q.data_ptr(), kv.data_ptr(), out.data_ptr(), dout.data_ptr(), dq.data_ptr(), dkv.data_ptr(), ws.data_ptr(),
                                               B, Nq, Nk, heads, Cc, (Cc // heads) ** -0.5, DT[q.dtype], stream_ptr()), "sr_attention_bwd")
     return dq, dkv
 

@@ -107,7 +107,7 @@ def test_sr_attention_forward_backward(dtype, Cc, heads, Nq):
     assert rel(out, ref) < tol(dtype)
     do = torch.randn(B * Nq, Cc, device="cuda").to(dtype)
     ref.backward(do.float())
-    dq, dkv = KF.sr_attention_backward(q, kv, do, B, Nq, Nk, heads)
+    dq, dkv = KF.sr_attention_backward(q, kv, out, do, B, Nq, Nk, heads)
     assert rel(dq, qr.grad) < tol(dtype) and rel(dkv, kvr.grad) < tol(dtype)
 
 
