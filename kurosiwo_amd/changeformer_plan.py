@@ -396,7 +396,7 @@ class ChangeFormerPlan(PlanBase):
             du = rec["z"]                                         # z is dead after gelu_backward: reuse as d(fc1 output)
             self.bwd.add("ksmi_dwconv3x3_backward_input", lambda du=du, wd=wd: (t4.data_ptr(), wd, du.data_ptr(), B2, Hs, Ws, 4 * Cc, dt),
                          self._elt_meta("dwconv_bwd", 2 * R * 4 * Cc))
-            rows = max(1, min(128, R // 64))
+            rows = max(1, min(1024 // max(1, -(-(4 * Cc // (8 if self.dtype == torch.bfloat16 else 4)) // 64)), R // 16))
             self.need("dwp", rows * 10 * 4 * Cc * 4)
             kw, kb = f"{k}.mlp.dwconv.dwconv.weight", f"{k}.mlp.dwconv.dwconv.bias"
             gw, gb = m._g(kw).data_ptr(), m._g(kb).data_ptr()

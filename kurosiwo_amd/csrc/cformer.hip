@@ -96,35 +96,46 @@ __global__ void affine_kernel(const T* x, const float* scale, const float* shift
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 
+// thread = (pixel lane tid / 32, channel vector blockIdx.y*32 + tid % 32): the 9 x VEC tap weights live in registers and the
+// thread walks PPT pixels of its block's pixel slab (the per-pixel version re-fetched 72 weights per output vector)
 template <typename T, int MODE>
-__global__ void dwconv3x3_kernel(const T* x, const float* w, const float* bias, T* z, T* g, int B, int H, int W, int C) {
+__global__ __launch_bounds__(256) void dwconv3x3_kernel(const T* x, const float* w, const float* bias, T* z, T* g, int B, int H, int W, int C,
+                                                        int pix_per_block) {
   constexpr int VEC = ElemTraits<T>::kVec;
   const int CV = C / VEC;
-  const int64_t n = (int64_t)B * H * W * CV;
-  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (int64_t)gridDim.x * blockDim.x) {
-    const int cv = v % CV; int64_t r = v / CV;
-    const int px = r % W; r /= W;
-    const int py = r % H; const int b = r / H;
-    const int c0 = cv * VEC;
+  const int cv = blockIdx.y * 32 + (threadIdx.x & 31), pl = threadIdx.x >> 5;
+  if (cv >= CV) return;
+  const int c0 = cv * VEC;
+  float wr[9][VEC], br[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    br[j] = (MODE == 0 && bias) ? bias[c0 + j] : 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wr[t][j] = w[(c0 + j) * 9 + (MODE == 0 ? t : 8 - t)];
+  }
+  const int64_t npix = (int64_t)B * H * W;
+  const int64_t p0 = (int64_t)blockIdx.x * pix_per_block, p1 = min(npix, p0 + pix_per_block);
+  for (int64_t p = p0 + pl; p < p1; p += 8) {
+    const int px = p % W; const int64_t r = p / W;
+    const int py = r % H;
     float acc[VEC];
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) acc[j] = (MODE == 0 && bias) ? bias[c0 + j] : 0.f;
+    for (int j = 0; j < VEC; ++j) acc[j] = br[j];
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
       const int dy = t / 3 - 1, dx = t % 3 - 1;
       const int iy = py + dy, ix = px + dx;
       if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
       float xx[VEC];
-      vec_unpack<T>(*(const u32x4*)(x + (((int64_t)b * H + iy) * W + ix) * C + c0), xx);
-      const int tw = MODE == 0 ? t : 8 - t;
+      vec_unpack<T>(*(const u32x4*)(x + (p + (int64_t)dy * W + dx) * C + c0), xx);
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) acc[j] += xx[j] * w[(c0 + j) * 9 + tw];
+      for (int j = 0; j < VEC; ++j) acc[j] += xx[j] * wr[t][j];
     }
-    *(u32x4*)(z + v * VEC) = vec_pack<T>(acc);
+    *(u32x4*)(z + p * C + c0) = vec_pack<T>(acc);
     if (MODE == 0) {
 #pragma unroll
       for (int j = 0; j < VEC; ++j) acc[j] = gelu_f(ElemTraits<T>::cvt(acc[j]));
-      *(u32x4*)(g + v * VEC) = vec_pack<T>(acc);
+      *(u32x4*)(g + p * C + c0) = vec_pack<T>(acc);
     }
   }
 }
@@ -599,22 +610,24 @@ int ksmi_dwconv3x3_gelu_forward(const void* x, const float* w, const float* bias
                                 int dtype, void* stream) {
   const int vec = dtype == KSMI_BF16 ? 8 : 4;
   if (C % vec) return ksmi_fail(KSMI_E_ARG, "dwconv: C must be a multiple of the 16-byte vector");
-  const int64_t n = (int64_t)B * H * W * (C / vec);
   hipStream_t st = (hipStream_t)stream;
+  const int ppb = 128;
+  const dim3 grid((unsigned)(((int64_t)B * H * W + ppb - 1) / ppb), (C / vec + 31) / 32);
   KSMI_DT(dtype,
-          hipLaunchKernelGGL((dwconv3x3_kernel<bf16_t, 0>), dim3(grid_for(n, 65536)), dim3(256), 0, st, (const bf16_t*)x, w, bias, (bf16_t*)z, (bf16_t*)g, B, H, W, C),
-          hipLaunchKernelGGL((dwconv3x3_kernel<float, 0>), dim3(grid_for(n, 65536)), dim3(256), 0, st, (const float*)x, w, bias, (float*)z, (float*)g, B, H, W, C));
+          hipLaunchKernelGGL((dwconv3x3_kernel<bf16_t, 0>), grid, dim3(256), 0, st, (const bf16_t*)x, w, bias, (bf16_t*)z, (bf16_t*)g, B, H, W, C, ppb),
+          hipLaunchKernelGGL((dwconv3x3_kernel<float, 0>), grid, dim3(256), 0, st, (const float*)x, w, bias, (float*)z, (float*)g, B, H, W, C, ppb));
   return ksmi_check_launch("dwconv3x3_gelu_fwd");
 }
 
 int ksmi_dwconv3x3_backward_input(const void* dz, const float* w, void* dx, int B, int H, int W, int C, int dtype, void* stream) {
   const int vec = dtype == KSMI_BF16 ? 8 : 4;
   if (C % vec) return ksmi_fail(KSMI_E_ARG, "dwconv: C must be a multiple of the 16-byte vector");
-  const int64_t n = (int64_t)B * H * W * (C / vec);
   hipStream_t st = (hipStream_t)stream;
+  const int ppb = 128;
+  const dim3 grid((unsigned)(((int64_t)B * H * W + ppb - 1) / ppb), (C / vec + 31) / 32);
   KSMI_DT(dtype,
-          hipLaunchKernelGGL((dwconv3x3_kernel<bf16_t, 1>), dim3(grid_for(n, 65536)), dim3(256), 0, st, (const bf16_t*)dz, w, (const float*)nullptr, (bf16_t*)dx, (bf16_t*)nullptr, B, H, W, C),
-          hipLaunchKernelGGL((dwconv3x3_kernel<float, 1>), dim3(grid_for(n, 65536)), dim3(256), 0, st, (const float*)dz, w, (const float*)nullptr, (float*)dx, (float*)nullptr, B, H, W, C));
+          hipLaunchKernelGGL((dwconv3x3_kernel<bf16_t, 1>), grid, dim3(256), 0, st, (const bf16_t*)dz, w, (const float*)nullptr, (bf16_t*)dx, (bf16_t*)nullptr, B, H, W, C, ppb),
+          hipLaunchKernelGGL((dwconv3x3_kernel<float, 1>), grid, dim3(256), 0, st, (const float*)dz, w, (const float*)nullptr, (float*)dx, (float*)nullptr, B, H, W, C, ppb));
   return ksmi_check_launch("dwconv3x3_bwd_input");
 }
 

@@ -15,38 +15,48 @@ constexpr int kThreads = 256;
 // ------------------------------------------------------------------------------------------------
 // LayerNorm over the last dim: one wave per row (vision_transformer.py:22,43,72,124,126; eps 1e-5)
 // ------------------------------------------------------------------------------------------------
-template <typename T, int MAXV>
+// sum over the LPR consecutive lanes that share a row (LPR = 8, 16, 32 or 64)
+template <int LPR> __device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// LPR lanes per row, 64/LPR rows per wave (narrow rows: C = 64 keeps all lanes busy with 8 rows per wave), MAXV vectors per lane
+template <typename T, int MAXV, int LPR>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* x, const float* gamma, const float* beta, T* y,
                                                             float* mean, float* rstd, int rows, int C, float eps) {
-  constexpr int VEC = ElemTraits<T>::kVec;
+  constexpr int VEC = ElemTraits<T>::kVec, RPW = 64 / LPR;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int row = blockIdx.x * 4 + wave;
-  if (row >= rows) return;
+  const int sl = lane % LPR;
+  const int row = (blockIdx.x * 4 + wave) * RPW + lane / LPR;
+  const bool rok = row < rows;
   const int nv = C / VEC;
   float v[MAXV][VEC];
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
-    const int q = lane + i * 64;
-    if (q < nv) {
+    const int q = sl + i * LPR;
+    if (rok && q < nv) {
       vec_unpack<T>(*(const u32x4*)(x + (size_t)row * C + q * VEC), v[i]);
 #pragma unroll
       for (int j = 0; j < VEC; ++j) s += v[i][j];
     }
   }
-  const float mu = wave_sum(s) / (float)C;
+  const float mu = group_sum<LPR>(s) / (float)C;
   float q2 = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i)
-    if (lane + i * 64 < nv) {
+    if (rok && sl + i * LPR < nv) {
 #pragma unroll
       for (int j = 0; j < VEC; ++j) { const float dlt = v[i][j] - mu; q2 += dlt * dlt; }
     }
-  const float rs = 1.0f / sqrtf(wave_sum(q2) / (float)C + eps);
-  if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+  const float rs = 1.0f / sqrtf(group_sum<LPR>(q2) / (float)C + eps);
+  if (!rok) return;
+  if (sl == 0) { mean[row] = mu; rstd[row] = rs; }
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
-    const int q = lane + i * 64;
+    const int q = sl + i * LPR;
     if (q < nv) {
       float o[VEC];
 #pragma unroll
@@ -57,12 +67,13 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* x, const fl
 }
 
 // dx = rstd*(g*dy - mean(g*dy) - xhat*mean(g*dy*xhat)); partial[blk][0][c] = sum dy, [1][c] = sum dy*xhat
-template <typename T, int MAXV>
+template <typename T, int MAXV, int LPR>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dy, const T* x, const float* mean, const float* rstd,
                                                             const float* gamma, T* dx, int accumulate, float* partial,
                                                             int rows, int C, int rows_per_block) {
-  constexpr int VEC = ElemTraits<T>::kVec;
+  constexpr int VEC = ElemTraits<T>::kVec, RPW = 64 / LPR;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sl = lane % LPR, rslot = lane / LPR;
   const int nv = C / VEC;
   float gsum[MAXV][VEC], bsum[MAXV][VEC], gam[MAXV][VEC];
 #pragma unroll
@@ -70,19 +81,21 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dy, const T
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
       gsum[i][j] = 0.f; bsum[i][j] = 0.f;
-      const int q = lane + i * 64;
+      const int q = sl + i * LPR;
       gam[i][j] = q < nv ? gamma[q * VEC + j] : 0.f;
     }
   const int r0 = blockIdx.x * rows_per_block;
   const int r1 = min(rows, r0 + rows_per_block);
-  for (int row = r0 + wave; row < r1; row += 4) {
-    const float mu = mean[row], rs = rstd[row];
+  for (int rb = r0 + wave * RPW; rb < r1; rb += 4 * RPW) {
+    const int row = rb + rslot;
+    const bool rok = row < r1;
+    const float mu = rok ? mean[row] : 0.f, rs = rok ? rstd[row] : 0.f;
     float g[MAXV][VEC], xh[MAXV][VEC];
     float a = 0.f, b = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
-      const int q = lane + i * 64;
-      if (q < nv) {
+      const int q = sl + i * LPR;
+      if (rok && q < nv) {
         float xv[VEC];
         vec_unpack<T>(*(const u32x4*)(dy + (size_t)row * C + q * VEC), g[i]);
         vec_unpack<T>(*(const u32x4*)(x + (size_t)row * C + q * VEC), xv);
@@ -95,11 +108,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dy, const T
         }
       }
     }
-    a = wave_sum(a) / (float)C; b = wave_sum(b) / (float)C;
+    a = group_sum<LPR>(a) / (float)C; b = group_sum<LPR>(b) / (float)C;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
-      const int q = lane + i * 64;
-      if (q < nv) {
+      const int q = sl + i * LPR;
+      if (rok && q < nv) {
         float o[VEC];
         T* dp = dx + (size_t)row * C + q * VEC;
         if (accumulate) vec_unpack<T>(*(const u32x4*)dp, o);
@@ -112,14 +125,20 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dy, const T
       }
     }
   }
-  // combine the 4 waves through LDS, write partial[blk][2][C]
+  // combine the row slots of a wave (lanes sl, sl + LPR, ...) by shuffles, then the 4 waves through LDS: partial[blk][2][C]
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i)
+#pragma unroll
+    for (int j = 0; j < VEC; ++j)
+#pragma unroll
+      for (int o = LPR; o < 64; o <<= 1) { bsum[i][j] += __shfl_xor(bsum[i][j], o, 64); gsum[i][j] += __shfl_xor(gsum[i][j], o, 64); }
   extern __shared__ float red[];                 // [2][C]
   for (int ph = 0; ph < 4; ++ph) {
     __syncthreads();
-    if (wave == ph) {
+    if (wave == ph && rslot == 0) {
 #pragma unroll
       for (int i = 0; i < MAXV; ++i) {
-        const int q = lane + i * 64;
+        const int q = sl + i * LPR;
         if (q < nv)
 #pragma unroll
           for (int j = 0; j < VEC; ++j) {
@@ -480,20 +499,53 @@ int grid_for(int64_t n, int cap = 8192) {
     else return ksmi_fail(KSMI_E_ARG, "bad dtype");                          \
   } while (0)
 
+// (MAXV, LPR) by the number of 16-byte vectors per row
+#define KSMI_LN_DISPATCH(nv_, CALL)                                                         \
+  do {                                                                                      \
+    if ((nv_) <= 8) { CALL(1, 8); }                                                         \
+    else if ((nv_) <= 16) { CALL(1, 16); }                                                  \
+    else if ((nv_) <= 32) { CALL(1, 32); }                                                  \
+    else if ((nv_) <= 64) { CALL(1, 64); }                                                  \
+    else if ((nv_) <= 128) { CALL(2, 64); }                                                 \
+    else if ((nv_) <= 256) { CALL(4, 64); }                                                 \
+    else { CALL(8, 64); }                                                                   \
+  } while (0)
+
+template <typename T>
+void layernorm_fwd_launch(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int rows, int C,
+                          float eps, hipStream_t st) {
+  const int nv = C / ElemTraits<T>::kVec;
+#define KSMI_LN_FWD(MAXV_, LPR_)                                                                                           \
+  hipLaunchKernelGGL((layernorm_fwd_kernel<T, MAXV_, LPR_>), dim3((rows + 4 * (64 / LPR_) - 1) / (4 * (64 / LPR_))), dim3(256), 0, st, \
+                     (const T*)x, gamma, beta, (T*)y, mean, rstd, rows, C, eps)
+  KSMI_LN_DISPATCH(nv, KSMI_LN_FWD);
+#undef KSMI_LN_FWD
+}
+
+template <typename T>
+void layernorm_bwd_launch(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma, void* dx, int accumulate,
+                          float* partial, int rows, int C, int nblk, int rpb, hipStream_t st) {
+  const int nv = C / ElemTraits<T>::kVec;
+  const size_t lds = (size_t)2 * C * sizeof(float);
+#define KSMI_LN_BWD(MAXV_, LPR_)                                                                                           \
+  hipLaunchKernelGGL((layernorm_bwd_kernel<T, MAXV_, LPR_>), dim3(nblk), dim3(256), lds, st, (const T*)dy, (const T*)x, mean, rstd, gamma, \
+                     (T*)dx, accumulate, partial, rows, C, rpb)
+  KSMI_LN_DISPATCH(nv, KSMI_LN_BWD);
+#undef KSMI_LN_BWD
+}
+
 extern "C" {
 
 int ksmi_layernorm_forward(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                            int rows, int C, float eps, int dtype, void* stream) {
   const int vec = dtype == KSMI_BF16 ? 8 : 4;
   if (C % vec || C / vec > 64 * 8) return ksmi_fail(KSMI_E_ARG, "layernorm: C must be a multiple of the vector and <= 512 vectors");
-  const dim3 grid((rows + 3) / 4);
-  KSMI_DT(dtype,
-          hipLaunchKernelGGL((layernorm_fwd_kernel<bf16_t, 8>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, rows, C, eps),
-          hipLaunchKernelGGL((layernorm_fwd_kernel<float, 8>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, gamma, beta, (float*)y, mean, rstd, rows, C, eps));
+  KSMI_DT(dtype, layernorm_fwd_launch<bf16_t>(x, gamma, beta, y, mean, rstd, rows, C, eps, (hipStream_t)stream),
+          layernorm_fwd_launch<float>(x, gamma, beta, y, mean, rstd, rows, C, eps, (hipStream_t)stream));
   return ksmi_check_launch("layernorm_fwd");
 }
 
-int ksmi_layernorm_bwd_blocks(int rows) { int b = (rows + 31) / 32; return b > 512 ? 512 : (b < 1 ? 1 : b); }
+int ksmi_layernorm_bwd_blocks(int rows) { int b = (rows + 7) / 8; return b > 1024 ? 1024 : (b < 1 ? 1 : b); }
 
 int ksmi_layernorm_backward(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma, void* dx,
                             int accumulate, float* partial, int rows, int C, int dtype, void* stream) {
@@ -501,10 +553,8 @@ int ksmi_layernorm_backward(const void* dy, const void* x, const float* mean, co
   if (C % vec || C / vec > 64 * 8) return ksmi_fail(KSMI_E_ARG, "layernorm_bwd: unsupported C");
   const int nblk = ksmi_layernorm_bwd_blocks(rows);
   const int rpb = (rows + nblk - 1) / nblk;
-  const size_t lds = (size_t)2 * C * sizeof(float);
-  KSMI_DT(dtype,
-          hipLaunchKernelGGL((layernorm_bwd_kernel<bf16_t, 8>), dim3(nblk), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x, mean, rstd, gamma, (bf16_t*)dx, accumulate, partial, rows, C, rpb),
-          hipLaunchKernelGGL((layernorm_bwd_kernel<float, 8>), dim3(nblk), dim3(256), lds, (hipStream_t)stream, (const float*)dy, (const float*)x, mean, rstd, gamma, (float*)dx, accumulate, partial, rows, C, rpb));
+  KSMI_DT(dtype, layernorm_bwd_launch<bf16_t>(dy, x, mean, rstd, gamma, dx, accumulate, partial, rows, C, nblk, rpb, (hipStream_t)stream),
+          layernorm_bwd_launch<float>(dy, x, mean, rstd, gamma, dx, accumulate, partial, rows, C, nblk, rpb, (hipStream_t)stream));
   return ksmi_check_launch("layernorm_bwd");
 }
 

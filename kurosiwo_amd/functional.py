@@ -262,7 +262,7 @@ def dwconv3x3_backward(x, dz, weight):
     lib = _lib.load()
     dx = torch.empty_like(x)
     _lib.check(lib.ksmi_dwconv3x3_backward_input(dz.data_ptr(), weight.data_ptr(), dx.data_ptr(), B, H, W, Cc, DT[x.dtype], stream_ptr()), "dwconv_bwd")
-    rows = max(1, min(256, B * H * W // 64))
+    rows = max(1, min(1024, B * H * W // 16))
     partial = torch.empty((rows, 10 * Cc), dtype=torch.float32, device=x.device)
     _lib.check(lib.ksmi_dwconv3x3_wgrad(x.data_ptr(), dz.data_ptr(), partial.data_ptr(), rows, B, H, W, Cc, DT[x.dtype], stream_ptr()), "dwconv_wgrad")
     dw = torch.empty((Cc, 1, 3, 3), dtype=torch.float32, device=x.device)
