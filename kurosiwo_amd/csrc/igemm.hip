@@ -585,6 +585,34 @@ __global__ __launch_bounds__(256) void gemm_tn_wgrad_kernel(const ksmi_wgrad_des
     }
 }
 
+// split reduction of the token-GEMM path: float4 per thread along n (coalesced slab reads), fixed summation order
+__global__ void tn_reduce_kernel(const ksmi_wgrad_desc d, int KC, int K) {
+  const int Npad = (d.N + 15) & ~15, NV = Npad / 4;
+  const size_t total = (size_t)K * NV, slab = (size_t)K * Npad;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int krow = i / NV, n4 = (int)(i - (size_t)krow * NV) * 4;
+    const int ch = krow / KC, kc = krow - ch * KC;
+    const int koff = d.uniform_kc ? ch * d.uniform_kc : d.k_off[ch];
+    const int klen = d.uniform_kc ? min(d.uniform_kc, d.k_total - koff) : d.k_len[ch];
+    if (kc >= klen) continue;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    const float* p = d.partial + (size_t)krow * Npad + n4;
+    for (int sp = 0; sp < d.nsplit; ++sp) {
+      const f32x4 v = *(const f32x4*)(p + (size_t)sp * slab);
+      s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+    }
+    const int64_t k = koff + kc;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n4 + j;
+      if (n < d.N) {
+        float* g = d.grad + k * d.gK + (int64_t)n * d.gN;
+        *g = d.accumulate ? *g + s[j] : s[j];
+      }
+    }
+  }
+}
+
 // eligibility of the token-GEMM path and its split geometry
 static bool gemm_tn_eligible(const ksmi_wgrad_desc* d, int es) {
   return es == 2 && d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && d->nsrc == 1 && d->src[0].scale == nullptr &&
@@ -641,10 +669,10 @@ int launch_wgrad(const ksmi_wgrad_desc* d, hipStream_t st) {
     hipLaunchKernelGGL(gemm_tn_wgrad_kernel, dim3(g.tk, g.tnn, g.nsplit), dim3(256), 0, st, *d, d->B * d->Hout * d->Wout, g.rps, d->nchunks * g.kc);
     int rc0 = ksmi_check_launch("gemm_tn_wgrad");
     if (rc0) return rc0;
-    const size_t total0 = (size_t)d->nchunks * g.kc * g.npad;
-    int blocks0 = (int)((total0 * 8 + 255) / 256); if (blocks0 > 4096) blocks0 = 4096;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks0), dim3(256), 0, st, *d, 1, g.kc);
-    return ksmi_check_launch("wgrad_reduce");
+    const size_t total0 = (size_t)d->nchunks * g.kc * g.npad / 4;
+    int blocks0 = (int)((total0 + 255) / 256); if (blocks0 > 8192) blocks0 = 8192;
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3(blocks0), dim3(256), 0, st, *d, g.kc, d->nchunks * g.kc);
+    return ksmi_check_launch("tn_reduce");
   }
   const dim3 grid(g.nsplit, d->nchunks, g.ntiles);
 #define KSMI_LAUNCH_WG(NT_, KH_, KW_)                                                               \

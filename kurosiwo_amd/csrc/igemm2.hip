@@ -253,7 +253,9 @@ int launch2(const ksmi_conv_desc* d, int dbg, hipStream_t st) {
   if (d->TH * d->TW > 256 || HP * 4 > 2048) return ksmi_fail(KSMI_E_ARG, "conv: patch too large (TH*TW<=256, halo<=512 px)");
   static const int nt_cap = getenv("KSMI_NT_CAP") ? atoi(getenv("KSMI_NT_CAP")) : 2;      // BN=32: 80 KB of LDS = 2 workgroups per CU beats the BN=64 tile (1 per CU) by 15-35 %
   int nt = d->Npad >= 64 ? 4 : (d->Npad >= 32 ? 2 : 1);
-  if (nt > nt_cap) nt = nt_cap;
+  // token GEMMs (1x1) keep both a small halo (16 KB) and a small weight slab: BN = 64 still leaves 2 workgroups per CU
+  static const int nt_cap11 = getenv("KSMI_NT_CAP_1X1") ? atoi(getenv("KSMI_NT_CAP_1X1")) : 2;
+  if (nt > (taps == 1 ? nt_cap11 : nt_cap)) nt = taps == 1 ? nt_cap11 : nt_cap;
   const int bn = nt * 16;
   const dim3 grid(gm, (d->Npad + bn - 1) / bn);
   const size_t hpb = ((size_t)HP * 64 + 1023) & ~(size_t)1023;
