@@ -339,6 +339,17 @@ int ksmi_affine(const void* x, const float* scale, const float* shift, void* y, 
 int ksmi_out_to_nchw(const void* x, float* y, int B, int C, int Cs, int64_t HW, int act, int dtype, void* stream);
 int ksmi_dout_to_nhwc(const float* dy, const float* y, void* dx, int B, int C, int Cs, int64_t HW, int act, int dtype, void* stream);
 
+/* ---------------------------------------------------------------------------------
+ * Token GEMMs (bf16) = nn.Linear forward / input gradient on 128x128 MFMA tiles (csrc/gemm.hip).  `w` is the bf16 mirror of the
+ * fp32 parameter (ksmi_cast_bf16 of the arena once per step), row-major [N][K] with row stride w_rs; strides in elements.
+ * ------------------------------------------------------------------------------- */
+int ksmi_cast_bf16(const float* src, void* dst, int64_t n, void* stream);
+/* y[rows][N] = x[rows][K] w^T + bias (+ resid) */
+int ksmi_gemm_nt(const void* x, int x_rs, const void* w, int w_rs, const float* bias, const void* resid, int r_rs, void* y, int y_rs,
+                 int rows, int K, int N, void* stream);
+/* dx[rows][K] (+)= dy[rows][N] w */
+int ksmi_gemm_nn(const void* dy, int dy_rs, const void* w, int w_rs, void* dx, int dx_rs, int rows, int K, int N, int accumulate, void* stream);
+
 /* plumbing */
 int ksmi_fill_zero(void* p, size_t bytes, void* stream);
 /* NCHW fp32 -> NHWC dtype and back (tests / debugging only) */

@@ -117,6 +117,9 @@ SIGNATURES = {
     "ksmi_add": (_i, [_vp, _vp, _vp, _i64, _i, _vp]),
     "ksmi_relu_backward": (_i, [_vp, _vp, _vp, _i64, _i, _vp]),
     "ksmi_relu_forward": (_i, [_vp, _vp, _i64, _i, _vp]),
+    "ksmi_cast_bf16": (_i, [_vp, _vp, _i64, _vp]),
+    "ksmi_gemm_nt": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
+    "ksmi_gemm_nn": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     "ksmi_im2col": (_i, [_vp, _vp] + [_i] * 11 + [_i, _i, _vp]),
     "ksmi_col2im": (_i, [_vp, _vp, _i] + [_i] * 11 + [_i, _vp]),
     "ksmi_affine": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, C.c_float, _i, _vp]),

@@ -45,7 +45,7 @@ class ArenaModule(nn.Module):
         offs, o = OrderedDict(), 0
         for k, shp in self._pspec.items():
             offs[k] = o
-            o += -(-max(_numel(shp), 1) // 4) * 4            # 16-byte aligned views
+            o += -(-max(_numel(shp), 1) // 8) * 8            # 32-byte aligned views (16-byte aligned rows in the bf16 mirror)
         self._poff = offs
         self.flat_params = torch.zeros(o, dtype=torch.float32, device=device)
         self.flat_grads = torch.zeros(o, dtype=torch.float32, device=device)

@@ -669,6 +669,12 @@ int launch_wgrad(const ksmi_wgrad_desc* d, hipStream_t st) {
     hipLaunchKernelGGL(gemm_tn_wgrad_kernel, dim3(g.tk, g.tnn, g.nsplit), dim3(256), 0, st, *d, d->B * d->Hout * d->Wout, g.rps, d->nchunks * g.kc);
     int rc0 = ksmi_check_launch("gemm_tn_wgrad");
     if (rc0) return rc0;
+    if (g.nsplit > 16) {      // many thin slabs (small matrices): the 8-lanes-per-element tree reducer hides the slab walk better
+      const size_t totalr = (size_t)d->nchunks * g.kc * g.npad;
+      int blocksr = (int)((totalr * 8 + 255) / 256); if (blocksr > 4096) blocksr = 4096;
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocksr), dim3(256), 0, st, *d, 1, g.kc);
+      return ksmi_check_launch("wgrad_reduce");
+    }
     const size_t total0 = (size_t)d->nchunks * g.kc * g.npad / 4;
     int blocks0 = (int)((total0 + 255) / 256); if (blocks0 > 8192) blocks0 = 8192;
     hipLaunchKernelGGL(tn_reduce_kernel, dim3(blocks0), dim3(256), 0, st, *d, g.kc, d->nchunks * g.kc);

@@ -305,3 +305,31 @@ def bilinear_backward(dy, Hi, Wi, out=None):
         out = torch.empty((B, Hi, Wi, Cc), dtype=dy.dtype, device=dy.device)
     _lib.check(_lib.load().ksmi_bilinear_backward(dy.data_ptr(), out.data_ptr(), acc, B, Hi, Wi, Ho, Wo, Cc, DT[dy.dtype], stream_ptr()), "bilinear_bwd")
     return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# token GEMMs on the 128x128 MFMA tiles (gemm.hip, bf16)
+# ---------------------------------------------------------------------------------------------------
+def cast_bf16(w):
+    out = torch.empty(w.shape, dtype=torch.bfloat16, device=w.device)
+    _lib.check(_lib.load().ksmi_cast_bf16(w.data_ptr(), out.data_ptr(), w.numel(), stream_ptr()), "cast_bf16")
+    return out
+
+
+def gemm_nt(x, wb, bias=None, resid=None):
+    rows, K = x.shape
+    N = wb.shape[0]
+    y = torch.empty((rows, N), dtype=torch.bfloat16, device=x.device)
+    _lib.check(_lib.load().ksmi_gemm_nt(x.data_ptr(), K, wb.data_ptr(), K, None if bias is None else bias.data_ptr(),
+                                        None if resid is None else resid.data_ptr(), N, y.data_ptr(), N, rows, K, N, stream_ptr()), "gemm_nt")
+    return y
+
+
+def gemm_nn(dy, wb, out=None):
+    rows, N = dy.shape
+    K = wb.shape[1]
+    acc = 0 if out is None else 1
+    if out is None:
+        out = torch.empty((rows, K), dtype=torch.bfloat16, device=dy.device)
+    _lib.check(_lib.load().ksmi_gemm_nn(dy.data_ptr(), N, wb.data_ptr(), K, out.data_ptr(), K, rows, K, N, acc, stream_ptr()), "gemm_nn")
+    return out

@@ -22,6 +22,18 @@ class PlanBase:
         self.param_ready = {}
         self.named = {}            # debug/test access to intermediate activations
         self._need, self._bufs, self._later = {}, {}, []
+        # bf16 mirror of the parameter arena for the token GEMMs (gemm.hip): one cast launch per step
+        import os
+        self.wb = None
+        if dtype == torch.bfloat16 and not os.environ.get("KSMI_LINEAR_IGEMM"):
+            n = model.flat_params.numel()
+            assert n % 8 == 0
+            self.wb = torch.empty(n, dtype=torch.bfloat16, device=self.dev)
+            fp, wb = model.flat_params, self.wb
+            self.packs.add("ksmi_cast_bf16", lambda: (fp.data_ptr(), wb.data_ptr(), n), {"kind": "cast_bf16", "bytes": 6 * n, "flops": 0})
+
+    def _wb_ptr(self, key):
+        return self.wb.data_ptr() + 2 * self.m._poff[key]
 
     def _finish(self):
         if self._pack_descs:
@@ -107,6 +119,15 @@ class PlanBase:
     def _linear(self, name, x, Cin, wkey, bkey, out, N, rows, resid=None, k_real=None):
         """out[rows, N] = x[rows, Cin] @ W[N, k_real]^T + b [+ resid]; columns of x beyond k_real (default Cin) are zero padding."""
         kr = Cin if k_real is None else k_real
+        if self.wb is not None and kr == Cin and Cin % 8 == 0 and N % 8 == 0:
+            wp = self._wb_ptr(wkey)
+            bp = self.m._p(bkey).data_ptr() if bkey else None
+            es = 2
+            meta = {"kind": "gemm_nt", "bytes": (rows * Cin + rows * N * (2 if resid is not None else 1) + N * Cin) * es,
+                    "flops": 2 * rows * N * Cin, "tag": f"{name} K={Cin} N={N} M={rows}"}
+            self.fwd.add("ksmi_gemm_nt", lambda: (x.data_ptr(), Cin, wp, Cin, bp, None if resid is None else resid.data_ptr(), N,
+                                                  out.data_ptr(), N, rows, Cin, N), meta)
+            return
         d, table = make_conv([SrcSpec(x, Cin, k_real=kr)], [(out, N, 0, 0, N, 0)], out, self.m._p(bkey) if bkey else None, None,
                              1, rows, 1, rows, 1, 1, 1, 1, 0, N, self.dtype, resid=None if resid is None else (resid, N))
         d.wpk = self._packed(wkey, table, 1, N, N, 1, kr, 0, 0).data_ptr()
@@ -125,7 +146,12 @@ class PlanBase:
     def _linear_bwd(self, name, x, Cin, wkey, bkey, dy, N, rows, dx, want_w=True, dx_acc=0, k_real=None):
         """dx (+)= dy @ W (skipped if dx is None) ; dW = dy^T x ; db = colsum(dy)"""
         kr = Cin if k_real is None else k_real
-        if dx is not None:
+        if dx is not None and self.wb is not None and kr == Cin and Cin % 8 == 0 and N % 8 == 0:
+            wp = self._wb_ptr(wkey)
+            meta = {"kind": "gemm_nn", "bytes": (rows * N + rows * Cin * (2 if dx_acc else 1) + N * Cin) * 2,
+                    "flops": 2 * rows * N * Cin, "tag": f"{name} K={N} N={Cin} M={rows}"}
+            self.bwd.add("ksmi_gemm_nn", lambda: (dy.data_ptr(), N, wp, Cin, dx.data_ptr(), Cin, rows, Cin, N, dx_acc), meta)
+        elif dx is not None:
             d, table = make_conv([SrcSpec(dy, N)], [(dx, Cin, 0, 0, Cin, dx_acc)], dx, None, None,
                                  1, rows, 1, rows, 1, 1, 1, 1, 0, Cin, self.dtype)
             d.wpk = self._packed(wkey, table, 1, Cin, Cin, Cin, 1, 0, 0).data_ptr()

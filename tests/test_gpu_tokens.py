@@ -105,3 +105,29 @@ def test_attention(dev, dtype, B, N, H):
     assert (out.float().cpu() - o_ref.detach()).abs().max() < tol * o_ref.abs().max()
     dqkv = Fk.attention_backward(qd, out, lse, dout.to(dev).to(dtype), B, N, H)
     assert (dqkv.float().cpu() - qr.grad).abs().max() < tol * qr.grad.abs().max()
+
+
+@pytest.mark.parametrize("rows,K,N", [(3152, 1024, 3072), (3152, 2048, 1024), (394, 1536, 1024), (200704, 64, 256), (98, 512, 2048), (50, 320, 40)])
+def test_gemm_nt_nn_bf16(dev, rows, K, N):
+    """128x128-tile token GEMMs vs torch (bf16 operands, fp32 accumulation)."""
+    from kurosiwo_amd import functional as Fk
+    torch.manual_seed(rows + K)
+    x = (torch.randn(rows, K, device=dev) * 0.5).bfloat16()
+    w = torch.randn(N, K, device=dev) * K ** -0.5
+    b = torch.randn(N, device=dev)
+    res = torch.randn(rows, N, device=dev).bfloat16()
+    wb = Fk.cast_bf16(w)
+    assert torch.equal(wb, w.bfloat16())
+    ref = x.float() @ wb.float().t() + b
+    y = Fk.gemm_nt(x, wb, b)
+    assert float((y.float() - ref).abs().max() / ref.abs().max()) < 1e-2
+    y2 = Fk.gemm_nt(x, wb, None, res)
+    ref2 = x.float() @ wb.float().t() + res.float()
+    assert float((y2.float() - ref2).abs().max() / ref2.abs().max()) < 1e-2
+    dy = (torch.randn(rows, N, device=dev) * 0.5).bfloat16()
+    refd = dy.float() @ wb.float()
+    dx = Fk.gemm_nn(dy, wb)
+    assert float((dx.float() - refd).abs().max() / refd.abs().max()) < 1e-2
+    base = torch.randn(rows, K, device=dev).bfloat16()
+    dx2 = Fk.gemm_nn(dy, wb, out=base.clone())
+    assert float((dx2.float() - (refd + base.float())).abs().max() / refd.abs().max()) < 2e-2
