@@ -26,8 +26,8 @@ struct GemmP {
 };
 
 // lane's 16 consecutive outputs (acc[t][.][r], t = 0..3) of row m -> two 16-byte stores
-template <int NTW>
-__device__ __forceinline__ void store_row(const GemmP& p, const f32x4 (&acc)[4][4], int mt, int m, int c0, int ncols, bool has_bias, const float* bias16) {
+template <int MT>
+__device__ __forceinline__ void store_row(const GemmP& p, const f32x4 (&acc)[4][MT], int mt, int m, int c0, int ncols, bool has_bias, const float* bias16) {
   if (m >= p.rows) return;
   float v[16];
 #pragma unroll
@@ -63,21 +63,29 @@ __device__ __forceinline__ void store_row(const GemmP& p, const f32x4 (&acc)[4][
 }
 
 // ---------------------------------------------------------------------------------------------- forward (NT)
-// WG tile: 128 rows x 128 output channels; wave (wn, wm) = 64 channels x 64 rows = 4 x 4 MFMA tiles
+// WG tile: 128 rows x TN output channels.  TN = 128: wave (wn, wm) = 64 channels x 64 rows (4 x 4 MFMA tiles); TN = 64 (grids that
+// would not fill the chip with 128-wide tiles): wave wm = 64 channels x 32 rows (4 x 2 tiles)
+template <int TN>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
-  constexpr int TM = 128, TN = 128, KS = 32;
+  constexpr int TM = 128, KS = 32, MT = TN == 128 ? 4 : 2;
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (TM + TN) * 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
-  const int wn = wave >> 1, wm = wave & 1;
+  const int wn = TN == 128 ? wave >> 1 : 0, wm = TN == 128 ? wave & 1 : wave;
   const int m0 = blockIdx.x * TM, n0 = blockIdx.y * TN;
   const int nsteps = (p.K + KS - 1) / KS;
-  u32x4 rx[2], rw[2];
+  constexpr int WV = TN / 64;                                  // W-tile vectors per thread
+  u32x4 rx[2], rw[WV];
   auto gload = [&](int s) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int v = tid + i * 256, r = v >> 2, q = v & 3;
       const int k = s * KS + q * 8;
       rx[i] = ldv(p.a + (size_t)(m0 + r) * p.a_rs + k, m0 + r < p.rows && k < p.K);
+    }
+#pragma unroll
+    for (int i = 0; i < WV; ++i) {
+      const int v = tid + i * 256, r = v >> 2, q = v & 3;
+      const int k = s * KS + q * 8;
       // LDS row r (= MFMA row index nt*16 + g*4 + rr within the 64-row half) holds channel g*16 + nt*4 + rr
       const int h = r >> 6, j = r & 63;
       const int nloc = h * 64 + ((j >> 2) & 3) * 16 + (j >> 4) * 4 + (j & 3);
@@ -91,14 +99,18 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
     for (int i = 0; i < 2; ++i) {
       const int v = tid + i * 256, r = v >> 2, q = v & 3;
       *(u32x4*)(bx + r * 64 + ((q ^ swz4(r)) << 4)) = rx[i];
+    }
+#pragma unroll
+    for (int i = 0; i < WV; ++i) {
+      const int v = tid + i * 256, r = v >> 2, q = v & 3;
       *(u32x4*)(bw + r * 64 + ((q ^ swz4(r)) << 4)) = rw[i];
     }
   };
-  f32x4 acc[4][4];
+  f32x4 acc[4][MT];
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < MT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
   gload(0); lstore(0);
   __syncthreads();
   for (int s = 0; s < nsteps; ++s) {
@@ -106,17 +118,21 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
     if (more) gload(s + 1);
     const unsigned char* bx = smem + (s & 1) * (TM + TN) * 64;
     const unsigned char* bw = bx + TM * 64;
-    u32x4 fx[4], fw[4];
+    u32x4 fx[MT], fw[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const int rx_ = wm * 64 + t * 16 + l15, rw_ = wn * 64 + t * 16 + l15;
-      fx[t] = *(const u32x4*)(bx + rx_ * 64 + ((g ^ swz4(rx_)) << 4));
+      const int rw_ = wn * 64 + t * 16 + l15;
       fw[t] = *(const u32x4*)(bw + rw_ * 64 + ((g ^ swz4(rw_)) << 4));
+    }
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      const int rx_ = wm * 16 * MT + t * 16 + l15;
+      fx[t] = *(const u32x4*)(bx + rx_ * 64 + ((g ^ swz4(rx_)) << 4));
     }
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-      for (int b = 0; b < 4; ++b) mma16<bf16_t>(acc[a][b], fw[a], fx[b]);     // rows = channels, cols = token rows
+      for (int b = 0; b < MT; ++b) mma16<bf16_t>(acc[a][b], fw[a], fx[b]);    // rows = channels, cols = token rows
     if (more) lstore((s + 1) & 1);
     __syncthreads();
   }
@@ -128,19 +144,21 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmP p) {
     for (int j = 0; j < 16; ++j) bias16[j] = c0 + j < p.N ? p.bias[c0 + j] : 0.f;
   if (c0 >= p.N) return;
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt) store_row<4>(p, acc, mt, m0 + wm * 64 + mt * 16 + l15, c0, p.N, has_bias, bias16);
+  for (int mt = 0; mt < MT; ++mt) store_row<MT>(p, acc, mt, m0 + wm * 16 * MT + mt * 16 + l15, c0, p.N, has_bias, bias16);
 }
 
 // ---------------------------------------------------------------------------------------------- input gradient (NN)
 // out[m][k] = sum_n a[m][n] w[n][k]; p.K = number of output columns (k), p.N = reduction length (n)
+template <int TK>
 __global__ __launch_bounds__(256) void gemm_nn_kernel(GemmP p) {
-  constexpr int TM = 128, TK = 128, NS = 32;
+  constexpr int TM = 128, NS = 32, MT = TK == 128 ? 4 : 2, WROW = TK * 2, WVR = TK / 8;     // W tile: 32 rows of WROW bytes
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (TM * 64 + NS * TK * 2)];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
-  const int wk = wave >> 1, wm = wave & 1;
+  const int wk = TK == 128 ? wave >> 1 : 0, wm = TK == 128 ? wave & 1 : wave;
   const int m0 = blockIdx.x * TM, k0 = blockIdx.y * TK;
   const int nsteps = (p.N + NS - 1) / NS;
-  u32x4 ry[2], rw[2];
+  constexpr int WV = TK / 64, GM = WROW / 32 - 1;            // W-tile vectors per thread; granule mask of the swizzle
+  u32x4 ry[2], rw[WV];
   auto gload = [&](int s) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -148,7 +166,11 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(GemmP p) {
       const int r = v >> 2, q = v & 3;                       // dY tile: 128 rows x 4 vectors
       const int n = s * NS + q * 8;
       ry[i] = ldv(p.a + (size_t)(m0 + r) * p.a_rs + n, m0 + r < p.rows && n < p.N);
-      const int wr = v >> 4, wq = v & 15;                    // W tile: 32 rows (n) x 16 vectors (k)
+    }
+#pragma unroll
+    for (int i = 0; i < WV; ++i) {
+      const int v = tid + i * 256;
+      const int wr = v / WVR, wq = v - wr * WVR;             // W tile: 32 rows (n) x WVR vectors (k)
       rw[i] = ldv(p.w + (size_t)(s * NS + wr) * p.w_rs + k0 + wq * 8, s * NS + wr < p.N && k0 + wq * 8 < p.K);
     }
   };
@@ -160,15 +182,19 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(GemmP p) {
       const int v = tid + i * 256;
       const int r = v >> 2, q = v & 3;
       *(u32x4*)(by + r * 64 + ((q ^ swz4(r)) << 4)) = ry[i];
-      const int wr = v >> 4, wq = v & 15;
-      *(u32x4*)(bw + wr * 256 + (((wq * 16) >> 5 ^ (wr & 7)) << 5) + ((wq * 16) & 31)) = rw[i];   // 32-byte granule swizzle
+    }
+#pragma unroll
+    for (int i = 0; i < WV; ++i) {
+      const int v = tid + i * 256;
+      const int wr = v / WVR, wq = v - wr * WVR;
+      *(u32x4*)(bw + wr * WROW + (((((wq * 16) >> 5) ^ (wr & 7)) & GM) << 5) + ((wq * 16) & 31)) = rw[i];   // 32-byte granule swizzle
     }
   };
-  f32x4 acc[4][4];
+  f32x4 acc[4][MT];
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < MT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
   gload(0); lstore(0);
   __syncthreads();
   for (int s = 0; s < nsteps; ++s) {
@@ -176,18 +202,21 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(GemmP p) {
     if (more) gload(s + 1);
     const unsigned char* by = smem + (s & 1) * (TM * 64 + NS * TK * 2);
     const unsigned bw = (unsigned)(uintptr_t)(by + TM * 64);
-    u32x4 fy[4], fw[4];
+    u32x4 fy[MT], fw[4];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      const int ry_ = wm * 16 * MT + t * 16 + l15;
+      fy[t] = *(const u32x4*)(by + ry_ * 64 + ((g ^ swz4(ry_)) << 4));
+    }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const int ry_ = wm * 64 + t * 16 + l15;
-      fy[t] = *(const u32x4*)(by + ry_ * 64 + ((g ^ swz4(ry_)) << 4));
       // W^T fragment, output-column tile t: lane i = l15 is MFMA row i <-> output column wk*64 + (i>>2)*16 + t*4 + (i&3);
       // the lane's 4-column chunk (q = l15 & 3) of LDS row (n = g*8 + jr [+4]) starts at column wk*64 + q*16 + t*4
       const int jr = l15 >> 2, q = l15 & 3;
       const int cb = (wk * 64 + q * 16 + t * 4) * 2;
       const int r0 = g * 8 + jr, r1 = r0 + 4;
-      const unsigned a0 = bw + r0 * 256 + (((cb >> 5) ^ (r0 & 7)) << 5) + (cb & 31);
-      const unsigned a1 = bw + r1 * 256 + (((cb >> 5) ^ (r1 & 7)) << 5) + (cb & 31);
+      const unsigned a0 = bw + r0 * WROW + ((((cb >> 5) ^ (r0 & 7)) & GM) << 5) + (cb & 31);
+      const unsigned a1 = bw + r1 * WROW + ((((cb >> 5) ^ (r1 & 7)) & GM) << 5) + (cb & 31);
       const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(uintptr_t)a0);
       const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(uintptr_t)a1);
       fw[t][0] = (uint16_t)lo[0] | ((uint32_t)(uint16_t)lo[1] << 16);
@@ -198,7 +227,7 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(GemmP p) {
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-      for (int b = 0; b < 4; ++b) mma16<bf16_t>(acc[a][b], fw[a], fy[b]);     // rows = output columns, cols = token rows
+      for (int b = 0; b < MT; ++b) mma16<bf16_t>(acc[a][b], fw[a], fy[b]);    // rows = output columns, cols = token rows
     if (more) lstore((s + 1) & 1);
     __syncthreads();
   }
@@ -206,7 +235,7 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(GemmP p) {
   if (c0 >= p.K) return;
   float nob[16];
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt) store_row<4>(p, acc, mt, m0 + wm * 64 + mt * 16 + l15, c0, p.K, false, nob);
+  for (int mt = 0; mt < MT; ++mt) store_row<MT>(p, acc, mt, m0 + wm * 16 * MT + mt * 16 + l15, c0, p.K, false, nob);
 }
 
 __global__ void cast_bf16_kernel(const float* src, bf16_t* dst, int64_t nvec) {
@@ -237,14 +266,18 @@ int ksmi_gemm_nt(const void* x, int x_rs, const void* w, int w_rs, const float* 
                  int rows, int K, int N, void* stream) {
   if (!gemm_args_ok(x_rs, w_rs, y_rs, r_rs, K, N) || rows < 1) return ksmi_fail(KSMI_E_ARG, "gemm_nt: strides, K and N must be multiples of 8");
   GemmP p = {(const bf16_t*)x, x_rs, (const bf16_t*)w, w_rs, bias, (const bf16_t*)resid, r_rs, (bf16_t*)y, y_rs, rows, K, N, 0};
-  hipLaunchKernelGGL(gemm_nt_kernel, dim3((rows + 127) / 128, (N + 127) / 128), dim3(256), 0, (hipStream_t)stream, p);
+  const int mtiles = (rows + 127) / 128;
+  if (mtiles * ((N + 127) / 128) >= 512) hipLaunchKernelGGL(gemm_nt_kernel<128>, dim3(mtiles, (N + 127) / 128), dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(gemm_nt_kernel<64>, dim3(mtiles, (N + 63) / 64), dim3(256), 0, (hipStream_t)stream, p);
   return ksmi_check_launch("gemm_nt");
 }
 
 int ksmi_gemm_nn(const void* dy, int dy_rs, const void* w, int w_rs, void* dx, int dx_rs, int rows, int K, int N, int accumulate, void* stream) {
   if (!gemm_args_ok(dy_rs, w_rs, dx_rs, 0, K, N) || rows < 1) return ksmi_fail(KSMI_E_ARG, "gemm_nn: strides, K and N must be multiples of 8");
   GemmP p = {(const bf16_t*)dy, dy_rs, (const bf16_t*)w, w_rs, nullptr, nullptr, 0, (bf16_t*)dx, dx_rs, rows, K, N, accumulate};
-  hipLaunchKernelGGL(gemm_nn_kernel, dim3((rows + 127) / 128, (K + 127) / 128), dim3(256), 0, (hipStream_t)stream, p);
+  const int mtiles = (rows + 127) / 128;
+  if (mtiles * ((K + 127) / 128) >= 512) hipLaunchKernelGGL(gemm_nn_kernel<128>, dim3(mtiles, (K + 127) / 128), dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(gemm_nn_kernel<64>, dim3(mtiles, (K + 63) / 64), dim3(256), 0, (hipStream_t)stream, p);
   return ksmi_check_launch("gemm_nn");
 }
 
