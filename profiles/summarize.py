@@ -39,6 +39,7 @@ def counter(db, name):
 def main():
     prefix, outp = sys.argv[1], sys.argv[2]
     note = sys.argv[3] if len(sys.argv) > 3 else ""
+    cmd = sys.argv[4] if len(sys.argv) > 4 else "python bench.py --steps 5 --warmup 2 --no-cpu-baseline` (7 train steps of SNUNet-ECAM bs=32 bf16)"
     stats = glob.glob(prefix + "_stats/*.db")[0]
     times = kernel_times(stats)
     fetch = counter(glob.glob(prefix + "_fetch/*.db")[0], "FETCH_SIZE") if glob.glob(prefix + "_fetch/*.db") else {}
@@ -46,7 +47,7 @@ def main():
     tot = sum(t[2] for t in times)
     lines = ["# rocprofv3 summary: " + prefix, "", note, "",
              "`rocprofv3 --kernel-trace --stats` (+ separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes) of",
-             "`python bench.py --steps 5 --warmup 2 --no-cpu-baseline` (7 train steps of SNUNet-ECAM bs=32 bf16).", "",
+             "`" + cmd + ".  Plan construction (buffer zero fills) is included in the trace and excluded from the bench timing.", "",
              f"total kernel time {tot:.1f} ms over all dispatches", "",
              "| kernel | calls | total ms | avg us | % | FETCH_SIZE avg KB (raw) | x2 corrected MB | WRITE_SIZE avg KB (raw) |",
              "|---|---|---|---|---|---|---|---|"]
