@@ -108,8 +108,9 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
-    if world > 1:
+    if world > 1 or os.environ.get("KSMI_DP_FORCE"):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from kurosiwo_amd.synthetic import cd_inputs, make_batch, seg_inputs
@@ -231,7 +232,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.model == "snunet":
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -7,8 +7,12 @@ the last launch that writes into it.  ProcessGroupNCCL runs the collective on it
 (it waits on the launching stream's event), i.e. the reduction overlaps the remaining backward
 kernels; the optimiser waits for the handles and folds the 1/world average into its kernel.
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+_FORCE = bool(os.environ.get("KSMI_DP_FORCE"))      # exercise the collective path in a 1-rank group (single-GPU smoke test of RCCL)
 
 
 def make_buckets(ready_index, offsets, numels, total, bucket_elems):
@@ -41,7 +45,7 @@ class BucketedAllReduce:
     def after_launch(self, idx):
         for (s, e, _) in self.by_launch.get(idx, ()):
             self.issued.append((s, e))
-            if self.world() > 1:
+            if self.world() > 1 or (_FORCE and dist.is_initialized()):
                 self.handles.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def wait(self):
