@@ -24,21 +24,27 @@ struct Igemm2Args {            // kernel argument: the public descriptor + launc
   int stages;                        // LDS stages: 2 = double-buffered k-chunks, 1 = single
 };
 
-template <typename T, int NT, int KH, int KW, bool AFF, bool EX>
-__global__ __launch_bounds__(256) void igemm2_fwd_kernel(const Igemm2Args ka) {
+// WN = 1: 4 waves, each 64 pixels x BNW = 16*NT channels.  WN = 2: 8 waves = two channel groups sharing ONE halo image
+// (M = 256 pixels, N = 2*BNW): the L2 -> LDS traffic per output channel halves for N >= 64 (measured: the DMA path moves
+// 2.3x the unique bytes and is the resource the K loop waits on).
+template <typename T, int NT, int KH, int KW, bool AFF, bool EX, int WN>
+__global__ __launch_bounds__(256 * WN) void igemm2_fwd_kernel(const Igemm2Args ka) {
   const ksmi_conv_desc& d = ka.d;
   const long long tm0 = __builtin_readcyclecounter();
+  constexpr int NTHR = 256 * WN;
   constexpr int TAPS = KH * KW;
-  constexpr int BN = NT * 16;
+  constexpr int BNW = NT * 16;                              // channels per wave
+  constexpr int BN = BNW * WN;                              // channels per workgroup
   constexpr int VEC = ElemTraits<T>::kVec;
   constexpr int KC = VEC * 4;
   constexpr int WVEC = TAPS * BN * 4;                       // 16-byte vectors of one weight slab
-  constexpr int WITER = (WVEC + 255) / 256;
+  constexpr int WITER = (WVEC + NTHR - 1) / NTHR;
   constexpr int MAXSLOT = 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 3, wn = wave >> 2;                  // pixel group / channel group of this wave
   const int g = lane >> 4, l15 = lane & 15;
 
   const int tilesX = (d.Wout + d.TW - 1) / d.TW, tilesY = (d.Hout + d.TH - 1) / d.TH;
@@ -55,7 +61,7 @@ __global__ __launch_bounds__(256) void igemm2_fwd_kernel(const Igemm2Args ka) {
   const int P = d.TH * d.TW;
   const int HPB = (HP * 64 + 1023) & ~1023;                 // halo bytes, whole wave-instructions (1 KiB)
   const int BUFB = HPB + TAPS * BN * 64;                    // one stage
-  const int nslot = HPB / 4096 + ((HPB % 4096) ? 1 : 0);    // 256 lanes x 16 B per slot-iteration
+  const int nslot = (HPB + NTHR * 16 - 1) / (NTHR * 16);    // NTHR lanes x 16 B per slot-iteration
   const FastDiv dHW(HW, ka.m_hw), dTW(d.TW, ka.m_tw);
 
   // ---- per-thread halo slots: LDS position v = s*256 + tid <-> (pixel v>>2, slot v&3) -----------
@@ -64,7 +70,7 @@ __global__ __launch_bounds__(256) void igemm2_fwd_kernel(const Igemm2Args ka) {
   int slot_lds[MAXSLOT];                                    // register path: where k-group myq of the pixel goes
 #pragma unroll
   for (int s = 0; s < MAXSLOT; ++s) {
-    const int v = tid + s * 256;
+    const int v = tid + s * NTHR;
     slot_goff[s] = -1; slot_q[s] = 0; slot_lds[s] = 0;
     if (v < HP * 4) {
       const int pix = v >> 2, sl = v & 3;
@@ -80,8 +86,8 @@ __global__ __launch_bounds__(256) void igemm2_fwd_kernel(const Igemm2Args ka) {
   const bool two_stage = ka.stages > 1;
 #pragma unroll
   for (int s = 0; s < MAXSLOT; ++s) {
-    if (tid + s * 256 < HP * 4 && slot_goff[s] < 0) {
-      const int off = AFF ? slot_lds[s] : (s * 256 + tid) * 16;
+    if (tid + s * NTHR < HP * 4 && slot_goff[s] < 0) {
+      const int off = AFF ? slot_lds[s] : (s * NTHR + tid) * 16;
       *(u32x4*)(smem + off) = (u32x4){0u, 0u, 0u, 0u};
       if (two_stage) *(u32x4*)(smem + BUFB + off) = (u32x4){0u, 0u, 0u, 0u};
     }
@@ -91,7 +97,7 @@ __global__ __launch_bounds__(256) void igemm2_fwd_kernel(const Igemm2Args ka) {
   int a_addr[4][TAPS];
 #pragma unroll
   for (int mf = 0; mf < 4; ++mf) {
-    int p = wave * 64 + mf * 16 + l15;
+    int p = wm * 64 + mf * 16 + l15;
     if (p >= P) p = 0;
     const int ly = dTW.div(p), lx = p - ly * d.TW;
     const int base = ly * S * HW + lx * S;
@@ -104,18 +110,20 @@ __global__ __launch_bounds__(256) void igemm2_fwd_kernel(const Igemm2Args ka) {
   int b_addr[NT];
 #pragma unroll
   for (int nf = 0; nf < NT; ++nf) {
-    const int n = nf * 16 + l15;
+    const int n = wn * BNW + nf * 16 + l15;
     b_addr[nf] = n * 64 + ((g ^ swz(n)) << 4);
   }
   // weight DMA: vector v = i*256 + tid -> row (tap*BN + n), slot; source k-group = slot ^ swz(n)
   int w_src[WITER];                                         // element offset inside one chunk's slab, or -1
 #pragma unroll
   for (int i = 0; i < WITER; ++i) {
-    const int v = i * 256 + tid;
+    const int v = i * NTHR + tid;
     const int row = v >> 2, sl = v & 3;
     const int t = row / BN, n = row - t * BN;
-    // LDS row n = nf*16 + g*4 + r of the A operand holds output channel g*4*NT + nf*4 + r (epilogue: igemm_epilogue.h, epi_col)
-    const int nsrc_ = ((n >> 2) & 3) * 4 * NT + (n >> 4) * 4 + (n & 3);
+    // LDS row j = nf*16 + g*4 + r of a wave's A operand holds output channel g*4*NT + nf*4 + r of its channel group
+    // (epilogue: igemm_epilogue.h, epi_col)
+    const int nb = n / BNW, j = n - nb * BNW;
+    const int nsrc_ = nb * BNW + ((j >> 2) & 3) * 4 * NT + (j >> 4) * 4 + (j & 3);
     w_src[i] = (v < WVEC && n0 + nsrc_ < d.Npad) ? ((t * d.Npad + n0 + nsrc_) * KC + ((sl ^ swz(n)) * VEC)) : -1;
   }
 
@@ -135,7 +143,7 @@ __global__ __launch_bounds__(256) void igemm2_fwd_kernel(const Igemm2Args ka) {
     for (int i = 0; i < WITER; ++i) {
       if (w_src[i] >= 0)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + w_src[i]),
-                                         (__attribute__((address_space(3))) void*)(wdst + (i * 256 + wave * 64) * 16), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void*)(wdst + (i * NTHR + wave * 64) * 16), 16, 0, 0);
     }
   };
   auto issue_halo_dma = [&](int ch, int buf) {
@@ -147,7 +155,7 @@ __global__ __launch_bounds__(256) void igemm2_fwd_kernel(const Igemm2Args ka) {
       if (s < nslot && slot_goff[s] >= 0)
         __builtin_amdgcn_global_load_lds(
             (const __attribute__((address_space(1))) void*)(sp + (size_t)slot_goff[s] * sr.C + slot_q[s] * VEC),
-            (__attribute__((address_space(3))) void*)(hdst + (s * 256 + wave * 64) * 16), 16, 0, 0);
+            (__attribute__((address_space(3))) void*)(hdst + (s * NTHR + wave * 64) * 16), 16, 0, 0);
     }
   };
   auto load_halo_regs = [&](int ch) {                      // AFF: thread owns k-group myq of its slot pixels
@@ -233,7 +241,7 @@ __global__ __launch_bounds__(256) void igemm2_fwd_kernel(const Igemm2Args ka) {
     }
   }
   const long long tm2 = __builtin_readcyclecounter();
-  if (!(dbg & 4)) igemm_epilogue_direct<T, NT, EX>(d, acc, smem, tid, wave, g, l15, b, oy0, ox0, n0, P, ka.m_tw);
+  if (!(dbg & 4)) igemm_epilogue_direct<T, NT, EX, WN>(d, acc, smem, tid, wm, g, l15, b, oy0, ox0, n0 + wn * BNW, P, ka.m_tw, wn, n0);
   if ((dbg & 8) && d.stats && tid == 0 && blockIdx.y == 0) {   // per-block phase timestamps (profiling only; clobbers stats)
     const long long tm3a = __builtin_readcyclecounter();      // epilogue instructions issued
     __builtin_amdgcn_s_waitcnt(0);
@@ -256,14 +264,17 @@ int launch2(const ksmi_conv_desc* d, int dbg, hipStream_t st) {
   // token GEMMs (1x1) keep both a small halo (16 KB) and a small weight slab: BN = 64 still leaves 2 workgroups per CU
   static const int nt_cap11 = getenv("KSMI_NT_CAP_1X1") ? atoi(getenv("KSMI_NT_CAP_1X1")) : 2;
   if (nt > (taps == 1 ? nt_cap11 : nt_cap)) nt = taps == 1 ? nt_cap11 : nt_cap;
-  const int bn = nt * 16;
+  // two channel groups per workgroup (8 waves, one halo image): 3x3 / 2x2 / 1x1 with at least 64 output channels
+  static const bool wn_off = getenv("KSMI_WN1") != nullptr;
+  const int wn = (!wn_off && nt == 2 && d->Npad >= 64 && taps <= 9) ? 2 : 1;
+  const int bn = nt * 16 * wn;
   const dim3 grid(gm, (d->Npad + bn - 1) / bn);
   const size_t hpb = ((size_t)HP * 64 + 1023) & ~(size_t)1023;
   // single-chunk convolutions (K <= 32 bf16 channels) need one stage only: 40 KB -> 3-4 workgroups per CU
   static const int stage_cap = getenv("KSMI_STAGES") ? atoi(getenv("KSMI_STAGES")) : 2;
   const int stages = (d->nchunks > 1 && stage_cap > 1) ? 2 : 1;
   size_t lds = stages * (hpb + (size_t)taps * bn * 64);
-  if (lds < 4 * 2 * bn * sizeof(float)) lds = 4 * 2 * bn * sizeof(float);
+  if (lds < (size_t)4 * wn * 2 * (bn / wn) * sizeof(float)) lds = (size_t)4 * wn * 2 * (bn / wn) * sizeof(float);
   const bool aff = d->src[0].scale != nullptr;
   // epilogue extras (scale, residual, ReLU, strided placement) compile into a separate kernel: the common path stays lean
   const bool extras = d->alpha != 0.f || d->resid != nullptr || d->relu_out != 0 || d->out_sy != 0;
@@ -272,11 +283,16 @@ int launch2(const ksmi_conv_desc* d, int dbg, hipStream_t st) {
   ka.m_tw = fastdiv_magic(d->TW); ka.m_hw = fastdiv_magic(HW); ka.m_tx = fastdiv_magic(tilesX); ka.m_ty = fastdiv_magic(tilesY);
   ka.dbg = dbg;
   ka.stages = stages;
+#define KSMI_L2W(NT_, KH_, KW_, AFF_, EX_, WN_)                                                     \
+  do {                                                                                              \
+    auto kfn = igemm2_fwd_kernel<T, NT_, KH_, KW_, AFF_, EX_, WN_>;                                 \
+    if (lds > 65536) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL(kfn, grid, dim3(256 * WN_), lds, st, ka);                                    \
+  } while (0)
 #define KSMI_L2X(NT_, KH_, KW_, AFF_, EX_)                                                          \
   do {                                                                                              \
-    auto kfn = igemm2_fwd_kernel<T, NT_, KH_, KW_, AFF_, EX_>;                                      \
-    if (lds > 65536) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, ka);                                          \
+    if constexpr (NT_ == 2 && KH_ * KW_ <= 9) { if (wn == 2) KSMI_L2W(NT_, KH_, KW_, AFF_, EX_, 2); else KSMI_L2W(NT_, KH_, KW_, AFF_, EX_, 1); } \
+    else KSMI_L2W(NT_, KH_, KW_, AFF_, EX_, 1);                                                     \
   } while (0)
 #define KSMI_L2(NT_, KH_, KW_, AFF_)                                                                \
   do { if (extras) KSMI_L2X(NT_, KH_, KW_, AFF_, true); else KSMI_L2X(NT_, KH_, KW_, AFF_, false); } while (0)
@@ -294,6 +310,7 @@ int launch2(const ksmi_conv_desc* d, int dbg, hipStream_t st) {
 #undef KSMI_D2
 #undef KSMI_L2
 #undef KSMI_L2X
+#undef KSMI_L2W
   return ksmi_check_launch("igemm2_fwd");
 }
 

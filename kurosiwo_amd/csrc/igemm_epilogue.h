@@ -230,10 +230,12 @@ __device__ __forceinline__ float row16_sum(float v) {
 // instead of 16 half rows).
 template <int NT> __device__ __forceinline__ int epi_col(int nf, int g) { return g * 4 * NT + nf * 4; }
 
-template <typename T, int NT, bool EX = true>
+// wave = pixel group (0..3) of the calling wave; n0 = first channel of the WAVE; wn / n0wg = channel group of the wave and
+// first channel of the workgroup (WN channel groups share the statistics reduction buffer)
+template <typename T, int NT, bool EX = true, int WN = 1>
 __device__ __forceinline__ void igemm_epilogue_direct(const ksmi_conv_desc& d, f32x4 (&acc)[4][NT], unsigned char* smem, int tid,
                                                       int wave, int g, int l15, int b, int oy0, int ox0, int n0, int P,
-                                                      uint32_t magic_tw = 0xffffffffu) {
+                                                      uint32_t magic_tw = 0xffffffffu, int wn = 0, int n0wg = -1) {
   constexpr int BN = NT * 16;
   const FastDiv dTW = magic_tw != 0xffffffffu ? FastDiv(d.TW, magic_tw) : FastDiv(d.TW);
   size_t opix[4];
@@ -366,20 +368,24 @@ __device__ __forceinline__ void igemm_epilogue_direct(const ksmi_conv_desc& d, f
   if (d.stats) {
     // reduce over the 16 pixel lanes (l15) of each k-group with DPP row operations, then over the 4 waves through LDS
     __syncthreads();                                     // (all waves are past their last LDS reads)
-    float* red = (float*)smem;                           // [4 waves][2][BN]
+    float* red = (float*)smem;                           // [WN groups][4 waves][2][BN]
+    const int ws = wn * 4 + wave;
 #pragma unroll
     for (int nf = 0; nf < NT; ++nf)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float a = row16_sum(ssum[nf][r]), q = row16_sum(ssq[nf][r]);
         const int col = epi_col<NT>(nf, g) + r;
-        if (l15 == 0) { red[(wave * 2 + 0) * BN + col] = a; red[(wave * 2 + 1) * BN + col] = q; }
+        if (l15 == 0) { red[(ws * 2 + 0) * BN + col] = a; red[(ws * 2 + 1) * BN + col] = q; }
       }
     __syncthreads();
-    if (tid < 2 * BN) {
-      const int which = tid / BN, n = tid - which * BN;
-      const float v = red[(0 * 2 + which) * BN + n] + red[(1 * 2 + which) * BN + n] + red[(2 * 2 + which) * BN + n] + red[(3 * 2 + which) * BN + n];
-      if (n0 + n < d.Npad) d.stats[((size_t)blockIdx.x * 2 + which) * d.Npad + n0 + n] = v;
+    if (tid < 2 * BN * WN) {
+      const int which = tid / (BN * WN), nn = tid - which * (BN * WN);
+      const int grp = nn / BN, n = nn - grp * BN;
+      const float* rg = red + (size_t)grp * 4 * 2 * BN;
+      const float v = rg[(0 * 2 + which) * BN + n] + rg[(1 * 2 + which) * BN + n] + rg[(2 * 2 + which) * BN + n] + rg[(3 * 2 + which) * BN + n];
+      const int nbase = n0wg >= 0 ? n0wg : n0;
+      if (nbase + nn < d.Npad) d.stats[((size_t)blockIdx.x * 2 + which) * d.Npad + nbase + nn] = v;
     }
   }
 }
