@@ -92,6 +92,10 @@ typedef struct ksmi_conv_desc {
   /* single-source descriptors may exceed KSMI_MAX_CHUNKS: uniform_kc = chunk elements (ksmi_chunk_elems) means
    * chunk ch starts at channel ch*uniform_kc of src[0] and the chunk tables are ignored; 0 = use the tables */
   int32_t uniform_kc;
+  /* strided input view (input gradient of ConvTranspose2d k4 s2 p1 as four 2x2 convolutions over the parity sub-images of dOut):
+   * logical source pixel (iy, ix) of the Hin x Win view lives at (iy*in_sy + in_oy, ix*in_sx + in_ox) of a [B, in_H, in_W, C]
+   * tensor; in_sy == 0 => dense [B,Hin,Win,C] */
+  int32_t in_sy, in_sx, in_oy, in_ox, in_H, in_W;
   /* epilogue extras (igemm2 path): v = alpha*(acc + bias) [alpha == 0 means 1] ; v += resid[pixel][n] (dense
    * [B,Hout,Wout,residC] `dtype`, ResidualBlock of models/changeformer.py:471-483) ; v = max(v, 0) if relu_out
    * (conv -> ReLU -> BatchNorm ordering of conv_diff / make_prediction, changeformer.py:31-46: the BN statistics in
@@ -144,6 +148,12 @@ typedef struct ksmi_wgrad_desc {
   uint16_t chunk_c0[KSMI_MAX_CHUNKS];
   uint8_t chunk_src[KSMI_MAX_CHUNKS];
   int32_t uniform_kc, k_total;    /* same meaning as in the pack descriptor: single source, more than KSMI_MAX_CHUNKS chunks */
+  /* phase weight gradients of ConvTranspose2d k4 s2 p1: strided view of the halo-side source (as ksmi_conv_desc.in_*), separate left
+   * padding, and an explicit tap -> gradient offset table (use_tap_off: grad[k*gK + n*gN + tap_off[tap]]) */
+  int32_t in_sy, in_sx, in_oy, in_ox, in_H, in_W;
+  int32_t pad_x_set, pad_x;
+  int32_t use_tap_off;
+  int32_t tap_off[16];
 } ksmi_wgrad_desc;
 size_t ksmi_conv_wgrad_workspace(const ksmi_wgrad_desc* d, int dtype);
 int ksmi_conv_wgrad(const ksmi_wgrad_desc* d, int dtype, void* stream);

@@ -40,7 +40,8 @@ class ConvDesc(C.Structure):
                 ("chunk_c0", C.c_uint16 * MAX_CHUNKS), ("chunk_src", C.c_uint8 * MAX_CHUNKS),
                 ("pad_x", C.c_int32), ("out_sy", C.c_int32), ("out_sx", C.c_int32), ("out_oy", C.c_int32),
                 ("out_ox", C.c_int32), ("out_H", C.c_int32), ("out_W", C.c_int32),
-                ("uniform_kc", C.c_int32), ("alpha", C.c_float), ("relu_out", C.c_int32), ("residC", C.c_int32),
+                ("uniform_kc", C.c_int32), ("in_sy", C.c_int32), ("in_sx", C.c_int32), ("in_oy", C.c_int32), ("in_ox", C.c_int32),
+                ("in_H", C.c_int32), ("in_W", C.c_int32), ("alpha", C.c_float), ("relu_out", C.c_int32), ("residC", C.c_int32),
                 ("resid", C.c_void_p)]
 
 
@@ -63,7 +64,9 @@ class WgradDesc(C.Structure):
                 ("gK", C.c_int64), ("gN", C.c_int64), ("gT", C.c_int64), ("accumulate", C.c_int32),
                 ("k_off", C.c_int32 * MAX_CHUNKS), ("k_len", C.c_int32 * MAX_CHUNKS),
                 ("chunk_c0", C.c_uint16 * MAX_CHUNKS), ("chunk_src", C.c_uint8 * MAX_CHUNKS),
-                ("uniform_kc", C.c_int32), ("k_total", C.c_int32)]
+                ("uniform_kc", C.c_int32), ("k_total", C.c_int32),
+                ("in_sy", C.c_int32), ("in_sx", C.c_int32), ("in_oy", C.c_int32), ("in_ox", C.c_int32), ("in_H", C.c_int32), ("in_W", C.c_int32),
+                ("pad_x_set", C.c_int32), ("pad_x", C.c_int32), ("use_tap_off", C.c_int32), ("tap_off", C.c_int32 * 16)]
 
 
 _vp, _i, _i64, _f, _d, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_size_t

@@ -365,16 +365,27 @@ class ChangeFormerPlan(PlanBase):
         D, B = "TDec_x2", self.B
         wkey, bkey = f"{D}.{name}.conv2d.weight", f"{D}.{name}.conv2d.bias"
         src = [SrcSpec(dout, N)]
-        d, table = make_conv(src, [(dx, Cin, 0, 0, Cin, 0)], dx, None, None, B, 2 * H, 2 * W, H, W, 4, 4, 2, 1, Cin, self.dtype,
-                             mask=self._nomask(r, sv))
-        d.wpk = self._packed(wkey, table, 16, Cin, Cin, 16, N * 16, 0, 1, 0).data_ptr()
-        rows = conv_grid_m(d)
-        self.need("stats", rows * 2 * d.Npad * 4)
-        self._later.append(lambda: setattr(d, "stats", self.scr("stats")))
-        self._conv(self.bwd, d, "deconv_dgrad", name)
-        self._last_rows, self._last_cpad = rows, d.Npad
-        dw, ws = make_wgrad(src, x, Cin, 0, Cin, self.m._g(wkey), 16, N * 16, 1, self._acc_param(wkey), B, 2 * H, 2 * W, H, W, 4, 4, 2, 1, self.dtype)
-        self._wgrad(dw, ws, wkey)
+        # four 2x2 phase convolutions over the parity sub-images of dout (see PlanBase._deconv_bwd); the BatchNorm-backward sums are
+        # linear in the gradient, so every phase writes its own block of partial rows and reduce_rows walks all of them
+        rows_total, first = 0, True
+        for py in range(2):
+            for px in range(2):
+                tap_map = []
+                for a in range(2):
+                    for b in range(2):
+                        tap_map.append((2 * a if py else 1 + 2 * a) * 4 + (2 * b if px else 1 + 2 * b))
+                d, table = make_conv(src, [(dx, Cin, 0, 0, Cin, 0 if first else 1)], dx, None, None, B, H, W, H, W, 2, 2, 1, py, Cin, self.dtype,
+                                     mask=self._nomask(r, sv), pad_x=px, in_map=(2, 2, py, px, 2 * H, 2 * W))
+                d.wpk = self._packed(wkey, table, 4, Cin, Cin, 16, N * 16, 0, 1, 0, tap_map).data_ptr()
+                rows = conv_grid_m(d)
+                off = rows_total * 2 * d.Npad * 4
+                rows_total += rows
+                self._later.append(lambda d=d, off=off: setattr(d, "stats", self.scr("stats") + off))
+                self._conv(self.bwd, d, "deconv_dgrad_phase", f"{name}.p{py}{px}")
+                first = False
+        self.need("stats", rows_total * 2 * d.Npad * 4)
+        self._last_rows, self._last_cpad = rows_total, d.Npad
+        self._deconv_wgrad(src, x, Cin, N, H, W, wkey, B)
         self._bias_grad(dout, B * 4 * H * W, N, bkey)
 
     def _encoder_stage_bwd(self, ft):

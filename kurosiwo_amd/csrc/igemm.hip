@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const ksmi_conv_desc d) 
       const int pix = v >> 2, q = v & 3;
       const int hy = pix / HW, hx = pix - hy * HW;
       const int iy = oy0 * S - d.pad + hy, ix = ox0 * S - d.pad_x + hx;
-      slot_goff[s] = (iy >= 0 && iy < d.Hin && ix >= 0 && ix < d.Win) ? ((b * d.Hin + iy) * d.Win + ix) : -1;
+      slot_goff[s] = (iy >= 0 && iy < d.Hin && ix >= 0 && ix < d.Win) ? src_pixel(d, b, iy, ix) : -1;
       slot_lds[s] = pix * 64 + ((q ^ swz(pix)) << 4);
     }
   }
@@ -303,10 +303,12 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const ksmi_wgrad_desc 
       for (int v = tid; v < HP * 4; v += 256) {
         const int pix = v >> 2;
         const int hy = dHW.div(pix), hx = pix - hy * HW;
-        const int iy = oy0 * S - d.pad + hy, ix = ox0 * S - d.pad + hx;
+        const int iy = oy0 * S - d.pad + hy, ix = ox0 * S - (d.pad_x_set ? d.pad_x : d.pad) + hx;
         u32x4 x = (u32x4){0u, 0u, 0u, 0u};
         if (cvalid && iy >= 0 && iy < d.Hin && ix >= 0 && ix < d.Win) {
-          x = *(const u32x4*)(sp + ((size_t)(b * d.Hin + iy) * d.Win + ix) * sr.C);
+          const size_t spix = d.in_sy == 0 ? (size_t)(b * d.Hin + iy) * d.Win + ix
+                                           : (size_t)(b * d.in_H + (iy * d.in_sy + d.in_oy)) * d.in_W + (ix * d.in_sx + d.in_ox);
+          x = *(const u32x4*)(sp + spix * sr.C);
           if (aff) {
             float f[VEC];
             vec_unpack<T>(x, f);
@@ -453,7 +455,7 @@ __global__ void wgrad_reduce_kernel(const ksmi_wgrad_desc d, int taps, int KC) {
     const int klen = d.uniform_kc ? min(d.uniform_kc, d.k_total - koff) : d.k_len[ch];
     if (l8 == 0 && n < d.N && kc < klen) {
       const int64_t k = koff + kc;
-      float* gp = d.grad + k * d.gK + (int64_t)n * d.gN + (int64_t)t * d.gT;
+      float* gp = d.grad + k * d.gK + (int64_t)n * d.gN + (d.use_tap_off ? (int64_t)d.tap_off[t] : (int64_t)t * d.gT);
       *gp = d.accumulate ? (*gp + s) : s;
     }
   }

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256 * WN) void igemm2_fwd_kernel(const Igemm2Args k
       const int pix = v >> 2, sl = v & 3;
       const int hy = dHW.div(pix), hx = pix - hy * HW;
       const int iy = oy0 * S - d.pad + hy, ix = ox0 * S - d.pad_x + hx;
-      if (iy >= 0 && iy < d.Hin && ix >= 0 && ix < d.Win) slot_goff[s] = (b * d.Hin + iy) * d.Win + ix;
+      if (iy >= 0 && iy < d.Hin && ix >= 0 && ix < d.Win) slot_goff[s] = src_pixel(d, b, iy, ix);
       slot_q[s] = sl ^ swz(pix);
       slot_lds[s] = pix * 64 + ((sl ^ swz(pix)) << 4);     // (register path: thread owns k-group sl)
     }

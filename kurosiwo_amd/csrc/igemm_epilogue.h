@@ -30,6 +30,12 @@ __device__ __forceinline__ int chunk_src_of(const ksmi_conv_desc& d, int ch) {
   return (int)((((const uint32_t*)d.chunk_src)[ch >> 2] >> ((ch & 3) * 8)) & 0xffu);
 }
 
+// source pixel index of logical input pixel (b, iy, ix): dense, or the strided view of a parity sub-image
+__device__ __forceinline__ int src_pixel(const ksmi_conv_desc& d, int b, int iy, int ix) {
+  if (d.in_sy == 0) return (b * d.Hin + iy) * d.Win + ix;
+  return (b * d.in_H + (iy * d.in_sy + d.in_oy)) * d.in_W + (ix * d.in_sx + d.in_ox);
+}
+
 // destination pixel index of result pixel (b, oy, ox): dense, or the strided placement of a phase convolution
 __device__ __forceinline__ size_t dst_pixel(const ksmi_conv_desc& d, int b, int oy, int ox) {
   if (d.out_sy == 0) return ((size_t)b * d.Hout + oy) * d.Wout + ox;

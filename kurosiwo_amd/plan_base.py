@@ -206,6 +206,22 @@ class PlanBase:
                 d.wpk = self._packed(wkey, table, 4, N, N, N * 16, 16, 0, 1, 0, tap_map).data_ptr()
                 self._conv(self.fwd, d, "deconv_phase", f"{name}.p{py}{px}")
 
+    def _deconv_wgrad(self, src, x, Cin, N, H, W, wkey, B):
+        """dW[c][n][ky][kx] = sum x[iy,ix,c] dOut[2iy-1+ky, 2ix-1+kx, n] as four 2x2 stride-1 weight-gradient GEMMs over the parity
+        sub-images of dOut (tap (a,b) of phase (py,px) <-> ky = 2a | 1+2a, kx = 2b | 1+2b), each writing its 4 of the 16 taps"""
+        import os
+        acc = self._acc_param(wkey)
+        if os.environ.get("KSMI_DECONV_WGRAD_4X4"):
+            dw, ws = make_wgrad(src, x, Cin, 0, Cin, self.m._g(wkey), 16, N * 16, 1, acc, B, 2 * H, 2 * W, H, W, 4, 4, 2, 1, self.dtype)
+            self._wgrad(dw, ws, wkey)
+            return
+        for py in range(2):
+            for px in range(2):
+                tap_off = [(2 * a if py else 1 + 2 * a) * 4 + (2 * b if px else 1 + 2 * b) for a in range(2) for b in range(2)]
+                dw, ws = make_wgrad(src, x, Cin, 0, Cin, self.m._g(wkey), 16, N * 16, 0, acc, B, H, W, H, W, 2, 2, 1, py, self.dtype,
+                                    pad_x=px, in_map=(2, 2, py, px, 2 * H, 2 * W), tap_off=tap_off)
+                self._wgrad(dw, ws, wkey)
+
     def _deconv_bwd(self, name, x, Cin, N, H, W, dout, doutC, dx, mask=None, prefix="head.", suffix="", B=None, stats=None):
         """dout [B,2H,2W,doutC] (first N channels real).  dx[B,H,W,Cin] = 4x4 stride-2 conv of dout (optionally
         ReLU-masked by `mask`), dW via the stride-2 weight-gradient GEMM, db = channel sums."""
@@ -216,13 +232,32 @@ class PlanBase:
             mk = None
             if mask is not None:
                 mk = (mask, self.const[0], self.const[1], self.const[1], self.const[0])
-            d, table = make_conv(src, [(dx, Cin, 0, 0, Cin, 0)], dx, None, None, B, 2 * H, 2 * W, H, W, 4, 4, 2, 1, Cin,
-                                 self.dtype, mask=mk)
-            d.wpk = self._packed(wkey, table, 16, Cin, Cin, 16, N * 16, 0, 1, 0).data_ptr()
-            self._conv(self.bwd, d, "deconv_dgrad", name)
-        dw, ws = make_wgrad(src, x, Cin, 0, Cin, self.m._g(wkey), 16, N * 16, 1, self._acc_param(wkey),
-                            B, 2 * H, 2 * W, H, W, 4, 4, 2, 1, self.dtype)
-        self._wgrad(dw, ws, wkey)
+            import os
+            if os.environ.get("KSMI_DECONV_DGRAD_4X4"):
+                d, table = make_conv(src, [(dx, Cin, 0, 0, Cin, 0)], dx, None, None, B, 2 * H, 2 * W, H, W, 4, 4, 2, 1, Cin,
+                                     self.dtype, mask=mk)
+                d.wpk = self._packed(wkey, table, 16, Cin, Cin, 16, N * 16, 0, 1, 0).data_ptr()
+                self._conv(self.bwd, d, "deconv_dgrad", name)
+            else:
+                # dIn[iy] = sum_ky dOut[2 iy - 1 + ky] W[ky]: split by the parity of the dOut row.  Even rows E[m] = dOut[2m]: taps a = 0,1
+                # read E[iy + a] with ky = 1 + 2a (pad 0); odd rows O[m] = dOut[2m+1]: taps read O[iy - 1 + a] with ky = 2a (pad 1).
+                # Four dense 2x2 stride-1 convolutions over the strided views (every M-tile row useful; the single 4x4 stride-2
+                # convolution is limited to 100-pixel patches by its 22x22 halo = 39 % of the 256-row tile), accumulated in dx.
+                first = True
+                for py in range(2):
+                    for px in range(2):
+                        tap_map = []
+                        for a in range(2):
+                            for b in range(2):
+                                ky = 2 * a if py else 1 + 2 * a
+                                kx = 2 * b if px else 1 + 2 * b
+                                tap_map.append(ky * 4 + kx)
+                        d, table = make_conv(src, [(dx, Cin, 0, 0, Cin, 0 if first else 1)], dx, None, None, B, H, W, H, W, 2, 2, 1, py, Cin,
+                                             self.dtype, mask=mk, pad_x=px, in_map=(2, 2, py, px, 2 * H, 2 * W))   # 0/1 mask on every partial = mask on the sum
+                        d.wpk = self._packed(wkey, table, 4, Cin, Cin, 16, N * 16, 0, 1, 0, tap_map).data_ptr()
+                        self._conv(self.bwd, d, "deconv_dgrad_phase", f"{name}.p{py}{px}")
+                        first = False
+        self._deconv_wgrad(src, x, Cin, N, H, W, wkey, B)
         # bias gradient over the real channels only
         rows = B * 4 * H * W
         r = max(1, min(512, rows // 256))

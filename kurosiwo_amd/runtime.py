@@ -160,7 +160,7 @@ def make_pack(w, out, table, taps, N, Npad, n_mod, sK, sN, sD, sT, flip, tap_map
 
 
 def make_conv(srcs, dsts, wpk, bias, stats, B, Hin, Win, Hout, Wout, KH, KW, stride, pad, N, dtype,
-              mask=None, ps_cout=0, max_pix=256, pad_x=None, out_map=None, alpha=0.0, relu_out=0, resid=None):
+              mask=None, ps_cout=0, max_pix=256, pad_x=None, out_map=None, alpha=0.0, relu_out=0, resid=None, in_map=None):
     """dsts: list of (tensor, C, c_off, n_begin, n_len, accumulate).  mask: (tensor, mean, rstd, scale, shift).
     resid: (tensor, C) added after alpha scaling; relu_out: ReLU before statistics/store."""
     kc = chunk_elems(dtype)
@@ -179,6 +179,8 @@ def make_conv(srcs, dsts, wpk, bias, stats, B, Hin, Win, Hout, Wout, KH, KW, str
     d.B, d.Hin, d.Win, d.Hout, d.Wout = B, Hin, Win, Hout, Wout
     d.KH, d.KW, d.stride, d.pad = KH, KW, stride, pad
     d.pad_x = pad if pad_x is None else pad_x
+    if in_map is not None:           # (sy, sx, oy, ox, H, W): strided view of the source tensor
+        d.in_sy, d.in_sx, d.in_oy, d.in_ox, d.in_H, d.in_W = in_map
     d.alpha, d.relu_out = alpha, relu_out
     if resid is not None:
         d.resid, d.residC = resid[0].data_ptr(), resid[1]
@@ -206,7 +208,7 @@ def packed_weight_numel(table, taps, Npad, dtype):
 
 
 def make_wgrad(srcs, dy, dyC, dy_c_off, N, grad, gK, gN, gT, accumulate, B, Hin, Win, Hout, Wout,
-               KH, KW, stride, pad, dtype):
+               KH, KW, stride, pad, dtype, pad_x=None, in_map=None, tap_off=None):
     kc = chunk_elems(dtype)
     table, _ = _chunk_table(srcs, kc)
     d = WgradDesc()
@@ -217,6 +219,14 @@ def make_wgrad(srcs, dy, dyC, dy_c_off, N, grad, gK, gN, gT, accumulate, B, Hin,
     mp = 256 if stride == 1 else 128
     d.TH, d.TW = choose_patch(Hout, Wout, stride, KH, KW, mp)
     d.N, d.nchunks = N, len(table)
+    if pad_x is not None:
+        d.pad_x_set, d.pad_x = 1, pad_x
+    if in_map is not None:
+        d.in_sy, d.in_sx, d.in_oy, d.in_ox, d.in_H, d.in_W = in_map
+    if tap_off is not None:
+        d.use_tap_off = 1
+        for i, t in enumerate(tap_off):
+            d.tap_off[i] = t
     d.grad, d.gK, d.gN, d.gT, d.accumulate = grad.data_ptr(), gK, gN, gT, accumulate
     kc_u, ktot = _uniform(table, kc)
     if kc_u:
