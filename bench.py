@@ -90,7 +90,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--model", default="snunet", choices=["snunet", "floodvit", "changeformer"],
+    ap.add_argument("--model", default="snunet", choices=["snunet", "floodvit", "changeformer", "unet"],
                     help="snunet = BASELINE.json configs[1] (the headline); changeformer = configs[3] (bs 32); "
                          "floodvit = configs[4] per-GPU shard (bs 16)")
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (weak scaling); default 32 snunet/changeformer, 16 floodvit")
@@ -140,6 +140,16 @@ def main():
         workload = ("BASELINE.json configs[3]: ChangeFormerV6 CD (embed 256), 2 dates x 2-ch 224x224, "
                     f"per-GPU batch {B}, ce+dice on the sigmoid map, SGD(0.99, wd 1e-5), fwd+loss+bwd+optimizer")
         metric = "SAR tiles/sec (224x224, ChangeFormerV6 change-detection train step)"
+    elif args.model == "unet":
+        from kurosiwo_amd.trainer import SegTrainStep
+        from kurosiwo_amd.unet import Unet
+        model = Unet("resnet18", encoder_weights=None, in_channels=2, classes=3, precision=args.precision).to(dev).train()
+        step = SegTrainStep(model, B, loss_function="cross_entropy", lr=1e-3, bucket_mb=8.0, image_size=(H, W))
+        x, mask = seg_inputs(batch, ("post_event",))
+        step.set_batch(x.to(dev), mask.to(dev))
+        workload = ("BASELINE.json configs[0] model on the GPU: Unet(resnet18) segmentation, 2-ch GRD 224x224, "
+                    f"per-GPU batch {B}, CE, Adam, fwd+loss+bwd+optimizer")
+        metric = "SAR tiles/sec (224x224, Unet-resnet18 segmentation train step)"
     else:
         from kurosiwo_amd.floodvit import FinetunerSegmentation, ViT
         from kurosiwo_amd.trainer import SegTrainStep

@@ -120,7 +120,7 @@ typedef struct ksmi_pack_desc {
   int32_t flip;
   int32_t k_off[KSMI_MAX_CHUNKS];
   int32_t k_len[KSMI_MAX_CHUNKS];
-  int32_t use_tap_map;            /* 1: tap' = tap_map[tap] (phase kernels of ConvTranspose2d k4 s2 p1) */
+  int32_t use_tap_map;            /* 1: tap' = tap_map[tap] (phase kernels of ConvTranspose2d k4 s2 p1 / strided-conv gradients); < 0: zero tap */
   int32_t tap_map[16];
   int32_t uniform_kc, k_total;    /* uniform_kc != 0: k_off = chunk*uniform_kc, k_len = min(uniform_kc, k_total - k_off); tables ignored */
 } ksmi_pack_desc;
@@ -339,8 +339,15 @@ int ksmi_bilinear_forward(const void* x, const void* add, void* y, int B, int Hi
 int ksmi_bilinear_backward(const void* dy, void* dx, int accumulate, int B, int Hi, int Wi, int Ho, int Wo, int C, int dtype, void* stream);
 /* input gradient of y = BN(r), r = relu(v) or v (conv -> ReLU -> BN of conv_diff / make_prediction :31-46; linear_fuse :563-567):
  * dv = gamma*rstd*(dy - sums[0]/n - rhat*sums[1]/n) [masked by r > 0] */
+/* partial[rows][2][C] = (sum dy, sum dy*xhat) of a plain BatchNorm (ResNet downsample branch of row U1) for ksmi_reduce_rows */
+int ksmi_bn_bwd_reduce(const void* dy, const void* x, const float* mean, const float* rstd, float* partial, int rows, int64_t npix, int C,
+                       int dtype, void* stream);
 int ksmi_bn_bwd_apply(const void* dy, const void* r, const float* mean, const float* rstd, const float* gamma, const float* sums,
                       void* dv, int relu_mask, double count, int64_t npix, int C, int dtype, void* stream);
+/* nn.MaxPool2d(kernel_size=3, stride=2, padding=1) of the ResNet stem (U1 row: torchvision-style ResNet18 encoder); backward routes
+ * to the first maximum in window scan order, dx (+)= */
+int ksmi_maxpool3x3s2_forward(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream);
+int ksmi_maxpool3x3s2_backward(const void* x, const void* dy, void* dx, int accumulate, int B, int H, int W, int C, int dtype, void* stream);
 /* y = alpha * [relu](x*scale[c] + shift[c]) (scale = shift = NULL: plain scaled copy): the materialised BatchNorm output of
  * linear_fuse (:563-567) and the 0.1 branch scale of ResidualBlock (:479-481) in the backward pass */
 int ksmi_affine(const void* x, const float* scale, const float* shift, void* y, int64_t npix, int C, int relu, float alpha, int dtype,

@@ -125,6 +125,8 @@ SIGNATURES = {
     "ksmi_gemm_nn": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     "ksmi_im2col": (_i, [_vp, _vp] + [_i] * 11 + [_i, _i, _vp]),
     "ksmi_col2im": (_i, [_vp, _vp, _i] + [_i] * 11 + [_i, _vp]),
+    "ksmi_maxpool3x3s2_forward": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "ksmi_maxpool3x3s2_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ksmi_affine": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, C.c_float, _i, _vp]),
     "ksmi_dwconv3x3_gelu_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ksmi_dwconv3x3_backward_input": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
@@ -135,6 +137,7 @@ SIGNATURES = {
     "ksmi_attention_bwd_workspace": (C.c_size_t, [_i, _i, _i, _i, _i]),
     "ksmi_bilinear_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "ksmi_bilinear_backward": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "ksmi_bn_bwd_reduce": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp]),
     "ksmi_bn_bwd_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, C.c_double, _i64, _i, _i, _vp]),
     "ksmi_out_to_nchw": (_i, [_vp, _vp, _i, _i, _i, _i64, _i, _i, _vp]),
     "ksmi_dout_to_nhwc": (_i, [_vp, _vp, _vp, _i, _i, _i, _i64, _i, _i, _vp]),

@@ -91,6 +91,87 @@ __global__ void affine_kernel(const T* x, const float* scale, const float* shift
 }
 
 // ------------------------------------------------------------------------------------------------
+// max pool 3x3 stride 2 pad 1 (ResNet stem).  Ho = (H + 1) / 2.  Backward (gather form): input pixel (iy, ix) collects dy of
+// every window that contains it and whose FIRST maximum (scan order ky, kx) is this pixel.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void maxpool3s2_fwd_kernel(const T* x, T* y, int B, int H, int W, int C) {
+  constexpr int VEC = ElemTraits<T>::kVec;
+  const int CV = C / VEC, Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  const int64_t n = (int64_t)B * Ho * Wo * CV;
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (int64_t)gridDim.x * blockDim.x) {
+    const int cv = v % CV; int64_t r = v / CV;
+    const int ox = r % Wo; r /= Wo;
+    const int oy = r % Ho; const int b = r / Ho;
+    float m[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) m[j] = -3.0e38f;
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = 2 * oy - 1 + ky;
+      if (iy < 0 || iy >= H) continue;
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = 2 * ox - 1 + kx;
+        if (ix < 0 || ix >= W) continue;
+        float t[VEC];
+        vec_unpack<T>(*(const u32x4*)(x + (((int64_t)b * H + iy) * W + ix) * C + cv * VEC), t);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) m[j] = fmaxf(m[j], t[j]);
+      }
+    }
+    *(u32x4*)(y + v * VEC) = vec_pack<T>(m);
+  }
+}
+template <typename T>
+__global__ void maxpool3s2_bwd_kernel(const T* x, const T* dy, T* dx, int accumulate, int B, int H, int W, int C) {
+  constexpr int VEC = ElemTraits<T>::kVec;
+  const int CV = C / VEC, Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  const int64_t n = (int64_t)B * H * W * CV;
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (int64_t)gridDim.x * blockDim.x) {
+    const int cv = v % CV; int64_t r = v / CV;
+    const int ix = r % W; r /= W;
+    const int iy = r % H; const int b = r / H;
+    float me[VEC], s[VEC];
+    vec_unpack<T>(*(const u32x4*)(x + v * VEC), me);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) s[j] = 0.f;
+    for (int oy = (iy - 1 + 1) / 2; oy <= (iy + 1) / 2 && oy < Ho; ++oy) {          // windows with 2*oy-1 <= iy <= 2*oy+1
+      if (2 * oy - 1 > iy) continue;
+      for (int ox = ix / 2; ox <= (ix + 1) / 2 && ox < Wo; ++ox) {
+        if (2 * ox - 1 > ix) continue;
+        // is (iy, ix) the first maximum of window (oy, ox)?  per channel: no earlier element >= me, no later element > me
+        bool first[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) first[j] = true;
+        for (int ky = 0; ky < 3; ++ky) {
+          const int yy = 2 * oy - 1 + ky;
+          if (yy < 0 || yy >= H) continue;
+          for (int kx = 0; kx < 3; ++kx) {
+            const int xx = 2 * ox - 1 + kx;
+            if (xx < 0 || xx >= W || (yy == iy && xx == ix)) continue;
+            const bool earlier = yy < iy || (yy == iy && xx < ix);
+            float t[VEC];
+            vec_unpack<T>(*(const u32x4*)(x + (((int64_t)b * H + yy) * W + xx) * C + cv * VEC), t);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) if (earlier ? t[j] >= me[j] : t[j] > me[j]) first[j] = false;
+          }
+        }
+        float g[VEC];
+        vec_unpack<T>(*(const u32x4*)(dy + (((int64_t)b * Ho + oy) * Wo + ox) * C + cv * VEC), g);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) if (first[j]) s[j] += g[j];
+      }
+    }
+    if (accumulate) {
+      float o[VEC];
+      vec_unpack<T>(*(const u32x4*)(dx + v * VEC), o);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) s[j] += o[j];
+    }
+    *(u32x4*)(dx + v * VEC) = vec_pack<T>(s);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // depth-wise 3x3 conv, pad 1 (DWConv, changeformer.py:85-96): z = dw(x) + b ; g = gelu(z) (exact erf).
 // MODE 0: forward (writes z and g) ; MODE 1: adjoint (flipped taps, no bias, writes z only)
 // ------------------------------------------------------------------------------------------------
@@ -500,6 +581,40 @@ __global__ void bn_bwd_apply_kernel(const T* dy, const T* r, const float* mean, 
   }
 }
 
+// partial[row][0][c] = sum dy, partial[row][1][c] = sum dy * xhat over the row's pixel slab (plain BatchNorm, no ReLU mask):
+// grid (rows, ceil(CV/64)); thread = (pixel lane t>>6, channel vector t&63)
+template <typename T>
+__global__ void bn_bwd_reduce_kernel(const T* dy, const T* x, const float* mean, const float* rstd, float* partial, int64_t npix, int C) {
+  constexpr int VEC = ElemTraits<T>::kVec;
+  __shared__ float red[4][64][2 * VEC + 1];
+  const int CV = C / VEC;
+  const int cvl = threadIdx.x & 63, cv = blockIdx.y * 64 + cvl, pl = threadIdx.x >> 6;
+  float a[VEC], b[VEC], mu[VEC], rs[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) { a[j] = 0.f; b[j] = 0.f; mu[j] = cv < CV ? mean[cv * VEC + j] : 0.f; rs[j] = cv < CV ? rstd[cv * VEC + j] : 0.f; }
+  if (cv < CV) {
+    const int64_t per = (npix + gridDim.x - 1) / gridDim.x;
+    const int64_t p0 = per * blockIdx.x, p1 = min(npix, p0 + per);
+    for (int64_t p = p0 + pl; p < p1; p += 4) {
+      float g[VEC], xv[VEC];
+      vec_unpack<T>(*(const u32x4*)(dy + p * C + cv * VEC), g);
+      vec_unpack<T>(*(const u32x4*)(x + p * C + cv * VEC), xv);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) { a[j] += g[j]; b[j] += g[j] * (xv[j] - mu[j]) * rs[j]; }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) { red[pl][cvl][j] = a[j]; red[pl][cvl][VEC + j] = b[j]; }
+  __syncthreads();
+  if (pl == 0 && cv < CV) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      partial[((size_t)blockIdx.x * 2 + 0) * C + cv * VEC + j] = red[0][cvl][j] + red[1][cvl][j] + red[2][cvl][j] + red[3][cvl][j];
+      partial[((size_t)blockIdx.x * 2 + 1) * C + cv * VEC + j] = red[0][cvl][VEC + j] + red[1][cvl][VEC + j] + red[2][cvl][VEC + j] + red[3][cvl][VEC + j];
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // head output NHWC [B][HW][Cs] -> NCHW fp32 with optional sigmoid (changeformer.py:635-639) and its adjoint
 // ------------------------------------------------------------------------------------------------
@@ -582,6 +697,28 @@ int ksmi_im2col(const void* x, void* out, int B, int Cin, int H, int W, int Ho, 
             hipLaunchKernelGGL((im2col_kernel<float, false>), dim3(grid_for(n, 65536)), dim3(256), 0, st, x, (float*)out, B, Cin, H, W, Ho, Wo, KH, KW, stride, pad, Kpad));
   }
   return ksmi_check_launch("im2col");
+}
+
+int ksmi_maxpool3x3s2_forward(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream) {
+  const int vec = dtype == KSMI_BF16 ? 8 : 4;
+  if (C % vec) return ksmi_fail(KSMI_E_ARG, "maxpool3x3s2: C must be a multiple of the 16-byte vector");
+  const int64_t n = (int64_t)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / vec);
+  hipStream_t st = (hipStream_t)stream;
+  KSMI_DT(dtype,
+          hipLaunchKernelGGL(maxpool3s2_fwd_kernel<bf16_t>, dim3(grid_for(n, 65536)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, B, H, W, C),
+          hipLaunchKernelGGL(maxpool3s2_fwd_kernel<float>, dim3(grid_for(n, 65536)), dim3(256), 0, st, (const float*)x, (float*)y, B, H, W, C));
+  return ksmi_check_launch("maxpool3x3s2_fwd");
+}
+
+int ksmi_maxpool3x3s2_backward(const void* x, const void* dy, void* dx, int accumulate, int B, int H, int W, int C, int dtype, void* stream) {
+  const int vec = dtype == KSMI_BF16 ? 8 : 4;
+  if (C % vec) return ksmi_fail(KSMI_E_ARG, "maxpool3x3s2: C must be a multiple of the 16-byte vector");
+  const int64_t n = (int64_t)B * H * W * (C / vec);
+  hipStream_t st = (hipStream_t)stream;
+  KSMI_DT(dtype,
+          hipLaunchKernelGGL(maxpool3s2_bwd_kernel<bf16_t>, dim3(grid_for(n, 65536)), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, accumulate, B, H, W, C),
+          hipLaunchKernelGGL(maxpool3s2_bwd_kernel<float>, dim3(grid_for(n, 65536)), dim3(256), 0, st, (const float*)x, (const float*)dy, (float*)dx, accumulate, B, H, W, C));
+  return ksmi_check_launch("maxpool3x3s2_bwd");
 }
 
 int ksmi_affine(const void* x, const float* scale, const float* shift, void* y, int64_t npix, int C, int relu, float alpha, int dtype,
@@ -721,6 +858,18 @@ int ksmi_bn_bwd_apply(const void* dy, const void* r, const float* mean, const fl
           hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(grid_for(nvec, 65536)), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)r, mean, rstd, gamma, sums, (bf16_t*)dv, relu_mask, inv_n, nvec, C / vec, C),
           hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid_for(nvec, 65536)), dim3(256), 0, st, (const float*)dy, (const float*)r, mean, rstd, gamma, sums, (float*)dv, relu_mask, inv_n, nvec, C / vec, C));
   return ksmi_check_launch("bn_bwd_apply");
+}
+
+int ksmi_bn_bwd_reduce(const void* dy, const void* x, const float* mean, const float* rstd, float* partial, int rows, int64_t npix, int C,
+                       int dtype, void* stream) {
+  const int vec = dtype == KSMI_BF16 ? 8 : 4;
+  if (C % vec || rows < 1) return ksmi_fail(KSMI_E_ARG, "bn_bwd_reduce: bad args");
+  const dim3 grid(rows, (C / vec + 63) / 64);
+  hipStream_t st = (hipStream_t)stream;
+  KSMI_DT(dtype,
+          hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, mean, rstd, partial, npix, C),
+          hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, grid, dim3(256), 0, st, (const float*)dy, (const float*)x, mean, rstd, partial, npix, C));
+  return ksmi_check_launch("bn_bwd_reduce");
 }
 
 int ksmi_out_to_nchw(const void* x, float* y, int B, int C, int Cs, int64_t HW, int act, int dtype, void* stream) {

@@ -170,7 +170,7 @@ __global__ void pack_weights_kernel(const ksmi_pack_desc d) {
     if (j < d.N && kk < klen) {
       const int64_t k = koff + kk;
       const int tp = d.use_tap_map ? d.tap_map[tap] : (d.flip ? (d.taps - 1 - tap) : tap);
-      v = d.w[k * d.sK + (int64_t)(j % d.n_mod) * d.sN + (int64_t)(j / d.n_mod) * d.sD + tp * d.sT];
+      if (tp >= 0) v = d.w[k * d.sK + (int64_t)(j % d.n_mod) * d.sN + (int64_t)(j / d.n_mod) * d.sD + tp * d.sT];
     }
     ElemTraits<T>::st((T*)d.out + i, v);
   }
@@ -195,7 +195,7 @@ __global__ void pack_weights_batched_kernel(const ksmi_pack_desc* descs) {
     if (j < N && kk < klen) {
       const int64_t k = koff + kk;
       const int tp = d.use_tap_map ? d.tap_map[tap] : (flip ? (taps - 1 - tap) : tap);
-      v = w[k * sK + (int64_t)(j % n_mod) * sN + (int64_t)(j / n_mod) * sD + tp * sT];
+      if (tp >= 0) v = w[k * sK + (int64_t)(j % n_mod) * sN + (int64_t)(j / n_mod) * sD + tp * sT];
     }
     ElemTraits<T>::st(out + i, v);
   }

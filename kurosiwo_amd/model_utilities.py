@@ -32,8 +32,14 @@ def initialize_segmentation_model(config, model_configs):
     (FinetunerSegmentation over a pickled MAE-pretrained ViT encoder, :158-165).  Without `config["encoder"]` a
     randomly initialised encoder of configs/method/mae/mae.json's size is used (no checkpoint can be fetched here)."""
     from .floodvit import FinetunerSegmentation, ViT
+    if config["method"].lower() == "unet":
+        from .unet import Unet
+        model = Unet(encoder_name=model_configs["backbone"], encoder_weights=model_configs["encoder_weights"], in_channels=config["num_channels"],
+                     classes=config["num_classes"], precision=config.get("precision", "bf16" if config.get("mixed_precision") else "fp32"))
+        print(model.__class__.__name__, f"({sum(p.numel() for p in model.parameters())} parameters, precision={model.precision})")
+        return model.to(config["device"])
     if config["method"].lower() != "finetune":
-        raise _lib.KsmiError(f"segmentation method {config['method']!r} has no HIP implementation (in scope: finetune = FloodViT)")
+        raise _lib.KsmiError(f"segmentation method {config['method']!r} has no HIP implementation (in scope: unet, finetune = FloodViT)")
     if config.get("encoder"):
         encoder = torch.load(config["encoder"], map_location="cpu", weights_only=False)
     else:

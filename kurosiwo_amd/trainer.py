@@ -94,8 +94,13 @@ class SegTrainStep(_PlanTrainStep):
     [post, (dem), pre1, pre2] (:107-147); default criterion = create_loss 'cross_entropy' with class weights."""
 
     def __init__(self, model, B, loss_function="cross_entropy", class_weights=(1.0, 1.0, 1.0), **kw):
-        ih, iw = model.hp["image_size"]
-        super().__init__(model, model.plan(B, True, True), B, ih, iw, loss_function, class_weights, **kw)
+        if hasattr(model, "hp"):                      # FloodViT: fixed image size
+            ih, iw = model.hp["image_size"]
+            plan = model.plan(B, True, True)
+        else:                                         # Unet(resnet18): plan per (B, H, W)
+            ih, iw = kw.pop("image_size", (224, 224))
+            plan = model.plan(B, ih, iw, True, True)
+        super().__init__(model, plan, B, ih, iw, loss_function, class_weights, **kw)
 
     def _set_inputs(self, x):
         self.plan.x.copy_(x, non_blocking=True)
