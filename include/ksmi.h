@@ -367,6 +367,10 @@ int ksmi_gemm_nt(const void* x, int x_rs, const void* w, int w_rs, const float* 
 /* dx[rows][K] (+)= dy[rows][N] w */
 int ksmi_gemm_nn(const void* dy, int dy_rs, const void* w, int w_rs, void* dx, int dx_rs, int rows, int K, int N, int accumulate, void* stream);
 
+/* GPU-side input pipeline: the Dataset's per-tile clamp -> nan_to_num -> Normalize (dataset/Dataset.py:164-168,
+ * 193-198) on raw backscatter tiles already in HBM; x, y NCHW fp32 (y may alias x) */
+int ksmi_sar_preprocess(const float* x, const float* mean, const float* stdv, float* y, int B, int C, int64_t HW, float clamp_input, void* stream);
+
 /* plumbing */
 int ksmi_fill_zero(void* p, size_t bytes, void* stream);
 /* NCHW fp32 -> NHWC dtype and back (tests / debugging only) */

@@ -120,6 +120,7 @@ SIGNATURES = {
     "ksmi_add": (_i, [_vp, _vp, _vp, _i64, _i, _vp]),
     "ksmi_relu_backward": (_i, [_vp, _vp, _vp, _i64, _i, _vp]),
     "ksmi_relu_forward": (_i, [_vp, _vp, _i64, _i, _vp]),
+    "ksmi_sar_preprocess": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i64, C.c_float, _vp]),
     "ksmi_cast_bf16": (_i, [_vp, _vp, _i64, _vp]),
     "ksmi_gemm_nt": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
     "ksmi_gemm_nn": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),

@@ -616,6 +616,19 @@ __global__ void bn_bwd_reduce_kernel(const T* dy, const T* x, const float* mean,
 }
 
 // ------------------------------------------------------------------------------------------------
+// SAR tile preprocessing of the reference's Dataset (dataset/Dataset.py:164-168,193-198): clamp to [0, clamp_input],
+// NaN -> clamp_input (torch.nan_to_num(image, clamp_input): +inf/-inf were already clamped), (x - mean[c]) / std[c]; NCHW fp32
+// ------------------------------------------------------------------------------------------------
+__global__ void sar_preprocess_kernel(const float* x, const float* mean, const float* stdv, float* y, int C, int64_t HW, int64_t n, float clampv) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)((i / HW) % C);
+    float v = x[i];
+    v = (v != v) ? clampv : fminf(fmaxf(v, 0.f), clampv);
+    y[i] = (v - mean[c]) / stdv[c];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // head output NHWC [B][HW][Cs] -> NCHW fp32 with optional sigmoid (changeformer.py:635-639) and its adjoint
 // ------------------------------------------------------------------------------------------------
 template <typename T>
@@ -870,6 +883,12 @@ int ksmi_bn_bwd_reduce(const void* dy, const void* x, const float* mean, const f
           hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, mean, rstd, partial, npix, C),
           hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, grid, dim3(256), 0, st, (const float*)dy, (const float*)x, mean, rstd, partial, npix, C));
   return ksmi_check_launch("bn_bwd_reduce");
+}
+
+int ksmi_sar_preprocess(const float* x, const float* mean, const float* stdv, float* y, int B, int C, int64_t HW, float clamp_input, void* stream) {
+  const int64_t n = (int64_t)B * C * HW;
+  hipLaunchKernelGGL(sar_preprocess_kernel, dim3(grid_for(n, 65536)), dim3(256), 0, (hipStream_t)stream, x, mean, stdv, y, C, HW, n, clamp_input);
+  return ksmi_check_launch("sar_preprocess");
 }
 
 int ksmi_out_to_nchw(const void* x, float* y, int B, int C, int Cs, int64_t HW, int act, int dtype, void* stream) {

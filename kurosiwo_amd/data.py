@@ -45,3 +45,19 @@ def prepare_loaders(configs):
     print("Samples in Val Set: ", len(ds["val"]))
     print("Samples in Test Set: ", len(ds["test"]))
     return tr, va, te
+
+
+def preprocess_gpu(raw, mean, std, clamp_input=0.15, out=None):
+    """The Dataset's clamp -> nan_to_num -> Normalize (dataset/Dataset.py:164-168,193-198) on a raw [B,C,H,W] fp32 CUDA tensor."""
+    import torch
+    from . import _lib
+    from .runtime import require_gpu, stream_ptr
+    require_gpu(raw)
+    raw = raw.contiguous().float()
+    B, Cc, H, W = raw.shape
+    m = torch.as_tensor(mean, dtype=torch.float32, device=raw.device)
+    s = torch.as_tensor(std, dtype=torch.float32, device=raw.device)
+    out = torch.empty_like(raw) if out is None else out
+    _lib.check(_lib.load().ksmi_sar_preprocess(raw.data_ptr(), m.data_ptr(), s.data_ptr(), out.data_ptr(), B, Cc, H * W, float(clamp_input), stream_ptr()),
+               "sar_preprocess")
+    return out

@@ -205,3 +205,18 @@ def test_adam_and_sgd_match_reference_formulas(dev):
             pd.grad = g.clone().to(dev)
             opt.step()
         assert (pd.detach().cpu() - pr.detach()).abs().max() < 2e-6, kind
+
+
+def test_sar_preprocess_matches_dataset_pipeline():
+    """clamp -> nan_to_num -> Normalize of dataset/Dataset.py:164-168,193-198."""
+    from kurosiwo_amd.data import preprocess_gpu
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand((3, 2, 64, 48), generator=g) * 0.4 - 0.05
+    x[0, 0, 3, 4] = float("nan")
+    x[1, 1, 0, 0] = float("inf")
+    x[2, 0, 5, 5] = -float("inf")
+    mean, std, cl = [0.0953, 0.0264], [0.0427, 0.0215], 0.15
+    ref = torch.nan_to_num(torch.clamp(x, min=0.0, max=cl), cl)
+    ref = (ref - torch.tensor(mean).view(1, 2, 1, 1)) / torch.tensor(std).view(1, 2, 1, 1)
+    out = preprocess_gpu(x.cuda(), mean, std, cl).cpu()
+    assert torch.allclose(out, ref, rtol=1e-6, atol=1e-6)
