@@ -27,8 +27,12 @@ struct Igemm2Args {            // kernel argument: the public descriptor + launc
 // WN = 1: 4 waves, each 64 pixels x BNW = 16*NT channels.  WN = 2: 8 waves = two channel groups sharing ONE halo image
 // (M = 256 pixels, N = 2*BNW): the L2 -> LDS traffic per output channel halves for N >= 64 (measured: the DMA path moves
 // 2.3x the unique bytes and is the resource the K loop waits on).
-template <typename T, int NT, int KH, int KW, bool AFF, bool EX, int WN>
-__global__ __launch_bounds__(256 * WN) void igemm2_fwd_kernel(const Igemm2Args ka) {
+// LEAN (single-chunk convolutions, K <= 32 bf16 channels: 13 level-0 launches per SNUNet step at ~200 us each): these
+// workgroups are one long dependent chain (address setup -> DMA wait -> 72 MFMAs -> epilogue, ~24k cycles) and only latency
+// matters, so the variant trades the per-lane address table and the tap double-buffer for registers: <= 168 VGPRs and 40 KB
+// of LDS let 3 workgroups share a CU instead of 2.
+template <typename T, int NT, int KH, int KW, bool AFF, bool EX, int WN, bool LEAN = false>
+__global__ __launch_bounds__(256 * WN, LEAN ? 3 : 1) void igemm2_fwd_kernel(const Igemm2Args ka) {
   const ksmi_conv_desc& d = ka.d;
   const long long tm0 = __builtin_readcyclecounter();
   constexpr int NTHR = 256 * WN;
@@ -94,17 +98,21 @@ __global__ __launch_bounds__(256 * WN) void igemm2_fwd_kernel(const Igemm2Args k
   }
 
   // ---- per-lane fragment addresses ---------------------------------------------------------------
-  int a_addr[4][TAPS];
+  int a_addr[LEAN ? 1 : 4][LEAN ? 1 : TAPS];
+  int a_base[4];
 #pragma unroll
   for (int mf = 0; mf < 4; ++mf) {
     int p = wm * 64 + mf * 16 + l15;
     if (p >= P) p = 0;
     const int ly = dTW.div(p), lx = p - ly * d.TW;
     const int base = ly * S * HW + lx * S;
+    a_base[mf] = base;
+    if constexpr (!LEAN) {
 #pragma unroll
-    for (int t = 0; t < TAPS; ++t) {
-      const int ap = base + (t / KW) * HW + (t % KW);
-      a_addr[mf][t] = ap * 64 + ((g ^ swz(ap)) << 4);
+      for (int t = 0; t < TAPS; ++t) {
+        const int ap = base + (t / KW) * HW + (t % KW);
+        a_addr[mf][t] = ap * 64 + ((g ^ swz(ap)) << 4);
+      }
     }
   }
   int b_addr[NT];
@@ -206,7 +214,26 @@ __global__ __launch_bounds__(256 * WN) void igemm2_fwd_kernel(const Igemm2Args k
     }
     const unsigned char* lds_halo = smem + buf * BUFB;
     const unsigned char* lds_w = lds_halo + HPB;
-    if (!(dbg & 1)) {
+    if constexpr (LEAN) {
+      if (!(dbg & 1)) {
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) {
+          const int toff = (t / KW) * HW + (t % KW);
+          u32x4 fa1[4], fb1[NT];
+#pragma unroll
+          for (int mf = 0; mf < 4; ++mf) {
+            const int ap = a_base[mf] + toff;
+            fa1[mf] = *(const u32x4*)(lds_halo + ap * 64 + ((g ^ swz(ap)) << 4));
+          }
+#pragma unroll
+          for (int nf = 0; nf < NT; ++nf) fb1[nf] = *(const u32x4*)(lds_w + t * BN * 64 + b_addr[nf]);
+#pragma unroll
+          for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+            for (int nf = 0; nf < NT; ++nf) mma16<T>(acc[mf][nf], fb1[nf], fa1[mf]);
+        }
+      }
+    } else if (!(dbg & 1)) {
     // fragments of tap t+1 are fetched from LDS while the MFMAs of tap t issue (one wave per SIMD:
     // nothing else hides the LDS latency)
     u32x4 fa[2][4], fb[2][NT];
@@ -266,7 +293,9 @@ int launch2(const ksmi_conv_desc* d, int dbg, hipStream_t st) {
   if (nt > (taps == 1 ? nt_cap11 : nt_cap)) nt = taps == 1 ? nt_cap11 : nt_cap;
   // two channel groups per workgroup (8 waves, one halo image): 3x3 / 2x2 / 1x1 with at least 64 output channels
   static const bool wn_off = getenv("KSMI_WN1") != nullptr;
-  const int wn = (!wn_off && nt == 2 && d->Npad >= 64 && taps <= 9) ? 2 : 1;
+  static const bool lean_off = getenv("KSMI_NO_LEAN") != nullptr;
+  const bool lean = !lean_off && d->nchunks == 1 && taps == 9 && nt == 2 && HP * 64 <= 24576 && d->src[0].scale == nullptr;   // (the AFF path spills at 168 VGPRs)
+  const int wn = (!lean && !wn_off && nt == 2 && d->Npad >= 64 && taps <= 9) ? 2 : 1;
   const int bn = nt * 16 * wn;
   const dim3 grid(gm, (d->Npad + bn - 1) / bn);
   const size_t hpb = ((size_t)HP * 64 + 1023) & ~(size_t)1023;
@@ -289,9 +318,16 @@ int launch2(const ksmi_conv_desc* d, int dbg, hipStream_t st) {
     if (lds > 65536) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     hipLaunchKernelGGL(kfn, grid, dim3(256 * WN_), lds, st, ka);                                    \
   } while (0)
+#define KSMI_L2LEAN(NT_, KH_, KW_, AFF_, EX_)                                                       \
+  do {                                                                                              \
+    auto kfn = igemm2_fwd_kernel<T, NT_, KH_, KW_, AFF_, EX_, 1, true>;                             \
+    hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, ka);                                          \
+  } while (0)
 #define KSMI_L2X(NT_, KH_, KW_, AFF_, EX_)                                                          \
   do {                                                                                              \
-    if constexpr (NT_ == 2 && KH_ * KW_ <= 9) { if (wn == 2) KSMI_L2W(NT_, KH_, KW_, AFF_, EX_, 2); else KSMI_L2W(NT_, KH_, KW_, AFF_, EX_, 1); } \
+    if constexpr (NT_ == 2 && KH_ * KW_ == 9) {                                                     \
+      if (lean) KSMI_L2LEAN(NT_, KH_, KW_, AFF_, EX_); else if (wn == 2) KSMI_L2W(NT_, KH_, KW_, AFF_, EX_, 2); else KSMI_L2W(NT_, KH_, KW_, AFF_, EX_, 1); \
+    } else if constexpr (NT_ == 2 && KH_ * KW_ < 9) { if (wn == 2) KSMI_L2W(NT_, KH_, KW_, AFF_, EX_, 2); else KSMI_L2W(NT_, KH_, KW_, AFF_, EX_, 1); } \
     else KSMI_L2W(NT_, KH_, KW_, AFF_, EX_, 1);                                                     \
   } while (0)
 #define KSMI_L2(NT_, KH_, KW_, AFF_)                                                                \
@@ -311,6 +347,7 @@ int launch2(const ksmi_conv_desc* d, int dbg, hipStream_t st) {
 #undef KSMI_L2
 #undef KSMI_L2X
 #undef KSMI_L2W
+#undef KSMI_L2LEAN
   return ksmi_check_launch("igemm2_fwd");
 }
 
