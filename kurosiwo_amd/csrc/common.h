@@ -15,12 +15,14 @@ typedef uint16_t bf16_t;   // storage type for bf16 activations (raw bits)
 
 // ---- scalar conversions -----------------------------------------------------
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {   // round-to-nearest-even, NaN preserved
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
+// round-to-nearest-even (v_cvt_pk_bf16_f32: one VALU instruction per PAIR instead of five per value)
+typedef float ksmi_f2 __attribute__((ext_vector_type(2)));
+typedef __bf16 ksmi_b2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t f32x2_to_bf16x2(float lo, float hi) {
+  const ksmi_f2 v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, ksmi_b2));
 }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(f32x2_to_bf16x2(f, 0.f) & 0xffffu); }
 
 template <typename T> struct ElemTraits;
 template <> struct ElemTraits<float> {
@@ -52,7 +54,7 @@ template <> __device__ __forceinline__ u32x4 vec_pack<float>(const float* f) {
 template <> __device__ __forceinline__ u32x4 vec_pack<bf16_t>(const float* f) {
   u32x4 v;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) v[i] = (uint32_t)f32_to_bf16(f[2 * i]) | ((uint32_t)f32_to_bf16(f[2 * i + 1]) << 16);
+  for (int i = 0; i < 4; ++i) v[i] = f32x2_to_bf16x2(f[2 * i], f[2 * i + 1]);
   return v;
 }
 

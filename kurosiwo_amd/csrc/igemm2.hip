@@ -268,7 +268,11 @@ __global__ __launch_bounds__(256 * WN, LEAN ? 3 : 1) void igemm2_fwd_kernel(cons
     }
   }
   const long long tm2 = __builtin_readcyclecounter();
-  if (!(dbg & 4)) igemm_epilogue_direct<T, NT, EX, WN>(d, acc, smem, tid, wm, g, l15, b, oy0, ox0, n0 + wn * BNW, P, ka.m_tw, wn, n0);
+  if (!(dbg & 4)) {
+    // EX == false on the bf16 NT = 2 tile means the launcher proved the preconditions of the lean epilogue
+    if constexpr (!EX && NT == 2 && sizeof(T) == 2) igemm_epilogue_fast<WN>(d, acc, smem, tid, wm, g, l15, b, oy0, ox0, n0 + wn * BNW, P, ka.m_tw, wn, n0);
+    else igemm_epilogue_direct<T, NT, EX, WN>(d, acc, smem, tid, wm, g, l15, b, oy0, ox0, n0 + wn * BNW, P, ka.m_tw, wn, n0);
+  }
   if ((dbg & 8) && d.stats && tid == 0 && blockIdx.y == 0) {   // per-block phase timestamps (profiling only; clobbers stats)
     const long long tm3a = __builtin_readcyclecounter();      // epilogue instructions issued
     __builtin_amdgcn_s_waitcnt(0);
@@ -306,7 +310,16 @@ int launch2(const ksmi_conv_desc* d, int dbg, hipStream_t st) {
   if (lds < (size_t)4 * wn * 2 * (bn / wn) * sizeof(float)) lds = (size_t)4 * wn * 2 * (bn / wn) * sizeof(float);
   const bool aff = d->src[0].scale != nullptr;
   // epilogue extras (scale, residual, ReLU, strided placement) compile into a separate kernel: the common path stays lean
-  const bool extras = d->alpha != 0.f || d->resid != nullptr || d->relu_out != 0 || d->out_sy != 0;
+  bool extras = d->alpha != 0.f || d->resid != nullptr || d->relu_out != 0 || d->out_sy != 0;
+  if (sizeof(T) == 2 && nt == 2) {
+    // the lean epilogue (igemm_epilogue.h: igemm_epilogue_fast) replaces the general one when its preconditions hold
+    auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+    const ksmi_dst& d0 = d->dst[0];
+    const bool fast = d->ndst == 1 && d->ps_cout == 0 && (d->N % 8) == 0 && d0.n_begin == 0 && (d0.C % 8) == 0 && (d0.c_off % 8) == 0 &&
+                      al16(d0.ptr) && al16(d->bias) && al16(d->mask_src) && al16(d->m_mean) && al16(d->m_rstd) && al16(d->m_scale) &&
+                      al16(d->m_shift) && (size_t)d->B * d->Hout * d->Wout < ((size_t)1 << 31);
+    if (!fast) extras = true;
+  }
   Igemm2Args ka;
   ka.d = *d;
   ka.m_tw = fastdiv_magic(d->TW); ka.m_hw = fastdiv_magic(HW); ka.m_tx = fastdiv_magic(tilesX); ka.m_ty = fastdiv_magic(tilesY);

@@ -395,3 +395,98 @@ __device__ __forceinline__ void igemm_epilogue_direct(const ksmi_conv_desc& d, f
     }
   }
 }
+
+// -------------------------------------------------------------------------------------------------
+// Lean epilogue of the common case (bf16, NT = 2, ONE destination, channel groups of 8 aligned, no pixel shuffle / strided
+// placement / alpha / residual): the launcher proves the preconditions (igemm2.hip, `fast`), so everything the general epilogue
+// decides per lane at run time (segment lookup, vector eligibility, scalar tails) is gone -- ~6400 -> ~500 instructions of
+// straight-line code; the general one costs ~11k cycles per workgroup, as much as the rest of a K = 32 convolution.
+// Lane (g, l15) owns channels n0 + 8g .. 8g+7 of pixel l15 of each 16-pixel row group: one 16-byte access per (lane, mf).
+// -------------------------------------------------------------------------------------------------
+template <int WN>
+__device__ __forceinline__ void igemm_epilogue_fast(const ksmi_conv_desc& d, f32x4 (&acc)[4][2], unsigned char* smem, int tid,
+                                                    int wave, int g, int l15, int b, int oy0, int ox0, int n0, int P,
+                                                    uint32_t magic_tw, int wn, int n0wg) {
+  typedef bf16_t T;
+  constexpr int BN = 32;
+  const FastDiv dTW(d.TW, magic_tw);
+  const int nc = n0 + g * 8;
+  const bool nv = nc < d.N;
+  const bool has_mask = d.mask_src != nullptr;
+  const bool accum = d.dst[0].accumulate != 0;
+  const int dC = d.dst[0].C;
+  T* const obase = (T*)d.dst[0].ptr + d.dst[0].c_off + nc;
+  const T* const mbase = (const T*)d.mask_src + nc;
+  // pixel offsets and the loads that do not depend on the accumulators go first
+  uint32_t opix[4];
+  bool ok[4];
+  u32x4 mv[4], ov[4];
+#pragma unroll
+  for (int mf = 0; mf < 4; ++mf) {
+    const int p = wave * 64 + mf * 16 + l15;
+    const int ly = dTW.div(p), lx = p - ly * d.TW;
+    const int oy = oy0 + ly, ox = ox0 + lx;
+    ok[mf] = nv && p < P && oy < d.Hout && ox < d.Wout;
+    opix[mf] = (uint32_t)((b * d.Hout + oy) * d.Wout + ox);
+    mv[mf] = (u32x4){0u, 0u, 0u, 0u}; ov[mf] = (u32x4){0u, 0u, 0u, 0u};
+    if (has_mask && ok[mf]) mv[mf] = *(const u32x4*)(mbase + (size_t)opix[mf] * d.N);
+    if (accum && ok[mf]) ov[mf] = *(const u32x4*)(obase + (size_t)opix[mf] * dC);
+  }
+  float bias[8], mm[8], mr[8], mg[8], mb[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { bias[j] = 0.f; mm[j] = 0.f; mr[j] = 0.f; mg[j] = 0.f; mb[j] = 0.f; }
+  auto ld8 = [&](const float* q, float* o) {
+    const f32x4 a = *(const f32x4*)(q + nc), c = *(const f32x4*)(q + nc + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { o[j] = a[j]; o[4 + j] = c[j]; }
+  };
+  if (d.bias && nv) ld8(d.bias, bias);
+  if (has_mask && nv) { ld8(d.m_mean, mm); ld8(d.m_rstd, mr); ld8(d.m_scale, mg); ld8(d.m_shift, mb); }
+  float ssum[8], ssq[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
+#pragma unroll
+  for (int mf = 0; mf < 4; ++mf) {
+    float v[8];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { v[r] = acc[mf][0][r] + bias[r]; v[4 + r] = acc[mf][1][r] + bias[4 + r]; }
+    if (has_mask) {
+      float m[8];
+      vec_unpack<T>(mv[mf], m);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float xh = (m[j] - mm[j]) * mr[j];
+        if (!(m[j] * mg[j] + mb[j] > 0.f)) v[j] = 0.f;
+        if (ok[mf]) { ssum[j] += v[j]; ssq[j] += v[j] * xh; }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) if (ok[mf]) { ssum[j] += v[j]; ssq[j] += v[j] * v[j]; }
+    }
+    if (accum) {
+      float o[8];
+      vec_unpack<T>(ov[mf], o);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] += o[j];
+    }
+    if (ok[mf]) *(u32x4*)(obase + (size_t)opix[mf] * dC) = vec_pack<T>(v);
+  }
+  if (d.stats) {
+    __syncthreads();                                     // (all waves are past their last LDS reads)
+    float* red = (float*)smem;                           // [WN groups][4 waves][2][BN]
+    const int ws = wn * 4 + wave;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float a = row16_sum(ssum[j]), q = row16_sum(ssq[j]);
+      if (l15 == 0) { red[(ws * 2 + 0) * BN + g * 8 + j] = a; red[(ws * 2 + 1) * BN + g * 8 + j] = q; }
+    }
+    __syncthreads();
+    if (tid < 2 * BN * WN) {
+      const int which = tid / (BN * WN), nn = tid - which * (BN * WN);
+      const int grp = nn / BN, n = nn - grp * BN;
+      const float* rg = red + (size_t)grp * 4 * 2 * BN;
+      const float v = rg[(0 * 2 + which) * BN + n] + rg[(1 * 2 + which) * BN + n] + rg[(2 * 2 + which) * BN + n] + rg[(3 * 2 + which) * BN + n];
+      if (n0wg + nn < d.Npad) d.stats[((size_t)blockIdx.x * 2 + which) * d.Npad + n0wg + nn] = v;
+    }
+  }
+}
