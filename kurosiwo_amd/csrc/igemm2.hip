@@ -69,21 +69,24 @@ __global__ __launch_bounds__(256 * WN, LEAN ? 3 : 1) void igemm2_fwd_kernel(cons
   const FastDiv dHW(HW, ka.m_hw), dTW(d.TW, ka.m_tw);
 
   // ---- per-thread halo slots: LDS position v = s*256 + tid <-> (pixel v>>2, slot v&3) -----------
+  // (branch-free: selects only; the strided input view exists only in the EX variant)
   int slot_goff[MAXSLOT];                                   // pixel index in the image, or -1
-  int slot_q[MAXSLOT];                                      // k-group fetched into this LDS slot (DMA path)
-  int slot_lds[MAXSLOT];                                    // register path: where k-group myq of the pixel goes
+  int slot_qb[MAXSLOT];                                     // DMA path: byte offset of the k-group fetched into this LDS slot
+  int slot_lds[AFF ? MAXSLOT : 1];                          // register path: where k-group myq of the pixel goes
+  const int iy0 = oy0 * S - d.pad, ix0 = ox0 * S - d.pad_x;
 #pragma unroll
   for (int s = 0; s < MAXSLOT; ++s) {
     const int v = tid + s * NTHR;
-    slot_goff[s] = -1; slot_q[s] = 0; slot_lds[s] = 0;
-    if (v < HP * 4) {
-      const int pix = v >> 2, sl = v & 3;
-      const int hy = dHW.div(pix), hx = pix - hy * HW;
-      const int iy = oy0 * S - d.pad + hy, ix = ox0 * S - d.pad_x + hx;
-      if (iy >= 0 && iy < d.Hin && ix >= 0 && ix < d.Win) slot_goff[s] = src_pixel(d, b, iy, ix);
-      slot_q[s] = sl ^ swz(pix);
-      slot_lds[s] = pix * 64 + ((sl ^ swz(pix)) << 4);     // (register path: thread owns k-group sl)
-    }
+    const int pix = v >> 2, sl = v & 3;
+    const int hy = dHW.div(pix), hx = pix - hy * HW;
+    const int iy = iy0 + hy, ix = ix0 + hx;
+    const bool ok = v < HP * 4 && (unsigned)iy < (unsigned)d.Hin && (unsigned)ix < (unsigned)d.Win;
+    int gp;
+    if constexpr (EX) gp = src_pixel(d, b, iy, ix);
+    else gp = (b * d.Hin + iy) * d.Win + ix;
+    slot_goff[s] = ok ? gp : -1;
+    slot_qb[s] = (sl ^ swz(pix)) << 4;
+    if constexpr (AFF) slot_lds[s] = pix * 64 + ((sl ^ swz(pix)) << 4);   // (register path: thread owns k-group sl)
   }
   const int myq = tid & 3;
   // padding positions are never written by the DMA: zero them once (both stages; interior patches have none)
@@ -91,7 +94,7 @@ __global__ __launch_bounds__(256 * WN, LEAN ? 3 : 1) void igemm2_fwd_kernel(cons
 #pragma unroll
   for (int s = 0; s < MAXSLOT; ++s) {
     if (tid + s * NTHR < HP * 4 && slot_goff[s] < 0) {
-      const int off = AFF ? slot_lds[s] : (s * NTHR + tid) * 16;
+      const int off = AFF ? slot_lds[AFF ? s : 0] : (s * NTHR + tid) * 16;
       *(u32x4*)(smem + off) = (u32x4){0u, 0u, 0u, 0u};
       if (two_stage) *(u32x4*)(smem + BUFB + off) = (u32x4){0u, 0u, 0u, 0u};
     }
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(256 * WN, LEAN ? 3 : 1) void igemm2_fwd_kernel(cons
     // (epilogue: igemm_epilogue.h, epi_col)
     const int nb = n / BNW, j = n - nb * BNW;
     const int nsrc_ = nb * BNW + ((j >> 2) & 3) * 4 * NT + (j >> 4) * 4 + (j & 3);
-    w_src[i] = (v < WVEC && n0 + nsrc_ < d.Npad) ? ((t * d.Npad + n0 + nsrc_) * KC + ((sl ^ swz(n)) * VEC)) : -1;
+    w_src[i] = (v < WVEC && n0 + nsrc_ < d.Npad) ? ((t * d.Npad + n0 + nsrc_) * 64 + ((sl ^ swz(n)) << 4)) : -1;   // bytes
   }
 
   f32x4 acc[4][NT];
@@ -141,44 +144,55 @@ __global__ __launch_bounds__(256 * WN, LEAN ? 3 : 1) void igemm2_fwd_kernel(cons
 #pragma unroll
     for (int nf = 0; nf < NT; ++nf) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const T* wpk = (const T*)d.wpk;
   u32x4 hreg[AFF ? MAXSLOT : 1];
 
+  // Per-chunk scalars of the source (base pointer of the chunk's first channel, bytes per pixel): fetched ONE chunk ahead of
+  // their use so the scalar loads never stall the wave between the barrier and the MFMAs.  All per-lane offsets are 32-bit
+  // (the launcher checks every source spans < 4 GiB) -> SGPR-base + VGPR-offset addressing, no 64-bit VALU in the loop.
+  struct ChunkSrc { const unsigned char* sp; uint32_t cb; const float* scale; const float* shift; int relu; };
+  auto chunk_scalars = [&](int ch) -> ChunkSrc {
+    ChunkSrc c;
+    const int si = chunk_src_of(d, ch);
+    const ksmi_src& sr = d.src[si];
+    c.sp = (const unsigned char*)((const T*)sr.ptr + sr.c_off + chunk_c0_of(d, ch));
+    c.cb = (uint32_t)sr.C * (uint32_t)sizeof(T);
+    if constexpr (AFF) { c.scale = sr.scale + chunk_c0_of(d, ch); c.shift = sr.shift + chunk_c0_of(d, ch); c.relu = sr.relu; }
+    else { c.scale = nullptr; c.shift = nullptr; c.relu = 0; }
+    return c;
+  };
+  const unsigned char* const wpk = (const unsigned char*)d.wpk;
+  const uint32_t wslab = (uint32_t)TAPS * (uint32_t)d.Npad * 64u;   // bytes of one chunk's weight slab
   auto issue_weights = [&](int ch, int buf) {
-    const T* wsrc = wpk + (size_t)ch * TAPS * d.Npad * KC;
+    const unsigned char* wsrc = wpk + (size_t)ch * wslab;
     unsigned char* wdst = smem + buf * BUFB + HPB;
 #pragma unroll
     for (int i = 0; i < WITER; ++i) {
       if (w_src[i] >= 0)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + w_src[i]),
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + (uint32_t)w_src[i]),
                                          (__attribute__((address_space(3))) void*)(wdst + (i * NTHR + wave * 64) * 16), 16, 0, 0);
     }
   };
-  auto issue_halo_dma = [&](int ch, int buf) {
-    const ksmi_src& sr = d.src[chunk_src_of(d, ch)];
-    const T* sp = (const T*)sr.ptr + sr.c_off + chunk_c0_of(d, ch);
+  auto issue_halo_dma = [&](const ChunkSrc& c, int buf) {
     unsigned char* hdst = smem + buf * BUFB;
 #pragma unroll
     for (int s = 0; s < MAXSLOT; ++s) {
+      const uint32_t off = (uint32_t)slot_goff[s] * c.cb + (uint32_t)slot_qb[s];
       if (s < nslot && slot_goff[s] >= 0)
-        __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void*)(sp + (size_t)slot_goff[s] * sr.C + slot_q[s] * VEC),
-            (__attribute__((address_space(3))) void*)(hdst + (s * NTHR + wave * 64) * 16), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(c.sp + off),
+                                         (__attribute__((address_space(3))) void*)(hdst + (s * NTHR + wave * 64) * 16), 16, 0, 0);
     }
   };
-  auto load_halo_regs = [&](int ch) {                      // AFF: thread owns k-group myq of its slot pixels
-    const ksmi_src& sr = d.src[chunk_src_of(d, ch)];
-    const T* sp = (const T*)sr.ptr + sr.c_off + chunk_c0_of(d, ch) + myq * VEC;
+  auto load_halo_regs = [&](const ChunkSrc& c) {           // AFF: thread owns k-group myq of its slot pixels
 #pragma unroll
-    for (int s = 0; s < MAXSLOT; ++s)
-      if (s < nslot && slot_goff[s] >= 0) hreg[AFF ? s : 0] = *(const u32x4*)(sp + (size_t)slot_goff[s] * sr.C);
+    for (int s = 0; s < MAXSLOT; ++s) {
+      const uint32_t off = (uint32_t)slot_goff[s] * c.cb + (uint32_t)(myq * 16);
+      if (s < nslot && slot_goff[s] >= 0) hreg[AFF ? s : 0] = *(const u32x4*)(c.sp + off);
+    }
   };
-  auto store_halo_regs = [&](int ch, int buf) {
-    const ksmi_src& sr = d.src[chunk_src_of(d, ch)];
-    const int cq = chunk_c0_of(d, ch) + myq * VEC;
+  auto store_halo_regs = [&](const ChunkSrc& c, int buf) {
     float sc[VEC], sh[VEC];
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) { sc[j] = sr.scale[cq + j]; sh[j] = sr.shift[cq + j]; }
+    for (int j = 0; j < VEC; ++j) { sc[j] = c.scale[myq * VEC + j]; sh[j] = c.shift[myq * VEC + j]; }
     unsigned char* hdst = smem + buf * BUFB;
 #pragma unroll
     for (int s = 0; s < MAXSLOT; ++s)
@@ -188,18 +202,20 @@ __global__ __launch_bounds__(256 * WN, LEAN ? 3 : 1) void igemm2_fwd_kernel(cons
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
           f[j] = f[j] * sc[j] + sh[j];
-          if (sr.relu) f[j] = fmaxf(f[j], 0.f);
+          if (c.relu) f[j] = fmaxf(f[j], 0.f);
         }
-        *(u32x4*)(hdst + slot_lds[s]) = vec_pack<T>(f);
+        *(u32x4*)(hdst + slot_lds[AFF ? s : 0]) = vec_pack<T>(f);
       }
   };
 
   const long long tm1 = __builtin_readcyclecounter();
   __syncthreads();                                          // zero fill visible before any DMA lands
   // ---- prologue: stage chunk 0 ---------------------------------------------------------------------
+  ChunkSrc cnext = chunk_scalars(0);
   issue_weights(0, 0);
-  if constexpr (AFF) { load_halo_regs(0); store_halo_regs(0, 0); }
-  else issue_halo_dma(0, 0);
+  if constexpr (AFF) { load_halo_regs(cnext); store_halo_regs(cnext, 0); }
+  else issue_halo_dma(cnext, 0);
+  if (d.nchunks > 1) cnext = chunk_scalars(1);
 
   const int dbg = ka.dbg;            // profiling switches (KSMI_DBG): 1 no MFMA, 2 no DMA, 4 no epilogue
   for (int ch = 0; ch < d.nchunks; ++ch) {
@@ -207,11 +223,13 @@ __global__ __launch_bounds__(256 * WN, LEAN ? 3 : 1) void igemm2_fwd_kernel(cons
     const int nbuf = two_stage ? (buf ^ 1) : 0;
     __syncthreads();                                        // chunk ch landed (vmcnt(0) before the barrier); the other stage is free
     const bool more = ch + 1 < d.nchunks;
+    const ChunkSrc ccur = cnext;                            // scalars of chunk ch + 1
     if (two_stage && more && !(dbg & 2)) {
       issue_weights(ch + 1, nbuf);
-      if constexpr (AFF) load_halo_regs(ch + 1);
-      else issue_halo_dma(ch + 1, nbuf);
+      if constexpr (AFF) load_halo_regs(ccur);
+      else issue_halo_dma(ccur, nbuf);
     }
+    if (ch + 2 < d.nchunks) cnext = chunk_scalars(ch + 2);  // in flight during the MFMAs
     const unsigned char* lds_halo = smem + buf * BUFB;
     const unsigned char* lds_w = lds_halo + HPB;
     if constexpr (LEAN) {
@@ -258,13 +276,13 @@ __global__ __launch_bounds__(256 * WN, LEAN ? 3 : 1) void igemm2_fwd_kernel(cons
     }
     }
     if (two_stage) {
-      if constexpr (AFF) { if (more) store_halo_regs(ch + 1, nbuf); }
+      if constexpr (AFF) { if (more) store_halo_regs(ccur, nbuf); }
     } else if (more) {
       // single stage (40 KB: more workgroups per CU instead of intra-workgroup overlap): refill after the MFMAs
       __syncthreads();
       issue_weights(ch + 1, 0);
-      if constexpr (AFF) { load_halo_regs(ch + 1); store_halo_regs(ch + 1, 0); }
-      else issue_halo_dma(ch + 1, 0);
+      if constexpr (AFF) { load_halo_regs(ccur); store_halo_regs(ccur, 0); }
+      else issue_halo_dma(ccur, 0);
     }
   }
   const long long tm2 = __builtin_readcyclecounter();
@@ -290,6 +308,10 @@ int launch2(const ksmi_conv_desc* d, int dbg, hipStream_t st) {
   const int HH = (d->TH - 1) * d->stride + d->KH, HW = (d->TW - 1) * d->stride + d->KW;
   const int HP = HH * HW;
   if (d->TH * d->TW > 256 || HP * 4 > 2048) return ksmi_fail(KSMI_E_ARG, "conv: patch too large (TH*TW<=256, halo<=512 px)");
+  for (int i = 0; i < d->nsrc; ++i) {   // per-lane source offsets are 32-bit
+    const size_t px = d->in_sy ? (size_t)d->B * d->in_H * d->in_W : (size_t)d->B * d->Hin * d->Win;
+    if (px * (size_t)d->src[i].C * sizeof(T) >= ((size_t)1 << 32)) return ksmi_fail(KSMI_E_UNSUPPORTED, "conv: a source tensor of 4 GiB or more is not supported");
+  }
   static const int nt_cap = getenv("KSMI_NT_CAP") ? atoi(getenv("KSMI_NT_CAP")) : 2;      // BN=32: 80 KB of LDS = 2 workgroups per CU beats the BN=64 tile (1 per CU) by 15-35 %
   int nt = d->Npad >= 64 ? 4 : (d->Npad >= 32 ? 2 : 1);
   // token GEMMs (1x1) keep both a small halo (16 KB) and a small weight slab: BN = 64 still leaves 2 workgroups per CU
@@ -310,7 +332,7 @@ int launch2(const ksmi_conv_desc* d, int dbg, hipStream_t st) {
   if (lds < (size_t)4 * wn * 2 * (bn / wn) * sizeof(float)) lds = (size_t)4 * wn * 2 * (bn / wn) * sizeof(float);
   const bool aff = d->src[0].scale != nullptr;
   // epilogue extras (scale, residual, ReLU, strided placement) compile into a separate kernel: the common path stays lean
-  bool extras = d->alpha != 0.f || d->resid != nullptr || d->relu_out != 0 || d->out_sy != 0;
+  bool extras = d->alpha != 0.f || d->resid != nullptr || d->relu_out != 0 || d->out_sy != 0 || d->in_sy != 0;
   if (sizeof(T) == 2 && nt == 2) {
     // the lean epilogue (igemm_epilogue.h: igemm_epilogue_fast) replaces the general one when its preconditions hold
     auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
