@@ -241,7 +241,7 @@ __device__ __forceinline__ int wg_dy_off(int row, int byte) {
 }
 
 template <typename T, int NT, int KH, int KW>
-__global__ __launch_bounds__(256) void igemm_wgrad_kernel(const ksmi_wgrad_desc d, int patches_total, int patches_per_split) {
+__global__ __launch_bounds__(256, 2) void igemm_wgrad_kernel(const ksmi_wgrad_desc d, int patches_total, int patches_per_split) {
   constexpr int TAPS = KH * KW;
   constexpr int BN = NT * 16;
   constexpr int VEC = ElemTraits<T>::kVec;
@@ -289,101 +289,168 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const ksmi_wgrad_desc 
 #pragma unroll
       for (int n = 0; n < NT; ++n) acc[a][c][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  // ---- patch-invariant per-thread tables (the patch loop then needs a handful of VALU per 16-byte vector) ------------
+  constexpr int MAXS = 8;                      // HP*4 <= 2048 vectors, 256 threads
+  constexpr int VPR = BN / VEC;                // 16-byte vectors per dY row = dY vectors per thread (Ppad <= 256)
+  const int padx = d.pad_x_set ? d.pad_x : d.pad;
+  const uint32_t xcb = (uint32_t)sr.C * ES, dycb = (uint32_t)d.dyC * ES;
+  const int x_sy = d.in_sy == 0 ? d.Win : d.in_sy * d.in_W, x_sx = d.in_sy == 0 ? 1 : d.in_sx;
+  int x_hyx[MAXS];                             // (hy << 16) | hx of the halo pixel of slot s, -1: none
+#pragma unroll
+  for (int s_ = 0; s_ < MAXS; ++s_) {
+    const int v = tid + s_ * 256;
+    const int pix = v >> 2;
+    const int hy = dHW.div(pix), hx = pix - hy * HW;
+    x_hyx[s_] = v < HP * 4 ? ((hy << 16) | hx) : -1;
+  }
+  const int dq = tid % VPR;                    // 256 % VPR == 0: a thread always owns vector dq of its dY rows
+  const bool dqvalid = n0 + dq * VEC < d.N;
+  int dy_lyx[VPR];                             // (ly << 16) | lx, -2: zero row of the k padding, -1: no vector
+#pragma unroll
+  for (int s_ = 0; s_ < VPR; ++s_) {
+    const int pp = tid / VPR + s_ * (256 / VPR);
+    const int ly = dTW.div(pp), lx = pp - ly * d.TW;
+    dy_lyx[s_] = pp < Ppad ? (pp < P ? ((ly << 16) | lx) : -2) : -1;
+  }
+  const unsigned char* const xsp = (const unsigned char*)((const T*)sr.ptr + sr.c_off + cq);
+  const unsigned char* const dyp = (const unsigned char*)((const T*)d.dy + d.dy_c_off + n0 + dq * VEC);
+
   const int p_begin = split * patches_per_split;
   const int p_end = min(patches_total, p_begin + patches_per_split);
-  for (int patch = p_begin; patch < p_end; ++patch) {
+  // Software pipeline over patches: the global loads of patch i+1 are issued before the MFMAs of patch i and land in registers
+  // while they run (a workgroup walks 6-25 patches and only 1-3 workgroups share a CU: nothing else hides the load latency).
+  u32x4 xv[MAXS], dv[VPR];
+  auto patch_origin = [&](int patch, int& b, int& oy0, int& ox0) {
     int bm = patch;
     const int tx = bm % tilesX; bm /= tilesX;
-    const int ty = bm % tilesY; const int b = bm / tilesY;
-    const int oy0 = ty * d.TH, ox0 = tx * d.TW;
-    __syncthreads();
-    // ---- stage X halo -------------------------------------------------------------------
-    {
-      const T* sp = (const T*)sr.ptr + sr.c_off + cq;
-      for (int v = tid; v < HP * 4; v += 256) {
-        const int pix = v >> 2;
-        const int hy = dHW.div(pix), hx = pix - hy * HW;
-        const int iy = oy0 * S - d.pad + hy, ix = ox0 * S - (d.pad_x_set ? d.pad_x : d.pad) + hx;
-        u32x4 x = (u32x4){0u, 0u, 0u, 0u};
-        if (cvalid && iy >= 0 && iy < d.Hin && ix >= 0 && ix < d.Win) {
-          const size_t spix = d.in_sy == 0 ? (size_t)(b * d.Hin + iy) * d.Win + ix
-                                           : (size_t)(b * d.in_H + (iy * d.in_sy + d.in_oy)) * d.in_W + (ix * d.in_sx + d.in_ox);
-          x = *(const u32x4*)(sp + spix * sr.C);
-          if (aff) {
+    const int ty = bm % tilesY; b = bm / tilesY;
+    oy0 = ty * d.TH; ox0 = tx * d.TW;
+  };
+  auto load_patch = [&](int patch) {
+    int b, oy0, ox0;
+    patch_origin(patch, b, oy0, ox0);
+    const int iy0 = oy0 * S - d.pad, ix0 = ox0 * S - padx;
+    const int xbase = d.in_sy == 0 ? (b * d.Hin + iy0) * d.Win + ix0
+                                   : (b * d.in_H + iy0 * d.in_sy + d.in_oy) * d.in_W + ix0 * d.in_sx + d.in_ox;
+    const int dybase = (b * d.Hout + oy0) * d.Wout + ox0;
+#pragma unroll
+    for (int s_ = 0; s_ < MAXS; ++s_) {
+      xv[s_] = (u32x4){0u, 0u, 0u, 0u};
+      if (s_ * 256 < HP * 4) {
+        const int hy = x_hyx[s_] >> 16, hx = x_hyx[s_] & 0xffff;
+        const int iy = iy0 + hy, ix = ix0 + hx;
+        if (x_hyx[s_] >= 0 && cvalid && (unsigned)iy < (unsigned)d.Hin && (unsigned)ix < (unsigned)d.Win)
+          xv[s_] = *(const u32x4*)(xsp + (uint32_t)(xbase + hy * x_sy + hx * x_sx) * xcb);
+      }
+    }
+#pragma unroll
+    for (int s_ = 0; s_ < VPR; ++s_) {
+      dv[s_] = (u32x4){0u, 0u, 0u, 0u};
+      const int ly = dy_lyx[s_] >> 16, lx = dy_lyx[s_] & 0xffff;
+      if (dy_lyx[s_] >= 0 && dqvalid && oy0 + ly < d.Hout && ox0 + lx < d.Wout)
+        dv[s_] = *(const u32x4*)(dyp + (uint32_t)(dybase + ly * d.Wout + lx) * dycb);
+    }
+  };
+  auto store_patch = [&](int patch) {
+    int b, oy0, ox0;
+    patch_origin(patch, b, oy0, ox0);
+    const int iy0 = oy0 * S - d.pad, ix0 = ox0 * S - padx;
+#pragma unroll
+    for (int s_ = 0; s_ < MAXS; ++s_)
+      if (s_ * 256 < HP * 4 && x_hyx[s_] >= 0) {
+        if (aff) {
+          const int hy = x_hyx[s_] >> 16, hx = x_hyx[s_] & 0xffff;
+          if (cvalid && (unsigned)(iy0 + hy) < (unsigned)d.Hin && (unsigned)(ix0 + hx) < (unsigned)d.Win) {
             float f[VEC];
-            vec_unpack<T>(x, f);
+            vec_unpack<T>(xv[s_], f);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
               f[j] = f[j] * sc[j] + sh[j];
               if (sr.relu) f[j] = fmaxf(f[j], 0.f);
             }
-            x = vec_pack<T>(f);
+            xv[s_] = vec_pack<T>(f);
           }
         }
-        *(u32x4*)(lds_x + wg_x_off(pix, myq * 16)) = x;
+        *(u32x4*)(lds_x + wg_x_off((tid >> 2) + s_ * 64, myq * 16)) = xv[s_];
       }
-    }
-    // ---- stage dY tile [Ppad][BN] (zero rows for invalid pixels) ------------------------------
-    {
-      constexpr int VPR = BN / VEC;            // 16-byte vectors per row
-      const T* dyp = (const T*)d.dy + d.dy_c_off + n0;
-      for (int v = tid; v < Ppad * VPR; v += 256) {
-        const int p = v / VPR, q = v - p * VPR;
-        const int ly = dTW.div(p), lx = p - ly * d.TW;
-        const int oy = oy0 + ly, ox = ox0 + lx;
-        u32x4 x = (u32x4){0u, 0u, 0u, 0u};
-        if (p < P && oy < d.Hout && ox < d.Wout && n0 + q * VEC < d.N)
-          x = *(const u32x4*)(dyp + ((size_t)(b * d.Hout + oy) * d.Wout + ox) * d.dyC + q * VEC);
-        *(u32x4*)(lds_dy + wg_dy_off<GR>(p, q * 16)) = x;
-      }
-    }
+#pragma unroll
+    for (int s_ = 0; s_ < VPR; ++s_)
+      if (dy_lyx[s_] != -1) *(u32x4*)(lds_dy + wg_dy_off<GR>(tid / VPR + s_ * (256 / VPR), dq * 16)) = dv[s_];
+  };
+  if (p_begin < p_end) load_patch(p_begin);
+  for (int patch = p_begin; patch < p_end; ++patch) {
+    __syncthreads();                           // the previous patch's MFMAs are done with the LDS images
+    store_patch(patch);
     __syncthreads();
+    if (patch + 1 < p_end) load_patch(patch + 1);
     // ---- MFMA over pixel k-steps --------------------------------------------------------------
     // 1x1 (token GEMM) case: a single tap would keep one wave busy, so the four waves split the pixel k-steps instead
     // and their accumulators are summed through LDS after the patch loop (SPLITK)
-    for (int ks = 0; ks < Ppad; ks += KSTEP) {
-      if (SPLITK && (((ks / KSTEP) & 3) != wave)) continue;
-      u32x4 bfrag[NT];
-      if constexpr (sizeof(T) == 2) {
+    if constexpr (sizeof(T) == 2) {
+      const unsigned ldx = (unsigned)(uintptr_t)lds_x + (l15 & 3) * 8, ldy = (unsigned)(uintptr_t)lds_dy + (l15 & 3) * 8;
+      for (int ks = 0; ks < Ppad; ks += KSTEP) {
+        if (SPLITK && (((ks / KSTEP) & 3) != wave)) continue;
+        // halo pixel of the two transposed-read rows (jr, 4 + jr) of this k-step: ONE division pair per k-step, shared by
+        // every tap / channel fragment (it used to be recomputed inside each fragment read)
+        int xa[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          int pp = ks + g * 8 + h * 4 + (l15 >> 2);
+          if (pp >= P) pp = 0;                 // dY rows >= P are zero
+          const int ly = dTW.div(pp), lx = pp - ly * d.TW;
+          xa[h] = ly * S * HW + lx * S;
+        }
+        u32x4 bfrag[NT];
 #pragma unroll
         for (int nf = 0; nf < NT; ++nf) {
-          auto rowaddr = [&](int j) -> unsigned {
-            return (unsigned)(uintptr_t)(lds_dy) + wg_dy_off<GR>(ks + g * 8 + j, nf * 32);
-          };
-          bfrag[nf] = TrRead<bf16_t>::read(rowaddr, l15);
+          const unsigned a0 = ldy + wg_dy_off<GR>(ks + g * 8 + (l15 >> 2), nf * 32), a1 = ldy + wg_dy_off<GR>(ks + g * 8 + 4 + (l15 >> 2), nf * 32);
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(uintptr_t)a0);
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(uintptr_t)a1);
+          bfrag[nf] = __builtin_bit_cast(u32x4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
         }
-      } else {
+#pragma unroll
+        for (int a_ = 0; a_ < TPW; ++a_) {
+          const int t = SPLITK ? 0 : wave + a_ * 4;
+          if (t >= TAPS) break;
+          const int toff = (t / KW) * HW + (t % KW);
+          const int hp0 = xa[0] + toff, hp1 = xa[1] + toff;
+#pragma unroll
+          for (int cf = 0; cf < CF; ++cf) {
+            const unsigned a0 = ldx + hp0 * 64 + (((cf ^ (hp0 >> 3)) & 1) << 5), a1 = ldx + hp1 * 64 + (((cf ^ (hp1 >> 3)) & 1) << 5);
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(uintptr_t)a0);
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(uintptr_t)a1);
+            const u32x4 afrag = __builtin_bit_cast(u32x4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+            for (int nf = 0; nf < NT; ++nf) mma16<T>(acc[a_][cf][nf], afrag, bfrag[nf]);
+          }
+        }
+      }
+    } else {
+      for (int ks = 0; ks < Ppad; ks += KSTEP) {
+        if (SPLITK && (((ks / KSTEP) & 3) != wave)) continue;
+        u32x4 bfrag[NT];
 #pragma unroll
         for (int nf = 0; nf < NT; ++nf)
 #pragma unroll
-          for (int s = 0; s < 4; ++s)
-            bfrag[nf][s] = *(const uint32_t*)(lds_dy + wg_dy_off<GR>(ks + g * 4 + s, (nf * 16 + l15) * 4));
-      }
+          for (int s_ = 0; s_ < 4; ++s_)
+            bfrag[nf][s_] = *(const uint32_t*)(lds_dy + wg_dy_off<GR>(ks + g * 4 + s_, (nf * 16 + l15) * 4));
 #pragma unroll
-      for (int a = 0; a < TPW; ++a) {
-        const int t = SPLITK ? 0 : wave + a * 4;
-        if (t >= TAPS) break;
-        const int toff = (t / KW) * HW + (t % KW);
+        for (int a_ = 0; a_ < TPW; ++a_) {
+          const int t = SPLITK ? 0 : wave + a_ * 4;
+          if (t >= TAPS) break;
+          const int toff = (t / KW) * HW + (t % KW);
 #pragma unroll
-        for (int cf = 0; cf < CF; ++cf) {
-          u32x4 afrag;
-          if constexpr (sizeof(T) == 2) {
-            auto rowaddr = [&](int j) -> unsigned {
-              int p = ks + g * 8 + j; if (p >= P) p = 0;      // dY rows >= P are zero
-              const int ly = dTW.div(p), lx = p - ly * d.TW;
-              return (unsigned)(uintptr_t)(lds_x) + wg_x_off(ly * S * HW + lx * S + toff, cf * 32);
-            };
-            afrag = TrRead<bf16_t>::read(rowaddr, l15);
-          } else {
+          for (int cf = 0; cf < CF; ++cf) {
+            u32x4 afrag;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-              int p = ks + g * 4 + s; if (p >= P) p = 0;
-              const int ly = dTW.div(p), lx = p - ly * d.TW;
-              afrag[s] = *(const uint32_t*)(lds_x + wg_x_off(ly * S * HW + lx * S + toff, l15 * 4));
+            for (int s_ = 0; s_ < 4; ++s_) {
+              int pp = ks + g * 4 + s_; if (pp >= P) pp = 0;
+              const int ly = dTW.div(pp), lx = pp - ly * d.TW;
+              afrag[s_] = *(const uint32_t*)(lds_x + wg_x_off(ly * S * HW + lx * S + toff, l15 * 4));
             }
-          }
 #pragma unroll
-          for (int nf = 0; nf < NT; ++nf) mma16<T>(acc[a][cf][nf], afrag, bfrag[nf]);
+            for (int nf = 0; nf < NT; ++nf) mma16<T>(acc[a_][cf][nf], afrag, bfrag[nf]);
+          }
         }
       }
     }
@@ -647,9 +714,11 @@ WgradGeom wgrad_geom(const ksmi_wgrad_desc* d) {
   const int tilesX = (d->Wout + d->TW - 1) / d->TW, tilesY = (d->Hout + d->TH - 1) / d->TH;
   g.patches = d->B * tilesX * tilesY;
   // aim at ~1024 workgroups in total; at most 256 splits
-  int want = 1024 / (d->nchunks * g.ntiles);
+  static const int wg_target = getenv("KSMI_WGRAD_WGS") ? atoi(getenv("KSMI_WGRAD_WGS")) : 1024;
+  static const int split_cap = getenv("KSMI_WGRAD_SPLITS") ? atoi(getenv("KSMI_WGRAD_SPLITS")) : 256;
+  int want = wg_target / (d->nchunks * g.ntiles);
   if (want < 1) want = 1;
-  if (want > 256) want = 256;
+  if (want > split_cap) want = split_cap;
   if (want > g.patches) want = g.patches;
   g.pps = (g.patches + want - 1) / want;
   g.nsplit = (g.patches + g.pps - 1) / g.pps;
@@ -681,6 +750,13 @@ int launch_wgrad(const ksmi_wgrad_desc* d, hipStream_t st) {
     int blocks0 = (int)((total0 + 255) / 256); if (blocks0 > 8192) blocks0 = 8192;
     hipLaunchKernelGGL(tn_reduce_kernel, dim3(blocks0), dim3(256), 0, st, *d, g.kc, d->nchunks * g.kc);
     return ksmi_check_launch("tn_reduce");
+  }
+  {   // per-lane offsets of the staging loads are 32-bit
+    const size_t pin = d->in_sy ? (size_t)d->B * d->in_H * d->in_W : (size_t)d->B * d->Hin * d->Win;
+    size_t cmax = d->dyC;
+    for (int i = 0; i < d->nsrc; ++i) if ((size_t)d->src[i].C > cmax) cmax = d->src[i].C;
+    const size_t pmax = pin > (size_t)d->B * d->Hout * d->Wout ? pin : (size_t)d->B * d->Hout * d->Wout;
+    if (pmax * cmax * sizeof(T) >= ((size_t)1 << 32)) return ksmi_fail(KSMI_E_UNSUPPORTED, "wgrad: a tensor of 4 GiB or more is not supported");
   }
   const dim3 grid(g.nsplit, d->nchunks, g.ntiles);
 #define KSMI_LAUNCH_WG(NT_, KH_, KW_)                                                               \
