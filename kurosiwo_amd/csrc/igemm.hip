@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_kernel(const ksmi_wgrad_de
   constexpr int GR = (BN * ES / 32) > 0 ? (BN * ES / 32) : 1;   // 32-byte granules per dY row
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, l15 = lane & 15;
   const int split = blockIdx.x, ch = blockIdx.y, n0 = blockIdx.z * BN;
   const int S = d.stride;
@@ -408,20 +408,36 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_kernel(const ksmi_wgrad_de
           const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(uintptr_t)a1);
           bfrag[nf] = __builtin_bit_cast(u32x4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
         }
-#pragma unroll
-        for (int a_ = 0; a_ < TPW; ++a_) {
+        // NT <= 2: every fragment of the k-step is requested before the first MFMA (one LDS round trip per k-step instead of
+        // one per (tap, channel fragment) group); the NT = 4 tile has no registers left for that
+        constexpr bool BATCH = NT <= 2;
+        u32x4 afrag[BATCH ? TPW : 1][BATCH ? CF : 1];
+        auto read_a = [&](int a_, int cf) -> u32x4 {
           const int t = SPLITK ? 0 : wave + a_ * 4;
-          if (t >= TAPS) break;
           const int toff = (t / KW) * HW + (t % KW);
           const int hp0 = xa[0] + toff, hp1 = xa[1] + toff;
+          const unsigned a0 = ldx + hp0 * 64 + (((cf ^ (hp0 >> 3)) & 1) << 5), a1 = ldx + hp1 * 64 + (((cf ^ (hp1 >> 3)) & 1) << 5);
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(uintptr_t)a0);
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(uintptr_t)a1);
+          return __builtin_bit_cast(u32x4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        };
+        if constexpr (BATCH) {
+#pragma unroll
+          for (int a_ = 0; a_ < TPW; ++a_) {
+            if ((SPLITK ? 0 : wave + a_ * 4) >= TAPS) break;
+#pragma unroll
+            for (int cf = 0; cf < CF; ++cf) afrag[a_][cf] = read_a(a_, cf);
+          }
+        }
+#pragma unroll
+        for (int a_ = 0; a_ < TPW; ++a_) {
+          if ((SPLITK ? 0 : wave + a_ * 4) >= TAPS) break;
 #pragma unroll
           for (int cf = 0; cf < CF; ++cf) {
-            const unsigned a0 = ldx + hp0 * 64 + (((cf ^ (hp0 >> 3)) & 1) << 5), a1 = ldx + hp1 * 64 + (((cf ^ (hp1 >> 3)) & 1) << 5);
-            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(uintptr_t)a0);
-            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(uintptr_t)a1);
-            const u32x4 afrag = __builtin_bit_cast(u32x4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            u32x4 af;
+            if constexpr (BATCH) af = afrag[a_][cf]; else af = read_a(a_, cf);
 #pragma unroll
-            for (int nf = 0; nf < NT; ++nf) mma16<T>(acc[a_][cf][nf], afrag, bfrag[nf]);
+            for (int nf = 0; nf < NT; ++nf) mma16<T>(acc[a_][cf][nf], af, bfrag[nf]);
           }
         }
       }
@@ -709,6 +725,8 @@ WgradGeom wgrad_geom(const ksmi_wgrad_desc* d) {
   g.kc = ElemTraits<T>::kVec * 4;
   g.npad = (d->N + 15) & ~15;
   g.nt = g.npad >= 64 ? 4 : (g.npad >= 32 ? 2 : 1);
+  static const int wnt_cap = getenv("KSMI_WGRAD_NT") ? atoi(getenv("KSMI_WGRAD_NT")) : 4;
+  if (g.nt > wnt_cap) g.nt = wnt_cap;
   g.bn = g.nt * 16;
   g.ntiles = (g.npad + g.bn - 1) / g.bn;
   const int tilesX = (d->Wout + d->TW - 1) / d->TW, tilesY = (d->Hout + d->TH - 1) / d->TH;
