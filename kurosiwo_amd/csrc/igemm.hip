@@ -229,10 +229,11 @@ template <> struct TrRead<bf16_t> {
 // the 2 x 32 lanes of a ds_read_b64_tr_b16 (4 rows x 32 B per 16-lane group; rows p..p+3 and p+8..p+11) land on
 // 8 distinct 32-byte bank groups (unswizzled: 2-way on the X tile, 4-way on the dY tile; rocprofv3 showed
 // SQ_LDS_BANK_CONFLICT = 58 % of SQ_LDS_IDX_ACTIVE):
-//   X halo tile [halo pixel][64 B]        granule' = granule ^ ((hp >> 3) & 1)
+//   X halo tile [halo pixel][64 B]        granule' = granule ^ (((hx >> 3) ^ hy) & 1)   (hy, hx = halo row / column: for patches
+//                                          whose width divides 16 the term is the same for every pixel k-step of a lane)
 //   dY tile     [pixel row][GR * 32 B]    granule' = granule ^ f(row),  f = (row>>1 & 1) | (row>>3 & 1) << 1   (row & 7 for GR = 8)
-__device__ __forceinline__ int wg_x_off(int hp, int byte) {
-  return hp * 64 + ((((byte >> 5) ^ (hp >> 3)) & 1) << 5) + (byte & 31);
+__device__ __forceinline__ int wg_x_off(int hp, int hy, int hx, int byte) {
+  return hp * 64 + ((((byte >> 5) ^ (hx >> 3) ^ hy) & 1) << 5) + (byte & 31);
 }
 template <int GR>
 __device__ __forceinline__ int wg_dy_off(int row, int byte) {
@@ -240,8 +241,8 @@ __device__ __forceinline__ int wg_dy_off(int row, int byte) {
   return row * (GR * 32) + ((((byte >> 5) ^ f) & (GR - 1)) << 5) + (byte & 31);
 }
 
-template <typename T, int NT, int KH, int KW>
-__global__ __launch_bounds__(256, 2) void igemm_wgrad_kernel(const ksmi_wgrad_desc d, int patches_total, int patches_per_split) {
+template <typename T, int NT, int KH, int KW, bool LIN>
+__global__ __launch_bounds__(256, ((NT == 4 && KH * KW >= 9) ? 1 : 2)) void igemm_wgrad_kernel(const ksmi_wgrad_desc d, int patches_total, int patches_per_split, int dbg) {
   constexpr int TAPS = KH * KW;
   constexpr int BN = NT * 16;
   constexpr int VEC = ElemTraits<T>::kVec;
@@ -295,25 +296,48 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_kernel(const ksmi_wgrad_de
   const int padx = d.pad_x_set ? d.pad_x : d.pad;
   const uint32_t xcb = (uint32_t)sr.C * ES, dycb = (uint32_t)d.dyC * ES;
   const int x_sy = d.in_sy == 0 ? d.Win : d.in_sy * d.in_W, x_sx = d.in_sy == 0 ? 1 : d.in_sx;
-  int x_hyx[MAXS];                             // (hy << 16) | hx of the halo pixel of slot s, -1: none
-#pragma unroll
-  for (int s_ = 0; s_ < MAXS; ++s_) {
-    const int v = tid + s_ * 256;
-    const int pix = v >> 2;
-    const int hy = dHW.div(pix), hx = pix - hy * HW;
-    x_hyx[s_] = v < HP * 4 ? ((hy << 16) | hx) : -1;
-  }
+  // slot s of a thread: X halo vector tid + 256 s -> halo pixel (tid >> 2) + 64 s; dY vector of pixel tid / VPR + s (256 / VPR).
+  // (hy, hx) / (ly, lx) are recomputed per patch from two multiplies: cheaper than 16 table registers on the NT = 4 tile.
+  auto x_slot = [&](int s_, int& hy, int& hx) -> bool {
+    const int pix = (tid >> 2) + s_ * 64;
+    hy = dHW.div(pix); hx = pix - hy * HW;
+    return pix < HP;
+  };
   const int dq = tid % VPR;                    // 256 % VPR == 0: a thread always owns vector dq of its dY rows
   const bool dqvalid = n0 + dq * VEC < d.N;
-  int dy_lyx[VPR];                             // (ly << 16) | lx, -2: zero row of the k padding, -1: no vector
-#pragma unroll
-  for (int s_ = 0; s_ < VPR; ++s_) {
+  auto dy_slot = [&](int s_, int& ly, int& lx) -> int {      // 1: pixel row, 0: zero row of the k padding, -1: no vector
     const int pp = tid / VPR + s_ * (256 / VPR);
-    const int ly = dTW.div(pp), lx = pp - ly * d.TW;
-    dy_lyx[s_] = pp < Ppad ? (pp < P ? ((ly << 16) | lx) : -2) : -1;
-  }
+    ly = dTW.div(pp); lx = pp - ly * d.TW;
+    return pp < Ppad ? (pp < P ? 1 : 0) : -1;
+  };
   const unsigned char* const xsp = (const unsigned char*)((const T*)sr.ptr + sr.c_off + cq);
   const unsigned char* const dyp = (const unsigned char*)((const T*)d.dy + d.dy_c_off + n0 + dq * VEC);
+
+  // bf16 fragment address tables of k-step 0 (dY: the swizzle term repeats every 32 rows; X: see LIN above)
+  unsigned b0_tab[sizeof(T) == 2 ? NT : 1][2];
+  unsigned a0_tab[(LIN && sizeof(T) == 2) ? TPW : 1][2];      // channel fragment 0; fragment 1 is the other 32-byte half (^ 32)
+  unsigned lin_stride = 0;
+  if constexpr (sizeof(T) == 2) {
+    const unsigned ldx0 = (unsigned)(uintptr_t)lds_x + (l15 & 3) * 8, ldy0 = (unsigned)(uintptr_t)lds_dy + (l15 & 3) * 8;
+#pragma unroll
+    for (int nf = 0; nf < NT; ++nf)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) b0_tab[nf][h] = ldy0 + wg_dy_off<GR>(g * 8 + h * 4 + (l15 >> 2), nf * 32);
+    if constexpr (LIN) {
+      lin_stride = (unsigned)((KSTEP / d.TW) * S * HW * 64);
+#pragma unroll
+      for (int a_ = 0; a_ < TPW; ++a_) {
+        const int t = SPLITK ? 0 : min(wave + a_ * 4, TAPS - 1);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int pp = g * 8 + h * 4 + (l15 >> 2);
+          const int ly = dTW.div(pp), lx = pp - ly * d.TW;
+          const int hy = ly * S + t / KW, hx = lx * S + t % KW;
+          a0_tab[a_][h] = ldx0 + wg_x_off(hy * HW + hx, hy, hx, 0);
+        }
+      }
+    }
+  }
 
   const int p_begin = split * patches_per_split;
   const int p_end = min(patches_total, p_begin + patches_per_split);
@@ -337,17 +361,19 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_kernel(const ksmi_wgrad_de
     for (int s_ = 0; s_ < MAXS; ++s_) {
       xv[s_] = (u32x4){0u, 0u, 0u, 0u};
       if (s_ * 256 < HP * 4) {
-        const int hy = x_hyx[s_] >> 16, hx = x_hyx[s_] & 0xffff;
+        int hy, hx;
+        const bool in = x_slot(s_, hy, hx);
         const int iy = iy0 + hy, ix = ix0 + hx;
-        if (x_hyx[s_] >= 0 && cvalid && (unsigned)iy < (unsigned)d.Hin && (unsigned)ix < (unsigned)d.Win)
+        if (in && cvalid && (unsigned)iy < (unsigned)d.Hin && (unsigned)ix < (unsigned)d.Win)
           xv[s_] = *(const u32x4*)(xsp + (uint32_t)(xbase + hy * x_sy + hx * x_sx) * xcb);
       }
     }
 #pragma unroll
     for (int s_ = 0; s_ < VPR; ++s_) {
       dv[s_] = (u32x4){0u, 0u, 0u, 0u};
-      const int ly = dy_lyx[s_] >> 16, lx = dy_lyx[s_] & 0xffff;
-      if (dy_lyx[s_] >= 0 && dqvalid && oy0 + ly < d.Hout && ox0 + lx < d.Wout)
+      int ly, lx;
+      const int kind = dy_slot(s_, ly, lx);
+      if (kind > 0 && dqvalid && oy0 + ly < d.Hout && ox0 + lx < d.Wout)
         dv[s_] = *(const u32x4*)(dyp + (uint32_t)(dybase + ly * d.Wout + lx) * dycb);
     }
   };
@@ -357,9 +383,10 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_kernel(const ksmi_wgrad_de
     const int iy0 = oy0 * S - d.pad, ix0 = ox0 * S - padx;
 #pragma unroll
     for (int s_ = 0; s_ < MAXS; ++s_)
-      if (s_ * 256 < HP * 4 && x_hyx[s_] >= 0) {
+      if (s_ * 256 < HP * 4) {
+        int hy, hx;
+        if (!x_slot(s_, hy, hx)) continue;
         if (aff) {
-          const int hy = x_hyx[s_] >> 16, hx = x_hyx[s_] & 0xffff;
           if (cvalid && (unsigned)(iy0 + hy) < (unsigned)d.Hin && (unsigned)(ix0 + hx) < (unsigned)d.Win) {
             float f[VEC];
             vec_unpack<T>(xv[s_], f);
@@ -371,18 +398,21 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_kernel(const ksmi_wgrad_de
             xv[s_] = vec_pack<T>(f);
           }
         }
-        *(u32x4*)(lds_x + wg_x_off((tid >> 2) + s_ * 64, myq * 16)) = xv[s_];
+        *(u32x4*)(lds_x + wg_x_off((tid >> 2) + s_ * 64, hy, hx, myq * 16)) = xv[s_];
       }
 #pragma unroll
-    for (int s_ = 0; s_ < VPR; ++s_)
-      if (dy_lyx[s_] != -1) *(u32x4*)(lds_dy + wg_dy_off<GR>(tid / VPR + s_ * (256 / VPR), dq * 16)) = dv[s_];
+    for (int s_ = 0; s_ < VPR; ++s_) {
+      int ly, lx;
+      if (dy_slot(s_, ly, lx) >= 0) *(u32x4*)(lds_dy + wg_dy_off<GR>(tid / VPR + s_ * (256 / VPR), dq * 16)) = dv[s_];
+    }
   };
   if (p_begin < p_end) load_patch(p_begin);
   for (int patch = p_begin; patch < p_end; ++patch) {
     __syncthreads();                           // the previous patch's MFMAs are done with the LDS images
-    store_patch(patch);
+    if (!(dbg & 4)) store_patch(patch);
     __syncthreads();
-    if (patch + 1 < p_end) load_patch(patch + 1);
+    if (patch + 1 < p_end && !(dbg & 2)) load_patch(patch + 1);
+    if (dbg & 1) continue;
     // ---- MFMA over pixel k-steps --------------------------------------------------------------
     // 1x1 (token GEMM) case: a single tap would keep one wave busy, so the four waves split the pixel k-steps instead
     // and their accumulators are summed through LDS after the patch loop (SPLITK)
@@ -390,20 +420,23 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_kernel(const ksmi_wgrad_de
       const unsigned ldx = (unsigned)(uintptr_t)lds_x + (l15 & 3) * 8, ldy = (unsigned)(uintptr_t)lds_dy + (l15 & 3) * 8;
       for (int ks = 0; ks < Ppad; ks += KSTEP) {
         if (SPLITK && (((ks / KSTEP) & 3) != wave)) continue;
-        // halo pixel of the two transposed-read rows (jr, 4 + jr) of this k-step: ONE division pair per k-step, shared by
-        // every tap / channel fragment (it used to be recomputed inside each fragment read)
-        int xa[2];
+        // halo pixel of the two transposed-read rows (jr, 4 + jr) of this k-step.  LIN (patch width divides 16, whole k-steps):
+        // a lane's column and row parity are the same in every k-step, so its addresses are the k-step-0 table plus a scalar.
+        int xa[2], xhy[2], xhx[2];
+        const unsigned a_ks = LIN ? (unsigned)(ks / KSTEP) * lin_stride : 0u;
+        if constexpr (!LIN) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          int pp = ks + g * 8 + h * 4 + (l15 >> 2);
-          if (pp >= P) pp = 0;                 // dY rows >= P are zero
-          const int ly = dTW.div(pp), lx = pp - ly * d.TW;
-          xa[h] = ly * S * HW + lx * S;
+          for (int h = 0; h < 2; ++h) {
+            int pp = ks + g * 8 + h * 4 + (l15 >> 2);
+            if (pp >= P) pp = 0;               // dY rows >= P are zero
+            const int ly = dTW.div(pp), lx = pp - ly * d.TW;
+            xa[h] = ly * S * HW + lx * S; xhy[h] = ly * S; xhx[h] = lx * S;
+          }
         }
         u32x4 bfrag[NT];
 #pragma unroll
         for (int nf = 0; nf < NT; ++nf) {
-          const unsigned a0 = ldy + wg_dy_off<GR>(ks + g * 8 + (l15 >> 2), nf * 32), a1 = ldy + wg_dy_off<GR>(ks + g * 8 + 4 + (l15 >> 2), nf * 32);
+          const unsigned a0 = b0_tab[nf][0] + (unsigned)ks * (GR * 32), a1 = b0_tab[nf][1] + (unsigned)ks * (GR * 32);
           const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(uintptr_t)a0);
           const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(uintptr_t)a1);
           bfrag[nf] = __builtin_bit_cast(u32x4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
@@ -413,10 +446,15 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_kernel(const ksmi_wgrad_de
         constexpr bool BATCH = NT <= 2;
         u32x4 afrag[BATCH ? TPW : 1][BATCH ? CF : 1];
         auto read_a = [&](int a_, int cf) -> u32x4 {
-          const int t = SPLITK ? 0 : wave + a_ * 4;
-          const int toff = (t / KW) * HW + (t % KW);
-          const int hp0 = xa[0] + toff, hp1 = xa[1] + toff;
-          const unsigned a0 = ldx + hp0 * 64 + (((cf ^ (hp0 >> 3)) & 1) << 5), a1 = ldx + hp1 * 64 + (((cf ^ (hp1 >> 3)) & 1) << 5);
+          unsigned a0, a1;
+          if constexpr (LIN) {
+            a0 = (a0_tab[a_][0] ^ (unsigned)(cf * 32)) + a_ks; a1 = (a0_tab[a_][1] ^ (unsigned)(cf * 32)) + a_ks;
+          } else {
+            const int t = SPLITK ? 0 : wave + a_ * 4;
+            const int toff = (t / KW) * HW + (t % KW);
+            a0 = ldx + wg_x_off(xa[0] + toff, xhy[0] + t / KW, xhx[0] + t % KW, cf * 32);
+            a1 = ldx + wg_x_off(xa[1] + toff, xhy[1] + t / KW, xhx[1] + t % KW, cf * 32);
+          }
           const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(uintptr_t)a0);
           const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(uintptr_t)a1);
           return __builtin_bit_cast(u32x4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
@@ -462,7 +500,7 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_kernel(const ksmi_wgrad_de
             for (int s_ = 0; s_ < 4; ++s_) {
               int pp = ks + g * 4 + s_; if (pp >= P) pp = 0;
               const int ly = dTW.div(pp), lx = pp - ly * d.TW;
-              afrag[s_] = *(const uint32_t*)(lds_x + wg_x_off(ly * S * HW + lx * S + toff, l15 * 4));
+              afrag[s_] = *(const uint32_t*)(lds_x + wg_x_off(ly * S * HW + lx * S + toff, ly * S + t / KW, lx * S + t % KW, l15 * 4));
             }
 #pragma unroll
             for (int nf = 0; nf < NT; ++nf) mma16<T>(acc[a_][cf][nf], afrag, bfrag[nf]);
@@ -727,6 +765,10 @@ WgradGeom wgrad_geom(const ksmi_wgrad_desc* d) {
   g.nt = g.npad >= 64 ? 4 : (g.npad >= 32 ? 2 : 1);
   static const int wnt_cap = getenv("KSMI_WGRAD_NT") ? atoi(getenv("KSMI_WGRAD_NT")) : 4;
   if (g.nt > wnt_cap) g.nt = wnt_cap;
+  // 3x3 / 4x4: the 64-column tile (96+ accumulators beside the prefetch registers of the patch pipeline) spills at 256 VGPRs and is
+  // latency-starved at 512; two 32-column workgroups re-read X from L2 instead and run the same speed or better
+  static const bool wnt4 = getenv("KSMI_WGRAD_NT4") != nullptr;
+  if (g.taps >= 9 && g.nt > 2 && !wnt4) g.nt = 2;
   g.bn = g.nt * 16;
   g.ntiles = (g.npad + g.bn - 1) / g.bn;
   const int tilesX = (d->Wout + d->TW - 1) / d->TW, tilesY = (d->Hout + d->TH - 1) / d->TH;
@@ -776,12 +818,22 @@ int launch_wgrad(const ksmi_wgrad_desc* d, hipStream_t st) {
     const size_t pmax = pin > (size_t)d->B * d->Hout * d->Wout ? pin : (size_t)d->B * d->Hout * d->Wout;
     if (pmax * cmax * sizeof(T) >= ((size_t)1 << 32)) return ksmi_fail(KSMI_E_UNSUPPORTED, "wgrad: a tensor of 4 GiB or more is not supported");
   }
+  static const int wdbg = getenv("KSMI_WDBG") ? atoi(getenv("KSMI_WDBG")) : 0;   // profiling switches: 1 no MFMA, 2 no global loads, 4 no LDS stores
   const dim3 grid(g.nsplit, d->nchunks, g.ntiles);
+  // LIN: bf16, patch width divides 16 and the patch is a whole number of 32-pixel k-steps (see the kernel)
+  static const bool lin_off = getenv("KSMI_WGRAD_NOLIN") != nullptr;
+  const bool lin = !lin_off && sizeof(T) == 2 && (16 % d->TW) == 0 && ((d->TH * d->TW) % 32) == 0;
 #define KSMI_LAUNCH_WG(NT_, KH_, KW_)                                                               \
   do {                                                                                              \
-    auto kfn = igemm_wgrad_kernel<T, NT_, KH_, KW_>;                                                \
-    if (g.lds > 65536) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds); \
-    hipLaunchKernelGGL(kfn, grid, dim3(256), g.lds, st, *d, g.patches, g.pps);                      \
+    if (lin) {                                                                                      \
+      auto kfn = igemm_wgrad_kernel<T, NT_, KH_, KW_, true>;                                        \
+      if (g.lds > 65536) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds); \
+      hipLaunchKernelGGL(kfn, grid, dim3(256), g.lds, st, *d, g.patches, g.pps, wdbg);              \
+    } else {                                                                                        \
+      auto kfn = igemm_wgrad_kernel<T, NT_, KH_, KW_, false>;                                       \
+      if (g.lds > 65536) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds); \
+      hipLaunchKernelGGL(kfn, grid, dim3(256), g.lds, st, *d, g.patches, g.pps, wdbg);              \
+    }                                                                                               \
   } while (0)
 #define KSMI_DISPATCH_WNT(KH_, KW_)                                                                 \
   switch (g.nt) {                                                                                   \
