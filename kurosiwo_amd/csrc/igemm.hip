@@ -277,6 +277,7 @@ __global__ __launch_bounds__(256, ((NT == 4 && KH * KW >= 9) ? 1 : 2)) void igem
   const bool cvalid = cq < sr.c_len;
   float sc[VEC], sh[VEC];
   const bool aff = sr.scale != nullptr;
+  const bool aff_relu = sr.relu != 0;          // (kept in a register: a reference into the kernarg is re-fetched at every use)
   if (aff && cvalid) {
 #pragma unroll
     for (int j = 0; j < VEC; ++j) { sc[j] = sr.scale[cq + j]; sh[j] = sr.shift[cq + j]; }
@@ -393,7 +394,7 @@ __global__ __launch_bounds__(256, ((NT == 4 && KH * KW >= 9) ? 1 : 2)) void igem
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
               f[j] = f[j] * sc[j] + sh[j];
-              if (sr.relu) f[j] = fmaxf(f[j], 0.f);
+              if (aff_relu) f[j] = fmaxf(f[j], 0.f);
             }
             xv[s_] = vec_pack<T>(f);
           }

@@ -337,9 +337,9 @@ int launch2(const ksmi_conv_desc* d, int dbg, hipStream_t st) {
     // the lean epilogue (igemm_epilogue.h: igemm_epilogue_fast) replaces the general one when its preconditions hold
     auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
     const ksmi_dst& d0 = d->dst[0];
-    const bool fast = d->ndst == 1 && d->ps_cout == 0 && (d->N % 8) == 0 && d0.n_begin == 0 && (d0.C % 8) == 0 && (d0.c_off % 8) == 0 &&
+    const bool fast = d->ndst == 1 && (d->ps_cout == 0 || ((d->ps_cout % 8) == 0 && d->mask_src == nullptr)) && (d->N % 8) == 0 && d0.n_begin == 0 && (d0.C % 8) == 0 && (d0.c_off % 8) == 0 &&
                       al16(d0.ptr) && al16(d->bias) && al16(d->mask_src) && al16(d->m_mean) && al16(d->m_rstd) && al16(d->m_scale) &&
-                      al16(d->m_shift) && (size_t)d->B * d->Hout * d->Wout < ((size_t)1 << 31);
+                      al16(d->m_shift) && (size_t)d->B * d->Hout * d->Wout * (d->ps_cout > 0 ? 4 : 1) < ((size_t)1 << 31);
     if (!fast) extras = true;
   }
   Igemm2Args ka;

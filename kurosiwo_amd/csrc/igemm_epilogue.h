@@ -415,7 +415,10 @@ __device__ __forceinline__ void igemm_epilogue_fast(const ksmi_conv_desc& d, f32
   const bool has_mask = d.mask_src != nullptr;
   const bool accum = d.dst[0].accumulate != 0;
   const int dC = d.dst[0].C;
-  T* const obase = (T*)d.dst[0].ptr + d.dst[0].c_off + nc;
+  // pixel shuffle (ConvTranspose2d k2 s2 as a 1x1 GEMM over 4*C columns): column group nc -> quadrant dd, channel nn
+  int dd = 0, nn = nc;
+  if (d.ps_cout > 0) { dd = nc / d.ps_cout; nn = nc - dd * d.ps_cout; }
+  T* const obase = (T*)d.dst[0].ptr + d.dst[0].c_off + nn;
   const T* const mbase = (const T*)d.mask_src + nc;
   // pixel offsets and the loads that do not depend on the accumulators go first
   uint32_t opix[4];
@@ -427,7 +430,8 @@ __device__ __forceinline__ void igemm_epilogue_fast(const ksmi_conv_desc& d, f32
     const int ly = dTW.div(p), lx = p - ly * d.TW;
     const int oy = oy0 + ly, ox = ox0 + lx;
     ok[mf] = nv && p < P && oy < d.Hout && ox < d.Wout;
-    opix[mf] = (uint32_t)((b * d.Hout + oy) * d.Wout + ox);
+    opix[mf] = d.ps_cout > 0 ? (uint32_t)((b * 2 * d.Hout + 2 * oy + (dd >> 1)) * (2 * d.Wout) + 2 * ox + (dd & 1))
+                             : (uint32_t)((b * d.Hout + oy) * d.Wout + ox);
     mv[mf] = (u32x4){0u, 0u, 0u, 0u}; ov[mf] = (u32x4){0u, 0u, 0u, 0u};
     if (has_mask && ok[mf]) mv[mf] = *(const u32x4*)(mbase + (size_t)opix[mf] * d.N);
     if (accum && ok[mf]) ov[mf] = *(const u32x4*)(obase + (size_t)opix[mf] * dC);
@@ -435,13 +439,13 @@ __device__ __forceinline__ void igemm_epilogue_fast(const ksmi_conv_desc& d, f32
   float bias[8], mm[8], mr[8], mg[8], mb[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { bias[j] = 0.f; mm[j] = 0.f; mr[j] = 0.f; mg[j] = 0.f; mb[j] = 0.f; }
-  auto ld8 = [&](const float* q, float* o) {
-    const f32x4 a = *(const f32x4*)(q + nc), c = *(const f32x4*)(q + nc + 4);
+  auto ld8 = [&](const float* q, float* o, int at) {
+    const f32x4 a = *(const f32x4*)(q + at), c = *(const f32x4*)(q + at + 4);
 #pragma unroll
     for (int j = 0; j < 4; ++j) { o[j] = a[j]; o[4 + j] = c[j]; }
   };
-  if (d.bias && nv) ld8(d.bias, bias);
-  if (has_mask && nv) { ld8(d.m_mean, mm); ld8(d.m_rstd, mr); ld8(d.m_scale, mg); ld8(d.m_shift, mb); }
+  if (d.bias && nv) ld8(d.bias, bias, nn);
+  if (has_mask && nv) { ld8(d.m_mean, mm, nc); ld8(d.m_rstd, mr, nc); ld8(d.m_scale, mg, nc); ld8(d.m_shift, mb, nc); }
   float ssum[8], ssq[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
