@@ -774,9 +774,9 @@ WgradGeom wgrad_geom(const ksmi_wgrad_desc* d) {
   g.ntiles = (g.npad + g.bn - 1) / g.bn;
   const int tilesX = (d->Wout + d->TW - 1) / d->TW, tilesY = (d->Hout + d->TH - 1) / d->TH;
   g.patches = d->B * tilesX * tilesY;
-  // aim at ~1024 workgroups in total; at most 256 splits
+  // aim at ~1024 workgroups in total; at most 512 splits
   static const int wg_target = getenv("KSMI_WGRAD_WGS") ? atoi(getenv("KSMI_WGRAD_WGS")) : 1024;
-  static const int split_cap = getenv("KSMI_WGRAD_SPLITS") ? atoi(getenv("KSMI_WGRAD_SPLITS")) : 256;
+  static const int split_cap = getenv("KSMI_WGRAD_SPLITS") ? atoi(getenv("KSMI_WGRAD_SPLITS")) : 512;   // single-chunk gradients (K <= 32) otherwise run one workgroup per CU
   int want = wg_target / (d->nchunks * g.ntiles);
   if (want < 1) want = 1;
   if (want > split_cap) want = split_cap;
