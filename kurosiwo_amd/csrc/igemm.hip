@@ -5,6 +5,7 @@
 //   N = output channels (BN = 16*NT per workgroup)
 //   K = taps x channels; channels walk the virtual-concat sources in 64-byte chunks
 //       (32 bf16 / 16 fp32), one halo tile + one weight slab in LDS per chunk.
+#include <stdio.h>
 #include <stdlib.h>
 #include "common.h"
 #include "../../include/ksmi.h"
@@ -798,6 +799,13 @@ int launch_wgrad(const ksmi_wgrad_desc* d, hipStream_t st) {
   if (d->TH * d->TW > 256) return ksmi_fail(KSMI_E_ARG, "wgrad: patch too large");
   if (d->nsplit != g.nsplit) return ksmi_fail(KSMI_E_ARG, "wgrad: nsplit does not match ksmi_conv_wgrad_workspace geometry");
   if (g.tn) {
+    // plain row-major nn.Linear gradient (unit K stride, one tap at offset 0, contiguous k rows): large problems go to hipBLASLt
+    bool plain = d->gK == 1 && (!d->use_tap_off || d->tap_off[0] == 0) && d->gN >= d->src[0].c_len && d->gN < ((int64_t)1 << 31);
+    if (plain && !d->uniform_kc)
+      for (int i = 0; i < d->nchunks; ++i) plain = plain && d->k_off[i] == i * g.kc;
+    if (plain && ksmi_lt_linear_wgrad((const bf16_t*)d->src[0].ptr + d->src[0].c_off, d->src[0].C, (const bf16_t*)d->dy + d->dy_c_off, d->dyC,
+                                      d->grad, (int)d->gN, d->B * d->Hout * d->Wout, d->src[0].c_len, d->N, d->accumulate, st) == 0)
+      return 0;
     hipLaunchKernelGGL(gemm_tn_wgrad_kernel, dim3(g.tk, g.tnn, g.nsplit), dim3(256), 0, st, *d, d->B * d->Hout * d->Wout, g.rps, d->nchunks * g.kc);
     int rc0 = ksmi_check_launch("gemm_tn_wgrad");
     if (rc0) return rc0;

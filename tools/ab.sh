@@ -1,5 +1,5 @@
 mkdir -p gpurun_out
-for s in 256 512 1024; do
-KSMI_WGRAD_SPLITS=$s python bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/ab_bench_s$s.json 2>gpurun_out/ab_bench.err
-done
-KSMI_WGRAD_SPLITS=512 BENCH_DETAIL=wgrad python bench.py --steps 5 --warmup 2 --no-cpu-baseline --time-all > gpurun_out/ab_detail.txt 2>&1
+timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | tail -3 > gpurun_out/ab_tests.txt
+python bench.py --steps 10 --warmup 3 --no-cpu-baseline --model changeformer > gpurun_out/ab_cf.json 2>>gpurun_out/ab_bench.err
+python bench.py --steps 10 --warmup 3 --no-cpu-baseline --model floodvit > gpurun_out/ab_fv.json 2>>gpurun_out/ab_bench.err
+KSMI_NO_HIPBLASLT=1 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --model changeformer > gpurun_out/ab_cf_no.json 2>>gpurun_out/ab_bench.err
