@@ -205,6 +205,9 @@ int ksmi_bn_bwd_apply_add(void* r_di, const void* g, const void* i, const float*
                           int64_t npix, int C, int dtype, void* stream);
 /* partial[rows][1][C] = per-channel sum of x (bias gradients) */
 int ksmi_channel_sum(const void* x, float* partial, int rows, int64_t npix, int C, int dtype, void* stream);
+/* out[c] (+)= sum_r x[r][c] of a row-major token matrix in one launch (bias gradient of nn.Linear, vision_transformer.py:22-31:
+ * a few thousand rows; long pixel axes use ksmi_channel_sum + ksmi_reduce_rows).  Deterministic summation order. */
+int ksmi_colsum(const void* x, int64_t rows, int C, float* out, int accumulate, int dtype, void* stream);
 
 /* nn.MaxPool2d(2,2)  models/snunet.py:73 ; backward routes to the first maximum */
 int ksmi_maxpool2x2_forward(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream);

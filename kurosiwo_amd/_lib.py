@@ -95,6 +95,7 @@ SIGNATURES = {
     "ksmi_bnrelu_bwd_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _i64, _i, _i, _vp]),
     "ksmi_bn_bwd_apply_add": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _d, _i64, _i, _i, _vp]),
     "ksmi_channel_sum": (_i, [_vp, _vp, _i, _i64, _i, _i, _vp]),
+    "ksmi_colsum": (_i, [_vp, _i64, _i, _vp, _i, _i, _vp]),
     "ksmi_maxpool2x2_forward": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ksmi_maxpool2x2_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ksmi_ecam_pool": (_i, [_P4, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

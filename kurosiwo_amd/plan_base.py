@@ -134,6 +134,12 @@ class PlanBase:
         self._conv(self.fwd, d, "linear", name)
 
     def _bias_grad(self, dy, rows, N, bkey):
+        if rows <= 8192:                                   # token matrices: one launch (long pixel axes: two-stage below)
+            acc = self._acc_param(bkey)
+            gb = self.m._g(bkey).data_ptr()
+            self.bwd.add("ksmi_colsum", lambda: (dy.data_ptr(), rows, N, gb, acc, self.dt), self._elt_meta("colsum", rows * N))
+            self._mark(bkey)
+            return
         r = max(1, min(512, rows // 64))
         self.need("red", r * N * 4)
         acc = self._acc_param(bkey)
