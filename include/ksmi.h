@@ -294,6 +294,23 @@ int ksmi_add(const void* a, const void* b, void* out, int64_t n, int dtype, void
 int ksmi_relu_backward(const void* dy, const void* x, void* dx, int64_t n, int dtype, void* stream);
 int ksmi_relu_forward(const void* x, void* y, int64_t n, int dtype, void* stream);   /* Decoder.relu, model_utilities.py:44 */
 /* x[:, 1:] (vision_transformer.py:150-151): backward=0 [B][N1][C] -> dense [B][N1-1][C]; backward=1 the adjoint (cls rows zero) */
+/* ---- MAE pre-training (models/mae.py:54-124) --------------------------------------------------------
+ * Token shuffles driven by slices of the per-sample permutation `rand_indices` (:73-78): idx is int64 [B][idx_rs] (row stride in
+ * elements), rows are [B*N][C] in `dtype`, tables / fill vectors are fp32 parameters.
+ *   gather : dst[b][j] = src[b][idx[b][j]] (+ table[idx[b][j] + table_off])     tokens[batch_range, unmasked_indices] (:78) with
+ *            the position rows (:65), masked_patches (:82), decoded mask tokens (:113)
+ *   scatter: dst[b][idx[b][j]] = (src ? src[b][j] : fill) + table[idx[b][j]]     decoder_tokens assembly (:94-110); with
+ *            table = fill = NULL it is the adjoint of gather (the destination must be zeroed where no row lands)
+ *   batch_sum: out[i] (+)= sum_b x[b][i]   gradient of a position table;  mse_loss: F.mse_loss (:122) and its gradient
+ *            dpred = 2 (pred - target) grad_scale [* *upstream, a device scalar] / n in one pass (dpred, upstream may be NULL). */
+int ksmi_gather_rows(const void* src, const int64_t* idx, int idx_rs, void* dst, const float* table, int table_off, int B, int Ns, int Nd, int C,
+                     int dtype, void* stream);
+int ksmi_scatter_rows(const void* src, const float* fill, const int64_t* idx, int idx_rs, const float* table, void* dst, int B, int Nsrc, int Nd,
+                      int C, int dtype, void* stream);
+int ksmi_batch_sum(const void* x, float* out, int B, int64_t n, int accumulate, int dtype, void* stream);
+size_t ksmi_mse_workspace(void);
+int ksmi_mse_loss(const void* pred, const void* target, void* dpred, float grad_scale, const float* upstream, float* loss, float* workspace,
+                  int64_t n, int dtype, void* stream);
 int ksmi_drop_cls(const void* x, void* y, int B, int N1, int C, int backward, int dtype, void* stream);
 /* head output NHWC [B][HW][Cs] (first C channels real) -> NCHW fp32 logits, and d(logits) back (pad channels zero) */
 int ksmi_logits_to_nchw(const void* x, float* y, int B, int C, int Cs, int64_t HW, int dtype, void* stream);

@@ -96,6 +96,11 @@ SIGNATURES = {
     "ksmi_bn_bwd_apply_add": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _d, _i64, _i, _i, _vp]),
     "ksmi_channel_sum": (_i, [_vp, _vp, _i, _i64, _i, _i, _vp]),
     "ksmi_colsum": (_i, [_vp, _i64, _i, _vp, _i, _i, _vp]),
+    "ksmi_gather_rows": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "ksmi_scatter_rows": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "ksmi_batch_sum": (_i, [_vp, _vp, _i, _i64, _i, _i, _vp]),
+    "ksmi_mse_workspace": (C.c_size_t, []),
+    "ksmi_mse_loss": (_i, [_vp, _vp, _vp, _f, _vp, _vp, _vp, _i64, _i, _vp]),
     "ksmi_maxpool2x2_forward": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ksmi_maxpool2x2_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ksmi_ecam_pool": (_i, [_P4, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

@@ -434,6 +434,100 @@ __global__ void upsample2_bwd_kernel(const T* dy, const T* xpre, T* dx, int B, i
   }
 }
 
+// ---- MAE token shuffles (models/mae.py:73-118) ------------------------------------------------------------------------
+// gather : dst[b][j][:] = src[b][idx[b][j]][:] (+ table[idx[b][j] + table_off][:])           (:77-78, :82, :113)
+// scatter: dst[b][idx[b][j]][:] = (src ? src[b][j][:] : fill[:]) + table[idx[b][j]][:]       (:94-110; the adjoint of gather
+//          with table = fill = null).  idx rows are slices of a permutation, so no two sources hit one destination row.
+template <typename T>
+__global__ void gather_rows_kernel(const T* src, const int64_t* idx, int idx_rs, T* dst, const float* table, int table_off, int B, int Ns,
+                                   int Nd, int C) {
+  constexpr int VEC = ElemTraits<T>::kVec;
+  const int CV = C / VEC;
+  const int64_t n = (int64_t)B * Nd * CV;
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (int64_t)gridDim.x * blockDim.x) {
+    const int cv = v % CV; int64_t r = v / CV;
+    const int j = r % Nd; const int b = r / Nd;
+    const int t = (int)idx[(int64_t)b * idx_rs + j];
+    float f[VEC];
+    vec_unpack<T>(*(const u32x4*)(src + (((int64_t)b * Ns + t) * CV + cv) * VEC), f);
+    if (table) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) f[e] += table[(int64_t)(t + table_off) * C + cv * VEC + e];
+    }
+    *(u32x4*)(dst + v * VEC) = vec_pack<T>(f);
+  }
+}
+
+template <typename T>
+__global__ void scatter_rows_kernel(const T* src, const float* fill, const int64_t* idx, int idx_rs, const float* table, T* dst, int B,
+                                    int Nsrc, int Nd, int C) {
+  constexpr int VEC = ElemTraits<T>::kVec;
+  const int CV = C / VEC;
+  const int64_t n = (int64_t)B * Nsrc * CV;
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (int64_t)gridDim.x * blockDim.x) {
+    const int cv = v % CV; int64_t r = v / CV;
+    const int j = r % Nsrc; const int b = r / Nsrc;
+    const int t = (int)idx[(int64_t)b * idx_rs + j];
+    float f[VEC];
+    if (src) vec_unpack<T>(*(const u32x4*)(src + v * VEC), f);
+    else {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) f[e] = fill ? fill[cv * VEC + e] : 0.f;
+    }
+    if (table) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) f[e] += table[(int64_t)t * C + cv * VEC + e];
+    }
+    *(u32x4*)(dst + (((int64_t)b * Nd + t) * CV + cv) * VEC) = vec_pack<T>(f);
+  }
+}
+
+// out[i] (+)= sum_b x[b][i], i < n (gradients of the position tables: every sample touches every row once); fixed order over b
+template <typename T>
+__global__ void batch_sum_kernel(const T* x, float* out, int B, int64_t n, int accumulate) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += ElemTraits<T>::ld(x + (int64_t)b * n + i);
+    out[i] = accumulate ? out[i] + s : s;
+  }
+}
+
+// F.mse_loss (models/mae.py:122): partial[block] = sum (pred - target)^2 over the block's elements, dpred = 2 (pred - target) scale
+template <typename T>
+__global__ void mse_kernel(const T* pred, const T* target, T* dpred, float* partial, int64_t nvec, float scale0, const float* upstream) {
+  constexpr int VEC = ElemTraits<T>::kVec;
+  const float scale = scale0 * (upstream ? *upstream : 1.f);
+  __shared__ float red[256];
+  float s = 0.f;
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * blockDim.x) {
+    float a[VEC], b[VEC], g[VEC];
+    vec_unpack<T>(*(const u32x4*)(pred + v * VEC), a);
+    vec_unpack<T>(*(const u32x4*)(target + v * VEC), b);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { const float d = a[e] - b[e]; s += d * d; g[e] = 2.f * d * scale; }
+    if (dpred) *(u32x4*)(dpred + v * VEC) = vec_pack<T>(g);
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int k = 128; k >= 1; k >>= 1) {
+    if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+__global__ void mse_finish_kernel(const float* partial, int nblk, double count, float* loss) {
+  __shared__ double red[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nblk; i += 256) s += (double)partial[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int k = 128; k >= 1; k >>= 1) {
+    if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *loss = (float)(red[0] / count);
+}
+
 // x[:, 1:] of the token sequence (vision_transformer.py:150-151) as a dense [B][N1-1][C] image, and its adjoint
 template <typename T>
 __global__ void drop_cls_kernel(const T* x, T* y, int B, int N1, int C, int backward) {
@@ -582,6 +676,52 @@ int ksmi_drop_cls(const void* x, void* y, int B, int N1, int C, int backward, in
           hipLaunchKernelGGL(drop_cls_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, B, N1, C, backward),
           hipLaunchKernelGGL(drop_cls_kernel<float>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, B, N1, C, backward));
   return ksmi_check_launch("drop_cls");
+}
+
+int ksmi_gather_rows(const void* src, const int64_t* idx, int idx_rs, void* dst, const float* table, int table_off, int B, int Ns, int Nd, int C,
+                     int dtype, void* stream) {
+  const int vec = dtype == KSMI_BF16 ? 8 : 4;
+  if (C % vec || B < 1 || Nd < 1 || Ns < 1) return ksmi_fail(KSMI_E_ARG, "gather_rows: C must be a multiple of the vector");
+  const int64_t n = (int64_t)B * Nd * (C / vec);
+  KSMI_DT(dtype,
+          hipLaunchKernelGGL(gather_rows_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, idx, idx_rs, (bf16_t*)dst, table, table_off, B, Ns, Nd, C),
+          hipLaunchKernelGGL(gather_rows_kernel<float>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const float*)src, idx, idx_rs, (float*)dst, table, table_off, B, Ns, Nd, C));
+  return ksmi_check_launch("gather_rows");
+}
+
+int ksmi_scatter_rows(const void* src, const float* fill, const int64_t* idx, int idx_rs, const float* table, void* dst, int B, int Nsrc, int Nd,
+                      int C, int dtype, void* stream) {
+  const int vec = dtype == KSMI_BF16 ? 8 : 4;
+  if (C % vec || B < 1 || Nd < 1 || Nsrc < 1) return ksmi_fail(KSMI_E_ARG, "scatter_rows: C must be a multiple of the vector");
+  const int64_t n = (int64_t)B * Nsrc * (C / vec);
+  KSMI_DT(dtype,
+          hipLaunchKernelGGL(scatter_rows_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, fill, idx, idx_rs, table, (bf16_t*)dst, B, Nsrc, Nd, C),
+          hipLaunchKernelGGL(scatter_rows_kernel<float>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const float*)src, fill, idx, idx_rs, table, (float*)dst, B, Nsrc, Nd, C));
+  return ksmi_check_launch("scatter_rows");
+}
+
+int ksmi_batch_sum(const void* x, float* out, int B, int64_t n, int accumulate, int dtype, void* stream) {
+  if (B < 1 || n < 1) return ksmi_fail(KSMI_E_ARG, "batch_sum: bad args");
+  KSMI_DT(dtype,
+          hipLaunchKernelGGL(batch_sum_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, out, B, n, accumulate),
+          hipLaunchKernelGGL(batch_sum_kernel<float>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const float*)x, out, B, n, accumulate));
+  return ksmi_check_launch("batch_sum");
+}
+
+size_t ksmi_mse_workspace(void) { return 1024 * sizeof(float); }
+
+int ksmi_mse_loss(const void* pred, const void* target, void* dpred, float grad_scale, const float* upstream, float* loss, float* workspace,
+                  int64_t n, int dtype, void* stream) {
+  const int vec = dtype == KSMI_BF16 ? 8 : 4;
+  if (n < 1 || n % vec || !loss || !workspace) return ksmi_fail(KSMI_E_ARG, "mse_loss: element count must be a multiple of the vector");
+  const int64_t nvec = n / vec;
+  int blocks = (int)((nvec + 255) / 256); if (blocks > 1024) blocks = 1024;
+  const float scale = grad_scale / (float)n;
+  KSMI_DT(dtype,
+          hipLaunchKernelGGL(mse_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)pred, (const bf16_t*)target, (bf16_t*)dpred, workspace, nvec, scale, upstream),
+          hipLaunchKernelGGL(mse_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)pred, (const float*)target, (float*)dpred, workspace, nvec, scale, upstream));
+  hipLaunchKernelGGL(mse_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, workspace, blocks, (double)n, loss);
+  return ksmi_check_launch("mse_loss");
 }
 
 int ksmi_logits_to_nchw(const void* x, float* y, int B, int C, int Cs, int64_t HW, int dtype, void* stream) {

@@ -65,12 +65,8 @@ class FloodViTPlan(PlanBase):
         self.fwd.add("ksmi_vit_embed_forward", lambda X0=X: (E1.data_ptr(), cls, pos, X0.data_ptr(), B, self.N1, D, dt),
                      self._elt_meta("vit_embed", 2 * R * D))
 
-        if self.with_backward:
-            gx = self.buf(R, D)              # gradient of the residual stream, updated in place layer by layer
-            tD, tI, tM, tQ = self.buf(R, D), self.buf(R, I), self.buf(R, M), self.buf(R, 3 * I)
-        else:
-            gx = tD = tI = tM = tQ = None
-        t1 = self.buf(R, D)
+        gx = self.buf(R, D) if self.with_backward else None     # gradient of the residual stream, updated in place layer by layer
+        tD = self.buf(R, D) if self.with_backward else None
 
         def embed_bwd():
             dE1, dE0, dP1 = self.buf(Rp, D), self.buf(Rp, D), self.buf(Rp, pd)
@@ -85,48 +81,7 @@ class FloodViTPlan(PlanBase):
         bwd_steps.append(embed_bwd)
 
         # ---- transformer (vision_transformer.py:84-89) ------------------------------------------
-        for li in range(self.depth):
-            a, f = f"model.transformer.layers.{li}.0", f"model.transformer.layers.{li}.1"
-            x_in = X
-            h1, qkv, att, x_mid = self.buf(R, D), self.buf(R, 3 * I), self.buf(R, I), self.buf(R, D)
-            h2, u, g, x_out = self.buf(R, D), self.buf(R, M), self.buf(R, M), self.buf(R, D)
-            lse = self.fbuf(B, self.heads, self.N1)
-            scale = float(self.m.hp["dim_head"]) ** -0.5
-            st1 = self._ln(x_in, f"{a}.norm.weight", f"{a}.norm.bias", h1, R, D)
-            self._linear(f"L{li}.to_qkv", h1, D, f"{a}.to_qkv.weight", None, qkv, 3 * I, R)
-            aflops = 4 * B * self.heads * self.N1 * self.N1 * 64
-            self.fwd.add("ksmi_attention_forward", lambda qkv=qkv, att=att, lse=lse: (
-                qkv.data_ptr(), att.data_ptr(), lse.data_ptr(), B, self.N1, self.heads, 64, scale, dt),
-                {"kind": "attention_fwd", "bytes": 4 * R * I * self._es(), "flops": aflops})
-            self._linear(f"L{li}.to_out", att, I, f"{a}.to_out.0.weight", f"{a}.to_out.0.bias", t1, D, R)
-            self.fwd.add("ksmi_add", lambda x_in=x_in, x_mid=x_mid: (t1.data_ptr(), x_in.data_ptr(), x_mid.data_ptr(), R * D, dt),
-                         self._elt_meta("add", 3 * R * D))
-            st2 = self._ln(x_mid, f"{f}.net.0.weight", f"{f}.net.0.bias", h2, R, D)
-            self._linear(f"L{li}.ff1", h2, D, f"{f}.net.1.weight", f"{f}.net.1.bias", u, M, R)
-            self.fwd.add("ksmi_gelu_forward", lambda u=u, g=g: (u.data_ptr(), g.data_ptr(), R * M, dt), self._elt_meta("gelu", 2 * R * M))
-            self._linear(f"L{li}.ff2", g, M, f"{f}.net.4.weight", f"{f}.net.4.bias", t1, D, R)
-            self.fwd.add("ksmi_add", lambda x_mid=x_mid, x_out=x_out: (t1.data_ptr(), x_mid.data_ptr(), x_out.data_ptr(), R * D, dt),
-                         self._elt_meta("add", 3 * R * D))
-            X = x_out
-            self.named[f"layer{li}"] = x_out
-
-            def layer_bwd(li=li, a=a, f=f, x_in=x_in, h1=h1, qkv=qkv, att=att, x_mid=x_mid, h2=h2, u=u, g=g, lse=lse,
-                          st1=st1, st2=st2, scale=scale, aflops=aflops):
-                # FeedForward: x_out = x_mid + W2 gelu(W1 LN(x_mid) + b1) + b2
-                self._linear_bwd(f"L{li}.ff2", g, M, f"{f}.net.4.weight", f"{f}.net.4.bias", gx, D, R, tM)
-                self.bwd.add("ksmi_gelu_backward", lambda: (tM.data_ptr(), u.data_ptr(), tM.data_ptr(), R * M, dt),
-                             self._elt_meta("gelu_bwd", 3 * R * M))
-                self._linear_bwd(f"L{li}.ff1", h2, D, f"{f}.net.1.weight", f"{f}.net.1.bias", tM, M, R, tD)
-                self._ln_bwd(tD, x_mid, st2, f"{f}.net.0.weight", f"{f}.net.0.bias", gx, 1, R, D)
-                # Attention: x_mid = x_in + Wo attn(Wqkv LN(x_in)) + bo
-                self._linear_bwd(f"L{li}.to_out", att, I, f"{a}.to_out.0.weight", f"{a}.to_out.0.bias", gx, D, R, tI)
-                self.need("attn", self.lib.ksmi_attention_bwd_workspace(B, self.N1, self.heads, 64, dt))
-                self.bwd.add("ksmi_attention_backward", lambda: (qkv.data_ptr(), att.data_ptr(), lse.data_ptr(), tI.data_ptr(),
-                                                                 tQ.data_ptr(), self.scr("attn"), B, self.N1, self.heads, 64, scale, dt),
-                             {"kind": "attention_bwd", "bytes": 8 * R * I * self._es(), "flops": 5 * aflops // 2})
-                self._linear_bwd(f"L{li}.to_qkv", h1, D, f"{a}.to_qkv.weight", None, tQ, 3 * I, R, tD)
-                self._ln_bwd(tD, x_in, st1, f"{a}.norm.weight", f"{a}.norm.bias", gx, 1, R, D)
-            bwd_steps.append(layer_bwd)
+        X = self._transformer_layers(X, self.depth, "model.transformer", B, self.N1, D, self.heads, self.m.hp["dim_head"], M, gx, bwd_steps)
 
         # ---- final LN, drop cls, Decoder (vision_transformer.py:89,150-151; model_utilities.py:85-93,36-48) ----
         XF, F = self.buf(R, D), self.buf(Rp, D)

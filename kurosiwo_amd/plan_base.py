@@ -191,6 +191,63 @@ class PlanBase:
             self.bwd.add("ksmi_reduce_rows", lambda: (self.scr("lnp"), nblk, 2, Cc, Cc, None, gw, gb, a1))
             self._mark(wkey, bkey)
 
+    # ---------------------------------------------------------------- pre-norm transformer layers
+    def _transformer_layers(self, X, depth, prefix, B, Ntok, D, heads, dim_head, M, gx, bwd_steps, tag="L"):
+        """depth x [x += Attention(LN(x)); x += FeedForward(LN(x))] on token rows [B*Ntok][D] (vision_transformer.py:35-66,19-32,
+        84-88; the final Transformer.norm is the caller's).  Parameter names follow `{prefix}.layers.{i}.0|1.*`.  Backward closures
+        are appended to `bwd_steps` in forward order (the caller runs them reversed); they update `gx`, the gradient of the
+        residual stream, in place."""
+        R, I = B * Ntok, heads * dim_head
+        dt = self.dt
+        if dim_head != 64:
+            raise _lib.KsmiError("attention kernel is specialised for dim_head = 64")
+        if self.with_backward:
+            tD, tI, tM, tQ = self.buf(R, D), self.buf(R, I), self.buf(R, M), self.buf(R, 3 * I)
+        t1 = self.buf(R, D)
+        scale = float(dim_head) ** -0.5
+        for li in range(depth):
+            a, f = f"{prefix}.layers.{li}.0", f"{prefix}.layers.{li}.1"
+            x_in = X
+            h1, qkv, att, x_mid = self.buf(R, D), self.buf(R, 3 * I), self.buf(R, I), self.buf(R, D)
+            h2, u, g, x_out = self.buf(R, D), self.buf(R, M), self.buf(R, M), self.buf(R, D)
+            lse = self.fbuf(B, heads, Ntok)
+            st1 = self._ln(x_in, f"{a}.norm.weight", f"{a}.norm.bias", h1, R, D)
+            self._linear(f"{tag}{li}.to_qkv", h1, D, f"{a}.to_qkv.weight", None, qkv, 3 * I, R)
+            aflops = 4 * B * heads * Ntok * Ntok * 64
+            self.fwd.add("ksmi_attention_forward", lambda qkv=qkv, att=att, lse=lse: (
+                qkv.data_ptr(), att.data_ptr(), lse.data_ptr(), B, Ntok, heads, 64, scale, dt),
+                {"kind": "attention_fwd", "bytes": 4 * R * I * self._es(), "flops": aflops})
+            self._linear(f"{tag}{li}.to_out", att, I, f"{a}.to_out.0.weight", f"{a}.to_out.0.bias", t1, D, R)
+            self.fwd.add("ksmi_add", lambda x_in=x_in, x_mid=x_mid: (t1.data_ptr(), x_in.data_ptr(), x_mid.data_ptr(), R * D, dt),
+                         self._elt_meta("add", 3 * R * D))
+            st2 = self._ln(x_mid, f"{f}.net.0.weight", f"{f}.net.0.bias", h2, R, D)
+            self._linear(f"{tag}{li}.ff1", h2, D, f"{f}.net.1.weight", f"{f}.net.1.bias", u, M, R)
+            self.fwd.add("ksmi_gelu_forward", lambda u=u, g=g: (u.data_ptr(), g.data_ptr(), R * M, dt), self._elt_meta("gelu", 2 * R * M))
+            self._linear(f"{tag}{li}.ff2", g, M, f"{f}.net.4.weight", f"{f}.net.4.bias", t1, D, R)
+            self.fwd.add("ksmi_add", lambda x_mid=x_mid, x_out=x_out: (t1.data_ptr(), x_mid.data_ptr(), x_out.data_ptr(), R * D, dt),
+                         self._elt_meta("add", 3 * R * D))
+            X = x_out
+            self.named[f"layer{li}" if tag == "L" else f"{tag}layer{li}"] = x_out
+
+            def layer_bwd(li=li, a=a, f=f, x_in=x_in, h1=h1, qkv=qkv, att=att, x_mid=x_mid, h2=h2, u=u, g=g, lse=lse,
+                          st1=st1, st2=st2, aflops=aflops):
+                # FeedForward: x_out = x_mid + W2 gelu(W1 LN(x_mid) + b1) + b2
+                self._linear_bwd(f"{tag}{li}.ff2", g, M, f"{f}.net.4.weight", f"{f}.net.4.bias", gx, D, R, tM)
+                self.bwd.add("ksmi_gelu_backward", lambda: (tM.data_ptr(), u.data_ptr(), tM.data_ptr(), R * M, dt),
+                             self._elt_meta("gelu_bwd", 3 * R * M))
+                self._linear_bwd(f"{tag}{li}.ff1", h2, D, f"{f}.net.1.weight", f"{f}.net.1.bias", tM, M, R, tD)
+                self._ln_bwd(tD, x_mid, st2, f"{f}.net.0.weight", f"{f}.net.0.bias", gx, 1, R, D)
+                # Attention: x_mid = x_in + Wo attn(Wqkv LN(x_in)) + bo
+                self._linear_bwd(f"{tag}{li}.to_out", att, I, f"{a}.to_out.0.weight", f"{a}.to_out.0.bias", gx, D, R, tI)
+                self.need("attn", self.lib.ksmi_attention_bwd_workspace(B, Ntok, heads, 64, dt))
+                self.bwd.add("ksmi_attention_backward", lambda: (qkv.data_ptr(), att.data_ptr(), lse.data_ptr(), tI.data_ptr(),
+                                                                 tQ.data_ptr(), self.scr("attn"), B, Ntok, heads, 64, scale, dt),
+                             {"kind": "attention_bwd", "bytes": 8 * R * I * self._es(), "flops": 5 * aflops // 2})
+                self._linear_bwd(f"{tag}{li}.to_qkv", h1, D, f"{a}.to_qkv.weight", None, tQ, 3 * I, R, tD)
+                self._ln_bwd(tD, x_in, st1, f"{a}.norm.weight", f"{a}.norm.bias", gx, 1, R, D)
+            bwd_steps.append(layer_bwd)
+        return X
+
     # ---------------------------------------------------------------- ConvTranspose2d(k4, s2, p1)
     def _deconv(self, name, x, Cin, N, H, W, out, outC, prefix="head.", suffix="", B=None):
         """out[B,2H,2W,outC][..., :N] = ConvTranspose2d(x) + bias as 4 phase convolutions with 2x2 taps:

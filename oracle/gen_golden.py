@@ -253,6 +253,52 @@ def gen_floodvit(tag, hp, B):
     np.savez_compressed(os.path.join(OUT, f"floodvit_{tag}.npz"), **out)
 
 
+MAE_SMALL = dict(channels=2, image_size=224, patch_size=16, dim=1024, depth=2, heads=4, mlp_dim=512, decoder_dim=512, decoder_depth=2,
+                 decoder_heads=4)
+MAE_GRAD_KEYS = ["mask_token", "encoder.to_patch_embedding.2.bias", "encoder.transformer.norm.weight", "encoder.transformer.layers.0.0.to_out.0.bias",
+                 "encoder.transformer.layers.1.1.net.4.bias", "enc_to_dec.bias", "decoder.norm.weight", "decoder.layers.0.0.norm.weight",
+                 "decoder.layers.1.1.net.1.bias", "to_pixels.bias"]
+
+
+def gen_mae():
+    """models/mae.py with `vit_pytorch.vit.Transformer` bound to the reference's in-tree copy of that class
+    (models/vision_transformer.py:69-89): the third-party package is not vendored and not installed here."""
+    import types
+    ViT, _ = _import_floodvit_reference()
+    import models.vision_transformer as vt
+    if "vit_pytorch" not in sys.modules:
+        import importlib.machinery
+        pkg = types.ModuleType("vit_pytorch"); pkg.__spec__ = importlib.machinery.ModuleSpec("vit_pytorch", None); pkg.__path__ = []
+        sub = types.ModuleType("vit_pytorch.vit"); sub.__spec__ = importlib.machinery.ModuleSpec("vit_pytorch.vit", None)
+        sub.Transformer = vt.Transformer
+        sys.modules["vit_pytorch"], sys.modules["vit_pytorch.vit"] = pkg, sub
+    from models.mae import MAE  # noqa: E402  (reference)
+    hp = MAE_SMALL
+    B = 2
+    enc = ViT(image_size=hp["image_size"], patch_size=hp["patch_size"], num_classes=1000, dim=hp["dim"], depth=hp["depth"], heads=hp["heads"],
+              mlp_dim=hp["mlp_dim"], channels=hp["channels"])
+    model = MAE(encoder=enc, masking_ratio=0.75, decoder_dim=hp["decoder_dim"], decoder_depth=hp["decoder_depth"], decoder_heads=hp["decoder_heads"])
+    seeded_fill_(model.state_dict())
+    model.train()
+    x = sar_like("mae.small.x", (B, hp["channels"], 224, 224))
+    out = {"state_dict_keys": np.array(list(model.state_dict().keys()))}
+    torch.manual_seed(4242)
+    idx = torch.rand(B, 196).argsort(dim=-1)                  # the draw MAE.forward makes first (mae.py:73)
+    torch.manual_seed(4242)
+    loss = model(x)
+    loss.backward()
+    out["rand_indices"] = idx.numpy()
+    out["loss"] = np.array(float(loss))
+    for k, p in model.named_parameters():
+        g = p.grad if p.grad is not None else torch.zeros_like(p)
+        gd = g.detach().double()
+        out[f"gstat.{k}"] = np.array([float(gd.norm()), float(gd.sum()), float(gd.abs().max())])
+        if k in MAE_GRAD_KEYS:
+            out[f"grad.{k}"] = g.detach().numpy().copy()
+    print("mae_small loss", float(loss))
+    np.savez_compressed(os.path.join(OUT, "mae_small.npz"), **out)
+
+
 def _import_changeformer_reference():
     """models/changeformer.py needs three helpers of timm (not installed): DropPath, to_2tuple, trunc_normal_.  The placeholders
     below stand in for them during the import: weights are seeded-filled afterwards (initialisation is irrelevant) and every
@@ -372,3 +418,5 @@ if __name__ == "__main__":
         gen_floodvit("full", FLOODVIT_FULL, 1)
     if not only or "changeformer" in only:
         gen_changeformer()
+    if not only or "mae" in only:
+        gen_mae()
