@@ -90,7 +90,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--model", default="snunet", choices=["snunet", "floodvit", "changeformer", "unet"],
+    ap.add_argument("--model", default="snunet", choices=["snunet", "floodvit", "changeformer", "unet", "mae"],
                     help="snunet = BASELINE.json configs[1] (the headline); changeformer = configs[3] (bs 32); "
                          "floodvit = configs[4] per-GPU shard (bs 16)")
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (weak scaling); default 32 snunet/changeformer, 16 floodvit")
@@ -150,6 +150,18 @@ def main():
         workload = ("BASELINE.json configs[0] model on the GPU: Unet(resnet18) segmentation, 2-ch GRD 224x224, "
                     f"per-GPU batch {B}, CE, Adam, fwd+loss+bwd+optimizer")
         metric = "SAR tiles/sec (224x224, Unet-resnet18 segmentation train step)"
+    elif args.model == "mae":
+        from kurosiwo_amd.config import load_json5
+        from kurosiwo_amd.mae import build_mae
+        from kurosiwo_amd.trainer import MAETrainStep
+        mc = load_json5(os.path.join(os.path.dirname(os.path.abspath(__file__)), "configs/method/mae/mae.json"))
+        model = build_mae(mc, precision=args.precision, channels=2).to(dev).train()
+        step = MAETrainStep(model, B, lr=mc["learning_rate"], bucket_mb=32.0)
+        x, _ = seg_inputs(batch, ("post_event",))
+        step.set_batch(x.to(dev))                                     # a fresh random permutation is drawn every step (mae.py:73)
+        workload = ("SURVEY.md §8(f) N3: MAE pre-training (configs/method/mae/mae.json: ViT d1024 L24 h16 encoder on 25 % of 196 patches, "
+                    f"decoder d512 L8 h16), 2-ch GRD 224x224, per-GPU batch {B}, MSE on the masked patches, Adam, fwd+loss+bwd+optimizer")
+        metric = "SAR tiles/sec (224x224, MAE pre-training step)"
     else:
         from kurosiwo_amd.floodvit import FinetunerSegmentation, ViT
         from kurosiwo_amd.trainer import SegTrainStep

@@ -104,3 +104,48 @@ class SegTrainStep(_PlanTrainStep):
 
     def _set_inputs(self, x):
         self.plan.x.copy_(x, non_blocking=True)
+
+
+class MAETrainStep:
+    """training/train_mae.py:62-122 on the MAE plan: step(image) = zero_grad -> mae(image) (fresh random permutation,
+    models/mae.py:73) -> backward (+ bucketed all-reduce) -> Adam, as one launch sequence.  loss_out[0] = reconstruction loss."""
+
+    def __init__(self, model, B, optimizer=None, lr=1e-5, bucket_mb=32.0, group=None, loss_scale=1.0):
+        self.model, self.B = model, B
+        self.lib = _lib.load()
+        self.plan = model.plan(B, True)
+        self.optimizer = optimizer if optimizer is not None else FusedAdam(model.parameters(), lr=lr)
+        n = model.flat_params.numel()
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        ready = {k: self.plan.param_ready.get(k, -1) for k in model._poff}
+        self.reducer = BucketedAllReduce(model.flat_grads, make_buckets(ready, model._poff, None, n, int(bucket_mb * 1e6 / 4)), group)
+        self.loss_out = self.plan.loss
+        self.plan.dloss.fill_(loss_scale)
+        self.timer = None
+
+    def set_batch(self, image, rand_indices=None):
+        self.plan.x.copy_(image, non_blocking=True)
+        if rand_indices is not None:
+            self.plan.idx.copy_(rand_indices, non_blocking=True)
+        self._fixed_idx = rand_indices is not None
+
+    def run(self):
+        p, t = self.plan, self.timer
+        if not getattr(self, "_fixed_idx", False):                 # mae.py:73
+            p.idx.copy_(torch.rand(self.B, p.N, device=p.dev).argsort(dim=-1))
+        p.packs.run(t)
+        p.fwd.run(t)
+        p.bwd.run(t, self.reducer.after_launch)
+        self.reducer.wait()
+        mf = self.model
+        on = t is not None and t.wants("optimizer")
+        if on:
+            t.begin("optimizer")
+        self.optimizer.step_arena(mf.flat_params.data_ptr(), mf.flat_grads.data_ptr(), mf.flat_params.numel(), p.dev, 1.0 / self.world)
+        if on:
+            t.end()
+
+    def step(self, image, rand_indices=None):
+        self.set_batch(image, rand_indices)
+        self.run()
+        return self.loss_out

@@ -5,6 +5,7 @@ for the tasks/methods that have a HIP implementation: task "cd" method "snunet",
 
   python main.py --method snunet --inputs pre_event_1 post_event [--dem] [--slope] [--batch_size N] [--seed S]
   python main.py --method finetune --inputs pre_event_1 pre_event_2 post_event [--batch_size N]
+  python main.py --method mae [--batch_size N]        (MAE pre-training of the FloodViT encoder)
 """
 import argparse
 import pprint
@@ -44,6 +45,17 @@ def main(argv=None):
         model_configs["backbone"] = args.backbone
     configs.update(model_configs)
     configs = update_config(configs, args)          # (the reference drops --dem without --inputs: main.py:66-69 bug, not kept)
+    if name == "mae" or configs.get("task") == "mae":
+        # main.py:160-163 of the reference: task "mae" -> training.train_mae.train(configs)
+        from kurosiwo_amd.training import train_mae
+        configs["task"] = "mae"
+        configs["num_channels"] = len(configs["channels"])
+        configs["checkpoint_path"] = create_checkpoint_directory(configs, model_configs)
+        if args.batch_size is not None:
+            configs["batch_size"] = int(args.batch_size)
+        pprint.pprint(configs)
+        train_mae.train(configs)
+        return 0.0
     if name in ("snunet", "changeformer", "siam-conc", "siam-diff", "bit-cd", "hfa-net", "adhr-cdnet"):
         configs["task"] = "cd"
         configs["num_channels"] = len(configs["channels"]) + (1 if configs["dem"] else 0)

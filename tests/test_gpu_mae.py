@@ -96,3 +96,32 @@ def test_mae_draws_the_reference_permutation_and_trains():
         opt.step()
         losses.append(float(loss))
     assert np.isfinite(losses).all() and losses[-1] < first
+
+
+def test_main_entry_mae_end_to_end_tiny(tmp_path, monkeypatch):
+    """main.py --method mae on a tiny synthetic set with a 2-layer encoder / 1-layer decoder: one epoch of the reference's
+    accumulate-4 loop, the four checkpoint files of train_mae.py:203-229, and the pickled encoder feeds FinetunerSegmentation."""
+    import re
+    import shutil
+    import main as entry
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    shutil.copytree(os.path.join(root, "configs"), tmp_path / "configs")
+    cfg = tmp_path / "configs" / "method" / "mae" / "mae.json"
+    txt = cfg.read_text()
+    for a, b in (('"depth": 24', '"depth": 2'), ('"mlp_dim": 2048', '"mlp_dim": 256'), ('"decoder_depth": 8', '"decoder_depth": 1'),
+                 ('"num_samples_per_epoch": 700000', '"num_samples_per_epoch": 16'), ('"warmup_epochs": 10', '"warmup_epochs": 1')):
+        txt = txt.replace(a, b)
+    cfg.write_text(txt)
+    tc = tmp_path / "configs" / "train" / "train_config.json"
+    tc.write_text(re.sub(r'"epochs"\s*:\s*\d+', '"epochs": 2', tc.read_text()))
+    monkeypatch.chdir(tmp_path)
+    entry.main(["--method", "mae", "--batch_size", "2"])
+    ck = tmp_path / "checkpoints" / "mae"
+    for f in ("mae_0.pt", "vit_0.pt", "mae_1.pt", "vit_1.pt", "mae_vit_2.pt", "trained_vit_2.pt"):
+        assert (ck / f).exists(), f
+    from kurosiwo_amd.floodvit import FinetunerSegmentation
+    enc = torch.load(ck / "trained_vit_2.pt", weights_only=False)
+    model = FinetunerSegmentation(enc, {"decoder": True, "num_classes": 3, "image_size": 224}).cuda().eval()
+    with torch.no_grad():
+        out = model(torch.randn(1, enc.hp["channels"], 224, 224, device="cuda"))
+    assert out.shape == (1, 3, 224, 224) and torch.isfinite(out).all()

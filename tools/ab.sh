@@ -1,2 +1,4 @@
 mkdir -p gpurun_out
-timeout 1500 python -m pytest tests/test_gpu_mae.py tests/test_gpu_floodvit.py -x -q -m gpu 2>&1 | tail -25 > gpurun_out/ab_tests.txt
+python bench.py --model mae --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/ab_mae.json 2>gpurun_out/ab_bench.err
+python bench.py --model mae --batch 64 --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/ab_mae64.json 2>>gpurun_out/ab_bench.err
+python bench.py --model mae --steps 5 --warmup 2 --no-cpu-baseline --time-all > gpurun_out/ab_detail_mae.txt 2>&1
