@@ -100,6 +100,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    # The contract is ONE JSON line on stdout.  Libraries write banners to the C-level stdout (RCCL prints its version block when a
+    # communicator is created / destroyed): send file descriptor 1 to stderr for the life of the process and keep a private copy
+    # of the real stdout for the result line.
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -256,9 +263,14 @@ def main():
                       f"{meta['flops'] * n / ms / 1e9:7.1f} TF/s {meta['bytes'] * n / ms / 1e6:7.1f} GB/s", file=sys.stderr)
         if world == 1 and not args.no_cpu_baseline and args.model == "snunet":
             res["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(res), flush=True)
+        result_line = json.dumps(res)
+    else:
+        result_line = None
     if dist.is_initialized():
         dist.destroy_process_group()
+    if result_line is not None:
+        real_stdout.write(result_line + "\n")
+        real_stdout.flush()
 
 
 if __name__ == "__main__":
