@@ -94,3 +94,27 @@ def test_metrics_oracle_hand_cases():
     mm = metrics_from_cm(torch.tensor(cm))
     for k in ("accuracy", "precision", "recall", "f1", "iou"):
         assert np.allclose(mm[k].numpy(), m[k])
+
+
+def test_mae_learning_rate_schedule_and_config():
+    """training/train_mae.py:14-33 (half-cycle cosine after a linear warm-up, in fractional epochs) and the values of
+    configs/method/mae/mae.json the MAE route reads."""
+    import math
+    import os
+    from kurosiwo_amd.config import load_json5
+    from kurosiwo_amd.training.train_mae import adjust_learning_rate
+
+    class Opt:
+        param_groups = [{"lr": 0.0}, {"lr": 0.0, "lr_scale": 0.5}]
+
+    cfg = {"warmup_epochs": 10, "lr": 4e-5, "min_lr": 0.0, "epochs": 100}
+    assert adjust_learning_rate(Opt, 0.0, cfg) == 0.0
+    assert abs(adjust_learning_rate(Opt, 2.5, cfg) - 1e-5) < 1e-12
+    assert Opt.param_groups[1]["lr"] == 0.5 * Opt.param_groups[0]["lr"]
+    mid = adjust_learning_rate(Opt, 55.0, cfg)
+    assert abs(mid - 4e-5 * 0.5 * (1 + math.cos(math.pi * 45 / 90))) < 1e-12
+    assert abs(adjust_learning_rate(Opt, 100.0, cfg)) < 1e-12
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    mc = load_json5(os.path.join(root, "configs/method/mae/mae.json"))
+    assert (mc["dim"], mc["depth"], mc["heads"], mc["mlp_dim"], mc["decoder_dim"], mc["decoder_depth"], mc["decoder_heads"]) == (1024, 24, 16, 2048, 512, 8, 16)
+    assert mc["masked_ratio"] == 0.75 and mc["accumulate_gradients"] == 4 and mc["warmup_epochs"] == 10
