@@ -8,8 +8,16 @@ import pytest
 import torch
 
 from oracle import mae_ref
-from oracle.gen_golden import MAE_SMALL, sar_like
-from oracle.seeded import seeded_fill_
+from oracle.seeded import seeded_fill_, seeded_tensor
+
+# (the same values as oracle/gen_golden.py MAE_SMALL / sar_like; that module imports /root/reference and must not be imported here)
+MAE_SMALL = dict(channels=2, image_size=224, patch_size=16, dim=1024, depth=2, heads=4, mlp_dim=512, decoder_dim=512, decoder_depth=2,
+                 decoder_heads=4)
+
+
+def sar_like(name, shape):
+    return seeded_tensor(name, shape).clamp_(-2.23, 5.75)
+
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "mae_small.npz")
 
