@@ -639,7 +639,8 @@ int ksmi_layernorm_forward(const void* x, const float* gamma, const float* beta,
   return ksmi_check_launch("layernorm_fwd");
 }
 
-int ksmi_layernorm_bwd_blocks(int rows) { int b = (rows + 7) / 8; return b > 1024 ? 1024 : (b < 1 ? 1 : b); }
+// at most 256 partial rows: one workgroup per CU and the parameter-gradient reduction stays a single launch (no fold pass)
+int ksmi_layernorm_bwd_blocks(int rows) { int b = (rows + 7) / 8; return b > 256 ? 256 : (b < 1 ? 1 : b); }
 
 int ksmi_layernorm_backward(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma, void* dx,
                             int accumulate, float* partial, int rows, int C, int dtype, void* stream) {
