@@ -203,7 +203,6 @@ class PlanBase:
             raise _lib.KsmiError("attention kernel is specialised for dim_head = 64")
         if self.with_backward:
             tD, tI, tM, tQ = self.buf(R, D), self.buf(R, I), self.buf(R, M), self.buf(R, 3 * I)
-        t1 = self.buf(R, D)
         scale = float(dim_head) ** -0.5
         for li in range(depth):
             a, f = f"{prefix}.layers.{li}.0", f"{prefix}.layers.{li}.1"
@@ -217,15 +216,12 @@ class PlanBase:
             self.fwd.add("ksmi_attention_forward", lambda qkv=qkv, att=att, lse=lse: (
                 qkv.data_ptr(), att.data_ptr(), lse.data_ptr(), B, Ntok, heads, 64, scale, dt),
                 {"kind": "attention_fwd", "bytes": 4 * R * I * self._es(), "flops": aflops})
-            self._linear(f"{tag}{li}.to_out", att, I, f"{a}.to_out.0.weight", f"{a}.to_out.0.bias", t1, D, R)
-            self.fwd.add("ksmi_add", lambda x_in=x_in, x_mid=x_mid: (t1.data_ptr(), x_in.data_ptr(), x_mid.data_ptr(), R * D, dt),
-                         self._elt_meta("add", 3 * R * D))
+            # the residual adds ride in the GEMM epilogues (one rounding of acc + bias + x instead of two)
+            self._linear(f"{tag}{li}.to_out", att, I, f"{a}.to_out.0.weight", f"{a}.to_out.0.bias", x_mid, D, R, resid=x_in)
             st2 = self._ln(x_mid, f"{f}.net.0.weight", f"{f}.net.0.bias", h2, R, D)
             self._linear(f"{tag}{li}.ff1", h2, D, f"{f}.net.1.weight", f"{f}.net.1.bias", u, M, R)
             self.fwd.add("ksmi_gelu_forward", lambda u=u, g=g: (u.data_ptr(), g.data_ptr(), R * M, dt), self._elt_meta("gelu", 2 * R * M))
-            self._linear(f"{tag}{li}.ff2", g, M, f"{f}.net.4.weight", f"{f}.net.4.bias", t1, D, R)
-            self.fwd.add("ksmi_add", lambda x_mid=x_mid, x_out=x_out: (t1.data_ptr(), x_mid.data_ptr(), x_out.data_ptr(), R * D, dt),
-                         self._elt_meta("add", 3 * R * D))
+            self._linear(f"{tag}{li}.ff2", g, M, f"{f}.net.4.weight", f"{f}.net.4.bias", x_out, D, R, resid=x_mid)
             X = x_out
             self.named[f"layer{li}" if tag == "L" else f"{tag}layer{li}"] = x_out
 
