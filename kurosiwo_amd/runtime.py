@@ -92,6 +92,32 @@ def choose_patch(H, W, stride=1, KH=3, KW=3, max_pix=256, max_halo=512):
     return best[1], best[2]
 
 
+def choose_patch_wgrad(H, W, stride=1, KH=3, KW=3, max_pix=256, max_halo=512):
+    """Patch of the weight-gradient kernel.  Its bf16 fast path (k-step-invariant fragment addresses, csrc/igemm.hip LIN) needs a patch
+    width that divides 16 and a whole number of 32-pixel k-steps; prefer such a patch when it does not need more patches than the
+    default choice (28x28 maps: 28x8 instead of 14x14; 14x14 maps: 14x16, the two extra columns are masked)."""
+    import os
+    th0, tw0 = choose_patch(H, W, stride, KH, KW, max_pix, max_halo)
+    if os.environ.get("KSMI_PATCH") or ((16 % tw0) == 0 and (th0 * tw0) % 32 == 0):
+        return th0, tw0
+    tiles0 = -(-H // th0) * -(-W // tw0)
+    best = None
+    for tw in (16, 8, 4):
+        if tw >= 2 * W:
+            continue
+        for th in range(1, min(H, max_pix // tw) + 1):
+            if (th * tw) % 32:
+                continue
+            hp = ((th - 1) * stride + KH) * ((tw - 1) * stride + KW)
+            if hp > max_halo:
+                continue
+            tiles = -(-H // th) * -(-W // tw)
+            key = (tiles, th * tw, hp)
+            if tiles <= tiles0 and (best is None or key < best[0]):
+                best = (key, th, tw)
+    return (best[1], best[2]) if best else (th0, tw0)
+
+
 def _chunk_table(srcs, kc):
     """[(src_idx, c0, k_global, k_len)] walking the virtual concat in kc-element chunks."""
     table, kbase = [], 0
@@ -217,7 +243,7 @@ def make_wgrad(srcs, dy, dyC, dy_c_off, N, grad, gK, gN, gT, accumulate, B, Hin,
     d.B, d.Hin, d.Win, d.Hout, d.Wout = B, Hin, Win, Hout, Wout
     d.KH, d.KW, d.stride, d.pad = KH, KW, stride, pad
     mp = 256 if stride == 1 else 128
-    d.TH, d.TW = choose_patch(Hout, Wout, stride, KH, KW, mp)
+    d.TH, d.TW = choose_patch_wgrad(Hout, Wout, stride, KH, KW, mp)
     d.N, d.nchunks = N, len(table)
     if pad_x is not None:
         d.pad_x_set, d.pad_x = 1, pad_x
