@@ -55,7 +55,46 @@ __global__ __launch_bounds__(256) void ecam_pool_kernel(const T* x0, const T* x1
         if (q > m[4][j]) { m[4][j] = q; mi[4][j] = p; }
       }
     }
-  // reduce over pixel lanes through LDS
+  // reduce over the pixel lanes.  Lanes with the same channel vector are CV apart: when CV is a power of two that divides 64 the
+  // 64 / CV pixel lanes of a wave combine by xor-shuffles in registers and only the 4 wave results go through LDS (the old path
+  // walked 64 LDS entries with CV threads, 40 times: it cost more than streaming the four 103 MB tensors)
+  if ((CV & (CV - 1)) == 0 && CV <= 64 && C <= 128) {
+    __shared__ float ws[4][5 * 128], wm[4][5 * 128];
+    __shared__ int wi[4][5 * 128];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        float a = s[k][j], mx = m[k][j];
+        int ix = mi[k][j];
+        for (int o = CV; o < 64; o <<= 1) {
+          a += __shfl_xor(a, o, 64);
+          const float m2 = __shfl_xor(mx, o, 64);
+          const int i2 = __shfl_xor(ix, o, 64);
+          if (m2 > mx || (m2 == mx && i2 < ix)) { mx = m2; ix = i2; }
+        }
+        if (lane < CV) {
+          const int e = (k * VEC + j) * CV + lane;
+          ws[wave][e] = a; wm[wave][e] = mx; wi[wave][e] = ix;
+        }
+      }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 5 * VEC * CV; e += kThreads) {
+      float a = 0.f, mx = -INFINITY; int ix = 0x7fffffff;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        a += ws[w][e];
+        if (wm[w][e] > mx || (wm[w][e] == mx && wi[w][e] < ix)) { mx = wm[w][e]; ix = wi[w][e]; }
+      }
+      const int kj = e / CV, cvv = e - kj * CV;
+      const int k = kj / VEC, j = kj - k * VEC;
+      const int c = k * C + cvv * VEC + j;
+      const size_t o = ((size_t)b * S + sp) * 5 * C + c;
+      psum[o] = a; pmax[o] = mx; pidx[o] = ix;
+    }
+    return;
+  }
   __shared__ float rs[kThreads], rm[kThreads];
   __shared__ int ri[kThreads];
 #pragma unroll
