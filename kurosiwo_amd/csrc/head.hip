@@ -8,7 +8,7 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kPoolSplit = 16;       // pixel splits per image for the global pools
-constexpr int kBwdSplit = 64;
+constexpr int kBwdSplit = 16;        // (64 made the single-block finish kernel walk 64 partial slabs: 0.24 ms)
 
 // ------------------------------------------------------------------------------------------------
 // ECAM global avg+max pool over H*W for cat(x0_1..x0_4) [4C] and for their sum [C]
