@@ -2,6 +2,7 @@
 // max-pool, first-layer conv, bias/channel reductions, optimiser, layout helpers.
 // All activations NHWC in T (fp32 / bf16), accessed as 16-byte vectors; all
 // statistics, parameters and gradients fp32 (reductions finish in fp64).
+#include <stdlib.h>
 #include "common.h"
 #include "../../include/ksmi.h"
 #include "errors.h"
@@ -65,6 +66,7 @@ __global__ void bn_finalize_kernel(const float* partial, int rows, int Cpad, int
   }
   double s = 0.0, q = 0.0;
   if (c < C)
+#pragma unroll 8
     for (int r = rl; r < rows; r += 64) {
       s += (double)partial[((size_t)r * 2 + 0) * Cpad + c];
       q += (double)partial[((size_t)r * 2 + 1) * Cpad + c];
@@ -110,7 +112,8 @@ __global__ void rows_fold_kernel(float* partial, int rows, int K, int Cstride, i
 
 static int fold_rows(float* partial, int rows, int K, int Cstride, int C, hipStream_t st) {
   constexpr int R = 32;
-  if (rows <= 8 * R) return rows;                 // up to 256 rows: the finishing kernel's 64 row lanes walk 4 rows each, no extra launch
+  static const int fold_min = getenv("KSMI_FOLD_MIN") ? atoi(getenv("KSMI_FOLD_MIN")) : 8 * R;
+  if (rows <= fold_min) return rows;              // up to 256 rows: the finishing kernel's 64 row lanes walk 4 rows each, no extra launch
   hipLaunchKernelGGL(rows_fold_kernel, dim3((C + 15) / 16, R), dim3(256), 0, st, partial, rows, K, Cstride, C, R);
   return R;
 }
@@ -124,6 +127,7 @@ __global__ void reduce_rows_kernel(const float* partial, int rows, int K, int Cs
   for (int k = 0; k < K; ++k) {
     double s = 0.0;
     if (c < C)
+#pragma unroll 8
       for (int r = rl; r < rows; r += 64) s += (double)partial[((size_t)r * K + k) * Cstride + c];
     __syncthreads();
     red[rl][cl] = s;
