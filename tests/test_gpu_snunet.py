@@ -188,3 +188,36 @@ def test_main_entry_end_to_end_tiny(dev, tmp_path, monkeypatch):
     d = torch.load(ck[0], map_location="cpu")
     assert set(d) == {"epoch", "model_state_dict", "optimizer_state_dict", "lr_scheduler_state_dict", "loss"}
     assert len(d["model_state_dict"]) == 236
+
+
+def test_headline_config_is_bitwise_reproducible_and_learns(dev):
+    """BASELINE.json configs[1] at full size (bs=32, 224x224, bf16, ce+dice, Adam): size-independent properties of the fused step.
+    (i) two runs from the same state give bit-identical parameters after 3 steps: every reduction has a fixed order
+    (pixel-split weight-gradient slabs, BatchNorm partial rows, loss partials), nothing uses float atomics;
+    (ii) the loss is finite and decreases on a repeated batch; (iii) the BatchNorm counters of the shared (siamese) encoder advance
+    twice per step, once per date, as nn.BatchNorm2d does when models/snunet.py:123-131 calls the block on xA and on xB."""
+    from kurosiwo_amd.snunet import SNUNet_ECAM
+    from kurosiwo_amd.synthetic import cd_inputs, make_batch
+    from kurosiwo_amd.trainer import CDTrainStep
+    B, H, W = 32, 224, 224
+    batch = make_batch(B, H, W, seed=1234)
+    (xA, xB), mask = cd_inputs(batch, ("pre_event_1", "post_event"))
+
+    def run():
+        torch.manual_seed(999)
+        model = SNUNet_ECAM(2, 3, base_channel=32, precision="bf16").to(dev).train()
+        step = CDTrainStep(model, B, H, W, loss_function="ce+dice", lr=1e-3)
+        step.set_batch(xA.to(dev), xB.to(dev), mask.to(dev))
+        losses = []
+        for _ in range(3):
+            step.run()
+            losses.append(step.loss_out.clone())
+        torch.cuda.synchronize()
+        nbt = model.state_dict()["conv0_0.bn1.num_batches_tracked"].item()
+        return model.flat_params.clone(), torch.stack(losses).cpu(), nbt
+
+    p1, l1, n1 = run()
+    p2, l2, n2 = run()
+    assert torch.equal(p1, p2) and torch.equal(l1, l2)
+    assert torch.isfinite(l1).all() and float(l1[-1, 0]) < float(l1[0, 0])
+    assert n1 == 6 and n2 == 6
