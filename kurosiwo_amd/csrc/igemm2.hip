@@ -321,7 +321,8 @@ int launch2(const ksmi_conv_desc* d, int dbg, hipStream_t st) {
   static const bool wn_off = getenv("KSMI_WN1") != nullptr;
   static const bool lean_off = getenv("KSMI_NO_LEAN") != nullptr;
   const bool lean = !lean_off && d->nchunks == 1 && taps == 9 && nt == 2 && HP * 64 <= 24576 && d->src[0].scale == nullptr;   // (the AFF path spills at 168 VGPRs)
-  const int wn = (!lean && !wn_off && nt == 2 && d->Npad >= 64 && taps <= 9) ? 2 : 1;
+  static const int wn_min = getenv("KSMI_WN_MIN") ? atoi(getenv("KSMI_WN_MIN")) : 64;
+  const int wn = (!lean && !wn_off && nt == 2 && d->Npad >= wn_min && taps <= 9) ? 2 : 1;
   const int bn = nt * 16 * wn;
   const dim3 grid(gm, (d->Npad + bn - 1) / bn);
   const size_t hpb = ((size_t)HP * 64 + 1023) & ~(size_t)1023;
