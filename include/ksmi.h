@@ -336,6 +336,16 @@ int ksmi_upsample2_backward(const void* dy, const void* x_pre, void* dx, int B, 
  * ------------------------------------------------------------------------------- */
 /* out[b,oy,ox, c*KH*KW + ky*KW + kx] (Kpad columns, zero padded) from an NHWC `dtype` activation or (src_nchw_f32) the raw
  * NCHW fp32 image: OverlapPatchEmbed.proj (:267) and Attention.sr (:166) become GEMMs against the OIHW-flattened weight */
+/* Channel-fastest variant of the same family (K index = tap * Cin + c, NHWC source only): every (pixel, tap) moves whole 16-byte
+ * channel vectors in both directions.  The GEMM weight of the convolution (OIHW, fp32: changeformer.py:262-263, :163) is re-ordered
+ * to match by ksmi_weight_to_tc (out[n][tap*Cin + c] = w[n][c][tap], zero K padding) and its gradient is returned to OIHW order by
+ * ksmi_grad_from_tc. */
+int ksmi_im2col_tc(const void* x, void* out, int B, int Cin, int H, int W, int Ho, int Wo, int KH, int KW, int stride, int pad, int Kpad,
+                   int dtype, void* stream);
+int ksmi_col2im_tc(const void* dcol, void* dx, int accumulate, int B, int Cin, int H, int W, int Ho, int Wo, int KH, int KW, int stride,
+                   int pad, int Kpad, int dtype, void* stream);
+int ksmi_weight_to_tc(const float* w, void* out, int N, int Cin, int taps, int Kpad, int dtype, void* stream);
+int ksmi_grad_from_tc(const float* g, float* grad, int N, int Cin, int taps, int Kpad, int accumulate, void* stream);
 int ksmi_im2col(const void* x, void* out, int B, int Cin, int H, int W, int Ho, int Wo, int KH, int KW, int stride, int pad,
                 int Kpad, int src_nchw_f32, int dtype, void* stream);
 int ksmi_col2im(const void* dcol, void* dx, int accumulate, int B, int Cin, int H, int W, int Ho, int Wo, int KH, int KW, int stride, int pad,

@@ -132,6 +132,10 @@ SIGNATURES = {
     "ksmi_gemm_nn": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     "ksmi_im2col": (_i, [_vp, _vp] + [_i] * 11 + [_i, _i, _vp]),
     "ksmi_col2im": (_i, [_vp, _vp, _i] + [_i] * 11 + [_i, _vp]),
+    "ksmi_im2col_tc": (_i, [_vp, _vp] + [_i] * 11 + [_i, _vp]),
+    "ksmi_col2im_tc": (_i, [_vp, _vp, _i] + [_i] * 11 + [_i, _vp]),
+    "ksmi_weight_to_tc": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "ksmi_grad_from_tc": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ksmi_maxpool3x3s2_forward": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ksmi_maxpool3x3s2_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ksmi_affine": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, C.c_float, _i, _vp]),

@@ -107,10 +107,17 @@ class ChangeFormerPlan(PlanBase):
             Kreal = src_c * 49
             Kpad = -(-Kreal // kc) * kc
             col, t0, t = self.buf(R, Kpad), self.buf(R, Cc), self.buf(R, Cc)
-            self.fwd.add("ksmi_im2col", lambda src=src, col=col, src_c=src_c, Hi=Hi, Wi=Wi, Hs=Hs, Ws=Ws, stride=stride, Kpad=Kpad, st=st: (
-                src.data_ptr(), col.data_ptr(), B2, src_c, Hi, Wi, Hs, Ws, 7, 7, stride, 3, Kpad, 1 if st == 0 else 0, dt),
-                self._elt_meta("im2col", 2 * R * Kpad))
-            self._linear(f"pe{st + 1}", col, Kpad, f"{pe}.proj.weight", f"{pe}.proj.bias", t0, Cc, R, k_real=Kreal)
+            pe_tc = st > 0 and self._tc_ok(src_c)
+            pe_wtc = None
+            if pe_tc:
+                self.fwd.add("ksmi_im2col_tc", lambda src=src, col=col, src_c=src_c, Hi=Hi, Wi=Wi, Hs=Hs, Ws=Ws, stride=stride, Kpad=Kpad: (
+                    src.data_ptr(), col.data_ptr(), B2, src_c, Hi, Wi, Hs, Ws, 7, 7, stride, 3, Kpad, dt), self._elt_meta("im2col", 2 * R * Kpad))
+                pe_wtc = self._linear_tc(f"pe{st + 1}", col, Kpad, f"{pe}.proj.weight", f"{pe}.proj.bias", t0, Cc, R, src_c, 49)
+            else:
+                self.fwd.add("ksmi_im2col", lambda src=src, col=col, src_c=src_c, Hi=Hi, Wi=Wi, Hs=Hs, Ws=Ws, stride=stride, Kpad=Kpad, st=st: (
+                    src.data_ptr(), col.data_ptr(), B2, src_c, Hi, Wi, Hs, Ws, 7, 7, stride, 3, Kpad, 1 if st == 0 else 0, dt),
+                    self._elt_meta("im2col", 2 * R * Kpad))
+                self._linear(f"pe{st + 1}", col, Kpad, f"{pe}.proj.weight", f"{pe}.proj.bias", t0, Cc, R, k_real=Kreal)
             st_pe = self._ln(t0, f"{pe}.norm.weight", f"{pe}.norm.bias", t, R, Cc, 1e-5)
             self.named[f"pe{st + 1}"] = t
             blocks = []
@@ -123,10 +130,16 @@ class ChangeFormerPlan(PlanBase):
                 if sr > 1:
                     Ksr = Cc * sr * sr
                     col2, xr, xn = self.buf(Rk, Ksr), self.buf(Rk, Cc), self.buf(Rk, Cc)
-                    self.fwd.add("ksmi_im2col", lambda h=h, col2=col2, Cc=Cc, Hs=Hs, Ws=Ws, sr=sr, Ksr=Ksr: (
-                        h.data_ptr(), col2.data_ptr(), B2, Cc, Hs, Ws, Hs // sr, Ws // sr, sr, sr, sr, 0, Ksr, 0, dt),
-                        self._elt_meta("im2col", 2 * Rk * Ksr))
-                    self._linear(f"{k}.sr", col2, Ksr, f"{k}.attn.sr.weight", f"{k}.attn.sr.bias", xr, Cc, Rk)
+                    if self._tc_ok(Cc):
+                        self.fwd.add("ksmi_im2col_tc", lambda h=h, col2=col2, Cc=Cc, Hs=Hs, Ws=Ws, sr=sr, Ksr=Ksr: (
+                            h.data_ptr(), col2.data_ptr(), B2, Cc, Hs, Ws, Hs // sr, Ws // sr, sr, sr, sr, 0, Ksr, dt),
+                            self._elt_meta("im2col", 2 * Rk * Ksr))
+                        rec["sr_wtc"] = self._linear_tc(f"{k}.sr", col2, Ksr, f"{k}.attn.sr.weight", f"{k}.attn.sr.bias", xr, Cc, Rk, Cc, sr * sr)
+                    else:
+                        self.fwd.add("ksmi_im2col", lambda h=h, col2=col2, Cc=Cc, Hs=Hs, Ws=Ws, sr=sr, Ksr=Ksr: (
+                            h.data_ptr(), col2.data_ptr(), B2, Cc, Hs, Ws, Hs // sr, Ws // sr, sr, sr, sr, 0, Ksr, 0, dt),
+                            self._elt_meta("im2col", 2 * Rk * Ksr))
+                        self._linear(f"{k}.sr", col2, Ksr, f"{k}.attn.sr.weight", f"{k}.attn.sr.bias", xr, Cc, Rk)
                     rec["st_sr"] = self._ln(xr, f"{k}.attn.norm.weight", f"{k}.attn.norm.bias", xn, Rk, Cc, 1e-5)
                     rec.update(col2=col2, xr=xr, xn=xn, Ksr=Ksr)
                 else:
@@ -155,7 +168,7 @@ class ChangeFormerPlan(PlanBase):
             st_n = self._ln(t, f"Tenc_x2.norm{st + 1}.weight", f"Tenc_x2.norm{st + 1}.bias", f, R, Cc, 1e-6)
             self.named[f"f{st + 1}"] = f
             feats.append(dict(f=f, C=Cc, H=Hs, W=Ws, R=R, Rk=Rk, heads=heads, sr=sr, stride=stride, Hi=Hi, Wi=Wi, src=src, src_c=src_c,
-                              col=col, Kpad=Kpad, Kreal=Kreal, t0=t0, st_pe=st_pe, pe=pe, blocks=blocks, t_last=t, st_n=st_n, st=st))
+                              col=col, Kpad=Kpad, Kreal=Kreal, t0=t0, st_pe=st_pe, pe=pe, blocks=blocks, t_last=t, st_n=st_n, st=st, pe_wtc=pe_wtc))
             src, src_c = f, Cc
         self.feats = feats
         self._build_decoder()
@@ -435,9 +448,14 @@ class ChangeFormerPlan(PlanBase):
                 dxr = rec["xn"]                                   # xn is dead after the kv weight gradient
                 self._ln_bwd(tk, rec["xr"], rec["st_sr"], f"{k}.attn.norm.weight", f"{k}.attn.norm.bias", dxr, 0, Rk, Cc)
                 dcol2 = self.buf(Rk, Ksr)
-                self._linear_bwd(f"{k}.sr", rec["col2"], Ksr, f"{k}.attn.sr.weight", f"{k}.attn.sr.bias", dxr, Cc, Rk, dcol2)
-                self.bwd.add("ksmi_col2im", lambda dcol2=dcol2, dh=dh, Ksr=Ksr: (dcol2.data_ptr(), dh.data_ptr(), 0, B2, Cc, Hs, Ws, Hs // sr, Ws // sr,
-                                                                                  sr, sr, sr, 0, Ksr, dt), self._elt_meta("col2im", 2 * Rk * Ksr))
+                if "sr_wtc" in rec:
+                    self._linear_tc_bwd(f"{k}.sr", rec["col2"], Ksr, f"{k}.attn.sr.weight", f"{k}.attn.sr.bias", dxr, Cc, Rk, dcol2, rec["sr_wtc"], Cc, sr * sr)
+                    self.bwd.add("ksmi_col2im_tc", lambda dcol2=dcol2, dh=dh, Ksr=Ksr: (dcol2.data_ptr(), dh.data_ptr(), 0, B2, Cc, Hs, Ws, Hs // sr, Ws // sr,
+                                                                                         sr, sr, sr, 0, Ksr, dt), self._elt_meta("col2im", 2 * Rk * Ksr))
+                else:
+                    self._linear_bwd(f"{k}.sr", rec["col2"], Ksr, f"{k}.attn.sr.weight", f"{k}.attn.sr.bias", dxr, Cc, Rk, dcol2)
+                    self.bwd.add("ksmi_col2im", lambda dcol2=dcol2, dh=dh, Ksr=Ksr: (dcol2.data_ptr(), dh.data_ptr(), 0, B2, Cc, Hs, Ws, Hs // sr, Ws // sr,
+                                                                                      sr, sr, sr, 0, Ksr, dt), self._elt_meta("col2im", 2 * Rk * Ksr))
                 self._linear_bwd(f"{k}.q", rec["h"], Cc, f"{k}.attn.q.weight", f"{k}.attn.q.bias", tq, Cc, R, dh, dx_acc=1)
             else:
                 self._linear_bwd(f"{k}.kv", rec["xn"], Cc, f"{k}.attn.kv.weight", f"{k}.attn.kv.bias", tkv, 2 * Cc, Rk, dh)
@@ -451,10 +469,46 @@ class ChangeFormerPlan(PlanBase):
             self._linear_bwd(f"pe{st + 1}", ft["col"], ft["Kpad"], f"{pe}.proj.weight", f"{pe}.proj.bias", dt0, Cc, R, None, k_real=ft["Kreal"])
         else:
             dcol = ft["col"] if False else self.buf(R, ft["Kpad"])
-            self._linear_bwd(f"pe{st + 1}", ft["col"], ft["Kpad"], f"{pe}.proj.weight", f"{pe}.proj.bias", dt0, Cc, R, dcol)
             prev = self.feats[st - 1]
-            self.bwd.add("ksmi_col2im", lambda dcol=dcol, prev=prev: (dcol.data_ptr(), prev["df"].data_ptr(), 1, B2, prev["C"], prev["H"], prev["W"],
-                                                                      Hs, Ws, 7, 7, 2, 3, ft["Kpad"], dt), self._elt_meta("col2im", 2 * R * ft["Kpad"]))
+            if ft.get("pe_wtc") is not None:
+                self._linear_tc_bwd(f"pe{st + 1}", ft["col"], ft["Kpad"], f"{pe}.proj.weight", f"{pe}.proj.bias", dt0, Cc, R, dcol, ft["pe_wtc"], prev["C"], 49)
+                self.bwd.add("ksmi_col2im_tc", lambda dcol=dcol, prev=prev: (dcol.data_ptr(), prev["df"].data_ptr(), 1, B2, prev["C"], prev["H"], prev["W"],
+                                                                             Hs, Ws, 7, 7, 2, 3, ft["Kpad"], dt), self._elt_meta("col2im", 2 * R * ft["Kpad"]))
+            else:
+                self._linear_bwd(f"pe{st + 1}", ft["col"], ft["Kpad"], f"{pe}.proj.weight", f"{pe}.proj.bias", dt0, Cc, R, dcol)
+                self.bwd.add("ksmi_col2im", lambda dcol=dcol, prev=prev: (dcol.data_ptr(), prev["df"].data_ptr(), 1, B2, prev["C"], prev["H"], prev["W"],
+                                                                          Hs, Ws, 7, 7, 2, 3, ft["Kpad"], dt), self._elt_meta("col2im", 2 * R * ft["Kpad"]))
+
+    # ---------------------------------------------------------------- convolutions as GEMMs over a channel-fastest im2col
+    def _tc_ok(self, Cin):
+        """bf16 performance mode: im2col matrices in (tap, channel) order (ksmi_im2col_tc), weights re-ordered per step."""
+        import os
+        return self.dtype == torch.bfloat16 and self.wb is not None and Cin % 8 == 0 and not os.environ.get("KSMI_IM2COL_CT")
+
+    def _linear_tc(self, name, col, Kpad, wkey, bkey, out, N, rows, Cin, taps):
+        wtc = torch.empty((N, Kpad), dtype=self.dtype, device=self.dev)
+        self.keep.append(wtc)
+        w = self.m._p(wkey).data_ptr()
+        self.packs.add("ksmi_weight_to_tc", lambda: (w, wtc.data_ptr(), N, Cin, taps, Kpad, self.dt), {"kind": "weight_to_tc", "bytes": 6 * N * Kpad, "flops": 0})
+        bp = self.m._p(bkey).data_ptr() if bkey else None
+        meta = {"kind": "gemm_nt", "bytes": (rows * Kpad + rows * N + N * Kpad) * 2, "flops": 2 * rows * N * Kpad, "tag": f"{name} K={Kpad} N={N} M={rows}"}
+        self.fwd.add("ksmi_gemm_nt", lambda: (col.data_ptr(), Kpad, wtc.data_ptr(), Kpad, bp, None, N, out.data_ptr(), N, rows, Kpad, N), meta)
+        return wtc
+
+    def _linear_tc_bwd(self, name, col, Kpad, wkey, bkey, dy, N, rows, dcol, wtc, Cin, taps):
+        if dcol is not None:
+            meta = {"kind": "gemm_nn", "bytes": (rows * N + rows * Kpad + N * Kpad) * 2, "flops": 2 * rows * N * Kpad, "tag": f"{name} K={N} N={Kpad} M={rows}"}
+            self.bwd.add("ksmi_gemm_nn", lambda: (dy.data_ptr(), N, wtc.data_ptr(), Kpad, dcol.data_ptr(), Kpad, rows, Kpad, N, 0), meta)
+        gtc = torch.empty((N, Kpad), dtype=torch.float32, device=self.dev)
+        self.keep.append(gtc)
+        dw, ws = make_wgrad([SrcSpec(col, Kpad)], dy, N, 0, N, gtc, 1, Kpad, 0, 0, 1, rows, 1, rows, 1, 1, 1, 1, 0, self.dtype)
+        self._wgrad(dw, ws, wkey)
+        acc = self._acc_param(wkey)
+        g = self.m._g(wkey).data_ptr()
+        self.bwd.add("ksmi_grad_from_tc", lambda: (gtc.data_ptr(), g, N, Cin, taps, Kpad, acc), {"kind": "grad_from_tc", "bytes": 8 * N * Kpad, "flops": 0})
+        self._mark(wkey)
+        if bkey:
+            self._bias_grad(dy, rows, N, bkey)
 
     # ---------------------------------------------------------------- execution
     def run_forward(self, x1, x2):

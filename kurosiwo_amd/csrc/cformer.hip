@@ -693,7 +693,133 @@ int sr_attn_dispatch(int which, const void* q, const void* kv, const void* io, v
     else return ksmi_fail(KSMI_E_ARG, "bad dtype");                          \
   } while (0)
 
+// ---- channel-fastest im2col family (K index = tap * Cin + c) ---------------------------------------------------------
+// The OIHW-flattened order above (k = c * taps + tap) makes both directions 2-byte gathers at a stride of `taps` elements
+// (col2im: 181 us per ChangeFormer patch embedding).  With the channel fastest every (pixel, tap) pair moves whole 16-byte
+// channel vectors, coalesced on both sides; the GEMM weight is re-ordered to match (weight_to_tc, a few MB per step) and the
+// weight gradient is put back in OIHW order by grad_from_tc.
+template <typename T>
+__global__ void im2col_tc_kernel(const T* x, T* out, int B, int Cin, int H, int W, int Ho, int Wo, int KH, int KW, int stride, int pad,
+                                 int Kpad) {
+  constexpr int VEC = ElemTraits<T>::kVec;
+  const int KV = Kpad / VEC, CV = Cin / VEC, taps = KH * KW;
+  const int64_t n = (int64_t)B * Ho * Wo * KV;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int kv = (int)(i % KV); int64_t r = i / KV;
+    const int ox = (int)(r % Wo); r /= Wo;
+    const int oy = (int)(r % Ho); const int b = (int)(r / Ho);
+    u32x4 v = (u32x4){0u, 0u, 0u, 0u};
+    const int t = kv / CV, cv = kv - t * CV;
+    if (t < taps) {
+      const int ky = t / KW, kx = t - ky * KW;
+      const int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
+      if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = *(const u32x4*)(x + (((int64_t)b * H + iy) * W + ix) * Cin + cv * VEC);
+    }
+    *(u32x4*)(out + i * VEC) = v;
+  }
+}
+
+template <typename T>
+__global__ void col2im_tc_kernel(const T* dcol, T* dx, int B, int Cin, int H, int W, int Ho, int Wo, int KH, int KW, int stride, int pad,
+                                 int Kpad, int accumulate) {
+  constexpr int VEC = ElemTraits<T>::kVec;
+  const int CV = Cin / VEC;
+  const int64_t n = (int64_t)B * H * W * CV;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int cv = (int)(i % CV); int64_t r = i / CV;
+    const int ix = (int)(r % W); r /= W;
+    const int iy = (int)(r % H); const int b = (int)(r / H);
+    float s[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) s[j] = 0.f;
+    for (int ky = 0; ky < KH; ++ky) {
+      const int ty = iy + pad - ky;
+      if (ty < 0 || ty % stride) continue;
+      const int oy = ty / stride;
+      if (oy >= Ho) continue;
+      for (int kx = 0; kx < KW; ++kx) {
+        const int tx = ix + pad - kx;
+        if (tx < 0 || tx % stride) continue;
+        const int ox = tx / stride;
+        if (ox >= Wo) continue;
+        float f[VEC];
+        vec_unpack<T>(*(const u32x4*)(dcol + (((int64_t)b * Ho + oy) * Wo + ox) * Kpad + (ky * KW + kx) * Cin + cv * VEC), f);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) s[j] += f[j];
+      }
+    }
+    if (accumulate) {
+      float o[VEC];
+      vec_unpack<T>(*(const u32x4*)(dx + i * VEC), o);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) s[j] += o[j];
+    }
+    *(u32x4*)(dx + i * VEC) = vec_pack<T>(s);
+  }
+}
+
+// out[n][t * Cin + c] = w[n][c][t] (activation dtype, zero in the K padding); grad[n][c][t] (+)= g[n][t * Cin + c]
+template <typename T>
+__global__ void weight_to_tc_kernel(const float* w, T* out, int N, int Cin, int taps, int Kpad) {
+  const int64_t n = (int64_t)N * Kpad;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(i % Kpad); const int o = (int)(i / Kpad);
+    const int t = k / Cin, c = k - t * Cin;
+    ElemTraits<T>::st(out + i, t < taps ? w[((int64_t)o * Cin + c) * taps + t] : 0.f);
+  }
+}
+__global__ void grad_from_tc_kernel(const float* g, float* grad, int N, int Cin, int taps, int Kpad, int accumulate) {
+  const int64_t n = (int64_t)N * Cin * taps;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int t = (int)(i % taps); int64_t r = i / taps;
+    const int c = (int)(r % Cin); const int o = (int)(r / Cin);
+    const float v = g[(int64_t)o * Kpad + t * Cin + c];
+    grad[i] = accumulate ? grad[i] + v : v;
+  }
+}
+
 extern "C" {
+
+int ksmi_im2col_tc(const void* x, void* out, int B, int Cin, int H, int W, int Ho, int Wo, int KH, int KW, int stride, int pad, int Kpad,
+                   int dtype, void* stream) {
+  const int vec = dtype == KSMI_BF16 ? 8 : 4;
+  if (Cin % vec || Kpad % vec || Kpad < Cin * KH * KW) return ksmi_fail(KSMI_E_ARG, "im2col_tc: Cin and Kpad must be multiples of the 16-byte vector");
+  const int64_t n = (int64_t)B * Ho * Wo * (Kpad / vec);
+  hipStream_t st = (hipStream_t)stream;
+  KSMI_DT(dtype,
+          hipLaunchKernelGGL(im2col_tc_kernel<bf16_t>, dim3(grid_for(n, 65536)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)out, B, Cin, H, W, Ho, Wo, KH, KW, stride, pad, Kpad),
+          hipLaunchKernelGGL(im2col_tc_kernel<float>, dim3(grid_for(n, 65536)), dim3(256), 0, st, (const float*)x, (float*)out, B, Cin, H, W, Ho, Wo, KH, KW, stride, pad, Kpad));
+  return ksmi_check_launch("im2col_tc");
+}
+
+int ksmi_col2im_tc(const void* dcol, void* dx, int accumulate, int B, int Cin, int H, int W, int Ho, int Wo, int KH, int KW, int stride,
+                   int pad, int Kpad, int dtype, void* stream) {
+  const int vec = dtype == KSMI_BF16 ? 8 : 4;
+  if (Cin % vec || Kpad % vec || Kpad < Cin * KH * KW) return ksmi_fail(KSMI_E_ARG, "col2im_tc: Cin and Kpad must be multiples of the 16-byte vector");
+  const int64_t n = (int64_t)B * H * W * (Cin / vec);
+  hipStream_t st = (hipStream_t)stream;
+  KSMI_DT(dtype,
+          hipLaunchKernelGGL(col2im_tc_kernel<bf16_t>, dim3(grid_for(n, 65536)), dim3(256), 0, st, (const bf16_t*)dcol, (bf16_t*)dx, B, Cin, H, W, Ho, Wo, KH, KW, stride, pad, Kpad, accumulate),
+          hipLaunchKernelGGL(col2im_tc_kernel<float>, dim3(grid_for(n, 65536)), dim3(256), 0, st, (const float*)dcol, (float*)dx, B, Cin, H, W, Ho, Wo, KH, KW, stride, pad, Kpad, accumulate));
+  return ksmi_check_launch("col2im_tc");
+}
+
+int ksmi_weight_to_tc(const float* w, void* out, int N, int Cin, int taps, int Kpad, int dtype, void* stream) {
+  if (Kpad < Cin * taps) return ksmi_fail(KSMI_E_ARG, "weight_to_tc: Kpad < Cin*taps");
+  const int64_t n = (int64_t)N * Kpad;
+  hipStream_t st = (hipStream_t)stream;
+  KSMI_DT(dtype,
+          hipLaunchKernelGGL(weight_to_tc_kernel<bf16_t>, dim3(grid_for(n, 65536)), dim3(256), 0, st, w, (bf16_t*)out, N, Cin, taps, Kpad),
+          hipLaunchKernelGGL(weight_to_tc_kernel<float>, dim3(grid_for(n, 65536)), dim3(256), 0, st, w, (float*)out, N, Cin, taps, Kpad));
+  return ksmi_check_launch("weight_to_tc");
+}
+
+int ksmi_grad_from_tc(const float* g, float* grad, int N, int Cin, int taps, int Kpad, int accumulate, void* stream) {
+  if (Kpad < Cin * taps) return ksmi_fail(KSMI_E_ARG, "grad_from_tc: Kpad < Cin*taps");
+  const int64_t n = (int64_t)N * Cin * taps;
+  hipLaunchKernelGGL(grad_from_tc_kernel, dim3(grid_for(n, 65536)), dim3(256), 0, (hipStream_t)stream, g, grad, N, Cin, taps, Kpad, accumulate);
+  return ksmi_check_launch("grad_from_tc");
+}
 
 int ksmi_im2col(const void* x, void* out, int B, int Cin, int H, int W, int Ho, int Wo, int KH, int KW, int stride, int pad,
                 int Kpad, int src_nchw_f32, int dtype, void* stream) {

@@ -197,3 +197,39 @@ def test_bn_bwd_apply_and_affine_and_sigmoid_out(dtype, relu_mask):
     _lib.check(lib.ksmi_dout_to_nhwc(g.data_ptr(), yo.data_ptr(), dxh.data_ptr(), B, 3, Cs, H * W, 1, DT[dtype], stream_ptr()))
     refd = (g * ref * (1 - ref)).permute(0, 2, 1)
     assert rel(dxh.float()[:, :, :3], refd) < tol(dtype) and float(dxh.float()[:, :, 3:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cin,cout,k,s,p,hw", [(64, 128, 7, 2, 3, 56), (320, 512, 7, 2, 3, 14), (64, 64, 8, 8, 0, 56), (128, 128, 4, 4, 0, 28)])
+def test_channel_fastest_im2col_family(dtype, cin, cout, k, s, p, hw):
+    """ksmi_im2col_tc / col2im_tc / weight_to_tc / grad_from_tc (K index = tap * Cin + c) against the OIHW-ordered family: the
+    column matrices are permutations of each other, the re-ordered weight gives the same product, and the weight gradient comes
+    back in OIHW order."""
+    from kurosiwo_amd import _lib
+    from kurosiwo_amd import functional as KF
+    from kurosiwo_amd.runtime import DT, stream_ptr
+    lib = _lib.load()
+    torch.manual_seed(1)
+    B, T = 2, k * k
+    K = cin * T
+    x = nhwc(torch.randn(B, cin, hw, hw, device="cuda"), dtype)
+    col = KF.im2col(x, k, k, s, p)
+    _, Ho, Wo, Kp = col.shape
+    assert Kp == K
+    col_tc = torch.empty_like(col)
+    _lib.check(lib.ksmi_im2col_tc(x.data_ptr(), col_tc.data_ptr(), B, cin, hw, hw, Ho, Wo, k, k, s, p, K, DT[dtype], stream_ptr()), "im2col_tc")
+    assert torch.equal(col_tc.reshape(-1, T, cin), col.reshape(-1, cin, T).transpose(1, 2))
+    g = torch.randn(B, Ho, Wo, K, device="cuda").to(dtype)
+    g_tc = g.reshape(-1, cin, T).transpose(1, 2).contiguous().reshape(B, Ho, Wo, K)
+    dx = KF.col2im(g, cin, hw, hw, k, k, s, p)
+    dx_tc = torch.full_like(dx, 0.5)
+    _lib.check(lib.ksmi_col2im_tc(g_tc.data_ptr(), dx_tc.data_ptr(), 1, B, cin, hw, hw, Ho, Wo, k, k, s, p, K, DT[dtype], stream_ptr()), "col2im_tc")
+    assert rel(dx_tc.float() - 0.5, dx) < (1e-5 if dtype == torch.float32 else 2e-2)
+    w = torch.randn(cout, cin, k, k, device="cuda")
+    w_tc = torch.empty(cout, K, device="cuda", dtype=dtype)
+    _lib.check(lib.ksmi_weight_to_tc(w.data_ptr(), w_tc.data_ptr(), cout, cin, T, K, DT[dtype], stream_ptr()), "weight_to_tc")
+    assert torch.equal(w_tc, w.reshape(cout, cin, T).transpose(1, 2).reshape(cout, K).to(dtype))
+    gt = torch.randn(cout, K, device="cuda")
+    grad = torch.ones(cout, cin, k, k, device="cuda")
+    _lib.check(lib.ksmi_grad_from_tc(gt.data_ptr(), grad.data_ptr(), cout, cin, T, K, 1, stream_ptr()), "grad_from_tc")
+    assert torch.equal(grad, 1 + gt.reshape(cout, T, cin).transpose(1, 2).reshape(cout, cin, k, k))

