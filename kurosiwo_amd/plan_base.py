@@ -140,7 +140,7 @@ class PlanBase:
             self.bwd.add("ksmi_colsum", lambda: (dy.data_ptr(), rows, N, gb, acc, self.dt), self._elt_meta("colsum", rows * N))
             self._mark(bkey)
             return
-        r = max(1, min(256, rows // 64))                   # <= 256 partial rows: the finishing reduction is one launch (no fold pass)
+        r = max(1, min(512, rows // 64))                   # (256 would save the fold launch but halves the streaming kernel's grid: slower)
         self.need("red", r * N * 4)
         acc = self._acc_param(bkey)
         gb = self.m._g(bkey).data_ptr()
