@@ -11,6 +11,7 @@
 #include "../../include/ksmi.h"
 #include "errors.h"
 #include "igemm_epilogue.h"
+#include "wgrad3.h"
 
 namespace {
 
@@ -756,7 +757,7 @@ static void gemm_tn_geom(const ksmi_wgrad_desc* d, int kc, int& nsplit, int& rps
   nsplit = (rows + rps - 1) / rps;
 }
 
-struct WgradGeom { int taps, kc, nt, bn, patches, pps, nsplit, ntiles, npad; size_t lds; bool tn; int rps, tk, tnn; };
+struct WgradGeom { int taps, kc, nt, bn, patches, pps, nsplit, ntiles, npad; size_t lds; bool tn; int rps, tk, tnn; bool v3; ksmi_wgrad3_geom_t g3; };
 
 template <typename T>
 WgradGeom wgrad_geom(const ksmi_wgrad_desc* d) {
@@ -790,6 +791,9 @@ WgradGeom wgrad_geom(const ksmi_wgrad_desc* d) {
   if (g.taps == 1 && g.lds < (size_t)(g.kc / 16) * g.nt * 4096) g.lds = (size_t)(g.kc / 16) * g.nt * 4096;   // split-k reduction buffer
   g.tn = gemm_tn_eligible(d, (int)sizeof(T));
   if (g.tn) gemm_tn_geom(d, g.kc, g.nsplit, g.rps, g.tk, g.tnn);
+  // 3x3 stride-1 bf16 gradients with whole 32-channel chunks: channel-owner kernel (wgrad3.hip), same slab layout and reducer
+  g.v3 = !g.tn && ksmi_wgrad3_geom(d, sizeof(T) == 2 ? KSMI_BF16 : KSMI_F32, &g.g3);
+  if (g.v3) g.nsplit = g.g3.nsplit;
   return g;
 }
 
@@ -798,6 +802,14 @@ int launch_wgrad(const ksmi_wgrad_desc* d, hipStream_t st) {
   WgradGeom g = wgrad_geom<T>(d);
   if (d->TH * d->TW > 256) return ksmi_fail(KSMI_E_ARG, "wgrad: patch too large");
   if (d->nsplit != g.nsplit) return ksmi_fail(KSMI_E_ARG, "wgrad: nsplit does not match ksmi_conv_wgrad_workspace geometry");
+  if (g.v3) {
+    int rc3 = ksmi_wgrad3_launch(d, &g.g3, st);
+    if (rc3) return rc3;
+    const size_t total3 = (size_t)g.taps * d->nchunks * g.kc * g.npad;
+    int blocks3 = (int)((total3 * 8 + 255) / 256); if (blocks3 > 4096) blocks3 = 4096;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks3), dim3(256), 0, st, *d, g.taps, g.kc);
+    return ksmi_check_launch("wgrad_reduce");
+  }
   if (g.tn) {
     // plain row-major nn.Linear gradient (unit K stride, one tap at offset 0, contiguous k rows): large problems go to hipBLASLt
     bool plain = d->gK == 1 && (!d->use_tap_off || d->tap_off[0] == 0) && d->gN >= d->src[0].c_len && d->gN < ((int64_t)1 << 31);

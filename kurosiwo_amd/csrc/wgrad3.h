@@ -1,0 +1,16 @@
+// wgrad3.hip: weight gradient of 3x3 / stride 1 / pad 1 convolutions (bf16), channel-owner tiling.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/ksmi.h"
+
+struct ksmi_wgrad3_geom_t {
+  int TH, TW, HWc, tilesX, tilesY;   // pixel patch (TH*TW <= 128), staged halo width, patches per image
+  int WC, NTL;                       // waves along the channel axis (2 / 4 -> 32 / 64 channels per tile), columns per tile (32 / 64)
+  int KT, NTt;                       // tiles along K and N
+  int patches, pps, nsplit;          // patches, patches per split, splits (= partial slabs)
+  int xpl, stage;                    // LDS bytes of one X plane / one stage
+  size_t lds;
+};
+// false: the descriptor does not qualify (the caller uses igemm_wgrad_kernel)
+bool ksmi_wgrad3_geom(const ksmi_wgrad_desc* d, int dtype, ksmi_wgrad3_geom_t* g);
+int ksmi_wgrad3_launch(const ksmi_wgrad_desc* d, const ksmi_wgrad3_geom_t* g, hipStream_t st);

@@ -1,0 +1,382 @@
+// Weight gradient of the 3x3 / stride 1 / pad 1 convolutions (bf16), "channel-owner" tiling.
+//
+//   G[tap][k][n] = sum_pixels X[pixel + tap - 1][k] * dY[pixel][n]        (models/snunet.py:15-17 backward)
+//
+// A workgroup owns an output tile of CT = 16*WC input channels x NTL = 16*WN*NF output channels x ALL 9 taps and walks a
+// contiguous range of 128-pixel patches (one "split" of the pixel axis).  Wave w owns ONE 16-channel fragment (cfi = w % WC)
+// for every tap and NF column fragments: 9*NF accumulator tiles per wave, so a k-step of 32 pixels issues 9*NF MFMAs for
+// 9 + NF fragment reads (the first kernel, igemm.hip: 12 MFMAs for 8 reads) and both operands of a patch are fetched from
+// L2 / HBM once per CT x NTL tile instead of once per 32 x 32 tile.
+// Both LDS images are plane-major ([32-channel plane][pixel row][64 B]), double-buffered and filled by LDS-DMA
+// (global_load_lds_dwordx4: lane-linear destination, so the 32-byte bank swizzle is applied on the SOURCE address,
+// cdna_hip_programming.md rule 21); positions outside the image are written as zeros with ds_write.  The MFMA K axis is the
+// pixel axis: both operands are read transposed (ds_read_b64_tr_b16); a lane's fragment addresses are a table for k-step 0
+// plus a uniform stride per k-step (the patch width divides 32, so a lane keeps its column and swizzle term in every k-step).
+// A fused BN-apply + ReLU operand (conv2 of conv_block_nested reads relu(bn1(i)), snunet.py:24-25) is transformed IN LDS after
+// the DMA has landed.  Partial slabs [split][tap][K][Npad] are summed by wgrad_reduce_kernel (igemm.hip), unchanged.
+#include <stdlib.h>
+#include "common.h"
+#include "../../include/ksmi.h"
+#include "errors.h"
+#include "igemm_epilogue.h"
+#include "wgrad3.h"
+
+namespace {
+
+struct Wg3Args {
+  ksmi_wgrad_desc d;
+  int TH, TW, HWc, HPv;            // patch; staged halo width (min(TW, W) + 2); staged halo rows (TH + 2) * HWc
+  int xpl, stage;                  // bytes of one X plane / of one stage
+  int tilesX, tilesY, patches, pps;
+  int KT, NTt;
+  uint32_t m_hw, m_tw, m_tx, m_ty, m_tiles, m_ntt;
+  int kstride;                     // bytes between k-steps inside an X plane
+  int hymask;                      // 1: the swizzle term of the X image includes the halo row parity (TW == 8)
+  int lds_bytes;
+};
+
+// LDS-DMA issued from inline asm: hipcc (ROCm 7.2) puts `s_waitcnt vmcnt(0)` in front of every ds_read_b64_tr_b16 that follows a
+// __builtin_amdgcn_global_load_lds (the transposed-read intrinsic carries no memory operand, so it may alias the DMA), which
+// serialises the DMA of patch i+1 with the MFMAs of patch i.  An asm DMA is invisible to that pass; its completion is waited for
+// by hand (dma_wait) in front of the barrier that publishes the stage.  lane i lands at dst_wave_base + 16 * i.
+__device__ __forceinline__ void glds16(const unsigned char* base, uint32_t off, unsigned dst_wave_base) {
+  unsigned keep;
+  dst_wave_base = __builtin_amdgcn_readfirstlane(dst_wave_base);    // provably uniform for the "s" constraint
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(off), "s"(base), "s"(dst_wave_base) : "memory");
+}
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+__device__ __forceinline__ u32x4 tr_frag(unsigned a0, unsigned a1) {
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(uintptr_t)a0);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(uintptr_t)a1);
+  return __builtin_bit_cast(u32x4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+// chunk tables as dword scalar loads (see igemm_epilogue.h: chunk_c0_of)
+__device__ __forceinline__ int wg_chunk_c0(const ksmi_wgrad_desc& d, int ch) {
+  if (d.uniform_kc) return ch * d.uniform_kc;
+  const uint32_t w = ((const uint32_t*)d.chunk_c0)[ch >> 1];
+  return (ch & 1) ? (int)(w >> 16) : (int)(w & 0xffffu);
+}
+__device__ __forceinline__ int wg_chunk_src(const ksmi_wgrad_desc& d, int ch) {
+  if (d.uniform_kc) return 0;
+  return (int)((((const uint32_t*)d.chunk_src)[ch >> 2] >> ((ch & 3) * 8)) & 0xffu);
+}
+
+template <int WC, int WN, int NF, bool AFF>
+__global__ __launch_bounds__(256, 2) void wgrad3_kernel(const Wg3Args ka) {
+  typedef bf16_t T;
+  const ksmi_wgrad_desc& d = ka.d;
+  constexpr int CPT = WC / 2;                      // 32-channel planes of X per tile
+  constexpr int NFT = WN * NF;                     // column fragments per tile
+  constexpr int NPL = (NFT + 1) / 2;               // 32-column planes of dY per tile
+  constexpr int NTL = NFT * 16;
+  constexpr int XIT = 4;                           // X slot iterations: 256 * 4 slots of 16 B >= 4 * halo rows (<= 256)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cfi = wave % WC, wn = wave / WC;
+  const int g = lane >> 4, l15 = lane & 15;
+
+  // ---- which tile / split (XCD-aware: the tiles of one split are consecutive logical ids on one XCD and share its L2) ----
+  const int L = (int)xcd_remap(blockIdx.x, gridDim.x);
+  const FastDiv dTiles(ka.KT * ka.NTt, ka.m_tiles), dNTt(ka.NTt, ka.m_ntt);
+  const int split = dTiles.div(L);
+  const int rem = L - split * (ka.KT * ka.NTt);
+  const int kt = dNTt.div(rem), nt = rem - kt * ka.NTt;
+  const int n0 = nt * NTL;
+  const int TW = ka.TW, TH = ka.TH, HWc = ka.HWc;
+  const int P = TH * TW;
+  const FastDiv dHW(HWc, ka.m_hw), dTW(TW, ka.m_tw), dTX(ka.tilesX, ka.m_tx), dTY(ka.tilesY, ka.m_ty);
+  const int xpl = ka.xpl, stage = ka.stage;
+
+  // ---- the tile's X planes ------------------------------------------------------------------------------------
+  const unsigned char* sp[CPT];
+  uint32_t cb[CPT];
+  bool cvalid[CPT];
+  int cc0[CPT];
+#pragma unroll
+  for (int c = 0; c < CPT; ++c) {
+    const int ch = kt * CPT + c;
+    cvalid[c] = ch < d.nchunks;
+    const int chs = cvalid[c] ? ch : 0;
+    const ksmi_src& sr = d.src[wg_chunk_src(d, chs)];
+    cc0[c] = wg_chunk_c0(d, chs);
+    sp[c] = (const unsigned char*)((const T*)sr.ptr + sr.c_off + cc0[c]);
+    cb[c] = (uint32_t)sr.C * 2u;
+  }
+  const unsigned char* const dyp = (const unsigned char*)((const T*)d.dy + d.dy_c_off);
+  const uint32_t dycb = (uint32_t)d.dyC * 2u;
+
+  // ---- zero the whole LDS allocation once (rows of the k padding, slack rows: everything an MFMA may touch is finite) ----
+  for (int i = tid * 16; i < ka.lds_bytes; i += 256 * 16) *(u32x4*)(smem + i) = (u32x4){0u, 0u, 0u, 0u};
+  float* aff_tab = (float*)(smem + 2 * stage);                      // AFF: [CPT*32][2] scale, shift of the tile's channels
+  if constexpr (AFF) {
+    __syncthreads();
+    if (tid < CPT * 32) {
+      const int c = tid >> 5, j = tid & 31;
+      const ksmi_src& sr = d.src[0];
+      const bool ok = cvalid[c];
+      aff_tab[tid * 2 + 0] = ok ? sr.scale[cc0[c] + j] : 0.f;
+      aff_tab[tid * 2 + 1] = ok ? sr.shift[cc0[c] + j] : 0.f;
+    }
+  }
+  const bool aff_relu = AFF && d.src[0].relu != 0;
+
+  // ---- fragment address tables of k-step 0, stage 0 --------------------------------------------------------------
+  // X: [halo-row parity of the tap][tap column][half]; tap row 2 = tap row 0 + two halo rows (same parity, same swizzle term)
+  const unsigned lds0 = (unsigned)(uintptr_t)smem;
+  unsigned a_tab[2][3][2], b_tab[NF][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int p0 = g * 8 + h * 4 + (l15 >> 2);                      // pixel row of this lane's transposed read
+    const int ly = dTW.div(p0), lx = p0 - ly * TW;
+#pragma unroll
+    for (int ty = 0; ty < 2; ++ty)
+#pragma unroll
+      for (int tx = 0; tx < 3; ++tx) {
+        const int hy = ly + ty, hx = lx + tx;
+        const int f = ((hx >> 3) ^ (hy & ka.hymask)) & 1;
+        a_tab[ty][tx][h] = lds0 + (unsigned)((cfi >> 1) * xpl + (hy * HWc + hx) * 64 + ((((cfi & 1) ^ f)) << 5) + (l15 & 3) * 8);
+      }
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) {
+      const int nfg = wn * NF + nf;
+      const int fd = (p0 >> 3) & 1;
+      b_tab[nf][h] = lds0 + (unsigned)(CPT * xpl + (nfg >> 1) * 8192 + p0 * 64 + ((((nfg & 1) ^ fd)) << 5) + (l15 & 3) * 8);
+    }
+  }
+  const unsigned row2 = (unsigned)(2 * HWc * 64);
+
+  f32x4 acc[9][NF];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) acc[t][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // ---- staging ------------------------------------------------------------------------------------------------------
+  auto patch_origin = [&](int patch, int& b, int& oy0, int& ox0) {
+    const int q1 = dTX.div(patch);
+    const int tx = patch - q1 * ka.tilesX;
+    b = dTY.div(q1);
+    const int ty = q1 - b * ka.tilesY;
+    oy0 = ty * TH; ox0 = tx * TW;
+  };
+  auto issue_loads = [&](int patch, int stg) {
+    int b, oy0, ox0;
+    patch_origin(patch, b, oy0, ox0);
+    unsigned char* const sb = smem + stg * stage;
+#pragma unroll
+    for (int it = 0; it < XIT; ++it) {
+      const int v = it * 256 + tid;
+      const int R = v >> 2, s = v & 3;
+      const int hy = dHW.div(R), hx = R - hy * HWc;
+      const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+      const bool inr = v < ka.HPv * 4;
+      const bool ok = inr && (unsigned)iy < (unsigned)d.Hin && (unsigned)ix < (unsigned)d.Win;
+      const int f = ((hx >> 3) ^ (hy & ka.hymask)) & 1;
+      const uint32_t pix = (uint32_t)((b * d.Hin + iy) * d.Win + ix);
+      const uint32_t slb = (uint32_t)((s ^ (f << 1)) * 16);
+      if (it * 256 < ka.HPv * 4) {
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) {
+          if (!cvalid[c]) continue;
+          if (ok) glds16(sp[c], pix * cb[c] + slb, lds0 + (unsigned)(stg * stage + c * xpl + (it * 256 + wave * 64) * 16));
+          else if (inr) *(u32x4*)(sb + c * xpl + v * 16) = (u32x4){0u, 0u, 0u, 0u};
+        }
+      }
+    }
+    unsigned char* const db = sb + CPT * xpl;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int v = it * 256 + tid;
+      const int p = v >> 2, s = v & 3;
+      const int ly = dTW.div(p), lx = p - ly * TW;
+      const bool pv = p < P && oy0 + ly < d.Hout && ox0 + lx < d.Wout;
+      const uint32_t pix = (uint32_t)((b * d.Hout + oy0 + ly) * d.Wout + ox0 + lx);
+      const int sl = s ^ (((p >> 3) & 1) << 1);
+#pragma unroll
+      for (int j = 0; j < NPL; ++j) {
+        const int n = n0 + j * 32 + sl * 8;
+        if (pv && n < d.N) glds16(dyp, pix * dycb + (uint32_t)(n * 2), lds0 + (unsigned)(stg * stage + CPT * xpl + j * 8192 + (it * 256 + wave * 64) * 16));
+        else *(u32x4*)(db + j * 8192 + v * 16) = (u32x4){0u, 0u, 0u, 0u};
+      }
+    }
+  };
+  // AFF: relu(x * scale + shift) over the in-image positions of the landed X planes (padding stays zero: it applies AFTER the transform)
+  auto transform = [&](int patch, int stg) {
+    int b, oy0, ox0;
+    patch_origin(patch, b, oy0, ox0);
+    unsigned char* const sb = smem + stg * stage;
+    const int sl = tid & 3;
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+      if (!cvalid[c]) continue;
+      float sc[8], sh[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { sc[j] = aff_tab[(c * 32 + sl * 8 + j) * 2]; sh[j] = aff_tab[(c * 32 + sl * 8 + j) * 2 + 1]; }
+#pragma unroll
+      for (int it = 0; it < XIT; ++it) {
+        const int v = it * 256 + tid;
+        const int R = v >> 2;
+        const int hy = dHW.div(R), hx = R - hy * HWc;
+        const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+        if (v < ka.HPv * 4 && (unsigned)iy < (unsigned)d.Hin && (unsigned)ix < (unsigned)d.Win) {
+          const int f = ((hx >> 3) ^ (hy & ka.hymask)) & 1;
+          u32x4* q = (u32x4*)(sb + c * xpl + R * 64 + ((sl ^ (f << 1)) * 16));
+          float x[8];
+          vec_unpack<T>(*q, x);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            x[j] = x[j] * sc[j] + sh[j];
+            if (aff_relu) x[j] = fmaxf(x[j], 0.f);
+          }
+          *q = vec_pack<T>(x);
+        }
+      }
+    }
+  };
+
+  const int p_begin = split * ka.pps;
+  const int p_end = min(ka.patches, p_begin + ka.pps);
+  const bool mine = cvalid[cfi >> 1];                               // this wave's channel fragment exists
+  __syncthreads();                                                  // zero fill (and the affine table) visible
+  if (p_begin < p_end) issue_loads(p_begin, 0);
+  for (int patch = p_begin; patch < p_end; ++patch) {
+    const int stg = (patch - p_begin) & 1;
+    dma_wait();                                                     // this wave's DMA of stage `stg` has landed ...
+    __syncthreads();                                                // ... and everybody's; the other stage is free (its MFMAs are done)
+    if constexpr (AFF) {
+      transform(patch, stg);
+      __syncthreads();
+    }
+    if (patch + 1 < p_end) issue_loads(patch + 1, stg ^ 1);         // in flight during the MFMAs below
+    if (!mine) continue;
+    const unsigned so = (unsigned)(stg * stage);
+    // flat (k-step, tap) sequence with the NEXT tap's X fragment requested before the MFMAs of the current one
+    u32x4 af = tr_frag(a_tab[0][0][0] + so, a_tab[0][0][1] + so);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const unsigned ao = so + (unsigned)(ks * ka.kstride), bo = so + (unsigned)(ks * 2048);
+      u32x4 bf[NF];
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) bf[nf] = tr_frag(b_tab[nf][0] + bo, b_tab[nf][1] + bo);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        u32x4 afn = af;
+        if (t + 1 < 9 || ks + 1 < 4) {
+          const int t1 = (t + 1) % 9;
+          const int ty = t1 / 3, tx = t1 % 3;
+          const unsigned o = (t + 1 < 9 ? ao : ao + (unsigned)ka.kstride) + (ty == 2 ? row2 : 0u);
+          afn = tr_frag(a_tab[ty & 1][tx][0] + o, a_tab[ty & 1][tx][1] + o);
+        }
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) mma16<T>(acc[t][nf], af, bf[nf]);
+        af = afn;
+      }
+    }
+  }
+  if (!mine) return;
+  // ---- partial slab [split][tap][K][Npad]: row = channel (g*4 + r of the fragment), column = n (l15) ----------------
+  const int Npad = (d.N + 15) & ~15;
+  const int Ktot = d.nchunks * 32;
+  const int krow0 = (kt * CPT + (cfi >> 1)) * 32 + (cfi & 1) * 16 + g * 4;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) {
+      const int n = n0 + (wn * NF + nf) * 16 + l15;
+      if (n >= Npad) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        d.partial[(((size_t)split * 9 + t) * Ktot + krow0 + r) * Npad + n] = acc[t][nf][r];
+    }
+}
+
+}  // namespace
+
+// ---- host side --------------------------------------------------------------------------------------------------------
+bool ksmi_wgrad3_geom(const ksmi_wgrad_desc* d, int dtype, ksmi_wgrad3_geom_t* g) {
+  static const bool off = getenv("KSMI_WGRAD3_OFF") != nullptr;
+  if (off || dtype != KSMI_BF16) return false;
+  if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || (d->pad_x_set && d->pad_x != 1) || d->in_sy != 0 || d->use_tap_off) return false;
+  if (d->Hin != d->Hout || d->Win != d->Wout || (d->N % 8) != 0 || d->N < 16) return false;
+  for (int i = 0; i < d->nsrc; ++i) {
+    if (d->src[i].c_len % 32) return false;
+    if (d->src[i].scale && (i > 0 || d->nsrc != 1)) return false;
+    if ((size_t)d->B * d->Hin * d->Win * (size_t)d->src[i].C * 2 >= ((size_t)1 << 32)) return false;
+  }
+  if ((size_t)d->B * d->Hout * d->Wout * (size_t)d->dyC * 2 >= ((size_t)1 << 32)) return false;
+  if (d->uniform_kc) { if (d->uniform_kc != 32 || d->k_total != d->nchunks * 32) return false; }
+  else for (int i = 0; i < d->nchunks; ++i) if (d->k_len[i] != 32) return false;
+  // patch: width 8 / 16 / 32, at most 128 pixels; fewest patches, then smallest halo
+  const int H = d->Hout, W = d->Wout;
+  long best = -1;
+  for (int tw = 8; tw <= 32; tw *= 2) {
+    const int thmax = 128 / tw;
+    const int tilesX = (W + tw - 1) / tw;
+    const int tilesY0 = (H + thmax - 1) / thmax;
+    const int th = (H + tilesY0 - 1) / tilesY0;                    // smallest patch height with the same number of patch rows
+    const int hwc = (tw < W ? tw : W) + 2;
+    const long key = (long)tilesX * tilesY0 * 100000 + (long)(thmax + 2) * hwc;
+    if ((thmax + 2) * hwc > 256) continue;
+    if (best < 0 || key <= best) { best = key;   // ties: the wider patch (longer contiguous rows)
+      g->TW = tw; g->TH = th; g->HWc = hwc; g->tilesX = tilesX; g->tilesY = tilesY0; }
+  }
+  if (best < 0) return false;
+  const int npad = (d->N + 15) & ~15;
+  // tile: one chunk -> 32 channels (2 x 2 waves), else 64 channels (4 x 1 waves); 64 columns when there are at least 48
+  g->WC = d->nchunks == 1 ? 2 : 4;
+  g->NTL = npad >= 48 ? 64 : 32;
+  g->KT = (d->nchunks + g->WC / 2 - 1) / (g->WC / 2);
+  g->NTt = (npad + g->NTL - 1) / g->NTL;
+  g->patches = d->B * g->tilesX * g->tilesY;
+  static const int wg_target = getenv("KSMI_WGRAD3_WGS") ? atoi(getenv("KSMI_WGRAD3_WGS")) : 512;
+  int want = wg_target / (g->KT * g->NTt);
+  if (want < 1) want = 1;
+  if (want > g->patches) want = g->patches;
+  g->pps = (g->patches + want - 1) / want;
+  g->nsplit = (g->patches + g->pps - 1) / g->pps;
+  const int hh_alloc = 128 / g->TW + 2;
+  g->xpl = hh_alloc * g->HWc * 64;
+  g->stage = (g->WC / 2) * g->xpl + (g->NTL / 32) * 8192;
+  g->lds = 2 * g->stage + 1024;                                    // slack: rows read (never used) past the last plane; AFF table
+  return g->lds <= 160 * 1024;
+}
+
+int ksmi_wgrad3_launch(const ksmi_wgrad_desc* d, const ksmi_wgrad3_geom_t* g, hipStream_t st) {
+  Wg3Args ka;
+  ka.d = *d;
+  ka.TH = g->TH; ka.TW = g->TW; ka.HWc = g->HWc; ka.HPv = (g->TH + 2) * g->HWc;
+  ka.xpl = g->xpl; ka.stage = g->stage;
+  ka.tilesX = g->tilesX; ka.tilesY = g->tilesY; ka.patches = g->patches; ka.pps = g->pps;
+  ka.KT = g->KT; ka.NTt = g->NTt;
+  ka.m_hw = fastdiv_magic(g->HWc); ka.m_tw = fastdiv_magic(g->TW); ka.m_tx = fastdiv_magic(g->tilesX); ka.m_ty = fastdiv_magic(g->tilesY);
+  ka.m_tiles = fastdiv_magic(g->KT * g->NTt); ka.m_ntt = fastdiv_magic(g->NTt);
+  ka.kstride = (32 / g->TW) * g->HWc * 64;
+  ka.hymask = g->TW == 8 ? 1 : 0;
+  ka.lds_bytes = (int)g->lds;
+  if ((size_t)g->patches * 1 >= ((size_t)1 << 31) / 1024) return ksmi_fail(KSMI_E_UNSUPPORTED, "wgrad3: too many patches");
+  const dim3 grid(g->nsplit * g->KT * g->NTt);
+  const bool aff = d->src[0].scale != nullptr;
+#define KSMI_W3(WC_, WN_, NF_)                                                                       \
+  do {                                                                                               \
+    if (aff) {                                                                                       \
+      auto kfn = wgrad3_kernel<WC_, WN_, NF_, true>;                                                 \
+      if (g->lds > 65536) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g->lds); \
+      hipLaunchKernelGGL(kfn, grid, dim3(256), g->lds, st, ka);                                      \
+    } else {                                                                                         \
+      auto kfn = wgrad3_kernel<WC_, WN_, NF_, false>;                                                \
+      if (g->lds > 65536) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g->lds); \
+      hipLaunchKernelGGL(kfn, grid, dim3(256), g->lds, st, ka);                                      \
+    }                                                                                                \
+  } while (0)
+  if (g->WC == 4 && g->NTL == 64) KSMI_W3(4, 1, 4);
+  else if (g->WC == 4) KSMI_W3(4, 1, 2);
+  else if (g->NTL == 64) KSMI_W3(2, 2, 2);
+  else KSMI_W3(2, 2, 1);
+#undef KSMI_W3
+  return ksmi_check_launch("wgrad3");
+}

@@ -145,6 +145,40 @@ def test_conv3x3_forward_dgrad_wgrad(dev, dtype, cfg):
     assert (dw - wr.grad).abs().max() < tol * wr.grad.abs().max()
 
 
+@pytest.mark.parametrize("cfg", [
+    dict(B=2, H=56, W=56, cs=[64], N=128),            # TW=8 patches, 64-column tiles, several splits
+    dict(B=3, H=28, W=28, cs=[128, 32], N=64),        # TW=32 patches with masked columns, odd chunk count
+    dict(B=2, H=14, W=14, cs=[256], N=512),           # 14x14 maps, 8 x 8 tiles
+    dict(B=1, H=112, W=112, cs=[32], N=64),           # single chunk: 2 x 2 wave layout, 64 columns
+    dict(B=1, H=224, W=224, cs=[32, 32, 64, 32], N=32),   # level-0 shape: virtual concat, 32 columns
+    dict(B=2, H=33, W=19, cs=[64, 32], N=48),         # ragged map, N not a multiple of 32
+    dict(B=1, H=40, W=72, cs=[32], N=32, aff=True),   # fused BN-apply + ReLU operand transformed in LDS
+    dict(B=2, H=28, W=28, cs=[64], N=64, aff=True),
+])
+def test_wgrad3_channel_owner_kernel(dev, cfg):
+    """csrc/wgrad3.hip (bf16 3x3 s1 weight gradient, channel-owner tiling) vs F.conv2d's weight gradient on CPU."""
+    from kurosiwo_amd import functional as Fk
+    dtype = torch.bfloat16
+    B, H, W, cs, N = cfg["B"], cfg["H"], cfg["W"], cfg["cs"], cfg["N"]
+    tag = f"wg3{B}{H}{W}{cs}{N}"
+    xs = [seeded_tensor(f"{tag}.x{i}", (B, c, H, W)) for i, c in enumerate(cs)]
+    dy = seeded_tensor(tag + ".dy", (B, N, H, W))
+    q = (lambda t: t.to(dtype).float())
+    K = sum(cs)
+    aff = None
+    xq = torch.cat([q(x) for x in xs], 1)
+    if cfg.get("aff"):
+        sc, sh = 1.0 + 0.3 * seeded_tensor(tag + ".sc", (K,)), 0.2 * seeded_tensor(tag + ".sh", (K,))
+        xq = q(torch.relu(xq * sc[None, :, None, None] + sh[None, :, None, None]))
+        aff = (sc.to(dev), sh.to(dev), 1)
+    wr = torch.zeros((N, K, 3, 3)).requires_grad_(True)
+    F.conv2d(xq, wr, None, padding=1).backward(q(dy))
+    xd = [Fk.to_nhwc(x.to(dev), dtype) for x in xs]
+    dw = Fk.conv3x3_wgrad(xd, Fk.to_nhwc(dy.to(dev), dtype), affine=aff).cpu()
+    err = float((dw - wr.grad).abs().max() / wr.grad.abs().max())
+    assert err < 2e-3, err            # operands are identical bf16 values; fp32 accumulation order differs
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_conv3x3_fused_affine_relu_operand(dev, dtype):
     from kurosiwo_amd import functional as Fk
