@@ -805,10 +805,7 @@ int launch_wgrad(const ksmi_wgrad_desc* d, hipStream_t st) {
   if (g.v3) {
     int rc3 = ksmi_wgrad3_launch(d, &g.g3, st);
     if (rc3) return rc3;
-    const size_t total3 = (size_t)g.taps * d->nchunks * g.kc * g.npad;
-    int blocks3 = (int)((total3 * 8 + 255) / 256); if (blocks3 > 4096) blocks3 = 4096;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks3), dim3(256), 0, st, *d, g.taps, g.kc);
-    return ksmi_check_launch("wgrad_reduce");
+    return ksmi_wgrad3_reduce(d, &g.g3, st);
   }
   if (g.tn) {
     // plain row-major nn.Linear gradient (unit K stride, one tap at offset 0, contiguous k rows): large problems go to hipBLASLt

@@ -14,3 +14,4 @@ struct ksmi_wgrad3_geom_t {
 // false: the descriptor does not qualify (the caller uses igemm_wgrad_kernel)
 bool ksmi_wgrad3_geom(const ksmi_wgrad_desc* d, int dtype, ksmi_wgrad3_geom_t* g);
 int ksmi_wgrad3_launch(const ksmi_wgrad_desc* d, const ksmi_wgrad3_geom_t* g, hipStream_t st);
+int ksmi_wgrad3_reduce(const ksmi_wgrad_desc* d, const ksmi_wgrad3_geom_t* g, hipStream_t st);   // slabs -> fp32 gradient

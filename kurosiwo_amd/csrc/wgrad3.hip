@@ -295,6 +295,49 @@ __global__ __launch_bounds__(256, 2) void wgrad3_kernel(const Wg3Args ka) {
     }
 }
 
+// Sum of the split slabs + scatter into the fp32 gradient (fixed summation tree => deterministic).  A block owns 16 float4
+// (256 contiguous bytes of a slab) x 16 slab lanes: every wave instruction reads four 256-byte runs; slab lane sl walks slabs
+// sl, sl + 16, ...; the 16 lanes of an element are combined by two shuffles (inside a wave) and one LDS step (across the waves).
+__global__ __launch_bounds__(256) void wgrad3_reduce_kernel(const ksmi_wgrad_desc d, int nsplit) {
+  __shared__ f32x4 red[4][16];
+  const int Npad = (d.N + 15) & ~15;
+  const int Ktot = d.nchunks * 32;
+  const size_t total4 = (size_t)9 * Ktot * Npad / 4;
+  const int tid = threadIdx.x, e = tid & 15, sl = tid >> 4;
+  const size_t i4 = (size_t)blockIdx.x * 16 + e;
+  f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+  if (i4 < total4) {
+    const f32x4* p = (const f32x4*)d.partial + i4;
+    int sp = sl;
+    for (; sp + 16 < nsplit; sp += 32) { a0 += p[(size_t)sp * total4]; a1 += p[(size_t)(sp + 16) * total4]; }
+    if (sp < nsplit) a0 += p[(size_t)sp * total4];
+  }
+  f32x4 s = a0 + a1;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    s[j] += __shfl_xor(s[j], 16, 64);
+    s[j] += __shfl_xor(s[j], 32, 64);
+  }
+  if ((tid & 63) < 16) red[tid >> 6][e] = s;
+  __syncthreads();
+  if (tid < 16 && i4 < total4) {
+    const f32x4 v = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+    const size_t i = i4 * 4;
+    const int n = (int)(i % Npad);
+    const size_t r = i / Npad;
+    const int krow = (int)(r % Ktot), t = (int)(r / Ktot);
+    const int ch = krow >> 5;
+    const int64_t k = (d.uniform_kc ? ch * d.uniform_kc : d.k_off[ch]) + (krow & 31);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (n + j < d.N) {
+        float* gp = d.grad + k * d.gK + (int64_t)(n + j) * d.gN + (int64_t)t * d.gT;
+        *gp = d.accumulate ? (*gp + v[j]) : v[j];
+      }
+    }
+  }
+}
+
 }  // namespace
 
 // ---- host side --------------------------------------------------------------------------------------------------------
@@ -333,17 +376,49 @@ bool ksmi_wgrad3_geom(const ksmi_wgrad_desc* d, int dtype, ksmi_wgrad3_geom_t* g
   g->KT = (d->nchunks + g->WC / 2 - 1) / (g->WC / 2);
   g->NTt = (npad + g->NTL - 1) / g->NTL;
   g->patches = d->B * g->tilesX * g->tilesY;
-  static const int wg_target = getenv("KSMI_WGRAD3_WGS") ? atoi(getenv("KSMI_WGRAD3_WGS")) : 512;
-  int want = wg_target / (g->KT * g->NTt);
-  if (want < 1) want = 1;
-  if (want > g->patches) want = g->patches;
-  g->pps = (g->patches + want - 1) / want;
-  g->nsplit = (g->patches + g->pps - 1) / g->pps;
   const int hh_alloc = 128 / g->TW + 2;
   g->xpl = hh_alloc * g->HWc * 64;
   g->stage = (g->WC / 2) * g->xpl + (g->NTL / 32) * 8192;
-  g->lds = 2 * g->stage + 1024;                                    // slack: rows read (never used) past the last plane; AFF table
-  return g->lds <= 160 * 1024;
+  g->lds = 2 * g->stage + 1024;                                    // slack: AFF table
+  if (g->lds > 160 * 1024) return false;
+  // number of workgroups: every workgroup dumps its 9 x CT x NTL fp32 tile once, so small gradients pay for many splits in slab
+  // traffic (K = N = 64 at 512 workgroups: 75 MB of slabs against 103 MB of operands), while too few workgroups cannot keep
+  // HBM busy (one stage in flight each).  Pick the count that minimises, in microseconds with coarse measured constants,
+  //   max(MFMA time, operand bytes / min(4.5 TB/s, workgroups x stage / 5 us)) + slab write + slab read.
+  static const int wg_force = getenv("KSMI_WGRAD3_WGS") ? atoi(getenv("KSMI_WGRAD3_WGS")) : 0;
+  const int tiles = g->KT * g->NTt;
+  const int nfw = (g->NTL / 16) / (4 / g->WC);                      // column fragments per wave
+  const double t_patch = 4.0 * 9.0 * nfw * 16.0 / 2100.0;           // one 128-pixel patch on one wave at the MFMA rate
+  const double tile_mb = 9.0 * (g->WC * 16) * g->NTL * 4.0 / 1e6;
+  const double op_bytes = (double)d->B * H * W * (d->nchunks * 32.0 + npad) * 2.0;
+  const int max_per_cu = (int)(160 * 1024 / g->lds) < 4 ? (int)(160 * 1024 / g->lds) : 4;
+  static const double eff[5] = {0.0, 0.55, 0.8, 0.85, 0.9};         // MFMA-phase efficiency by workgroups per CU (DMA waits overlap)
+  double best_t = 1e30;
+  static const int cand[] = {128, 192, 256, 384, 512, 768, 1024};
+  for (int ci = 0; ci < 7; ++ci) {
+    const int wg = wg_force ? wg_force : cand[ci];
+    if (wg > 256 * max_per_cu && !wg_force) break;
+    int want = wg / tiles;
+    if (want < 1) want = 1;
+    if (want > g->patches) want = g->patches;
+    const int pps = (g->patches + want - 1) / want;
+    const int ns = (g->patches + pps - 1) / pps;
+    int per_cu = (ns * tiles + 255) / 256;
+    if (per_cu > 4) per_cu = 4;
+    double t_main = pps * t_patch * per_cu / eff[per_cu];
+    double bw = (double)ns * tiles * g->stage / 5.0;                 // bytes per microsecond in flight
+    if (bw > 4.5e6) bw = 4.5e6;
+    if (t_main < op_bytes / bw) t_main = op_bytes / bw;
+    const double t = t_main + 7.0 + 2.0 * ns * tiles * tile_mb / 4.0;
+    if (t < best_t) { best_t = t; g->pps = pps; g->nsplit = ns; }
+  }
+  return true;
+}
+
+int ksmi_wgrad3_reduce(const ksmi_wgrad_desc* d, const ksmi_wgrad3_geom_t* g, hipStream_t st) {
+  const size_t total4 = (size_t)9 * d->nchunks * 32 * ((d->N + 15) & ~15) / 4;
+  hipLaunchKernelGGL(wgrad3_reduce_kernel, dim3((unsigned)((total4 + 15) / 16)), dim3(256), 0, st, *d, g->nsplit);
+  return ksmi_check_launch("wgrad3_reduce");
 }
 
 int ksmi_wgrad3_launch(const ksmi_wgrad_desc* d, const ksmi_wgrad3_geom_t* g, hipStream_t st) {
