@@ -194,6 +194,18 @@ int ksmi_bnrelu_bwd_reduce(const void* dout, const void* out, const void* z, con
  * dgamma (+)= sums[1], dbeta (+)= sums[0] */
 int ksmi_reduce_rows(const float* partial, int rows, int K, int Cstride, int C, float* sums,
                      float* dgamma, float* dbeta, int accumulate, void* stream);
+/* Deferred row reductions of a whole backward pass in ONE launch (parameter gradients nobody waits for: conv / deconv bias
+ * gradients, models/snunet.py:15-17,41): entry e sums partial[(r*K + k)*Cstride + c] over its rows (fp64, fixed order) into
+ * dst[c] (+= if accumulate); rows == 0 contributes nothing (a bias followed by a train-mode BatchNorm gets exact zeros).
+ * Entries sharing one dst (a module called twice: the siamese encoder blocks) form a chain: `head` = 1 on the first, `next` =
+ * index of the following entry or -1; the head's block sums the whole chain.  n descriptors in DEVICE memory. */
+typedef struct ksmi_rowsum_desc {
+  const float* partial;
+  float* dst;
+  int32_t rows, K, k, Cstride, C, accumulate;
+  int32_t head, next;
+} ksmi_rowsum_desc;
+int ksmi_reduce_rows_batched(const ksmi_rowsum_desc* descs_device, int n, void* stream);
 /* pass 2: g = dout*(out>0) -> dout (in place); dz = gamma*rstd*(g - s0/n - zhat*s1/n) */
 int ksmi_bnrelu_bwd_apply(void* dout_g, const void* out, const void* z, const float* mean, const float* rstd,
                           const float* gamma, const float* sums, void* dz, double count,

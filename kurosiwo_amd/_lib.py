@@ -54,6 +54,11 @@ class PackDesc(C.Structure):
                 ("use_tap_map", C.c_int32), ("tap_map", C.c_int32 * 16), ("uniform_kc", C.c_int32), ("k_total", C.c_int32)]
 
 
+class RowsumDesc(C.Structure):
+    _fields_ = [("partial", C.c_void_p), ("dst", C.c_void_p), ("rows", C.c_int32), ("K", C.c_int32), ("k", C.c_int32),
+                ("Cstride", C.c_int32), ("C", C.c_int32), ("accumulate", C.c_int32), ("head", C.c_int32), ("next", C.c_int32)]
+
+
 class WgradDesc(C.Structure):
     _fields_ = [("src", Src * MAX_SRC), ("nsrc", C.c_int32),
                 ("dy", C.c_void_p), ("dyC", C.c_int32), ("dy_c_off", C.c_int32),
@@ -92,6 +97,7 @@ SIGNATURES = {
     "ksmi_bn_add_relu": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp]),
     "ksmi_bnrelu_bwd_reduce": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp]),
     "ksmi_reduce_rows": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp]),
+    "ksmi_reduce_rows_batched": (_i, [_vp, _i, _vp]),
     "ksmi_bnrelu_bwd_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _i64, _i, _i, _vp]),
     "ksmi_bn_bwd_apply_add": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _d, _i64, _i, _i, _vp]),
     "ksmi_channel_sum": (_i, [_vp, _vp, _i, _i64, _i, _i, _vp]),

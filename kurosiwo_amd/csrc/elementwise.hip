@@ -143,6 +143,38 @@ __global__ void reduce_rows_kernel(const float* partial, int rows, int K, int Cs
   }
 }
 
+// all deferred row reductions of a step: block (entry, 16-channel group); 16 row lanes x 16 channel lanes, fp64, fixed order
+__global__ __launch_bounds__(256) void reduce_rows_batched_kernel(const ksmi_rowsum_desc* descs) {
+  __shared__ double red[16][17];
+  const ksmi_rowsum_desc d0 = descs[blockIdx.x];
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = blockIdx.y * 16 + cl;
+  if (!d0.head || blockIdx.y * 16 >= d0.C) return;
+  double s = 0.0;
+  int e = blockIdx.x;
+  while (e >= 0) {                                   // the chain of entries writing this destination, in order
+    const ksmi_rowsum_desc d = descs[e];
+    if (c < d.C) {
+      double sa = 0.0, sb = 0.0;
+      int r = rl;
+      for (; r + 16 < d.rows; r += 32) {
+        sa += (double)d.partial[((size_t)r * d.K + d.k) * d.Cstride + c];
+        sb += (double)d.partial[((size_t)(r + 16) * d.K + d.k) * d.Cstride + c];
+      }
+      if (r < d.rows) sa += (double)d.partial[((size_t)r * d.K + d.k) * d.Cstride + c];
+      s += sa + sb;
+    }
+    e = d.next;
+  }
+  red[rl][cl] = s;
+  __syncthreads();
+  if (threadIdx.x < 16 && c < d0.C) {
+    s = 0.0;
+    for (int r = 0; r < 16; ++r) s += red[r][cl];
+    d0.dst[c] = d0.accumulate ? d0.dst[c] + (float)s : (float)s;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // elementwise glue
 // ------------------------------------------------------------------------------------------------
@@ -716,6 +748,12 @@ int ksmi_reduce_rows(const float* partial, int rows, int K, int Cstride, int C, 
   hipLaunchKernelGGL(reduce_rows_kernel, dim3((C + 15) / 16), dim3(1024), 0, (hipStream_t)stream, partial, rows, K, Cstride, C, sums,
                      dgamma, dbeta, accumulate);
   return ksmi_check_launch("reduce_rows");
+}
+
+int ksmi_reduce_rows_batched(const ksmi_rowsum_desc* descs_device, int n, void* stream) {
+  if (!descs_device || n < 1) return ksmi_fail(KSMI_E_ARG, "reduce_rows_batched: bad args");
+  hipLaunchKernelGGL(reduce_rows_batched_kernel, dim3(n, 32), dim3(256), 0, (hipStream_t)stream, descs_device);   // up to 512 channels
+  return ksmi_check_launch("reduce_rows_batched");
 }
 
 int ksmi_bn_add_relu(const void* z, const void* identity, const float* scale, const float* shift, void* out, int64_t npix,

@@ -66,6 +66,7 @@ class SNUNetPlan:
         self._pack_descs = []      # every weight-pack descriptor of the plan -> ONE batched launch per step
         self.param_ready = {}      # parameter key -> index of the last backward launch writing its gradient
         self._need, self._bufs, self._later = {}, {}, []
+        self._rowsums = []         # deferred row reductions (bias gradients): (RowsumDesc, parameter key) -> ONE launch ending the backward
         n, c = model.base_channel, model.in_channels
         self.n = n
         f = [n, 2 * n, 4 * n, 8 * n, 16 * n]
@@ -105,6 +106,15 @@ class SNUNetPlan:
         if with_backward:
             for build in reversed(self.bwd_builders):
                 build()
+            if self._rowsums:
+                import ctypes
+                nr = len(self._rowsums)
+                arr_r = (_lib.RowsumDesc * nr)(*[r for r, _ in self._rowsums])
+                raw_r = bytes(ctypes.string_at(ctypes.addressof(arr_r), ctypes.sizeof(arr_r)))
+                rtable = torch.frombuffer(bytearray(raw_r), dtype=torch.uint8).to(self.dev)
+                self.keep.append(rtable)
+                self.bwd.add("ksmi_reduce_rows_batched", lambda: (rtable.data_ptr(), nr))
+                self._mark(*[k for _, k in self._rowsums])
         # all weight packs of the step as one launch over a device-resident descriptor table
         if self._pack_descs:
             import ctypes
@@ -153,6 +163,20 @@ class SNUNetPlan:
         for k in keys:
             self.param_ready[k] = len(self.bwd.pending) - 1
 
+    def _defer_rowsum(self, key, partial, rows, K, k, Cstride, Cc):
+        """grad[key][c] (+)= sum_rows partial[(r*K + k)*Cstride + c] in the batched launch that ends the backward; partial = None: zeros"""
+        r = _lib.RowsumDesc()
+        r.partial = partial.data_ptr() if partial is not None else None
+        r.dst = self.m._g(key).data_ptr()
+        r.rows, r.K, r.k, r.Cstride, r.C = (rows if partial is not None else 0), K, k, Cstride, Cc
+        r.accumulate, r.head, r.next = 0, 1, -1
+        if self._acc_param(key):                      # a second call of the same module (siamese branches): chain behind the first entry
+            prev = [q for q, kk in self._rowsums if kk == key][-1]
+            prev.next, r.head = len(self._rowsums), 0
+        if partial is not None:
+            self.keep.append(partial)
+        self._rowsums.append((r, key))
+
     def _es(self):
         return 2 if self.dtype == torch.bfloat16 else 4
 
@@ -184,7 +208,7 @@ class SNUNetPlan:
         self._mark(*keys)
 
     # ---------------------------------------------------------------- "virtual sum" input gradient
-    def _emit_dgrad(self, act):
+    def _emit_dgrad(self, act, bias_key=None):
         """d act = sum over the 3x3 convs that read `act` of convT(di_j, W_j[:, slice_j]) as ONE implicit GEMM
         whose K axis walks the consumers' `di` tensors (the dual of the forward's virtual concat): every
         gradient tensor is written once instead of read-modify-written per consumer, and K grows from
@@ -192,7 +216,7 @@ class SNUNetPlan:
         backward order)."""
         cons = getattr(act, "consumers", [])
         if not cons:
-            return
+            return False
         B, H, W, Cc = act.B, act.H, act.W, act.C
         srcs = [SrcSpec(r, cj) for (r, cj, _, _, _) in cons]
         acc = act.take_acc_flag()
@@ -214,7 +238,15 @@ class SNUNetPlan:
             ch0 += nch
         d.wpk = wpk.data_ptr()
         self.keep.append(wpk)
+        if bias_key is not None:
+            # `act` is the output of a ConvTranspose2d whose bias gradient is sum_pixels d act: the statistics epilogue of this launch
+            # emits the per-tile sums (was: one more pass over the gradient tensor, ksmi_channel_sum)
+            rows_g = conv_grid_m(d)
+            st = torch.empty(rows_g * 2 * Npad, dtype=torch.float32, device=self.dev)
+            d.stats = st.data_ptr()
+            self._defer_rowsum(bias_key, st, rows_g, 2, 0, Npad, Cc)
         self._conv(self.bwd, d, "dgrad")
+        return True
 
     # ---------------------------------------------------------------- nn.MaxPool2d(2,2)  (snunet.py:73)
     def _pool(self, x, name):
@@ -243,7 +275,7 @@ class SNUNetPlan:
         self._conv(self.fwd, d)
 
         def build_bwd():
-            self._emit_dgrad(y)
+            fused_bias = self._emit_dgrad(y, bias_key=bkey)
             gy = y.grad()
             s2 = [SrcSpec(gy, Cc)]
             acc = x.take_acc_flag()
@@ -257,15 +289,12 @@ class SNUNetPlan:
             dw, ws = make_wgrad(s2, x.t, Cc, 0, Cc, self.m._g(wkey), 4, Cc * 4, 1, self._acc_param(wkey),
                                 B, 2 * H, 2 * W, H, W, 2, 2, 2, 0, self.dtype)
             self._wgrad(dw, ws, wkey)
-            # bias gradient
-            npix = B * 4 * H * W
-            rows = self._rows(npix)
-            self.need("red", rows * Cc * 4)
-            a_b = self._acc_param(bkey)
-            gb = self.m._g(bkey).data_ptr()
-            self.bwd.add("ksmi_channel_sum", lambda: (gy.data_ptr(), self.scr("red"), rows, npix, Cc, self.dt))
-            self.bwd.add("ksmi_reduce_rows", lambda: (self.scr("red"), rows, 1, Cc, Cc, None, None, gb, a_b))
-            self._mark(bkey)
+            if not fused_bias:                                      # (no 3x3 consumer: separate pass over the gradient)
+                npix = B * 4 * H * W
+                rows = self._rows(npix)
+                pb = torch.empty(rows * Cc, dtype=torch.float32, device=self.dev)
+                self.bwd.add("ksmi_channel_sum", lambda: (gy.data_ptr(), pb.data_ptr(), rows, npix, Cc, self.dt))
+                self._defer_rowsum(bkey, pb, rows, 1, 0, Cc, Cc)
         self.bwd_builders.append(build_bwd)
         return y
 
@@ -359,13 +388,12 @@ class SNUNetPlan:
                                                            P("bn2.weight"), s2p, dz.data_ptr(), float(npix), npix, Cc, dt))
             # conv2.bias feeds a train-mode BatchNorm: its gradient sum(dz) is analytically 0 (the reference holds
             # ~1e-6 of rounding noise there); write exact zeros instead of two reduction launches.
-            self._acc_param(f"{name}.conv2.bias")
             if training:
-                self.bwd.add("ksmi_fill_zero", lambda: (G("conv2.bias"), Cc * 4))
+                self._defer_rowsum(f"{name}.conv2.bias", None, 0, 1, 0, Cc, Cc)
             else:                                                   # eval-mode BN: d bias = sum(dz)
-                self.bwd.add("ksmi_channel_sum", lambda: (dz.data_ptr(), self.scr("red"), rows, npix, Cc, dt))
-                self.bwd.add("ksmi_reduce_rows", lambda: (self.scr("red"), rows, 1, Cc, Cc, None, None, G("conv2.bias"), 0))
-            self._mark(f"{name}.conv2.bias")
+                pz = torch.empty(rows * Cc, dtype=torch.float32, device=self.dev)
+                self.bwd.add("ksmi_channel_sum", lambda: (dz.data_ptr(), pz.data_ptr(), rows, npix, Cc, dt))
+                self._defer_rowsum(f"{name}.conv2.bias", pz, rows, 1, 0, Cc, Cc)
             # dgrad of conv2 with fused ReLU mask + BN1-backward statistics in the epilogue
             dg2, tg2 = make_conv([SrcSpec(dz, Cc)], [(r, Cc, 0, 0, Cc, 0)], dz, None, None, B, H, W, H, W, 3, 3, 1, 1, Cc, dtype,
                                  mask=(i_act.t, sv1.t[0], sv1.t[1], sv1.t[2], sv1.t[3]))
@@ -383,11 +411,10 @@ class SNUNetPlan:
                                   self._acc_param(f"{name}.conv2.weight"), B, H, W, H, W, 3, 3, 1, 1, dtype)
             self._wgrad(dw2, ws2, f"{name}.conv2.weight")
             # di = g + BN1 backward (over r, in place); conv1 bias gradient
-            a_c1b = self._acc_param(f"{name}.conv1.bias")
+            pb1 = torch.empty(rows * Cc, dtype=torch.float32, device=self.dev)      # per-block partial sums of di (conv1 bias gradient)
             self.bwd.add("ksmi_bn_bwd_apply_add", lambda: (r.data_ptr(), gout, i_act.t.data_ptr(), sv1.mean, sv1.rstd,
-                                                           P("bn1.weight"), s1p, self.scr("red"), rows, float(npix), npix, Cc, dt))
-            self.bwd.add("ksmi_reduce_rows", lambda: (self.scr("red"), rows, 1, Cc, Cc, None, None, G("conv1.bias"), a_c1b))
-            self._mark(f"{name}.conv1.bias")
+                                                           P("bn1.weight"), s1p, pb1.data_ptr(), rows, float(npix), npix, Cc, dt))
+            self._defer_rowsum(f"{name}.conv1.bias", pb1, rows, 1, 0, Cc, Cc)
             a_w1 = self._acc_param(f"{name}.conv1.weight")
             if first:
                 # dW[n][c*9+t] = sum_px im2col[px][c*9+t] * di[px][n]  (1x1 weight-gradient GEMM over the saved im2col)
