@@ -104,10 +104,16 @@ typedef struct ksmi_conv_desc {
   int32_t relu_out;
   int32_t residC;
   const void* resid;
+  /* rows of `stats` the caller allocated, as returned by ksmi_conv_stats_rows (0: one row per M-tile = ksmi_conv_grid_m, the only
+   * layout of the non-persistent kernels).  Short-K bf16 convolutions run on persistent workgroups (csrc/igemm3.hip) that emit one
+   * row per workgroup; that kernel is only chosen for a descriptor with statistics when stats_rows announces its row count. */
+  int32_t stats_rows;
 } ksmi_conv_desc;
 
-/* number of M-tiles (= rows of `stats`) a descriptor launches */
+/* number of M-tiles (= rows of `stats` when stats_rows == 0) a descriptor launches */
 int ksmi_conv_grid_m(const ksmi_conv_desc* d);
+/* rows of `stats` ksmi_conv_forward(d, dtype) will write when d->stats_rows is set to the returned value */
+int ksmi_conv_stats_rows(const ksmi_conv_desc* d, int dtype);
 int ksmi_conv_forward(const ksmi_conv_desc* d, int dtype, void* stream);
 
 /* Weight packing fp32 parameter -> `dtype` [nchunks][taps][Npad][chunk_elems].

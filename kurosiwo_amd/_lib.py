@@ -42,7 +42,7 @@ class ConvDesc(C.Structure):
                 ("out_ox", C.c_int32), ("out_H", C.c_int32), ("out_W", C.c_int32),
                 ("uniform_kc", C.c_int32), ("in_sy", C.c_int32), ("in_sx", C.c_int32), ("in_oy", C.c_int32), ("in_ox", C.c_int32),
                 ("in_H", C.c_int32), ("in_W", C.c_int32), ("alpha", C.c_float), ("relu_out", C.c_int32), ("residC", C.c_int32),
-                ("resid", C.c_void_p)]
+                ("resid", C.c_void_p), ("stats_rows", C.c_int32)]
 
 
 class PackDesc(C.Structure):
@@ -88,6 +88,7 @@ SIGNATURES = {
     "ksmi_pack_weights_batched": (_i, [_vp, _i, _i, _vp]),
     "ksmi_conv_wgrad_workspace": (_sz, [C.POINTER(WgradDesc), _i]),
     "ksmi_conv_wgrad": (_i, [C.POINTER(WgradDesc), _i, _vp]),
+    "ksmi_conv_stats_rows": (_i, [C.POINTER(ConvDesc), _i]),
     "ksmi_conv_first_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ksmi_conv_first_stats_rows": (_i, [_i, _i, _i]),
     "ksmi_im2col3x3": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

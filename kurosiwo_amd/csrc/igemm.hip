@@ -12,6 +12,7 @@
 #include "errors.h"
 #include "igemm_epilogue.h"
 #include "wgrad3.h"
+#include "igemm3.h"
 
 namespace {
 
@@ -885,12 +886,28 @@ int ksmi_conv_grid_m(const ksmi_conv_desc* d) {
   return d->B * tilesX * tilesY;
 }
 
+int ksmi_conv_stats_rows(const ksmi_conv_desc* d, int dtype) {
+  if (!d) return 0;
+  ksmi_conv_desc c = *d;
+  if (!c.stats) c.stats = (float*)(uintptr_t)16;     // the answer is for the launch WITH statistics
+  ksmi_igemm3_geom_t g3;
+  if (ksmi_igemm3_geom(&c, dtype, &g3)) return g3.gx;
+  return ksmi_conv_grid_m(d);
+}
+
 int ksmi_conv_forward(const ksmi_conv_desc* d, int dtype, void* stream) {
   if (!d || d->nsrc < 1 || d->nsrc > KSMI_MAX_SRC || d->ndst < 1 || d->ndst > KSMI_MAX_SRC || d->nchunks < 1 ||
       (d->nchunks > KSMI_MAX_CHUNKS && !(d->uniform_kc && d->nsrc == 1)))
     return ksmi_fail(KSMI_E_ARG, "conv: bad descriptor");
   if (dtype != KSMI_BF16 && dtype != KSMI_F32) return ksmi_fail(KSMI_E_ARG, "conv: bad dtype");
   static const bool force_v1 = getenv("KSMI_IGEMM_V1") != nullptr;      // A/B switch for profiling
+  {   // short K, bf16: persistent workgroups with register-resident weights (its statistics rows = workgroups, not tiles)
+    ksmi_igemm3_geom_t g3;
+    if (!force_v1 && ksmi_igemm3_geom(d, dtype, &g3) && (d->stats == nullptr || d->stats_rows == g3.gx))
+      return ksmi_igemm3_launch(d, &g3, (hipStream_t)stream);
+  }
+  if (d->stats && d->stats_rows != 0 && d->stats_rows != ksmi_conv_grid_m(d))
+    return ksmi_fail(KSMI_E_ARG, "conv: stats_rows does not match the kernel this descriptor runs on (set it from ksmi_conv_stats_rows)");
   if (!force_v1 && ksmi_igemm2_eligible(d, dtype)) return ksmi_igemm2_launch(d, dtype, (hipStream_t)stream);
   if (d->alpha != 0.f || d->resid || d->relu_out || d->uniform_kc)
     return ksmi_fail(KSMI_E_UNSUPPORTED, "conv: alpha/resid/relu_out/uniform chunks need whole-chunk sources (igemm2 path)");

@@ -1,0 +1,419 @@
+// Implicit-GEMM convolution for SHORT K (<= 8 k-chunks x taps <= 18 weight fragments per column fragment), bf16:
+// persistent workgroups with the weights held in REGISTERS.
+//
+// The layers this serves are bandwidth- or latency-bound, not MFMA-bound (SNUNet: conv2 / conv1 of the 32- and 64-channel levels,
+// ConvTranspose2d k2 s2 forward as a 1x1 GEMM over 4C columns, its input gradient as a 2x2 stride-2 convolution): in igemm2.hip a
+// workgroup of such a layer is one dependent chain (tables -> DMA wait -> 72..144 MFMAs -> epilogue) and re-fetches its weight slab
+// per k-chunk.  Here a workgroup
+//   * loads the weight fragments of its column tile ONCE into VGPRs (MFMA A operand, swapped-operand orientation of igemm2),
+//   * walks pixel tiles t = blockIdx.x, blockIdx.x + gridDim.x, ... with the halo image of tile i+1 in flight (LDS-DMA, two
+//     stages) while the MFMAs and the epilogue stores of tile i run,
+//   * issues the SAME number of DMA instructions for every tile: positions outside the image read a zero page instead of being
+//     exec-masked (zero padding without ds_write fills or per-tile zeroing),
+//   * keeps BatchNorm statistics in registers across its tiles: `stats` has one row per workgroup (ksmi_conv_stats_rows) instead
+//     of one per tile, so the finalize kernels need no folding pass.
+// A fused BN-apply + ReLU operand (conv2 reads relu(bn1(i)), models/snunet.py:24-25) is transformed in LDS after landing.
+// Epilogue = the lean epilogue of igemm_epilogue.h (bias, ReLU-mask + BN-backward sums, pixel shuffle), restated for persistence.
+#include <stdlib.h>
+#include "common.h"
+#include "../../include/ksmi.h"
+#include "errors.h"
+#include "igemm_epilogue.h"
+#include "igemm3.h"
+
+namespace {
+
+__device__ __attribute__((aligned(64))) unsigned char ig3_zero_page[64];      // zero-initialised device memory
+
+struct Ig3Args {
+  ksmi_conv_desc d;
+  uint32_t m_tw, m_hw, m_tx, m_ty;
+  int tiles, hpb, nslot, stage;
+  const unsigned char* zero;       // >= 16 zero bytes (positions outside the image read them)
+};
+
+template <int KH, int KW, int NCH, int WN, bool AFF, int NTI, bool MASK>
+__global__ __launch_bounds__(256 * WN, (WN == 1 && NCH * KH * KW * NTI <= 9) ? 2 : 1) void igemm3_kernel(const Ig3Args ka) {
+  typedef bf16_t T;
+  const ksmi_conv_desc& d = ka.d;
+  constexpr int NTHR = 256 * WN;
+  constexpr int TAPS = KH * KW;
+  constexpr int BN = 32 * WN;
+  constexpr int MAXSLOT = 2048 / NTHR;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 3, wn = wave >> 2;
+  const int g = lane >> 4, l15 = lane & 15;
+  const int S = d.stride;
+  const int HH = (d.TH - 1) * S + KH, HW = (d.TW - 1) * S + KW;
+  const int HP = HH * HW;
+  const int P = d.TH * d.TW;
+  const int tilesX = (d.Wout + d.TW - 1) / d.TW, tilesY = (d.Hout + d.TH - 1) / d.TH;
+  const FastDiv dTX(tilesX, ka.m_tx), dTY(tilesY, ka.m_ty), dHW(HW, ka.m_hw), dTW(d.TW, ka.m_tw);
+  const int hpb = ka.hpb, stage = ka.stage;
+
+  // ---- tile-invariant tables ------------------------------------------------------------------------------------------
+  int slot_yx[MAXSLOT], slot_qb[MAXSLOT];
+#pragma unroll
+  for (int s = 0; s < MAXSLOT; ++s) {
+    const int v = tid + s * NTHR;
+    const int pix = v >> 2, sl = v & 3;
+    const int hy = dHW.div(pix), hx = pix - hy * HW;
+    slot_yx[s] = v < HP * 4 ? ((hy << 16) | hx) : -1;
+    slot_qb[s] = (sl ^ swz(pix)) << 4;
+  }
+  int a_base[4];
+#pragma unroll
+  for (int mf = 0; mf < 4; ++mf) {
+    int p = wm * 64 + mf * 16 + l15;
+    if (p >= P) p = 0;
+    const int ly = dTW.div(p), lx = p - ly * d.TW;
+    a_base[mf] = ly * S * HW + lx * S;
+  }
+  // per-chunk source (virtual concat): base pointer of the chunk's first channel, bytes per pixel
+  const unsigned char* sp[NCH];
+  uint32_t cb[NCH];
+  int cc0[NCH];
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) {
+    const ksmi_src& sr = d.src[chunk_src_of(d, ch)];
+    cc0[ch] = chunk_c0_of(d, ch);
+    sp[ch] = (const unsigned char*)((const T*)sr.ptr + sr.c_off + cc0[ch]);
+    cb[ch] = (uint32_t)sr.C * 2u;
+  }
+  // ---- weights -> registers: fragment nf, row j = l15 of the MFMA A operand = output channel 8*(j>>2) + 4*nf + (j&3) of the wave's
+  //      32 columns (the lean epilogue's ownership: lane (g, l15) ends up with channels 8g .. 8g+7 of pixel l15) --------------------
+  u32x4 wreg[NTI][NCH][TAPS][2];
+#pragma unroll
+  for (int ni = 0; ni < NTI; ++ni)
+#pragma unroll
+    for (int nf = 0; nf < 2; ++nf) {
+      const int n = (blockIdx.y * NTI + ni) * BN + wn * 32 + 8 * (l15 >> 2) + 4 * nf + (l15 & 3);
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) {
+          wreg[ni][ch][t][nf] = (u32x4){0u, 0u, 0u, 0u};
+          if (n < d.Npad) wreg[ni][ch][t][nf] = *(const u32x4*)((const unsigned char*)d.wpk + ((size_t)(ch * TAPS + t) * d.Npad + n) * 64 + g * 16);
+        }
+    }
+  float* aff_tab = (float*)(smem + 2 * stage);                      // AFF: [NCH*32][2] scale, shift
+  if constexpr (AFF) {
+    if (tid < NCH * 32) {
+      const int ch = tid >> 5, j = tid & 31;
+      const ksmi_src& sr = d.src[0];
+      aff_tab[tid * 2 + 0] = sr.scale[cc0[ch] + j];
+      aff_tab[tid * 2 + 1] = sr.shift[cc0[ch] + j];
+    }
+  }
+  const bool aff_relu = AFF && d.src[0].relu != 0;
+
+  // ---- staging --------------------------------------------------------------------------------------------------------
+  auto tile_origin = [&](int t, int& b, int& oy0, int& ox0) {
+    const int q1 = dTX.div(t);
+    const int tx = t - q1 * tilesX;
+    b = dTY.div(q1);
+    const int ty = q1 - b * tilesY;
+    oy0 = ty * d.TH; ox0 = tx * d.TW;
+  };
+  auto issue = [&](int t, int stg) {
+    int b, oy0, ox0;
+    tile_origin(t, b, oy0, ox0);
+    const int iy0 = oy0 * S - d.pad, ix0 = ox0 * S - d.pad_x;
+    unsigned char* const sb = smem + stg * stage;
+#pragma unroll
+    for (int s = 0; s < MAXSLOT; ++s) {
+      if (s < ka.nslot) {
+        const int hy = slot_yx[s] >> 16, hx = slot_yx[s] & 0xffff;
+        const int iy = iy0 + hy, ix = ix0 + hx;
+        const bool ok = slot_yx[s] >= 0 && (unsigned)iy < (unsigned)d.Hin && (unsigned)ix < (unsigned)d.Win;
+        const uint32_t pix = (uint32_t)((b * d.Hin + iy) * d.Win + ix);
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+          // (two 32-bit selects: a pointer select compiles to two exec-masked DMA instructions)
+          const uint64_t av = (uint64_t)(uintptr_t)sp[ch] + (uint64_t)pix * cb[ch] + (uint64_t)slot_qb[s];
+          const uint64_t zv = (uint64_t)(uintptr_t)ka.zero;
+          const uint32_t lo = ok ? (uint32_t)av : (uint32_t)zv, hi = ok ? (uint32_t)(av >> 32) : (uint32_t)(zv >> 32);
+          const unsigned char* src = (const unsigned char*)(uintptr_t)(((uint64_t)hi << 32) | lo);
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                           (__attribute__((address_space(3))) void*)(sb + ch * hpb + (s * NTHR + wave * 64) * 16), 16, 0, 0);
+        }
+      }
+    }
+  };
+  // AFF: relu(x * scale + shift) over the in-image positions of the landed halo images (padding stays zero)
+  auto transform = [&](int t, int stg) {
+    int b, oy0, ox0;
+    tile_origin(t, b, oy0, ox0);
+    const int iy0 = oy0 * S - d.pad, ix0 = ox0 * S - d.pad_x;
+    unsigned char* const sb = smem + stg * stage;
+    const int q = tid & 3;                                          // k-group of this thread (logical)
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      float sc[8], sh[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { sc[j] = aff_tab[(ch * 32 + q * 8 + j) * 2]; sh[j] = aff_tab[(ch * 32 + q * 8 + j) * 2 + 1]; }
+#pragma unroll
+      for (int s = 0; s < MAXSLOT; ++s) {
+        if (s < ka.nslot && slot_yx[s] >= 0) {
+          const int hy = slot_yx[s] >> 16, hx = slot_yx[s] & 0xffff;
+          const int iy = iy0 + hy, ix = ix0 + hx;
+          if ((unsigned)iy < (unsigned)d.Hin && (unsigned)ix < (unsigned)d.Win) {
+            const int pix = (tid + s * NTHR) >> 2;
+            u32x4* p = (u32x4*)(sb + ch * hpb + pix * 64 + ((q ^ swz(pix)) << 4));
+            float x[8];
+            vec_unpack<T>(*p, x);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              x[j] = x[j] * sc[j] + sh[j];
+              if (aff_relu) x[j] = fmaxf(x[j], 0.f);
+            }
+            *p = vec_pack<T>(x);
+          }
+        }
+      }
+    }
+  };
+
+  // ---- epilogue state ---------------------------------------------------------------------------------------------------
+  constexpr bool has_mask = MASK;
+  const int dC = d.dst[0].C;
+  float ssum[8], ssq[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
+
+  int t = blockIdx.x;
+  if (t < ka.tiles) issue(t, 0);
+  for (int it = 0; t < ka.tiles; t += gridDim.x, ++it) {
+    const int cur = it & 1;
+    __syncthreads();                     // tile t landed (vmcnt(0) in front of the barrier); the other stage is free
+    if constexpr (AFF) {
+      transform(t, cur);
+      __syncthreads();
+    }
+    if (t + (int)gridDim.x < ka.tiles) issue(t + gridDim.x, cur ^ 1);
+    int b, oy0, ox0;
+    tile_origin(t, b, oy0, ox0);
+    const unsigned char* lds_h = smem + cur * stage;
+#pragma unroll
+    for (int ni = 0; ni < NTI; ++ni) {
+      f32x4 acc[4][2];
+#pragma unroll
+      for (int mf = 0; mf < 4; ++mf) { acc[mf][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[mf][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+      // flat (chunk, tap) sequence; the pixel fragments of step i+1 are requested before the MFMAs of step i, and a scheduling
+      // barrier per step keeps the compiler from hoisting more of them (the weights already take 72-144 VGPRs)
+      auto load_fa = [&](int step, u32x4 (&fa)[4]) {
+        const int ch = step / TAPS, tp = step - ch * TAPS;
+        const int toff = (tp / KW) * HW + (tp % KW);
+#pragma unroll
+        for (int mf = 0; mf < 4; ++mf) {
+          const int ap = a_base[mf] + toff;
+          fa[mf] = *(const u32x4*)(lds_h + ch * hpb + ap * 64 + ((g ^ swz(ap)) << 4));
+        }
+      };
+      u32x4 fa0[4], fa1[4];
+      load_fa(0, fa0);
+#pragma unroll
+      for (int step = 0; step < NCH * TAPS; ++step) {
+        const int ch = step / TAPS, tp = step - ch * TAPS;
+        if (step + 1 < NCH * TAPS) { if (step & 1) load_fa(step + 1, fa0); else load_fa(step + 1, fa1); }
+#pragma unroll
+        for (int mf = 0; mf < 4; ++mf) {
+          const u32x4& f = (step & 1) ? fa1[mf] : fa0[mf];
+          mma16<T>(acc[mf][0], wreg[ni][ch][tp][0], f);           // D = W * X^T
+          mma16<T>(acc[mf][1], wreg[ni][ch][tp][1], f);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // ---- epilogue of (tile, column tile): lane (g, l15) owns channels nc .. nc+7 of pixel l15 of each 16-pixel row group -----
+      const int nc = (blockIdx.y * NTI + ni) * BN + wn * 32 + g * 8;
+      const bool nv = nc < d.N;
+      int dd = 0, nn = nc;
+      if (d.ps_cout > 0) { dd = nc / d.ps_cout; nn = nc - dd * d.ps_cout; }
+      T* const obase = (T*)d.dst[0].ptr + d.dst[0].c_off + nn;
+      const T* const mbase = (const T*)d.mask_src + nc;
+      float bias[8], mm[MASK ? 8 : 1], mr[MASK ? 8 : 1], mg[MASK ? 8 : 1], mb[MASK ? 8 : 1];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bias[j] = 0.f;
+      auto ld8 = [&](const float* qp, float* o, int at) {
+        const f32x4 a = *(const f32x4*)(qp + at), c = *(const f32x4*)(qp + at + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { o[j] = a[j]; o[4 + j] = c[j]; }
+      };
+      if (d.bias && nv) ld8(d.bias, bias, nn);
+      if constexpr (MASK) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { mm[j] = 0.f; mr[j] = 0.f; mg[j] = 0.f; mb[j] = 0.f; }
+        if (nv) { ld8(d.m_mean, mm, nc); ld8(d.m_rstd, mr, nc); ld8(d.m_scale, mg, nc); ld8(d.m_shift, mb, nc); }
+      }
+      uint32_t opix[4];
+      bool ok[4];
+      u32x4 mv[MASK ? 4 : 1];
+#pragma unroll
+      for (int mf = 0; mf < 4; ++mf) {
+        const int p = wm * 64 + mf * 16 + l15;
+        const int ly = dTW.div(p), lx = p - ly * d.TW;
+        const int oy = oy0 + ly, ox = ox0 + lx;
+        ok[mf] = nv && p < P && oy < d.Hout && ox < d.Wout;
+        opix[mf] = d.ps_cout > 0 ? (uint32_t)((b * 2 * d.Hout + 2 * oy + (dd >> 1)) * (2 * d.Wout) + 2 * ox + (dd & 1))
+                                 : (uint32_t)((b * d.Hout + oy) * d.Wout + ox);
+        if constexpr (MASK) {
+          mv[mf] = (u32x4){0u, 0u, 0u, 0u};
+          if (ok[mf]) mv[mf] = *(const u32x4*)(mbase + (size_t)opix[mf] * d.N);
+        }
+      }
+#pragma unroll
+      for (int mf = 0; mf < 4; ++mf) {
+        float v[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { v[r] = acc[mf][0][r] + bias[r]; v[4 + r] = acc[mf][1][r] + bias[4 + r]; }
+        if constexpr (MASK) {
+          float m[8];
+          vec_unpack<T>(mv[MASK ? mf : 0], m);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float xh = (m[j] - mm[j]) * mr[j];
+            if (!(m[j] * mg[j] + mb[j] > 0.f)) v[j] = 0.f;
+            if (ok[mf]) { ssum[j] += v[j]; ssq[j] += v[j] * xh; }
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) if (ok[mf]) { ssum[j] += v[j]; ssq[j] += v[j] * v[j]; }
+        }
+        if (ok[mf]) *(u32x4*)(obase + (size_t)opix[mf] * dC) = vec_pack<T>(v);
+      }
+    }
+  }
+  // ---- statistics: one row per workgroup -----------------------------------------------------------------------------------
+  if (NTI == 1 && d.stats) {
+    __syncthreads();
+    float* red = (float*)smem;                                      // [WN groups][4 waves][2][32]
+    const int ws = wn * 4 + wm;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float a = row16_sum(ssum[j]), q = row16_sum(ssq[j]);
+      if (l15 == 0) { red[(ws * 2 + 0) * 32 + g * 8 + j] = a; red[(ws * 2 + 1) * 32 + g * 8 + j] = q; }
+    }
+    __syncthreads();
+    if (tid < 2 * BN) {
+      const int which = tid / BN, nn = tid - which * BN;
+      const int grp = nn >> 5, n = nn & 31;
+      const float* rg = red + (size_t)grp * 4 * 2 * 32;
+      const float v = rg[(0 * 2 + which) * 32 + n] + rg[(1 * 2 + which) * 32 + n] + rg[(2 * 2 + which) * 32 + n] + rg[(3 * 2 + which) * 32 + n];
+      const int ncol = blockIdx.y * BN + nn;
+      if (ncol < d.Npad) d.stats[((size_t)blockIdx.x * 2 + which) * d.Npad + ncol] = v;
+    }
+  }
+}
+
+}  // namespace
+
+// ---- host side --------------------------------------------------------------------------------------------------------------
+bool ksmi_igemm3_geom(const ksmi_conv_desc* d, int dtype, ksmi_igemm3_geom_t* g) {
+  static const bool off = getenv("KSMI_IGEMM3_OFF") != nullptr;
+  if (off || dtype != KSMI_BF16) return false;
+  const int taps = d->KH * d->KW;
+  if (!((d->KH == 3 && d->KW == 3) || (d->KH == 1 && d->KW == 1) || (d->KH == 2 && d->KW == 2))) return false;
+  if (d->uniform_kc || d->nchunks < 1 || d->nchunks > 8) return false;
+  if (d->ndst != 1 || d->dst[0].accumulate || d->dst[0].n_begin != 0) return false;
+  if (d->alpha != 0.f || d->resid || d->relu_out || d->out_sy || d->in_sy) return false;
+  if ((d->N % 8) || (d->dst[0].C % 8) || (d->dst[0].c_off % 8) || d->Npad < 32) return false;
+  if (d->ps_cout && (d->ps_cout % 8)) return false;
+  if (d->mask_src) return false;                                    // (ReLU-mask epilogue: igemm2's lean kernel is already HBM-bound)
+  auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+  if (!al16(d->dst[0].ptr) || !al16(d->bias)) return false;
+  for (int i = 0; i < d->nsrc; ++i) {
+    if (d->src[i].c_len % 32) return false;
+    if (d->src[i].scale && (i > 0 || d->nsrc != 1)) return false;
+    if ((size_t)d->B * d->Hin * d->Win * (size_t)d->src[i].C * 2 >= ((size_t)1 << 32)) return false;
+  }
+  if ((size_t)d->B * d->Hout * d->Wout * (d->ps_cout > 0 ? 4 : 1) >= ((size_t)1 << 31)) return false;
+  const int HH = (d->TH - 1) * d->stride + d->KH, HW = (d->TW - 1) * d->stride + d->KW;
+  const int HP = HH * HW;
+  if (d->TH * d->TW > 256 || HP > 512) return false;
+  // instances (the ones that compile without scratch): 3x3 with 1 chunk (one or two channel groups) or 2 chunks (one channel group,
+  // one wave per SIMD, weights partly in AGPRs); 2x2 with 1, 2 (4: one group) chunks; 1x1 with 2, 4, 8 chunks and up to 4 column
+  // tiles walked inside a workgroup (weights of all of them in registers: x is then read once for every column tile)
+  const bool aff = d->src[0].scale != nullptr;
+  g->WN = d->Npad >= 64 ? 2 : 1;
+  g->NTI = 1;
+  if (taps == 9) {
+    if (d->nchunks > 2) return false;
+    if (d->nchunks == 2) g->WN = 1;
+  } else if (taps == 4) {
+    if (aff || (d->nchunks != 1 && d->nchunks != 2 && d->nchunks != 4)) return false;
+    if (d->nchunks == 4) g->WN = 1;
+  } else {
+    if (aff || (d->nchunks != 2 && d->nchunks != 4 && d->nchunks != 8)) return false;
+  }
+  const int nthr = 256 * g->WN;
+  const int bn = 32 * g->WN;
+  const int ntiles = (d->Npad + bn - 1) / bn;
+  if (taps == 1 && d->stats == nullptr) {
+    if (d->nchunks == 2 && ntiles % 4 == 0) g->NTI = 4;
+    else if (d->nchunks <= 4 && ntiles % 2 == 0) g->NTI = 2;
+  }
+  g->hpb = (HP * 64 + nthr * 16 - 1) / (nthr * 16) * (nthr * 16);
+  g->nslot = g->hpb / (nthr * 16);
+  g->stage = d->nchunks * g->hpb;
+  g->lds = 2 * (size_t)g->stage + 1024;
+  if (g->lds < (size_t)4 * 2 * 2 * 32 * g->WN * sizeof(float)) g->lds = (size_t)4 * 2 * 2 * 32 * g->WN * sizeof(float);
+  if (g->lds > 160 * 1024) return false;
+  const int tilesX = (d->Wout + d->TW - 1) / d->TW, tilesY = (d->Hout + d->TH - 1) / d->TH;
+  g->tiles = d->B * tilesX * tilesY;
+  int per_cu = (int)(160 * 1024 / g->lds);
+  const int cap = (g->WN == 1 && d->nchunks * taps * g->NTI <= 9) ? 2 : 1;      // = the kernel's __launch_bounds__
+  if (per_cu > cap) per_cu = cap;
+  const char* cus_env = getenv("KSMI_IGEMM3_CUS");            // (read per call: the tests shrink the grid to force many rounds)
+  const int cus = cus_env ? atoi(cus_env) : 256;
+  const int gy = ntiles / g->NTI;
+  int gx = cus * per_cu / gy;
+  if (gx < 1) gx = 1;
+  if (gx > g->tiles) gx = g->tiles;
+  // equalise: every workgroup walks ceil(tiles / gx) tiles -> the smallest grid with the same number of rounds
+  const int rounds = (g->tiles + gx - 1) / gx;
+  gx = (g->tiles + rounds - 1) / rounds;
+  g->gx = gx; g->gy = gy;
+  return true;
+}
+
+int ksmi_igemm3_launch(const ksmi_conv_desc* d, const ksmi_igemm3_geom_t* g, hipStream_t st) {
+  Ig3Args ka;
+  ka.d = *d;
+  const int HW = (d->TW - 1) * d->stride + d->KW;
+  const int tilesX = (d->Wout + d->TW - 1) / d->TW, tilesY = (d->Hout + d->TH - 1) / d->TH;
+  ka.m_tw = fastdiv_magic(d->TW); ka.m_hw = fastdiv_magic(HW); ka.m_tx = fastdiv_magic(tilesX); ka.m_ty = fastdiv_magic(tilesY);
+  ka.tiles = g->tiles; ka.hpb = g->hpb; ka.nslot = g->nslot; ka.stage = g->stage;
+  static void* zero_page = nullptr;
+  if (!zero_page && hipGetSymbolAddress(&zero_page, HIP_SYMBOL(ig3_zero_page)) != hipSuccess) return ksmi_fail(KSMI_E_UNSUPPORTED, "igemm3: zero page");
+  ka.zero = (const unsigned char*)zero_page;
+  const dim3 grid(g->gx, g->gy);
+  const bool aff = d->src[0].scale != nullptr;
+  const int taps = d->KH * d->KW;
+#define KSMI_G3(KH_, KW_, NCH_, WN_, AFF_, NTI_)                                                     \
+  do {                                                                                               \
+    auto kfn = igemm3_kernel<KH_, KW_, NCH_, WN_, AFF_, NTI_, false>;                                \
+    if (g->lds > 65536) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g->lds); \
+    hipLaunchKernelGGL(kfn, grid, dim3(256 * WN_), g->lds, st, ka);                                  \
+    return ksmi_check_launch("igemm3");                                                              \
+  } while (0)
+#define KSMI_G3W(KH_, KW_, NCH_, AFF_, NTI_)                                                         \
+  do { if (g->WN == 2) KSMI_G3(KH_, KW_, NCH_, 2, AFF_, NTI_); else KSMI_G3(KH_, KW_, NCH_, 1, AFF_, NTI_); } while (0)
+  if (taps == 9) {
+    if (d->nchunks == 1) { if (aff) KSMI_G3W(3, 3, 1, true, 1); else KSMI_G3W(3, 3, 1, false, 1); }
+    if (d->nchunks == 2) { if (aff) KSMI_G3(3, 3, 2, 1, true, 1); else KSMI_G3(3, 3, 2, 1, false, 1); }
+  } else if (taps == 1) {
+    if (d->nchunks == 2) { if (g->NTI == 4) KSMI_G3W(1, 1, 2, false, 4); else if (g->NTI == 2) KSMI_G3W(1, 1, 2, false, 2); else KSMI_G3W(1, 1, 2, false, 1); }
+    if (d->nchunks == 4) { if (g->NTI == 2) KSMI_G3W(1, 1, 4, false, 2); else KSMI_G3W(1, 1, 4, false, 1); }
+    if (d->nchunks == 8) KSMI_G3W(1, 1, 8, false, 1);
+  } else if (taps == 4) {
+    if (d->nchunks == 1) KSMI_G3W(2, 2, 1, false, 1);
+    if (d->nchunks == 2) KSMI_G3W(2, 2, 2, false, 1);
+    if (d->nchunks == 4) KSMI_G3(2, 2, 4, 1, false, 1);
+  }
+#undef KSMI_G3W
+#undef KSMI_G3
+  return ksmi_fail(KSMI_E_UNSUPPORTED, "igemm3: no instance (geometry / launch mismatch)");
+}

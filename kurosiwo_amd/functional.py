@@ -6,7 +6,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from .runtime import DT, SrcSpec, conv_grid_m, make_conv, make_pack, make_wgrad, packed_weight_numel, require_gpu, stream_ptr
+from .runtime import DT, SrcSpec, conv_grid_m, conv_stats_rows, make_conv, make_pack, make_wgrad, packed_weight_numel, require_gpu, stream_ptr
 
 
 def to_nhwc(x_nchw, dtype):
@@ -50,7 +50,7 @@ def conv3x3(xs, weight, bias=None, affine=None, want_stats=False, alpha=0.0, rel
     d.wpk = wpk.data_ptr()
     stats = None
     if want_stats:
-        stats = torch.zeros((conv_grid_m(d), 2, d.Npad), dtype=torch.float32, device=out.device)
+        stats = torch.zeros((conv_stats_rows(d, dtype), 2, d.Npad), dtype=torch.float32, device=out.device)
         d.stats = stats.data_ptr()
     _lib.check(_lib.load().ksmi_conv_forward(C.byref(d), DT[dtype], stream_ptr()), "conv_forward")
     return out, stats

@@ -229,6 +229,14 @@ def conv_grid_m(d):
     return _lib.load().ksmi_conv_grid_m(C.byref(d))
 
 
+def conv_stats_rows(d, dtype):
+    """rows of the `stats` buffer of this descriptor (recorded in d.stats_rows: the persistent short-K kernel writes one row per
+    workgroup, every other kernel one per M-tile); call after the descriptor is complete, with d.stats already non-null."""
+    rows = _lib.load().ksmi_conv_stats_rows(C.byref(d), DT[dtype])
+    d.stats_rows = rows
+    return rows
+
+
 def packed_weight_numel(table, taps, Npad, dtype):
     return len(table) * taps * Npad * chunk_elems(dtype)
 

@@ -12,7 +12,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from .runtime import DT, Act, SrcSpec, conv_grid_m, make_conv, make_pack, make_wgrad, packed_weight_numel, stream_ptr
+from .runtime import DT, Act, SrcSpec, conv_grid_m, conv_stats_rows, make_conv, make_pack, make_wgrad, packed_weight_numel, stream_ptr
 from .snunet import BN_EPS, BN_MOMENTUM
 
 
@@ -241,7 +241,7 @@ class SNUNetPlan:
         if bias_key is not None:
             # `act` is the output of a ConvTranspose2d whose bias gradient is sum_pixels d act: the statistics epilogue of this launch
             # emits the per-tile sums (was: one more pass over the gradient tensor, ksmi_channel_sum)
-            rows_g = conv_grid_m(d)
+            rows_g = conv_stats_rows(d, self.dtype)
             st = torch.empty(rows_g * 2 * Npad, dtype=torch.float32, device=self.dev)
             d.stats = st.data_ptr()
             self._defer_rowsum(bias_key, st, rows_g, 2, 0, Npad, Cc)
@@ -338,7 +338,7 @@ class SNUNetPlan:
                                B, H, W, H, W, 3, 3, 1, 1, Cc, dtype)
             w1 = self._packed(f"{name}.conv1.weight", t1, 9, Cc, Cc, 9, Ktot * 9, 0, 1, 0)
             d1.wpk = w1.data_ptr()
-            rows1, cpad1 = conv_grid_m(d1), Npad
+            rows1, cpad1 = conv_stats_rows(d1, dtype), Npad
             if training:
                 self.need("stats", rows1 * 2 * Npad * 4)
                 self.patch(d1, "stats", "stats")
@@ -358,7 +358,7 @@ class SNUNetPlan:
                            B, H, W, H, W, 3, 3, 1, 1, Cc, dtype)
         w2 = self._packed(f"{name}.conv2.weight", t2, 9, Cc, Cc, 9, Cc * 9, 0, 1, 0)
         d2.wpk = w2.data_ptr()
-        rows2 = conv_grid_m(d2)
+        rows2 = conv_stats_rows(d2, dtype)
         if training:
             self.need("stats", rows2 * 2 * Npad * 4)
             self.patch(d2, "stats", "stats")
@@ -399,7 +399,7 @@ class SNUNetPlan:
                                  mask=(i_act.t, sv1.t[0], sv1.t[1], sv1.t[2], sv1.t[3]))
             wg2 = self._packed(f"{name}.conv2.weight", tg2, 9, Cc, Cc, Cc * 9, 9, 0, 1, 1)
             dg2.wpk = wg2.data_ptr()
-            rows_g = conv_grid_m(dg2)
+            rows_g = conv_stats_rows(dg2, dtype)
             self.need("stats", rows_g * 2 * Npad * 4)
             self.patch(dg2, "stats", "stats")
             self._conv(self.bwd, dg2, "dgrad")

@@ -1,0 +1,95 @@
+"""GPU parity of the persistent short-K convolution kernel (csrc/igemm3.hip: register-resident weights, zero-page padding,
+one statistics row per workgroup) against stock torch-CPU fp32 convolutions on the same bf16-quantised operands.
+KSMI_IGEMM3_CUS shrinks the persistent grid so that every workgroup walks several tiles (both LDS stages, the tail round)."""
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle.seeded import seeded_tensor
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from kurosiwo_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(params=["256", "3"])
+def cus(request):
+    old = os.environ.get("KSMI_IGEMM3_CUS")
+    os.environ["KSMI_IGEMM3_CUS"] = request.param
+    yield request.param
+    if old is None:
+        os.environ.pop("KSMI_IGEMM3_CUS", None)
+    else:
+        os.environ["KSMI_IGEMM3_CUS"] = old
+
+
+def q(t):
+    return t.to(torch.bfloat16).float()
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(B=2, H=48, W=40, cs=[32], N=32),                   # one chunk, one channel group
+    dict(B=2, H=33, W=50, cs=[32], N=64),                   # two channel groups sharing the halo; ragged map
+    dict(B=1, H=64, W=64, cs=[64], N=64),                   # two chunks: weights partly in AGPRs, one wave per SIMD
+    dict(B=2, H=24, W=24, cs=[32, 32], N=32),               # two chunks from two sources (virtual concat)
+    dict(B=1, H=40, W=72, cs=[32], N=32, aff=True),         # fused BN-apply + ReLU operand, transformed in LDS
+    dict(B=2, H=28, W=28, cs=[64], N=128, aff=True),
+    dict(B=3, H=16, W=16, cs=[32], N=128),                  # several column tiles (grid.y)
+])
+def test_igemm3_conv3x3_forward_stats(dev, cus, cfg):
+    from kurosiwo_amd import functional as Fk
+    dtype = torch.bfloat16
+    B, H, W, cs, N = cfg["B"], cfg["H"], cfg["W"], cfg["cs"], cfg["N"]
+    tag = f"ig3.{B}{H}{W}{cs}{N}"
+    xs = [seeded_tensor(f"{tag}.x{i}", (B, c, H, W)) for i, c in enumerate(cs)]
+    K = sum(cs)
+    w = seeded_tensor(tag + ".w", (N, K, 3, 3)) * (2.0 / (K * 9)) ** 0.5
+    bias = seeded_tensor(tag + ".b", (N,)) * 0.1
+    xq = torch.cat([q(x) for x in xs], 1)
+    aff = None
+    if cfg.get("aff"):
+        sc, sh = 1.0 + 0.3 * seeded_tensor(tag + ".sc", (K,)), 0.2 * seeded_tensor(tag + ".sh", (K,))
+        xq = q(torch.relu(xq * sc[None, :, None, None] + sh[None, :, None, None]))
+        aff = (sc.to(dev), sh.to(dev), 1)
+    y_ref = F.conv2d(xq, q(w), bias, padding=1)
+    xd = [Fk.to_nhwc(x.to(dev), dtype) for x in xs]
+    y, stats = Fk.conv3x3(xd, w.to(dev), bias.to(dev), affine=aff, want_stats=True)
+    yn = Fk.to_nchw(y).cpu()
+    assert (yn - y_ref).abs().max() < 2.5e-2 * y_ref.abs().max()
+    s = stats.sum(0).cpu()
+    assert (s[0, :N] - y_ref.sum((0, 2, 3))).abs().max() < 1e-3 * max(1.0, float(y_ref.abs().sum((0, 2, 3)).max()))
+    assert (s[1, :N] - (y_ref ** 2).sum((0, 2, 3))).abs().max() < 1e-3 * float((y_ref ** 2).sum((0, 2, 3)).max())
+    # the persistent kernel writes one statistics row per workgroup (a tile kernel would write B * tiles rows)
+    from kurosiwo_amd.runtime import choose_patch
+    th, tw = choose_patch(H, W)
+    assert stats.shape[0] <= B * -(-H // th) * -(-W // tw)
+
+
+@pytest.mark.parametrize("shape", [(2, 56, 56, 64), (1, 30, 22, 128), (2, 14, 14, 256), (3, 9, 7, 32)])
+def test_igemm3_deconv2x2_forward_and_input_gradient(dev, cus, shape):
+    """ConvTranspose2d k2 s2 forward = 1x1 GEMM over 4C columns with the pixel-shuffle store (several column tiles per workgroup);
+    its input gradient = 2x2 stride-2 convolution."""
+    from kurosiwo_amd import functional as Fk
+    dtype = torch.bfloat16
+    B, H, W, Cc = shape
+    x = seeded_tensor("ig3dc.x" + str(shape), (B, Cc, H, W))
+    w = seeded_tensor("ig3dc.w" + str(shape), (Cc, Cc, 2, 2)) * (1.0 / Cc) ** 0.5
+    b = seeded_tensor("ig3dc.b" + str(shape), (Cc,)) * 0.1
+    dy = seeded_tensor("ig3dc.dy" + str(shape), (B, Cc, 2 * H, 2 * W))
+    xr, wr = q(x).requires_grad_(True), q(w).requires_grad_(True)
+    y_ref = F.conv_transpose2d(xr, wr, b, stride=2)
+    y_ref.backward(q(dy))
+    xd = Fk.to_nhwc(x.to(dev), dtype)
+    y = Fk.deconv2x2(xd, w.to(dev), b.to(dev))
+    assert (Fk.to_nchw(y).cpu() - y_ref.detach()).abs().max() < 2.5e-2 * y_ref.abs().max()
+    dx, dw = Fk.deconv2x2_backward(xd, Fk.to_nhwc(dy.to(dev), dtype), w.to(dev))
+    assert (Fk.to_nchw(dx).cpu() - xr.grad).abs().max() < 2.5e-2 * xr.grad.abs().max()
+    assert (dw.cpu() - wr.grad).abs().max() < 2.5e-2 * wr.grad.abs().max()
