@@ -5,7 +5,7 @@
 
 struct ksmi_igemm3_geom_t {
   int WN, NTI;          // channel groups per workgroup (32 columns each); column tiles walked inside a workgroup
-  int hpb, nslot, stage;
+  int hpb, nslot, stage, ns;
   int tiles, gx, gy;    // pixel tiles; grid (gx persistent workgroups along the pixel axis = rows of `stats`)
   size_t lds;
 };

@@ -29,8 +29,38 @@ struct Ig3Args {
   ksmi_conv_desc d;
   uint32_t m_tw, m_hw, m_tx, m_ty;
   int tiles, hpb, nslot, stage;
+  int dbg;                         // KSMI_IG3_DBG profiling switches (wrong results): 1 skip the AFF transform, 2 skip its barrier too, 4 skip the epilogue stores
+  int ns;                          // LDS stages: 3 (two tiles in flight) when they fit, else 2
   const unsigned char* zero;       // >= 16 zero bytes (positions outside the image read them)
 };
+
+// LDS-DMA from inline asm (lane i lands at dst_wave_base + 16 * i): the compiler does not see it, so it neither drains it at a
+// barrier nor in front of an unrelated global load, and TWO tiles can stay in flight; completion is waited for with a counted
+// vmcnt (every tile issues the same number of DMA instructions per wave: positions outside the image read the zero page).
+__device__ __forceinline__ void glds16_flat(const unsigned char* src, unsigned dst_wave_base) {
+  unsigned keep;
+  dst_wave_base = __builtin_amdgcn_readfirstlane(dst_wave_base);
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(src), "s"(dst_wave_base) : "memory");
+}
+// wait until at most n vector-memory operations of this wave are outstanding (n = DMA instructions of the tiles issued later)
+__device__ __forceinline__ void vm_wait(int n) {
+#define KSMI_VMW(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+  switch (n) {
+    KSMI_VMW(1) KSMI_VMW(2) KSMI_VMW(3) KSMI_VMW(4) KSMI_VMW(5) KSMI_VMW(6) KSMI_VMW(7) KSMI_VMW(8) KSMI_VMW(9) KSMI_VMW(10)
+    KSMI_VMW(11) KSMI_VMW(12) KSMI_VMW(13) KSMI_VMW(14) KSMI_VMW(15) KSMI_VMW(16) KSMI_VMW(17) KSMI_VMW(18) KSMI_VMW(19) KSMI_VMW(20)
+    KSMI_VMW(21) KSMI_VMW(22) KSMI_VMW(23) KSMI_VMW(24) KSMI_VMW(25) KSMI_VMW(26) KSMI_VMW(27) KSMI_VMW(28) KSMI_VMW(29) KSMI_VMW(30)
+    KSMI_VMW(31) KSMI_VMW(32)
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+#undef KSMI_VMW
+}
+// workgroup barrier that does NOT drain vector memory: LDS operations of this wave complete, then s_barrier
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
 
 template <int KH, int KW, int NCH, int WN, bool AFF, int NTI, bool MASK>
 __global__ __launch_bounds__(256 * WN, (WN == 1 && NCH * KH * KW * NTI <= 9) ? 2 : 1) void igemm3_kernel(const Ig3Args ka) {
@@ -55,15 +85,8 @@ __global__ __launch_bounds__(256 * WN, (WN == 1 && NCH * KH * KW * NTI <= 9) ? 2
   const int hpb = ka.hpb, stage = ka.stage;
 
   // ---- tile-invariant tables ------------------------------------------------------------------------------------------
-  int slot_yx[MAXSLOT], slot_qb[MAXSLOT];
-#pragma unroll
-  for (int s = 0; s < MAXSLOT; ++s) {
-    const int v = tid + s * NTHR;
-    const int pix = v >> 2, sl = v & 3;
-    const int hy = dHW.div(pix), hx = pix - hy * HW;
-    slot_yx[s] = v < HP * 4 ? ((hy << 16) | hx) : -1;
-    slot_qb[s] = (sl ^ swz(pix)) << 4;
-  }
+  // halo slot v = tid + s * NTHR <-> (pixel v >> 2, 16-byte k-group slot v & 3); (hy, hx) are recomputed where needed (one
+  // multiply-high each: cheaper than 2 * MAXSLOT table registers next to 72-144 registers of weights)
   int a_base[4];
 #pragma unroll
   for (int mf = 0; mf < 4; ++mf) {
@@ -99,13 +122,14 @@ __global__ __launch_bounds__(256 * WN, (WN == 1 && NCH * KH * KW * NTI <= 9) ? 2
           if (n < d.Npad) wreg[ni][ch][t][nf] = *(const u32x4*)((const unsigned char*)d.wpk + ((size_t)(ch * TAPS + t) * d.Npad + n) * 64 + g * 16);
         }
     }
-  float* aff_tab = (float*)(smem + 2 * stage);                      // AFF: [NCH*32][2] scale, shift
+  const unsigned lds0 = (unsigned)(uintptr_t)smem;
+  float* aff_tab = (float*)(smem + ka.ns * stage);                      // AFF: [NCH*32][2] scale, shift
   if constexpr (AFF) {
-    if (tid < NCH * 32) {
+    if (tid < NCH * 32) {                                           // layout [chunk][k-group q]{scale[8], shift[8]}
       const int ch = tid >> 5, j = tid & 31;
       const ksmi_src& sr = d.src[0];
-      aff_tab[tid * 2 + 0] = sr.scale[cc0[ch] + j];
-      aff_tab[tid * 2 + 1] = sr.shift[cc0[ch] + j];
+      aff_tab[(ch * 4 + (j >> 3)) * 16 + (j & 7)] = sr.scale[cc0[ch] + j];
+      aff_tab[(ch * 4 + (j >> 3)) * 16 + 8 + (j & 7)] = sr.shift[cc0[ch] + j];
     }
   }
   const bool aff_relu = AFF && d.src[0].relu != 0;
@@ -122,57 +146,84 @@ __global__ __launch_bounds__(256 * WN, (WN == 1 && NCH * KH * KW * NTI <= 9) ? 2
     int b, oy0, ox0;
     tile_origin(t, b, oy0, ox0);
     const int iy0 = oy0 * S - d.pad, ix0 = ox0 * S - d.pad_x;
-    unsigned char* const sb = smem + stg * stage;
+    int tv = tid;
+    asm volatile("" : "+v"(tv));          // opaque per call: keeps hipcc from hoisting the (tile-invariant) slot arithmetic out of the
+                                          // tile loop into 30+ table registers (the weights already hold 72-144)
 #pragma unroll
     for (int s = 0; s < MAXSLOT; ++s) {
       if (s < ka.nslot) {
-        const int hy = slot_yx[s] >> 16, hx = slot_yx[s] & 0xffff;
+        const int v = tv + s * NTHR;
+        const int pix = v >> 2;
+        const int hy = dHW.div(pix), hx = pix - hy * HW;
         const int iy = iy0 + hy, ix = ix0 + hx;
-        const bool ok = slot_yx[s] >= 0 && (unsigned)iy < (unsigned)d.Hin && (unsigned)ix < (unsigned)d.Win;
-        const uint32_t pix = (uint32_t)((b * d.Hin + iy) * d.Win + ix);
+        const bool ok = v < HP * 4 && (unsigned)iy < (unsigned)d.Hin && (unsigned)ix < (unsigned)d.Win;
+        const uint32_t gpix = (uint32_t)((b * d.Hin + iy) * d.Win + ix);
+        const uint32_t qb = (uint32_t)(((v & 3) ^ swz(pix)) << 4);
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
           // (two 32-bit selects: a pointer select compiles to two exec-masked DMA instructions)
-          const uint64_t av = (uint64_t)(uintptr_t)sp[ch] + (uint64_t)pix * cb[ch] + (uint64_t)slot_qb[s];
+          const uint64_t av = (uint64_t)(uintptr_t)sp[ch] + (uint64_t)gpix * cb[ch] + (uint64_t)qb;
           const uint64_t zv = (uint64_t)(uintptr_t)ka.zero;
           const uint32_t lo = ok ? (uint32_t)av : (uint32_t)zv, hi = ok ? (uint32_t)(av >> 32) : (uint32_t)(zv >> 32);
           const unsigned char* src = (const unsigned char*)(uintptr_t)(((uint64_t)hi << 32) | lo);
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                           (__attribute__((address_space(3))) void*)(sb + ch * hpb + (s * NTHR + wave * 64) * 16), 16, 0, 0);
+          glds16_flat(src, lds0 + (unsigned)(stg * stage + ch * hpb + (s * NTHR + wave * 64) * 16));
         }
       }
     }
   };
-  // AFF: relu(x * scale + shift) over the in-image positions of the landed halo images (padding stays zero)
+  // AFF: relu(x * scale + shift) over the in-image positions of the landed halo images (padding stays zero).  Straight-line: all
+  // reads of a chunk are issued before the first use (thread = k-group q of pixel (tid + s * NTHR) >> 2; the table row is lane-constant)
   auto transform = [&](int t, int stg) {
     int b, oy0, ox0;
     tile_origin(t, b, oy0, ox0);
     const int iy0 = oy0 * S - d.pad, ix0 = ox0 * S - d.pad_x;
     unsigned char* const sb = smem + stg * stage;
-    const int q = tid & 3;                                          // k-group of this thread (logical)
+    int tv = tid;
+    asm volatile("" : "+v"(tv));          // (see issue)
+    const int q = tv & 3;
+    bool okv[MAXSLOT];
+#pragma unroll
+    for (int s = 0; s < MAXSLOT; ++s) {
+      const int v = tv + s * NTHR;
+      const int pix = v >> 2;
+      const int hy = dHW.div(pix), hx = pix - hy * HW;
+      const int iy = iy0 + hy, ix = ix0 + hx;
+      okv[s] = s < ka.nslot && v < HP * 4 && (unsigned)iy < (unsigned)d.Hin && (unsigned)ix < (unsigned)d.Win;
+    }
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
-      float sc[8], sh[8];
+      const f32x4* tab = (const f32x4*)(aff_tab + (ch * 4 + q) * 16);       // [chunk][k-group]{scale[8], shift[8]}
+      const f32x4 s0 = tab[0], s1 = tab[1], h0 = tab[2], h1 = tab[3];
+      constexpr int BATCH = MAXSLOT > 4 ? 4 : MAXSLOT;               // reads in flight per batch (registers)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { sc[j] = aff_tab[(ch * 32 + q * 8 + j) * 2]; sh[j] = aff_tab[(ch * 32 + q * 8 + j) * 2 + 1]; }
+      for (int s0i = 0; s0i < MAXSLOT; s0i += BATCH) {
+        u32x4 xv[BATCH];
 #pragma unroll
-      for (int s = 0; s < MAXSLOT; ++s) {
-        if (s < ka.nslot && slot_yx[s] >= 0) {
-          const int hy = slot_yx[s] >> 16, hx = slot_yx[s] & 0xffff;
-          const int iy = iy0 + hy, ix = ix0 + hx;
-          if ((unsigned)iy < (unsigned)d.Hin && (unsigned)ix < (unsigned)d.Win) {
-            const int pix = (tid + s * NTHR) >> 2;
-            u32x4* p = (u32x4*)(sb + ch * hpb + pix * 64 + ((q ^ swz(pix)) << 4));
+        for (int k = 0; k < BATCH; ++k) {
+          const int pix = (tv + (s0i + k) * NTHR) >> 2;
+          if (s0i + k < ka.nslot) xv[k] = *(const u32x4*)(sb + ch * hpb + pix * 64 + ((q ^ swz(pix)) << 4));
+        }
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k) {
+          if (s0i + k < ka.nslot) {
+            const int pix = (tv + (s0i + k) * NTHR) >> 2;
             float x[8];
-            vec_unpack<T>(*p, x);
+            vec_unpack<T>(xv[k], x);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              x[j] = x[j] * sc[j] + sh[j];
-              if (aff_relu) x[j] = fmaxf(x[j], 0.f);
+            for (int j = 0; j < 4; ++j) {
+              x[j] = x[j] * s0[j] + h0[j];
+              x[4 + j] = x[4 + j] * s1[j] + h1[j];
             }
-            *p = vec_pack<T>(x);
+            if (aff_relu) {             // one v_med3_f32 per value (fmaxf compiles to a canonicalising v_max plus the v_max)
+#pragma unroll
+              for (int j = 0; j < 8; ++j) x[j] = __builtin_amdgcn_fmed3f(x[j], 0.f, 3.0e38f);
+            }
+            u32x4 o = vec_pack<T>(x);
+            if (!okv[s0i + k]) o = (u32x4){0u, 0u, 0u, 0u};
+            *(u32x4*)(sb + ch * hpb + pix * 64 + ((q ^ swz(pix)) << 4)) = o;
           }
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   };
@@ -184,16 +235,39 @@ __global__ __launch_bounds__(256 * WN, (WN == 1 && NCH * KH * KW * NTI <= 9) ? 2
 #pragma unroll
   for (int j = 0; j < 8; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
 
-  int t = blockIdx.x;
-  if (t < ka.tiles) issue(t, 0);
-  for (int it = 0; t < ka.tiles; t += gridDim.x, ++it) {
-    const int cur = it & 1;
-    __syncthreads();                     // tile t landed (vmcnt(0) in front of the barrier); the other stage is free
-    if constexpr (AFF) {
-      transform(t, cur);
-      __syncthreads();
+  // bias of the column tile(s): loaded once (a global load inside the tile loop would make hipcc drain the DMA queue for it)
+  float biasr[NTI][8];
+#pragma unroll
+  for (int ni = 0; ni < NTI; ++ni) {
+    const int nc = (blockIdx.y * NTI + ni) * BN + wn * 32 + g * 8;
+    int nn = nc;
+    if (d.ps_cout > 0) nn = nc - (nc / d.ps_cout) * d.ps_cout;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) biasr[ni][j] = 0.f;
+    if (d.bias && nc < d.N) {
+      const f32x4 a = *(const f32x4*)(d.bias + nn), c = *(const f32x4*)(d.bias + nn + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { biasr[ni][j] = a[j]; biasr[ni][4 + j] = c[j]; }
     }
-    if (t + (int)gridDim.x < ka.tiles) issue(t + gridDim.x, cur ^ 1);
+  }
+  const int G = gridDim.x, NS = ka.ns, LA = NS - 1;               // lookahead: tiles in flight beyond the current one
+  const int ndma = ka.nslot * NCH;                                  // DMA instructions per wave per tile
+  __syncthreads();                                                  // affine table visible; nothing in flight yet
+  int t = blockIdx.x;
+  for (int k = 0; k < LA; ++k)
+    if (t + k * G < ka.tiles) issue(t + k * G, k);
+  for (int it = 0; t < ka.tiles; t += G, ++it) {
+    const int cur = it % NS;
+    // tile t has landed once at most the DMA instructions of the tiles issued after it are outstanding
+    int later = 0;
+    for (int k = 1; k < LA; ++k) if (t + k * G < ka.tiles) ++later;
+    vm_wait(later * ndma);
+    lds_barrier();                       // ... for every wave; the stage of tile t - G is free (its MFMAs are done)
+    if (t + LA * G < ka.tiles) issue(t + LA * G, (it + LA) % NS);
+    if constexpr (AFF) {
+      if (!(ka.dbg & 1)) transform(t, cur);
+      if (!(ka.dbg & 2)) lds_barrier();
+    }
     int b, oy0, ox0;
     tile_origin(t, b, oy0, ox0);
     const unsigned char* lds_h = smem + cur * stage;
@@ -234,15 +308,13 @@ __global__ __launch_bounds__(256 * WN, (WN == 1 && NCH * KH * KW * NTI <= 9) ? 2
       if (d.ps_cout > 0) { dd = nc / d.ps_cout; nn = nc - dd * d.ps_cout; }
       T* const obase = (T*)d.dst[0].ptr + d.dst[0].c_off + nn;
       const T* const mbase = (const T*)d.mask_src + nc;
-      float bias[8], mm[MASK ? 8 : 1], mr[MASK ? 8 : 1], mg[MASK ? 8 : 1], mb[MASK ? 8 : 1];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) bias[j] = 0.f;
+      float mm[MASK ? 8 : 1], mr[MASK ? 8 : 1], mg[MASK ? 8 : 1], mb[MASK ? 8 : 1];
+      const float (&bias)[8] = biasr[ni];
       auto ld8 = [&](const float* qp, float* o, int at) {
         const f32x4 a = *(const f32x4*)(qp + at), c = *(const f32x4*)(qp + at + 4);
 #pragma unroll
         for (int j = 0; j < 4; ++j) { o[j] = a[j]; o[4 + j] = c[j]; }
       };
-      if (d.bias && nv) ld8(d.bias, bias, nn);
       if constexpr (MASK) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) { mm[j] = 0.f; mr[j] = 0.f; mg[j] = 0.f; mb[j] = 0.f; }
@@ -282,7 +354,7 @@ __global__ __launch_bounds__(256 * WN, (WN == 1 && NCH * KH * KW * NTI <= 9) ? 2
 #pragma unroll
           for (int j = 0; j < 8; ++j) if (ok[mf]) { ssum[j] += v[j]; ssq[j] += v[j] * v[j]; }
         }
-        if (ok[mf]) *(u32x4*)(obase + (size_t)opix[mf] * dC) = vec_pack<T>(v);
+        if (ok[mf] && !(ka.dbg & 4)) *(u32x4*)(obase + (size_t)opix[mf] * dC) = vec_pack<T>(v);
       }
     }
   }
@@ -341,7 +413,7 @@ bool ksmi_igemm3_geom(const ksmi_conv_desc* d, int dtype, ksmi_igemm3_geom_t* g)
   g->NTI = 1;
   if (taps == 9) {
     if (d->nchunks > 2) return false;
-    if (d->nchunks == 2) g->WN = 1;
+    if (d->nchunks == 2) { if (aff) return false; g->WN = 1; }       // (fused-operand K = 64: igemm2's register staging is as fast)
   } else if (taps == 4) {
     if (aff || (d->nchunks != 1 && d->nchunks != 2 && d->nchunks != 4)) return false;
     if (d->nchunks == 4) g->WN = 1;
@@ -358,13 +430,18 @@ bool ksmi_igemm3_geom(const ksmi_conv_desc* d, int dtype, ksmi_igemm3_geom_t* g)
   g->hpb = (HP * 64 + nthr * 16 - 1) / (nthr * 16) * (nthr * 16);
   g->nslot = g->hpb / (nthr * 16);
   g->stage = d->nchunks * g->hpb;
-  g->lds = 2 * (size_t)g->stage + 1024;
+  const size_t LDS_CU = 160 * 1024;
+  const size_t l2 = 2 * (size_t)g->stage + 1024, l3 = 3 * (size_t)g->stage + 1024;
+  if (l2 > LDS_CU) return false;
+  const int cap = (g->WN == 1 && d->nchunks * taps * g->NTI <= 9) ? 2 : 1;      // workgroups per CU by registers (= the kernel's __launch_bounds__)
+  // three stages (two tiles in flight) when that does not cost a workgroup per CU
+  if (cap == 2) g->ns = (2 * l3 <= LDS_CU) ? 3 : ((2 * l2 <= LDS_CU) ? 2 : (l3 <= LDS_CU ? 3 : 2));
+  else g->ns = l3 <= LDS_CU ? 3 : 2;
+  g->lds = g->ns == 3 ? l3 : l2;
   if (g->lds < (size_t)4 * 2 * 2 * 32 * g->WN * sizeof(float)) g->lds = (size_t)4 * 2 * 2 * 32 * g->WN * sizeof(float);
-  if (g->lds > 160 * 1024) return false;
   const int tilesX = (d->Wout + d->TW - 1) / d->TW, tilesY = (d->Hout + d->TH - 1) / d->TH;
   g->tiles = d->B * tilesX * tilesY;
-  int per_cu = (int)(160 * 1024 / g->lds);
-  const int cap = (g->WN == 1 && d->nchunks * taps * g->NTI <= 9) ? 2 : 1;      // = the kernel's __launch_bounds__
+  int per_cu = (int)(LDS_CU / g->lds);
   if (per_cu > cap) per_cu = cap;
   const char* cus_env = getenv("KSMI_IGEMM3_CUS");            // (read per call: the tests shrink the grid to force many rounds)
   const int cus = cus_env ? atoi(cus_env) : 256;
@@ -385,7 +462,9 @@ int ksmi_igemm3_launch(const ksmi_conv_desc* d, const ksmi_igemm3_geom_t* g, hip
   const int HW = (d->TW - 1) * d->stride + d->KW;
   const int tilesX = (d->Wout + d->TW - 1) / d->TW, tilesY = (d->Hout + d->TH - 1) / d->TH;
   ka.m_tw = fastdiv_magic(d->TW); ka.m_hw = fastdiv_magic(HW); ka.m_tx = fastdiv_magic(tilesX); ka.m_ty = fastdiv_magic(tilesY);
-  ka.tiles = g->tiles; ka.hpb = g->hpb; ka.nslot = g->nslot; ka.stage = g->stage;
+  const char* dbg_env = getenv("KSMI_IG3_DBG");
+  ka.dbg = dbg_env ? atoi(dbg_env) : 0;
+  ka.tiles = g->tiles; ka.hpb = g->hpb; ka.nslot = g->nslot; ka.stage = g->stage; ka.ns = g->ns;
   static void* zero_page = nullptr;
   if (!zero_page && hipGetSymbolAddress(&zero_page, HIP_SYMBOL(ig3_zero_page)) != hipSuccess) return ksmi_fail(KSMI_E_UNSUPPORTED, "igemm3: zero page");
   ka.zero = (const unsigned char*)zero_page;
