@@ -21,7 +21,9 @@ class SyntheticCDDataset(torch.utils.data.Dataset):
         return self.n
 
     def __getitem__(self, i):
-        b = make_batch(1, seed=self.seed0 + i, dem=bool(self.cfg.get("dem")), channels=len(self.cfg["channels"]))
+        # SLC tiles: 4 bands per date (utilities/utilities.py:386-390 doubles the SAR channels)
+        nch = len(self.cfg["channels"]) * (2 if self.cfg.get("slc") else 1)
+        b = make_batch(1, seed=self.seed0 + i, dem=bool(self.cfg.get("dem")), channels=nch)
         out = []
         for t in b:
             if isinstance(t, list):

@@ -1,0 +1,119 @@
+"""Process-level data parallelism of the trainers: one process per GPU, launched by
+`python -m torch.distributed.run --nproc-per-node N main.py ...` (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment);
+backend "nccl" (= RCCL over xGMI on ROCm) on GPUs, "gloo" for the CPU tests.
+
+The reference is single-process (training/change_detection_trainer.py, utilities/utilities.py:96-103: one shuffled DataLoader with
+drop_last).  Here every rank builds the SAME loader (same seed => same shuffle order), takes the contiguous shard
+[r*B/W, (r+1)*B/W) of each global batch, trains on it with the fused step (gradient buckets all-reduced during backward,
+kurosiwo_amd/dp.py; 1/W folded into the optimiser kernel), and evaluates its shard of every validation batch; the 4x4 confusion
+matrices and loss sums are all-reduced, so every rank returns the same metrics; only rank 0 prints and writes checkpoints.
+BatchNorm statistics stay per rank (the reference has no SyncBN): results equal a single-GPU run at batch B/W per BN call.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    return int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def init_distributed(configs=None):
+    """Join the process group described by the torchrun environment (no-op for a single process).  Returns (rank, local_rank, world)
+    and, when `configs` is given, records them and points configs['device'] at this rank's GPU."""
+    world = env_world()
+    rank, local = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        # KSMI_DIST_BACKEND=gloo: several ranks on ONE GPU (the single-GPU test box; RCCL refuses duplicate devices)
+        backend = os.environ.get("KSMI_DIST_BACKEND", "nccl" if torch.cuda.is_available() else "gloo")
+        if torch.cuda.is_available():
+            local = local % torch.cuda.device_count() if backend == "gloo" else local
+            torch.cuda.set_device(local)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    if configs is not None:
+        configs["rank"], configs["local_rank"], configs["world_size"] = rank, local, world
+        if world > 1 and torch.cuda.is_available():
+            configs["gpu"] = local
+            configs["device"] = f"cuda:{local}"
+    return rank, local, world
+
+
+def world_size():
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+
+def get_rank():
+    return dist.get_rank() if dist.is_initialized() else 0
+
+
+def is_main():
+    return get_rank() == 0
+
+
+def shard_batch(batch, rank=None, world=None, even=True):
+    """Contiguous rank shard of a collated batch tuple (tensors sliced on dim 0; the lists of per-channel scale tensors of
+    dataset/Dataset.py:824-860 element-wise).  even=True (training: loaders use drop_last): the global batch must divide by the
+    world size; even=False (evaluation: the last batch is ragged): rank r takes [n*r//W, n*(r+1)//W), possibly empty."""
+    rank = get_rank() if rank is None else rank
+    world = world_size() if world is None else world
+    if world == 1:
+        return batch
+
+    def cut(t):
+        if torch.is_tensor(t):
+            n = t.shape[0]
+            if even and n % world:
+                raise ValueError(f"global batch {n} is not divisible by world size {world}")
+            return t[n * rank // world:n * (rank + 1) // world]
+        if isinstance(t, (list, tuple)):
+            return type(t)(cut(x) for x in t)
+        return t
+    return tuple(cut(t) for t in batch)
+
+
+def all_reduce_sum_(*tensors):
+    """In-place SUM over the ranks (confusion matrices, loss / sample counters)."""
+    if world_size() > 1:
+        for t in tensors:
+            if dist.get_backend() == "gloo" and t.is_cuda:          # (CPU-backend tests with device tensors)
+                c = t.cpu()
+                dist.all_reduce(c, op=dist.ReduceOp.SUM)
+                t.copy_(c)
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return tensors
+
+
+def broadcast_model_(model, src=0):
+    """Rank `src`'s parameters, BatchNorm statistics and counters on every rank (the arenas are flat: three broadcasts)."""
+    if world_size() > 1:
+        for name in ("flat_params", "flat_buffers", "flat_counters"):
+            t = getattr(model, name, None)
+            if t is not None and t.numel():
+                if dist.get_backend() == "gloo" and t.is_cuda:
+                    c = t.cpu()
+                    dist.broadcast(c, src)
+                    t.copy_(c)
+                else:
+                    dist.broadcast(t, src)
+    return model
+
+
+def barrier():
+    if world_size() > 1:
+        dist.barrier()
+
+
+def broadcast_object(obj, src=0):
+    """rank `src`'s picklable object on every rank (e.g. the time-stamped checkpoint directory name)."""
+    if world_size() > 1:
+        box = [obj]
+        dist.broadcast_object_list(box, src=src)
+        return box[0]
+    return obj

@@ -46,9 +46,28 @@ class BucketedAllReduce:
         for (s, e, _) in self.by_launch.get(idx, ()):
             self.issued.append((s, e))
             if self.world() > 1 or (_FORCE and dist.is_initialized()):
-                self.handles.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                view = self.flat[s:e]
+                if dist.get_backend(self.group) == "gloo" and view.is_cuda:       # CPU-backend tests with device gradients
+                    torch.cuda.current_stream().synchronize()
+                    host = view.cpu()
+                    dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+                    view.copy_(host)
+                else:
+                    self.handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def flush(self):
+        """issue every bucket that has not been issued yet (a bucket whose readiness index was never reached: a parameter
+        without a registered gradient writer must still be averaged)"""
+        done = set(self.issued)
+        for (s, e, after) in self.buckets:
+            if (s, e) not in done:
+                self.by_launch.setdefault(-2, []).append((s, e, -2))
+        if -2 in self.by_launch:
+            self.after_launch(-2)
+            del self.by_launch[-2]
 
     def wait(self):
+        self.flush()
         for h in self.handles:
             h.wait()
         self.handles = []

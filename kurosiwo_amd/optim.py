@@ -14,17 +14,24 @@ from .runtime import stream_ptr
 
 
 def _arena_of(params):
-    """(base_ptr, numel) if the tensors tile one contiguous fp32 buffer in order, else None."""
+    """(base_ptr, numel) of the flat fp32 arena the tensors are views of, in order, else None.  The arena is taken from the
+    views' common storage (model.flat_params / flat_grads), so its numel is the model's own (SNUNet aligns its views to 4
+    floats, ArenaModule to 8: the padding between views belongs to the arena and the optimiser state must cover it, or the
+    autograd path (`opt.step()`) and the fused path (`step_arena`) would disagree on the state size and reset it)."""
     params = list(params)
-    if not params:
+    if not params or params[0].dtype != torch.float32:
         return None
-    base = params[0].data_ptr()
-    end = base
+    st = params[0].untyped_storage()                       # (nn.Parameter(view) drops ._base; the storage is the arena)
+    lo, nbytes = st.data_ptr(), st.nbytes()
+    if nbytes % 4:
+        return None
+    end = lo
     for p in params:
-        if p.dtype != torch.float32 or not p.is_contiguous() or p.data_ptr() < end or p.data_ptr() - end > 12:
+        if (p.dtype != torch.float32 or not p.is_contiguous() or p.untyped_storage().data_ptr() != lo or p.data_ptr() < end
+                or p.data_ptr() + 4 * p.numel() > lo + nbytes):
             return None
         end = p.data_ptr() + 4 * p.numel()
-    return base, (end - base) // 4
+    return lo, nbytes // 4
 
 
 class _FlatOptimizer(torch.optim.Optimizer):

@@ -9,6 +9,9 @@ import torch
 
 DATA_MEAN = (0.0953, 0.0264)
 DATA_STD = (0.0427, 0.0215)
+# SLC tiles carry 4 bands per date (dataset/Dataset.py:986-1228; configs/train/data_config.json slc_mean / slc_std)
+SLC_MEAN = (0.022367, 39.242, 81.13, 0.043526)
+SLC_STD = (1.2843, 25.6152, 58.0151, 1.2844)
 DEM_MEAN, DEM_STD = 93.4313, 1410.8382
 
 
@@ -28,8 +31,12 @@ def _ellipse_mask(B, H, W, n, gen):
 def make_batch(B, H=224, W=224, seed=999, dem=False, channels=2, device="cpu"):
     """Returns the 12-tuple (13 with dem) of the reference's collated batch."""
     g = torch.Generator().manual_seed(seed)
-    mean = torch.tensor(DATA_MEAN[:channels]).view(1, channels, 1, 1)
-    std = torch.tensor(DATA_STD[:channels]).view(1, channels, 1, 1)
+    if channels > 2:                      # SLC: band statistics of the 4-band product; the speckle model is reused per band
+        base_mean, base_std = (0.0953, 0.0264, 0.0953, 0.0264)[:channels], (0.0427, 0.0215, 0.0427, 0.0215)[:channels]
+    else:
+        base_mean, base_std = DATA_MEAN[:channels], DATA_STD[:channels]
+    mean = torch.tensor(base_mean).view(1, channels, 1, 1)
+    std = torch.tensor(base_std).view(1, channels, 1, 1)
     perm = _ellipse_mask(B, H, W, 2, g)
     flood = _ellipse_mask(B, H, W, 2, g) & ~perm
     mask = torch.zeros((B, H, W), dtype=torch.int64)
@@ -48,7 +55,7 @@ def make_batch(B, H=224, W=224, seed=999, dem=False, channels=2, device="cpu"):
     post = date(perm | flood)
     pre1 = date(perm)
     pre2 = date(perm)
-    sv = lambda v: [torch.full((B,), float(x), dtype=torch.float64) for x in v[:channels]]
+    sv = lambda v: [torch.full((B,), float(x), dtype=torch.float64) for x in (v if channels <= 2 else (SLC_MEAN if v is DATA_MEAN else SLC_STD))[:channels]]
     clz = torch.randint(1, 4, (B,), generator=g, dtype=torch.int64)
     activ = torch.randint(100, 600, (B,), generator=g, dtype=torch.int64)
     items = [sv(DATA_MEAN), sv(DATA_STD), post, mask, sv(DATA_MEAN), sv(DATA_STD), pre1, sv(DATA_MEAN), sv(DATA_STD), pre2]

@@ -13,6 +13,7 @@ from pathlib import Path
 
 import torch
 
+from .. import distributed as D
 from ..config import init_lr_scheduler
 from ..loss import create_loss
 from ..metrics import ConfusionMetrics, metrics_from_cm
@@ -36,6 +37,8 @@ def _make_optimizer(model, configs, model_configs):
 
 
 def _print_metrics(prefix, m, loss):
+    if not D.is_main():
+        return
     print(f"{prefix} loss {loss:.5f} | mIoU {100 * float(m['miou']):.2f} | "
           + " | ".join(f"{CLASS_LABELS[c]}: acc {100 * float(m['accuracy'][c]):.2f} F1 {100 * float(m['f1'][c]):.2f} "
                        f"IoU {100 * float(m['iou'][c]):.2f}" for c in range(3)))
@@ -45,32 +48,36 @@ def train_change_detection(model, train_loader, val_loader, test_loader, configs
     assert len(configs["inputs"]) == 2, f'Model {model_configs["method"]} requires exactly 2 input images.'
     dev = torch.device(configs["device"])
     model.to(dev)
+    D.broadcast_model_(model)                       # identical weights / BatchNorm statistics on every rank (rank 0's)
+    main = D.is_main()
     optimizer = _make_optimizer(model, configs, model_configs)
     lr_scheduler = init_lr_scheduler(optimizer, configs, model_configs, steps=len(train_loader))
     metrics = ConfusionMetrics(dev)
     best_val, loss_val = 0.0, float("nan")
     step = None
-    print(f'===== checkpoint_path: {configs["checkpoint_path"]} ====')
+    if main:
+        print(f'===== checkpoint_path: {configs["checkpoint_path"]} ====')
     for epoch in range(0, configs["epochs"]):
         model.train()
         metrics.reset()
         loss_acc = torch.zeros(3, dtype=torch.float32, device=dev)
         nb = 0
         for index, batch in enumerate(train_loader):
+            batch = D.shard_batch(batch)            # this rank's contiguous slice of the global batch (§8(e))
             (xA, xB), mask = cd_inputs(batch, configs["inputs"], bool(configs["dem"]))
             if step is None or step.B != xA.shape[0]:
                 step = CDTrainStep(model, xA.shape[0], xA.shape[2], xA.shape[3], configs["loss_function"],
-                                   configs.get("class_weights", [1.0, 1.0, 1.0]) if configs["loss_function"] != "cross_entropy"
-                                   or True else [1.0, 1.0, 1.0], optimizer=optimizer)
+                                   configs.get("class_weights", [1.0, 1.0, 1.0]), optimizer=optimizer)
             step.step(xA.to(dev, non_blocking=True), xB.to(dev, non_blocking=True), mask.to(dev, non_blocking=True))
             metrics.update(step.plan.logits, step.labels)
             loss_acc += step.loss_out
             nb += 1
             if configs.get("on_screen_prints") and (index + 1) % configs["print_frequency"] == 0:
                 _print_metrics(f"[{epoch}:{index + 1}]", metrics.compute(), float(loss_acc[0]) / nb)
-        loss_val = float(loss_acc[0]) / max(nb, 1)
+        D.all_reduce_sum_(metrics.cm, loss_acc)
+        loss_val = float(loss_acc[0]) / max(nb, 1) / D.world_size()
         _print_metrics(f"Epoch {epoch} train", metrics.compute(), loss_val)
-        if (epoch + 1) % configs.get("train_save_checkpoint_freq", 1) == 0:
+        if main and (epoch + 1) % configs.get("train_save_checkpoint_freq", 1) == 0:
             torch.save({"epoch": epoch, "model_state_dict": model.state_dict(), "optimizer_state_dict": optimizer.state_dict(),
                         "lr_scheduler_state_dict": lr_scheduler.state_dict(), "loss": loss_val},
                        Path(configs["checkpoint_path"]) / f"checkpoint_epoch={epoch}.pt")
@@ -78,15 +85,17 @@ def train_change_detection(model, train_loader, val_loader, test_loader, configs
         val_acc, val_score, miou = eval_change_detection(model, val_loader, settype="Validation", configs=configs,
                                                          model_configs=model_configs)
         if miou > best_val:
+            best_val = miou
+        if miou >= best_val and main:               # (every rank holds the same all-reduced metrics; rank 0 writes)
             print(f"New best validation mIoU: {miou}")
             print(f'Saving model to: {configs["checkpoint_path"]}/best_segmentation.pt')
-            best_val = miou
             torch.save({"epoch": epoch, "model_state_dict": model.state_dict(), "optimizer_state_dict": optimizer.state_dict(),
                         "lr_scheduler_state_dict": lr_scheduler.state_dict(), "loss": loss_val},
                        Path(configs["checkpoint_path"]) / "best_segmentation.pt")
             with open(Path(configs["checkpoint_path"]) / "best_segmentation.txt", "w") as f:
                 f.write(f"{epoch}\n")
                 f.write(f"{miou}")
+        D.barrier()                                 # checkpoints of this epoch are on disk before any rank moves on
 
 
 def eval_change_detection(model, loader, settype, configs=None, model_configs=None):
@@ -101,7 +110,10 @@ def eval_change_detection(model, loader, settype, configs=None, model_configs=No
     nsamples = 0
     with torch.no_grad():
         for batch in loader:
+            batch = D.shard_batch(batch, even=False)
             (xA, xB), mask = cd_inputs(batch, configs["inputs"], bool(configs["dem"]))
+            if xA.shape[0] == 0:
+                continue
             xA, xB, mask = xA.to(dev), xB.to(dev), mask.to(dev)
             clz, activ = batch[-2], batch[-1]
             output = model(xA, xB)
@@ -116,10 +128,13 @@ def eval_change_detection(model, loader, settype, configs=None, model_configs=No
                         k = int(key[i])
                         if k in group:
                             group[k].update(output[i:i + 1], mask[i:i + 1])
+    ns = torch.tensor([float(nsamples)], dtype=torch.float64, device=dev)
+    D.all_reduce_sum_(metrics.cm, total_loss, ns, *[g.cm for g in list(per_aoi.values()) + list(per_zone.values())])
+    nsamples = int(ns.item())
     m = metrics.compute()
     loss = float(total_loss) / max(nsamples, 1)
     _print_metrics(f"{settype}", m, loss)
-    if configs.get("evaluate_water"):
+    if configs.get("evaluate_water") and D.is_main():
         cm = metrics.cm.cpu().double()
         # water-only F1: classes {1,2} merged (cd_trainer:414-419)
         w = torch.zeros((4, 4), dtype=torch.float64)
@@ -131,7 +146,7 @@ def eval_change_detection(model, loader, settype, configs=None, model_configs=No
         print(f'{settype} water-only F1: no-water {100 * float(wm["f1"][0]):.2f} water {100 * float(wm["f1"][1]):.2f}')
     for name, group in (("AOI", per_aoi), ("climate zone", per_zone)):
         for k, cmx in group.items():
-            if int(cmx.cm.sum()) > 0:
+            if int(cmx.cm.sum()) > 0 and D.is_main():
                 gm = cmx.compute()
                 print(f"{settype} {name} {k}: mIoU {100 * float(gm['miou']):.2f}")
     return 100 * m["accuracy"], 100 * m["f1"][:3].mean(), 100 * m["miou"]

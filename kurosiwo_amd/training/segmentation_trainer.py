@@ -12,6 +12,7 @@ from pathlib import Path
 
 import torch
 
+from .. import distributed as D
 from ..config import init_lr_scheduler
 from ..loss import create_loss
 from ..metrics import ConfusionMetrics, metrics_from_cm
@@ -24,6 +25,8 @@ from .change_detection_trainer import _print_metrics
 def train_semantic_segmentation(model, train_loader, val_loader, test_loader, configs, model_configs):
     dev = torch.device(configs["device"])
     model.to(dev)
+    D.broadcast_model_(model)
+    main = D.is_main()
     optimizer = FusedAdam(model.parameters(), lr=model_configs["learning_rate"])
     lr_scheduler = init_lr_scheduler(optimizer, configs, model_configs, steps=len(train_loader))
     metrics = ConfusionMetrics(dev)
@@ -36,6 +39,7 @@ def train_semantic_segmentation(model, train_loader, val_loader, test_loader, co
         loss_acc = torch.zeros(3, dtype=torch.float32, device=dev)
         nb = 0
         for index, batch in enumerate(train_loader):
+            batch = D.shard_batch(batch)
             image, mask = seg_inputs(batch, configs["inputs"], bool(configs["dem"]))
             if step is None or step.B != image.shape[0]:
                 step = SegTrainStep(model, image.shape[0], configs["loss_function"], weights, optimizer=optimizer,
@@ -46,21 +50,24 @@ def train_semantic_segmentation(model, train_loader, val_loader, test_loader, co
             nb += 1
             if configs.get("on_screen_prints") and (index + 1) % configs["print_frequency"] == 0:
                 _print_metrics(f"[{epoch}:{index + 1}]", metrics.compute(), float(loss_acc[0]) / nb)
-        _print_metrics(f"Epoch {epoch} train", metrics.compute(), float(loss_acc[0]) / max(nb, 1))
+        D.all_reduce_sum_(metrics.cm, loss_acc)
+        _print_metrics(f"Epoch {epoch} train", metrics.compute(), float(loss_acc[0]) / max(nb, 1) / D.world_size())
         lr_scheduler.step()
         model.eval()
         val_acc, val_score, miou = eval_semantic_segmentation(model, val_loader, settype="Val", configs=configs,
                                                               model_configs=model_configs)
         if miou > best_val:
+            best_val = miou
+            best_stats["miou"], best_stats["epoch"] = best_val, epoch
+        if miou >= best_val and main:
             print("Epoch: ", epoch)
             print("New best validation mIOU: ", float(miou))
             print("Saving model to: ", configs["checkpoint_path"] + "/" + "best_segmentation.pt")
-            best_val = miou
-            best_stats["miou"], best_stats["epoch"] = best_val, epoch
             model._plans = {}                 # plans hold device buffers and ctypes descriptors: not part of the pickle
             torch.save(model, Path(configs["checkpoint_path"]) / "best_segmentation.pt")
             torch.save({"epoch": epoch, "model_state_dict": model.state_dict()},
                        Path(configs["checkpoint_path"]) / "best_segmentation_state.pt")
+        D.barrier()
     return best_stats
 
 
@@ -76,7 +83,10 @@ def eval_semantic_segmentation(model, loader, configs=None, settype="Test", mode
     nsamples = 0
     with torch.no_grad():
         for batch in loader:
+            batch = D.shard_batch(batch, even=False)
             image, mask = seg_inputs(batch, configs["inputs"], bool(configs["dem"]))
+            if image.shape[0] == 0:
+                continue
             image, mask = image.to(dev), mask.to(dev)
             clz, activ = batch[-2], batch[-1]
             output = model(image)
@@ -89,9 +99,12 @@ def eval_semantic_segmentation(model, loader, configs=None, settype="Test", mode
                         k = int(key[i])
                         if k in group:
                             group[k].update(output[i:i + 1], mask[i:i + 1])
+    ns = torch.tensor([float(nsamples)], dtype=torch.float64, device=dev)
+    D.all_reduce_sum_(metrics.cm, total_loss, ns, *[g.cm for g in list(per_aoi.values()) + list(per_zone.values())])
+    nsamples = int(ns.item())
     m = metrics.compute()
     _print_metrics(f"{settype}", m, float(total_loss) / max(nsamples, 1))
-    if configs.get("evaluate_water"):
+    if configs.get("evaluate_water") and D.is_main():
         cm = metrics.cm.cpu().double()
         w = torch.zeros((4, 4), dtype=torch.float64)
         w[0, 0], w[0, 1], w[1, 0], w[1, 1] = cm[0, 0], cm[0, 1] + cm[0, 2], cm[1, 0] + cm[2, 0], cm[1:3, 1:3].sum()
@@ -99,6 +112,6 @@ def eval_semantic_segmentation(model, loader, configs=None, settype="Test", mode
         print(f'{settype} water-only F1: no-water {100 * float(wm["f1"][0]):.2f} water {100 * float(wm["f1"][1]):.2f}')
     for name, group in (("AOI", per_aoi), ("climate zone", per_zone)):
         for k, cmx in group.items():
-            if int(cmx.cm.sum()) > 0:
+            if int(cmx.cm.sum()) > 0 and D.is_main():
                 print(f"{settype} {name} {k}: mIoU {100 * float(cmx.compute()['miou']):.2f}")
     return 100 * m["accuracy"], 100 * m["f1"][:3].mean(), 100 * m["miou"]

@@ -1,0 +1,76 @@
+"""CPU, world_size 2, gloo: the process-level data-parallel plumbing of the trainers (kurosiwo_amd/distributed.py): contiguous
+rank shards of the collated batch tuple, summed confusion matrices / loss counters, rank-0 weights on every rank, rank-0-named
+checkpoint directory.  The same calls run over RCCL ("nccl") under torchrun on the GPUs."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from kurosiwo_amd import distributed as D
+from kurosiwo_amd.synthetic import cd_inputs, make_batch
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_shard_batch_is_a_contiguous_partition():
+    batch = make_batch(8, 16, 16, seed=5, dem=True)
+    parts = [D.shard_batch(batch, r, 4) for r in range(4)]
+    for idx in (2, 3, 6, 9, 10, 11, 12):                      # post, mask, pre1, pre2, dem, clz, activation
+        assert torch.equal(torch.cat([p[idx] for p in parts], 0), batch[idx])
+    assert all(len(p[0]) == 2 and p[0][0].shape == (2,) for p in parts)      # per-channel scale lists are sliced too
+    (xA, xB), mask = cd_inputs(parts[1], ("pre_event_1", "post_event"), True)
+    assert xA.shape == (2, 3, 16, 16) and mask.shape == (2, 16, 16)
+    # ragged evaluation batches: sizes differ by at most one, nothing lost
+    rag = [D.shard_batch(tuple(t[:5] if torch.is_tensor(t) else [x[:5] for x in t] for t in batch), r, 4, even=False) for r in range(4)]
+    assert [p[2].shape[0] for p in rag] == [1, 1, 1, 2]
+    assert D.shard_batch(batch, 0, 1) is batch
+    try:
+        D.shard_batch(tuple(t[:6] if torch.is_tensor(t) else t for t in batch), 0, 4)
+        assert False, "uneven training batch must raise"
+    except ValueError:
+        pass
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world))
+    cfg = {"device": "cpu", "gpu": None}
+    r, lr, w = D.init_distributed(cfg)
+    assert (r, w) == (rank, world) and cfg["world_size"] == world and D.is_main() == (rank == 0)
+    cm = torch.full((4, 4), rank + 1, dtype=torch.int64)
+    loss = torch.tensor([float(rank + 1)])
+    D.all_reduce_sum_(cm, loss)
+
+    class M:                                                # the three arenas of an ArenaModule
+        flat_params = torch.full((10,), float(rank))
+        flat_buffers = torch.full((4,), float(rank) + 0.5)
+        flat_counters = torch.full((2,), rank, dtype=torch.int64)
+    D.broadcast_model_(M)
+    path = D.broadcast_object(f"checkpoints/run_{rank}" if rank == 0 else None)
+    D.barrier()
+    q.put((rank, int(cm[0, 0]), float(loss), float(M.flat_params[0]), float(M.flat_buffers[0]), int(M.flat_counters[0]), path))
+    dist.destroy_process_group()
+
+
+def test_world2_gloo_reductions_and_broadcasts():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, cm00, loss, p0, b0, c0, path in res:
+        assert cm00 == 3 and loss == 3.0                      # SUM over ranks
+        assert (p0, b0, c0) == (0.0, 0.5, 0)                  # rank 0's arenas everywhere
+        assert path == "checkpoints/run_0"

@@ -1,0 +1,137 @@
+"""Data parallelism on a real model: two ranks training on the two halves of a batch must take the
+same optimiser step as one rank on the whole batch.  Both ranks share the one GPU of the test box, so the process group is gloo
+(device gradients staged through the host by kurosiwo_amd/dp.py); on a multi-GPU node the identical code runs over RCCL.
+BN-free model (FloodViT, fp32): equality to rounding.  SNUNet keeps per-rank BatchNorm statistics (the reference has no SyncBN),
+so its two-rank step equals the single-rank step only through the BN-free parameters; that is checked as a documented property."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+SMALL = dict(channels=6, image_size=224, patch_size=16, dim=1024, depth=2, heads=4, mlp_dim=512)
+CFG = {"mlp": False, "decoder": True, "num_classes": 3, "image_size": 224, "finetuning_patch_size": 16}
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _build():
+    from kurosiwo_amd.floodvit import FinetunerSegmentation, ViT
+    from oracle import vit_ref as V
+    from oracle.seeded import seeded_fill_
+    hp = SMALL
+    enc = ViT(image_size=hp["image_size"], patch_size=hp["patch_size"], num_classes=1000, dim=hp["dim"], depth=hp["depth"],
+              heads=hp["heads"], mlp_dim=hp["mlp_dim"], channels=hp["channels"])
+    model = FinetunerSegmentation(enc, CFG, precision="fp32")
+    model.load_state_dict(seeded_fill_(V.new_state_dict(**hp)))
+    return model.cuda().train()
+
+
+def _data(B):
+    from oracle.seeded import seeded_labels, seeded_tensor
+    x = seeded_tensor("dp.x", (B, 6, 224, 224)).clamp_(-2.23, 5.75)
+    lbl = seeded_labels("dp.lbl", (B, 224, 224), p_invalid=0.0)        # no ignored pixels: every shard normalises by the same count
+    return x, lbl
+
+
+def _steps(model, x, lbl, n):
+    from kurosiwo_amd.optim import FusedSGD
+    from kurosiwo_amd.trainer import SegTrainStep
+    # plain SGD: the parameter update is linear in the gradient (Adam turns rounding noise of near-zero gradients into +-lr steps)
+    step = SegTrainStep(model, x.shape[0], "cross_entropy", [1.0, 1.0, 1.0], optimizer=FusedSGD(model.parameters(), lr=0.05),
+                        bucket_mb=16.0)
+    losses = []
+    for _ in range(n):
+        losses.append(float(step.step(x.cuda(), lbl.cuda())[0]))
+    torch.cuda.synchronize()
+    return losses, step
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from kurosiwo_amd import distributed as D
+    model = _build()
+    if rank == 1:
+        model.flat_params.mul_(1.5)                     # a rank that started from different weights ...
+    D.broadcast_model_(model)                           # ... is overwritten by rank 0's
+    x, lbl = _data(4)
+    xs, ls = D.shard_batch((x, lbl), rank, world)
+    losses, step = _steps(model, xs, ls, 2)
+    covered = sum(e - s for s, e, _ in step.reducer.buckets)
+    q.put((rank, losses, model.flat_params.detach().cpu().numpy(), covered == model.flat_params.numel()))   # (by value)
+    dist.destroy_process_group()
+
+
+def test_two_rank_step_equals_single_rank_step_on_the_whole_batch():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    model = _build()
+    p0 = model.flat_params.detach().cpu().clone()
+    x, lbl = _data(4)
+    losses, _ = _steps(model, x, lbl, 2)
+    ref = model.flat_params.detach().cpu()
+    (r0, l0, w0, c0), (r1, l1, w1, c1) = res
+    w0, w1 = torch.from_numpy(w0), torch.from_numpy(w1)
+    assert c0 and c1, "gradient buckets must cover the whole arena"
+    assert torch.equal(w0, w1), "ranks diverged"
+    upd = (ref - p0).abs().max()
+    assert float((w0 - ref).abs().max()) < 1e-3 * float(upd) + 1e-7, (float((w0 - ref).abs().max()), float(upd))
+    # mean of the shard losses = loss of the whole batch (equal shard sizes, no ignored pixels)
+    for k in range(2):
+        assert abs(0.5 * (l0[k] + l1[k]) - losses[k]) < 2e-4 * abs(losses[k]), (k, l0[k], l1[k], losses[k])
+
+
+def test_every_parameter_with_a_gradient_has_a_readiness_index():
+    """A parameter missing from plan.param_ready would be reduced before (or never after) its writer ran."""
+    from kurosiwo_amd.snunet import SNUNet_ECAM
+    m = SNUNet_ECAM(2, 3, base_channel=16, precision="bf16").cuda().train()
+    plan = m.plan(2, 32, 32, True, True)
+    missing = [k for k in m._poff if k not in plan.param_ready]
+    assert not missing, missing
+    assert max(plan.param_ready.values()) == len(plan.bwd.calls) - 1
+
+
+def test_main_entry_under_torchrun_two_ranks(tmp_path):
+    """`python -m torch.distributed.run --nproc-per-node 2 main.py --method snunet ...`: both ranks join the group, shard every batch,
+    all-reduce gradients / confusion matrices, rank 0 alone writes the checkpoints, every rank reports the same test mIoU."""
+    import re
+    import shutil
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    shutil.copytree(os.path.join(root, "configs"), tmp_path / "configs")
+    env = dict(os.environ, KSMI_SYNTHETIC_TILES="8,4,4", KSMI_DIST_BACKEND="gloo", PYTHONPATH=root, MASTER_ADDR="127.0.0.1")
+    wrapper = tmp_path / "run_main.py"
+    wrapper.write_text("import os, sys\nsys.path.insert(0, %r)\nimport main\nm = main.main(sys.argv[1:])\n"
+                       "print('RANK', os.environ['RANK'], 'MIOU', repr(float(m)), flush=True)\n" % root)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(wrapper), "--method", "snunet", "--inputs", "pre_event_1", "post_event", "--batch_size", "4"]
+    out = subprocess.run(cmd, cwd=tmp_path, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    mious = dict(re.findall(r"RANK (\d) MIOU ([0-9.e+-]+)", out.stdout))
+    assert set(mious) == {"0", "1"}, out.stdout[-2000:]
+    assert mious["0"] == mious["1"], mious
+    runs = list((tmp_path / "checkpoints" / "snunet").glob("*"))
+    assert len(runs) == 1, runs                      # one time-stamped directory, named by rank 0
+    assert (runs[0] / "best_segmentation.pt").exists()
+    assert out.stdout.count("Samples in Train Set") >= 1
