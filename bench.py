@@ -95,6 +95,7 @@ def main():
                          "floodvit = configs[4] per-GPU shard (bs 16)")
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (weak scaling); default 32 snunet/changeformer, 16 floodvit")
     ap.add_argument("--base-channel", type=int, default=32)
+    ap.add_argument("--channels", type=int, default=2, help="bands per date: 2 = GRD (VV, VH), 4 = SLC (BASELINE.json configs[3] as written)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--time-all", action="store_true", help="HIP-event time every kernel class (diagnostic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -124,7 +125,7 @@ def main():
 
     B, H, W = args.batch or (16 if args.model == "floodvit" else 32), 224, 224
     torch.manual_seed(999)                      # same init on every rank (reference default seed, main.py:36)
-    batch = make_batch(B, H, W, seed=999 + rank)
+    batch = make_batch(B, H, W, seed=999 + rank, channels=args.channels if args.model == "changeformer" else 2)
     if args.model == "snunet":
         from kurosiwo_amd.snunet import SNUNet_ECAM
         from kurosiwo_amd.trainer import CDTrainStep
@@ -139,12 +140,12 @@ def main():
         from kurosiwo_amd.changeformer import ChangeFormerV6
         from kurosiwo_amd.optim import FusedSGD
         from kurosiwo_amd.trainer import CDTrainStep
-        model = ChangeFormerV6(input_nc=2, output_nc=3, decoder_softmax=True, embed_dim=256, precision=args.precision).to(dev).train()
+        model = ChangeFormerV6(input_nc=args.channels, output_nc=3, decoder_softmax=True, embed_dim=256, precision=args.precision).to(dev).train()
         opt = FusedSGD(model.parameters(), lr=6e-4, momentum=0.99, weight_decay=1e-5)      # configs/method/changeformer/changeformer.json
         step = CDTrainStep(model, B, H, W, loss_function="ce+dice", optimizer=opt, bucket_mb=16.0)
         (xA, xB), mask = cd_inputs(batch, ("pre_event_1", "post_event"))
         step.set_batch(xA.to(dev), xB.to(dev), mask.to(dev))
-        workload = ("BASELINE.json configs[3]: ChangeFormerV6 CD (embed 256), 2 dates x 2-ch 224x224, "
+        workload = (f"BASELINE.json configs[3]: ChangeFormerV6 CD (embed 256), 2 dates x {args.channels}-ch {'SLC' if args.channels == 4 else 'GRD'} 224x224, "
                     f"per-GPU batch {B}, ce+dice on the sigmoid map, SGD(0.99, wd 1e-5), fwd+loss+bwd+optimizer")
         metric = "SAR tiles/sec (224x224, ChangeFormerV6 change-detection train step)"
     elif args.model == "unet":

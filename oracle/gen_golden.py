@@ -403,6 +403,60 @@ def gen_changeformer():
     np.savez_compressed(os.path.join(OUT, "changeformer.npz"), **out)
 
 
+def gen_changeformer_slc():
+    """BASELINE.json configs[3] as written: SLC tiles, 4 bands per date (dataset/Dataset.py:986-1228; utilities/utilities.py:386-390
+    doubles num_channels) -> ChangeFormerV6(input_nc=4).  Small fixture: eval outputs, train loss, gradient statistics, the first
+    patch-embedding gradient (the only tensor whose shape depends on input_nc)."""
+    ChangeFormerV6 = _import_changeformer_reference()
+    out = {}
+    c = 4
+
+    def ref_model():
+        m = ChangeFormerV6(input_nc=c, output_nc=3, decoder_softmax=True, embed_dim=256)
+        seeded_fill_(m.state_dict())
+        return m
+    model = ref_model()
+    sd = model.state_dict()
+    out["state_dict_keys"] = np.array(list(sd.keys()))
+    out["state_dict_shapes"] = np.array([",".join(str(d) for d in v.shape) for v in sd.values()])
+    x1 = sar_like("changeformer.slc.eval.x1", (1, c, 224, 224))
+    x2 = sar_like("changeformer.slc.eval.x2", (1, c, 224, 224))
+    model.eval()
+    with torch.no_grad():
+        outs = model(x1, x2)
+    for i, o in enumerate(outs[:4]):
+        out[f"eval.out{i}"] = o.numpy().copy()
+    out["eval.out4_sub"] = outs[4][:, :, ::8, ::8].numpy().copy()
+    out["eval.argmax"] = outs[4].argmax(1).numpy().astype(np.uint8)
+    top2 = outs[4].topk(2, dim=1).values
+    out["eval.margin"] = (top2[:, 0] - top2[:, 1]).numpy().astype(np.float16)
+    x1 = sar_like("changeformer.slc.train.x1", (2, c, 224, 224))
+    x2 = sar_like("changeformer.slc.train.x2", (2, c, 224, 224))
+    lbl = seeded_labels("changeformer.slc.train.lbl", (2, 224, 224))
+    model = ref_model()
+    model.train()
+    for mod in model.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+        if hasattr(mod, "drop_prob"):
+            mod.drop_prob = 0.0
+    crit = BCEandDiceLoss(weights=CLASS_WEIGHTS, ignore_index=3, use_softmax=True)
+    outs = model(x1, x2)
+    loss = crit(outs[-1], lbl)
+    loss.backward()
+    out["train.out4_sub"] = outs[4][:, :, ::8, ::8].detach().numpy().copy()
+    out["train.loss"] = np.array(float(loss.detach()))
+    for k, p in model.named_parameters():
+        if p.grad is None:                     # (parameters outside the graph of output[-1]: the multi-scale prediction heads)
+            out[f"gstat.{k}"] = np.zeros(3)
+            continue
+        g = p.grad.detach().double()
+        out[f"gstat.{k}"] = np.array([float(g.norm()), float(g.sum()), float(g.abs().max())])
+    out["grad.Tenc_x2.patch_embed1.proj.weight"] = dict(model.named_parameters())["Tenc_x2.patch_embed1.proj.weight"].grad.detach().numpy().copy()
+    print("changeformer slc train loss", float(loss.detach()), "keys", len(sd))
+    np.savez_compressed(os.path.join(OUT, "changeformer_slc.npz"), **out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -418,5 +472,7 @@ if __name__ == "__main__":
         gen_floodvit("full", FLOODVIT_FULL, 1)
     if not only or "changeformer" in only:
         gen_changeformer()
+    if not only or "changeformer_slc" in only:
+        gen_changeformer_slc()
     if not only or "mae" in only:
         gen_mae()

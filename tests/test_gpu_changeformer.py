@@ -170,3 +170,64 @@ def test_main_entry_changeformer_end_to_end_tiny(tmp_path, monkeypatch):
     assert ck, "best checkpoint missing"
     d = torch.load(ck[0], map_location="cpu")
     assert len(d["model_state_dict"]) == 373
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_slc_four_band_inputs_vs_reference_golden(golden_dir, precision):
+    """BASELINE.json configs[3] as written: SLC tiles, 4 bands per date -> ChangeFormerV6(input_nc=4).  HIP path against the golden
+    vectors of the REAL reference (tests/golden/changeformer_slc.npz): eval probability maps + argmax, train loss, gradients."""
+    from kurosiwo_amd.changeformer import ChangeFormerV6
+    from kurosiwo_amd.loss import BCEandDiceLoss
+    from oracle import changeformer_ref as R
+    from oracle.seeded import seeded_fill_, seeded_labels
+    gold = np.load(os.path.join(golden_dir, "changeformer_slc.npz"))
+    model = ChangeFormerV6(4, 3, decoder_softmax=True, embed_dim=256, precision=precision)
+    sd = seeded_fill_(R.new_state_dict(4, 3, 256))
+    assert list(model.state_dict().keys()) == list(gold["state_dict_keys"])
+    model.load_state_dict(sd)
+    model = model.cuda().eval()
+    x1 = sar_like("changeformer.slc.eval.x1", (1, 4, 224, 224))
+    x2 = sar_like("changeformer.slc.eval.x2", (1, 4, 224, 224))
+    with torch.no_grad():
+        outs = model(x1.cuda(), x2.cuda())
+    def close(a, b, what):
+        e = np.abs(a - b)
+        if precision == "fp32":
+            assert e.max() < 1e-3, (what, e.max())
+        else:                       # bf16 storage through 13 blocks: bound the mean tightly, the maximum loosely
+            assert e.mean() < 1e-2 and e.max() < 0.15, (what, e.mean(), e.max())
+    for i in range(4):
+        close(outs[i].cpu().numpy(), gold[f"eval.out{i}"], i)
+    close(outs[4].cpu()[:, :, ::8, ::8].numpy(), gold["eval.out4_sub"], 4)
+    margin = gold["eval.margin"].astype(np.float32)
+    band = 2e-3 if precision == "fp32" else 0.12
+    am = outs[4].argmax(1).cpu().numpy().astype(np.uint8)
+    assert (am == gold["eval.argmax"])[margin > band].all()
+    inband = int((am != gold["eval.argmax"]).sum())
+    assert inband <= (50 if precision == "fp32" else 0.02 * am.size), inband      # bounded, not just printed
+    # train step: loss + gradients (stochastic layers at p = 0 on both sides)
+    model.train()
+    x1 = sar_like("changeformer.slc.train.x1", (2, 4, 224, 224))
+    x2 = sar_like("changeformer.slc.train.x2", (2, 4, 224, 224))
+    lbl = seeded_labels("changeformer.slc.train.lbl", (2, 224, 224))
+    outs = model(x1.cuda(), x2.cuda())
+    loss = BCEandDiceLoss(weights=CLASS_WEIGHTS, ignore_index=3, use_softmax=True)(outs[-1], lbl.cuda())
+    loss.backward()
+    assert abs(float(loss) - float(gold["train.loss"])) < (3e-4 if precision == "fp32" else 3e-2)
+    assert np.abs(outs[4].detach().cpu()[:, :, ::8, ::8].numpy() - gold["train.out4_sub"]).max() < (1e-3 if precision == "fp32" else 0.35)
+    k = "Tenc_x2.patch_embed1.proj.weight"
+    g = dict(model.named_parameters())[k].grad.detach().float().cpu().numpy()
+    assert g.shape == (64, 4, 7, 7)
+    ref = gold[f"grad.{k}"]
+    cos = float((g.astype(np.float64) * ref).sum() / (np.linalg.norm(g.astype(np.float64)) * np.linalg.norm(ref.astype(np.float64)) + 1e-30))
+    assert cos > (0.999 if precision == "fp32" else 0.9), cos
+    if precision == "fp32":
+        bad = {}
+        for kk, p in model.named_parameters():
+            st = gold[f"gstat.{kk}"]
+            nrm = float(p.grad.double().norm()) if p.grad is not None else 0.0
+            if kk == "TDec_x2.linear_fuse.0.bias":
+                continue                      # conv bias in front of BatchNorm: analytically zero
+            if abs(nrm - st[0]) > 2e-2 * st[0] + 1e-6:
+                bad[kk] = (nrm, st[0])
+        assert not bad, dict(list(bad.items())[:8])

@@ -68,3 +68,32 @@ def test_train_step(gold):
         assert np.abs(new_stats[f"{k}.running_mean"].numpy() - gold[f"bn.{k}.running_mean"]).max() < 1e-4
         assert np.abs(new_stats[f"{k}.running_var"].numpy() - gold[f"bn.{k}.running_var"]).max() < 1e-3 * max(1.0, float(gold[f"bn.{k}.running_var"].max()))
         assert int(new_stats[f"{k}.num_batches_tracked"]) == int(gold[f"bn.{k}.num_batches_tracked"])
+
+
+def test_slc_four_band_inputs(golden_dir):
+    """BASELINE.json configs[3] as written (SLC, 4 bands per date -> input_nc = 4, utilities/utilities.py:386-390): the oracle against the
+    reference's golden vectors for that configuration (eval outputs, train loss, gradient norms, the first patch-embedding gradient)."""
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    gold = np.load(os.path.join(golden_dir, "changeformer_slc.npz"))
+    spec = R.changeformer_state_dict_spec(4, 3, 256)
+    assert list(spec.keys()) == list(gold["state_dict_keys"])
+    assert [",".join(str(d) for d in s) for s in spec.values()] == list(gold["state_dict_shapes"])
+    sd = seeded_fill_(R.new_state_dict(4, 3, 256))
+    x1 = sar_like("changeformer.slc.eval.x1", (1, 4, 224, 224))
+    x2 = sar_like("changeformer.slc.eval.x2", (1, 4, 224, 224))
+    with torch.no_grad():
+        outs = R.changeformer_forward(sd, x1, x2, training=False)
+    for i in range(4):
+        assert np.abs(outs[i].numpy() - gold[f"eval.out{i}"]).max() < 1e-4
+    assert np.abs(outs[4][:, :, ::8, ::8].numpy() - gold["eval.out4_sub"]).max() < 1e-4
+    x1 = sar_like("changeformer.slc.train.x1", (2, 4, 224, 224))
+    x2 = sar_like("changeformer.slc.train.x2", (2, 4, 224, 224))
+    lbl = seeded_labels("changeformer.slc.train.lbl", (2, 224, 224))
+    outs, loss, grads, _ = R.loss_and_grads(sd, x1, x2, lbl, CLASS_WEIGHTS, True)
+    assert abs(loss - float(gold["train.loss"])) < 1e-5
+    for k, g in grads.items():
+        ref = gold[f"gstat.{k}"]
+        assert abs(float(g.double().norm()) - ref[0]) <= 2e-3 * ref[0] + 1e-7, k
+    k = "Tenc_x2.patch_embed1.proj.weight"
+    assert tuple(grads[k].shape) == (64, 4, 7, 7)
+    assert np.abs(grads[k].numpy() - gold[f"grad.{k}"]).max() <= 2e-3 * np.abs(gold[f"grad.{k}"]).max() + 1e-8
