@@ -1,0 +1,61 @@
+"""Golden vectors of the bf16 parity gate of SURVEY.md §8(d)(ii): "mIoU within +-0.002 of CPU fp32 after an identical K-step training
+run from identical weights on the 64 held-out tiles (seed 424242)".
+
+TEST INFRASTRUCTURE.  Runs the CPU oracle (oracle/snunet_ref.py: pinned to /root/reference/models/snunet.py + utilities/bce_and_dice.py
+by tests/golden/snunet_*.npz) -- fp32, 40 Adam steps of ce+dice on batches of 4 synthetic tiles, then eval-mode inference on the 64
+held-out tiles after 20 and after 40 steps -- and stores the loss trajectory, the 4x4 confusion matrix, per-class IoU and mIoU in tests/golden/snunet_parity_run.npz.
+The GPU test (tests/test_gpu_parity_gate.py) repeats the run on the HIP path in bf16 and in fp32 from the same weights and tiles.
+
+    python oracle/gen_parity_run.py          # ~3 minutes on 8 CPU threads
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from kurosiwo_amd.synthetic import cd_inputs, make_batch  # noqa: E402  (host-side tile generator, no device code)
+from oracle import metrics_ref, snunet_ref as R  # noqa: E402
+from oracle.seeded import seeded_fill_  # noqa: E402
+
+K_STEPS, TRAIN_TILES, BATCH, HELD_OUT, HELD_OUT_SEED, TRAIN_SEED = 40, 8, 4, 64, 424242, 31337
+CHECKPOINTS = (20, 40)      # evaluate after this many steps: 20 = still on the steep part of the learning curve, 40 = on the plateau
+
+
+def protocol_tiles():
+    (xA, xB), mask = cd_inputs(make_batch(TRAIN_TILES, seed=TRAIN_SEED), ("pre_event_1", "post_event"))
+    (eA, eB), emask = cd_inputs(make_batch(HELD_OUT, seed=HELD_OUT_SEED), ("pre_event_1", "post_event"))
+    return (xA, xB, mask), (eA, eB, emask)
+
+
+def main():
+    torch.set_num_threads(8)
+    (xA, xB, mask), (eA, eB, emask) = protocol_tiles()
+    sd = seeded_fill_(R.new_state_dict(2, 3, 32))
+    opt = R.AdamRef(sd, lr=1e-3)
+    losses, out = [], {}
+
+    def evaluate(tag):
+        cm = np.zeros((4, 4), np.int64)
+        with torch.no_grad():
+            for s in range(0, HELD_OUT, 8):
+                logits = R.snunet_forward(sd, eA[s:s + 8], eB[s:s + 8], training=False)
+                cm += metrics_ref.confusion_matrix(metrics_ref.argmax_lowest_index(logits.numpy()), emask[s:s + 8].numpy())
+        m = metrics_ref.metrics_from_cm(cm)
+        print(tag, "cm\n", cm, "\niou", m["iou"], "miou", m["miou"], flush=True)
+        out[f"cm{tag}"], out[f"iou{tag}"], out[f"miou{tag}"], out[f"f1{tag}"] = cm, m["iou"], np.array(m["miou"]), m["f1"]
+    for k in range(K_STEPS):
+        s = (k % (TRAIN_TILES // BATCH)) * BATCH
+        loss, _, _ = R.train_step(sd, opt, xA[s:s + BATCH], xB[s:s + BATCH], mask[s:s + BATCH])
+        losses.append(loss)
+        print(f"step {k}: loss {loss:.6f}", flush=True)
+        if k + 1 in CHECKPOINTS:
+            evaluate(str(k + 1))
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "snunet_parity_run.npz"), losses=np.array(losses),
+                        protocol=np.array([K_STEPS, TRAIN_TILES, BATCH, HELD_OUT, HELD_OUT_SEED, TRAIN_SEED]), **out)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,76 @@
+"""The bf16 parity gate of SURVEY.md §8(d)(ii): after an identical K-step training run from identical weights, the mIoU of the HIP
+path on the 64 held-out synthetic tiles (seed 424242) is within +-0.002 of the CPU fp32 run.
+
+The CPU side is the oracle's run (oracle/gen_parity_run.py -> tests/golden/snunet_parity_run.npz: 40 Adam steps of ce+dice on
+batches of 4 tiles, eval-mode inference on the held-out tiles after 20 and after 40 steps; 130 s on 8 CPU threads, so it is a
+committed fixture rather than recomputed here).  The HIP side repeats the protocol through the fused train step in bf16 (the
+benchmarked dtype) and in fp32.
+
+What is asserted, and why two checkpoints.  K = 40 is on the plateau of the learning curve (mIoU 0.986): there the gate is the
+survey's +-0.002 for bf16 (fp32: 5e-4).  K = 20 is on the steep part (mIoU rises 0.66 -> 0.97 between steps 10 and 20): fp32 HIP
+still tracks the CPU run to 2e-4, while a bf16 TRAINING trajectory is a slightly different trajectory and sits up to 0.015 lower
+at that step before it rejoins (measured: -0.0144 at 20, +0.0011 at 40, -0.0005 at 80); bf16 INFERENCE is not the cause -- evaluating
+the same weights in bf16 and in fp32 differs by < 5e-5 mIoU (last assertion).  The K = 20 bf16 bound (0.03) records that behaviour.
+Reference semantics: training/change_detection_trainer.py:135-180 (step), :152,189 (argmax, mIoU = IoU[:3].mean())."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_kstep_run_miou_matches_cpu_fp32_oracle(golden_dir, precision):
+    from kurosiwo_amd.snunet import SNUNet_ECAM
+    from kurosiwo_amd.trainer import CDTrainStep
+    from oracle import metrics_ref, snunet_ref as R
+    from oracle.gen_parity_run import BATCH, CHECKPOINTS, HELD_OUT, K_STEPS, TRAIN_TILES, protocol_tiles
+    from oracle.seeded import seeded_fill_
+    gold = np.load(os.path.join(golden_dir, "snunet_parity_run.npz"))
+    assert list(gold["protocol"][:4]) == [K_STEPS, TRAIN_TILES, BATCH, HELD_OUT] and CHECKPOINTS == (20, 40)
+    dev = torch.device("cuda:0")
+    (xA, xB, mask), (eA, eB, emask) = protocol_tiles()
+    model = SNUNet_ECAM(2, 3, base_channel=32, precision=precision)
+    model.load_state_dict(seeded_fill_(R.new_state_dict(2, 3, 32)))
+    model = model.to(dev).train()
+    step = CDTrainStep(model, BATCH, 224, 224, loss_function="ce+dice", class_weights=(1.0, 1.0, 1.0), lr=1e-3)
+
+    def evaluate(m):
+        m.eval()
+        cm = np.zeros((4, 4), np.int64)
+        with torch.no_grad():
+            for s in range(0, HELD_OUT, 8):
+                logits = m(eA[s:s + 8].to(dev), eB[s:s + 8].to(dev)).float().cpu().numpy()
+                cm += metrics_ref.confusion_matrix(metrics_ref.argmax_lowest_index(logits), emask[s:s + 8].numpy())
+        m.train()
+        return cm, metrics_ref.metrics_from_cm(cm)
+
+    # (K, |delta mIoU| bound, per-class IoU bound)
+    bounds = {"fp32": {20: (5e-4, 1.5e-3), 40: (5e-4, 1.5e-3)}, "bf16": {20: (3e-2, 5e-2), 40: (2e-3, 5e-3)}}[precision]
+    losses = []
+    for k in range(K_STEPS):
+        s = (k % (TRAIN_TILES // BATCH)) * BATCH
+        losses.append(float(step.step(xA[s:s + BATCH].to(dev), xB[s:s + BATCH].to(dev), mask[s:s + BATCH].to(dev))[0]))
+        if k + 1 in CHECKPOINTS:
+            cm, m = evaluate(model)
+            g_miou, g_iou, g_cm = float(gold[f"miou{k + 1}"]), gold[f"iou{k + 1}"], gold[f"cm{k + 1}"]
+            d_miou, d_iou = float(m["miou"]) - g_miou, m["iou"][:3] - g_iou[:3]
+            print(f"{precision} K={k + 1}: mIoU {m['miou']:.5f} (CPU fp32 {g_miou:.5f}, delta {d_miou:+.5f}); per-class IoU delta "
+                  f"{np.array2string(d_iou, precision=5)}; pixels in other confusion-matrix cells: {int(np.abs(cm - g_cm).sum()) // 2} of "
+                  f"{int(cm.sum())}; loss {losses[-1]:.5f} vs {gold['losses'][k]:.5f}")
+            assert abs(d_miou) <= bounds[k + 1][0], (k + 1, d_miou)
+            assert np.abs(d_iou).max() <= bounds[k + 1][1], (k + 1, d_iou)
+    # the loss trajectory follows the oracle's: first step to rounding, the whole run within a band
+    assert abs(losses[0] - gold["losses"][0]) < (2e-4 if precision == "fp32" else 2e-2) * gold["losses"][0]
+    rel = np.abs(np.array(losses) - gold["losses"]) / gold["losses"]
+    assert rel.max() < (0.05 if precision == "fp32" else 0.35), rel
+    if precision == "bf16":
+        # bf16 inference of the trained weights vs fp32 inference of the SAME weights: the eval path is not where bf16 differs
+        m32 = SNUNet_ECAM(2, 3, base_channel=32, precision="fp32")
+        m32.load_state_dict({k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
+        _, a = evaluate(model)
+        _, b = evaluate(m32.to(dev))
+        print(f"same weights, bf16 vs fp32 inference: mIoU {a['miou']:.5f} vs {b['miou']:.5f}")
+        assert abs(float(a["miou"]) - float(b["miou"])) < 3e-4
