@@ -184,6 +184,40 @@ def gen_snunet_full():
     np.savez_compressed(os.path.join(OUT, "snunet_full.npz"), **out)
 
 
+def gen_snunet_bench():
+    """The benchmarked configuration (BASELINE.json configs[1]: SNUNet-ECAM c=2 bc=32, batch 32, 224x224) on the REAL reference in
+    fp32: train-mode logits (BatchNorm statistics over 32 tiles), ce+dice loss, gradient statistics.  Inputs are the synthetic SAR
+    tiles of the benchmark (kurosiwo_amd/synthetic.make_batch) so the bf16 HIP path is checked on the data distribution it is timed on."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from kurosiwo_amd.synthetic import cd_inputs, make_batch
+    out = {}
+    c, bc, B = 2, 32, 32
+    (xA, xB), lbl = cd_inputs(make_batch(B, 224, 224, seed=1234), ("pre_event_1", "post_event"))
+    model = _ref_model(c, bc)
+    model.train()
+    crit = BCEandDiceLoss(weights=[1.0, 1.0, 1.0], ignore_index=3, use_softmax=True)
+    logits = model(xA, xB)
+    loss = crit(logits, lbl)
+    loss.backward()
+    out["train_logits_sub"] = logits[:, :, ::16, ::16].detach().numpy().copy()
+    out["train_logits_absmax"] = np.array(float(logits.detach().abs().max()))
+    out["train_argmax_sub"] = logits[::8].detach().argmax(1).numpy().astype(np.uint8)
+    top2 = logits[::8].detach().topk(2, dim=1).values
+    out["train_margin_sub"] = (top2[:, 0] - top2[:, 1]).numpy().astype(np.float16)
+    out["train_loss"] = np.array(float(loss))
+    stats, full = _grad_stats(model)
+    for k, v in stats.items():
+        out[f"gstat.{k}"] = v
+    for k in ("conv_final.weight", "conv0_4.conv1.weight", "Up1_3.up.weight", "conv0_0.bn1.weight"):
+        out[f"grad.{k}"] = dict(model.named_parameters())[k].grad.numpy().copy()
+    sd = model.state_dict()
+    for k in ("conv0_0.bn1", "conv0_4.bn2", "conv2_1.bn1"):
+        out[f"bn.{k}.running_mean"] = sd[f"{k}.running_mean"].numpy().copy()
+        out[f"bn.{k}.running_var"] = sd[f"{k}.running_var"].numpy().copy()
+    print("snunet_bench loss", float(loss))
+    np.savez_compressed(os.path.join(OUT, "snunet_bench.npz"), **out)
+
+
 def _import_floodvit_reference():
     import types
     import models.upernet  # noqa: F401  (pulls in transformers before the placeholders exist)
@@ -467,6 +501,8 @@ if __name__ == "__main__":
     if not only or "snunet" in only:
         gen_snunet_small()
         gen_snunet_full()
+    if not only or "snunet_bench" in only:
+        gen_snunet_bench()
     if not only or "floodvit" in only:
         gen_floodvit("small", FLOODVIT_SMALL, 2)
         gen_floodvit("full", FLOODVIT_FULL, 1)

@@ -221,3 +221,49 @@ def test_headline_config_is_bitwise_reproducible_and_learns(dev):
     assert torch.equal(p1, p2) and torch.equal(l1, l2)
     assert torch.isfinite(l1).all() and float(l1[-1, 0]) < float(l1[0, 0])
     assert n1 == 6 and n2 == 6
+
+
+def test_bf16_at_the_benchmarked_size_vs_reference_golden(dev, golden_dir):
+    """BASELINE.json configs[1] exactly as benchmarked (batch 32, 224x224, bf16, synthetic SAR tiles) against fp32 vectors of the REAL
+    reference (tests/golden/snunet_bench.npz, oracle/gen_golden.py::gen_snunet_bench): train-mode logits, ce+dice loss, argmax with a
+    BOUNDED number of in-margin disagreements, gradient norms / directions, BatchNorm running statistics."""
+    from kurosiwo_amd.loss import BCEandDiceLoss
+    from kurosiwo_amd.synthetic import cd_inputs, make_batch
+    gold = np.load(os.path.join(golden_dir, "snunet_bench.npz"))
+    (xA, xB), lbl = cd_inputs(make_batch(32, 224, 224, seed=1234), ("pre_event_1", "post_event"))
+    sd = seeded_fill_(R.new_state_dict(2, 3, 32))
+    m = _model(2, 32, "bf16", sd, dev).train()
+    logits = m(xA.to(dev), xB.to(dev))
+    loss = BCEandDiceLoss([1.0, 1.0, 1.0], 3, True)(logits, lbl.to(dev))
+    loss.backward()
+    lg = logits.detach().float().cpu()
+    scale = float(gold["train_logits_absmax"])
+    err = (lg[:, :, ::16, ::16].numpy() - gold["train_logits_sub"])
+    print(f"bf16 bs32: logits max err {np.abs(err).max() / scale:.4f} of scale, rms {np.sqrt((err ** 2).mean()) / scale:.5f}; "
+          f"loss {float(loss):.5f} vs {float(gold['train_loss']):.5f}")
+    assert np.abs(err).max() < 4e-2 * scale and np.sqrt((err ** 2).mean()) < 6e-3 * scale
+    assert abs(float(loss) - float(gold["train_loss"])) < 5e-3 * float(gold["train_loss"])
+    am = lg[::8].argmax(1).numpy().astype(np.uint8)
+    margin = gold["train_margin_sub"].astype(np.float32)
+    decisive = margin > 3e-2 * scale
+    assert (am[decisive] == gold["train_argmax_sub"][decisive]).all()
+    mism = int((am != gold["train_argmax_sub"]).sum())
+    assert mism <= 0.01 * am.size, (mism, am.size)                     # in-margin disagreements: bounded, not just printed
+    coss, bad = [], {}
+    for k, p in m.named_parameters():
+        st = gold[f"gstat.{k}"]
+        if k.endswith("conv2.bias"):
+            continue                                                   # analytically zero (BatchNorm follows)
+        nrm = float(p.grad.double().norm())
+        if not abs(nrm - st[0]) < 8e-2 * st[0] + 1e-6:
+            bad[k] = (nrm, st[0])
+        fk = f"grad.{k}"
+        if fk in gold:
+            g, r = p.grad.detach().double().cpu().numpy().ravel(), gold[fk].astype(np.float64).ravel()
+            coss.append(float((g * r).sum() / (np.linalg.norm(g) * np.linalg.norm(r) + 1e-30)))
+    assert not bad, dict(list(bad.items())[:10])
+    assert min(coss) > 0.97 and sorted(coss)[1] > 0.995, coss       # (the lowest: conv0_0.bn1.weight, end of the longest backward path)
+    msd = m.state_dict()
+    for k in ("conv0_0.bn1", "conv0_4.bn2", "conv2_1.bn1"):
+        assert np.abs(msd[f"{k}.running_mean"].cpu().numpy() - gold[f"bn.{k}.running_mean"]).max() < 2e-2 * max(1.0, np.abs(gold[f"bn.{k}.running_mean"]).max())
+        assert np.abs(msd[f"{k}.running_var"].cpu().numpy() - gold[f"bn.{k}.running_var"]).max() < 3e-2 * max(1.0, float(gold[f"bn.{k}.running_var"].max()))
