@@ -62,6 +62,32 @@ class KernelTimer:
         return out
 
 
+# bench kernel class -> the rocprofv3 kernel names that make up one "launch" of it (profiles/<tag>_traffic.json, written by
+# profiles/summarize.py from the --pmc FETCH_SIZE / WRITE_SIZE passes of this same command)
+TRAFFIC_KERNELS = {
+    "igemm_wgrad<3x3s1>": ("wgrad3_kernel", "wgrad3_reduce_kernel", "igemm_wgrad_kernel<bf16, 2, 3, 3", "wgrad_reduce_kernel"),
+    "igemm_fwd<3x3s1,BN32>": ("igemm2_fwd_kernel<bf16, 2, 3, 3", "igemm3_kernel<3, 3"),
+    "igemm_dgrad<3x3s1,BN32>": ("igemm2_fwd_kernel<bf16, 2, 3, 3", "igemm3_kernel<3, 3"),
+}
+
+
+def measured_traffic(kind):
+    """HBM bytes per launch of the dominant kernel class from the committed PMC table (None when there is none for this class):
+    call-weighted mean of 2 x FETCH_SIZE + WRITE_SIZE over the class's kernels (x2: the guide's gfx950 FETCH_SIZE correction)."""
+    path = os.path.join(ROOT, "profiles", "r02_snunet_traffic.json")
+    if kind not in TRAFFIC_KERNELS or not os.path.exists(path):
+        return None
+    tab = json.load(open(path))["kernels"]
+    tot, calls = 0.0, 0
+    main_calls = 0
+    for name, row in tab.items():
+        if any(name.startswith(p) for p in TRAFFIC_KERNELS[kind]) and row.get("fetch_kb_raw") is not None and row.get("write_kb_raw") is not None:
+            tot += row["calls"] * (2.0 * row["fetch_kb_raw"] + row["write_kb_raw"]) * 1024.0
+            if "reduce" not in name:
+                main_calls += row["calls"]
+    return {"bytes_per_launch": round(tot / main_calls), "source": "profiles/r02_snunet_traffic.json (2 x FETCH_SIZE + WRITE_SIZE)"} if main_calls else None
+
+
 def cpu_baseline(budget_s=20.0):
     """The CPU oracle (port of the reference's train step, pinned to it by tests/golden) on the
     host cores: SNUNet-ECAM c=2 bc=32, bs=4, fp32, ce+dice, Adam; 1 warm-up + timed steps."""
@@ -238,7 +264,7 @@ def main():
                          if d["flops"] / MFMA_BF16_PEAK_TF / 1e12 > d["bytes"] / HBM_PEAK_GBS / 1e9 and args.precision == "bf16" else
                          {"kernel": dominant, "bound": "hbm", "achieved": round(ach_gbs, 1), "peak": HBM_PEAK_GBS,
                           "unit": "GB/s", "frac": round(ach_gbs / HBM_PEAK_GBS, 4)}) | {
-                         "traffic": None, "launches_timed": d["n"], "avg_launch_ms": round(avg_ms, 4),
+                         "traffic": measured_traffic(dominant), "launches_timed": d["n"], "avg_launch_ms": round(avg_ms, 4),
                          "share_of_step": round(d["ms"] / (dt * 1e3), 3),
                          "algorithmic_GBs": round(ach_gbs, 1), "hbm_frac": round(ach_gbs / HBM_PEAK_GBS, 4),
                          "tflops": round(ach_tf, 1), "mfma_frac": round(ach_tf / MFMA_BF16_PEAK_TF, 4),

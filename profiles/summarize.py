@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
 """Turn the rocprofv3 (rocpd sqlite) outputs of tools_profile.sh into a small committed summary.
 
-  python profiles/summarize.py gpurun_out/prof_<tag> profiles/<tag>_summary.md
+  python profiles/summarize.py gpurun_out/prof_<tag> profiles/<tag>_summary.md [note] [command] [traffic.json]
 
-Reads <prefix>_stats/*.db (kernel trace), <prefix>_fetch/*.db (--pmc FETCH_SIZE) and
-<prefix>_write/*.db (--pmc WRITE_SIZE).  FETCH_SIZE on gfx950 under-reports wide coalesced
+Reads <prefix>_stats/*.db (kernel trace), <prefix>_fetch/*.db (--pmc FETCH_SIZE), <prefix>_write/*.db (--pmc WRITE_SIZE) and
+<prefix>_mfma/*.db (--pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE: MFMA utilisation = MFMA-busy cycles summed over
+the SIMDs / (4 SIMDs x 256 CUs x GRBM_GUI_ACTIVE)).  With a 5th argument also writes the per-kernel table as JSON
+(profiles/<tag>_traffic.json), which bench.py reads to fill `roofline.traffic`.  FETCH_SIZE on gfx950 under-reports wide coalesced
 reads by exactly 2x (MI355X_MICROARCH.md §HBM): both the raw and the doubled figure are listed;
 WRITE_SIZE is uncalibrated and listed raw.
 """
@@ -44,19 +46,31 @@ def main():
     times = kernel_times(stats)
     fetch = counter(glob.glob(prefix + "_fetch/*.db")[0], "FETCH_SIZE") if glob.glob(prefix + "_fetch/*.db") else {}
     write = counter(glob.glob(prefix + "_write/*.db")[0], "WRITE_SIZE") if glob.glob(prefix + "_write/*.db") else {}
+    mdb = glob.glob(prefix + "_mfma/*.db")
+    mbusy = counter(mdb[0], "SQ_VALU_MFMA_BUSY_CYCLES") if mdb else {}
+    gui = counter(mdb[0], "GRBM_GUI_ACTIVE") if mdb else {}
     tot = sum(t[2] for t in times)
     lines = ["# rocprofv3 summary: " + prefix, "", note, "",
              "`rocprofv3 --kernel-trace --stats` (+ separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes) of",
              "`" + cmd + ".  Plan construction (buffer zero fills) is included in the trace and excluded from the bench timing.", "",
              f"total kernel time {tot:.1f} ms over all dispatches", "",
-             "| kernel | calls | total ms | avg us | % | FETCH_SIZE avg KB (raw) | x2 corrected MB | WRITE_SIZE avg KB (raw) |",
-             "|---|---|---|---|---|---|---|---|"]
-    for n, c, t, a, p in times[:40]:
+             "| kernel | calls | total ms | avg us | % | FETCH_SIZE avg KB (raw) | x2 corrected MB | WRITE_SIZE avg KB (raw) | MFMA busy % |",
+             "|---|---|---|---|---|---|---|---|---|"]
+    table = {}
+    for n, c, t, a, p in times[:48]:
         f = fetch.get(n, (None,))[0]
         w = write.get(n, (None,))[0]
+        mb, ga = mbusy.get(n, (None,))[0], gui.get(n, (None,))[0]
+        util = None if mb is None or not ga else 100.0 * mb / (4.0 * 256.0 * ga)      # counter summed over all SIMDs of the chip
         lines.append(f"| {n} | {c} | {t:.2f} | {a:.1f} | {p:.1f} | {'' if f is None else f'{f:.0f}'} | "
-                     f"{'' if f is None else f'{2 * f / 1024:.1f}'} | {'' if w is None else f'{w:.0f}'} |")
+                     f"{'' if f is None else f'{2 * f / 1024:.1f}'} | {'' if w is None else f'{w:.0f}'} | {'' if util is None else f'{util:.1f}'} |")
+        table[n] = {"calls": c, "avg_us": a, "fetch_kb_raw": f, "write_kb_raw": w, "mfma_busy_pct": util}
     open(outp, "w").write("\n".join(lines) + "\n")
+    if len(sys.argv) > 5:
+        import json
+        json.dump({"note": "per-launch averages; HBM read bytes = 2 x FETCH_SIZE (gfx950 rocprofv3 counts 128-byte requests as 64, "
+                           "MI355X_MICROARCH.md HBM section), write bytes = WRITE_SIZE (uncalibrated)", "kernels": table},
+                  open(sys.argv[5], "w"), indent=1)
     print("\n".join(lines[8:24]))
 
 

@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $R/gpurun_out
 python $R/bench.py > $R/gpurun_out/bench_${TAG}_snunet.json 2> $R/gpurun_out/bench_${TAG}.err
 for m in changeformer floodvit unet mae; do python $R/bench.py --model $m --no-cpu-baseline > $R/gpurun_out/bench_${TAG}_$m.json 2>> $R/gpurun_out/bench_${TAG}.err; done
-bash $R/tools_profile.sh ${TAG} > $R/gpurun_out/prof_${TAG}.log 2>&1
+bash $R/tools/profile.sh ${TAG} > $R/gpurun_out/prof_${TAG}.log 2>&1
 cd /tmp && export TMPDIR=/tmp
 for m in changeformer floodvit unet mae; do
   rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${TAG}_${m}_stats -o stats -- python $R/bench.py --model $m --steps 3 --warmup 2 --no-cpu-baseline > $R/gpurun_out/prof_${TAG}_$m.log 2>&1
