@@ -24,6 +24,8 @@ class ConfusionMetrics:
         require_gpu(logits)
         B, Cc, H, W = logits.shape
         logits = logits.contiguous().float()
+        if target.dtype != torch.int64:          # the kernel reads int64 labels (the reference's masks are .long(), Dataset.py:824-860)
+            target = target.long()
         pred = torch.empty((B, H, W), dtype=torch.int64, device=logits.device) if return_predictions else None
         lib = _lib.load()
         _lib.check(lib.ksmi_argmax_confusion(logits.data_ptr(), target.contiguous().data_ptr(),
