@@ -382,6 +382,23 @@ int ksmi_sr_attention_forward(const void* q, const void* kv, void* out, int B, i
 size_t ksmi_sr_attention_bwd_workspace(int B, int Nq, int Nk, int H, int C);
 int ksmi_sr_attention_backward(const void* q, const void* kv, const void* out, const void* dout, void* dq, void* dkv, void* workspace, int B,
                                int Nq, int Nk, int H, int C, float scale, int dtype, void* stream);
+/* Stochastic layers of ChangeFormerV6 (drop_rate = attn_drop = drop_path_rate = 0.1, changeformer.py:267-275).  The reference draws
+ * its Bernoulli masks from torch's global generator; here a draw is a pure function of (seed, step, site, element): the backward
+ * pass regenerates the forward's mask and oracle/rng_ref.py reproduces it on the CPU.  rng_state = 2 words in device memory
+ * {seed, step}; ksmi_rng_advance does step += 1 on the stream (once per training forward).  thr = round(p * 2^32), an element
+ * is kept when its 32-bit draw >= thr and scaled by inv_keep = 1/(1-p); thr = 0 switches a layer off.
+ *   ksmi_dropout_apply: y[r][c] = [resid[r][c] +] x[r][c] * Dropout(site; element r*cols+c) * DropPath(dp_site; sample
+ *   r / rows_per_sample) -- nn.Dropout (:107,162) fused with DropPath (:236-241, timm drop_path: per-sample mask / keep_prob)
+ *   and the residual add of Block.forward; the backward of the branch is the same call on the gradient with resid = NULL.
+ *   ksmi_sr_attention_*_drop: attn_drop (:160,203) on the softmax rows, element ((b*H+h)*Nq+q)*Nk+key. */
+int ksmi_rng_advance(uint32_t* rng_state, void* stream);
+int ksmi_dropout_apply(const void* x, const void* resid, void* y, int64_t rows, int cols, int rows_per_sample, uint32_t thr, float inv_keep,
+                       uint32_t site, uint32_t dp_thr, float dp_inv_keep, uint32_t dp_site, const uint32_t* rng_state, int dtype, void* stream);
+int ksmi_sr_attention_forward_drop(const void* q, const void* kv, void* out, int B, int Nq, int Nk, int H, int C, float scale,
+                                   uint32_t drop_thr, float drop_inv_keep, uint32_t site, const uint32_t* rng_state, int dtype, void* stream);
+int ksmi_sr_attention_backward_drop(const void* q, const void* kv, const void* out, const void* dout, void* dq, void* dkv, void* workspace,
+                                    int B, int Nq, int Nk, int H, int C, float scale, uint32_t drop_thr, float drop_inv_keep, uint32_t site,
+                                    const uint32_t* rng_state, int dtype, void* stream);
 /* F.interpolate(mode="bilinear", align_corners=False) (:581-608): y = [add +] resize(x); adjoint dx (+)= resize^T(dy) (upsampling) */
 int ksmi_bilinear_forward(const void* x, const void* add, void* y, int B, int Hi, int Wi, int Ho, int Wo, int C, int dtype, void* stream);
 int ksmi_bilinear_backward(const void* dy, void* dx, int accumulate, int B, int Hi, int Wi, int Ho, int Wo, int C, int dtype, void* stream);

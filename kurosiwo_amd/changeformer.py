@@ -10,9 +10,12 @@ implicit/explicit GEMMs on the MFMA kernels; the decoder's 3x3 / transposed conv
 LDS-DMA implicit-GEMM kernel with ReLU, BatchNorm statistics, the 0.1-scaled residual and the concat fused into its
 operand load / epilogue.
 
-Deviation (documented): the reference hard-codes Dropout(0.1) / attention dropout 0.1 / DropPath(<=0.1) (:651-653), which
-are active in train mode.  They are identities here (torch's RNG stream cannot be reproduced by a fused kernel anyway);
-eval-mode results and train-mode results with those probabilities set to 0 match the reference (tests/golden).
+Stochastic layers: the reference hard-codes Dropout(0.1) / attention dropout 0.1 / DropPath(linspace(0, 0.1, 13)) (:651-653),
+active in train mode.  They are applied here with the same probabilities and at the same places; the Bernoulli draws come from
+a counter-based stream keyed by (seed, step, site, element) instead of torch's global generator (csrc/common.h, stochastic.hip),
+so the backward pass regenerates the masks and oracle/rng_ref.py replays them: tests/golden/changeformer_drop.npz is the
+reference's own modules run with their Dropout / DropPath draws replaced by that stream.  `drop_rate`, `attn_drop`,
+`drop_path_rate` are attributes (set them to 0 for a deterministic regulariser-free run); `manual_seed(seed, step)` pins the stream.
 Only the gradient of the last output (`cp`) is propagated: the reference trainer's default `multi_scale_train: false`
 (configs/method/changeformer/changeformer.json, change_detection_trainer.py:138-166).
 """
@@ -106,6 +109,11 @@ def changeformer_specs(input_nc, output_nc, embed_dim):
     return p, b, c
 
 
+def _as_i32(words):
+    """two unsigned 32-bit words as the int32 tensor torch can hold"""
+    return torch.tensor([v - (1 << 32) if v >= (1 << 31) else v for v in words], dtype=torch.int32)
+
+
 class ChangeFormerV6(ArenaModule):
     def __init__(self, input_nc=3, output_nc=2, decoder_softmax=False, embed_dim=256, precision="bf16"):
         super().__init__()
@@ -116,6 +124,8 @@ class ChangeFormerV6(ArenaModule):
         self.input_nc, self.output_nc, self.decoder_softmax, self.embedding_dim = input_nc, output_nc, bool(decoder_softmax), embed_dim
         self.embed_dims, self.depths = list(EMBED_DIMS), list(DEPTHS)
         self.precision = precision
+        self.drop_rate, self.attn_drop, self.drop_path_rate = 0.1, 0.1, 0.1       # ChangeFormerV6.__init__ :651-653
+        self._rng_state, self._rng_init = None, None
         ps, bs, cs = changeformer_specs(input_nc, output_nc, embed_dim)
         self._setup_arena(ps, bs, cs)
         self._init_parameters()
@@ -152,9 +162,27 @@ class ChangeFormerV6(ArenaModule):
     def _is_bn(self, key):
         return (key.rsplit(".", 1)[0] + ".running_mean") in self._bspec
 
+    def manual_seed(self, seed, step=0):
+        """pin the random stream of the stochastic layers: the next training forward uses (seed, step + 1)"""
+        self._rng_init = (int(seed) & 0xFFFFFFFF, int(step) & 0xFFFFFFFF)
+        if self._rng_state is not None:
+            self._rng_state.copy_(_as_i32(self._rng_init))
+        return self
+
+    def rng_state(self):
+        """device words {seed, step} read by the dropout kernels (default seed: torch.initial_seed(), so torch.manual_seed steers it)"""
+        self._ensure_arena()
+        if self._rng_state is None:
+            if self._rng_init is None:
+                self._rng_init = (torch.initial_seed() & 0xFFFFFFFF, 0)
+            dev = next(self.parameters()).device
+            self._rng_state = _as_i32(self._rng_init).to(dev)
+        return self._rng_state
+
     def plan(self, B, H, W, training, with_backward):
         self._ensure_arena()
-        key = (B, H, W, self.act_dtype(), bool(training), bool(with_backward))
+        key = (B, H, W, self.act_dtype(), bool(training), bool(with_backward),
+               (self.drop_rate, self.attn_drop, self.drop_path_rate) if training else None)
         if key not in self._plans:
             from .changeformer_plan import ChangeFormerPlan
             self._plans[key] = ChangeFormerPlan(self, B, H, W, self.act_dtype(), training, with_backward)

@@ -18,6 +18,18 @@ from .snunet_plan import _Saved
 
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
 CS = 8            # channel stride of the 3-channel NHWC heads (vector-aligned pad channels)
+# random-stream sites of one encoder block (site id = 8 * global block index + one of these; oracle/rng_ref.py mirrors them)
+SITE_ATTN, SITE_PROJ, SITE_MLP1, SITE_MLP2, SITE_PATH_ATTN, SITE_PATH_MLP = range(6)
+NO_SITE = (0, 1.0, 0)
+
+
+def drop_threshold(p):
+    """(thr, inv_keep): an element is dropped when its 32-bit draw < thr = round(p * 2^32); kept ones are scaled by 1/(1-p)"""
+    if p <= 0.0:
+        return 0, 1.0
+    if p >= 1.0:
+        raise ValueError("drop probability must be < 1")
+    return min(0xFFFFFFFF, int(round(p * 4294967296.0))), 1.0 / (1.0 - p)
 
 
 class ChangeFormerPlan(PlanBase):
@@ -40,12 +52,37 @@ class ChangeFormerPlan(PlanBase):
         self.const = torch.zeros((2, max(self.E, 8)), dtype=torch.float32, device=self.dev)   # row 0 zeros, row 1 ones
         self.const[1].fill_(1.0)
         self._bsteps = []
+        # stochastic layers (changeformer.py:267-275: drop_rate = attn_drop_rate = drop_path_rate = 0.1, dpr = linspace(0, 0.1, 13));
+        # train mode only, exactly as nn.Dropout / DropPath
+        nblk = sum(DEPTHS)
+        self.p_drop = float(model.drop_rate) if training else 0.0
+        self.p_attn = float(model.attn_drop) if training else 0.0
+        dp = float(model.drop_path_rate) if training else 0.0
+        self.dpr = [dp * i / (nblk - 1) for i in range(nblk)]
+        self.stochastic = self.p_drop > 0 or self.p_attn > 0 or dp > 0
+        self.rng_ptr = model.rng_state().data_ptr() if self.stochastic else None
+        if self.stochastic:
+            self.fwd.add("ksmi_rng_advance", lambda: (self.rng_ptr,))
         self._build()
         if with_backward:
             self._build_backward()
         self._finish()
 
     # ---------------------------------------------------------------- helpers
+    def _site(self, gi, site, p):
+        thr, inv = drop_threshold(p)
+        return (thr, inv, 8 * gi + site)
+
+    def _branch_active(self, gi):
+        """does the residual branch of block gi pass through Dropout / DropPath (-> unfused residual add)?"""
+        return self.p_drop > 0 or self.dpr[gi] > 0
+
+    def _drop(self, ll, x, resid, y, rows, cols, rows_per_sample, el, path):
+        """y = [resid +] x * Dropout(el) * DropPath(path)   (forward of a residual branch; with resid None its backward)"""
+        ll.add("ksmi_dropout_apply", lambda: (x.data_ptr(), None if resid is None else resid.data_ptr(), y.data_ptr(), rows, cols, rows_per_sample,
+                                              el[0], el[1], el[2], path[0], path[1], path[2], self.rng_ptr, self.dt),
+               self._elt_meta("dropout", (2 if resid is None else 3) * rows * cols))
+
     def _stats_ptr(self):
         return (lambda: self.scr("stats")) if self.training else (lambda: None)
 
@@ -121,9 +158,11 @@ class ChangeFormerPlan(PlanBase):
             st_pe = self._ln(t0, f"{pe}.norm.weight", f"{pe}.norm.bias", t, R, Cc, 1e-5)
             self.named[f"pe{st + 1}"] = t
             blocks = []
+            ptmp = self.buf(R, Cc) if self.stochastic else None     # branch output before Dropout / DropPath / residual add
             for i in range(DEPTHS[st]):
                 k = f"Tenc_x2.block{st + 1}.{i}"
-                rec = dict(k=k, t_in=t)
+                rec = dict(k=k, t_in=t, gi=sum(DEPTHS[:st]) + i)
+                gi = rec["gi"]
                 h, q, att, t_mid = self.buf(R, Cc), self.buf(R, Cc), self.buf(R, Cc), self.buf(R, Cc)
                 rec["st1"] = self._ln(t, f"{k}.norm1.weight", f"{k}.norm1.bias", h, R, Cc, 1e-6)
                 self._linear(f"{k}.q", h, Cc, f"{k}.attn.q.weight", f"{k}.attn.q.bias", q, Cc, R)
@@ -149,17 +188,28 @@ class ChangeFormerPlan(PlanBase):
                 self._linear(f"{k}.kv", xn, Cc, f"{k}.attn.kv.weight", f"{k}.attn.kv.bias", kv, 2 * Cc, Rk)
                 scale = float(Cc // heads) ** -0.5
                 aflops = 4 * B2 * Hs * Ws * 49 * Cc
-                self.fwd.add("ksmi_sr_attention_forward", lambda q=q, kv=kv, att=att, Hs=Hs, Ws=Ws, heads=heads, Cc=Cc, scale=scale: (
-                    q.data_ptr(), kv.data_ptr(), att.data_ptr(), B2, Hs * Ws, 49, heads, Cc, scale, dt),
+                ad = self._site(gi, SITE_ATTN, self.p_attn)
+                self.fwd.add("ksmi_sr_attention_forward_drop", lambda q=q, kv=kv, att=att, Hs=Hs, Ws=Ws, heads=heads, Cc=Cc, scale=scale, ad=ad: (
+                    q.data_ptr(), kv.data_ptr(), att.data_ptr(), B2, Hs * Ws, 49, heads, Cc, scale, ad[0], ad[1], ad[2], self.rng_ptr, dt),
                     {"kind": "sr_attention_fwd", "bytes": (3 * R * Cc + 2 * Rk * Cc) * self._es(), "flops": aflops})
-                self._linear(f"{k}.proj", att, Cc, f"{k}.attn.proj.weight", f"{k}.attn.proj.bias", t_mid, Cc, R, resid=t)
+                if self._branch_active(gi):
+                    self._linear(f"{k}.proj", att, Cc, f"{k}.attn.proj.weight", f"{k}.attn.proj.bias", ptmp, Cc, R)
+                    self._drop(self.fwd, ptmp, t, t_mid, R, Cc, Hs * Ws, self._site(gi, SITE_PROJ, self.p_drop), self._site(gi, SITE_PATH_ATTN, self.dpr[gi]))
+                else:
+                    self._linear(f"{k}.proj", att, Cc, f"{k}.attn.proj.weight", f"{k}.attn.proj.bias", t_mid, Cc, R, resid=t)
                 h2, u, z, g, t_out = self.buf(R, Cc), self.buf(R, 4 * Cc), self.buf(R, 4 * Cc), self.buf(R, 4 * Cc), self.buf(R, Cc)
                 rec["st2"] = self._ln(t_mid, f"{k}.norm2.weight", f"{k}.norm2.bias", h2, R, Cc, 1e-6)
                 self._linear(f"{k}.fc1", h2, Cc, f"{k}.mlp.fc1.weight", f"{k}.mlp.fc1.bias", u, 4 * Cc, R)
                 wd, bd = m._p(f"{k}.mlp.dwconv.dwconv.weight").data_ptr(), m._p(f"{k}.mlp.dwconv.dwconv.bias").data_ptr()
                 self.fwd.add("ksmi_dwconv3x3_gelu_forward", lambda u=u, z=z, g=g, wd=wd, bd=bd, Hs=Hs, Ws=Ws, Cc=Cc: (
                     u.data_ptr(), wd, bd, z.data_ptr(), g.data_ptr(), B2, Hs, Ws, 4 * Cc, dt), self._elt_meta("dwconv_gelu", 3 * R * 4 * Cc))
-                self._linear(f"{k}.fc2", g, 4 * Cc, f"{k}.mlp.fc2.weight", f"{k}.mlp.fc2.bias", t_out, Cc, R, resid=t_mid)
+                if self._branch_active(gi):
+                    if self.p_drop > 0:                            # Mlp.drop after the activation (:130): in place, fc2 and its wgrad read it
+                        self._drop(self.fwd, g, None, g, R, 4 * Cc, Hs * Ws, self._site(gi, SITE_MLP1, self.p_drop), NO_SITE)
+                    self._linear(f"{k}.fc2", g, 4 * Cc, f"{k}.mlp.fc2.weight", f"{k}.mlp.fc2.bias", ptmp, Cc, R)
+                    self._drop(self.fwd, ptmp, t_mid, t_out, R, Cc, Hs * Ws, self._site(gi, SITE_MLP2, self.p_drop), self._site(gi, SITE_PATH_MLP, self.dpr[gi]))
+                else:
+                    self._linear(f"{k}.fc2", g, 4 * Cc, f"{k}.mlp.fc2.weight", f"{k}.mlp.fc2.bias", t_out, Cc, R, resid=t_mid)
                 rec.update(h=h, q=q, kv=kv, att=att, t_mid=t_mid, h2=h2, u=u, z=z, g=g, scale=scale, aflops=aflops)
                 blocks.append(rec)
                 t = t_out
@@ -413,10 +463,19 @@ class ChangeFormerPlan(PlanBase):
         self._ln_bwd(ft["df"], ft["t_last"], ft["st_n"], f"Tenc_x2.norm{st + 1}.weight", f"Tenc_x2.norm{st + 1}.bias", gt, 0, R, Cc)
         ws_attn = self.lib.ksmi_sr_attention_bwd_workspace(B2, Hs * Ws, 49, heads, Cc)
         self.need("attn", ws_attn)
+        N = Hs * Ws
+        tD = self.buf(R, Cc) if self.stochastic else None           # gradient of a branch output behind Dropout / DropPath
         for rec in reversed(ft["blocks"]):
-            k = rec["k"]
+            k, gi = rec["k"], rec["gi"]
+            active = self._branch_active(gi)
             # Mlp
-            self._linear_bwd(f"{k}.fc2", rec["g"], 4 * Cc, f"{k}.mlp.fc2.weight", f"{k}.mlp.fc2.bias", gt, Cc, R, t4)
+            gy = gt
+            if active:
+                self._drop(self.bwd, gt, None, tD, R, Cc, N, self._site(gi, SITE_MLP2, self.p_drop), self._site(gi, SITE_PATH_MLP, self.dpr[gi]))
+                gy = tD
+            self._linear_bwd(f"{k}.fc2", rec["g"], 4 * Cc, f"{k}.mlp.fc2.weight", f"{k}.mlp.fc2.bias", gy, Cc, R, t4)
+            if active and self.p_drop > 0:
+                self._drop(self.bwd, t4, None, t4, R, 4 * Cc, N, self._site(gi, SITE_MLP1, self.p_drop), NO_SITE)
             self.bwd.add("ksmi_gelu_backward", lambda z=rec["z"]: (t4.data_ptr(), z.data_ptr(), t4.data_ptr(), R * 4 * Cc, dt),
                          self._elt_meta("gelu_bwd", 3 * R * 4 * Cc))
             wd = m._p(f"{k}.mlp.dwconv.dwconv.weight").data_ptr()
@@ -437,9 +496,15 @@ class ChangeFormerPlan(PlanBase):
             self._linear_bwd(f"{k}.fc1", rec["h2"], Cc, f"{k}.mlp.fc1.weight", f"{k}.mlp.fc1.bias", du, 4 * Cc, R, tC)
             self._ln_bwd(tC, rec["t_mid"], rec["st2"], f"{k}.norm2.weight", f"{k}.norm2.bias", gt, 1, R, Cc)
             # Attention
-            self._linear_bwd(f"{k}.proj", rec["att"], Cc, f"{k}.attn.proj.weight", f"{k}.attn.proj.bias", gt, Cc, R, tC)
-            self.bwd.add("ksmi_sr_attention_backward", lambda q=rec["q"], kv=rec["kv"], att=rec["att"], scale=rec["scale"]: (
-                q.data_ptr(), kv.data_ptr(), att.data_ptr(), tC.data_ptr(), tq.data_ptr(), tkv.data_ptr(), self.scr("attn"), B2, Hs * Ws, 49, heads, Cc, scale, dt),
+            gy = gt
+            if active:
+                self._drop(self.bwd, gt, None, tD, R, Cc, N, self._site(gi, SITE_PROJ, self.p_drop), self._site(gi, SITE_PATH_ATTN, self.dpr[gi]))
+                gy = tD
+            self._linear_bwd(f"{k}.proj", rec["att"], Cc, f"{k}.attn.proj.weight", f"{k}.attn.proj.bias", gy, Cc, R, tC)
+            ad = self._site(gi, SITE_ATTN, self.p_attn)
+            self.bwd.add("ksmi_sr_attention_backward_drop", lambda q=rec["q"], kv=rec["kv"], att=rec["att"], scale=rec["scale"], ad=ad: (
+                q.data_ptr(), kv.data_ptr(), att.data_ptr(), tC.data_ptr(), tq.data_ptr(), tkv.data_ptr(), self.scr("attn"), B2, Hs * Ws, 49, heads, Cc, scale,
+                ad[0], ad[1], ad[2], self.rng_ptr, dt),
                 {"kind": "sr_attention_bwd", "bytes": (6 * R * Cc + 4 * Rk * Cc) * self._es(), "flops": 5 * rec["aflops"] // 2})
             dh = self.buf(R, Cc) if False else rec["h2"]         # h2 is dead here (fc1 wgrad done): reuse as d(norm1 output)
             if sr > 1:

@@ -27,6 +27,7 @@ struct AttnP {
   int Nq, Nk, H, B;
   float scale;
   int qsplit, q_per_split;
+  uint32_t drop_thr, drop_site; float drop_inv; const uint32_t* rng;   // attn_drop (changeformer.py:160,203): 0 = off
 };
 
 __device__ __forceinline__ f32x4 mma16k(f32x4 acc, s16x4 a, s16x4 b) {
@@ -117,6 +118,15 @@ __global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(AttnP p) {
       l += e;
     }
   l = xg_sum(l);
+  if (p.drop_thr) {                                        // attn_drop on the normalised probabilities: the row sum stays undropped
+    const uint32_t key = ksmi_rng_key(p.rng, p.drop_site);
+    const uint32_t base = (((uint32_t)b * p.H + h) * p.Nq + qrow) * p.Nk;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        S[kt][r] = ksmi_rng_keep(key, base + kt * 16 + g * 4 + r, p.drop_thr) ? S[kt][r] * p.drop_inv : 0.f;
+  }
   f32x4 O[G::DT];
 #pragma unroll
   for (int dt = 0; dt < G::DT; ++dt) O[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -210,6 +220,8 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_q_kernel(AttnP p) {
   f32x4 dQ[G::DT];
 #pragma unroll
   for (int dt = 0; dt < G::DT; ++dt) dQ[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const uint32_t dkey = p.drop_thr ? ksmi_rng_key(p.rng, p.drop_site) : 0u;
+  const uint32_t dbase = (uint32_t)ridx * p.Nk;
 #pragma unroll
   for (int kt = 0; kt < NKT; ++kt) {
     const f32x4 s = S[kt];
@@ -222,7 +234,9 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_q_kernel(AttnP p) {
     for (int r = 0; r < 4; ++r) {
       const bool kok = kt * 16 + g * 4 + r < p.Nk;
       const float pr = (kok && qok) ? __expf(s[r] * p.scale - lse) : 0.f;
-      ds[r] = pr * (dp[r] - delta) * p.scale;
+      float dpr = dp[r];
+      if (p.drop_thr) dpr = ksmi_rng_keep(dkey, dbase + kt * 16 + g * 4 + r, p.drop_thr) ? dpr * p.drop_inv : 0.f;
+      ds[r] = pr * (dpr - delta) * p.scale;
     }
     const s16x4 db = pack4(ds[0], ds[1], ds[2], ds[3]);
 #pragma unroll
@@ -271,6 +285,7 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kv_kernel(AttnP p, int kchu
 #pragma unroll
   for (int dt = 0; dt < G::DT; ++dt) { dK[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dV[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
   const int qb = split * p.q_per_split, qe = min(p.Nq, qb + p.q_per_split);
+  const uint32_t dkey = p.drop_thr ? ksmi_rng_key(p.rng, p.drop_site) : 0u;
   for (int q0 = qb; q0 < qe; q0 += QT) {
     __syncthreads();
     const int nv = min(QT, qe - q0);
@@ -298,7 +313,11 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kv_kernel(AttnP p, int kchu
       for (int r = 0; r < 4; ++r) {
         const int qi = t * 16 + g * 4 + r;
         pr[r] = kok ? __expf(s[r] * p.scale - Ls[qi]) : 0.f;
-        ds[r] = pr[r] * (dp[r] - Ds[qi]) * p.scale;
+        float mk = 1.f;
+        if (p.drop_thr)
+          mk = ksmi_rng_keep(dkey, ((((uint32_t)b * p.H + h) * p.Nq + q0 + qi) * p.Nk + key), p.drop_thr) ? p.drop_inv : 0.f;
+        ds[r] = pr[r] * (dp[r] * mk - Ds[qi]) * p.scale;
+        pr[r] *= mk;                                       // dV sees the dropped probabilities
       }
       const s16x4 pb = pack4(pr[0], pr[1], pr[2], pr[3]), db = pack4(ds[0], ds[1], ds[2], ds[3]);
 #pragma unroll
@@ -435,7 +454,8 @@ int ksmi_attn_mfma_vit(int backward, const void* qkv, void* out, float* lse, con
 
 // ChangeFormer shape: q [B*Nq][C], kv [B*Nk][2C] with Nk <= 64, head dim 64 or 80
 int ksmi_attn_mfma_sr(int backward, const void* q, const void* kv, void* out, float* lse, const void* dout, void* dq, void* dkv,
-                      void* workspace, int B, int Nq, int Nk, int H, int C, float scale, void* stream) {
+                      void* workspace, int B, int Nq, int Nk, int H, int C, float scale, uint32_t drop_thr, float drop_inv,
+                      uint32_t drop_site, const uint32_t* rng, void* stream) {
   if (Nk > 64) return ksmi_fail(KSMI_E_UNSUPPORTED, "sr attention (MFMA): at most 64 keys");
   const int D = C / H;
   AttnP p = {};
@@ -443,6 +463,7 @@ int ksmi_attn_mfma_sr(int backward, const void* q, const void* kv, void* out, fl
   p.o = (bf16_t*)out; p.lse = lse;                        // lse may be null: the backward recomputes it
   p.q_rs = C; p.k_rs = p.v_rs = 2 * C; p.o_rs = C;
   p.Nq = Nq; p.Nk = Nk; p.H = H; p.B = B; p.scale = scale;
+  p.drop_thr = drop_thr; p.drop_inv = drop_inv; p.drop_site = drop_site; p.rng = rng;
   if (backward) {
     p.dout = (const bf16_t*)dout;
     p.dq = (bf16_t*)dq; p.dk = (bf16_t*)dkv; p.dv = p.dk + C;

@@ -308,10 +308,12 @@ __device__ __forceinline__ void axpy_row(float* o, float p, const float* row) {
   }
 }
 
+struct SrDrop { uint32_t thr, site; float inv; const uint32_t* rng; };   // attn_drop (:160,203): thr = 0 -> off
+
 // forward: one query per thread, keys walked with an online softmax (no per-key register arrays: the fully unrolled
 // 49 x D version spilled kilobytes of scratch per thread)
 template <typename T, int D, int NK>
-__global__ __launch_bounds__(256) void sr_attn_fwd_kernel(const T* q, const T* kv, T* out, int Nq, int C, float scale) {
+__global__ __launch_bounds__(256) void sr_attn_fwd_kernel(const T* q, const T* kv, T* out, int Nq, int C, float scale, SrDrop dr) {
   __shared__ __attribute__((aligned(16))) float sK[NK * D];
   __shared__ __attribute__((aligned(16))) float sV[NK * D];
   const int b = blockIdx.z, h = blockIdx.y;
@@ -324,6 +326,8 @@ __global__ __launch_bounds__(256) void sr_attn_fwd_kernel(const T* q, const T* k
 #pragma unroll
   for (int d = 0; d < D; ++d) { qr[d] = ElemTraits<T>::ld(qp + d) * scale; o[d] = 0.f; }
   float m = -3.0e38f, l = 0.f;
+  const uint32_t dkey = dr.thr ? ksmi_rng_key(dr.rng, dr.site) : 0u;
+  const uint32_t dbase = (((uint32_t)b * gridDim.y + h) * Nq + i) * NK;
 #pragma unroll 1
   for (int j = 0; j < NK; ++j) {
     const float a = dot_row<D>(qr, sK + j * D);
@@ -335,8 +339,9 @@ __global__ __launch_bounds__(256) void sr_attn_fwd_kernel(const T* q, const T* k
       m = a;
     }
     const float p = __expf(a - m);
-    l += p;
-    axpy_row<D>(o, p, sV + j * D);
+    l += p;                                                              // attn_drop acts on the normalised row: l stays whole
+    const float pd = !dr.thr ? p : (ksmi_rng_keep(dkey, dbase + j, dr.thr) ? p * dr.inv : 0.f);
+    axpy_row<D>(o, pd, sV + j * D);
   }
   const float inv = 1.f / l;
   T* op = out + ((int64_t)b * Nq + i) * C + h * D;
@@ -348,7 +353,7 @@ __global__ __launch_bounds__(256) void sr_attn_fwd_kernel(const T* q, const T* k
 // Three walks over the keys: (1) softmax max / sum, (2) P, dP (parked in the scratch rows) and delta, (3) dS and dq.
 template <typename T, int D, int NK>
 __global__ __launch_bounds__(256) void sr_attn_bwd_q_kernel(const T* q, const T* kv, const T* dout, T* dq, float* Pbuf, float* dSbuf,
-                                                            int Nq, int C, int H, float scale) {
+                                                            int Nq, int C, int H, float scale, SrDrop dr) {
   __shared__ __attribute__((aligned(16))) float sK[NK * D];
   __shared__ __attribute__((aligned(16))) float sV[NK * D];
   const int b = blockIdx.z, h = blockIdx.y;
@@ -364,6 +369,8 @@ __global__ __launch_bounds__(256) void sr_attn_bwd_q_kernel(const T* q, const T*
 #pragma unroll
   for (int d = 0; d < D; ++d) { qr[d] = ElemTraits<T>::ld(qp + d) * scale; gr[d] = ElemTraits<T>::ld(gp + d); }
   float m = -3.0e38f;
+  const uint32_t dkey = dr.thr ? ksmi_rng_key(dr.rng, dr.site) : 0u;
+  const uint32_t dbase = (((uint32_t)b * H + h) * Nq + i) * NK;
 #pragma unroll 1
   for (int j = 0; j < NK; ++j) {
     const float a = dot_row<D>(qr, sK + j * D);
@@ -378,7 +385,8 @@ __global__ __launch_bounds__(256) void sr_attn_bwd_q_kernel(const T* q, const T*
 #pragma unroll 1
   for (int j = 0; j < NK; ++j) {
     const float p = __expf(Pp[j] - m) * inv;
-    const float dp = dot_row<D>(gr, sV + j * D);
+    float dp = dot_row<D>(gr, sV + j * D);
+    if (dr.thr) dp = ksmi_rng_keep(dkey, dbase + j, dr.thr) ? dp * dr.inv : 0.f;
     Pp[j] = p;
     Sp[j] = dp;
     delta += p * dp;
@@ -389,6 +397,7 @@ __global__ __launch_bounds__(256) void sr_attn_bwd_q_kernel(const T* q, const T*
   for (int j = 0; j < NK; ++j) {
     const float ds = Pp[j] * (Sp[j] - delta) * scale;
     Sp[j] = ds;
+    if (dr.thr) Pp[j] = ksmi_rng_keep(dkey, dbase + j, dr.thr) ? Pp[j] * dr.inv : 0.f;   // the kv pass (dV) reads the dropped row
     axpy_row<D>(gr, ds, sK + j * D);
   }
   T* op = dq + ((int64_t)b * Nq + i) * C + h * D;
@@ -660,27 +669,27 @@ __global__ void dout_to_nhwc_kernel(const float* dy, const float* y, T* dx, int 
 
 template <typename T, int D>
 int sr_attn_launch(int which, const void* q, const void* kv, const void* io, void* o2, float* Pb, float* Sb, float* partial,
-                   int B, int Nq, int H, int C, float scale, int nsplit, hipStream_t st) {
+                   int B, int Nq, int H, int C, float scale, int nsplit, SrDrop dr, hipStream_t st) {
   constexpr int NK = 49;
   const dim3 grid((Nq + 255) / 256, H, B);
-  if (which == 0) hipLaunchKernelGGL((sr_attn_fwd_kernel<T, D, NK>), grid, dim3(256), 0, st, (const T*)q, (const T*)kv, (T*)o2, Nq, C, scale);
+  if (which == 0) hipLaunchKernelGGL((sr_attn_fwd_kernel<T, D, NK>), grid, dim3(256), 0, st, (const T*)q, (const T*)kv, (T*)o2, Nq, C, scale, dr);
   else if (which == 1)
-    hipLaunchKernelGGL((sr_attn_bwd_q_kernel<T, D, NK>), grid, dim3(256), 0, st, (const T*)q, (const T*)kv, (const T*)io, (T*)o2, Pb, Sb, Nq, C, H, scale);
+    hipLaunchKernelGGL((sr_attn_bwd_q_kernel<T, D, NK>), grid, dim3(256), 0, st, (const T*)q, (const T*)kv, (const T*)io, (T*)o2, Pb, Sb, Nq, C, H, scale, dr);
   else
     hipLaunchKernelGGL((sr_attn_bwd_kv_kernel<T, D, NK>), dim3(nsplit, H, B), dim3(256), 0, st, (const T*)q, (const T*)io, Pb, Sb, partial, Nq, C, H, B);
   return ksmi_check_launch("sr_attention");
 }
 
 int sr_attn_dispatch(int which, const void* q, const void* kv, const void* io, void* o2, float* Pb, float* Sb, float* partial,
-                     int B, int Nq, int Nk, int H, int C, float scale, int nsplit, int dtype, hipStream_t st) {
+                     int B, int Nq, int Nk, int H, int C, float scale, int nsplit, int dtype, SrDrop dr, hipStream_t st) {
   if (Nk != 49) return ksmi_fail(KSMI_E_UNSUPPORTED, "sr_attention: specialised for 49 keys (224x224 tiles: 7x7 after spatial reduction)");
   if (H < 1 || C % H) return ksmi_fail(KSMI_E_ARG, "sr_attention: C must be divisible by heads");
   const int D = C / H;
   if (dtype != KSMI_BF16 && dtype != KSMI_F32) return ksmi_fail(KSMI_E_ARG, "bad dtype");
-  if (D == 64) return dtype == KSMI_BF16 ? sr_attn_launch<bf16_t, 64>(which, q, kv, io, o2, Pb, Sb, partial, B, Nq, H, C, scale, nsplit, st)
-                                         : sr_attn_launch<float, 64>(which, q, kv, io, o2, Pb, Sb, partial, B, Nq, H, C, scale, nsplit, st);
-  if (D == 80) return dtype == KSMI_BF16 ? sr_attn_launch<bf16_t, 80>(which, q, kv, io, o2, Pb, Sb, partial, B, Nq, H, C, scale, nsplit, st)
-                                         : sr_attn_launch<float, 80>(which, q, kv, io, o2, Pb, Sb, partial, B, Nq, H, C, scale, nsplit, st);
+  if (D == 64) return dtype == KSMI_BF16 ? sr_attn_launch<bf16_t, 64>(which, q, kv, io, o2, Pb, Sb, partial, B, Nq, H, C, scale, nsplit, dr, st)
+                                         : sr_attn_launch<float, 64>(which, q, kv, io, o2, Pb, Sb, partial, B, Nq, H, C, scale, nsplit, dr, st);
+  if (D == 80) return dtype == KSMI_BF16 ? sr_attn_launch<bf16_t, 80>(which, q, kv, io, o2, Pb, Sb, partial, B, Nq, H, C, scale, nsplit, dr, st)
+                                         : sr_attn_launch<float, 80>(which, q, kv, io, o2, Pb, Sb, partial, B, Nq, H, C, scale, nsplit, dr, st);
   return ksmi_fail(KSMI_E_UNSUPPORTED, "sr_attention: head dim must be 64 or 80 (ChangeFormerV6 embed_dims / num_heads)");
 }
 
@@ -923,10 +932,19 @@ static bool sr_mfma(int dtype, int Nk, int C, int H) {
   return dtype == KSMI_BF16 && Nk <= 64 && H > 0 && (C / H == 64 || C / H == 80) && !valu;
 }
 
+int ksmi_sr_attention_forward_drop(const void* q, const void* kv, void* out, int B, int Nq, int Nk, int H, int C, float scale,
+                                   uint32_t drop_thr, float drop_inv_keep, uint32_t site, const uint32_t* rng_state, int dtype, void* stream) {
+  if (drop_thr && !rng_state) return ksmi_fail(KSMI_E_ARG, "sr_attention: dropout needs the rng state");
+  if ((uint64_t)B * H * Nq * Nk >= (1ull << 32)) return ksmi_fail(KSMI_E_UNSUPPORTED, "sr_attention: B*H*Nq*Nk must stay below 2^32");
+  if (sr_mfma(dtype, Nk, C, H))
+    return ksmi_attn_mfma_sr(0, q, kv, out, nullptr, nullptr, nullptr, nullptr, nullptr, B, Nq, Nk, H, C, scale, drop_thr, drop_inv_keep, site,
+                             rng_state, stream);
+  const SrDrop dr = {drop_thr, site, drop_inv_keep, rng_state};
+  return sr_attn_dispatch(0, q, kv, nullptr, out, nullptr, nullptr, nullptr, B, Nq, Nk, H, C, scale, 1, dtype, dr, (hipStream_t)stream);
+}
 int ksmi_sr_attention_forward(const void* q, const void* kv, void* out, int B, int Nq, int Nk, int H, int C, float scale, int dtype,
                               void* stream) {
-  if (sr_mfma(dtype, Nk, C, H)) return ksmi_attn_mfma_sr(0, q, kv, out, nullptr, nullptr, nullptr, nullptr, nullptr, B, Nq, Nk, H, C, scale, stream);
-  return sr_attn_dispatch(0, q, kv, nullptr, out, nullptr, nullptr, nullptr, B, Nq, Nk, H, C, scale, 1, dtype, (hipStream_t)stream);
+  return ksmi_sr_attention_forward_drop(q, kv, out, B, Nq, Nk, H, C, scale, 0u, 1.f, 0u, nullptr, dtype, stream);
 }
 
 size_t ksmi_sr_attention_bwd_workspace_valu(int B, int Nq, int Nk, int H, int C);
@@ -943,25 +961,33 @@ size_t ksmi_sr_attention_bwd_workspace_valu(int B, int Nq, int Nk, int H, int C)
   return 2 * ps + (size_t)ksmi_sr_attention_splits(Nq) * B * Nk * 2 * C * sizeof(float);
 }
 
-int ksmi_sr_attention_backward(const void* q, const void* kv, const void* out, const void* dout, void* dq, void* dkv, void* workspace, int B,
-                               int Nq, int Nk, int H, int C, float scale, int dtype, void* stream) {
+int ksmi_sr_attention_backward_drop(const void* q, const void* kv, const void* out, const void* dout, void* dq, void* dkv, void* workspace,
+                                    int B, int Nq, int Nk, int H, int C, float scale, uint32_t drop_thr, float drop_inv_keep, uint32_t site,
+                                    const uint32_t* rng_state, int dtype, void* stream) {
+  if (drop_thr && !rng_state) return ksmi_fail(KSMI_E_ARG, "sr_attention: dropout needs the rng state");
   if (sr_mfma(dtype, Nk, C, H))
-    return ksmi_attn_mfma_sr(1, q, kv, (void*)out, nullptr, dout, dq, dkv, workspace, B, Nq, Nk, H, C, scale, stream);
+    return ksmi_attn_mfma_sr(1, q, kv, (void*)out, nullptr, dout, dq, dkv, workspace, B, Nq, Nk, H, C, scale, drop_thr, drop_inv_keep, site,
+                             rng_state, stream);
+  const SrDrop dr = {drop_thr, site, drop_inv_keep, rng_state};
   const size_t ps = (size_t)B * H * Nq * Nk;
   float* Pb = (float*)workspace;
   float* Sb = Pb + ps;
   float* partial = Sb + ps;
   const int nsplit = ksmi_sr_attention_splits(Nq);
   hipStream_t st = (hipStream_t)stream;
-  int rc = sr_attn_dispatch(1, q, kv, dout, dq, Pb, Sb, partial, B, Nq, Nk, H, C, scale, nsplit, dtype, st);
+  int rc = sr_attn_dispatch(1, q, kv, dout, dq, Pb, Sb, partial, B, Nq, Nk, H, C, scale, nsplit, dtype, dr, st);
   if (rc) return rc;
-  rc = sr_attn_dispatch(2, q, kv, dout, nullptr, Pb, Sb, partial, B, Nq, Nk, H, C, scale, nsplit, dtype, st);
+  rc = sr_attn_dispatch(2, q, kv, dout, nullptr, Pb, Sb, partial, B, Nq, Nk, H, C, scale, nsplit, dtype, dr, st);
   if (rc) return rc;
   const int64_t n = (int64_t)B * Nk * 2 * C;
   KSMI_DT(dtype,
           hipLaunchKernelGGL(sum_splits_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, st, partial, (bf16_t*)dkv, n, nsplit),
           hipLaunchKernelGGL(sum_splits_kernel<float>, dim3(grid_for(n)), dim3(256), 0, st, partial, (float*)dkv, n, nsplit));
   return ksmi_check_launch("sr_attention_sum");
+}
+int ksmi_sr_attention_backward(const void* q, const void* kv, const void* out, const void* dout, void* dq, void* dkv, void* workspace, int B,
+                               int Nq, int Nk, int H, int C, float scale, int dtype, void* stream) {
+  return ksmi_sr_attention_backward_drop(q, kv, out, dout, dq, dkv, workspace, B, Nq, Nk, H, C, scale, 0u, 1.f, 0u, nullptr, dtype, stream);
 }
 
 int ksmi_bilinear_forward(const void* x, const void* add, void* y, int B, int Hi, int Wi, int Ho, int Wo, int C, int dtype, void* stream) {

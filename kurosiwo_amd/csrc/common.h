@@ -98,3 +98,18 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
   const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   return base + idx;
 }
+
+// ---- counter-based random stream of the stochastic layers ------------------------------------------------------------
+// nn.Dropout / DropPath of the reference draw from torch's global generator; here every Bernoulli draw is a pure function
+// of (seed, step, site, element index) so that the backward pass regenerates the forward's mask instead of storing it and
+// the CPU oracle (oracle/rng_ref.py) reproduces the same masks.  state[0] = seed, state[1] = step (device memory).
+__device__ __forceinline__ uint32_t ksmi_mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x21f0aaadu; x ^= x >> 15; x *= 0x735a2d97u; x ^= x >> 15;
+  return x;
+}
+__device__ __forceinline__ uint32_t ksmi_rng_key(const uint32_t* state, uint32_t site) {
+  return ksmi_mix32(state[0] ^ ksmi_mix32(state[1] ^ ksmi_mix32(site + 0x9e3779b9u)));
+}
+__device__ __forceinline__ uint32_t ksmi_rng_u32(uint32_t key, uint32_t idx) { return ksmi_mix32(ksmi_mix32(idx) ^ key); }
+// element kept with probability 1 - thr / 2^32
+__device__ __forceinline__ bool ksmi_rng_keep(uint32_t key, uint32_t idx, uint32_t thr) { return ksmi_rng_u32(key, idx) >= thr; }

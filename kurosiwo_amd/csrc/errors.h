@@ -15,7 +15,8 @@ size_t ksmi_attn_mfma_workspace(int B, int Nq, int Nk, int H, int D);
 int ksmi_attn_mfma_vit(int backward, const void* qkv, void* out, float* lse, const void* dout, void* dqkv, void* workspace, int B, int N,
                        int H, float scale, void* stream);
 int ksmi_attn_mfma_sr(int backward, const void* q, const void* kv, void* out, float* lse, const void* dout, void* dq, void* dkv,
-                      void* workspace, int B, int Nq, int Nk, int H, int C, float scale, void* stream);
+                      void* workspace, int B, int Nq, int Nk, int H, int C, float scale, uint32_t drop_thr, float drop_inv,
+                      uint32_t drop_site, const uint32_t* rng, void* stream);
 
 // gemm_lt.hip: plain nn.Linear GEMMs above a size threshold on hipBLASLt (bound at run time); 0 = launched, 1 = not taken
 int ksmi_lt_linear_forward(const void* x, int x_rs, const void* w, int w_rs, const float* bias, const void* resid, int r_rs, void* y, int y_rs,

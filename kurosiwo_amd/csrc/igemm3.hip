@@ -219,8 +219,10 @@ __global__ __launch_bounds__(256 * WN, (WN == 1 && NCH * KH * KW * NTI <= 9) ? 2
               for (int j = 0; j < 8; ++j) x[j] = __builtin_amdgcn_fmed3f(x[j], 0.f, 3.0e38f);
             }
             u32x4 o = vec_pack<T>(x);
+            if (ka.dbg & 16) o = xv[k];
             if (!okv[s0i + k]) o = (u32x4){0u, 0u, 0u, 0u};
-            *(u32x4*)(sb + ch * hpb + pix * 64 + ((q ^ swz(pix)) << 4)) = o;
+            if (!(ka.dbg & 8)) *(u32x4*)(sb + ch * hpb + pix * 64 + ((q ^ swz(pix)) << 4)) = o;
+            else asm volatile("" :: "v"(o));
           }
         }
         __builtin_amdgcn_sched_barrier(0);

@@ -272,22 +272,45 @@ def dwconv3x3_backward(x, dz, weight):
     return dx, dw, db
 
 
-def sr_attention(q, kv, B, Nq, Nk, heads):
+def _drop_args(p, site, rng_state):
+    """(thr, inv_keep, site, state pointer) of one stochastic layer; p = 0 -> off (see ksmi.h: ksmi_dropout_apply)"""
+    if p <= 0.0:
+        return 0, 1.0, 0, None
+    if rng_state is None or rng_state.dtype != torch.int32 or rng_state.numel() != 2:
+        raise ValueError("rng_state: int32[2] device tensor {seed, step}")
+    return min(0xFFFFFFFF, int(round(p * 4294967296.0))), 1.0 / (1.0 - p), site, rng_state.data_ptr()
+
+
+def sr_attention(q, kv, B, Nq, Nk, heads, p=0.0, site=0, rng_state=None):
     Cc = q.shape[1]
     out = torch.empty_like(q)
-    _lib.check(_lib.load().ksmi_sr_attention_forward(q.data_ptr(), kv.data_ptr(), out.data_ptr(), B, Nq, Nk, heads, Cc,
-                                                     (Cc // heads) ** -0.5, DT[q.dtype], stream_ptr()), "sr_attention_fwd")
+    thr, inv, site, st = _drop_args(p, site, rng_state)
+    _lib.check(_lib.load().ksmi_sr_attention_forward_drop(q.data_ptr(), kv.data_ptr(), out.data_ptr(), B, Nq, Nk, heads, Cc,
+                                                          (Cc // heads) ** -0.5, thr, inv, site, st, DT[q.dtype], stream_ptr()), "sr_attention_fwd")
     return out
 
 
-def sr_attention_backward(q, kv, out, dout, B, Nq, Nk, heads):
+def sr_attention_backward(q, kv, out, dout, B, Nq, Nk, heads, p=0.0, site=0, rng_state=None):
     Cc = q.shape[1]
     lib = _lib.load()
     ws = torch.empty(lib.ksmi_sr_attention_bwd_workspace(B, Nq, Nk, heads, Cc), dtype=torch.uint8, device=q.device)
     dq, dkv = torch.empty_like(q), torch.empty_like(kv)
-    _lib.check(lib.ksmi_sr_attention_backward(q.data_ptr(), kv.data_ptr(), out.data_ptr(), dout.data_ptr(), dq.data_ptr(), dkv.data_ptr(), ws.data_ptr(),
-                                              B, Nq, Nk, heads, Cc, (Cc // heads) ** -0.5, DT[q.dtype], stream_ptr()), "sr_attention_bwd")
+    thr, inv, site, st = _drop_args(p, site, rng_state)
+    _lib.check(lib.ksmi_sr_attention_backward_drop(q.data_ptr(), kv.data_ptr(), out.data_ptr(), dout.data_ptr(), dq.data_ptr(), dkv.data_ptr(),
+                                                   ws.data_ptr(), B, Nq, Nk, heads, Cc, (Cc // heads) ** -0.5, thr, inv, site, st, DT[q.dtype],
+                                                   stream_ptr()), "sr_attention_bwd")
     return dq, dkv
+
+
+def dropout_apply(x, rng_state, p=0.0, site=0, path_p=0.0, path_site=0, rows_per_sample=1, resid=None, out=None):
+    """y = [resid +] x * Dropout(p; site) * DropPath(path_p; path_site) over a [rows, cols] matrix (ksmi_dropout_apply)"""
+    rows, cols = x.shape
+    y = torch.empty_like(x) if out is None else out
+    t1, i1, s1, st1 = _drop_args(p, site, rng_state)
+    t2, i2, s2, st2 = _drop_args(path_p, path_site, rng_state)
+    _lib.check(_lib.load().ksmi_dropout_apply(x.data_ptr(), None if resid is None else resid.data_ptr(), y.data_ptr(), rows, cols, rows_per_sample,
+                                              t1, i1, s1, t2, i2, s2, st1 or st2, DT[x.dtype], stream_ptr()), "dropout_apply")
+    return y
 
 
 def bilinear(x, Ho, Wo, add=None):

@@ -5,15 +5,17 @@ A functional, state-dict driven fp32 restatement on stock PyTorch-CPU ops of /ro
   OverlapPatchEmbed        :251-292   -> _patch_embed
   Attention (SR)           :148-208   -> _attention
   Mlp + DWConv             :85-133    -> _mlp
-  Block                    :211-248   -> _block            (DropPath / Dropout are identities: see below)
+  Block                    :211-248   -> _block            (DropPath / Dropout: see below)
   EncoderTransformer_v3    :339-468   -> encoder_features
   conv_diff/make_prediction :31-46    -> _conv_diff / _make_pred (conv -> ReLU -> BatchNorm ordering)
   DecoderTransformer_v3    :485-641   -> decoder
   ChangeFormerV6.forward   :666-676   -> changeformer_forward
 
-Stochastic layers: ChangeFormerV6 hard-codes drop_rate = attn_drop = drop_path_rate = 0.1 (:651-653).  They are the
-identity in eval mode; for train-mode parity the golden vectors are generated with every nn.Dropout.p and DropPath.drop_prob
-set to 0 on the reference module (oracle/gen_golden.py), i.e. train mode = BatchNorm batch statistics only.
+Stochastic layers: ChangeFormerV6 hard-codes drop_rate = attn_drop = drop_path_rate = 0.1 (:651-653), identities in eval mode.
+Train-mode vectors exist in two flavours: changeformer.npz / changeformer_slc.npz with every nn.Dropout.p and DropPath.drop_prob
+set to 0 on the reference module, and changeformer_drop.npz with the layers ON, their Bernoulli draws taken from the
+counter-based stream of oracle/rng_ref.py (`stream=` below; the reference's own modules are run with the same draws in
+oracle/gen_golden.py:gen_changeformer_drop).
 
 Pinned to the real reference by tests/golden/changeformer_*.npz.  Only tests/, smoke() and bench.py's cpu_baseline may
 import this module.
@@ -141,7 +143,7 @@ def _patch_embed(sd, key, x, stride):
     return _ln(sd, f"{key}.norm", x, 1e-5), H, W              # OverlapPatchEmbed.norm = nn.LayerNorm default eps (:268)
 
 
-def _attention(sd, key, x, H, W, heads, sr):
+def _attention(sd, key, x, H, W, heads, sr, drop=None):
     B, N, Cc = x.shape
     d = Cc // heads
     q = F.linear(x, sd[f"{key}.q.weight"], sd[f"{key}.q.bias"]).reshape(B, N, heads, d).permute(0, 2, 1, 3)
@@ -154,34 +156,65 @@ def _attention(sd, key, x, H, W, heads, sr):
     kv = F.linear(x_, sd[f"{key}.kv.weight"], sd[f"{key}.kv.bias"]).reshape(B, -1, 2, heads, d).permute(2, 0, 3, 1, 4)
     k, v = kv[0], kv[1]
     attn = ((q @ k.transpose(-2, -1)) * d ** -0.5).softmax(dim=-1)
+    if drop is not None:                                       # attn_drop (:203): element ((b*heads + h)*N + q)*Nk + key
+        attn = attn * drop("attn", attn.shape)
     x = (attn @ v).transpose(1, 2).reshape(B, N, Cc)
-    return F.linear(x, sd[f"{key}.proj.weight"], sd[f"{key}.proj.bias"])
+    x = F.linear(x, sd[f"{key}.proj.weight"], sd[f"{key}.proj.bias"])
+    return x if drop is None else x * drop("proj", x.shape)    # proj_drop (:207)
 
 
-def _mlp(sd, key, x, H, W):
+def _mlp(sd, key, x, H, W, drop=None):
     B, N, _ = x.shape
     x = F.linear(x, sd[f"{key}.fc1.weight"], sd[f"{key}.fc1.bias"])
     Ch = x.shape[-1]
     x = x.transpose(1, 2).reshape(B, Ch, H, W)
     x = F.conv2d(x, sd[f"{key}.dwconv.dwconv.weight"], sd[f"{key}.dwconv.dwconv.bias"], padding=1, groups=Ch)
     x = F.gelu(x.flatten(2).transpose(1, 2))
-    return F.linear(x, sd[f"{key}.fc2.weight"], sd[f"{key}.fc2.bias"])
+    if drop is not None:
+        x = x * drop("mlp1", x.shape)                          # Mlp.drop after the activation (:130)
+    x = F.linear(x, sd[f"{key}.fc2.weight"], sd[f"{key}.fc2.bias"])
+    return x if drop is None else x * drop("mlp2", x.shape)    # ... and after fc2 (:132)
 
 
-def _block(sd, key, x, H, W, heads, sr):
-    x = x + _attention(sd, f"{key}.attn", _ln(sd, f"{key}.norm1", x, 1e-6), H, W, heads, sr)
-    return x + _mlp(sd, f"{key}.mlp", _ln(sd, f"{key}.norm2", x, 1e-6), H, W)
+def _block(sd, key, x, H, W, heads, sr, drop=None):
+    """Block.forward :245-248: x + drop_path(attn(norm1(x))), x + drop_path(mlp(norm2(x)))"""
+    a = _attention(sd, f"{key}.attn", _ln(sd, f"{key}.norm1", x, 1e-6), H, W, heads, sr, drop)
+    x = x + (a if drop is None else a * drop("path_attn", (x.shape[0], 1, 1)))
+    m = _mlp(sd, f"{key}.mlp", _ln(sd, f"{key}.norm2", x, 1e-6), H, W, drop)
+    return x + (m if drop is None else m * drop("path_mlp", (x.shape[0], 1, 1)))
 
 
-def encoder_features(sd, x, inter=None):
+def _block_drop(stream, gi, sample0):
+    """mask factory of block gi for the images sample0 .. sample0+B-1 of the 2B-image batch the HIP path runs (date 1 first):
+    element indices are row-major positions in that batched tensor (rng_ref.py)"""
+    from . import rng_ref as G
+    sites = {"attn": (G.SITE_ATTN, stream.p_attn), "proj": (G.SITE_PROJ, stream.p_drop), "mlp1": (G.SITE_MLP1, stream.p_drop),
+             "mlp2": (G.SITE_MLP2, stream.p_drop)}
+
+    def f(name, shape):
+        if name.startswith("path"):
+            m = stream.path(gi, G.SITE_PATH_ATTN if name == "path_attn" else G.SITE_PATH_MLP, sample0, shape[0])
+            return torch.from_numpy(m).reshape(shape)
+        site, p = sites[name]
+        per = 1
+        for d in shape[1:]:
+            per *= d
+        return torch.from_numpy(stream.elements(gi, site, p, sample0 * per, tuple(shape)))
+    return f
+
+
+def encoder_features(sd, x, inter=None, stream=None, sample0=0):
     B = x.shape[0]
     outs = []
+    gi = 0
     for st in range(4):
         t, H, W = _patch_embed(sd, f"Tenc_x2.patch_embed{st + 1}", x, 4 if st == 0 else 2)
         if inter is not None:
             inter[f"pe{st + 1}"] = t
         for i in range(DEPTHS[st]):
-            t = _block(sd, f"Tenc_x2.block{st + 1}.{i}", t, H, W, NUM_HEADS[st], SR_RATIOS[st])
+            t = _block(sd, f"Tenc_x2.block{st + 1}.{i}", t, H, W, NUM_HEADS[st], SR_RATIOS[st],
+                       None if stream is None else _block_drop(stream, gi, sample0))
+            gi += 1
             if inter is not None:
                 inter[f"s{st + 1}b{i}"] = t
         t = _ln(sd, f"Tenc_x2.norm{st + 1}", t, 1e-6)
@@ -252,11 +285,12 @@ def decoder(sd, f1, f2, training=False, new_stats=None, decoder_softmax=True, in
     return [torch.sigmoid(o) for o in outputs] if decoder_softmax else outputs
 
 
-def changeformer_forward(sd, x1, x2, training=False, new_stats=None, decoder_softmax=True, inter=None, masks=None):
+def changeformer_forward(sd, x1, x2, training=False, new_stats=None, decoder_softmax=True, inter=None, masks=None, stream=None):
     """Returns the list of 5 outputs [(B,3,7,7), (B,3,14,14), (B,3,28,28), (B,3,56,56), (B,3,224,224)] (for 224x224 input)."""
     i1 = {} if inter is not None else None
     i2 = {} if inter is not None else None
-    f1, f2 = encoder_features(sd, x1, i1), encoder_features(sd, x2, i2)
+    st = stream if training else None                           # nn.Dropout / DropPath are identities in eval mode
+    f1, f2 = encoder_features(sd, x1, i1, st, 0), encoder_features(sd, x2, i2, st, x1.shape[0])
     if inter is not None:
         inter.update({f"A.{k}": v for k, v in i1.items()})
         inter.update({f"B.{k}": v for k, v in i2.items()})
@@ -265,12 +299,12 @@ def changeformer_forward(sd, x1, x2, training=False, new_stats=None, decoder_sof
     return decoder(sd, f1, f2, training, new_stats, decoder_softmax, inter, masks)
 
 
-def loss_and_grads(sd, x1, x2, labels, weights=(1.0, 1.0, 1.0), with_dice=True, masks=None):
+def loss_and_grads(sd, x1, x2, labels, weights=(1.0, 1.0, 1.0), with_dice=True, masks=None, stream=None):
     """One train-mode forward/backward with the reference's CD criterion on output[-1] (cd_trainer:138-166)."""
     from .snunet_ref import torch_ce_dice
     params = {k: (v.detach().clone().requires_grad_(True) if not is_buffer(k) else v) for k, v in sd.items()}
     new_stats = {}
-    outs = changeformer_forward(params, x1, x2, training=True, new_stats=new_stats, masks=masks)
+    outs = changeformer_forward(params, x1, x2, training=True, new_stats=new_stats, masks=masks, stream=stream)
     loss = torch_ce_dice(outs[-1], labels, weights, with_dice)
     total = loss[0] if isinstance(loss, (tuple, list)) else loss
     total.backward()

@@ -346,8 +346,12 @@ def _import_changeformer_reference():
             self.drop_prob = drop_prob
 
         def forward(self, x):
-            assert not (self.training and self.drop_prob > 0), "golden vectors are generated with drop_path = 0"
-            return x
+            if not (self.training and self.drop_prob > 0):
+                return x
+            # timm drop_path: x / keep_prob * Bernoulli(keep_prob) per sample; the draw comes from the counter-based stream
+            # (gen_changeformer_drop) -- there is no golden vector with torch's own generator
+            assert getattr(self, "scale_fn", None) is not None, "drop_path > 0 needs the counter-based stream"
+            return x * self.scale_fn(x)
     attrs = {"timm": {}, "timm.models": {}, "timm.models.layers": {
         "DropPath": DropPath, "to_2tuple": lambda v: v if isinstance(v, tuple) else (v, v), "trunc_normal_": torch.nn.init.trunc_normal_}}
     for name, a in attrs.items():
@@ -491,6 +495,83 @@ def gen_changeformer_slc():
     np.savez_compressed(os.path.join(OUT, "changeformer_slc.npz"), **out)
 
 
+DROP_SEED, DROP_STEP = 20240607, 1
+
+
+def gen_changeformer_drop():
+    """Train-mode step of the REFERENCE ChangeFormerV6 with its stochastic layers ON (drop_rate = attn_drop = drop_path_rate = 0.1,
+    changeformer.py:651-653).  The module graph, the places and probabilities of every nn.Dropout / DropPath are the reference's;
+    only the source of the Bernoulli draws is replaced: each module instance draws from the counter-based stream of
+    oracle/rng_ref.py (site = 8 * block index + role, element index = position in the 2B-image batch the HIP path runs), which is
+    what the HIP kernels regenerate.  The k-th call of a module tells the role: Tenc_x2 runs date 1 then date 2 (:666-670), Mlp.drop
+    is called after the activation and after fc2 (:130,132), Block.drop_path for the attention and the Mlp branch (:246-247)."""
+    from oracle import rng_ref as G
+    ChangeFormerV6 = _import_changeformer_reference()
+    out = {}
+    c, B = 2, 2
+    model = ChangeFormerV6(input_nc=c, output_nc=3, decoder_softmax=True, embed_dim=256)
+    seeded_fill_(model.state_dict())
+    model.train()
+    stream = G.DropStream(DROP_SEED, DROP_STEP, model.drop_rate, model.attn_drop, model.drop_path_rate)
+    depths = [3, 3, 4, 3]
+    ndrop = 0
+
+    def install(mod, gi, roles, per_pass, path):
+        calls = {"n": 0}
+
+        def scale(x):
+            k = calls["n"]
+            calls["n"] += 1
+            sample0 = (k // per_pass) * B                       # pass 0 = date 1, pass 1 = date 2
+            role = roles[k % per_pass]
+            if path:
+                m = stream.path(gi, role, sample0, x.shape[0])
+                return torch.from_numpy(m).reshape(-1, *([1] * (x.dim() - 1)))
+            per = int(np.prod(x.shape[1:]))
+            p = stream.p_attn if role == G.SITE_ATTN else stream.p_drop
+            return torch.from_numpy(stream.elements(gi, role, p, sample0 * per, tuple(x.shape)))
+        if path:
+            mod.scale_fn = scale
+        else:
+            assert isinstance(mod, torch.nn.Dropout) and abs(mod.p - 0.1) < 1e-12
+            mod.forward = lambda x: x * scale(x)
+    gi = 0
+    for st in range(4):
+        for i in range(depths[st]):
+            blk = getattr(model.Tenc_x2, f"block{st + 1}")[i]
+            install(blk.attn.attn_drop, gi, [G.SITE_ATTN], 1, False)
+            install(blk.attn.proj_drop, gi, [G.SITE_PROJ], 1, False)
+            install(blk.mlp.drop, gi, [G.SITE_MLP1, G.SITE_MLP2], 2, False)
+            ndrop += 3
+            if gi > 0:                                          # dpr[0] = 0 -> nn.Identity (:222)
+                assert abs(blk.drop_path.drop_prob - stream.dpr[gi]) < 1e-7, (blk.drop_path.drop_prob, stream.dpr[gi])
+                install(blk.drop_path, gi, [G.SITE_PATH_ATTN, G.SITE_PATH_MLP], 2, True)
+            gi += 1
+    assert ndrop == sum(isinstance(m, torch.nn.Dropout) for m in model.modules()), "an nn.Dropout outside the encoder blocks"
+    x1 = sar_like("changeformer.drop.x1", (B, c, 224, 224))
+    x2 = sar_like("changeformer.drop.x2", (B, c, 224, 224))
+    lbl = seeded_labels("changeformer.drop.lbl", (B, 224, 224))
+    crit = BCEandDiceLoss(weights=CLASS_WEIGHTS, ignore_index=3, use_softmax=True)
+    outs = model(x1, x2)
+    loss = crit(outs[-1], lbl)
+    loss.backward()
+    out["seed_step"] = np.array([DROP_SEED, DROP_STEP])
+    for i, o in enumerate(outs[:4]):
+        out[f"train.out{i}"] = o.detach().numpy().copy()
+    out["train.out4_sub"] = outs[4][:, :, ::8, ::8].detach().numpy().copy()
+    out["train.loss"] = np.array(float(loss.detach()))
+    for k, p in model.named_parameters():
+        if p.grad is None:
+            out[f"gstat.{k}"] = np.zeros(3)
+            continue
+        g = p.grad.detach().double()
+        out[f"gstat.{k}"] = np.array([float(g.norm()), float(g.sum()), float(g.abs().max())])
+        if k in CHANGEFORMER_GRAD_KEYS:
+            out[f"grad.{k}"] = p.grad.detach().numpy().copy()
+    print("changeformer drop train loss", float(loss.detach()))
+    np.savez_compressed(os.path.join(OUT, "changeformer_drop.npz"), **out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -510,5 +591,7 @@ if __name__ == "__main__":
         gen_changeformer()
     if not only or "changeformer_slc" in only:
         gen_changeformer_slc()
+    if not only or "changeformer_drop" in only:
+        gen_changeformer_drop()
     if not only or "mae" in only:
         gen_mae()

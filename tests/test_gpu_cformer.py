@@ -111,6 +111,75 @@ def test_sr_attention_forward_backward(dtype, Cc, heads, Nq):
     assert rel(dq, qr.grad) < tol(dtype) and rel(dkv, kvr.grad) < tol(dtype)
 
 
+def _rng_state(seed, step):
+    return torch.tensor([seed, step], dtype=torch.int32, device="cuda")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_dropout_apply_regenerates_the_oracle_masks(dtype):
+    """ksmi_dropout_apply (nn.Dropout :107,162 + DropPath :236-241 + residual add): the masks are bit-identical to oracle/rng_ref.py,
+    and ksmi_rng_advance moves the stream to the next step."""
+    from kurosiwo_amd import _lib, functional as KF
+    from kurosiwo_amd.runtime import stream_ptr
+    from oracle import rng_ref as G
+    torch.manual_seed(11)
+    B2, N, Cc = 4, 49, 64
+    rows = B2 * N
+    seed, step, site, psite = 99, 5, 8 * 7 + G.SITE_MLP2, 8 * 7 + G.SITE_PATH_MLP
+    st = _rng_state(seed, step)
+    x = (torch.randn(rows, Cc, device="cuda") + 3.0).to(dtype)           # no zeros: the mask is readable from the output
+    r = torch.randn(rows, Cc, device="cuda").to(dtype)
+    m_el = torch.from_numpy(G.scale_mask(seed, step, site, 0.1, 0, (rows, Cc))).cuda()
+    m_path = torch.from_numpy(G.scale_mask(seed, step, psite, 0.3, 0, (B2,))).cuda().repeat_interleave(N)[:, None]
+    y = KF.dropout_apply(x, st, p=0.1, site=site)
+    assert torch.equal(y != 0, m_el > 0)
+    assert rel(y, x.float() * m_el) < tol(dtype)
+    y = KF.dropout_apply(x, st, path_p=0.3, path_site=psite, rows_per_sample=N)
+    assert torch.equal(y != 0, (m_path > 0).expand(rows, Cc))
+    y = KF.dropout_apply(x, st, p=0.1, site=site, path_p=0.3, path_site=psite, rows_per_sample=N, resid=r)
+    assert rel(y, r.float() + x.float() * m_el * m_path) < tol(dtype)
+    y2 = KF.dropout_apply(x.clone(), st, p=0.1, site=site, out=None)
+    xin = x.clone()
+    KF.dropout_apply(xin, st, p=0.1, site=site, out=xin)                 # in place (Mlp.drop on the activation)
+    assert torch.equal(xin, y2)
+    _lib.check(_lib.load().ksmi_rng_advance(st.data_ptr(), stream_ptr()), "rng_advance")
+    assert st.cpu().tolist() == [seed, step + 1]
+    y3 = KF.dropout_apply(x, st, p=0.1, site=site)
+    assert torch.equal(y3 != 0, torch.from_numpy(G.scale_mask(seed, step + 1, site, 0.1, 0, (rows, Cc))).cuda() > 0)
+    with pytest.raises(_lib.KsmiError):
+        KF.dropout_apply(x[:, :Cc - 1].contiguous(), st, p=0.1, site=site)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("Cc,heads,Nq", [(64, 1, 3136), (128, 2, 784), (320, 4, 196), (512, 8, 49)])
+def test_sr_attention_with_attention_dropout(dtype, Cc, heads, Nq):
+    """attn_drop (changeformer.py:160,203) inside the fused attention kernels (MFMA for bf16, VALU for fp32): forward and both backward
+    passes regenerate the mask of oracle/rng_ref.py at element ((b*heads + h)*Nq + q)*Nk + key."""
+    from kurosiwo_amd import functional as KF
+    from oracle import rng_ref as G
+    torch.manual_seed(3)
+    B, Nk, d = 2, 49, Cc // heads
+    seed, step, site, p = 1234, 7, 8 * 3 + G.SITE_ATTN, 0.1
+    st = _rng_state(seed, step)
+    q = torch.randn(B * Nq, Cc, device="cuda").to(dtype)
+    kv = torch.randn(B * Nk, 2 * Cc, device="cuda").to(dtype)
+    qr = q.float().requires_grad_(True)
+    kvr = kv.float().requires_grad_(True)
+    qq = qr.reshape(B, Nq, heads, d).permute(0, 2, 1, 3)
+    kk = kvr.reshape(B, Nk, 2, heads, d).permute(2, 0, 3, 1, 4)
+    mask = torch.from_numpy(G.scale_mask(seed, step, site, p, 0, (B, heads, Nq, Nk))).cuda()
+    attn = ((qq @ kk[0].transpose(-2, -1)) * d ** -0.5).softmax(-1) * mask
+    ref = (attn @ kk[1]).transpose(1, 2).reshape(B * Nq, Cc)
+    out = KF.sr_attention(q, kv, B, Nq, Nk, heads, p=p, site=site, rng_state=st)
+    assert rel(out, ref) < tol(dtype)
+    plain = KF.sr_attention(q, kv, B, Nq, Nk, heads)
+    assert rel(plain, ref) > 10 * tol(dtype)                              # the mask is really applied
+    do = torch.randn(B * Nq, Cc, device="cuda").to(dtype)
+    ref.backward(do.float())
+    dq, dkv = KF.sr_attention_backward(q, kv, out, do, B, Nq, Nk, heads, p=p, site=site, rng_state=st)
+    assert rel(dq, qr.grad) < tol(dtype) and rel(dkv, kvr.grad) < tol(dtype)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("hi,ho", [(7, 14), (7, 56), (14, 56), (28, 56)])
 def test_bilinear_forward_backward(dtype, hi, ho):

@@ -16,11 +16,14 @@ def sar_like(name, shape):
     return seeded_tensor(name, shape).clamp_(-2.23, 5.75)
 
 
-def build(precision):
+def build(precision, stochastic=False):
     from kurosiwo_amd.changeformer import ChangeFormerV6
     from oracle import changeformer_ref as R
     from oracle.seeded import seeded_fill_
     model = ChangeFormerV6(2, 3, decoder_softmax=True, embed_dim=256, precision=precision)
+    assert (model.drop_rate, model.attn_drop, model.drop_path_rate) == (0.1, 0.1, 0.1)       # changeformer.py:651-653
+    if not stochastic:      # the p = 0 golden vectors: train mode = BatchNorm batch statistics only
+        model.drop_rate = model.attn_drop = model.drop_path_rate = 0.0
     sd = seeded_fill_(R.new_state_dict(2, 3, 256))
     assert list(model.state_dict().keys()) == list(sd.keys())
     model.load_state_dict(sd)
@@ -156,6 +159,90 @@ def test_train_forward_backward_vs_oracle(golden_dir, precision):
     assert not worst, f"{precision}: {len(worst)} params: {dict(list(worst.items())[:12])}"
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_train_step_with_stochastic_layers_vs_reference_golden(golden_dir, precision):
+    """Dropout(0.1) / attention dropout 0.1 / DropPath(linspace(0, 0.1, 13)) ON (changeformer.py:651-653).  The golden vector is the
+    reference's own module graph with the draws of its nn.Dropout / DropPath instances taken from the counter-based stream
+    (oracle/gen_golden.py:gen_changeformer_drop); the HIP kernels regenerate the same masks in the forward and the backward pass."""
+    from oracle import changeformer_ref as R
+    from oracle import rng_ref as G
+    from oracle.seeded import seeded_labels
+    from kurosiwo_amd.loss import BCEandDiceLoss
+    gold = np.load(os.path.join(golden_dir, "changeformer_drop.npz"))
+    seed, step = (int(v) for v in gold["seed_step"])
+    B = 2
+    model, sd = build(precision, stochastic=True)
+    model.train()
+    model.manual_seed(seed, step - 1)                       # the forward advances the stream: step - 1 -> step
+    x1 = sar_like("changeformer.drop.x1", (B, 2, 224, 224))
+    x2 = sar_like("changeformer.drop.x2", (B, 2, 224, 224))
+    lbl = seeded_labels("changeformer.drop.lbl", (B, 224, 224))
+    outs = model(x1.cuda(), x2.cuda())
+    assert model.rng_state().cpu().tolist() == [seed, step]
+    plan = model.plan(B, 224, 224, True, True)
+    stream = G.DropStream(seed, step)
+    inter = {}
+    with torch.no_grad():
+        ref = R.changeformer_forward(sd, x1, x2, training=True, inter=inter, stream=stream)
+    compare_intermediates(plan, inter, B, 5e-4 if precision == "fp32" else 0.15)
+    if precision == "fp32":
+        for i in range(4):
+            assert np.abs(outs[i].detach().cpu().numpy() - gold[f"train.out{i}"]).max() < 1e-3
+        assert np.abs(outs[4].detach().cpu()[:, :, ::8, ::8].numpy() - gold["train.out4_sub"]).max() < 1e-3
+        for i in range(5):
+            assert float((outs[i].detach().cpu() - ref[i]).abs().max()) < 1e-3
+    else:
+        for i in range(5):
+            err = (outs[i].detach().cpu() - ref[i]).abs()
+            assert float(err.mean()) < 2e-2 and float(err.max()) < 0.35, (i, float(err.mean()), float(err.max()))
+    crit = BCEandDiceLoss(weights=CLASS_WEIGHTS, ignore_index=3, use_softmax=True)
+    loss = crit(outs[-1], lbl.cuda())
+    loss.backward()
+    assert abs(float(loss) - float(gold["train.loss"])) < (2e-4 if precision == "fp32" else 3e-2)
+    masks = {}
+    for i, h in ((4, 7), (3, 14), (2, 28), (1, 56)):
+        sc = plan.scales[i]
+        masks[f"diff_c{i}.0"] = (nchw(sc["r1"], B, h, h) > 0).float()
+        masks[f"diff_c{i}.3"] = (nchw(sc["r2"], B, h, h) > 0).float()
+    masks["dense_2x"] = (nchw(plan.dec["Ra"], B, 112, 112) > 0).float()
+    masks["dense_1x"] = (nchw(plan.dec["Rb"], B, 224, 224) > 0).float()
+    _, ref_loss, ref_grads, _ = R.loss_and_grads(sd, x1, x2, lbl, CLASS_WEIGHTS, True, masks=masks, stream=stream)
+    worst, coss = {}, []
+    for k, p in model.named_parameters():
+        g, r = p.grad.detach().float().cpu(), ref_grads[k]
+        if float(r.abs().max()) == 0.0:
+            assert float(g.abs().max()) == 0.0, k
+            continue
+        if k == "TDec_x2.linear_fuse.0.bias":
+            continue
+        if precision == "fp32":
+            e = float((g - r).abs().max() / (r.abs().max() + 1e-12))
+            l2 = float((g - r).double().norm() / (r.double().norm() + 1e-30))
+            if not (l2 < 2e-3 and e < 5e-3):
+                worst[k] = (e, l2)
+            ref = gold[f"gstat.{k}"]
+            if not abs(float(g.double().norm()) - ref[0]) <= 5e-3 * ref[0] + 1e-7:        # the reference's own gradient norms
+                worst[k + " (golden norm)"] = (float(g.double().norm()), ref[0])
+        else:
+            cos = float((g.double() * r.double()).sum() / (g.double().norm() * r.double().norm() + 1e-30))
+            coss.append(cos)
+            if not cos > 0.85:
+                worst[k] = cos
+    if coss:
+        assert float(np.median(coss)) > 0.97, float(np.median(coss))
+    assert not worst, f"{precision}: {len(worst)} params: {dict(list(worst.items())[:12])}"
+    # a second step draws new masks (step + 1): the output must change; the same (seed, step) must reproduce the first step bit for bit
+    model.zero_grad(set_to_none=True)
+    first = outs[4].detach().clone()
+    second = model(x1.cuda(), x2.cuda())[4].detach()
+    assert float((second - first).abs().max()) > 1e-4
+    model2, _ = build(precision, stochastic=True)
+    model2.train()
+    model2.manual_seed(seed, step - 1)
+    again = model2(x1.cuda(), x2.cuda())[4].detach()
+    assert torch.equal(again, first)
+
+
 def test_main_entry_changeformer_end_to_end_tiny(tmp_path, monkeypatch):
     """main.py --method changeformer on a tiny synthetic set: SGD(momentum .99, wd 1e-5) epoch, checkpoint, reload, test."""
     import shutil
@@ -182,6 +269,7 @@ def test_slc_four_band_inputs_vs_reference_golden(golden_dir, precision):
     from oracle.seeded import seeded_fill_, seeded_labels
     gold = np.load(os.path.join(golden_dir, "changeformer_slc.npz"))
     model = ChangeFormerV6(4, 3, decoder_softmax=True, embed_dim=256, precision=precision)
+    model.drop_rate = model.attn_drop = model.drop_path_rate = 0.0          # the golden train step has the stochastic layers at p = 0
     sd = seeded_fill_(R.new_state_dict(4, 3, 256))
     assert list(model.state_dict().keys()) == list(gold["state_dict_keys"])
     model.load_state_dict(sd)
