@@ -5,7 +5,8 @@
 
 Reads <prefix>_stats/*.db (kernel trace), <prefix>_fetch/*.db (--pmc FETCH_SIZE), <prefix>_write/*.db (--pmc WRITE_SIZE) and
 <prefix>_mfma/*.db (--pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE: MFMA utilisation = MFMA-busy cycles summed over
-the SIMDs / (4 SIMDs x 256 CUs x GRBM_GUI_ACTIVE)).  With a 5th argument also writes the per-kernel table as JSON
+the SIMDs / (4 SIMDs x 256 CUs x GRBM_GUI_ACTIVE / 8): rocprofv3 reports GRBM_GUI_ACTIVE summed over the 8 XCDs -- calibrated on
+wgrad3_kernel<4,1,4>, 885 TFLOP/s = 35 % of the dense bf16 peak by its launch time, 42 % MFMA-busy by this formula).  With a 5th argument also writes the per-kernel table as JSON
 (profiles/<tag>_traffic.json), which bench.py reads to fill `roofline.traffic`.  FETCH_SIZE on gfx950 under-reports wide coalesced
 reads by exactly 2x (MI355X_MICROARCH.md §HBM): both the raw and the doubled figure are listed;
 WRITE_SIZE is uncalibrated and listed raw.
@@ -61,7 +62,7 @@ def main():
         f = fetch.get(n, (None,))[0]
         w = write.get(n, (None,))[0]
         mb, ga = mbusy.get(n, (None,))[0], gui.get(n, (None,))[0]
-        util = None if mb is None or not ga else 100.0 * mb / (4.0 * 256.0 * ga)      # counter summed over all SIMDs of the chip
+        util = None if mb is None or not ga else 100.0 * mb / (4.0 * 256.0 * ga / 8.0)   # busy cycles summed over all SIMDs; GUI_ACTIVE over 8 XCDs
         lines.append(f"| {n} | {c} | {t:.2f} | {a:.1f} | {p:.1f} | {'' if f is None else f'{f:.0f}'} | "
                      f"{'' if f is None else f'{2 * f / 1024:.1f}'} | {'' if w is None else f'{w:.0f}'} | {'' if util is None else f'{util:.1f}'} |")
         table[n] = {"calls": c, "avg_us": a, "fetch_kb_raw": f, "write_kb_raw": w, "mfma_busy_pct": util}
