@@ -25,3 +25,11 @@ int ksmi_lt_linear_dgrad(const void* dy, int dy_rs, const void* w, int w_rs, voi
                          hipStream_t st);
 int ksmi_lt_linear_wgrad(const void* x, int x_rs, const void* dy, int dy_rs, float* grad, int g_rs, int rows, int K, int N, int accumulate,
                          hipStream_t st);
+
+// gemm2.hip: LDS-DMA token GEMMs; 0 = launched, 1 = shape not covered (fall back to gemm.hip), < 0 = error
+int ksmi_gemm2_nt(const void* x, int x_rs, const void* w, int w_rs, const float* bias, const void* resid, int r_rs, void* y, int y_rs,
+                  int rows, int K, int N, hipStream_t st);
+int ksmi_gemm2_nn(const void* dy, int dy_rs, const void* w, int w_rs, void* dx, int dx_rs, int rows, int K, int N, int accumulate,
+                  hipStream_t st);
+int ksmi_gemm2_tn(const void* x, int x_rs, const void* dy, int dy_rs, float* slab, int npad, float* grad, int64_t g_rs, int rows, int K, int N,
+                  int Kslab, int nsplit, int rows_per_split, int btile, int accumulate, hipStream_t st);

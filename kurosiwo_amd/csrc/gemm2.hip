@@ -1,0 +1,473 @@
+// Token GEMMs, second generation (bf16): the nn.Linear layers of FloodViT (vision_transformer.py:22-31,47-50; rows = 16 x 197 tokens,
+// K/N in {1024, 2048, 3072}) and the wide ChangeFormer linears, forward (NT) and input gradient (NN).
+//   NT : Y[m][n]  = sum_k X[m][k]  W[n][k] + bias[n] (+ R[m][n])
+//   NN : dX[m][k] = sum_n dY[m][n] W[n][k]           (+= optional)
+// What changed against gemm.hip (one 32-deep K step per barrier, register-staged tiles: 320 TFLOP/s):
+//   * tiles arrive by LDS-DMA (global_load_lds_dwordx4, lane-linear destination, the bank swizzle applied to the SOURCE address),
+//     three stages in flight, vmcnt counted per stage -- no register staging, no ds_write;
+//   * K step 64: 2 x (4 + MT) fragment reads feed 2 x 4 x MT MFMAs (v_mfma_f32_16x16x32_bf16) per barrier;
+//   * the single barrier of a K step sits BETWEEN its two MFMA groups: the fragments of the next group (the second half of this
+//     stage, then the first half of the next stage) are always requested before the current group's MFMAs issue;
+//   * the row tile is a template parameter (TM = 32 x MT rows): 3152 token rows x N/128 column tiles fill the 256 CUs in whole
+//     rounds (N = 1024: 128-row tiles, 200 WGs; N = 2048: 224 rows, 240 WGs; N = 3072: 160 rows, 480 WGs = 2 rounds).
+// Swapped-operand MFMA (D = W X^T) + permuted W rows as in gemm.hip: a lane owns 16 consecutive output channels of one token row.
+#include "common.h"
+#include "../../include/ksmi.h"
+#include "errors.h"
+
+namespace {
+
+struct Gemm2P {
+  const bf16_t* a; int a_rs;          // activations [rows][red]
+  const bf16_t* w; int w_rs;          // weights [N][K] bf16 (row-major as nn.Linear stores them)
+  const float* bias; const bf16_t* resid; int r_rs;
+  bf16_t* out; int o_rs;
+  int rows, red, cols, accumulate;    // reduction length, output columns
+  int mtiles, ntiles;
+};
+
+__device__ __forceinline__ void glds16(const unsigned char* src, unsigned dst_wave_base) {
+  unsigned keep;
+  dst_wave_base = __builtin_amdgcn_readfirstlane(dst_wave_base);
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(src), "s"(dst_wave_base) : "memory");
+}
+__device__ __forceinline__ void vm_wait(int n) {
+#define KSMI_VMW(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+  switch (n) {
+    KSMI_VMW(1) KSMI_VMW(2) KSMI_VMW(3) KSMI_VMW(4) KSMI_VMW(5) KSMI_VMW(6) KSMI_VMW(7) KSMI_VMW(8) KSMI_VMW(9) KSMI_VMW(10)
+    KSMI_VMW(11) KSMI_VMW(12) KSMI_VMW(13) KSMI_VMW(14) KSMI_VMW(15) KSMI_VMW(16) KSMI_VMW(17) KSMI_VMW(18) KSMI_VMW(19) KSMI_VMW(20)
+    KSMI_VMW(21) KSMI_VMW(22) KSMI_VMW(23) KSMI_VMW(24) KSMI_VMW(25) KSMI_VMW(26) KSMI_VMW(27) KSMI_VMW(28) KSMI_VMW(29) KSMI_VMW(30)
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+#undef KSMI_VMW
+}
+// lgkmcnt(0) as a real S_WAITCNT the compiler's own wait insertion sees (an asm wait is opaque to it: it would add a second,
+// later lgkmcnt(0) that also drains the fragment reads issued in between)
+__device__ __forceinline__ void lgkm_wait0() { __builtin_amdgcn_s_waitcnt(0xC07F); }
+__device__ __forceinline__ void lds_barrier() {
+  lgkm_wait0();
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+// 16-byte-unit swizzles of the reduction-major (transposed-read) images.  One ds_read_b64_tr_b16 has its 16 lanes read 4 rows x 4
+// eight-byte pieces; rows are a multiple of 256 bytes apart (the same banks), so the 16 pieces must sit in 16 different units:
+//   A side (pieces 32 bytes apart: units lu + 2 q): the row's low two bits go to unit bits 0 and 3
+//   B side (pieces adjacent: 2 units): the row's low two bits go to unit bits 1 and 2
+__device__ __forceinline__ int sw_a(int row) { return (row & 1) | ((row & 2) << 2); }
+__device__ __forceinline__ int sw_b(int row) { return (row & 3) << 1; }
+
+// lane's 16 consecutive outputs (acc[t][mt][r], t = 0..3) of row m -> two 16-byte stores
+template <int MT>
+__device__ __forceinline__ void store_row2(const Gemm2P& p, const f32x4 (&acc)[4][MT], int mt, int m, int c0, const float* bias16) {
+  if (m >= p.rows) return;
+  float v[16];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[t * 4 + r] = acc[t][mt][r] + bias16[t * 4 + r];
+  bf16_t* op = p.out + (size_t)m * p.o_rs + c0;
+  if (p.resid) {
+    float a[8], b[8];
+    vec_unpack<bf16_t>(*(const u32x4*)(p.resid + (size_t)m * p.r_rs + c0), a);
+    vec_unpack<bf16_t>(*(const u32x4*)(p.resid + (size_t)m * p.r_rs + c0 + 8), b);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { v[j] += a[j]; v[8 + j] += b[j]; }
+  }
+  if (p.accumulate) {
+    float a[8], b[8];
+    vec_unpack<bf16_t>(*(const u32x4*)op, a);
+    vec_unpack<bf16_t>(*(const u32x4*)(op + 8), b);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { v[j] += a[j]; v[8 + j] += b[j]; }
+  }
+  *(u32x4*)op = vec_pack<bf16_t>(v);
+  *(u32x4*)(op + 8) = vec_pack<bf16_t>(v + 8);
+}
+
+// MT: 16-row MFMA tiles per wave along the token axis (WG = 2 x 2 waves: 32*MT token rows x 128 output columns)
+// TRW: the W operand is stored reduction-major (input gradient: W[n][k], n = reduction) and read transposed (ds_read_b64_tr_b16)
+template <int MT, bool TRW>
+__global__ __launch_bounds__(256, 1) void gemm2_kernel(const Gemm2P p) {
+  constexpr int TM = 32 * MT, KS = 64, XB = TM * 128, WB = 128 * 128, STAGE = XB + WB, NS = 3;
+  constexpr int NQ = STAGE / 1024, NI = NQ / 4;              // DMA instructions per stage (1 KiB each) / per wave
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
+  const int wn = wave >> 1, wm = wave & 1;
+  // XCD-aware tile order: the tiles of one XCD (consecutive logical ids) walk the column tiles of a few row tiles
+  const unsigned t = xcd_remap(blockIdx.x, gridDim.x);
+  const int mt_i = t / p.ntiles, nt_i = t - mt_i * p.ntiles;
+  const int m0 = mt_i * TM, n0 = nt_i * 128;
+  const int nsteps = p.red / KS;
+  const unsigned lds0 = (unsigned)(uintptr_t)smem;
+
+  // ---- DMA sources: instruction q = wave + 4 i covers image rows q*8 .. q*8+7 (X rows first, then the W image)
+  const unsigned char* src[NI];
+  int step_bytes[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int q = wave + 4 * i;
+    if (q * 8 < TM) {
+      const int row = q * 8 + (lane >> 3), slot = lane & 7;
+      const int chunk = slot ^ ((row >> 1) & 7);
+      int m = m0 + row; if (m >= p.rows) m = p.rows - 1;
+      src[i] = (const unsigned char*)(p.a + (size_t)m * p.a_rs + chunk * 8);
+      step_bytes[i] = KS * 2;
+    } else if constexpr (!TRW) {
+      const int j = q * 8 - TM + (lane >> 3), slot = lane & 7;   // W image row j holds channel perm(j): see the fragment mapping below
+      const int chunk = slot ^ ((j >> 1) & 7);
+      const int h = j >> 6, jj = j & 63;
+      int n = n0 + h * 64 + ((jj >> 2) & 3) * 16 + (jj >> 4) * 4 + (jj & 3); if (n >= p.cols) n = p.cols - 1;
+      src[i] = (const unsigned char*)(p.w + (size_t)n * p.w_rs + chunk * 8);
+      step_bytes[i] = KS * 2;
+    } else {
+      // W image: 64 reduction rows x 256 bytes (128 output columns); 16-byte unit u of row wr holds logical unit u ^ sw_a(wr)
+      const int u4 = (q * 8 - TM) * 8 + lane;                    // 16-byte unit index within the W image
+      const int wr = u4 >> 4, u = u4 & 15;
+      const int cb = (u ^ sw_a(wr)) << 4;
+      int k = n0 + (cb >> 1); if (k + 8 > p.cols) k = p.cols - 8;
+      src[i] = (const unsigned char*)(p.w + (size_t)wr * p.w_rs + k);
+      step_bytes[i] = KS * p.w_rs * 2;
+    }
+  }
+  auto issue = [&](int s, int buf) {
+    const unsigned base = lds0 + (unsigned)(buf * STAGE);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) glds16(src[i] + (size_t)s * step_bytes[i], base + (unsigned)((wave + 4 * i) * 1024));
+  };
+
+  // ---- fragment addresses (bytes within a stage) for k-substep 0; substep 1 = chunk + 4
+  int fx_off[MT], fx_sw[MT], fw_off[4], fw_sw[4];
+#pragma unroll
+  for (int b = 0; b < MT; ++b) {
+    const int r = wm * 16 * MT + b * 16 + l15;
+    fx_off[b] = r * 128; fx_sw[b] = (r >> 1) & 7;
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int r = wn * 64 + a * 16 + l15;
+    fw_off[a] = XB + r * 128; fw_sw[a] = (r >> 1) & 7;
+  }
+  auto load_frags = [&](int buf, int sub, u32x4 (&fw)[4], u32x4 (&fx)[MT]) {
+    const unsigned char* st = smem + buf * STAGE;
+#pragma unroll
+    for (int b = 0; b < MT; ++b) fx[b] = *(const u32x4*)(st + fx_off[b] + (((sub * 4 + g) ^ fx_sw[b]) << 4));
+    if constexpr (!TRW) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a) fw[a] = *(const u32x4*)(st + fw_off[a] + (((sub * 4 + g) ^ fw_sw[a]) << 4));
+    } else {
+      // W^T fragment of output-column tile a: lane i = l15 is MFMA row i <-> output column wn*64 + (i>>2)*16 + a*4 + (i&3);
+      // its 8 reduction indices are rows sub*32 + g*8 + {jr, jr+4} .. of the image, read as two transposed 4-row pieces
+      const unsigned bw = (unsigned)(uintptr_t)(st + XB);
+      const int jr = l15 >> 2, q4 = l15 & 3;
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const int cb = (wn * 64 + q4 * 16 + a * 4) * 2;
+        const int r0 = sub * 32 + g * 8 + jr, r1 = r0 + 4;
+        const unsigned a0 = bw + r0 * 256 + (((cb >> 4) ^ sw_a(r0)) << 4) + (cb & 15);
+        const unsigned a1 = bw + r1 * 256 + (((cb >> 4) ^ sw_a(r1)) << 4) + (cb & 15);
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(uintptr_t)a0);
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(uintptr_t)a1);
+        fw[a][0] = (uint16_t)lo[0] | ((uint32_t)(uint16_t)lo[1] << 16);
+        fw[a][1] = (uint16_t)lo[2] | ((uint32_t)(uint16_t)lo[3] << 16);
+        fw[a][2] = (uint16_t)hi[0] | ((uint32_t)(uint16_t)hi[1] << 16);
+        fw[a][3] = (uint16_t)hi[2] | ((uint32_t)(uint16_t)hi[3] << 16);
+      }
+    }
+  };
+
+  // two accumulator sets, one per k-substep of a stage: with both MFMA groups of an iteration chained through ONE set the
+  // register allocator (ROCm 7.2) rotates every accumulator through a scratch quad (4 v_accvgpr_mov + s_nops per MFMA);
+  // the sets are summed in the epilogue
+  f32x4 acc[4][MT], acc2[4][MT];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < MT; ++b) { acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc2[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  auto mma_all = [&](f32x4 (&ac)[4][MT], const u32x4 (&fw)[4], const u32x4 (&fx)[MT]) {
+#pragma unroll
+    for (int b = 0; b < MT; ++b)
+#pragma unroll
+      for (int a = 0; a < 4; ++a) mma16<bf16_t>(ac[a][b], fw[a], fx[b]);     // rows = channels, cols = token rows
+  };
+
+  const int pre = nsteps < NS ? nsteps : NS;
+  for (int s = 0; s < pre; ++s) issue(s, s);
+  vm_wait((pre - 1) * NI);
+  lds_barrier();
+  u32x4 fwA[4], fxA[MT], fwB[4], fxB[MT];
+  load_frags(0, 0, fwA, fxA);
+  int cur = 0;
+  for (int s = 0; s + 1 < nsteps; ++s) {
+    lgkm_wait0();                                          // set A has landed (requested one MFMA group ago)
+    __builtin_amdgcn_sched_barrier(0);
+    load_frags(cur, 1, fwB, fxB);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_all(acc, fwA, fxA);
+    __builtin_amdgcn_sched_barrier(0);
+    // stage s+1 has landed once at most the DMAs of stage s+2 are outstanding; after the barrier every wave holds its fragments
+    // of stage s in registers, so that buffer is free for stage s+3
+    if (s + 2 < nsteps) vm_wait(NI); else vm_wait(0);
+    lds_barrier();
+    if (s + NS < nsteps) issue(s + NS, cur);
+    cur = cur + 1 == NS ? 0 : cur + 1;
+    load_frags(cur, 0, fwA, fxA);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_all(acc2, fwB, fxB);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  load_frags(cur, 1, fwB, fxB);
+  mma_all(acc, fwA, fxA);
+  mma_all(acc2, fwB, fxB);
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < MT; ++b) acc[a][b] += acc2[a][b];
+
+  const int c0 = n0 + wn * 64 + g * 16;
+  if (c0 >= p.cols) return;
+  float bias16[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) bias16[j] = p.bias ? p.bias[c0 + j] : 0.f;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) store_row2<MT>(p, acc, mt, m0 + wm * 16 * MT + mt * 16 + l15, c0, bias16);
+}
+
+template <int MT, bool TRW>
+int launch2(const Gemm2P& p, hipStream_t st) {
+  constexpr int lds = 3 * (32 * MT * 128 + 128 * 128);
+  auto kfn = gemm2_kernel<MT, TRW>;
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+  hipLaunchKernelGGL(kfn, dim3(p.mtiles * p.ntiles), dim3(256), lds, st, p);
+  return ksmi_check_launch(TRW ? "gemm2_nn" : "gemm2_nt");
+}
+
+// row-tile height: whole rounds of the 256 CUs cost rounds x TM; pick the cheapest (ties -> the taller tile)
+int pick_mt(int rows, int ntiles) {
+  static const int cand[] = {8, 7, 6, 5, 4, 3, 2};
+  static const int forced = getenv("KSMI_GEMM2_MT") ? atoi(getenv("KSMI_GEMM2_MT")) : 0;
+  if (forced) return forced;
+  long best = -1; int bm = 4;
+  for (int mt : cand) {
+    const int tm = 32 * mt;
+    const long wgs = (long)((rows + tm - 1) / tm) * ntiles;
+    const long cost = ((wgs + 255) / 256) * (tm + 24);          // + fixed per-tile prologue / epilogue
+    if (best < 0 || cost < best) { best = cost; bm = mt; }
+  }
+  return bm;
+}
+
+template <bool TRW>
+int dispatch2(Gemm2P& p, hipStream_t st) {
+  p.ntiles = p.cols / 128;
+  const int mt = pick_mt(p.rows, p.ntiles);
+  p.mtiles = (p.rows + 32 * mt - 1) / (32 * mt);
+  switch (mt) {
+    case 2: return launch2<2, TRW>(p, st);
+    case 3: return launch2<3, TRW>(p, st);
+    case 4: return launch2<4, TRW>(p, st);
+    case 5: return launch2<5, TRW>(p, st);
+    case 6: return launch2<6, TRW>(p, st);
+    case 7: return launch2<7, TRW>(p, st);
+    default: return launch2<8, TRW>(p, st);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- weight gradient (TN)
+// out[j][i] (+)= sum_m B[m][j] A[m][i]: both operands are reduction-major ([m][columns]) and read transposed.  The A side (128
+// columns per workgroup, 16 consecutive columns per lane) is the contiguous axis of the output, the B side (32*MT columns) its rows:
+//   slab mode   (split reduction): A = dY (n), B = X (k):  partial[split][k][Npad + n]  -> tn_reduce_kernel (igemm.hip)
+//   direct mode (one split)      : A = X (k),  B = dY (n): grad[n][k] (+)=               (row-major nn.Linear gradient)
+struct Gemm2T {
+  const bf16_t* a; int a_rs, a_cols;   // A-side matrix [rows][a_rs], valid columns
+  const bf16_t* b; int b_rs, b_cols;
+  float* out; int64_t o_rs; int64_t split_stride; int accumulate;
+  int rows, rows_per_split, atiles, btiles;
+  const unsigned char* zero;
+};
+__device__ __attribute__((aligned(64))) unsigned char gemm2_zero_page[64];
+
+template <int MT>
+__global__ __launch_bounds__(256, 1) void gemm2_tn_kernel(const Gemm2T p) {
+  constexpr int TB = 32 * MT, KS = 64, AB = 64 * 256, BROW = TB * 2, BB = 64 * BROW, STAGE = AB + BB, NS = 3;
+  constexpr int NQ = STAGE / 1024, NI = NQ / 4, BGM = BROW / 32 - 1, AU = 16, BU = BROW / 16;
+  static_assert(NQ % 4 == 0, "whole DMA rounds");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
+  const int wn = wave >> 1, wm = wave & 1;
+  const int tile = blockIdx.x, split = blockIdx.y;
+  const int bt = tile / p.atiles, at = tile - bt * p.atiles;
+  const int a0 = at * 128, b0 = bt * TB;
+  const int m_begin = split * p.rows_per_split;
+  const int m_end = min(p.rows, m_begin + p.rows_per_split);
+  const int nsteps = (max(m_end - m_begin, 0) + KS - 1) / KS;
+  const unsigned lds0 = (unsigned)(uintptr_t)smem;
+
+  // DMA: instruction q = wave + 4 i; 16-byte unit index within the stage -> (image, reduction row, column granule)
+  const unsigned char* src[NI];
+  int srow[NI], sstep[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int q = wave + 4 * i;
+    if (q * 1024 < AB) {
+      const int u4 = q * 64 + lane, wr = u4 / AU, u = u4 % AU;
+      const int cb = (u ^ sw_a(wr)) << 4;
+      int c = a0 + (cb >> 1); if (c + 8 > p.a_cols) c = p.a_cols - 8;
+      src[i] = (const unsigned char*)(p.a + (size_t)(m_begin + wr) * p.a_rs + c);
+      srow[i] = wr; sstep[i] = KS * p.a_rs * 2;
+    } else {
+      const int u4 = q * 64 - AB / 16 + lane, wr = u4 / BU, u = u4 % BU;
+      const int cb = (u ^ sw_b(wr)) << 4;
+      int c = b0 + (cb >> 1); if (c + 8 > p.b_cols) c = p.b_cols - 8;
+      src[i] = (const unsigned char*)(p.b + (size_t)(m_begin + wr) * p.b_rs + c);
+      srow[i] = wr; sstep[i] = KS * p.b_rs * 2;
+    }
+  }
+  auto issue = [&](int s, int buf) {
+    const unsigned base = lds0 + (unsigned)(buf * STAGE);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      // reduction rows past the split's end read the zero page (two 32-bit selects: a pointer select compiles to two masked DMAs)
+      const bool ok = m_begin + s * KS + srow[i] < m_end;
+      const uint64_t real = (uint64_t)(uintptr_t)(src[i] + (size_t)s * sstep[i]), zp = (uint64_t)(uintptr_t)p.zero;
+      const uint32_t lo = ok ? (uint32_t)real : (uint32_t)zp, hi = ok ? (uint32_t)(real >> 32) : (uint32_t)(zp >> 32);
+      glds16((const unsigned char*)(uintptr_t)(((uint64_t)hi << 32) | lo), base + (unsigned)((wave + 4 * i) * 1024));
+    }
+  };
+  auto tr8 = [&](unsigned img, int row_bytes, int sw, int r0, int cb) -> u32x4 {      // sw = swizzle of rows r0 and r0 + 4 (same low bits)
+    const int r1 = r0 + 4;
+    const unsigned x0 = img + r0 * row_bytes + (((cb >> 4) ^ sw) << 4) + (cb & 15);
+    const unsigned x1 = img + r1 * row_bytes + (((cb >> 4) ^ sw) << 4) + (cb & 15);
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(uintptr_t)x0);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(uintptr_t)x1);
+    u32x4 f;
+    f[0] = (uint16_t)lo[0] | ((uint32_t)(uint16_t)lo[1] << 16);
+    f[1] = (uint16_t)lo[2] | ((uint32_t)(uint16_t)lo[3] << 16);
+    f[2] = (uint16_t)hi[0] | ((uint32_t)(uint16_t)hi[1] << 16);
+    f[3] = (uint16_t)hi[2] | ((uint32_t)(uint16_t)hi[3] << 16);
+    return f;
+  };
+  auto load_frags = [&](int buf, int sub, u32x4 (&fa)[4], u32x4 (&fb)[MT]) {
+    const unsigned st = lds0 + (unsigned)(buf * STAGE);
+    const int jr = l15 >> 2, q4 = l15 & 3, r0 = sub * 32 + g * 8 + jr;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) fa[a] = tr8(st, 256, sw_a(r0), r0, (wn * 64 + q4 * 16 + a * 4) * 2);         // lane i <-> column wn*64 + (i>>2)*16 + a*4 + (i&3)
+#pragma unroll
+    for (int b = 0; b < MT; ++b) fb[b] = tr8(st + AB, BROW, sw_b(r0), r0, (wm * 16 * MT + b * 16 + q4 * 4) * 2);   // lane i <-> column wm*16*MT + b*16 + i
+  };
+  f32x4 acc[4][MT], acc2[4][MT];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < MT; ++b) { acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc2[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  auto mma_all = [&](f32x4 (&ac)[4][MT], const u32x4 (&fa)[4], const u32x4 (&fb)[MT]) {
+#pragma unroll
+    for (int b = 0; b < MT; ++b)
+#pragma unroll
+      for (int a = 0; a < 4; ++a) mma16<bf16_t>(ac[a][b], fa[a], fb[b]);
+  };
+  if (nsteps > 0) {
+    const int pre = nsteps < NS ? nsteps : NS;
+    for (int s = 0; s < pre; ++s) issue(s, s);
+    vm_wait((pre - 1) * NI);
+    lds_barrier();
+    u32x4 faA[4], fbA[MT], faB[4], fbB[MT];
+    load_frags(0, 0, faA, fbA);
+    int cur = 0;
+    for (int s = 0; s + 1 < nsteps; ++s) {
+      lgkm_wait0();
+      __builtin_amdgcn_sched_barrier(0);
+      load_frags(cur, 1, faB, fbB);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_all(acc, faA, fbA);
+      __builtin_amdgcn_sched_barrier(0);
+      if (s + 2 < nsteps) vm_wait(NI); else vm_wait(0);
+      lds_barrier();
+      if (s + NS < nsteps) issue(s + NS, cur);
+      cur = cur + 1 == NS ? 0 : cur + 1;
+      load_frags(cur, 0, faA, fbA);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_all(acc2, faB, fbB);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    load_frags(cur, 1, faB, fbB);
+    mma_all(acc, faA, fbA);
+    mma_all(acc2, faB, fbB);
+  }
+  // lane: 16 consecutive A-side columns (acc[a][.][r]: column g*16 + a*4 + r) of B-side column wm*16*MT + b*16 + l15
+  const int ac0 = a0 + wn * 64 + g * 16;
+  if (ac0 >= p.a_cols) return;
+  float* ob = p.out + (size_t)split * p.split_stride;
+#pragma unroll
+  for (int b = 0; b < MT; ++b) {
+    const int bc = b0 + wm * 16 * MT + b * 16 + l15;
+    if (bc >= p.b_cols) continue;
+    float* o = ob + (int64_t)bc * p.o_rs + ac0;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      f32x4 v = acc[a][b] + acc2[a][b];
+      if (ac0 + a * 4 + 4 <= p.a_cols) {
+        if (p.accumulate) { const f32x4 old = *(const f32x4*)(o + a * 4); v += old; }
+        *(f32x4*)(o + a * 4) = v;
+      } else {
+        for (int r = 0; r < 4; ++r)
+          if (ac0 + a * 4 + r < p.a_cols) o[a * 4 + r] = p.accumulate ? o[a * 4 + r] + v[r] : v[r];
+      }
+    }
+  }
+}
+
+}  // namespace
+
+// 0 = launched, 1 = shape not covered (the caller falls back to gemm.hip), < 0 = error
+int ksmi_gemm2_nt(const void* x, int x_rs, const void* w, int w_rs, const float* bias, const void* resid, int r_rs, void* y, int y_rs,
+                  int rows, int K, int N, hipStream_t st) {
+  static const bool off = getenv("KSMI_GEMM2_OFF") != nullptr;
+  if (off || K % 64 || N % 128 || rows < 64 || K < 128) return 1;
+  Gemm2P p = {(const bf16_t*)x, x_rs, (const bf16_t*)w, w_rs, bias, (const bf16_t*)resid, r_rs, (bf16_t*)y, y_rs, rows, K, N, 0, 0, 0};
+  return dispatch2<false>(p, st);
+}
+
+int ksmi_gemm2_nn(const void* dy, int dy_rs, const void* w, int w_rs, void* dx, int dx_rs, int rows, int K, int N, int accumulate,
+                  hipStream_t st) {
+  static const bool off = getenv("KSMI_GEMM2_OFF") != nullptr;
+  if (off || N % 64 || K % 128 || rows < 64 || N < 128) return 1;
+  Gemm2P p = {(const bf16_t*)dy, dy_rs, (const bf16_t*)w, w_rs, nullptr, nullptr, 0, (bf16_t*)dx, dx_rs, rows, N, K, accumulate, 0, 0};
+  return dispatch2<true>(p, st);
+}
+
+// weight gradient of a plain nn.Linear: x [rows][K] (row stride x_rs), dy [rows][N]; `slab` = split partial sums [nsplit][K][Npad]
+// (n contiguous: the layout of tn_reduce_kernel), or nsplit = 1 and grad [N][g_rs] written directly.  0 launched / 1 not covered
+int ksmi_gemm2_tn(const void* x, int x_rs, const void* dy, int dy_rs, float* slab, int npad, float* grad, int64_t g_rs, int rows, int K, int N,
+                  int Kslab, int nsplit, int rows_per_split, int btile, int accumulate, hipStream_t st) {
+  static const bool off = getenv("KSMI_GEMM2_OFF") != nullptr || getenv("KSMI_GEMM2_TN_OFF") != nullptr;
+  if (off || K % 8 || N % 8 || K < 64 || N < 64 || rows_per_split % 64) return 1;
+  static void* zero_page = nullptr;
+  if (!zero_page && hipGetSymbolAddress(&zero_page, HIP_SYMBOL(gemm2_zero_page)) != hipSuccess) return ksmi_fail(KSMI_E_UNSUPPORTED, "gemm2: zero page");
+  Gemm2T p = {};
+  p.rows = rows; p.rows_per_split = rows_per_split; p.zero = (const unsigned char*)zero_page;
+  if (nsplit == 1 && grad) {        // direct: A = x (k contiguous in grad), B = dy
+    p.a = (const bf16_t*)x; p.a_rs = x_rs; p.a_cols = K; p.b = (const bf16_t*)dy; p.b_rs = dy_rs; p.b_cols = N;
+    p.out = grad; p.o_rs = g_rs; p.split_stride = 0; p.accumulate = accumulate;
+  } else {                          // slabs: A = dy (n contiguous in the slab), B = x
+    p.a = (const bf16_t*)dy; p.a_rs = dy_rs; p.a_cols = N; p.b = (const bf16_t*)x; p.b_rs = x_rs; p.b_cols = K;
+    p.out = slab; p.o_rs = npad; p.split_stride = (int64_t)Kslab * npad; p.accumulate = 0;
+  }
+  p.atiles = (p.a_cols + 127) / 128; p.btiles = (p.b_cols + btile - 1) / btile;
+  if (btile == 128) {
+    constexpr int lds = 3 * (64 * 256 + 64 * 256);
+    auto kfn = gemm2_tn_kernel<4>;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+    hipLaunchKernelGGL(kfn, dim3(p.atiles * p.btiles, nsplit), dim3(256), lds, st, p);
+  } else if (btile == 64) {
+    constexpr int lds = 3 * (64 * 256 + 64 * 128);
+    auto kfn = gemm2_tn_kernel<2>;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+    hipLaunchKernelGGL(kfn, dim3(p.atiles * p.btiles, nsplit), dim3(256), lds, st, p);
+  } else return ksmi_fail(KSMI_E_ARG, "gemm2_tn: B-side tile must be 64 or 128");
+  return ksmi_check_launch("gemm2_tn");
+}

@@ -1,12 +1,10 @@
-// Plain nn.Linear GEMMs (vision_transformer.py:22-31,47-50; changeformer.py:110-113,157-161) above a size threshold go to
-// hipBLASLt: these are library-shaped problems (bias / residual / accumulate epilogues only) and on the FloodViT token shapes
-// (3152 x 1024 x 1024..3072) its 256-wide macro tiles reach 600-800 TFLOP/s where the 128 x 128 tiles of gemm.hip /
-// gemm_tn_wgrad_kernel stop at 300-430 (profiles/gemm_probe.py).  Everything with a fused operand transform or a non-GEMM
-// access pattern (convolutions, attention, normalisations) stays on the hand-written kernels, and so do the small GEMMs of
-// ChangeFormer, where the hand-written tiles win.
+// OPTIONAL comparison path, off by default: plain nn.Linear GEMMs (vision_transformer.py:22-31,47-50; changeformer.py:110-113,157-161)
+// above a size threshold can be sent to hipBLASLt with KSMI_USE_HIPBLASLT=1, to time the library next to the hand-written
+// LDS-DMA kernels of gemm2.hip, which are the product path (FloodViT step, MI355X: 949 tiles/s hand-written, 976 with the
+// library's 256-wide stream-K tiles; profiles/gemm_probe.py, tools/gemm_durations.py).
 //
 // The library is bound at run time (dlopen + dlsym; the copy a host process already holds is reused), so libksmi.so has no link
-// dependency on it: without it, or with KSMI_NO_HIPBLASLT set, every call below returns "not taken" and the caller runs its own
+// dependency on it: without KSMI_USE_HIPBLASLT=1 (or without the library) every call below returns "not taken" and the caller runs its own
 // kernel.  Row-major operands are passed as their column-major transposes:
 //   forward      Y^T [N x rows] = W [N x K] X^T      -> op(A) = T on the stored K x N image of W, op(B) = N on X (K x rows)
 //   input grad   dX^T [K x rows] = W^T dY^T          -> op(A) = N on W (K x N),                 op(B) = N on dY (N x rows)
@@ -46,7 +44,7 @@ LtApi* lt_api() {
   std::lock_guard<std::mutex> lk(mu);
   if (state) return state > 0 ? &api : nullptr;
   state = -1;
-  if (getenv("KSMI_NO_HIPBLASLT")) return nullptr;
+  if (!getenv("KSMI_USE_HIPBLASLT") || getenv("KSMI_NO_HIPBLASLT")) return nullptr;
   void* h = dlopen("libhipblaslt.so.1", RTLD_NOW | RTLD_NOLOAD);
   if (!h) h = dlopen("libhipblaslt.so.1", RTLD_NOW | RTLD_GLOBAL);
   if (!h) h = dlopen("/opt/rocm/lib/libhipblaslt.so.1", RTLD_NOW | RTLD_GLOBAL);

@@ -746,19 +746,39 @@ static bool gemm_tn_eligible(const ksmi_wgrad_desc* d, int es) {
          d->Hin == d->Hout && d->Win == d->Wout && (d->src[0].c_len % 8) == 0 && (d->N % 8) == 0 && d->N >= 64 && d->src[0].c_len >= 64 &&
          getenv("KSMI_WGRAD_GENERIC") == nullptr;
 }
-static void gemm_tn_geom(const ksmi_wgrad_desc* d, int kc, int& nsplit, int& rps, int& tk, int& tn) {
+// tile and split choice of the token-GEMM weight gradient (gemm2.hip: 128 A-side columns x `bt` B-side columns per workgroup).
+// direct (one split, row-major gradient): A = k, B = n; slabs: A = n, B = k.  Cost = whole rounds of the 256 CUs x 64-row steps
+// (measured: 0.95 us per step for bt = 128, ~0.6 for 64) + per-tile prologue/epilogue, + the slab traffic a split costs
+// (written once, read once by the reducer at ~4 TB/s) and the reducer launch.
+static void gemm_tn_geom(const ksmi_wgrad_desc* d, int kc, int& nsplit, int& rps, int& tk, int& tn, int& bt) {
   const int rows = d->B * d->Hout * d->Wout;
   const int K = d->nchunks * kc;
-  tk = (K + 127) / 128; tn = (((d->N + 15) & ~15) + 127) / 128;
-  int want = 768 / (tk * tn);
-  if (want < 1) want = 1;
-  if (want > 256) want = 256;
-  rps = ((rows + want - 1) / want + 31) & ~31;
-  if (rps < 32) rps = 32;
+  const int npad = (d->N + 15) & ~15;
+  tk = (K + 127) / 128; tn = (npad + 127) / 128;
+  bool plain = d->gK == 1 && (!d->use_tap_off || d->tap_off[0] == 0) && d->gN >= d->src[0].c_len && d->gN < ((int64_t)1 << 31);
+  if (plain && !d->uniform_kc)
+    for (int i = 0; i < d->nchunks; ++i) plain = plain && d->k_off[i] == i * kc;
+  const int steps_all = (rows + 63) / 64;
+  double best = 1e30; int bs = 1; bt = 128;
+  for (int b = 128; b >= 64; b >>= 1) {
+    const double step_us = b == 128 ? 0.95 : 0.6;
+    for (int s = 1; s <= 256 && s <= steps_all; s = s < 8 ? s + 1 : s * 2) {
+      if (s == 1 && !plain) continue;
+      // A-side tiles x B-side tiles (direct: A = k; slabs: A = n)
+      const int acols = s == 1 ? K : npad, bcols = s == 1 ? npad : K;
+      const int tiles = ((acols + 127) / 128) * ((bcols + b - 1) / b);
+      const int steps = (steps_all + s - 1) / s;
+      const int rounds = (tiles * s + 255) / 256;
+      double t = rounds * (steps * step_us + 3.0);
+      if (s > 1) t += 2.0 * s * (double)K * npad * 4.0 / 4.0e6 + 3.0;
+      if (t < best) { best = t; bs = s; bt = b; }
+    }
+  }
+  rps = ((steps_all + bs - 1) / bs) * 64;
   nsplit = (rows + rps - 1) / rps;
 }
 
-struct WgradGeom { int taps, kc, nt, bn, patches, pps, nsplit, ntiles, npad; size_t lds; bool tn; int rps, tk, tnn; bool v3; ksmi_wgrad3_geom_t g3; };
+struct WgradGeom { int taps, kc, nt, bn, patches, pps, nsplit, ntiles, npad; size_t lds; bool tn; int rps, tk, tnn, tbt; bool v3; ksmi_wgrad3_geom_t g3; };
 
 template <typename T>
 WgradGeom wgrad_geom(const ksmi_wgrad_desc* d) {
@@ -791,7 +811,7 @@ WgradGeom wgrad_geom(const ksmi_wgrad_desc* d) {
   g.lds = ((HH * HW * 64 + 255) & ~255) + (size_t)Ppad * g.bn * sizeof(T);
   if (g.taps == 1 && g.lds < (size_t)(g.kc / 16) * g.nt * 4096) g.lds = (size_t)(g.kc / 16) * g.nt * 4096;   // split-k reduction buffer
   g.tn = gemm_tn_eligible(d, (int)sizeof(T));
-  if (g.tn) gemm_tn_geom(d, g.kc, g.nsplit, g.rps, g.tk, g.tnn);
+  if (g.tn) gemm_tn_geom(d, g.kc, g.nsplit, g.rps, g.tk, g.tnn, g.tbt);
   // 3x3 stride-1 bf16 gradients with whole 32-channel chunks: channel-owner kernel (wgrad3.hip), same slab layout and reducer
   g.v3 = !g.tn && ksmi_wgrad3_geom(d, sizeof(T) == 2 ? KSMI_BF16 : KSMI_F32, &g.g3);
   if (g.v3) g.nsplit = g.g3.nsplit;
@@ -816,6 +836,21 @@ int launch_wgrad(const ksmi_wgrad_desc* d, hipStream_t st) {
     if (plain && ksmi_lt_linear_wgrad((const bf16_t*)d->src[0].ptr + d->src[0].c_off, d->src[0].C, (const bf16_t*)d->dy + d->dy_c_off, d->dyC,
                                       d->grad, (int)d->gN, d->B * d->Hout * d->Wout, d->src[0].c_len, d->N, d->accumulate, st) == 0)
       return 0;
+    {
+      const int rows = d->B * d->Hout * d->Wout;
+      const bool direct = plain && g.nsplit == 1;
+      const int r2 = ksmi_gemm2_tn((const bf16_t*)d->src[0].ptr + d->src[0].c_off, d->src[0].C, (const bf16_t*)d->dy + d->dy_c_off, d->dyC, d->partial,
+                                   g.npad, direct ? d->grad : nullptr, d->gN, rows, d->src[0].c_len, d->N, d->nchunks * g.kc, g.nsplit, g.rps,
+                                   g.tbt, d->accumulate, st);
+      if (r2 < 0) return r2;
+      if (r2 == 0) {
+        if (direct) return 0;
+        const size_t total0 = (size_t)d->nchunks * g.kc * g.npad / 4;
+        int blocks0 = (int)((total0 + 255) / 256); if (blocks0 > 8192) blocks0 = 8192;
+        hipLaunchKernelGGL(tn_reduce_kernel, dim3(blocks0), dim3(256), 0, st, *d, g.kc, d->nchunks * g.kc);
+        return ksmi_check_launch("tn_reduce");
+      }
+    }
     hipLaunchKernelGGL(gemm_tn_wgrad_kernel, dim3(g.tk, g.tnn, g.nsplit), dim3(256), 0, st, *d, d->B * d->Hout * d->Wout, g.rps, d->nchunks * g.kc);
     int rc0 = ksmi_check_launch("gemm_tn_wgrad");
     if (rc0) return rc0;

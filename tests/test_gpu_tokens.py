@@ -133,10 +133,61 @@ def test_gemm_nt_nn_bf16(dev, rows, K, N):
     assert float((dx2.float() - (refd + base.float())).abs().max() / refd.abs().max()) < 2e-2
 
 
+def _gemm2_row_tile(rows, ntiles):
+    """pick_mt of csrc/gemm2.hip: 32*MT token rows per workgroup, whole rounds of the 256 CUs"""
+    best, bm = None, 4
+    for mt in (8, 7, 6, 5, 4, 3, 2):
+        tm = 32 * mt
+        wgs = -(-rows // tm) * ntiles
+        cost = -(-wgs // 256) * (tm + 24)
+        if best is None or cost < best:
+            best, bm = cost, mt
+    return bm
+
+
+# (rows, K, N): every row-tile instance of gemm2_kernel<MT, .> (forward: N/128 column tiles; input gradient: K/128), ragged last
+# row tiles, reductions that are not a multiple of the 3-stage ring
+GEMM2_SHAPES = [(3152, 1024, 3072), (3152, 1024, 2048), (3152, 2048, 1024), (197, 128, 128), (4200, 192, 256), (5000, 256, 128),
+                (3000, 64 * 5, 128 * 3), (2500, 448, 1280), (1000, 128, 640), (40000, 128, 128), (777, 1024, 256),
+                (20000, 128, 128), (45000, 192, 128), (60000, 128, 128)]
+
+
+def test_gemm2_shapes_cover_every_row_tile():
+    seen = set()
+    for rows, K, N in GEMM2_SHAPES:
+        seen.add(_gemm2_row_tile(rows, N // 128))
+        seen.add(_gemm2_row_tile(rows, K // 128))
+    assert seen >= {2, 3, 4, 5, 6, 7, 8}, seen
+
+
+@pytest.mark.parametrize("rows,K,N", GEMM2_SHAPES)
+def test_gemm2_lds_dma_tiles(dev, rows, K, N):
+    """gemm2.hip (LDS-DMA, 3-stage ring, K step 64): forward with bias / residual, input gradient with and without accumulate,
+    weight gradient (direct and split-slab modes) against torch on the same bf16 operands."""
+    from kurosiwo_amd import functional as Fk
+    torch.manual_seed(rows + K + N)
+    x = (torch.randn(rows, K, device=dev) * 0.5).bfloat16()
+    wb = (torch.randn(N, K, device=dev) * K ** -0.5).bfloat16()
+    b = torch.randn(N, device=dev)
+    res = torch.randn(rows, N, device=dev).bfloat16()
+    rel = lambda got, ref: float((got.float() - ref).abs().max() / ref.abs().max())
+    ref = x.float() @ wb.float().t()
+    assert rel(Fk.gemm_nt(x, wb, b), ref + b) < 1e-2
+    assert rel(Fk.gemm_nt(x, wb, b, res), ref + b + res.float()) < 1e-2
+    dy = (torch.randn(rows, N, device=dev) * 0.5).bfloat16()
+    refd = dy.float() @ wb.float()
+    assert rel(Fk.gemm_nn(dy, wb), refd) < 1e-2
+    base = torch.randn(rows, K, device=dev).bfloat16()
+    assert float((Fk.gemm_nn(dy, wb, out=base.clone()).float() - (refd + base.float())).abs().max() / refd.abs().max()) < 2e-2
+    refw = dy.float().t() @ x.float()
+    got = Fk.linear_wgrad(x, dy)
+    assert got.dtype == torch.float32 and rel(got, refw) < 2e-3
+
+
 @pytest.mark.parametrize("rows,K,N", [(3152, 1024, 1024), (3152, 2048, 1024), (1568, 512, 2048)])
-def test_linear_wgrad_vit_size_library_route(dev, rows, K, N):
-    """nn.Linear weight gradient at ViT size (csrc/gemm_lt.hip route when hipBLASLt is loadable, the split-K tiles otherwise):
-    fp32 result straight into the gradient matrix, against torch on the same bf16 operands."""
+def test_linear_wgrad_vit_size(dev, rows, K, N):
+    """nn.Linear weight gradient at ViT size (gemm2_tn_kernel: direct fp32 write or split slabs + reducer): against torch on the
+    same bf16 operands."""
     from kurosiwo_amd import functional as Fk
     torch.manual_seed(rows + N)
     x = (torch.randn(rows, K, device=dev) * 0.5).bfloat16()
@@ -147,9 +198,10 @@ def test_linear_wgrad_vit_size_library_route(dev, rows, K, N):
     assert float((got - ref).abs().max() / ref.abs().max()) < 2e-3
 
 
-def test_library_route_and_hand_written_tiles_agree():
-    """The same ViT-size GEMMs with the hipBLASLt route disabled (KSMI_NO_HIPBLASLT=1, read once per process): both processes
-    must agree with torch, i.e. the fallback is a full implementation, not a stub."""
+def test_hand_written_gemm_generations_and_the_library_comparison_route_agree():
+    """The ViT-size GEMMs on (a) the default product path (gemm2.hip: LDS-DMA tiles), (b) the first-generation kernels
+    (KSMI_GEMM2_OFF=1: gemm.hip / gemm_tn_wgrad_kernel) and (c) the opt-in hipBLASLt comparison route (KSMI_USE_HIPBLASLT=1).  The
+    switches are read once per process: each variant runs in its own process and must agree with torch."""
     import os
     import subprocess
     import sys
@@ -164,7 +216,7 @@ def test_library_route_and_hand_written_tiles_agree():
         "r = lambda a, b: float((a.float() - b).abs().max() / b.abs().max())\n"
         "print('ERR', r(y, x.float() @ w.float().t() + b), r(dx, dy.float() @ w.float()), r(dw, dy.float().t() @ x.float()))\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for extra in ({}, {"KSMI_NO_HIPBLASLT": "1"}):
+    for extra in ({}, {"KSMI_GEMM2_OFF": "1"}, {"KSMI_USE_HIPBLASLT": "1"}):
         env = dict(os.environ, PYTHONPATH=root, **extra)
         out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, out.stderr[-2000:]
