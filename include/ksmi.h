@@ -394,6 +394,20 @@ int ksmi_sr_attention_backward(const void* q, const void* kv, const void* out, c
 int ksmi_rng_advance(uint32_t* rng_state, void* stream);
 int ksmi_dropout_apply(const void* x, const void* resid, void* y, int64_t rows, int cols, int rows_per_sample, uint32_t thr, float inv_keep,
                        uint32_t site, uint32_t dp_thr, float dp_inv_keep, uint32_t dp_site, const uint32_t* rng_state, int dtype, void* stream);
+/* FC-Siam (N2 row): y = relu(z*scale[c] + shift[c]) * Dropout2d -- nn.Dropout2d(p=0.2) after every BN+ReLU (siam_conc.py:20-93,
+ * 101-172) zeroes whole (sample, channel) planes: draw index b*C + c of `site`, kept planes scaled by inv_keep; thr = 0: plain BN+ReLU.
+ * Backward: the plane scale is a constant on the active set, so ksmi_bnrelu_bwd_reduce + ksmi_reduce_rows_scaled +
+ * ksmi_bnrelu_bwd_apply_scaled with alpha = inv_keep (the mask is read back from out > 0) are the adjoint. */
+int ksmi_bn_relu_drop2d(const void* z, const float* scale, const float* shift, void* y, int B, int64_t HW, int C, uint32_t thr, float inv_keep,
+                        uint32_t site, const uint32_t* rng_state, int dtype, void* stream);
+int ksmi_reduce_rows_scaled(const float* partial, int rows, int K, int Cstride, int C, float* sums, float* dgamma, float* dbeta,
+                            int accumulate, float alpha, void* stream);
+int ksmi_bnrelu_bwd_apply_scaled(void* dout_g, const void* out, const void* z, const float* mean, const float* rstd, const float* gamma,
+                                 const float* sums, void* dz, double count, int64_t npix, int C, float alpha, int dtype, void* stream);
+/* FC-Siam-diff skips (siam_diff.py:137-161): y = |a - b| ; da (+)= dy*sign(a-b), db (+)= -dy*sign(a-b) */
+int ksmi_absdiff_forward(const void* a, const void* b, void* y, int64_t n, int dtype, void* stream);
+int ksmi_absdiff_backward(const void* a, const void* b, const void* dy, void* da, void* db, int accumulate_a, int accumulate_b, int64_t n,
+                          int dtype, void* stream);
 int ksmi_sr_attention_forward_drop(const void* q, const void* kv, void* out, int B, int Nq, int Nk, int H, int C, float scale,
                                    uint32_t drop_thr, float drop_inv_keep, uint32_t site, const uint32_t* rng_state, int dtype, void* stream);
 int ksmi_sr_attention_backward_drop(const void* q, const void* kv, const void* out, const void* dout, void* dq, void* dkv, void* workspace,
@@ -417,7 +431,9 @@ int ksmi_maxpool3x3s2_backward(const void* x, const void* dy, void* dx, int accu
  * linear_fuse (:563-567) and the 0.1 branch scale of ResidualBlock (:479-481) in the backward pass */
 int ksmi_affine(const void* x, const float* scale, const float* shift, void* y, int64_t npix, int C, int relu, float alpha, int dtype,
                 void* stream);
-/* head output NHWC [B][HW][Cs] -> NCHW fp32, act = 1: sigmoid (:635-639); adjoint (y = the forward's NCHW output) */
+/* head output NHWC [B][HW][Cs] -> NCHW fp32, act = 1: sigmoid (:635-639), act = 2: softmax over the C channels (siam_conc.py:93,177),
+ * act = 3: log-softmax (siam_diff.py:93,173);
+ * adjoint (y = the forward's NCHW output) */
 int ksmi_out_to_nchw(const void* x, float* y, int B, int C, int Cs, int64_t HW, int act, int dtype, void* stream);
 int ksmi_dout_to_nhwc(const float* dy, const float* y, void* dx, int B, int C, int Cs, int64_t HW, int act, int dtype, void* stream);
 

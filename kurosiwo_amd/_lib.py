@@ -154,6 +154,11 @@ SIGNATURES = {
     "ksmi_sr_attention_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, C.c_float, _i, _vp]),
     "ksmi_attention_bwd_workspace": (C.c_size_t, [_i, _i, _i, _i, _i]),
     "ksmi_rng_advance": (_i, [_vp, _vp]),
+    "ksmi_bn_relu_drop2d": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, C.c_uint32, C.c_float, C.c_uint32, _vp, _i, _vp]),
+    "ksmi_reduce_rows_scaled": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, C.c_float, _vp]),
+    "ksmi_bnrelu_bwd_apply_scaled": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _i64, _i, C.c_float, _i, _vp]),
+    "ksmi_absdiff_forward": (_i, [_vp, _vp, _vp, _i64, _i, _vp]),
+    "ksmi_absdiff_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _i, _vp]),
     "ksmi_dropout_apply": (_i, [_vp, _vp, _vp, _i64, _i, _i, C.c_uint32, C.c_float, C.c_uint32, C.c_uint32, C.c_float, C.c_uint32, _vp, _i, _vp]),
     "ksmi_sr_attention_forward_drop": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, C.c_float, C.c_uint32, C.c_float, C.c_uint32, _vp, _i, _vp]),
     "ksmi_sr_attention_backward_drop": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, C.c_float, C.c_uint32, C.c_float, C.c_uint32,

@@ -22,6 +22,11 @@ def _numel(shape):
     return r
 
 
+def _as_i32(words):
+    """two unsigned 32-bit words as the int32 tensor torch can hold"""
+    return torch.tensor([v - (1 << 32) if v >= (1 << 31) else v for v in words], dtype=torch.int32)
+
+
 class ArenaModule(nn.Module):
     def _setup_arena(self, pspec, bspec=None, ispec=None):
         """pspec: OrderedDict key -> shape, in the reference's registration order; bspec: fp32 buffers (BatchNorm running
@@ -120,6 +125,24 @@ class ArenaModule(nn.Module):
 
     def _g(self, key):
         return self.flat_grads[self._poff[key]:self._poff[key] + _numel(self._pspec[key])]
+
+    # ---- random stream of the stochastic layers (nn.Dropout / DropPath / nn.Dropout2d of the reference models; csrc/common.h)
+    def manual_seed(self, seed, step=0):
+        """pin the counter-based stream: the next training forward uses (seed, step + 1)"""
+        self._rng_init = (int(seed) & 0xFFFFFFFF, int(step) & 0xFFFFFFFF)
+        if getattr(self, "_rng_state", None) is not None:
+            self._rng_state.copy_(_as_i32(self._rng_init))
+        return self
+
+    def rng_state(self):
+        """device words {seed, step} read by the dropout kernels (default seed: torch.initial_seed(), so torch.manual_seed steers it)"""
+        self._ensure_arena()
+        dev = self.flat_params.device
+        if getattr(self, "_rng_state", None) is None or self._rng_state.device != dev:
+            if getattr(self, "_rng_init", None) is None:
+                self._rng_init = (torch.initial_seed() & 0xFFFFFFFF, 0)
+            self._rng_state = _as_i32(self._rng_init).to(dev)
+        return self._rng_state
 
     def act_dtype(self):
         return torch.bfloat16 if self.precision == "bf16" else torch.float32

@@ -109,11 +109,6 @@ def changeformer_specs(input_nc, output_nc, embed_dim):
     return p, b, c
 
 
-def _as_i32(words):
-    """two unsigned 32-bit words as the int32 tensor torch can hold"""
-    return torch.tensor([v - (1 << 32) if v >= (1 << 31) else v for v in words], dtype=torch.int32)
-
-
 class ChangeFormerV6(ArenaModule):
     def __init__(self, input_nc=3, output_nc=2, decoder_softmax=False, embed_dim=256, precision="bf16"):
         super().__init__()
@@ -125,7 +120,6 @@ class ChangeFormerV6(ArenaModule):
         self.embed_dims, self.depths = list(EMBED_DIMS), list(DEPTHS)
         self.precision = precision
         self.drop_rate, self.attn_drop, self.drop_path_rate = 0.1, 0.1, 0.1       # ChangeFormerV6.__init__ :651-653
-        self._rng_state, self._rng_init = None, None
         ps, bs, cs = changeformer_specs(input_nc, output_nc, embed_dim)
         self._setup_arena(ps, bs, cs)
         self._init_parameters()
@@ -161,23 +155,6 @@ class ChangeFormerV6(ArenaModule):
 
     def _is_bn(self, key):
         return (key.rsplit(".", 1)[0] + ".running_mean") in self._bspec
-
-    def manual_seed(self, seed, step=0):
-        """pin the random stream of the stochastic layers: the next training forward uses (seed, step + 1)"""
-        self._rng_init = (int(seed) & 0xFFFFFFFF, int(step) & 0xFFFFFFFF)
-        if self._rng_state is not None:
-            self._rng_state.copy_(_as_i32(self._rng_init))
-        return self
-
-    def rng_state(self):
-        """device words {seed, step} read by the dropout kernels (default seed: torch.initial_seed(), so torch.manual_seed steers it)"""
-        self._ensure_arena()
-        if self._rng_state is None:
-            if self._rng_init is None:
-                self._rng_init = (torch.initial_seed() & 0xFFFFFFFF, 0)
-            dev = next(self.parameters()).device
-            self._rng_state = _as_i32(self._rng_init).to(dev)
-        return self._rng_state
 
     def plan(self, B, H, W, training, with_backward):
         self._ensure_arena()

@@ -646,8 +646,16 @@ __global__ void out_to_nchw_kernel(const T* x, float* y, int B, int C, int Cs, i
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t p = i % HW; int64_t r = i / HW;
     const int c = r % C; const int b = r / C;
-    float v = ElemTraits<T>::ld(x + ((int64_t)b * HW + p) * Cs + c);
+    const T* xp = x + ((int64_t)b * HW + p) * Cs;
+    float v = ElemTraits<T>::ld(xp + c);
     if (act == 1) v = 1.f / (1.f + __expf(-v));
+    else if (act == 2 || act == 3) {           // nn.Softmax(dim=1) (siam_conc.py:93,177) / nn.LogSoftmax(dim=1) (siam_diff.py:93,173)
+      float m = v;
+      for (int k = 0; k < C; ++k) m = fmaxf(m, ElemTraits<T>::ld(xp + k));
+      float l = 0.f;
+      for (int k = 0; k < C; ++k) l += __expf(ElemTraits<T>::ld(xp + k) - m);
+      v = act == 2 ? __expf(v - m) / l : v - m - __logf(l);
+    }
     y[i] = v;
   }
 }
@@ -662,6 +670,15 @@ __global__ void dout_to_nhwc_kernel(const float* dy, const float* y, T* dx, int 
       const int64_t j = ((int64_t)b * C + c) * HW + p;
       v = dy[j];
       if (act == 1) { const float s = y[j]; v *= s * (1.f - s); }
+      else if (act == 2) {                     // softmax adjoint: y_c (dy_c - sum_k y_k dy_k)
+        float dot = 0.f;
+        for (int k = 0; k < C; ++k) { const int64_t jk = ((int64_t)b * C + k) * HW + p; dot += y[jk] * dy[jk]; }
+        v = y[j] * (v - dot);
+      } else if (act == 3) {                   // log-softmax adjoint: dy_c - exp(y_c) sum_k dy_k
+        float tot = 0.f;
+        for (int k = 0; k < C; ++k) tot += dy[((int64_t)b * C + k) * HW + p];
+        v = v - __expf(y[j]) * tot;
+      }
     }
     ElemTraits<T>::st(dx + i, v);
   }

@@ -120,7 +120,7 @@ static int fold_rows(float* partial, int rows, int K, int Cstride, int C, hipStr
 
 // sums[k][c] = sum_rows partial[row][k][c]; optional accumulate into dgamma (k=1) / dbeta (k=0)
 __global__ void reduce_rows_kernel(const float* partial, int rows, int K, int Cstride, int C, float* sums,
-                                   float* dgamma, float* dbeta, int accumulate) {
+                                   float* dgamma, float* dbeta, int accumulate, float alpha) {
   __shared__ double red[64][17];
   const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
   const int c = blockIdx.x * 16 + cl;
@@ -138,7 +138,7 @@ __global__ void reduce_rows_kernel(const float* partial, int rows, int K, int Cs
       const float f = (float)s;
       if (sums) sums[k * C + c] = f;
       float* tgt = (k == 0) ? dbeta : (k == 1 ? dgamma : nullptr);
-      if (tgt) tgt[c] = accumulate ? tgt[c] + f : f;
+      if (tgt) tgt[c] = accumulate ? tgt[c] + alpha * f : alpha * f;   // sums stay unscaled (the apply kernel takes alpha itself)
     }
   }
 }
@@ -228,7 +228,8 @@ __global__ void bnrelu_bwd_reduce_kernel(const T* dout, const T* out, const T* z
 // pass 2: g -> dout (in place), dz = gamma*rstd*(g - s0/n - zhat*s1/n)
 template <typename T>
 __global__ void bnrelu_bwd_apply_kernel(T* dout, const T* out, const T* z, const float* mean, const float* rstd,
-                                        const float* gamma, const float* sums, T* dz, float inv_n, int64_t nvec, int CV, int C) {
+                                        const float* gamma, const float* sums, T* dz, float inv_n, int64_t nvec, int CV, int C,
+                                        float alpha) {
   constexpr int VEC = ElemTraits<T>::kVec;
   for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * blockDim.x) {
     const int c = (int)(v % CV) * VEC;
@@ -241,7 +242,7 @@ __global__ void bnrelu_bwd_apply_kernel(T* dout, const T* out, const T* z, const
       const float gg = o[j] > 0.f ? g[j] : 0.f;
       const float zh = (zz[j] - mean[c + j]) * rstd[c + j];
       g[j] = gg;
-      zz[j] = gamma[c + j] * rstd[c + j] * (gg - sums[c + j] * inv_n - zh * sums[C + c + j] * inv_n);
+      zz[j] = alpha * gamma[c + j] * rstd[c + j] * (gg - sums[c + j] * inv_n - zh * sums[C + c + j] * inv_n);
     }
     *(u32x4*)(dout + v * VEC) = vec_pack<T>(g);
     *(u32x4*)(dz + v * VEC) = vec_pack<T>(zz);
@@ -741,13 +742,17 @@ int ksmi_bn_finalize(const float* partial, int rows, int Cpad, int C, double cou
   return ksmi_check_launch("bn_finalize");
 }
 
-int ksmi_reduce_rows(const float* partial, int rows, int K, int Cstride, int C, float* sums, float* dgamma, float* dbeta,
-                     int accumulate, void* stream) {
+int ksmi_reduce_rows_scaled(const float* partial, int rows, int K, int Cstride, int C, float* sums, float* dgamma, float* dbeta,
+                            int accumulate, float alpha, void* stream) {
   if (rows < 1 || K < 1 || C < 1 || Cstride < C) return ksmi_fail(KSMI_E_ARG, "reduce_rows: bad args");
   rows = fold_rows((float*)partial, rows, K, Cstride, C, (hipStream_t)stream);
   hipLaunchKernelGGL(reduce_rows_kernel, dim3((C + 15) / 16), dim3(1024), 0, (hipStream_t)stream, partial, rows, K, Cstride, C, sums,
-                     dgamma, dbeta, accumulate);
+                     dgamma, dbeta, accumulate, alpha);
   return ksmi_check_launch("reduce_rows");
+}
+int ksmi_reduce_rows(const float* partial, int rows, int K, int Cstride, int C, float* sums, float* dgamma, float* dbeta,
+                     int accumulate, void* stream) {
+  return ksmi_reduce_rows_scaled(partial, rows, K, Cstride, C, sums, dgamma, dbeta, accumulate, 1.f, stream);
 }
 
 int ksmi_reduce_rows_batched(const ksmi_rowsum_desc* descs_device, int n, void* stream) {
@@ -780,9 +785,9 @@ int ksmi_bnrelu_bwd_reduce(const void* dout, const void* out, const void* z, con
   return ksmi_check_launch("bnrelu_bwd_reduce");
 }
 
-int ksmi_bnrelu_bwd_apply(void* dout_g, const void* out, const void* z, const float* mean, const float* rstd,
-                          const float* gamma, const float* sums, void* dz, double count, int64_t npix, int C, int dtype,
-                          void* stream) {
+int ksmi_bnrelu_bwd_apply_scaled(void* dout_g, const void* out, const void* z, const float* mean, const float* rstd,
+                                 const float* gamma, const float* sums, void* dz, double count, int64_t npix, int C, float alpha, int dtype,
+                                 void* stream) {
   if (!chan_ok(C, dtype)) return ksmi_fail(KSMI_E_ARG, "bnrelu_bwd_apply: bad C");
   const int vec = dtype == KSMI_BF16 ? 8 : 4;
   const int64_t nvec = npix * C / vec;
@@ -790,11 +795,16 @@ int ksmi_bnrelu_bwd_apply(void* dout_g, const void* out, const void* z, const fl
   KSMI_DT(dtype,
           hipLaunchKernelGGL(bnrelu_bwd_apply_kernel<bf16_t>, dim3(grid_for(nvec, 8192)), dim3(256), 0, (hipStream_t)stream,
                              (bf16_t*)dout_g, (const bf16_t*)out, (const bf16_t*)z, mean, rstd, gamma, sums, (bf16_t*)dz, inv_n, nvec,
-                             C / vec, C),
+                             C / vec, C, alpha),
           hipLaunchKernelGGL(bnrelu_bwd_apply_kernel<float>, dim3(grid_for(nvec, 8192)), dim3(256), 0, (hipStream_t)stream,
                              (float*)dout_g, (const float*)out, (const float*)z, mean, rstd, gamma, sums, (float*)dz, inv_n, nvec,
-                             C / vec, C));
+                             C / vec, C, alpha));
   return ksmi_check_launch("bnrelu_bwd_apply");
+}
+int ksmi_bnrelu_bwd_apply(void* dout_g, const void* out, const void* z, const float* mean, const float* rstd,
+                          const float* gamma, const float* sums, void* dz, double count, int64_t npix, int C, int dtype,
+                          void* stream) {
+  return ksmi_bnrelu_bwd_apply_scaled(dout_g, out, z, mean, rstd, gamma, sums, dz, count, npix, C, 1.f, dtype, stream);
 }
 
 int ksmi_bn_bwd_apply_add(void* r_di, const void* g, const void* i, const float* mean, const float* rstd, const float* gamma,

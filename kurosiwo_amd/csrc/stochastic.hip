@@ -42,6 +42,63 @@ __global__ __launch_bounds__(256) void drop_apply_kernel(const T* x, const T* re
 
 __global__ void rng_advance_kernel(uint32_t* state) { state[1] += 1u; }
 
+// y = relu(z * scale[c] + shift[c]) * Dropout2d(b, c): nn.Dropout2d zeroes whole (sample, channel) planes (siam_conc.py:20 ...)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_drop2d_kernel(const T* z, const float* __restrict__ scale, const float* __restrict__ shift, T* y,
+                                                             int64_t nvec, int CV, int64_t hw_cv, uint32_t thr, float inv, uint32_t site,
+                                                             const uint32_t* __restrict__ state) {
+  constexpr int V = ElemTraits<T>::kVec;
+  const uint32_t key = thr ? ksmi_rng_key(state, site) : 0u;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % CV) * V;
+    const uint32_t b = (uint32_t)(i / hw_cv);
+    float f[V];
+    vec_unpack<T>(((const u32x4*)z)[i], f);
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      float v = fmaxf(f[j] * scale[c + j] + shift[c + j], 0.f);
+      if (thr) v = ksmi_rng_keep(key, b * (uint32_t)(CV * V) + c + j, thr) ? v * inv : 0.f;
+      f[j] = v;
+    }
+    ((u32x4*)y)[i] = vec_pack<T>(f);
+  }
+}
+
+// FC-Siam-diff skip (siam_diff.py:137,146,154,161): y = |a - b|; adjoint: da = dy * sign(a - b), db = -da (da/db (+)=)
+template <typename T>
+__global__ __launch_bounds__(256) void absdiff_kernel(const T* a, const T* b, T* y, int64_t nvec) {
+  constexpr int V = ElemTraits<T>::kVec;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+    float fa[V], fb[V];
+    vec_unpack<T>(((const u32x4*)a)[i], fa);
+    vec_unpack<T>(((const u32x4*)b)[i], fb);
+#pragma unroll
+    for (int j = 0; j < V; ++j) fa[j] = fabsf(fa[j] - fb[j]);
+    ((u32x4*)y)[i] = vec_pack<T>(fa);
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void absdiff_bwd_kernel(const T* a, const T* b, const T* dy, T* da, T* db, int acc_a, int acc_b, int64_t nvec) {
+  constexpr int V = ElemTraits<T>::kVec;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+    float fa[V], fb[V], g[V], oa[V], ob[V];
+    vec_unpack<T>(((const u32x4*)a)[i], fa);
+    vec_unpack<T>(((const u32x4*)b)[i], fb);
+    vec_unpack<T>(((const u32x4*)dy)[i], g);
+    if (acc_a) vec_unpack<T>(((const u32x4*)da)[i], oa);
+    if (acc_b) vec_unpack<T>(((const u32x4*)db)[i], ob);
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const float d = fa[j] - fb[j];
+      const float s = d > 0.f ? g[j] : (d < 0.f ? -g[j] : 0.f);     // torch.abs: subgradient 0 at 0
+      oa[j] = acc_a ? oa[j] + s : s;
+      ob[j] = acc_b ? ob[j] - s : -s;
+    }
+    ((u32x4*)da)[i] = vec_pack<T>(oa);
+    ((u32x4*)db)[i] = vec_pack<T>(ob);
+  }
+}
+
 }  // namespace
 
 int ksmi_rng_advance(uint32_t* state, void* stream) {
@@ -70,4 +127,55 @@ int ksmi_dropout_apply(const void* x, const void* resid, void* y, int64_t rows, 
     hipLaunchKernelGGL(drop_apply_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)x, (const float*)resid, (float*)y, nvec,
                        cols, rows_per_sample, thr, inv_keep, site, dp_thr, dp_inv_keep, dp_site, rng_state);
   return ksmi_check_launch("dropout_apply");
+}
+
+int ksmi_bn_relu_drop2d(const void* z, const float* scale, const float* shift, void* y, int B, int64_t HW, int C, uint32_t thr, float inv_keep,
+                        uint32_t site, const uint32_t* rng_state, int dtype, void* stream) {
+  const int vec = dtype == KSMI_BF16 ? 8 : 4;
+  if (dtype != KSMI_BF16 && dtype != KSMI_F32) return ksmi_fail(KSMI_E_ARG, "bn_relu_drop2d: dtype");
+  if (C <= 0 || C % vec) return ksmi_fail(KSMI_E_ARG, "bn_relu_drop2d: C must be a multiple of the 16-byte vector");
+  if (thr && !rng_state) return ksmi_fail(KSMI_E_ARG, "bn_relu_drop2d: the rng state is required");
+  const int64_t nvec = (int64_t)B * HW * (C / vec);
+  if (nvec == 0) return 0;
+  int64_t blocks = (nvec + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == KSMI_BF16)
+    hipLaunchKernelGGL(bn_relu_drop2d_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)z, scale, shift, (bf16_t*)y, nvec, C / vec,
+                       HW * (C / vec), thr, inv_keep, site, rng_state);
+  else
+    hipLaunchKernelGGL(bn_relu_drop2d_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)z, scale, shift, (float*)y, nvec, C / vec,
+                       HW * (C / vec), thr, inv_keep, site, rng_state);
+  return ksmi_check_launch("bn_relu_drop2d");
+}
+
+int ksmi_absdiff_forward(const void* a, const void* b, void* y, int64_t n, int dtype, void* stream) {
+  const int vec = dtype == KSMI_BF16 ? 8 : 4;
+  if (n % vec) return ksmi_fail(KSMI_E_ARG, "absdiff: element count must be a multiple of the 16-byte vector");
+  const int64_t nvec = n / vec;
+  int64_t blocks = (nvec + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  if (blocks < 1) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == KSMI_BF16) hipLaunchKernelGGL(absdiff_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)y, nvec);
+  else hipLaunchKernelGGL(absdiff_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)a, (const float*)b, (float*)y, nvec);
+  return ksmi_check_launch("absdiff");
+}
+
+int ksmi_absdiff_backward(const void* a, const void* b, const void* dy, void* da, void* db, int accumulate_a, int accumulate_b, int64_t n,
+                          int dtype, void* stream) {
+  const int vec = dtype == KSMI_BF16 ? 8 : 4;
+  if (n % vec) return ksmi_fail(KSMI_E_ARG, "absdiff_bwd: element count must be a multiple of the 16-byte vector");
+  const int64_t nvec = n / vec;
+  int64_t blocks = (nvec + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  if (blocks < 1) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == KSMI_BF16)
+    hipLaunchKernelGGL(absdiff_bwd_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)b, (const bf16_t*)dy,
+                       (bf16_t*)da, (bf16_t*)db, accumulate_a, accumulate_b, nvec);
+  else
+    hipLaunchKernelGGL(absdiff_bwd_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)a, (const float*)b, (const float*)dy,
+                       (float*)da, (float*)db, accumulate_a, accumulate_b, nvec);
+  return ksmi_check_launch("absdiff_bwd");
 }

@@ -17,8 +17,14 @@ def initialize_cd_model(configs, model_configs, phase="train"):
         model = ChangeFormerV6(embed_dim=model_configs["embed_dim"], input_nc=configs["num_channels"], output_nc=configs["num_classes"],
                                decoder_softmax=model_configs["decoder_softmax"],
                                precision=configs.get("precision", "bf16" if configs.get("mixed_precision") else "fp32"))
+    elif method in ("siam-conc", "siam-diff"):             # model_utilities.py:183-190
+        from .fcsiam import SiamUnet_conc, SiamUnet_diff
+        cls = SiamUnet_conc if method == "siam-conc" else SiamUnet_diff
+        model = cls(input_nbr=configs["num_channels"], label_nbr=configs["num_classes"],
+                    precision=configs.get("precision", "bf16" if configs.get("mixed_precision") else "fp32"))
     else:
-        raise _lib.KsmiError(f"method {method!r} has no HIP implementation (change-detection methods in scope: snunet, changeformer)")
+        raise _lib.KsmiError(f"method {method!r} has no HIP implementation (change-detection methods in scope: snunet, changeformer, "
+                             "siam-conc, siam-diff)")
     model = model.to(configs["device"])
     if configs.get("resume_checkpoint"):
         ck = torch.load(configs["resume_checkpoint"], map_location=configs["device"])

@@ -572,6 +572,64 @@ def gen_changeformer_drop():
     np.savez_compressed(os.path.join(OUT, "changeformer_drop.npz"), **out)
 
 
+def gen_fcsiam():
+    """FC-Siam-conc / FC-Siam-diff (N2 row): the REFERENCE modules (models/siam_conc.py, siam_diff.py import with torch alone).  Eval
+    outputs, and one train-mode step with every nn.Dropout2d(p=0.2) ON, its plane mask drawn from the counter-based stream of
+    oracle/rng_ref.py: site = 2 * (index of the layer among the BatchNorm'ed layers) + date, where the date is the call count of the
+    module within the forward (the shared encoder modules run for date 1, then date 2: siam_conc.py:100-146)."""
+    from models.siam_conc import SiamUnet_conc
+    from models.siam_diff import SiamUnet_diff
+    from oracle import fcsiam_ref as R
+    from oracle import rng_ref as G
+    c, B, S = 2, 2, 96
+    for tag, cls in (("conc", SiamUnet_conc), ("diff", SiamUnet_diff)):
+        out = {}
+        model = cls(c, 3)
+        seeded_fill_(model.state_dict())
+        sd = model.state_dict()
+        out["state_dict_keys"] = np.array(list(sd.keys()))
+        out["state_dict_shapes"] = np.array([",".join(str(d) for d in v.shape) for v in sd.values()])
+        x1 = sar_like(f"fcsiam.{tag}.eval.x1", (1, c, S, S))
+        x2 = sar_like(f"fcsiam.{tag}.eval.x2", (1, c, S, S))
+        model.eval()
+        with torch.no_grad():
+            out["eval.out"] = model(x1, x2).numpy().copy()
+        model.train()
+        for name, mod in model.named_modules():
+            if isinstance(mod, torch.nn.Dropout2d):
+                assert name.startswith("do") and abs(mod.p - 0.2) < 1e-12
+                layer, calls = R.LAYERS.index(name[2:]), {"n": 0}
+
+                def fwd(x, layer=layer, calls=calls):
+                    site = 2 * layer + calls["n"]
+                    calls["n"] += 1
+                    m = G.scale_mask(DROP_SEED, DROP_STEP, site, 0.2, 0, (x.shape[0], x.shape[1]))
+                    return x * torch.from_numpy(m)[:, :, None, None]
+                mod.forward = fwd
+        x1 = sar_like(f"fcsiam.{tag}.train.x1", (B, c, S, S))
+        x2 = sar_like(f"fcsiam.{tag}.train.x2", (B, c, S, S))
+        lbl = seeded_labels(f"fcsiam.{tag}.train.lbl", (B, S, S))
+        crit = BCEandDiceLoss(weights=CLASS_WEIGHTS, ignore_index=3, use_softmax=True)
+        o = model(x1, x2)
+        loss = crit(o, lbl)                                      # change_detection_trainer.py:138-166: the model output goes to the criterion
+        loss.backward()
+        out["seed_step"] = np.array([DROP_SEED, DROP_STEP])
+        out["train.out"] = o.detach().numpy().copy()
+        out["train.loss"] = np.array(float(loss.detach()))
+        for k, p in model.named_parameters():
+            g = p.grad.detach().double()
+            out[f"gstat.{k}"] = np.array([float(g.norm()), float(g.sum()), float(g.abs().max())])
+            if k.startswith(("conv11.", "conv21.", "upconv1.", "conv22d.", "conv12d.", "conv11d.", "bn21.", "bn32d.")):
+                out[f"grad.{k}"] = p.grad.detach().numpy().copy()
+        sd = model.state_dict()
+        for k in ("bn11", "bn43", "bn43d", "bn12d"):
+            out[f"bn.{k}.running_mean"] = sd[f"{k}.running_mean"].numpy().copy()
+            out[f"bn.{k}.running_var"] = sd[f"{k}.running_var"].numpy().copy()
+            out[f"bn.{k}.num_batches_tracked"] = sd[f"{k}.num_batches_tracked"].numpy().copy()
+        print("fcsiam", tag, "train loss", float(loss.detach()), "keys", len(sd))
+        np.savez_compressed(os.path.join(OUT, f"fcsiam_{tag}.npz"), **out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -593,5 +651,7 @@ if __name__ == "__main__":
         gen_changeformer_slc()
     if not only or "changeformer_drop" in only:
         gen_changeformer_drop()
+    if not only or "fcsiam" in only:
+        gen_fcsiam()
     if not only or "mae" in only:
         gen_mae()
