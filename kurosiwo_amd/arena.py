@@ -159,6 +159,19 @@ class ArenaModule(nn.Module):
                                  "call optimizer.zero_grad(set_to_none=True) (the PyTorch default) before each step")
 
 
+def stamp_forward(plan):
+    """A plan owns ONE set of activation buffers: every grad-enabled forward gets a generation number and backward() refuses to
+    run on buffers a later forward of the same (shape, mode) plan has overwritten."""
+    plan._generation = getattr(plan, "_generation", 0) + 1
+    return plan._generation
+
+
+def check_forward_stamp(plan, gen):
+    if getattr(plan, "_generation", gen) != gen:
+        raise _lib.KsmiError("backward() of a forward whose activations were overwritten: the HIP plan keeps one set of activation buffers "
+                             "per (batch shape, mode), so call backward() before the next grad-enabled forward of the same shape")
+
+
 class PlanFn(torch.autograd.Function):
     """Whole-model autograd node: forward replays plan.fwd, backward replays plan.bwd and attaches the
     arena-backed .grad views (anchor = dummy leaf that makes autograd call us)."""
@@ -166,11 +179,13 @@ class PlanFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, model, plan, *inputs):
         ctx.model, ctx.plan = model, plan
+        ctx.gen = stamp_forward(plan)
         return plan.run_forward(*inputs).clone()
 
     @staticmethod
     def backward(ctx, dout):
         model, plan = ctx.model, ctx.plan
+        check_forward_stamp(plan, ctx.gen)
         model._check_no_grads()
         plan.run_backward(dout.contiguous().float())
         model._attach_grads()

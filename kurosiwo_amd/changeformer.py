@@ -184,7 +184,9 @@ class ChangeFormerV6(ArenaModule):
 class _ChangeFormerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, x1, x2, model, plan):
+        from .arena import stamp_forward
         ctx.model, ctx.plan = model, plan
+        ctx.gen = stamp_forward(plan)
         ctx.set_materialize_grads(False)
         plan.run_forward(x1, x2)
         return tuple(o.clone() for o in plan.outputs)
@@ -196,6 +198,8 @@ class _ChangeFormerFn(torch.autograd.Function):
             raise NotImplementedError("ChangeFormerV6 (HIP): only the last output (cp) is differentiable (multi_scale_train = false)")
         if douts[-1] is None:
             return (None,) * 5
+        from .arena import check_forward_stamp
+        check_forward_stamp(plan, ctx.gen)
         model._check_no_grads()
         plan.run_backward(douts[-1].contiguous().float())
         model._attach_grads()

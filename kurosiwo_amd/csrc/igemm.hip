@@ -770,7 +770,7 @@ static void gemm_tn_geom(const ksmi_wgrad_desc* d, int kc, int& nsplit, int& rps
       const int steps = (steps_all + s - 1) / s;
       const int rounds = (tiles * s + 255) / 256;
       double t = rounds * (steps * step_us + 3.0);
-      if (s > 1) t += 2.0 * s * (double)K * npad * 4.0 / 4.0e6 + 3.0;
+      if (s > 1) t += 2.0 * s * (double)K * npad * 4.0 / 4.0e6 + 3.0 + 0.08 * (s > 16 ? 16 + (s - 16) / 8 : s);   // + the reducer's serial slab walk
       if (t < best) { best = t; bs = s; bt = b; }
     }
   }
@@ -845,6 +845,12 @@ int launch_wgrad(const ksmi_wgrad_desc* d, hipStream_t st) {
       if (r2 < 0) return r2;
       if (r2 == 0) {
         if (direct) return 0;
+        if (g.nsplit > 16) {      // many thin slabs (small matrices): the 8-lanes-per-element tree reducer hides the slab walk better
+          const size_t totalr = (size_t)d->nchunks * g.kc * g.npad;
+          int blocksr = (int)((totalr * 8 + 255) / 256); if (blocksr > 4096) blocksr = 4096;
+          hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocksr), dim3(256), 0, st, *d, 1, g.kc);
+          return ksmi_check_launch("wgrad_reduce");
+        }
         const size_t total0 = (size_t)d->nchunks * g.kc * g.npad / 4;
         int blocks0 = (int)((total0 + 255) / 256); if (blocks0 > 8192) blocks0 = 8192;
         hipLaunchKernelGGL(tn_reduce_kernel, dim3(blocks0), dim3(256), 0, st, *d, g.kc, d->nchunks * g.kc);

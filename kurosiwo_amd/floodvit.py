@@ -185,7 +185,9 @@ class FinetunerSegmentation(ArenaModule):
 
     def plan(self, B, training, with_backward):
         self._ensure_arena()
-        key = (B, self.act_dtype(), bool(training), bool(with_backward))
+        # the plan skips the encoder's backward when every encoder parameter is frozen (linear_eval): part of the key
+        enc_trains = any(self._param_obj(k).requires_grad for k in self._pspec if k.startswith("model."))
+        key = (B, self.act_dtype(), bool(training), bool(with_backward), enc_trains)
         if key not in self._plans:
             from .floodvit_plan import FloodViTPlan
             self._plans[key] = FloodViTPlan(self, B, self.act_dtype(), with_backward)

@@ -240,12 +240,16 @@ class SNUNet_ECAM(nn.Module):
 class _SNUNetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, xA, xB, model, plan):
+        from .arena import stamp_forward
         ctx.model, ctx.plan = model, plan
+        ctx.gen = stamp_forward(plan)
         return plan.run_forward(xA, xB).clone()
 
     @staticmethod
     def backward(ctx, dlogits):
+        from .arena import check_forward_stamp
         model, plan = ctx.model, ctx.plan
+        check_forward_stamp(plan, ctx.gen)
         params = list(model.parameters())
         if any(p.grad is not None for p in params):
             raise _lib.KsmiError("gradient accumulation across backward() calls is not supported by the HIP SNUNet: "

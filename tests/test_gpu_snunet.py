@@ -267,3 +267,19 @@ def test_bf16_at_the_benchmarked_size_vs_reference_golden(dev, golden_dir):
     for k in ("conv0_0.bn1", "conv0_4.bn2", "conv2_1.bn1"):
         assert np.abs(msd[f"{k}.running_mean"].cpu().numpy() - gold[f"bn.{k}.running_mean"]).max() < 2e-2 * max(1.0, np.abs(gold[f"bn.{k}.running_mean"]).max())
         assert np.abs(msd[f"{k}.running_var"].cpu().numpy() - gold[f"bn.{k}.running_var"]).max() < 3e-2 * max(1.0, float(gold[f"bn.{k}.running_var"].max()))
+
+
+def test_backward_of_an_overwritten_forward_is_refused():
+    """A plan keeps one set of activation buffers per (shape, mode): backward() of a forward that a later grad-enabled forward of the
+    same shape has overwritten must fail loudly instead of returning the gradients of the wrong graph."""
+    from kurosiwo_amd import _lib
+    from kurosiwo_amd.snunet import SNUNet_ECAM
+    torch.manual_seed(0)
+    model = SNUNet_ECAM(2, 3, base_channel=32, precision="fp32").cuda().train()
+    x = torch.randn(1, 2, 32, 32, device="cuda")
+    first = model(x, x).sum()
+    second = model(x, x + 1).sum()
+    with pytest.raises(_lib.KsmiError, match="overwritten"):
+        first.backward()
+    second.backward()                       # the latest forward is still differentiable
+    assert all(p.grad is not None for p in model.parameters())
