@@ -85,7 +85,7 @@ def measured_traffic(kind):
             tot += row["calls"] * (2.0 * row["fetch_kb_raw"] + row["write_kb_raw"]) * 1024.0
             if "reduce" not in name:
                 main_calls += row["calls"]
-    return {"bytes_per_launch": round(tot / main_calls), "source": "profiles/r02_snunet_traffic.json (2 x FETCH_SIZE + WRITE_SIZE)"} if main_calls else None
+    return round(tot / main_calls) if main_calls else None
 
 
 def cpu_baseline(budget_s=20.0):
@@ -264,7 +264,11 @@ def main():
                          if d["flops"] / MFMA_BF16_PEAK_TF / 1e12 > d["bytes"] / HBM_PEAK_GBS / 1e9 and args.precision == "bf16" else
                          {"kernel": dominant, "bound": "hbm", "achieved": round(ach_gbs, 1), "peak": HBM_PEAK_GBS,
                           "unit": "GB/s", "frac": round(ach_gbs / HBM_PEAK_GBS, 4)}) | {
-                         "traffic": measured_traffic(dominant), "launches_timed": d["n"], "avg_launch_ms": round(avg_ms, 4),
+                         # HBM bytes per launch by the PMC counters (2 x FETCH_SIZE + WRITE_SIZE, profiles/r02_snunet_traffic.json; the forward
+                         # and input-gradient classes share their kernels, so the table row is their common mean) next to the algorithmic bytes
+                         "traffic": measured_traffic(dominant), "traffic_unit": "bytes/launch",
+                         "algorithmic_bytes_per_launch": round(d["bytes"] / max(d["n"], 1)),
+                         "launches_timed": d["n"], "avg_launch_ms": round(avg_ms, 4),
                          "share_of_step": round(d["ms"] / (dt * 1e3), 3),
                          "algorithmic_GBs": round(ach_gbs, 1), "hbm_frac": round(ach_gbs / HBM_PEAK_GBS, 4),
                          "tflops": round(ach_tf, 1), "mfma_frac": round(ach_tf / MFMA_BF16_PEAK_TF, 4),

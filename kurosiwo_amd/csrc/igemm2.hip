@@ -31,8 +31,12 @@ struct Igemm2Args {            // kernel argument: the public descriptor + launc
 // workgroups are one long dependent chain (address setup -> DMA wait -> 72 MFMAs -> epilogue, ~24k cycles) and only latency
 // matters, so the variant trades the per-lane address table and the tap double-buffer for registers: <= 168 VGPRs and 40 KB
 // of LDS let 3 workgroups share a CU instead of 2.
-template <typename T, int NT, int KH, int KW, bool AFF, bool EX, int WN, bool LEAN = false>
+// MP = 2 (WN = 2, no AFF): the workgroup computes TWO pixel tiles (blockIdx.x*2, +1) per weight slab: the L2 -> LDS traffic of a
+// k-chunk drops from 2 x (halo + slab) to (2 halos + slab) -- these launches are bound by that path, not by the MFMA pipe (25 %
+// busy) -- and every barrier covers twice the MFMAs.
+template <typename T, int NT, int KH, int KW, bool AFF, bool EX, int WN, bool LEAN = false, int MP = 1>
 __global__ __launch_bounds__(256 * WN, LEAN ? 3 : 1) void igemm2_fwd_kernel(const Igemm2Args ka) {
+  static_assert(MP == 1 || (!AFF && !LEAN), "two tiles per workgroup: DMA halo path only");
   const ksmi_conv_desc& d = ka.d;
   const long long tm0 = __builtin_readcyclecounter();
   constexpr int NTHR = 256 * WN;
@@ -53,24 +57,35 @@ __global__ __launch_bounds__(256 * WN, LEAN ? 3 : 1) void igemm2_fwd_kernel(cons
 
   const int tilesX = (d.Wout + d.TW - 1) / d.TW, tilesY = (d.Hout + d.TH - 1) / d.TH;
   const FastDiv dTX(tilesX, ka.m_tx), dTY(tilesY, ka.m_ty);
-  const int q1 = dTX.div(blockIdx.x);
-  const int tx = blockIdx.x - q1 * tilesX;
-  const int b = dTY.div(q1);
-  const int ty = q1 - b * tilesY;
-  const int oy0 = ty * d.TH, ox0 = tx * d.TW;
+  const int ntile = d.B * tilesX * tilesY;
+  int tb[MP], toy[MP], tox[MP];
+  bool tvalid[MP];
+#pragma unroll
+  for (int mp = 0; mp < MP; ++mp) {
+    int tile = blockIdx.x * MP + mp;
+    tvalid[mp] = tile < ntile;
+    if (!tvalid[mp]) tile = ntile - 1;                      // (odd tile count: the second tile is computed and dropped)
+    const int q1 = dTX.div(tile);
+    const int tx = tile - q1 * tilesX;
+    tb[mp] = dTY.div(q1);
+    const int ty = q1 - tb[mp] * tilesY;
+    toy[mp] = ty * d.TH; tox[mp] = tx * d.TW;
+  }
+  const int b = tb[0], oy0 = toy[0], ox0 = tox[0];
   const int n0 = blockIdx.y * BN;
   const int S = d.stride;
   const int HH = (d.TH - 1) * S + KH, HW = (d.TW - 1) * S + KW;
   const int HP = HH * HW;
   const int P = d.TH * d.TW;
   const int HPB = (HP * 64 + 1023) & ~1023;                 // halo bytes, whole wave-instructions (1 KiB)
-  const int BUFB = HPB + TAPS * BN * 64;                    // one stage
+  const int BUFB = MP * HPB + TAPS * BN * 64;               // one stage: MP halo images + the weight slab
   const int nslot = (HPB + NTHR * 16 - 1) / (NTHR * 16);    // NTHR lanes x 16 B per slot-iteration
   const FastDiv dHW(HW, ka.m_hw), dTW(d.TW, ka.m_tw);
 
   // ---- per-thread halo slots: LDS position v = s*256 + tid <-> (pixel v>>2, slot v&3) -----------
   // (branch-free: selects only; the strided input view exists only in the EX variant)
   int slot_goff[MAXSLOT];                                   // pixel index in the image, or -1
+  int slot_goff2[MP > 1 ? MAXSLOT : 1];                     // ... of the second tile
   int slot_qb[MAXSLOT];                                     // DMA path: byte offset of the k-group fetched into this LDS slot
   int slot_lds[AFF ? MAXSLOT : 1];                          // register path: where k-group myq of the pixel goes
   const int iy0 = oy0 * S - d.pad, ix0 = ox0 * S - d.pad_x;
@@ -85,6 +100,14 @@ __global__ __launch_bounds__(256 * WN, LEAN ? 3 : 1) void igemm2_fwd_kernel(cons
     if constexpr (EX) gp = src_pixel(d, b, iy, ix);
     else gp = (b * d.Hin + iy) * d.Win + ix;
     slot_goff[s] = ok ? gp : -1;
+    if constexpr (MP > 1) {
+      const int iy2 = toy[1] * S - d.pad + hy, ix2 = tox[1] * S - d.pad_x + hx;
+      const bool ok2 = v < HP * 4 && (unsigned)iy2 < (unsigned)d.Hin && (unsigned)ix2 < (unsigned)d.Win;
+      int gp2;
+      if constexpr (EX) gp2 = src_pixel(d, tb[1], iy2, ix2);
+      else gp2 = (tb[1] * d.Hin + iy2) * d.Win + ix2;
+      slot_goff2[s] = ok2 ? gp2 : -1;
+    }
     slot_qb[s] = (sl ^ swz(pix)) << 4;
     if constexpr (AFF) slot_lds[s] = pix * 64 + ((sl ^ swz(pix)) << 4);   // (register path: thread owns k-group sl)
   }
@@ -97,6 +120,13 @@ __global__ __launch_bounds__(256 * WN, LEAN ? 3 : 1) void igemm2_fwd_kernel(cons
       const int off = AFF ? slot_lds[AFF ? s : 0] : (s * NTHR + tid) * 16;
       *(u32x4*)(smem + off) = (u32x4){0u, 0u, 0u, 0u};
       if (two_stage) *(u32x4*)(smem + BUFB + off) = (u32x4){0u, 0u, 0u, 0u};
+    }
+    if constexpr (MP > 1) {
+      if (tid + s * NTHR < HP * 4 && slot_goff2[s] < 0) {
+        const int off = HPB + (s * NTHR + tid) * 16;
+        *(u32x4*)(smem + off) = (u32x4){0u, 0u, 0u, 0u};
+        if (two_stage) *(u32x4*)(smem + BUFB + off) = (u32x4){0u, 0u, 0u, 0u};
+      }
     }
   }
 
@@ -139,10 +169,14 @@ __global__ __launch_bounds__(256 * WN, LEAN ? 3 : 1) void igemm2_fwd_kernel(cons
   }
 
   f32x4 acc[4][NT];
+  f32x4 acc2[MP > 1 ? 4 : 1][NT];                           // second tile
 #pragma unroll
   for (int mf = 0; mf < 4; ++mf)
 #pragma unroll
-    for (int nf = 0; nf < NT; ++nf) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int nf = 0; nf < NT; ++nf) {
+      acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if constexpr (MP > 1) acc2[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
 
   u32x4 hreg[AFF ? MAXSLOT : 1];
 
@@ -164,7 +198,7 @@ __global__ __launch_bounds__(256 * WN, LEAN ? 3 : 1) void igemm2_fwd_kernel(cons
   const uint32_t wslab = (uint32_t)TAPS * (uint32_t)d.Npad * 64u;   // bytes of one chunk's weight slab
   auto issue_weights = [&](int ch, int buf) {
     const unsigned char* wsrc = wpk + (size_t)ch * wslab;
-    unsigned char* wdst = smem + buf * BUFB + HPB;
+    unsigned char* wdst = smem + buf * BUFB + MP * HPB;
 #pragma unroll
     for (int i = 0; i < WITER; ++i) {
       if (w_src[i] >= 0)
@@ -180,6 +214,15 @@ __global__ __launch_bounds__(256 * WN, LEAN ? 3 : 1) void igemm2_fwd_kernel(cons
       if (s < nslot && slot_goff[s] >= 0)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(c.sp + off),
                                          (__attribute__((address_space(3))) void*)(hdst + (s * NTHR + wave * 64) * 16), 16, 0, 0);
+    }
+    if constexpr (MP > 1) {
+#pragma unroll
+      for (int s = 0; s < MAXSLOT; ++s) {
+        const uint32_t off = (uint32_t)slot_goff2[s] * c.cb + (uint32_t)slot_qb[s];
+        if (s < nslot && slot_goff2[s] >= 0)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(c.sp + off),
+                                           (__attribute__((address_space(3))) void*)(hdst + HPB + (s * NTHR + wave * 64) * 16), 16, 0, 0);
+      }
     }
   };
   auto load_halo_regs = [&](const ChunkSrc& c) {           // AFF: thread owns k-group myq of its slot pixels
@@ -231,7 +274,7 @@ __global__ __launch_bounds__(256 * WN, LEAN ? 3 : 1) void igemm2_fwd_kernel(cons
     }
     if (ch + 2 < d.nchunks) cnext = chunk_scalars(ch + 2);  // in flight during the MFMAs
     const unsigned char* lds_halo = smem + buf * BUFB;
-    const unsigned char* lds_w = lds_halo + HPB;
+    const unsigned char* lds_w = lds_halo + MP * HPB;
     if constexpr (LEAN) {
       if (!(dbg & 1)) {
 #pragma unroll
@@ -249,6 +292,36 @@ __global__ __launch_bounds__(256 * WN, LEAN ? 3 : 1) void igemm2_fwd_kernel(cons
           for (int mf = 0; mf < 4; ++mf)
 #pragma unroll
             for (int nf = 0; nf < NT; ++nf) mma16<T>(acc[mf][nf], fb1[nf], fa1[mf]);
+        }
+      }
+    } else if constexpr (MP > 1) {
+      if (!(dbg & 1)) {
+        // steps u = tap * 2 + tile: the pixel fragments of step u+1 (and, entering a new tap, its weight fragments) are requested
+        // before the MFMAs of step u
+        u32x4 fa[2][4], fb[2][NT];
+#pragma unroll
+        for (int mf = 0; mf < 4; ++mf) fa[0][mf] = *(const u32x4*)(lds_halo + a_addr[mf][0]);
+#pragma unroll
+        for (int nf = 0; nf < NT; ++nf) fb[0][nf] = *(const u32x4*)(lds_w + b_addr[nf]);
+#pragma unroll
+        for (int u = 0; u < TAPS * 2; ++u) {
+          const int t = u >> 1, mp = u & 1, cur = u & 1, nxt = cur ^ 1, wc = t & 1;
+          if (u + 1 < TAPS * 2) {
+            const int t1 = (u + 1) >> 1, mp1 = (u + 1) & 1;
+#pragma unroll
+            for (int mf = 0; mf < 4; ++mf) fa[nxt][mf] = *(const u32x4*)(lds_halo + mp1 * HPB + a_addr[mf][t1]);
+            if (mp1 == 0) {
+#pragma unroll
+              for (int nf = 0; nf < NT; ++nf) fb[wc ^ 1][nf] = *(const u32x4*)(lds_w + t1 * BN * 64 + b_addr[nf]);
+            }
+          }
+#pragma unroll
+          for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+            for (int nf = 0; nf < NT; ++nf) {
+              if (mp == 0) mma16<T>(acc[mf][nf], fb[wc][nf], fa[cur][mf]);
+              else mma16<T>(acc2[mf][nf], fb[wc][nf], fa[cur][mf]);
+            }
         }
       }
     } else if (!(dbg & 1)) {
@@ -288,7 +361,17 @@ __global__ __launch_bounds__(256 * WN, LEAN ? 3 : 1) void igemm2_fwd_kernel(cons
   const long long tm2 = __builtin_readcyclecounter();
   if (!(dbg & 4)) {
     // EX == false on the bf16 NT = 2 tile means the launcher proved the preconditions of the lean epilogue
-    if constexpr (!EX && NT == 2 && sizeof(T) == 2) igemm_epilogue_fast<WN>(d, acc, smem, tid, wm, g, l15, b, oy0, ox0, n0 + wn * BNW, P, ka.m_tw, wn, n0);
+    if constexpr (MP > 1) {
+      // (tile validity is workgroup-uniform: the barriers inside the statistics epilogue stay convergent)
+      if constexpr (!EX && NT == 2 && sizeof(T) == 2) {
+        igemm_epilogue_fast<WN>(d, acc, smem, tid, wm, g, l15, tb[0], toy[0], tox[0], n0 + wn * BNW, P, ka.m_tw, wn, n0, blockIdx.x * 2);
+        if (tvalid[1]) igemm_epilogue_fast<WN>(d, acc2, smem, tid, wm, g, l15, tb[1], toy[1], tox[1], n0 + wn * BNW, P, ka.m_tw, wn, n0, blockIdx.x * 2 + 1);
+      } else {
+        igemm_epilogue_direct<T, NT, EX, WN>(d, acc, smem, tid, wm, g, l15, tb[0], toy[0], tox[0], n0 + wn * BNW, P, ka.m_tw, wn, n0, blockIdx.x * 2);
+        if (tvalid[1])
+          igemm_epilogue_direct<T, NT, EX, WN>(d, acc2, smem, tid, wm, g, l15, tb[1], toy[1], tox[1], n0 + wn * BNW, P, ka.m_tw, wn, n0, blockIdx.x * 2 + 1);
+      }
+    } else if constexpr (!EX && NT == 2 && sizeof(T) == 2) igemm_epilogue_fast<WN>(d, acc, smem, tid, wm, g, l15, b, oy0, ox0, n0 + wn * BNW, P, ka.m_tw, wn, n0);
     else igemm_epilogue_direct<T, NT, EX, WN>(d, acc, smem, tid, wm, g, l15, b, oy0, ox0, n0 + wn * BNW, P, ka.m_tw, wn, n0);
   }
   if ((dbg & 8) && d.stats && tid == 0 && blockIdx.y == 0) {   // per-block phase timestamps (profiling only; clobbers stats)
@@ -324,14 +407,22 @@ int launch2(const ksmi_conv_desc* d, int dbg, hipStream_t st) {
   static const int wn_min = getenv("KSMI_WN_MIN") ? atoi(getenv("KSMI_WN_MIN")) : 64;
   const int wn = (!lean && !wn_off && nt == 2 && d->Npad >= wn_min && taps <= 9) ? 2 : 1;
   const int bn = nt * 16 * wn;
-  const dim3 grid(gm, (d->Npad + bn - 1) / bn);
+  const int gy = (d->Npad + bn - 1) / bn;
   const size_t hpb = ((size_t)HP * 64 + 1023) & ~(size_t)1023;
   // single-chunk convolutions (K <= 32 bf16 channels) need one stage only: 40 KB -> 3-4 workgroups per CU
   static const int stage_cap = getenv("KSMI_STAGES") ? atoi(getenv("KSMI_STAGES")) : 2;
   const int stages = (d->nchunks > 1 && stage_cap > 1) ? 2 : 1;
-  size_t lds = stages * (hpb + (size_t)taps * bn * 64);
-  if (lds < (size_t)4 * wn * 2 * (bn / wn) * sizeof(float)) lds = (size_t)4 * wn * 2 * (bn / wn) * sizeof(float);
   const bool aff = d->src[0].scale != nullptr;
+  // two pixel tiles per workgroup and weight slab (MP = 2): long-K 3x3 convolutions on the 8-wave tile with >= 256 output channels
+  // (ChangeFormer's 256-channel 224^2 / 112^2 layers: +1.8 % on its step; neutral to -0.5 % on SNUNet's 64..128-channel layers, which
+  // keep one tile), when the halved grid still gives every CU >= 1.5 workgroups and two stages of (2 halos + slab) fit 160 KB of LDS
+  static const bool mp_off = getenv("KSMI_IGEMM2_MP1") != nullptr;
+  static const int mp_min_k = getenv("KSMI_IGEMM2_MP_MINK") ? atoi(getenv("KSMI_IGEMM2_MP_MINK")) : 4;
+  const bool mp2 = !mp_off && sizeof(T) == 2 && wn == 2 && nt == 2 && !aff && stages == 2 && taps == 9 && d->nchunks >= mp_min_k &&
+                   2 * (2 * hpb + (size_t)taps * bn * 64) <= (size_t)160 * 1024 && gy >= 4 && (size_t)((gm + 1) / 2) * gy >= 384;
+  const dim3 grid(mp2 ? (gm + 1) / 2 : gm, gy);
+  size_t lds = stages * ((mp2 ? 2 : 1) * hpb + (size_t)taps * bn * 64);
+  if (lds < (size_t)4 * wn * 2 * (bn / wn) * sizeof(float)) lds = (size_t)4 * wn * 2 * (bn / wn) * sizeof(float);
   // epilogue extras (scale, residual, ReLU, strided placement) compile into a separate kernel: the common path stays lean
   bool extras = d->alpha != 0.f || d->resid != nullptr || d->relu_out != 0 || d->out_sy != 0 || d->in_sy != 0;
   if (sizeof(T) == 2 && nt == 2) {
@@ -354,6 +445,12 @@ int launch2(const ksmi_conv_desc* d, int dbg, hipStream_t st) {
     if (lds > 65536) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     hipLaunchKernelGGL(kfn, grid, dim3(256 * WN_), lds, st, ka);                                    \
   } while (0)
+#define KSMI_L2MP(NT_, KH_, KW_, EX_)                                                               \
+  do {                                                                                              \
+    auto kfn = igemm2_fwd_kernel<T, NT_, KH_, KW_, false, EX_, 2, false, 2>;                        \
+    if (lds > 65536) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL(kfn, grid, dim3(512), lds, st, ka);                                          \
+  } while (0)
 #define KSMI_L2LEAN(NT_, KH_, KW_, AFF_, EX_)                                                       \
   do {                                                                                              \
     auto kfn = igemm2_fwd_kernel<T, NT_, KH_, KW_, AFF_, EX_, 1, true>;                             \
@@ -362,7 +459,12 @@ int launch2(const ksmi_conv_desc* d, int dbg, hipStream_t st) {
 #define KSMI_L2X(NT_, KH_, KW_, AFF_, EX_)                                                          \
   do {                                                                                              \
     if constexpr (NT_ == 2 && KH_ * KW_ == 9) {                                                     \
-      if (lean) KSMI_L2LEAN(NT_, KH_, KW_, AFF_, EX_); else if (wn == 2) KSMI_L2W(NT_, KH_, KW_, AFF_, EX_, 2); else KSMI_L2W(NT_, KH_, KW_, AFF_, EX_, 1); \
+      if (lean) KSMI_L2LEAN(NT_, KH_, KW_, AFF_, EX_);                                              \
+      else if (wn == 2) {                                                                           \
+        bool done_ = false;                                                                         \
+        if constexpr (!AFF_ && sizeof(T) == 2) { if (mp2) { KSMI_L2MP(NT_, KH_, KW_, EX_); done_ = true; } } \
+        if (!done_) KSMI_L2W(NT_, KH_, KW_, AFF_, EX_, 2);                                          \
+      } else KSMI_L2W(NT_, KH_, KW_, AFF_, EX_, 1);                                                 \
     } else if constexpr (NT_ == 2 && KH_ * KW_ < 9) { if (wn == 2) KSMI_L2W(NT_, KH_, KW_, AFF_, EX_, 2); else KSMI_L2W(NT_, KH_, KW_, AFF_, EX_, 1); } \
     else KSMI_L2W(NT_, KH_, KW_, AFF_, EX_, 1);                                                     \
   } while (0)
@@ -384,6 +486,7 @@ int launch2(const ksmi_conv_desc* d, int dbg, hipStream_t st) {
 #undef KSMI_L2X
 #undef KSMI_L2W
 #undef KSMI_L2LEAN
+#undef KSMI_L2MP
   return ksmi_check_launch("igemm2_fwd");
 }
 

@@ -241,7 +241,7 @@ template <int NT> __device__ __forceinline__ int epi_col(int nf, int g) { return
 template <typename T, int NT, bool EX = true, int WN = 1>
 __device__ __forceinline__ void igemm_epilogue_direct(const ksmi_conv_desc& d, f32x4 (&acc)[4][NT], unsigned char* smem, int tid,
                                                       int wave, int g, int l15, int b, int oy0, int ox0, int n0, int P,
-                                                      uint32_t magic_tw = 0xffffffffu, int wn = 0, int n0wg = -1) {
+                                                      uint32_t magic_tw = 0xffffffffu, int wn = 0, int n0wg = -1, int stats_row = -1) {
   constexpr int BN = NT * 16;
   const FastDiv dTW = magic_tw != 0xffffffffu ? FastDiv(d.TW, magic_tw) : FastDiv(d.TW);
   size_t opix[4];
@@ -391,7 +391,8 @@ __device__ __forceinline__ void igemm_epilogue_direct(const ksmi_conv_desc& d, f
       const float* rg = red + (size_t)grp * 4 * 2 * BN;
       const float v = rg[(0 * 2 + which) * BN + n] + rg[(1 * 2 + which) * BN + n] + rg[(2 * 2 + which) * BN + n] + rg[(3 * 2 + which) * BN + n];
       const int nbase = n0wg >= 0 ? n0wg : n0;
-      if (nbase + nn < d.Npad) d.stats[((size_t)blockIdx.x * 2 + which) * d.Npad + nbase + nn] = v;
+      const size_t srow = stats_row >= 0 ? (size_t)stats_row : (size_t)blockIdx.x;     // (two tiles per workgroup: igemm2 MP = 2)
+      if (nbase + nn < d.Npad) d.stats[(srow * 2 + which) * d.Npad + nbase + nn] = v;
     }
   }
 }
@@ -406,7 +407,7 @@ __device__ __forceinline__ void igemm_epilogue_direct(const ksmi_conv_desc& d, f
 template <int WN>
 __device__ __forceinline__ void igemm_epilogue_fast(const ksmi_conv_desc& d, f32x4 (&acc)[4][2], unsigned char* smem, int tid,
                                                     int wave, int g, int l15, int b, int oy0, int ox0, int n0, int P,
-                                                    uint32_t magic_tw, int wn, int n0wg) {
+                                                    uint32_t magic_tw, int wn, int n0wg, int stats_row = -1) {
   typedef bf16_t T;
   constexpr int BN = 32;
   const FastDiv dTW(d.TW, magic_tw);
@@ -490,7 +491,8 @@ __device__ __forceinline__ void igemm_epilogue_fast(const ksmi_conv_desc& d, f32
       const int grp = nn / BN, n = nn - grp * BN;
       const float* rg = red + (size_t)grp * 4 * 2 * BN;
       const float v = rg[(0 * 2 + which) * BN + n] + rg[(1 * 2 + which) * BN + n] + rg[(2 * 2 + which) * BN + n] + rg[(3 * 2 + which) * BN + n];
-      if (n0wg + nn < d.Npad) d.stats[((size_t)blockIdx.x * 2 + which) * d.Npad + n0wg + nn] = v;
+      const size_t srow = stats_row >= 0 ? (size_t)stats_row : (size_t)blockIdx.x;
+      if (n0wg + nn < d.Npad) d.stats[(srow * 2 + which) * d.Npad + n0wg + nn] = v;
     }
   }
 }
