@@ -12,6 +12,7 @@
 //   forward      : wave = 16 queries, loops over the key tiles              -> out, lse
 //   backward (q) : wave = 16 queries: dq, delta = rowsum(dO * O)            -> dq, delta
 //   backward (kv): wave = 16 keys, loops over its query slab                -> dK, dV (fp32 partial per query split)
+#include <stdlib.h>
 #include "common.h"
 #include "../../include/ksmi.h"
 #include "errors.h"
@@ -57,29 +58,30 @@ template <int D> struct Geo {
 };
 
 // rows [0, nrows) x DP columns of a [.. ][rs] global matrix into LDS (zero beyond n_valid rows / D columns)
-template <int D>
+template <int D, int NTHR = 256>
 __device__ __forceinline__ void stage_rows(unsigned char* lds, const bf16_t* src, int rs, int nrows, int n_valid, int tid) {
   constexpr int DP = Geo<D>::DP, RS = Geo<D>::RS, VPR = DP / 8;
-  for (int i = tid; i < nrows * VPR; i += 256) {
+  for (int i = tid; i < nrows * VPR; i += NTHR) {
     const int row = i / VPR, c8 = i - row * VPR;
     *(u32x4*)(lds + row * RS + c8 * 16) = ld16(src + (size_t)row * rs + c8 * 8, row < n_valid && c8 * 8 < D);
   }
 }
 
 // ------------------------------------------------------------------------------------------------ forward
-template <int D, int NKT>
-__global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(AttnP p) {
+// NW waves per workgroup; the workgroup walks the query tiles blockIdx.x*NW + wave, + gridDim.x*NW, ... (ViT shape: ONE workgroup of
+// 8 waves per (b, h) stages K and V once for all 13 query tiles; the 4-wave grid of 64-query workgroups staged them 4 times)
+template <int D, int NKT, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void attn_mfma_fwd_kernel(AttnP p) {
   using G = Geo<D>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* Ks = smem;
   unsigned char* Vs = smem + NKT * 16 * G::RS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
   const int b = blockIdx.z, h = blockIdx.y;
-  stage_rows<D>(Ks, p.k + (size_t)b * p.Nk * p.k_rs + h * D, p.k_rs, NKT * 16, p.Nk, tid);
-  stage_rows<D>(Vs, p.v + (size_t)b * p.Nk * p.v_rs + h * D, p.v_rs, NKT * 16, p.Nk, tid);
+  stage_rows<D, 64 * NW>(Ks, p.k + (size_t)b * p.Nk * p.k_rs + h * D, p.k_rs, NKT * 16, p.Nk, tid);
+  stage_rows<D, 64 * NW>(Vs, p.v + (size_t)b * p.Nk * p.v_rs + h * D, p.v_rs, NKT * 16, p.Nk, tid);
   __syncthreads();
-  const int q0 = (blockIdx.x * 4 + wave) * 16;
-  if (q0 >= p.Nq) return;
+  for (int q0 = (blockIdx.x * NW + wave) * 16; q0 < p.Nq; q0 += gridDim.x * NW * 16) {
   const int qrow = q0 + l15;
   const bool qok = qrow < p.Nq;
   const bf16_t* qp = p.q + ((size_t)b * p.Nq + qrow) * p.q_rs + h * D;
@@ -136,7 +138,7 @@ __global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(AttnP p) {
 #pragma unroll
     for (int dt = 0; dt < G::DT; ++dt) O[dt] = mma16k(O[dt], tr4(Vs, kt * 16 + g * 4, G::RS, dt * 32, l15), pb);
   }
-  if (!qok) return;
+  if (!qok) continue;
   const float inv = 1.f / l;
   bf16_t* op = p.o + ((size_t)b * p.Nq + qrow) * p.o_rs + h * D;
 #pragma unroll
@@ -150,6 +152,7 @@ __global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(AttnP p) {
     }
   }
   if (g == 0 && p.lse) p.lse[((size_t)b * p.H + h) * p.Nq + qrow] = m + __logf(l);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dq, delta
@@ -357,6 +360,147 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kv_kernel(AttnP p, int kchu
   }
 }
 
+// ------------------------------------------------------------------------------------------------ backward, one workgroup per (b, h)
+// ViT shape (Nq = Nk <= 208, d = 64): Q, K, V and dO of one head fit the LDS together (4 x 30 KB), so the whole backward of a head is
+// one workgroup with no slab loop and no partial sums: phase A (waves over query tiles, S^T orientation) writes dq and delta, phase B
+// (waves over key tiles, S orientation) walks all query tiles from LDS and writes dk, dv.  One launch of B*H workgroups (256 for the
+// FloodViT batch = one per CU) replaces bwd_q + bwd_kv (+ finish): 71 -> ~25 us per layer.
+template <int D, int NKT>
+__global__ __launch_bounds__(512) void attn_mfma_bwd_fused_kernel(AttnP p) {
+  using G = Geo<D>;
+  constexpr int ROWS = NKT * 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* Ks = smem;
+  unsigned char* Vs = Ks + ROWS * G::RS;
+  unsigned char* Qs = Vs + ROWS * G::RS;
+  unsigned char* Gs = Qs + ROWS * G::RS;
+  float* Ls = (float*)(Gs + ROWS * G::RS);
+  float* Ds = Ls + ROWS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
+  const int b = blockIdx.y, h = blockIdx.x;
+  stage_rows<D, 512>(Ks, p.k + (size_t)b * p.Nk * p.k_rs + h * D, p.k_rs, ROWS, p.Nk, tid);
+  stage_rows<D, 512>(Vs, p.v + (size_t)b * p.Nk * p.v_rs + h * D, p.v_rs, ROWS, p.Nk, tid);
+  stage_rows<D, 512>(Qs, p.q + (size_t)b * p.Nq * p.q_rs + h * D, p.q_rs, ROWS, p.Nq, tid);
+  stage_rows<D, 512>(Gs, p.dout + (size_t)b * p.Nq * p.o_rs + h * D, p.o_rs, ROWS, p.Nq, tid);
+  for (int i = tid; i < ROWS; i += 512) Ls[i] = i < p.Nq ? p.lse[((size_t)b * p.H + h) * p.Nq + i] : 3.0e38f;   // exp(s - 3e38) = 0: padded queries
+  __syncthreads();
+  // ---- phase A: dq and delta, wave = query tile ------------------------------------------------------------------
+  for (int qt = wave; qt * 16 < p.Nq; qt += 8) {             // 8 waves: 13 tiles = at most 2 per wave
+    const int qrow = qt * 16 + l15;
+    const bool qok = qrow < p.Nq;
+    const bf16_t* op = p.o + ((size_t)b * p.Nq + qrow) * p.o_rs + h * D;
+    u32x4 Qf[G::KS], Gf[G::KS];
+    float dsum = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < G::KS; ++ks) {
+      const int off = qrow * G::RS + (ks * 32 + g * 8) * 2;
+      Qf[ks] = *(const u32x4*)(Qs + off);
+      Gf[ks] = *(const u32x4*)(Gs + off);
+      const u32x4 of = ld16(op + ks * 32 + g * 8, qok && ks * 32 + g * 8 < D);
+      float a[8], c[8];
+      vec_unpack<bf16_t>(Gf[ks], a);
+      vec_unpack<bf16_t>(of, c);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dsum += a[j] * c[j];
+    }
+    const float delta = xg_sum(dsum);
+    if (g == 0) Ds[qrow] = qok ? delta : 0.f;
+    const float lse = Ls[qrow];
+    f32x4 dQ[G::DT];
+#pragma unroll
+    for (int dt = 0; dt < G::DT; ++dt) dQ[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < G::KS; ++ks) {
+        const int off = (kt * 16 + l15) * G::RS + (ks * 32 + g * 8) * 2;
+        mma16<bf16_t>(s, *(const u32x4*)(Ks + off), Qf[ks]);            // S^T[key = g*4+r][q = l15]
+        mma16<bf16_t>(dp, *(const u32x4*)(Vs + off), Gf[ks]);
+      }
+      float ds[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool kok = kt * 16 + g * 4 + r < p.Nk;
+        const float pr = (kok && qok) ? __expf(s[r] * p.scale - lse) : 0.f;
+        ds[r] = pr * (dp[r] - delta) * p.scale;
+      }
+      const s16x4 db = pack4(ds[0], ds[1], ds[2], ds[3]);
+#pragma unroll
+      for (int dt = 0; dt < G::DT; ++dt) dQ[dt] = mma16k(dQ[dt], tr4(Ks, kt * 16 + g * 4, G::RS, dt * 32, l15), db);
+    }
+    if (qok) {
+      bf16_t* dqp = p.dq + ((size_t)b * p.Nq + qrow) * p.dq_rs + h * D;
+#pragma unroll
+      for (int dt = 0; dt < G::DT; ++dt) {
+        const int d0 = dt * 16 + g * 4;
+        if (d0 < D) {
+          uint2 w;
+          w.x = (uint32_t)f32_to_bf16(dQ[dt][0]) | ((uint32_t)f32_to_bf16(dQ[dt][1]) << 16);
+          w.y = (uint32_t)f32_to_bf16(dQ[dt][2]) | ((uint32_t)f32_to_bf16(dQ[dt][3]) << 16);
+          *(uint2*)(dqp + d0) = w;
+        }
+      }
+    }
+  }
+  __syncthreads();                                        // delta of every query is in LDS
+  // ---- phase B: dk and dv, wave = key tile -----------------------------------------------------------------------
+  for (int kt = wave; kt * 16 < p.Nk; kt += 8) {
+    const int key = kt * 16 + l15;
+    const bool kok = key < p.Nk;
+    u32x4 Kf[G::KS], Vf[G::KS];
+#pragma unroll
+    for (int ks = 0; ks < G::KS; ++ks) {
+      const int off = key * G::RS + (ks * 32 + g * 8) * 2;
+      Kf[ks] = *(const u32x4*)(Ks + off);
+      Vf[ks] = *(const u32x4*)(Vs + off);
+    }
+    f32x4 dK[G::DT], dV[G::DT];
+#pragma unroll
+    for (int dt = 0; dt < G::DT; ++dt) { dK[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dV[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll 1
+    for (int t = 0; t * 16 < p.Nq; ++t) {
+      f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < G::KS; ++ks) {
+        const int off = (t * 16 + l15) * G::RS + (ks * 32 + g * 8) * 2;
+        mma16<bf16_t>(s, *(const u32x4*)(Qs + off), Kf[ks]);          // S[q = g*4+r][key = l15]
+        mma16<bf16_t>(dp, *(const u32x4*)(Gs + off), Vf[ks]);
+      }
+      float pr[4], ds[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int qi = t * 16 + g * 4 + r;
+        pr[r] = kok ? __expf(s[r] * p.scale - Ls[qi]) : 0.f;
+        ds[r] = pr[r] * (dp[r] - Ds[qi]) * p.scale;
+      }
+      const s16x4 pb = pack4(pr[0], pr[1], pr[2], pr[3]), db = pack4(ds[0], ds[1], ds[2], ds[3]);
+#pragma unroll
+      for (int dt = 0; dt < G::DT; ++dt) {
+        dV[dt] = mma16k(dV[dt], tr4(Gs, t * 16 + g * 4, G::RS, dt * 32, l15), pb);
+        dK[dt] = mma16k(dK[dt], tr4(Qs, t * 16 + g * 4, G::RS, dt * 32, l15), db);
+      }
+    }
+    if (kok) {
+      bf16_t* dkp = p.dk + ((size_t)b * p.Nk + key) * p.dk_rs + h * D;
+      bf16_t* dvp = p.dv + ((size_t)b * p.Nk + key) * p.dv_rs + h * D;
+#pragma unroll
+      for (int dt = 0; dt < G::DT; ++dt) {
+        const int d0 = dt * 16 + g * 4;
+        if (d0 < D) {
+          uint2 w;
+          w.x = (uint32_t)f32_to_bf16(dK[dt][0]) | ((uint32_t)f32_to_bf16(dK[dt][1]) << 16);
+          w.y = (uint32_t)f32_to_bf16(dK[dt][2]) | ((uint32_t)f32_to_bf16(dK[dt][3]) << 16);
+          *(uint2*)(dkp + d0) = w;
+          w.x = (uint32_t)f32_to_bf16(dV[dt][0]) | ((uint32_t)f32_to_bf16(dV[dt][1]) << 16);
+          w.y = (uint32_t)f32_to_bf16(dV[dt][2]) | ((uint32_t)f32_to_bf16(dV[dt][3]) << 16);
+          *(uint2*)(dvp + d0) = w;
+        }
+      }
+    }
+  }
+}
+
 // dk/dv = sum over the query splits of the fp32 partials
 template <int D>
 __global__ void attn_kv_finish_kernel(AttnP p) {
@@ -444,10 +588,27 @@ int ksmi_attn_mfma_vit(int backward, const void* qkv, void* out, float* lse, con
   p.o = (bf16_t*)out; p.lse = lse;
   p.q_rs = p.k_rs = p.v_rs = C3; p.o_rs = H * 64;
   p.Nq = p.Nk = N; p.H = H; p.B = B; p.scale = scale;
-  if (!backward) return launch_fwd<64, 13>(p, (hipStream_t)stream);
+  if (!backward) {
+    // one 8-wave workgroup per head measured the same as the 64-query workgroups (FloodViT 1011 vs 1016 tiles/s): kept as a switch
+    static const bool one_wg = getenv("KSMI_ATTN_FWD_ONE_WG") != nullptr;
+    if (!one_wg) return launch_fwd<64, 13>(p, (hipStream_t)stream);
+    const size_t lds = 2 * (size_t)13 * 16 * Geo<64>::RS;
+    auto kfn = attn_mfma_fwd_kernel<64, 13, 8>;
+    set_lds(kfn, lds);
+    hipLaunchKernelGGL(kfn, dim3(1, H, B), dim3(512), lds, (hipStream_t)stream, p);
+    return ksmi_check_launch("attn_mfma_fwd");
+  }
   p.dout = (const bf16_t*)dout;
   p.dq = (bf16_t*)dqkv; p.dk = p.dq + H * 64; p.dv = p.dq + 2 * H * 64;
   p.dq_rs = p.dk_rs = p.dv_rs = C3;
+  static const bool split = getenv("KSMI_ATTN_SPLIT") != nullptr;      // A/B: the two-kernel backward
+  if (!split && lse) {
+    constexpr size_t lds = 4 * (size_t)13 * 16 * Geo<64>::RS + 2 * 13 * 16 * sizeof(float);
+    auto kfn = attn_mfma_bwd_fused_kernel<64, 13>;
+    set_lds(kfn, lds);
+    hipLaunchKernelGGL(kfn, dim3(H, B), dim3(512), lds, (hipStream_t)stream, p);
+    return ksmi_check_launch("attn_mfma_bwd_fused");
+  }
   fill_split(p, workspace);
   return launch_bwd<64, 13, false>(p, (hipStream_t)stream);
 }
