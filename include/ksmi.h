@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define KSMI_ABI_VERSION 1
+#define KSMI_ABI_VERSION 2   /* 2: round 2 (stats_rows, stochastic layers, bias_grad in ksmi_wgrad_desc, ...) */
 #define KSMI_F32 0
 #define KSMI_BF16 1
 #define KSMI_E_ARG (-1)
@@ -160,9 +160,14 @@ typedef struct ksmi_wgrad_desc {
   int32_t pad_x_set, pad_x;
   int32_t use_tap_off;
   int32_t tap_off[16];
+  /* optional fused bias gradient of a plain nn.Linear (1x1, one source): bias_grad[n] (+)= sum over rows of dY[row][n].  Only the
+   * launches for which ksmi_conv_wgrad_fuses_bias() returns 1 compute it (the token-GEMM weight gradient that writes the gradient
+   * in one split: dY is already in LDS there); otherwise the field is ignored and the caller runs ksmi_colsum. */
+  float* bias_grad; int32_t bias_accumulate;
 } ksmi_wgrad_desc;
 size_t ksmi_conv_wgrad_workspace(const ksmi_wgrad_desc* d, int dtype);
 int ksmi_conv_wgrad(const ksmi_wgrad_desc* d, int dtype, void* stream);
+int ksmi_conv_wgrad_fuses_bias(const ksmi_wgrad_desc* d, int dtype);
 
 /* First-layer 3x3 conv on the raw image (NCHW fp32, Cin <= 8 -> Cout = 32*k):
  * models/snunet.py:75 conv0_0.conv1.  Forward writes NHWC `dtype` + BN partial stats;

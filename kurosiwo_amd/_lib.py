@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libksmi.so")
 
 KSMI_F32, KSMI_BF16 = 0, 1
 MAX_SRC, MAX_CHUNKS = 6, 72
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class KsmiError(RuntimeError):
@@ -71,7 +71,8 @@ class WgradDesc(C.Structure):
                 ("chunk_c0", C.c_uint16 * MAX_CHUNKS), ("chunk_src", C.c_uint8 * MAX_CHUNKS),
                 ("uniform_kc", C.c_int32), ("k_total", C.c_int32),
                 ("in_sy", C.c_int32), ("in_sx", C.c_int32), ("in_oy", C.c_int32), ("in_ox", C.c_int32), ("in_H", C.c_int32), ("in_W", C.c_int32),
-                ("pad_x_set", C.c_int32), ("pad_x", C.c_int32), ("use_tap_off", C.c_int32), ("tap_off", C.c_int32 * 16)]
+                ("pad_x_set", C.c_int32), ("pad_x", C.c_int32), ("use_tap_off", C.c_int32), ("tap_off", C.c_int32 * 16),
+                ("bias_grad", C.c_void_p), ("bias_accumulate", C.c_int32)]
 
 
 _vp, _i, _i64, _f, _d, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_size_t
@@ -88,6 +89,7 @@ SIGNATURES = {
     "ksmi_pack_weights_batched": (_i, [_vp, _i, _i, _vp]),
     "ksmi_conv_wgrad_workspace": (_sz, [C.POINTER(WgradDesc), _i]),
     "ksmi_conv_wgrad": (_i, [C.POINTER(WgradDesc), _i, _vp]),
+    "ksmi_conv_wgrad_fuses_bias": (_i, [C.POINTER(WgradDesc), _i]),
     "ksmi_conv_stats_rows": (_i, [C.POINTER(ConvDesc), _i]),
     "ksmi_conv_first_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ksmi_conv_first_stats_rows": (_i, [_i, _i, _i]),

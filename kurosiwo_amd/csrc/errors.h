@@ -32,4 +32,5 @@ int ksmi_gemm2_nt(const void* x, int x_rs, const void* w, int w_rs, const float*
 int ksmi_gemm2_nn(const void* dy, int dy_rs, const void* w, int w_rs, void* dx, int dx_rs, int rows, int K, int N, int accumulate,
                   hipStream_t st);
 int ksmi_gemm2_tn(const void* x, int x_rs, const void* dy, int dy_rs, float* slab, int npad, float* grad, int64_t g_rs, int rows, int K, int N,
-                  int Kslab, int nsplit, int rows_per_split, int btile, int accumulate, hipStream_t st);
+                  int Kslab, int nsplit, int rows_per_split, int btile, int accumulate, float* bias_grad, int bias_accumulate, hipStream_t st);
+bool ksmi_gemm2_tn_enabled(int K, int N, int rows_per_split);

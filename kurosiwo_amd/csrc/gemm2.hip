@@ -286,6 +286,7 @@ struct Gemm2T {
   float* out; int64_t o_rs; int64_t split_stride; int accumulate;
   int rows, rows_per_split, atiles, btiles;
   const unsigned char* zero;
+  float* bias; int bias_acc;           // direct mode: bias[b column] (+)= sum over the rows of B (the nn.Linear bias gradient)
 };
 __device__ __attribute__((aligned(64))) unsigned char gemm2_zero_page[64];
 
@@ -362,11 +363,22 @@ __global__ __launch_bounds__(256, 1) void gemm2_tn_kernel(const Gemm2T p) {
   for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int b = 0; b < MT; ++b) { acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc2[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-  auto mma_all = [&](f32x4 (&ac)[4][MT], const u32x4 (&fa)[4], const u32x4 (&fb)[MT]) {
+  // bias gradient = column sums of the B side: one extra MFMA per B fragment against an all-ones A fragment, in the workgroups of
+  // A tile 0 and the waves of A-side group 0 only (the other waves hold the same B fragments)
+  const bool do_bias = p.bias != nullptr && at == 0 && wn == 0;
+  f32x4 accb[MT], accb2[MT];
+#pragma unroll
+  for (int b = 0; b < MT; ++b) { accb[b] = (f32x4){0.f, 0.f, 0.f, 0.f}; accb2[b] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  const u32x4 ones = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+  auto mma_all = [&](f32x4 (&ac)[4][MT], f32x4 (&ab)[MT], const u32x4 (&fa)[4], const u32x4 (&fb)[MT]) {
 #pragma unroll
     for (int b = 0; b < MT; ++b)
 #pragma unroll
       for (int a = 0; a < 4; ++a) mma16<bf16_t>(ac[a][b], fa[a], fb[b]);
+    if (do_bias) {
+#pragma unroll
+      for (int b = 0; b < MT; ++b) mma16<bf16_t>(ab[b], ones, fb[b]);
+    }
   };
   if (nsteps > 0) {
     const int pre = nsteps < NS ? nsteps : NS;
@@ -381,7 +393,7 @@ __global__ __launch_bounds__(256, 1) void gemm2_tn_kernel(const Gemm2T p) {
       __builtin_amdgcn_sched_barrier(0);
       load_frags(cur, 1, faB, fbB);
       __builtin_amdgcn_sched_barrier(0);
-      mma_all(acc, faA, fbA);
+      mma_all(acc, accb, faA, fbA);
       __builtin_amdgcn_sched_barrier(0);
       if (s + 2 < nsteps) vm_wait(NI); else vm_wait(0);
       lds_barrier();
@@ -389,12 +401,19 @@ __global__ __launch_bounds__(256, 1) void gemm2_tn_kernel(const Gemm2T p) {
       cur = cur + 1 == NS ? 0 : cur + 1;
       load_frags(cur, 0, faA, fbA);
       __builtin_amdgcn_sched_barrier(0);
-      mma_all(acc2, faB, fbB);
+      mma_all(acc2, accb2, faB, fbB);
       __builtin_amdgcn_sched_barrier(0);
     }
     load_frags(cur, 1, faB, fbB);
-    mma_all(acc, faA, fbA);
-    mma_all(acc2, faB, fbB);
+    mma_all(acc, accb, faA, fbA);
+    mma_all(acc2, accb2, faB, fbB);
+  }
+  if (do_bias && g == 0) {                                // every accumulator row holds the column sum: take row 0 (g = 0, r = 0)
+#pragma unroll
+    for (int b = 0; b < MT; ++b) {
+      const int bc = b0 + wm * 16 * MT + b * 16 + l15;
+      if (bc < p.b_cols) { const float v = accb[b][0] + accb2[b][0]; p.bias[bc] = p.bias_acc ? p.bias[bc] + v : v; }
+    }
   }
   // lane: 16 consecutive A-side columns (acc[a][.][r]: column g*16 + a*4 + r) of B-side column wm*16*MT + b*16 + l15
   const int ac0 = a0 + wn * 64 + g * 16;
@@ -438,12 +457,16 @@ int ksmi_gemm2_nn(const void* dy, int dy_rs, const void* w, int w_rs, void* dx, 
   return dispatch2<true>(p, st);
 }
 
+bool ksmi_gemm2_tn_enabled(int K, int N, int rows_per_split) {
+  static const bool off = getenv("KSMI_GEMM2_OFF") != nullptr || getenv("KSMI_GEMM2_TN_OFF") != nullptr;
+  return !(off || K % 8 || N % 8 || K < 64 || N < 64 || rows_per_split % 64);
+}
+
 // weight gradient of a plain nn.Linear: x [rows][K] (row stride x_rs), dy [rows][N]; `slab` = split partial sums [nsplit][K][Npad]
 // (n contiguous: the layout of tn_reduce_kernel), or nsplit = 1 and grad [N][g_rs] written directly.  0 launched / 1 not covered
 int ksmi_gemm2_tn(const void* x, int x_rs, const void* dy, int dy_rs, float* slab, int npad, float* grad, int64_t g_rs, int rows, int K, int N,
-                  int Kslab, int nsplit, int rows_per_split, int btile, int accumulate, hipStream_t st) {
-  static const bool off = getenv("KSMI_GEMM2_OFF") != nullptr || getenv("KSMI_GEMM2_TN_OFF") != nullptr;
-  if (off || K % 8 || N % 8 || K < 64 || N < 64 || rows_per_split % 64) return 1;
+                  int Kslab, int nsplit, int rows_per_split, int btile, int accumulate, float* bias_grad, int bias_accumulate, hipStream_t st) {
+  if (!ksmi_gemm2_tn_enabled(K, N, rows_per_split)) return 1;
   static void* zero_page = nullptr;
   if (!zero_page && hipGetSymbolAddress(&zero_page, HIP_SYMBOL(gemm2_zero_page)) != hipSuccess) return ksmi_fail(KSMI_E_UNSUPPORTED, "gemm2: zero page");
   Gemm2T p = {};
@@ -451,6 +474,7 @@ int ksmi_gemm2_tn(const void* x, int x_rs, const void* dy, int dy_rs, float* sla
   if (nsplit == 1 && grad) {        // direct: A = x (k contiguous in grad), B = dy
     p.a = (const bf16_t*)x; p.a_rs = x_rs; p.a_cols = K; p.b = (const bf16_t*)dy; p.b_rs = dy_rs; p.b_cols = N;
     p.out = grad; p.o_rs = g_rs; p.split_stride = 0; p.accumulate = accumulate;
+    p.bias = bias_grad; p.bias_acc = bias_accumulate;
   } else {                          // slabs: A = dy (n contiguous in the slab), B = x
     p.a = (const bf16_t*)dy; p.a_rs = dy_rs; p.a_cols = N; p.b = (const bf16_t*)x; p.b_rs = x_rs; p.b_cols = K;
     p.out = slab; p.o_rs = npad; p.split_stride = (int64_t)Kslab * npad; p.accumulate = 0;

@@ -841,7 +841,7 @@ int launch_wgrad(const ksmi_wgrad_desc* d, hipStream_t st) {
       const bool direct = plain && g.nsplit == 1;
       const int r2 = ksmi_gemm2_tn((const bf16_t*)d->src[0].ptr + d->src[0].c_off, d->src[0].C, (const bf16_t*)d->dy + d->dy_c_off, d->dyC, d->partial,
                                    g.npad, direct ? d->grad : nullptr, d->gN, rows, d->src[0].c_len, d->N, d->nchunks * g.kc, g.nsplit, g.rps,
-                                   g.tbt, d->accumulate, st);
+                                   g.tbt, d->accumulate, direct ? d->bias_grad : nullptr, d->bias_accumulate, st);
       if (r2 < 0) return r2;
       if (r2 == 0) {
         if (direct) return 0;
@@ -979,6 +979,20 @@ size_t ksmi_conv_wgrad_workspace(const ksmi_wgrad_desc* d, int dtype) {
   WgradGeom g = dtype == KSMI_BF16 ? wgrad_geom<bf16_t>(d) : wgrad_geom<float>(d);
   // caller reads nsplit back through the returned size: bytes = nsplit * slab
   return (size_t)g.nsplit * g.taps * d->nchunks * g.kc * g.npad * sizeof(float);
+}
+
+// 1: ksmi_conv_wgrad(d) also writes d->bias_grad (the token-GEMM path of gemm2.hip in its one-split, direct-write mode)
+int ksmi_conv_wgrad_fuses_bias(const ksmi_wgrad_desc* d, int dtype) {
+  if (!d || dtype != KSMI_BF16 || d->nsrc != 1) return 0;
+  static const bool lt = getenv("KSMI_USE_HIPBLASLT") != nullptr;
+  static const bool off = getenv("KSMI_NO_FUSED_BIAS_GRAD") != nullptr;
+  if (lt || off) return 0;
+  WgradGeom g = wgrad_geom<bf16_t>(d);
+  if (!g.tn || g.v3 || g.nsplit != 1) return 0;
+  bool plain = d->gK == 1 && (!d->use_tap_off || d->tap_off[0] == 0) && d->gN >= d->src[0].c_len && d->gN < ((int64_t)1 << 31);
+  if (plain && !d->uniform_kc)
+    for (int i = 0; i < d->nchunks; ++i) plain = plain && d->k_off[i] == i * g.kc;
+  return plain && ksmi_gemm2_tn_enabled(d->src[0].c_len, d->N, g.rps) ? 1 : 0;
 }
 
 int ksmi_conv_wgrad(const ksmi_wgrad_desc* d, int dtype, void* stream) {

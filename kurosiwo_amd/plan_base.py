@@ -165,8 +165,18 @@ class PlanBase:
         if want_w:
             dw, ws = make_wgrad([SrcSpec(x, Cin, k_real=kr)], dy, N, 0, N, self.m._g(wkey), 1, kr, 0, self._acc_param(wkey),
                                 1, rows, 1, rows, 1, 1, 1, 1, 0, self.dtype)
+            fused = False
+            if bkey:       # the bias gradient rides on the weight-gradient GEMM when that launch holds dY in LDS anyway (gemm2.hip, direct mode)
+                dw.bias_grad = self.m._g(bkey).data_ptr()
+                fused = bool(self.lib.ksmi_conv_wgrad_fuses_bias(C.byref(dw), self.dt))
+                if fused:
+                    dw.bias_accumulate = self._acc_param(bkey)
+                else:
+                    dw.bias_grad = None
             self._wgrad(dw, ws, wkey)
-            if bkey:
+            if bkey and fused:
+                self._mark(bkey)
+            elif bkey:
                 self._bias_grad(dy, rows, N, bkey)
 
     # ---------------------------------------------------------------- nn.LayerNorm
