@@ -71,7 +71,7 @@ __device__ __forceinline__ void stage_rows(unsigned char* lds, const bf16_t* src
 // NW waves per workgroup; the workgroup walks the query tiles blockIdx.x*NW + wave, + gridDim.x*NW, ... (ViT shape: ONE workgroup of
 // 8 waves per (b, h) stages K and V once for all 13 query tiles; the 4-wave grid of 64-query workgroups staged them 4 times)
 template <int D, int NKT, int NW = 4>
-__global__ __launch_bounds__(64 * NW) void attn_mfma_fwd_kernel(AttnP p) {
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_mfma_fwd_kernel(AttnP p) {   // 4 waves: <= 256 VGPRs, two workgroups per CU
   using G = Geo<D>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* Ks = smem;

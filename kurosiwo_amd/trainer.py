@@ -53,8 +53,37 @@ class _PlanTrainStep:
         if on:
             t.end()
 
+    # ---- HIP graph: the step is a static launch list on one stream (no allocation, no host sync, device-side step counters and
+    # random-stream state), so it can be captured once and replayed -- the CPU then issues ONE graph launch per step instead of
+    # several hundred ctypes calls.  Single-GPU only (the RCCL bucket hooks stay eager); the learning rate is baked at capture time
+    # and a change re-captures.
+    _graph = None
+
+    def capture_graph(self):
+        if self.world > 1:
+            raise _lib.KsmiError("graph capture of the train step is single-GPU (the bucketed all-reduce hooks run eagerly)")
+        if self.timer is not None:
+            raise _lib.KsmiError("graph capture with a kernel timer attached")
+        self._graph = None
+        self.run()                                   # warm-up: lazy attribute / symbol look-ups happen outside the capture
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._run_eager()
+        self._graph, self._graph_lr = g, self.optimizer.param_groups[0]["lr"]
+        return self
+
     def run(self):
         """One train step on the batch currently resident in the plan's input buffers."""
+        if self._graph is not None and self.timer is None:
+            if self.optimizer.param_groups[0]["lr"] != self._graph_lr:
+                self.capture_graph()
+                return
+            self._graph.replay()
+            return
+        self._run_eager()
+
+    def _run_eager(self):
         p, lib, st = self.plan, self.lib, stream_ptr()
         t = self.timer
         p.packs.run(t)

@@ -51,9 +51,15 @@ def main():
     mbusy = counter(mdb[0], "SQ_VALU_MFMA_BUSY_CYCLES") if mdb else {}
     gui = counter(mdb[0], "GRBM_GUI_ACTIVE") if mdb else {}
     tot = sum(t[2] for t in times)
+    passes = ["`rocprofv3 --kernel-trace --stats`"]
+    if fetch or write:
+        passes.append("separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes")
+    if mbusy:
+        passes.append("a `--pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE` pass")
     lines = ["# rocprofv3 summary: " + prefix, "", note, "",
-             "`rocprofv3 --kernel-trace --stats` (+ separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes) of",
-             "`" + cmd + ".  Plan construction (buffer zero fills) is included in the trace and excluded from the bench timing.", "",
+             " + ".join(passes) + " of `" + cmd.rstrip("`") + "` (tools/profile.sh, tools/profile_all.sh).  Plan construction (buffer zero",
+             "fills, weight packing tables) is part of the traced process and excluded from the bench timing; empty columns = counter pass not",
+             "collected for this model.", "",
              f"total kernel time {tot:.1f} ms over all dispatches", "",
              "| kernel | calls | total ms | avg us | % | FETCH_SIZE avg KB (raw) | x2 corrected MB | WRITE_SIZE avg KB (raw) | MFMA busy % |",
              "|---|---|---|---|---|---|---|---|---|"]
