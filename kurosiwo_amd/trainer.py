@@ -16,7 +16,7 @@ class _PlanTrainStep:
     """zero_grad -> forward -> criterion -> backward (+ bucketed all-reduce) -> optimizer.step over a model plan."""
 
     def __init__(self, model, plan, B, H, W, loss_function="ce+dice", class_weights=(1.0, 1.0, 1.0), optimizer=None, lr=1e-3,
-                 bucket_mb=8.0, group=None):
+                 bucket_mb=8.0, group=None, graph=False):
         if loss_function not in ("ce+dice", "cross_entropy"):
             raise NotImplementedError(loss_function)
         self.model = model
@@ -36,6 +36,7 @@ class _PlanTrainStep:
         buckets = make_buckets(ready, model._poff, None, n, int(bucket_mb * 1e6 / 4))
         self.reducer = BucketedAllReduce(model.flat_grads, buckets, group)
         self.timer = None          # optional kernel timer (bench.py)
+        self.use_graph = bool(graph) and self.world == 1     # replay the step as one captured HIP graph (configs["hip_graph"])
 
     def _set_inputs(self, *inputs):
         raise NotImplementedError
@@ -65,7 +66,7 @@ class _PlanTrainStep:
         if self.timer is not None:
             raise _lib.KsmiError("graph capture with a kernel timer attached")
         self._graph = None
-        self.run()                                   # warm-up: lazy attribute / symbol look-ups happen outside the capture
+        self._run_eager()                            # warm-up: lazy attribute / symbol look-ups happen outside the capture
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
@@ -80,6 +81,9 @@ class _PlanTrainStep:
                 self.capture_graph()
                 return
             self._graph.replay()
+            return
+        if getattr(self, "use_graph", False) and self.timer is None:
+            self.capture_graph()                     # first step: one eager step + the capture
             return
         self._run_eager()
 

@@ -30,6 +30,8 @@ parser.add_argument("--slope", action="store_true", default=False)
 parser.add_argument("--batch_size", default=None)
 parser.add_argument("--inputs", nargs="+", default=None)
 parser.add_argument("--seed", type=int, default=999)
+parser.add_argument("--hip_graph", action="store_true", default=False,
+                    help="replay the fused train step as one captured HIP graph (single GPU; kurosiwo_amd/trainer.py)")
 
 
 def main(argv=None):
@@ -46,6 +48,8 @@ def main(argv=None):
         model_configs["backbone"] = args.backbone
     configs.update(model_configs)
     configs = update_config(configs, args)          # (the reference drops --dem without --inputs: main.py:66-69 bug, not kept)
+    if args.hip_graph:
+        configs["hip_graph"] = True
     # data parallelism: under `python -m torch.distributed.run --nproc-per-node N main.py ...` every process joins
     # the RCCL group, uses cuda:LOCAL_RANK and trains on its contiguous shard of each global batch (kurosiwo_amd/distributed.py)
     rank, local_rank, world = init_distributed(configs)

@@ -54,3 +54,20 @@ def test_graph_replay_equals_eager_steps(family):
     l1 = s1.step(xA.cuda(), xB.cuda(), y.cuda()).clone()
     l2 = s2.step(xA.cuda(), xB.cuda(), y.cuda()).clone()
     assert torch.equal(l1, l2) and torch.equal(m1.flat_params, m2.flat_params)
+
+
+def test_main_entry_with_hip_graph(tmp_path, monkeypatch):
+    """main.py --hip_graph: the trainer replays the captured step; same final mIoU as the eager run on the same synthetic set."""
+    import os
+    import shutil
+    import main as entry
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = []
+    for flag in ([], ["--hip_graph"]):
+        wd = tmp_path / ("g" if flag else "e")
+        wd.mkdir()
+        shutil.copytree(os.path.join(root, "configs"), wd / "configs")
+        monkeypatch.chdir(wd)
+        monkeypatch.setenv("KSMI_SYNTHETIC_TILES", "8,4,4")
+        res.append(entry.main(["--method", "snunet", "--inputs", "pre_event_1", "post_event", "--batch_size", "4"] + flag))
+    assert res[0] == res[1], res
