@@ -22,9 +22,13 @@ def initialize_cd_model(configs, model_configs, phase="train"):
         cls = SiamUnet_conc if method == "siam-conc" else SiamUnet_diff
         model = cls(input_nbr=configs["num_channels"], label_nbr=configs["num_classes"],
                     precision=configs.get("precision", "bf16" if configs.get("mixed_precision") else "fp32"))
+    elif method == "bit-cd":                               # model_utilities.py:191-192: define_G(model_configs, in_channels)
+        from .bitcd import define_G
+        model = define_G(model_configs, in_channels=configs["num_channels"],
+                         precision=configs.get("precision", "bf16" if configs.get("mixed_precision") else "fp32"))
     else:
         raise _lib.KsmiError(f"method {method!r} has no HIP implementation (change-detection methods in scope: snunet, changeformer, "
-                             "siam-conc, siam-diff)")
+                             "siam-conc, siam-diff, bit-cd)")
     model = model.to(configs["device"])
     if configs.get("resume_checkpoint"):
         ck = torch.load(configs["resume_checkpoint"], map_location=configs["device"])

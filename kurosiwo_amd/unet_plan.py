@@ -174,7 +174,7 @@ class UnetPlan(ChangeFormerPlan):
                 self._bn_plain_bwd(f"{k}.downsample.1", dout, ds, svd, dds, npix, Cout)
                 self._wg([SrcSpec(x_in, Cin)], dds, Cout, f"{k}.downsample.0.weight", H, W, Ho, Wo, 1, stride, 0, Cin)
                 d, table = make_conv([SrcSpec(dds, Cout)], [(dx, Cin, 0, 0, Cin, 1)], dx, None, None, B, Ho, Wo, Ho, Wo, 1, 1, 1, 0, Cin, self.dtype,
-                                     out_map=(stride, stride, 0, 0, H, W))
+                                     out_map=(stride, stride, 0, 0, H, W) if stride != 1 else None)   # (stride 1: BIT-CD's layer3 / layer4)
                 d.wpk = self._packed(f"{k}.downsample.0.weight", table, 1, Cin, Cin, Cin, 1, 0, 0).data_ptr()
                 self._conv(self.bwd, d, "dgrad_1x1s2", f"{k}.downsample")
             else:

@@ -630,6 +630,50 @@ def gen_fcsiam():
         np.savez_compressed(os.path.join(OUT, f"fcsiam_{tag}.npz"), **out)
 
 
+def gen_bitcd():
+    """BIT-CD as shipped (configs/method/bit-cd/bit_cd.json: net_G = base_resnet18): the REFERENCE `define_G` network (models/bit_cd.py imports
+    with torch + einops alone), seeded weights, eval output and one train-mode step (loss, gradient statistics, BatchNorm running stats)."""
+    from models.bit_cd import define_G
+    c, B, S = 2, 2, 64
+    out = {}
+    model = define_G({"net_G": "base_resnet18", "init_type": "normal", "init_gain": 0.02}, c)
+    seeded_fill_(model.state_dict())
+    sd = model.state_dict()
+    out["state_dict_keys"] = np.array(list(sd.keys()))
+    out["state_dict_shapes"] = np.array([",".join(str(d) for d in v.shape) for v in sd.values()])
+    x1 = sar_like("bitcd.eval.x1", (1, c, S, S))
+    x2 = sar_like("bitcd.eval.x2", (1, c, S, S))
+    model.eval()
+    with torch.no_grad():
+        out["eval.out"] = model(x1, x2).numpy().copy()
+    model.train()
+    x1 = sar_like("bitcd.train.x1", (B, c, S, S))
+    x2 = sar_like("bitcd.train.x2", (B, c, S, S))
+    lbl = seeded_labels("bitcd.train.lbl", (B, S, S))
+    crit = BCEandDiceLoss(weights=CLASS_WEIGHTS, ignore_index=3, use_softmax=True)
+    o = model(x1, x2)
+    loss = crit(o, lbl)
+    loss.backward()
+    out["train.out"] = o.detach().numpy().copy()
+    out["train.loss"] = np.array(float(loss.detach()))
+    for k, p in model.named_parameters():
+        if p.grad is None:
+            out[f"gstat.{k}"] = np.zeros(3)
+            continue
+        g = p.grad.detach().double()
+        out[f"gstat.{k}"] = np.array([float(g.norm()), float(g.sum()), float(g.abs().max())])
+        if k in ("resnet.conv1.weight", "resnet.layer2.0.downsample.0.weight", "resnet.bn1.weight", "classifier.0.weight", "classifier.3.weight",
+                 "classifier.3.bias", "conv_pred.bias", "resnet.layer3.0.bn2.bias"):
+            out[f"grad.{k}"] = p.grad.detach().numpy().copy()
+    sd = model.state_dict()
+    for k in ("resnet.bn1", "resnet.layer2.0.downsample.1", "resnet.layer4.1.bn2", "classifier.1"):
+        out[f"bn.{k}.running_mean"] = sd[f"{k}.running_mean"].numpy().copy()
+        out[f"bn.{k}.running_var"] = sd[f"{k}.running_var"].numpy().copy()
+        out[f"bn.{k}.num_batches_tracked"] = sd[f"{k}.num_batches_tracked"].numpy().copy()
+    print("bitcd train loss", float(loss.detach()), "keys", len(sd))
+    np.savez_compressed(os.path.join(OUT, "bitcd.npz"), **out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -653,5 +697,7 @@ if __name__ == "__main__":
         gen_changeformer_drop()
     if not only or "fcsiam" in only:
         gen_fcsiam()
+    if not only or "bitcd" in only:
+        gen_bitcd()
     if not only or "mae" in only:
         gen_mae()
