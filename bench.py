@@ -116,7 +116,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--model", default="snunet", choices=["snunet", "floodvit", "changeformer", "unet", "mae"],
+    ap.add_argument("--model", default="snunet", choices=["snunet", "floodvit", "changeformer", "unet", "mae", "siam-conc", "siam-diff", "bit-cd"],
                     help="snunet = BASELINE.json configs[1] (the headline); changeformer = configs[3] (bs 32); "
                          "floodvit = configs[4] per-GPU shard (bs 16)")
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (weak scaling); default 32 snunet/changeformer, 16 floodvit")
@@ -177,6 +177,26 @@ def main():
         workload = (f"BASELINE.json configs[3]: ChangeFormerV6 CD (embed 256), 2 dates x {args.channels}-ch {'SLC' if args.channels == 4 else 'GRD'} 224x224, "
                     f"per-GPU batch {B}, ce+dice on the sigmoid map, SGD(0.99, wd 1e-5), fwd+loss+bwd+optimizer")
         metric = "SAR tiles/sec (224x224, ChangeFormerV6 change-detection train step)"
+    elif args.model in ("siam-conc", "siam-diff", "bit-cd"):
+        # the other siamese change-detection baselines of the reference with their shipped method configs
+        from kurosiwo_amd.trainer import CDTrainStep
+        if args.model == "bit-cd":
+            from kurosiwo_amd.bitcd import define_G
+            from kurosiwo_amd.optim import FusedSGD
+            model = define_G({"net_G": "base_resnet18"}, args.channels, precision=args.precision).to(dev).train()
+            opt = FusedSGD(model.parameters(), lr=1e-5, momentum=0.9, weight_decay=5e-4)       # configs/method/bit-cd/bit_cd.json
+            desc = "BIT-CD (net_G base_resnet18: siamese ResNet-18 + difference head), SGD(0.9, wd 5e-4)"
+        else:
+            from kurosiwo_amd.fcsiam import SiamUnet_conc, SiamUnet_diff
+            from kurosiwo_amd.optim import FusedAdam
+            model = (SiamUnet_conc if args.model == "siam-conc" else SiamUnet_diff)(args.channels, 3, precision=args.precision).to(dev).train()
+            opt = FusedAdam(model.parameters(), lr=1e-5)                                         # configs/method/siam-conc/siam_conc.json
+            desc = f"FC-{args.model} (Dropout2d 0.2 on), Adam 1e-5"
+        step = CDTrainStep(model, B, H, W, loss_function="ce+dice", optimizer=opt, bucket_mb=8.0)
+        (xA, xB), mask = cd_inputs(batch, ("pre_event_1", "post_event"))
+        step.set_batch(xA.to(dev), xB.to(dev), mask.to(dev))
+        workload = f"SURVEY.md §8(f) N2: {desc}, 2 dates x {args.channels}-ch 224x224, per-GPU batch {B}, ce+dice, fwd+loss+bwd+optimizer"
+        metric = f"SAR tiles/sec (224x224, {args.model} change-detection train step)"
     elif args.model == "unet":
         from kurosiwo_amd.trainer import SegTrainStep
         from kurosiwo_amd.unet import Unet

@@ -5,7 +5,7 @@ TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $R/gpurun_out
 python $R/bench.py > $R/gpurun_out/${TAG}_bench_snunet.json 2> $R/gpurun_out/${TAG}_bench.err
-for m in changeformer floodvit unet mae; do python $R/bench.py --model $m --no-cpu-baseline > $R/gpurun_out/${TAG}_bench_$m.json 2>> $R/gpurun_out/${TAG}_bench.err; done
+for m in changeformer floodvit unet mae siam-conc siam-diff bit-cd; do python $R/bench.py --model $m --no-cpu-baseline > $R/gpurun_out/${TAG}_bench_$m.json 2>> $R/gpurun_out/${TAG}_bench.err; done
 python $R/bench.py --model changeformer --channels 4 --no-cpu-baseline > $R/gpurun_out/${TAG}_bench_changeformer_slc.json 2>> $R/gpurun_out/${TAG}_bench.err
 bash $R/tools/profile.sh ${TAG} > $R/gpurun_out/prof_${TAG}.log 2>&1
 cd /tmp && export TMPDIR=/tmp
