@@ -209,15 +209,23 @@ __global__ void bnrelu_bwd_reduce_kernel(const T* dout, const T* out, const T* z
     for (int j = 0; j < VEC; ++j) { mu[j] = mean[w.cv * VEC + j]; rs[j] = rstd[w.cv * VEC + j]; }
     const int64_t per = (npix + gridDim.x - 1) / gridDim.x;
     const int64_t p0 = per * blockIdx.x, p1 = min(npix, p0 + per);
-    for (int64_t p = p0 + w.pl; p < p1; p += w.npl) {
-      const int64_t off = p * C + w.cv * VEC;
+    // two pixels per trip: six 16-byte loads in flight per lane (the grid is only 2 workgroups per CU)
+    for (int64_t p = p0 + w.pl; p < p1; p += 2 * w.npl) {
+      const bool two = p + w.npl < p1;
+      const int64_t off0 = p * C + w.cv * VEC, off1 = two ? off0 + (int64_t)w.npl * C : off0;
+      const u32x4 rg0 = *(const u32x4*)(dout + off0), ro0 = *(const u32x4*)(out + off0), rz0 = *(const u32x4*)(z + off0);
+      const u32x4 rg1 = *(const u32x4*)(dout + off1), ro1 = *(const u32x4*)(out + off1), rz1 = *(const u32x4*)(z + off1);
       float g[VEC], o[VEC], zz[VEC];
-      vec_unpack<T>(*(const u32x4*)(dout + off), g);
-      vec_unpack<T>(*(const u32x4*)(out + off), o);
-      vec_unpack<T>(*(const u32x4*)(z + off), zz);
+      vec_unpack<T>(rg0, g); vec_unpack<T>(ro0, o); vec_unpack<T>(rz0, zz);
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
         const float gg = o[j] > 0.f ? g[j] : 0.f;
+        acc[j] += gg; acc[VEC + j] += gg * (zz[j] - mu[j]) * rs[j];
+      }
+      vec_unpack<T>(rg1, g); vec_unpack<T>(ro1, o); vec_unpack<T>(rz1, zz);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const float gg = (two && o[j] > 0.f) ? g[j] : 0.f;
         acc[j] += gg; acc[VEC + j] += gg * (zz[j] - mu[j]) * rs[j];
       }
     }
@@ -270,23 +278,31 @@ __global__ void bn_bwd_apply_add_kernel(T* r, const T* g, const T* iv, const flo
     }
     const int64_t per = (npix + gridDim.x - 1) / gridDim.x;
     const int64_t p0 = per * blockIdx.x, p1 = min(npix, p0 + per);
-    for (int64_t p = p0 + w.pl; p < p1; p += w.npl) {
-      const int64_t off = p * C + w.cv * VEC;
-      float rr[VEC], gg[VEC], ii[VEC];
-      vec_unpack<T>(*(const u32x4*)(r + off), rr);
-      vec_unpack<T>(*(const u32x4*)(g + off), gg);
-      vec_unpack<T>(*(const u32x4*)(iv + off), ii);
+    for (int64_t p = p0 + w.pl; p < p1; p += 2 * w.npl) {   // two pixels per trip, all six loads issued before the first store
+      const bool two = p + w.npl < p1;
+      const int64_t offs[2] = {p * C + w.cv * VEC, two ? (p + w.npl) * C + w.cv * VEC : p * C + w.cv * VEC};
+      u32x4 raw[2][3];
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) {
-        const float xh = (ii[j] - mu[j]) * rs[j];
-        const float di = gg[j] + gr[j] * (rr[j] - k0[j] - xh * k1[j]);
-        rr[j] = di;
+      for (int u = 0; u < 2; ++u) {
+        raw[u][0] = *(const u32x4*)(r + offs[u]); raw[u][1] = *(const u32x4*)(g + offs[u]); raw[u][2] = *(const u32x4*)(iv + offs[u]);
       }
-      const u32x4 pk = vec_pack<T>(rr);
-      *(u32x4*)(r + off) = pk;
-      vec_unpack<T>(pk, rr);                 // bias gradient sums what the next kernels will read
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) acc[j] += rr[j];
+      for (int u = 0; u < 2; ++u) {
+        if (u == 1 && !two) break;
+        float rr[VEC], gg[VEC], ii[VEC];
+        vec_unpack<T>(raw[u][0], rr); vec_unpack<T>(raw[u][1], gg); vec_unpack<T>(raw[u][2], ii);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          const float xh = (ii[j] - mu[j]) * rs[j];
+          const float di = gg[j] + gr[j] * (rr[j] - k0[j] - xh * k1[j]);
+          rr[j] = di;
+        }
+        const u32x4 pk = vec_pack<T>(rr);
+        *(u32x4*)(r + offs[u]) = pk;
+        vec_unpack<T>(pk, rr);                 // bias gradient sums what the next kernels will read
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] += rr[j];
+      }
     }
   }
   block_channel_reduce<1, VEC>(acc, w, CV, C, partial, blockIdx.x);
