@@ -12,6 +12,12 @@ LN_EPS = 1e-5
 
 
 class PlanBase:
+    # Weight-gradient launches may run on the train step's side lane (trainer.py overlap_wgrad) only in plans where (a) every user of
+    # the "wgrad" scratch goes through _wgrad (true here: the lane keeps them in order) and (b) no operand of a weight gradient is
+    # rewritten by a later launch of the same backward pass.  (b) holds for the convolutional plans, whose activations and gradients
+    # are dedicated buffers; the token plans (ChangeFormer encoder, FloodViT, MAE) recycle their per-block gradient buffers.
+    side_wgrad = False
+
     def _init_base(self, model, dtype, with_backward):
         self.m, self.dtype, self.with_backward = model, dtype, with_backward
         self.dev = model.flat_params.device
@@ -109,6 +115,8 @@ class PlanBase:
         pin, pout = d.B * d.Hin * d.Win, d.B * d.Hout * d.Wout
         meta = {"kind": f"igemm_wgrad<{d.KH}x{d.KW}s{d.stride}>", "bytes": (pin * ktot + pout * d.N) * es + taps * ktot * d.N * 4,
                 "flops": 2 * pout * d.N * ktot * taps, "tag": f"{key} K={ktot} N={d.N} M={pout}"}
+        if self.side_wgrad:
+            meta["side"] = True              # snunet_plan.LaunchList.run: eligible for the side lane
         self.bwd.add("ksmi_conv_wgrad", lambda: (C.byref(d), self.dt), meta)
         self._mark(key)
 

@@ -29,19 +29,49 @@ class LaunchList:
     def resolve(self, lib):
         self.calls = [(getattr(lib, name), tuple(argfn()), name, meta) for name, argfn, meta in self.pending]
 
-    def run(self, timer=None, hook=None):
+    def run(self, timer=None, hook=None, side=None):
+        """side = SideLane or None.  Launches whose meta carries "side" (the weight gradients: nothing on the critical path of the
+        backward pass reads them) go to the lane's stream behind an event recorded on the main stream at that point of the list, so
+        they fill the machine next to the bandwidth-bound BatchNorm / elementwise launches that follow on the main stream; the
+        caller joins the lane (SideLane.join) before anything reads the gradients."""
         st = stream_ptr()
         for idx, (fn, args, name, meta) in enumerate(self.calls):
             timed = timer is not None and timer.wants(meta["kind"])
             if timed:
                 timer.begin(meta["kind"], meta)
-            rc = fn(*args, st)
+            if side is not None and not timed and meta.get("side"):     # (a timed launch is bracketed by events on the main stream)
+                rc = fn(*args, side.fork())
+            else:
+                rc = fn(*args, st)
             if timed:
                 timer.end()
             if rc != 0:
                 _lib.check(rc, name)
             if hook is not None:
                 hook(idx)
+
+
+class SideLane:
+    """A second HIP stream for launches off the critical path (see LaunchList.run).  fork(): the lane waits for everything issued so
+    far on the current stream and returns its stream pointer; join(): the current stream waits for the lane.  Both are plain event
+    record / wait pairs, so a step that uses the lane still captures into one HIP graph (fork / join become graph edges)."""
+
+    def __init__(self, device):
+        self.stream = torch.cuda.Stream(device=device)       # (a high-priority lane measured the same)
+        self.ptr = C.c_void_p(self.stream.cuda_stream)
+        self.used = False
+
+    def fork(self):
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self.stream.wait_event(ev)
+        self.used = True
+        return self.ptr
+
+    def join(self):
+        if self.used:
+            torch.cuda.current_stream().wait_stream(self.stream)
+            self.used = False
 
 
 class _Saved:
@@ -204,6 +234,7 @@ class SNUNetPlan:
         meta = {"kind": f"igemm_wgrad<{d.KH}x{d.KW}s{d.stride}>", "bytes": (pin * ktot + pout * d.N) * es + taps * ktot * d.N * 4,
                 "flops": 2 * pout * d.N * ktot * taps}
         meta["tag"] = f"{keys[0] if keys else '?'} K={ktot} N={d.N} {d.Hout}x{d.Wout}"
+        meta["side"] = True                  # off the critical path: eligible for the side lane (LaunchList.run)
         self.bwd.add("ksmi_conv_wgrad", lambda: (C.byref(d), self.dt), meta)
         self._mark(*keys)
 

@@ -3,6 +3,8 @@
 criterion -> backward -> optimizer.step) as one launch sequence on one stream, with the
 data-parallel gradient reduction of kurosiwo_amd/dp.py overlapped with backward.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -16,7 +18,7 @@ class _PlanTrainStep:
     """zero_grad -> forward -> criterion -> backward (+ bucketed all-reduce) -> optimizer.step over a model plan."""
 
     def __init__(self, model, plan, B, H, W, loss_function="ce+dice", class_weights=(1.0, 1.0, 1.0), optimizer=None, lr=1e-3,
-                 bucket_mb=8.0, group=None, graph=False):
+                 bucket_mb=8.0, group=None, graph=False, overlap_wgrad=True):
         if loss_function not in ("ce+dice", "cross_entropy"):
             raise NotImplementedError(loss_function)
         self.model = model
@@ -37,9 +39,29 @@ class _PlanTrainStep:
         self.reducer = BucketedAllReduce(model.flat_grads, buckets, group)
         self.timer = None          # optional kernel timer (bench.py)
         self.use_graph = bool(graph) and self.world == 1     # replay the step as one captured HIP graph (configs["hip_graph"])
+        self.overlap_wgrad = bool(overlap_wgrad) and os.environ.get("KSMI_OVERLAP_WGRAD", "1") != "0"
 
     def _set_inputs(self, *inputs):
         raise NotImplementedError
+
+    # ---- side lane: the weight-gradient launches of the backward pass run on a second stream (snunet_plan.SideLane) next to the
+    # bandwidth-bound BatchNorm launches of the critical path.  overlap_wgrad=False / KSMI_OVERLAP_WGRAD=0 switch it off.
+    _side = None
+
+    def _lane(self):
+        if not self.overlap_wgrad:
+            return None
+        if self._side is None:
+            from .snunet_plan import SideLane
+            self._side = SideLane(self.plan.dev)
+        return self._side
+
+    def _after_launch(self, idx):
+        """bucket hook with the lane on: a bucket that becomes ready may hold gradients written on the lane, so the all-reduce is
+        issued behind both streams"""
+        if self.reducer.by_launch.get(idx):
+            self._side.join()
+        self.reducer.after_launch(idx)
 
     def set_batch(self, *args):
         self._set_inputs(*args[:-1])
@@ -99,7 +121,10 @@ class _PlanTrainStep:
         self._timed("ce_dice_backward", lambda: _lib.check(lib.ksmi_ce_dice_backward(
             p.logits.data_ptr(), self.labels.data_ptr(), self.cw.data_ptr(), self.with_dice, self.loss_ws.data_ptr(), None,
             p.dlogits.data_ptr(), B, HW, 3, st), "ce_dice_backward"))
-        p.bwd.run(t, self.reducer.after_launch)
+        lane = self._lane()
+        p.bwd.run(t, self._after_launch if lane is not None else self.reducer.after_launch, lane)
+        if lane is not None:
+            lane.join()
         self.reducer.wait()
         mf = self.model
         self._timed("optimizer", lambda: self.optimizer.step_arena(mf.flat_params.data_ptr(), mf.flat_grads.data_ptr(),

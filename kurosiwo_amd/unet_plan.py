@@ -19,6 +19,8 @@ from .unet import DECODER_CHANNELS, LAYERS
 class UnetPlan(ChangeFormerPlan):
     input_names = ("x",)
 
+    side_wgrad = True          # plan_base.PlanBase.side_wgrad: dedicated buffers throughout (self.buf), conv weight gradients only
+
     def __init__(self, model, B, H, W, dtype, training, with_backward):
         self._init_base(model, dtype, with_backward)
         self.B, self.H, self.W, self.training = B, H, W, training

@@ -71,3 +71,46 @@ def test_main_entry_with_hip_graph(tmp_path, monkeypatch):
         monkeypatch.setenv("KSMI_SYNTHETIC_TILES", "8,4,4")
         res.append(entry.main(["--method", "snunet", "--inputs", "pre_event_1", "post_event", "--batch_size", "4"] + flag))
     assert res[0] == res[1], res
+
+
+def _lane_case(family, B, S, overlap, graph):
+    from kurosiwo_amd.trainer import CDTrainStep, SegTrainStep
+    torch.manual_seed(5)
+    kw = dict(lr=1e-3, overlap_wgrad=overlap, graph=graph)
+    if family == "snunet":
+        from kurosiwo_amd.snunet import SNUNet_ECAM
+        m = SNUNet_ECAM(2, 3, base_channel=32, precision="bf16").cuda().train()
+        return m, CDTrainStep(m, B, S, S, "ce+dice", (1.0, 2.0, 3.0), **kw)
+    if family == "bitcd":
+        from kurosiwo_amd.bitcd import define_G
+        m = define_G({"net_G": "base_resnet18"}, 2, precision="bf16").cuda().train()
+        return m, CDTrainStep(m, B, S, S, "ce+dice", (1.0, 2.0, 3.0), **kw)
+    from kurosiwo_amd.unet import Unet
+    m = Unet("resnet18", encoder_weights=None, in_channels=2, classes=3, precision="bf16").cuda().train()
+    return m, SegTrainStep(m, B, "cross_entropy", (1.0, 2.0, 3.0), image_size=(S, S), **kw)
+
+
+@pytest.mark.parametrize("family,graph", [("snunet", False), ("snunet", True), ("bitcd", False), ("unet", False), ("unet", True)])
+def test_side_lane_equals_single_stream(family, graph):
+    """trainer.py overlap_wgrad: the weight-gradient launches run on a second stream (snunet_plan.SideLane); every kernel is deterministic,
+    so a missing dependency edge would show up as a different trajectory -- it must equal the single-stream one bit for bit, eagerly
+    and as a captured graph (fork / join become graph edges).  224 x 224 tiles: launches long enough to really overlap."""
+    B, S = 4, 224
+    data = _batches(5, B, 2, S, 21)
+    out = []
+    for overlap in (False, True):
+        m, st = _lane_case(family, B, S, overlap, graph and overlap)
+        assert st.overlap_wgrad == overlap
+        losses = []
+        for xA, xB, y in data:
+            args = (xA.cuda(), y.cuda()) if family == "unet" else (xA.cuda(), xB.cuda(), y.cuda())
+            losses.append(st.step(*args).clone())
+        torch.cuda.synchronize()
+        if overlap:
+            assert st._side is not None and (st._graph is not None) == graph
+            assert any(meta.get("side") for _, _, _, meta in st.plan.bwd.calls)
+        out.append((losses, m.flat_params.clone(), m.flat_grads.clone()))
+    for a, b in zip(out[0][0], out[1][0]):
+        assert torch.equal(a, b), (a.tolist(), b.tolist())
+    assert torch.equal(out[0][2], out[1][2])
+    assert torch.equal(out[0][1], out[1][1])
