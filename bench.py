@@ -292,6 +292,7 @@ def main():
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": workload + ("+RCCL all-reduce" if world > 1 else "") + (" [HIP graph replay]" if graph else ""),
                        "global_batch": B * world, "base_channel": args.base_channel, "parallelism": f"dp{world}",
+                       "hip_streams": 2 if (getattr(step, "overlap_wgrad", False) and getattr(step.plan, "side_wgrad", False)) else 1,
                        "loss_last": [round(x, 5) for x in loss]},
             # the roofline that bounds the dominant kernel class: the larger of bytes / HBM peak and flops / MFMA peak
             "roofline": ({"kernel": dominant, "bound": "mfma", "achieved": round(ach_tf, 1), "peak": MFMA_BF16_PEAK_TF,

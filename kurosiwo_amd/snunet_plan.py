@@ -84,6 +84,8 @@ class _Saved:
 
 
 class SNUNetPlan:
+    side_wgrad = True          # weight gradients on the train step's side lane (see LaunchList.run; plan_base.PlanBase.side_wgrad)
+
     def __init__(self, model, B, H, W, dtype, training, with_backward):
         self.m, self.B, self.H, self.W, self.dtype = model, B, H, W, dtype
         self.training, self.with_backward = training, with_backward
