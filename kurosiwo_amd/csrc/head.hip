@@ -8,7 +8,7 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kPoolSplit = 16;       // pixel splits per image for the global pools
-constexpr int kBwdSplit = 16;        // (64 made the single-block finish kernel walk 64 partial slabs: 0.24 ms)
+constexpr int kBwdSplit = 64;        // pixel splits of the phase-A reduction (the finish kernel is one block per sample)
 
 // ------------------------------------------------------------------------------------------------
 // ECAM global avg+max pool over H*W for cat(x0_1..x0_4) [4C] and for their sum [C]
@@ -260,110 +260,132 @@ __global__ __launch_bounds__(256) void ecam_bwd_reduce_kernel(const T* x0, const
   }
 }
 
-// finish phase A (one block): G, DL -> dca, dca1, dWf (=), dbias (=)
+// finish phase A, block = sample b: G[b], DL[b] (fp64 over the splits) -> gbuf / dlbuf, dca[b], dca1[b]
 template <int NCLS>
-__global__ void ecam_bwd_finish_kernel(const float* pg, const float* pd, const float* ca, const float* ca1, const float* wf,
-                                       float* dca, float* dca1, float* dwf, float* dbias, float* gbuf, float* dlbuf,
-                                       int B, int S, int C) {
-  const int C4 = 4 * C;
-  // G[b][k][c], DL[b][k] (fp64 over splits) into gbuf/dlbuf
-  for (int i = threadIdx.x; i < B * NCLS * C4; i += blockDim.x) {
-    const int c = i % C4; const int k = (i / C4) % NCLS; const int b = i / (C4 * NCLS);
+__global__ __launch_bounds__(256) void ecam_bwd_finish_kernel(const float* pg, const float* pd, const float* ca, const float* ca1, const float* wf,
+                                                              float* dca, float* dca1, float* gbuf, float* dlbuf, int S, int C) {
+  extern __shared__ float sm[];
+  const int C4 = 4 * C, b = blockIdx.x;
+  float* gs = sm;                      // [NCLS][4C]
+  float* dls = sm + NCLS * C4;         // [NCLS]
+  for (int i = threadIdx.x; i < NCLS * C4; i += blockDim.x) {
+    const int c = i % C4, k = i / C4;
     double a = 0.0;
     for (int sp = 0; sp < S; ++sp) a += (double)pg[(((size_t)b * S + sp) * NCLS + k) * C4 + c];
-    gbuf[i] = (float)a;
+    gs[i] = (float)a;
+    gbuf[(size_t)b * NCLS * C4 + i] = (float)a;
   }
-  for (int i = threadIdx.x; i < B * NCLS; i += blockDim.x) {
-    const int k = i % NCLS, b = i / NCLS;
+  for (int k = threadIdx.x; k < NCLS; k += blockDim.x) {
     double a = 0.0;
     for (int sp = 0; sp < S; ++sp) a += (double)pd[((size_t)b * S + sp) * NCLS + k];
-    dlbuf[i] = (float)a;
+    dls[k] = (float)a;
+    dlbuf[b * NCLS + k] = (float)a;
   }
   __syncthreads();
   // dca[b][c] = sum_k Wf[k][c] * (G[b][k][c] + ca1[b][c%C]*DL[b][k])
-  for (int i = threadIdx.x; i < B * C4; i += blockDim.x) {
-    const int c = i % C4, b = i / C4;
+  for (int c = threadIdx.x; c < C4; c += blockDim.x) {
     float a = 0.f;
-    for (int k = 0; k < NCLS; ++k) a += wf[k * C4 + c] * (gbuf[(b * NCLS + k) * C4 + c] + ca1[b * C + (c % C)] * dlbuf[b * NCLS + k]);
-    dca[i] = a;
+    for (int k = 0; k < NCLS; ++k) a += wf[k * C4 + c] * (gs[k * C4 + c] + ca1[b * C + (c % C)] * dls[k]);
+    dca[(size_t)b * C4 + c] = a;
   }
   // dca1[b][cc] = sum_j ca[b][cc+jC] * sum_k Wf[k][cc+jC]*DL[b][k]
-  for (int i = threadIdx.x; i < B * C; i += blockDim.x) {
-    const int cc = i % C, b = i / C;
+  for (int cc = threadIdx.x; cc < C; cc += blockDim.x) {
     float a = 0.f;
     for (int j = 0; j < 4; ++j) {
       float s1 = 0.f;
-      for (int k = 0; k < NCLS; ++k) s1 += wf[k * C4 + cc + j * C] * dlbuf[b * NCLS + k];
-      a += ca[b * C4 + cc + j * C] * s1;
+      for (int k = 0; k < NCLS; ++k) s1 += wf[k * C4 + cc + j * C] * dls[k];
+      a += ca[(size_t)b * C4 + cc + j * C] * s1;
     }
-    dca1[i] = a;
-  }
-  // dWf[k][c] = sum_b ca[b][c] * (G[b][k][c] + ca1[b][c%C]*DL[b][k])
-  for (int i = threadIdx.x; i < NCLS * C4; i += blockDim.x) {
-    const int c = i % C4, k = i / C4;
-    float a = 0.f;
-    for (int b = 0; b < B; ++b) a += ca[b * C4 + c] * (gbuf[(b * NCLS + k) * C4 + c] + ca1[b * C + (c % C)] * dlbuf[b * NCLS + k]);
-    dwf[i] = a;
-  }
-  for (int k = threadIdx.x; k < NCLS; k += blockDim.x) {
-    float a = 0.f;
-    for (int b = 0; b < B; ++b) a += dlbuf[b * NCLS + k];
-    dbias[k] = a;
+    dca1[(size_t)b * C + cc] = a;
   }
 }
 
-// MLP backward, one block (B is small): sigmoid' -> fc2 -> relu' -> fc1 ; grads of fc weights are assigned (=)
-__global__ void ecam_mlp_bwd_kernel(const float* avg, const float* mx, const float* hidden, const float* ca, const float* ca1,
-                                    const float* dca, const float* dca1, const float* w1, const float* w2, const float* v1,
-                                    const float* v2, float* davg, float* dmax, float* gw1, float* gw2, float* gv1, float* gv2,
-                                    float* scratch /* [B][5C] ds + [B][2][HT] dh */, int B, int C) {
-  const int C4 = 4 * C, H1 = C4 / 16, H2 = C / 4, HT = H1 + H2, C5 = 5 * C;
-  float* ds = scratch;                 // [B][5C] pre-sigmoid grad
-  float* dh = scratch + (size_t)B * C5; // [B][2][HT] grad wrt relu input
-  for (int i = threadIdx.x; i < B * C5; i += blockDim.x) {
-    const int c = i % C5, b = i / C5;
-    const float s = c < C4 ? ca[b * C4 + c] : ca1[b * C + c - C4];
-    const float d = c < C4 ? dca[b * C4 + c] : dca1[b * C + c - C4];
-    ds[i] = d * s * (1.f - s);
+// ... and across the samples: dWf[k][c] = sum_b ca[b][c] * (G[b][k][c] + ca1[b][c%C]*DL[b][k]) (=), dbias[k] = sum_b DL[b][k] (=)
+template <int NCLS>
+__global__ __launch_bounds__(256) void ecam_bwd_wf_kernel(const float* gbuf, const float* dlbuf, const float* ca, const float* ca1, float* dwf,
+                                                          float* dbias, int B, int C) {
+  const int C4 = 4 * C;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < NCLS * C4) {
+    const int c = i % C4, k = i / C4;
+    float a = 0.f;
+    for (int b = 0; b < B; ++b) a += ca[(size_t)b * C4 + c] * (gbuf[((size_t)b * NCLS + k) * C4 + c] + ca1[b * C + (c % C)] * dlbuf[b * NCLS + k]);
+    dwf[i] = a;
+  }
+  if (blockIdx.x == 0 && (int)threadIdx.x < NCLS) {
+    float a = 0.f;
+    for (int b = 0; b < B; ++b) a += dlbuf[b * NCLS + threadIdx.x];
+    dbias[threadIdx.x] = a;
+  }
+}
+
+// MLP backward, block = sample b: sigmoid' -> fc2 -> relu' -> fc1 (pre-sigmoid / pre-ReLU gradients also to `scratch` for the weights)
+__global__ __launch_bounds__(256) void ecam_mlp_bwd_kernel(const float* hidden, const float* ca, const float* ca1, const float* dca,
+                                                           const float* dca1, const float* w1, const float* w2, const float* v1, const float* v2,
+                                                           float* davg, float* dmax, float* scratch /* [B][5C] ds + [B][2][HT] dh */, int B, int C) {
+  extern __shared__ float sm[];
+  const int C4 = 4 * C, H1 = C4 / 16, H2 = C / 4, HT = H1 + H2, C5 = 5 * C, b = blockIdx.x;
+  float* ds = sm;                      // [5C] pre-sigmoid grad
+  float* dh = sm + C5;                 // [2][HT] grad wrt relu input
+  float* gds = scratch + (size_t)b * C5;
+  float* gdh = scratch + (size_t)B * C5 + (size_t)b * 2 * HT;
+  for (int c = threadIdx.x; c < C5; c += blockDim.x) {
+    const float s = c < C4 ? ca[(size_t)b * C4 + c] : ca1[(size_t)b * C + c - C4];
+    const float d = c < C4 ? dca[(size_t)b * C4 + c] : dca1[(size_t)b * C + c - C4];
+    const float v = d * s * (1.f - s);
+    ds[c] = v; gds[c] = v;
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < B * 2 * HT; i += blockDim.x) {
-    const int j = i % HT, which = (i / HT) % 2, b = i / (2 * HT);
+  for (int i = threadIdx.x; i < 2 * HT; i += blockDim.x) {
+    const int j = i % HT, which = i / HT;
     const float h = hidden[(size_t)b * 2 * HT + which * HT + j];
     float a = 0.f;
-    if (j < H1) { for (int c = 0; c < C4; ++c) a += w2[c * H1 + j] * ds[b * C5 + c]; }
-    else { const int jj = j - H1; for (int c = 0; c < C; ++c) a += v2[c * H2 + jj] * ds[b * C5 + C4 + c]; }
-    dh[i] = h > 0.f ? a : 0.f;
+    if (j < H1) { for (int c = 0; c < C4; ++c) a += w2[c * H1 + j] * ds[c]; }
+    else { const int jj = j - H1; for (int c = 0; c < C; ++c) a += v2[c * H2 + jj] * ds[C4 + c]; }
+    const float v = h > 0.f ? a : 0.f;
+    dh[i] = v; gdh[i] = v;
   }
   __syncthreads();
-  // input grads
-  for (int i = threadIdx.x; i < B * C5; i += blockDim.x) {
-    const int c = i % C5, b = i / C5;
+  for (int c = threadIdx.x; c < C5; c += blockDim.x) {
     float a = 0.f, m = 0.f;
-    if (c < C4) { for (int j = 0; j < H1; ++j) { a += w1[j * C4 + c] * dh[(b * 2 + 0) * HT + j]; m += w1[j * C4 + c] * dh[(b * 2 + 1) * HT + j]; } }
-    else { const int cc = c - C4; for (int j = 0; j < H2; ++j) { a += v1[j * C + cc] * dh[(b * 2 + 0) * HT + H1 + j]; m += v1[j * C + cc] * dh[(b * 2 + 1) * HT + H1 + j]; } }
-    davg[i] = a; dmax[i] = m;
+    if (c < C4) { for (int j = 0; j < H1; ++j) { a += w1[j * C4 + c] * dh[j]; m += w1[j * C4 + c] * dh[HT + j]; } }
+    else { const int cc = c - C4; for (int j = 0; j < H2; ++j) { a += v1[j * C + cc] * dh[H1 + j]; m += v1[j * C + cc] * dh[HT + H1 + j]; } }
+    davg[(size_t)b * C5 + c] = a; dmax[(size_t)b * C5 + c] = m;
   }
-  // weight grads: fc2: g[c][j] = sum_b ds[b][c]*(h_avg+h_max)[b][j] ; fc1: g[j][c] = sum_b dh_avg*avg + dh_max*max
-  for (int i = threadIdx.x; i < C4 * H1; i += blockDim.x) {
+}
+
+// weight grads across the samples (=): fc2: g[c][j] = sum_b ds[b][c]*(h_avg+h_max)[b][j] ; fc1: g[j][c] = sum_b dh_avg*avg + dh_max*max
+__global__ __launch_bounds__(256) void ecam_mlp_wgrad_kernel(const float* avg, const float* mx, const float* hidden, const float* scratch,
+                                                             float* gw1, float* gw2, float* gv1, float* gv2, int B, int C) {
+  const int C4 = 4 * C, H1 = C4 / 16, H2 = C / 4, HT = H1 + H2, C5 = 5 * C;
+  const float* ds = scratch;
+  const float* dh = scratch + (size_t)B * C5;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < C4 * H1) {
     const int j = i % H1, c = i / H1;
     float a = 0.f;
     for (int b = 0; b < B; ++b) a += ds[b * C5 + c] * (hidden[(size_t)b * 2 * HT + j] + hidden[(size_t)b * 2 * HT + HT + j]);
     gw2[i] = a;
+    return;
   }
-  for (int i = threadIdx.x; i < C * H2; i += blockDim.x) {
+  i -= C4 * H1;
+  if (i < C * H2) {
     const int j = i % H2, c = i / H2;
     float a = 0.f;
     for (int b = 0; b < B; ++b) a += ds[b * C5 + C4 + c] * (hidden[(size_t)b * 2 * HT + H1 + j] + hidden[(size_t)b * 2 * HT + HT + H1 + j]);
     gv2[i] = a;
+    return;
   }
-  for (int i = threadIdx.x; i < H1 * C4; i += blockDim.x) {
+  i -= C * H2;
+  if (i < H1 * C4) {
     const int c = i % C4, j = i / C4;
     float a = 0.f;
     for (int b = 0; b < B; ++b) a += dh[(b * 2 + 0) * HT + j] * avg[b * C5 + c] + dh[(b * 2 + 1) * HT + j] * mx[b * C5 + c];
     gw1[i] = a;
+    return;
   }
-  for (int i = threadIdx.x; i < H2 * C; i += blockDim.x) {
+  i -= H1 * C4;
+  if (i < H2 * C) {
     const int c = i % C, j = i / C;
     float a = 0.f;
     for (int b = 0; b < B; ++b) a += dh[(b * 2 + 0) * HT + H1 + j] * avg[b * C5 + C4 + c] + dh[(b * 2 + 1) * HT + H1 + j] * mx[b * C5 + C4 + c];
@@ -384,26 +406,33 @@ __global__ __launch_bounds__(256) void ecam_bwd_dx_kernel(T* d0, T* d1, T* d2, T
   for (int i = threadIdx.x; i < NCLS * C4; i += blockDim.x) weff[i] = wf[i] * ca[(size_t)b * C4 + (i % C4)];
   for (int i = threadIdx.x; i < C4; i += blockDim.x) cst[i] = (davg[(size_t)b * 5 * C + i] + davg[(size_t)b * 5 * C + C4 + (i % C)]) * inv;
   __syncthreads();
-  T* ds[4] = {d0, d1, d2, d3};
-  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += gridDim.x * blockDim.x) {
-    float d[NCLS];
+  // thread = (pixel lane, source, channel vector): its 16-byte store lands next to its neighbours' (one source row = C contiguous
+  // channels), and its VEC x (1 + NCLS) coefficients stay in registers across the pixel walk
+  const int CV = C / VEC, tpp = 4 * CV;              // threads per pixel
+  const int ppb = blockDim.x / tpp;                  // pixels per trip (launcher: tpp <= blockDim.x)
+  const int q = threadIdx.x % tpp, pl = threadIdx.x / tpp;
+  const int s = q / CV, c0 = (q - s * CV) * VEC;
+  if (pl >= ppb) return;
+  float w[NCLS][VEC], k0[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    k0[j] = cst[s * C + c0 + j];
+#pragma unroll
+    for (int k = 0; k < NCLS; ++k) w[k][j] = weff[k * C4 + s * C + c0 + j];
+  }
+  T* dst = (s == 0 ? d0 : s == 1 ? d1 : s == 2 ? d2 : d3) + (int64_t)b * HW * C + c0;
+  for (int p = blockIdx.x * ppb + pl; p < HW; p += gridDim.x * ppb) {
+    float d[NCLS], v[VEC];
 #pragma unroll
     for (int k = 0; k < NCLS; ++k) d[k] = dl[((int64_t)b * NCLS + k) * HW + p];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      T* row = ds[s] + ((int64_t)b * HW + p) * C;
-      for (int c0 = 0; c0 < C; c0 += VEC) {
-        float v[VEC];
+    for (int j = 0; j < VEC; ++j) {
+      float a = k0[j];
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-          float a = cst[s * C + c0 + j];
-#pragma unroll
-          for (int k = 0; k < NCLS; ++k) a += weff[k * C4 + s * C + c0 + j] * d[k];
-          v[j] = a;
-        }
-        *(u32x4*)(row + c0) = vec_pack<T>(v);
-      }
+      for (int k = 0; k < NCLS; ++k) a += w[k][j] * d[k];
+      v[j] = a;
     }
+    *(u32x4*)(dst + (int64_t)p * C) = vec_pack<T>(v);
   }
 }
 
@@ -630,8 +659,9 @@ int ksmi_ecam_final_backward_reduce(const void* const x[4], const float* dlogits
                              (const float*)x[0], (const float*)x[1], (const float*)x[2], (const float*)x[3], dlogits, pg, pd, HW, C));
   int rc = ksmi_check_launch("ecam_bwd_reduce");
   if (rc) return rc;
-  hipLaunchKernelGGL(ecam_bwd_finish_kernel<3>, dim3(1), dim3(1024), 0, (hipStream_t)stream, pg, pd, ca, ca1, wf, dca, dca1, dwf,
-                     dbias, gb, db, B, kBwdSplit, C);
+  hipLaunchKernelGGL(ecam_bwd_finish_kernel<3>, dim3(B), dim3(256), (size_t)(3 * 4 * C + 3) * sizeof(float), (hipStream_t)stream, pg, pd, ca, ca1,
+                     wf, dca, dca1, gb, db, kBwdSplit, C);
+  hipLaunchKernelGGL(ecam_bwd_wf_kernel<3>, dim3((3 * 4 * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, gb, db, ca, ca1, dwf, dbias, B, C);
   return ksmi_check_launch("ecam_bwd_finish");
 }
 
@@ -644,8 +674,12 @@ int ksmi_ecam_mlp_backward(const float* avg, const float* mx, const float* hidde
                            const float* ca1_fc2, float* davg, float* dmax, float* g_ca_fc1, float* g_ca_fc2, float* g_ca1_fc1,
                            float* g_ca1_fc2, float* workspace, int B, int C, void* stream) {
   if (C % 16 || !workspace) return ksmi_fail(KSMI_E_ARG, "ecam_mlp_backward: bad args");
-  hipLaunchKernelGGL(ecam_mlp_bwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, avg, mx, hidden, ca, ca1, dca, dca1, ca_fc1,
-                     ca_fc2, ca1_fc1, ca1_fc2, davg, dmax, g_ca_fc1, g_ca_fc2, g_ca1_fc1, g_ca1_fc2, workspace, B, C);
+  const int C4 = 4 * C, HT = C4 / 16 + C / 4;
+  hipLaunchKernelGGL(ecam_mlp_bwd_kernel, dim3(B), dim3(256), (size_t)(5 * C + 2 * HT) * sizeof(float), (hipStream_t)stream, hidden, ca, ca1, dca,
+                     dca1, ca_fc1, ca_fc2, ca1_fc1, ca1_fc2, davg, dmax, workspace, B, C);
+  const int items = 2 * (C4 * (C4 / 16) + C * (C / 4));
+  hipLaunchKernelGGL(ecam_mlp_wgrad_kernel, dim3((items + 255) / 256), dim3(256), 0, (hipStream_t)stream, avg, mx, hidden, workspace, g_ca_fc1,
+                     g_ca_fc2, g_ca1_fc1, g_ca1_fc2, B, C);
   return ksmi_check_launch("ecam_mlp_bwd");
 }
 
@@ -653,7 +687,12 @@ int ksmi_ecam_final_backward_dx(void* const dx[4], const float* dlogits, const f
                                 const float* dmax, const int32_t* argmax, int B, int HW, int C, int ncls, int dtype, void* stream) {
   if (ncls != 3 || !ecam_c_ok(C, dtype)) return ksmi_fail(KSMI_E_UNSUPPORTED, "ecam_final_bwd_dx: ncls must be 3");
   const size_t lds = (size_t)(3 * 4 * C + 4 * C) * sizeof(float);
-  const dim3 grid((HW + 255) / 256 > 256 ? 256 : (HW + 255) / 256, B);
+  const int tpp = 4 * C / (dtype == KSMI_BF16 ? 8 : 4);          // threads per pixel (source x channel vector)
+  if (tpp > 256) return ksmi_fail(KSMI_E_UNSUPPORTED, "ecam_final_bwd_dx: C too large for the (pixel, source, vector) thread map");
+  const int ppb = 256 / tpp, trips = 8;                          // ~8 pixel trips per workgroup amortise the coefficient loads
+  int gx = (HW + ppb * trips - 1) / (ppb * trips);
+  if (gx < 1) gx = 1;
+  const dim3 grid(gx, B);
   KSMI_DT(dtype,
           hipLaunchKernelGGL((ecam_bwd_dx_kernel<bf16_t, 3>), grid, dim3(256), lds, (hipStream_t)stream, (bf16_t*)dx[0], (bf16_t*)dx[1],
                              (bf16_t*)dx[2], (bf16_t*)dx[3], dlogits, ca, wf, davg, HW, C),

@@ -14,6 +14,6 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 pat = re.compile(sys.argv[2])
 for r in rows:
     if pat.search(r["Name"]):
-        name = re.sub(r"\(.*", "", r["Name"]).replace("void (anonymous namespace)::", "")
+        name = re.sub(r"\(.*", "", r["Name"].replace("(anonymous namespace)::", "").replace("void ", ""))
         print(f'{name[:70]:70s} calls {r["Calls"]:>5s} avg_us {float(r["AverageNs"]) / 1e3:8.1f} total_ms {float(r["TotalDurationNs"]) / 1e6:8.2f} {float(r["Percentage"]):5.1f}%')
 PY
