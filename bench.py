@@ -125,6 +125,9 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--time-all", action="store_true", help="HIP-event time every kernel class (diagnostic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-solo", action="store_true",
+                    help="skip the single-stream steps after the timed region (roofline.solo); the rocprof passes use it so that a trace "
+                         "holds the launches of ONE mode")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step as ONE captured HIP graph in the timed region (single GPU); the per-kernel roofline figures "
                          "then come from eager steps run after it")
@@ -270,6 +273,19 @@ def main():
         for _ in range(timer_steps):
             step.run()
         sync()
+    # With the side lane on (trainer.py overlap_wgrad) the launches timed above shared the machine with the weight-gradient lane, so
+    # their durations -- and the roofline block below, which is defined over the timed region -- describe the overlapped step, not
+    # the kernel.  A few more steps with the lane off give the same kernel class alone on the machine ("solo").
+    solo = None
+    two_streams = bool(getattr(step, "overlap_wgrad", False) and getattr(step.plan, "side_wgrad", False))
+    if two_streams and not graph and not args.no_solo:
+        solo_timer = KernelTimer({dominant})
+        step.timer, step.overlap_wgrad = solo_timer, False
+        for _ in range(min(args.steps, 5)):
+            step.run()
+        sync()
+        step.timer, step.overlap_wgrad = timer, True
+        solo = solo_timer.summary().get(dominant)
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -312,6 +328,15 @@ def main():
                          "step_hbm_frac": round(step_bytes / dt * args.steps / 1e9 / HBM_PEAK_GBS, 4),
                          "step_mfma_frac": round(step_flops / dt * args.steps / 1e12 / MFMA_BF16_PEAK_TF, 4)},
         }
+        if two_streams:
+            res["roofline"]["overlapped"] = ("the timed launches share the machine with the weight-gradient launches of the side lane "
+                                             "(config.hip_streams = 2): durations are per launch, not per machine-second")
+        if solo and solo["n"]:
+            hbm = res["roofline"]["bound"] == "hbm"
+            s_ach = (solo["bytes"] / 1e9 if hbm else solo["flops"] / 1e12) / (solo["ms"] * 1e-3)
+            res["roofline"]["solo"] = {"avg_launch_ms": round(solo["ms"] / solo["n"], 4), "achieved": round(s_ach, 1),
+                                       "frac": round(s_ach / (HBM_PEAK_GBS if hbm else MFMA_BF16_PEAK_TF), 4), "launches_timed": solo["n"],
+                                       "how": "same kernel class, lane off (single stream), steps run after the timed region"}
         if args.time_all:
             tot = sum(v["ms"] for v in ts.values())
             res["kernels"] = {k: {"ms_per_step": round(v["ms"] / args.steps, 3), "launches": v["n"] // args.steps,
