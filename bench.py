@@ -285,14 +285,17 @@ def main():
     # their durations -- and the roofline block below, which is defined over the timed region -- describe the overlapped step, not
     # the kernel.  A few more steps with the lane off give the same kernel class alone on the machine ("solo").
     solo = None
-    two_streams = bool(getattr(step, "overlap_wgrad", False) and getattr(step.plan, "side_wgrad", False))
+    n_streams = (1 + int(bool(getattr(step, "overlap_wgrad", False) and getattr(step.plan, "side_wgrad", False)))
+                 + int(bool(getattr(step, "overlap_lanes", False) and getattr(step.plan, "two_lanes", False))))
+    two_streams = n_streams > 1
     if two_streams and not graph and not args.no_solo:
         solo_timer = KernelTimer({dominant})
-        step.timer, step.overlap_wgrad = solo_timer, False
+        keep = (step.overlap_wgrad, step.overlap_lanes)
+        step.timer, step.overlap_wgrad, step.overlap_lanes = solo_timer, False, False
         for _ in range(min(args.steps, 5)):
             step.run()
         sync()
-        step.timer, step.overlap_wgrad = timer, True
+        step.timer, (step.overlap_wgrad, step.overlap_lanes) = timer, keep
         solo = solo_timer.summary().get(dominant)
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -316,7 +319,7 @@ def main():
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": workload + ("+RCCL all-reduce" if world > 1 else "") + (" [HIP graph replay]" if graph else ""),
                        "global_batch": B * world, "base_channel": args.base_channel, "parallelism": f"dp{world}",
-                       "hip_streams": 2 if (getattr(step, "overlap_wgrad", False) and getattr(step.plan, "side_wgrad", False)) else 1,
+                       "hip_streams": n_streams,
                        "loss_last": [round(x, 5) for x in loss]},
             # the roofline that bounds the dominant kernel class: the larger of bytes / HBM peak and flops / MFMA peak
             "roofline": ({"kernel": dominant, "bound": "mfma", "achieved": round(ach_tf, 1), "peak": MFMA_BF16_PEAK_TF,
@@ -337,14 +340,14 @@ def main():
                          "step_mfma_frac": round(step_flops / dt * args.steps / 1e12 / MFMA_BF16_PEAK_TF, 4)},
         }
         if two_streams:
-            res["roofline"]["overlapped"] = ("the timed launches share the machine with the weight-gradient launches of the side lane "
-                                             "(config.hip_streams = 2): durations are per launch, not per machine-second")
+            res["roofline"]["overlapped"] = ("the timed launches share the machine with the launches of the other streams of the step "
+                                             "(config.hip_streams; weight gradients, second decoder lane): durations are per launch, not per machine-second")
         if solo and solo["n"]:
             hbm = res["roofline"]["bound"] == "hbm"
             s_ach = (solo["bytes"] / 1e9 if hbm else solo["flops"] / 1e12) / (solo["ms"] * 1e-3)
             res["roofline"]["solo"] = {"avg_launch_ms": round(solo["ms"] / solo["n"], 4), "achieved": round(s_ach, 1),
                                        "frac": round(s_ach / (HBM_PEAK_GBS if hbm else MFMA_BF16_PEAK_TF), 4), "launches_timed": solo["n"],
-                                       "how": "same kernel class, lane off (single stream), steps run after the timed region"}
+                                       "how": "same kernel class, single stream, steps run after the timed region"}
         if args.time_all:
             tot = sum(v["ms"] for v in ts.values())
             res["kernels"] = {k: {"ms_per_step": round(v["ms"] / args.steps, 3), "launches": v["n"] // args.steps,

@@ -18,60 +18,111 @@ from .snunet import BN_EPS, BN_MOMENTUM
 
 class LaunchList:
     """(name, argfn, meta) triples; argfn() is evaluated once, after all scratch buffers exist.
-    meta = {"kind": kernel class, "bytes": algorithmic HBM bytes, "flops": 2*MAC} for the roofline."""
+    meta = {"kind": kernel class, "bytes": algorithmic HBM bytes, "flops": 2*MAC} for the roofline, plus the scheduling tags
+    "lane" (compute lane the launch belongs to: 0 = the caller's stream, 1 = the second lane) and "side" (weight gradient: may
+    run on the side stream).  ("@wait", (a, b)) entries order lane b behind everything lane a was handed so far."""
 
     def __init__(self):
         self.pending, self.calls = [], []
+        self.cur_lane = 0
 
     def add(self, name, argfn, meta=None):
-        self.pending.append((name, argfn, meta or {"kind": name[5:], "bytes": 0, "flops": 0}))
+        meta = dict(meta) if meta else {"kind": name[5:], "bytes": 0, "flops": 0}
+        meta["lane"] = self.cur_lane
+        self.pending.append((name, argfn, meta))
+
+    def add_wait(self, src, dst):
+        self.pending.append(("@wait", lambda: (src, dst), {"kind": "wait", "bytes": 0, "flops": 0, "lane": dst}))
 
     def resolve(self, lib):
-        self.calls = [(getattr(lib, name), tuple(argfn()), name, meta) for name, argfn, meta in self.pending]
+        self.calls = [(None if name == "@wait" else getattr(lib, name), tuple(argfn()), name, meta) for name, argfn, meta in self.pending]
 
-    def run(self, timer=None, hook=None, side=None):
-        """side = SideLane or None.  Launches whose meta carries "side" (the weight gradients: nothing on the critical path of the
-        backward pass reads them) go to the lane's stream behind an event recorded on the main stream at that point of the list, so
-        they fill the machine next to the bandwidth-bound BatchNorm / elementwise launches that follow on the main stream; the
-        caller joins the lane (SideLane.join) before anything reads the gradients."""
-        st = stream_ptr()
-        for idx, (fn, args, name, meta) in enumerate(self.calls):
-            timed = timer is not None and timer.wants(meta["kind"])
-            if timed:
-                timer.begin(meta["kind"], meta)
-            if side is not None and not timed and meta.get("side"):     # (a timed launch is bracketed by events on the main stream)
-                rc = fn(*args, side.fork())
-            else:
-                rc = fn(*args, st)
-            if timed:
-                timer.end()
-            if rc != 0:
-                _lib.check(rc, name)
-            if hook is not None:
-                hook(idx)
+    def run(self, timer=None, hook=None, streams=None):
+        """streams = StepStreams or None.  None: every launch on the current stream, in list order (always a valid order; the
+        "@wait" entries are no-ops).  With streams: launches of lane 1 go to the second compute stream, launches tagged "side" (the
+        weight gradients: nothing on the critical path of the backward pass reads them) to the side stream behind an event recorded
+        on the issuing lane's stream at that point of the list, so that independent work fills the machine next to the
+        bandwidth-bound BatchNorm / elementwise launches of the critical path; the caller joins (StepStreams.join) before
+        anything outside the lists reads the results."""
+        if streams is not None:
+            streams.begin()
+        st, cur = stream_ptr(), 0
+        try:
+            for idx, (fn, args, name, meta) in enumerate(self.calls):
+                if fn is None:
+                    if streams is not None and streams.lanes:
+                        streams.order(*args)
+                    if hook is not None:
+                        hook(idx)
+                    continue
+                lane = meta["lane"] if streams is not None and streams.lanes else 0
+                if lane != cur:
+                    torch.cuda.set_stream(streams.stream(lane))
+                    st, cur = stream_ptr(), lane
+                timed = timer is not None and timer.wants(meta["kind"])
+                if timed:
+                    timer.begin(meta["kind"], meta)
+                if streams is not None and streams.use_side and not timed and meta.get("side"):     # (a timed launch is bracketed by events on its lane's stream)
+                    rc = fn(*args, streams.fork_side())
+                else:
+                    rc = fn(*args, st)
+                if timed:
+                    timer.end()
+                if rc != 0:
+                    _lib.check(rc, name)
+                if hook is not None:
+                    hook(idx)
+        finally:
+            if cur != 0:
+                torch.cuda.set_stream(streams.main)
 
 
-class SideLane:
-    """A second HIP stream for launches off the critical path (see LaunchList.run).  fork(): the lane waits for everything issued so
-    far on the current stream and returns its stream pointer; join(): the current stream waits for the lane.  Both are plain event
-    record / wait pairs, so a step that uses the lane still captures into one HIP graph (fork / join become graph edges)."""
+class StepStreams:
+    """The HIP streams of one train step: main = the caller's current stream (lane 0), lane1 = a second compute lane for the
+    deeper decoder blocks (SNUNetPlan: they depend on the level-0 blocks only through the Up1_j edges), side = the weight gradients.
+    Cross-stream ordering is plain event record / wait pairs, so a step that uses them still captures into one HIP graph."""
 
-    def __init__(self, device):
-        self.stream = torch.cuda.Stream(device=device)       # (a high-priority lane measured the same)
-        self.ptr = C.c_void_p(self.stream.cuda_stream)
-        self.used = False
+    def __init__(self, device, lanes=True, side=True):
+        self.side = torch.cuda.Stream(device=device)       # (stream priorities measured no better, DESIGN.md §5)
+        self.lane1 = torch.cuda.Stream(device=device) if lanes else None
+        self.lanes, self.use_side = bool(lanes), bool(side)
+        self.side_ptr = C.c_void_p(self.side.cuda_stream)
+        self.main = None
+        self.dirty = False
 
-    def fork(self):
+    def begin(self):
+        if self.main is None:
+            self.main = torch.cuda.current_stream()
+
+    def stream(self, lane):
+        return self.main if lane == 0 else self.lane1
+
+    def order(self, src, dst):
+        ev = torch.cuda.Event()
+        ev.record(self.stream(src))
+        self.stream(dst).wait_event(ev)
+        self.dirty = True
+
+    def fork_side(self):
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
-        self.stream.wait_event(ev)
-        self.used = True
-        return self.ptr
+        self.side.wait_event(ev)
+        self.dirty = True
+        return self.side_ptr
 
     def join(self):
-        if self.used:
-            torch.cuda.current_stream().wait_stream(self.stream)
-            self.used = False
+        """the current stream waits for every other stream of the step"""
+        if self.dirty:
+            cur = torch.cuda.current_stream()
+            for s in (self.main, self.lane1, self.side):
+                if s is not None and s.cuda_stream != cur.cuda_stream:
+                    cur.wait_stream(s)
+        if self.main is not None and torch.cuda.current_stream().cuda_stream == self.main.cuda_stream:
+            self.dirty = False
+
+    def end(self):
+        self.join()
+        self.main = None
 
 
 class _Saved:
@@ -84,7 +135,8 @@ class _Saved:
 
 
 class SNUNetPlan:
-    side_wgrad = True          # weight gradients on the train step's side lane (see LaunchList.run; plan_base.PlanBase.side_wgrad)
+    side_wgrad = True          # weight gradients on the train step's side stream (see LaunchList.run; plan_base.PlanBase.side_wgrad)
+    two_lanes = True           # the decoder launches carry lane tags and hand-over entries (StepStreams)
 
     def __init__(self, model, B, H, W, dtype, training, with_backward):
         self.m, self.B, self.H, self.W, self.dtype = model, B, H, W, dtype
@@ -122,22 +174,33 @@ class SNUNetPlan:
         x3_0B = self._block("conv3_0", "B", [self._pool(x2_0B, "p2B")], A("x3_0B", 3, f[3]))
         x4_0B = self._block("conv4_0", "B", [self._pool(x3_0B, "p3B")], A("x4_0B", 4, f[4]))
 
-        x0_1 = self._block("conv0_1", "", [x0_0A, x0_0B, self._up("Up1_0", x1_0B)], A("x0_1", 0, f[0]))
-        x1_1 = self._block("conv1_1", "", [x1_0A, x1_0B, self._up("Up2_0", x2_0B)], A("x1_1", 1, f[1]))
-        x0_2 = self._block("conv0_2", "", [x0_0A, x0_0B, x0_1, self._up("Up1_1", x1_1)], A("x0_2", 0, f[0]))
-        x2_1 = self._block("conv2_1", "", [x2_0A, x2_0B, self._up("Up3_0", x3_0B)], A("x2_1", 2, f[2]))
+        # Decoder on two lanes (LaunchList.run / StepStreams): lane 0 = the level-0 column blocks + the Up1_j transposed convolutions
+        # feeding them + the head, lane 1 = every deeper block and its Up.  Lane 1 needs the encoder only; lane 0 needs lane 1 through
+        # x1_j -> Up1_j (forward) and lane 1 needs lane 0 through d Up1_j -> d x1_j (backward): three ordered hand-overs each way.
+        # The level-0 blocks carry the large BatchNorm / elementwise passes (224^2 maps), the deeper blocks are convolution-bound.
+        L = self._lane
+        self._handover(0, 1, back=(1, 0))                  # forward: lane 1 starts behind the encoder; backward: the encoder behind lane 1
+        L(0); x0_1 = self._block("conv0_1", "", [x0_0A, x0_0B, self._up("Up1_0", x1_0B)], A("x0_1", 0, f[0]))
+        L(1); x1_1 = self._block("conv1_1", "", [x1_0A, x1_0B, self._up("Up2_0", x2_0B)], A("x1_1", 1, f[1]))
+        self._handover(1, 0, back=(0, 1))
+        L(0); x0_2 = self._block("conv0_2", "", [x0_0A, x0_0B, x0_1, self._up("Up1_1", x1_1)], A("x0_2", 0, f[0]))
+        L(1); x2_1 = self._block("conv2_1", "", [x2_0A, x2_0B, self._up("Up3_0", x3_0B)], A("x2_1", 2, f[2]))
         x1_2 = self._block("conv1_2", "", [x1_0A, x1_0B, x1_1, self._up("Up2_1", x2_1)], A("x1_2", 1, f[1]))
-        x0_3 = self._block("conv0_3", "", [x0_0A, x0_0B, x0_1, x0_2, self._up("Up1_2", x1_2)], A("x0_3", 0, f[0]))
-        x3_1 = self._block("conv3_1", "", [x3_0A, x3_0B, self._up("Up4_0", x4_0B)], A("x3_1", 3, f[3]))
+        self._handover(1, 0, back=(0, 1))
+        L(0); x0_3 = self._block("conv0_3", "", [x0_0A, x0_0B, x0_1, x0_2, self._up("Up1_2", x1_2)], A("x0_3", 0, f[0]))
+        L(1); x3_1 = self._block("conv3_1", "", [x3_0A, x3_0B, self._up("Up4_0", x4_0B)], A("x3_1", 3, f[3]))
         x2_2 = self._block("conv2_2", "", [x2_0A, x2_0B, x2_1, self._up("Up3_1", x3_1)], A("x2_2", 2, f[2]))
         x1_3 = self._block("conv1_3", "", [x1_0A, x1_0B, x1_1, x1_2, self._up("Up2_2", x2_2)], A("x1_3", 1, f[1]))
-        x0_4 = self._block("conv0_4", "", [x0_0A, x0_0B, x0_1, x0_2, x0_3, self._up("Up1_3", x1_3)], A("x0_4", 0, f[0]))
+        self._handover(1, 0, back=(0, 1))
+        L(0); x0_4 = self._block("conv0_4", "", [x0_0A, x0_0B, x0_1, x0_2, x0_3, self._up("Up1_3", x1_3)], A("x0_4", 0, f[0]))
         self._head([x0_1, x0_2, x0_3, x0_4])
         self.acts = {a.name: a for a in (x0_0A, x0_0B, x1_0A, x1_0B, x3_0B, x4_0B, x0_1, x1_1, x0_2, x0_3, x0_4, x1_3, x3_1)}
 
         if with_backward:
-            for build in reversed(self.bwd_builders):
+            for lane, build in reversed(self.bwd_builders):
+                self._lane(lane)
                 build()
+            self._lane(0)
             if self._rowsums:
                 import ctypes
                 nr = len(self._rowsums)
@@ -165,6 +228,21 @@ class SNUNetPlan:
             ll.resolve(self.lib)
 
     # ---------------------------------------------------------------- helpers
+    def _lane(self, lane):
+        """launches appended from here on belong to compute lane `lane`"""
+        self.fwd.cur_lane = self.bwd.cur_lane = lane
+
+    def _sname(self, name):
+        """scratch buffers that live from one launch to the next of the same block are per lane"""
+        return name if self.fwd.cur_lane == 0 else f"{name}@{self.fwd.cur_lane}"
+
+    def _handover(self, src, dst, back):
+        """forward list: lane dst continues behind everything lane src was handed so far; backward list (built in reverse): lane
+        back[1] behind lane back[0] at the mirrored position"""
+        self.fwd.add_wait(src, dst)
+        a, b = back
+        self.bwd_builders.append((0, lambda: self.bwd.add_wait(a, b)))
+
     def need(self, name, nbytes):
         self._need[name] = max(self._need.get(name, 0), int(nbytes))
 
@@ -292,7 +370,7 @@ class SNUNetPlan:
             gy, gx = y.grad(), x.grad()
             self.bwd.add("ksmi_maxpool2x2_backward", lambda: (x.t.data_ptr(), gy.data_ptr(), gx.data_ptr(), acc,
                                                               x.B, x.H, x.W, x.C, self.dt))
-        self.bwd_builders.append(build_bwd)
+        self.bwd_builders.append((self.fwd.cur_lane, build_bwd))
         return y
 
     # ---------------------------------------------------------------- up = ConvTranspose2d(k2,s2)  (snunet.py:32-46)
@@ -328,7 +406,7 @@ class SNUNetPlan:
                 pb = torch.empty(rows * Cc, dtype=torch.float32, device=self.dev)
                 self.bwd.add("ksmi_channel_sum", lambda: (gy.data_ptr(), pb.data_ptr(), rows, npix, Cc, self.dt))
                 self._defer_rowsum(bkey, pb, rows, 1, 0, Cc, Cc)
-        self.bwd_builders.append(build_bwd)
+        self.bwd_builders.append((self.fwd.cur_lane, build_bwd))
         return y
 
     # ---------------------------------------------------------------- conv_block_nested  (snunet.py:11-29)
@@ -344,7 +422,8 @@ class SNUNetPlan:
         G = lambda s: m._g(f"{name}.{s}").data_ptr()
         Bf = lambda s: m._b(f"{name}.{s}").data_ptr()
         Npad = (Cc + 15) // 16 * 16
-        stats = (lambda: self.scr("stats")) if training else (lambda: None)
+        sS, sR = self._sname("stats"), self._sname("red")             # per-lane scratch (this block's lane, forward and backward)
+        stats = (lambda: self.scr(sS)) if training else (lambda: None)
 
         # ---- conv1 ----------------------------------------------------------------------
         if first:
@@ -356,7 +435,7 @@ class SNUNetPlan:
             kc = 32 if dtype == torch.bfloat16 else 16
             Kpad = -(-(cin * 9) // kc) * kc
             rows1, cpad1, Ktot = self.lib.ksmi_conv_first_stats_rows(B, H, W), Cc, cin
-            self.need("stats", rows1 * 2 * Cc * 4)
+            self.need(sS, rows1 * 2 * Cc * 4)
             self.fwd.add("ksmi_conv_first_forward", lambda: (x_img.data_ptr(), P("conv1.weight"), P("conv1.bias"),
                                                              i_act.t.data_ptr(), stats(), B, cin, H, W, Cc, dt))
             if self.with_backward:
@@ -373,8 +452,8 @@ class SNUNetPlan:
             d1.wpk = w1.data_ptr()
             rows1, cpad1 = conv_stats_rows(d1, dtype), Npad
             if training:
-                self.need("stats", rows1 * 2 * Npad * 4)
-                self.patch(d1, "stats", "stats")
+                self.need(sS, rows1 * 2 * Npad * 4)
+                self.patch(d1, "stats", sS)
             self._conv(self.fwd, d1)
 
         def bn_fin(bn, sv, rows, cpad):
@@ -393,8 +472,8 @@ class SNUNetPlan:
         d2.wpk = w2.data_ptr()
         rows2 = conv_stats_rows(d2, dtype)
         if training:
-            self.need("stats", rows2 * 2 * Npad * 4)
-            self.patch(d2, "stats", "stats")
+            self.need(sS, rows2 * 2 * Npad * 4)
+            self.patch(d2, "stats", sS)
         self._conv(self.fwd, d2)
         bn_fin("bn2", sv2, rows2, Npad)
         self.fwd.add("ksmi_bn_add_relu", lambda: (z_act.t.data_ptr(), i_act.t.data_ptr(), sv2.scale, sv2.shift,
@@ -404,7 +483,7 @@ class SNUNetPlan:
         def build_bwd():
             self._emit_dgrad(out)
             rows = self._rows(npix)
-            self.need("red", rows * 2 * Cc * 4)
+            self.need(sR, rows * 2 * Cc * 4)
             sums1 = torch.zeros((2, Cc), dtype=torch.float32, device=self.dev)
             sums2 = torch.zeros((2, Cc), dtype=torch.float32, device=self.dev)
             dz = torch.empty_like(z_act.t)     # grad wrt conv2 output
@@ -414,8 +493,8 @@ class SNUNetPlan:
             s1p, s2p = sums1.data_ptr(), sums2.data_ptr()
             a_bn2 = self._acc_param(f"{name}.bn2")
             self.bwd.add("ksmi_bnrelu_bwd_reduce", lambda: (gout, out.t.data_ptr(), z_act.t.data_ptr(), sv2.mean, sv2.rstd,
-                                                            self.scr("red"), rows, npix, Cc, dt))
-            self.bwd.add("ksmi_reduce_rows", lambda: (self.scr("red"), rows, 2, Cc, Cc, s2p, G("bn2.weight"), G("bn2.bias"), a_bn2))
+                                                            self.scr(sR), rows, npix, Cc, dt))
+            self.bwd.add("ksmi_reduce_rows", lambda: (self.scr(sR), rows, 2, Cc, Cc, s2p, G("bn2.weight"), G("bn2.bias"), a_bn2))
             self._mark(f"{name}.bn2.weight", f"{name}.bn2.bias")
             self.bwd.add("ksmi_bnrelu_bwd_apply", lambda: (gout, out.t.data_ptr(), z_act.t.data_ptr(), sv2.mean, sv2.rstd,
                                                            P("bn2.weight"), s2p, dz.data_ptr(), float(npix), npix, Cc, dt))
@@ -433,11 +512,11 @@ class SNUNetPlan:
             wg2 = self._packed(f"{name}.conv2.weight", tg2, 9, Cc, Cc, Cc * 9, 9, 0, 1, 1)
             dg2.wpk = wg2.data_ptr()
             rows_g = conv_stats_rows(dg2, dtype)
-            self.need("stats", rows_g * 2 * Npad * 4)
-            self.patch(dg2, "stats", "stats")
+            self.need(sS, rows_g * 2 * Npad * 4)
+            self.patch(dg2, "stats", sS)
             self._conv(self.bwd, dg2, "dgrad")
             a_bn1 = self._acc_param(f"{name}.bn1")
-            self.bwd.add("ksmi_reduce_rows", lambda: (self.scr("stats"), rows_g, 2, Npad, Cc, s1p, G("bn1.weight"), G("bn1.bias"), a_bn1))
+            self.bwd.add("ksmi_reduce_rows", lambda: (self.scr(sS), rows_g, 2, Npad, Cc, s1p, G("bn1.weight"), G("bn1.bias"), a_bn1))
             self._mark(f"{name}.bn1.weight", f"{name}.bn1.bias")
             # weight gradient of conv2: X = relu(bn1(i)) recomputed on load, dY = dz
             dw2, ws2 = make_wgrad(src2, dz, Cc, 0, Cc, m._g(f"{name}.conv2.weight"), 9, Cc * 9, 1,
@@ -467,7 +546,7 @@ class SNUNetPlan:
                 dw1, ws1 = make_wgrad(srcs, r, Cc, 0, Cc, m._g(f"{name}.conv1.weight"), 9, Ktot * 9, 1, a_w1,
                                       B, H, W, H, W, 3, 3, 1, 1, dtype)
                 self._wgrad(dw1, ws1, f"{name}.conv1.weight")
-        self.bwd_builders.append(build_bwd)
+        self.bwd_builders.append((self.fwd.cur_lane, build_bwd))
         return out
 
     # ---------------------------------------------------------------- ECAM head  (snunet.py:49-62,146-151)
@@ -516,7 +595,7 @@ class SNUNetPlan:
             self._mark("ca.fc1.weight", "ca.fc2.weight", "ca1.fc1.weight", "ca1.fc2.weight")
             self.bwd.add("ksmi_ecam_final_backward_dx", lambda: (
                 garr, dl, ca.data_ptr(), P("conv_final.weight"), davg.data_ptr(), dmax.data_ptr(), argmax.data_ptr(), B, HW, n, 3, dt))
-        self.bwd_builders.append(build_bwd)
+        self.bwd_builders.append((self.fwd.cur_lane, build_bwd))
 
     # ---------------------------------------------------------------- execution
     def run_forward(self, xA, xB):

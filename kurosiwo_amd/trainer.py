@@ -18,7 +18,7 @@ class _PlanTrainStep:
     """zero_grad -> forward -> criterion -> backward (+ bucketed all-reduce) -> optimizer.step over a model plan."""
 
     def __init__(self, model, plan, B, H, W, loss_function="ce+dice", class_weights=(1.0, 1.0, 1.0), optimizer=None, lr=1e-3,
-                 bucket_mb=8.0, group=None, graph=False, overlap_wgrad=True):
+                 bucket_mb=8.0, group=None, graph=False, overlap_wgrad=True, overlap_lanes=True):
         if loss_function not in ("ce+dice", "cross_entropy"):
             raise NotImplementedError(loss_function)
         self.model = model
@@ -40,27 +40,32 @@ class _PlanTrainStep:
         self.timer = None          # optional kernel timer (bench.py)
         self.use_graph = bool(graph) and self.world == 1     # replay the step as one captured HIP graph (configs["hip_graph"])
         self.overlap_wgrad = bool(overlap_wgrad) and os.environ.get("KSMI_OVERLAP_WGRAD", "1") != "0"
+        self.overlap_lanes = bool(overlap_lanes) and os.environ.get("KSMI_OVERLAP_LANES", "1") != "0"
 
     def _set_inputs(self, *inputs):
         raise NotImplementedError
 
-    # ---- side lane: the weight-gradient launches of the backward pass run on a second stream (snunet_plan.SideLane) next to the
-    # bandwidth-bound BatchNorm launches of the critical path.  overlap_wgrad=False / KSMI_OVERLAP_WGRAD=0 switch it off.
-    _side = None
+    # ---- streams of the step (snunet_plan.StepStreams): the weight-gradient launches of the backward pass run on a side stream next to
+    # the bandwidth-bound BatchNorm launches of the critical path (overlap_wgrad; plans with side_wgrad), and the deeper decoder blocks
+    # of SNUNet on a second compute lane next to the level-0 column (overlap_lanes; plans with two_lanes).  Switches: the constructor
+    # arguments / configs["overlap_wgrad"], configs["overlap_lanes"] / KSMI_OVERLAP_WGRAD=0, KSMI_OVERLAP_LANES=0.
+    _ss = None
 
-    def _lane(self):
-        if not self.overlap_wgrad:
+    def _streams(self):
+        side = self.overlap_wgrad and getattr(self.plan, "side_wgrad", False)
+        lanes = self.overlap_lanes and getattr(self.plan, "two_lanes", False)
+        if not (side or lanes):
             return None
-        if self._side is None:
-            from .snunet_plan import SideLane
-            self._side = SideLane(self.plan.dev)
-        return self._side
+        if self._ss is None or (self._ss.lanes, self._ss.use_side) != (lanes, side):
+            from .snunet_plan import StepStreams
+            self._ss = StepStreams(self.plan.dev, lanes=lanes, side=side)
+        return self._ss
 
     def _after_launch(self, idx):
-        """bucket hook with the lane on: a bucket that becomes ready may hold gradients written on the lane, so the all-reduce is
-        issued behind both streams"""
+        """bucket hook with more than one stream: a bucket that becomes ready may hold gradients written on any of them, so the
+        all-reduce is issued behind all"""
         if self.reducer.by_launch.get(idx):
-            self._side.join()
+            self._ss.join()
         self.reducer.after_launch(idx)
 
     def set_batch(self, *args):
@@ -113,7 +118,7 @@ class _PlanTrainStep:
         p, lib, st = self.plan, self.lib, stream_ptr()
         t = self.timer
         p.packs.run(t)
-        p.fwd.run(t)
+        p.fwd.run(t, None, self._streams())
         B, HW = self.B, self.HW
         self._timed("ce_dice_forward", lambda: _lib.check(lib.ksmi_ce_dice_forward(
             p.logits.data_ptr(), self.labels.data_ptr(), self.cw.data_ptr(), self.with_dice, self.loss_out.data_ptr(),
@@ -121,10 +126,10 @@ class _PlanTrainStep:
         self._timed("ce_dice_backward", lambda: _lib.check(lib.ksmi_ce_dice_backward(
             p.logits.data_ptr(), self.labels.data_ptr(), self.cw.data_ptr(), self.with_dice, self.loss_ws.data_ptr(), None,
             p.dlogits.data_ptr(), B, HW, 3, st), "ce_dice_backward"))
-        lane = self._lane()
-        p.bwd.run(t, self._after_launch if lane is not None else self.reducer.after_launch, lane)
-        if lane is not None:
-            lane.join()
+        ss = self._streams()
+        p.bwd.run(t, self._after_launch if ss is not None else self.reducer.after_launch, ss)
+        if ss is not None:
+            ss.end()
         self.reducer.wait()
         mf = self.model
         self._timed("optimizer", lambda: self.optimizer.step_arena(mf.flat_params.data_ptr(), mf.flat_grads.data_ptr(),

@@ -11,13 +11,13 @@ y = torch.randint(0, 3, (B, S, S)).cuda()
 for _ in range(5):
     st.step(xA, xB, y)
 torch.cuda.synchronize()
-lane = st._side
+lane = st._ss
 orig_join = lane.join
 rec = []
 def join():
-    if lane.used:
+    if lane.dirty:
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record(torch.cuda.current_stream()); b.record(lane.stream)
+        a.record(torch.cuda.current_stream()); b.record(lane.side)
         rec.append((a, b))
     orig_join()
 lane.join = join

@@ -76,7 +76,7 @@ def test_main_entry_with_hip_graph(tmp_path, monkeypatch):
 def _lane_case(family, B, S, overlap, graph):
     from kurosiwo_amd.trainer import CDTrainStep, SegTrainStep
     torch.manual_seed(5)
-    kw = dict(lr=1e-3, overlap_wgrad=overlap, graph=graph)
+    kw = dict(lr=1e-3, overlap_wgrad=overlap, overlap_lanes=overlap, graph=graph)
     if family == "snunet":
         from kurosiwo_amd.snunet import SNUNet_ECAM
         m = SNUNet_ECAM(2, 3, base_channel=32, precision="bf16").cuda().train()
@@ -92,9 +92,10 @@ def _lane_case(family, B, S, overlap, graph):
 
 @pytest.mark.parametrize("family,graph", [("snunet", False), ("snunet", True), ("bitcd", False), ("unet", False), ("unet", True)])
 def test_side_lane_equals_single_stream(family, graph):
-    """trainer.py overlap_wgrad: the weight-gradient launches run on a second stream (snunet_plan.SideLane); every kernel is deterministic,
-    so a missing dependency edge would show up as a different trajectory -- it must equal the single-stream one bit for bit, eagerly
-    and as a captured graph (fork / join become graph edges).  224 x 224 tiles: launches long enough to really overlap."""
+    """trainer.py overlap_wgrad / overlap_lanes: the weight-gradient launches run on a side stream and SNUNet's deeper decoder blocks on a
+    second compute lane (snunet_plan.StepStreams); every kernel is deterministic, so a missing dependency edge would show up as a
+    different trajectory -- it must equal the single-stream one bit for bit, eagerly and as a captured graph (fork / join become graph
+    edges).  224 x 224 tiles: launches long enough to really overlap."""
     B, S = 4, 224
     data = _batches(5, B, 2, S, 21)
     out = []
@@ -107,8 +108,10 @@ def test_side_lane_equals_single_stream(family, graph):
             losses.append(st.step(*args).clone())
         torch.cuda.synchronize()
         if overlap:
-            assert st._side is not None and (st._graph is not None) == graph
+            assert st._ss is not None and (st._graph is not None) == graph
             assert any(meta.get("side") for _, _, _, meta in st.plan.bwd.calls)
+            if family == "snunet":
+                assert st._ss.lanes and any(meta["lane"] == 1 for _, _, _, meta in st.plan.fwd.calls + st.plan.bwd.calls)
         out.append((losses, m.flat_params.clone(), m.flat_grads.clone()))
     for a, b in zip(out[0][0], out[1][0]):
         assert torch.equal(a, b), (a.tolist(), b.tolist())
