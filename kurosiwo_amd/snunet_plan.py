@@ -164,22 +164,31 @@ class SNUNetPlan:
             return Act(name, B, H >> lvl, W >> lvl, ch, dtype, self.dev)
 
         # ---- forward graph (snunet.py:118-153) -----------------------------------------------
-        x0_0A = self._block("conv0_0", "A", [self.xA], A("x0_0A", 0, f[0]), first=True)
-        x1_0A = self._block("conv1_0", "A", [self._pool(x0_0A, "p0A")], A("x1_0A", 1, f[1]))
-        x2_0A = self._block("conv2_0", "A", [self._pool(x1_0A, "p1A")], A("x2_0A", 2, f[2]))
-        x3_0A = self._block("conv3_0", "A", [self._pool(x2_0A, "p2A")], A("x3_0A", 3, f[3]))
-        x0_0B = self._block("conv0_0", "B", [self.xB], A("x0_0B", 0, f[0]), first=True)
-        x1_0B = self._block("conv1_0", "B", [self._pool(x0_0B, "p0B")], A("x1_0B", 1, f[1]))
-        x2_0B = self._block("conv2_0", "B", [self._pool(x1_0B, "p1B")], A("x2_0B", 2, f[2]))
-        x3_0B = self._block("conv3_0", "B", [self._pool(x2_0B, "p2B")], A("x3_0B", 3, f[3]))
+        # Siamese encoder, level by level: date A on lane 0, date B on lane 1, B one block behind A.  Both dates share every parameter:
+        # BatchNorm running statistics are updated A first, then B (the reference's order, snunet.py:121-130), and in the backward list
+        # (built in reverse) the date-B block writes the shared BatchNorm gradients ("=") before the date-A block accumulates ("+=");
+        # the hand-over entries between the two blocks of a level keep exactly that order on two streams.
+        L = self._lane
+        L(0); x0_0A = self._block("conv0_0", "A", [self.xA], A("x0_0A", 0, f[0]), first=True)
+        self._handover(0, 1, back=(1, 0))
+        L(1); x0_0B = self._block("conv0_0", "B", [self.xB], A("x0_0B", 0, f[0]), first=True)
+        L(0); x1_0A = self._block("conv1_0", "A", [self._pool(x0_0A, "p0A")], A("x1_0A", 1, f[1]))
+        self._handover(0, 1, back=(1, 0))
+        L(1); x1_0B = self._block("conv1_0", "B", [self._pool(x0_0B, "p0B")], A("x1_0B", 1, f[1]))
+        L(0); x2_0A = self._block("conv2_0", "A", [self._pool(x1_0A, "p1A")], A("x2_0A", 2, f[2]))
+        self._handover(0, 1, back=(1, 0))
+        L(1); x2_0B = self._block("conv2_0", "B", [self._pool(x1_0B, "p1B")], A("x2_0B", 2, f[2]))
+        L(0); x3_0A = self._block("conv3_0", "A", [self._pool(x2_0A, "p2A")], A("x3_0A", 3, f[3]))
+        self._handover(0, 1, back=(1, 0))
+        L(1); x3_0B = self._block("conv3_0", "B", [self._pool(x2_0B, "p2B")], A("x3_0B", 3, f[3]))
         x4_0B = self._block("conv4_0", "B", [self._pool(x3_0B, "p3B")], A("x4_0B", 4, f[4]))
+        self._handover(1, 0, back=(0, 1))                  # encoder | decoder: both lanes have everything of the other side
 
         # Decoder on two lanes (LaunchList.run / StepStreams): lane 0 = the level-0 column blocks + the Up1_j transposed convolutions
         # feeding them + the head, lane 1 = every deeper block and its Up.  Lane 1 needs the encoder only; lane 0 needs lane 1 through
         # x1_j -> Up1_j (forward) and lane 1 needs lane 0 through d Up1_j -> d x1_j (backward): three ordered hand-overs each way.
         # The level-0 blocks carry the large BatchNorm / elementwise passes (224^2 maps), the deeper blocks are convolution-bound.
-        L = self._lane
-        self._handover(0, 1, back=(1, 0))                  # forward: lane 1 starts behind the encoder; backward: the encoder behind lane 1
+        self._handover(0, 1, back=(1, 0))
         L(0); x0_1 = self._block("conv0_1", "", [x0_0A, x0_0B, self._up("Up1_0", x1_0B)], A("x0_1", 0, f[0]))
         L(1); x1_1 = self._block("conv1_1", "", [x1_0A, x1_0B, self._up("Up2_0", x2_0B)], A("x1_1", 1, f[1]))
         self._handover(1, 0, back=(0, 1))
