@@ -184,24 +184,27 @@ class SNUNetPlan:
         x4_0B = self._block("conv4_0", "B", [self._pool(x3_0B, "p3B")], A("x4_0B", 4, f[4]))
         self._handover(1, 0, back=(0, 1))                  # encoder | decoder: both lanes have everything of the other side
 
-        # Decoder on two lanes (LaunchList.run / StepStreams): lane 0 = the level-0 column blocks + the Up1_j transposed convolutions
-        # feeding them + the head, lane 1 = every deeper block and its Up.  Lane 1 needs the encoder only; lane 0 needs lane 1 through
+        # Decoder on two lanes (LaunchList.run / StepStreams): lane 0 = the level-0 column blocks + the head, lane 1 = every deeper block and the Ups
+        # leaving it (Up1_0, fed by the encoder, stays with lane 0).  Lane 1 needs the encoder only; lane 0 needs lane 1 through
         # x1_j -> Up1_j (forward) and lane 1 needs lane 0 through d Up1_j -> d x1_j (backward): three ordered hand-overs each way.
         # The level-0 blocks carry the large BatchNorm / elementwise passes (224^2 maps), the deeper blocks are convolution-bound.
         self._handover(0, 1, back=(1, 0))
         L(0); x0_1 = self._block("conv0_1", "", [x0_0A, x0_0B, self._up("Up1_0", x1_0B)], A("x0_1", 0, f[0]))
         L(1); x1_1 = self._block("conv1_1", "", [x1_0A, x1_0B, self._up("Up2_0", x2_0B)], A("x1_1", 1, f[1]))
+        u1_1 = self._up("Up1_1", x1_1)                      # (the Up1_j ride on lane 1 with their source block: lane 0 is the longer one)
         self._handover(1, 0, back=(0, 1))
-        L(0); x0_2 = self._block("conv0_2", "", [x0_0A, x0_0B, x0_1, self._up("Up1_1", x1_1)], A("x0_2", 0, f[0]))
+        L(0); x0_2 = self._block("conv0_2", "", [x0_0A, x0_0B, x0_1, u1_1], A("x0_2", 0, f[0]))
         L(1); x2_1 = self._block("conv2_1", "", [x2_0A, x2_0B, self._up("Up3_0", x3_0B)], A("x2_1", 2, f[2]))
         x1_2 = self._block("conv1_2", "", [x1_0A, x1_0B, x1_1, self._up("Up2_1", x2_1)], A("x1_2", 1, f[1]))
+        u1_2 = self._up("Up1_2", x1_2)
         self._handover(1, 0, back=(0, 1))
-        L(0); x0_3 = self._block("conv0_3", "", [x0_0A, x0_0B, x0_1, x0_2, self._up("Up1_2", x1_2)], A("x0_3", 0, f[0]))
+        L(0); x0_3 = self._block("conv0_3", "", [x0_0A, x0_0B, x0_1, x0_2, u1_2], A("x0_3", 0, f[0]))
         L(1); x3_1 = self._block("conv3_1", "", [x3_0A, x3_0B, self._up("Up4_0", x4_0B)], A("x3_1", 3, f[3]))
         x2_2 = self._block("conv2_2", "", [x2_0A, x2_0B, x2_1, self._up("Up3_1", x3_1)], A("x2_2", 2, f[2]))
         x1_3 = self._block("conv1_3", "", [x1_0A, x1_0B, x1_1, x1_2, self._up("Up2_2", x2_2)], A("x1_3", 1, f[1]))
+        u1_3 = self._up("Up1_3", x1_3)
         self._handover(1, 0, back=(0, 1))
-        L(0); x0_4 = self._block("conv0_4", "", [x0_0A, x0_0B, x0_1, x0_2, x0_3, self._up("Up1_3", x1_3)], A("x0_4", 0, f[0]))
+        L(0); x0_4 = self._block("conv0_4", "", [x0_0A, x0_0B, x0_1, x0_2, x0_3, u1_3], A("x0_4", 0, f[0]))
         self._head([x0_1, x0_2, x0_3, x0_4])
         self.acts = {a.name: a for a in (x0_0A, x0_0B, x1_0A, x1_0B, x3_0B, x4_0B, x0_1, x1_1, x0_2, x0_3, x0_4, x1_3, x3_1)}
 
