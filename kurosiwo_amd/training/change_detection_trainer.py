@@ -68,7 +68,7 @@ def train_change_detection(model, train_loader, val_loader, test_loader, configs
             if step is None or step.B != xA.shape[0]:
                 step = CDTrainStep(model, xA.shape[0], xA.shape[2], xA.shape[3], configs["loss_function"],
                                    configs.get("class_weights", [1.0, 1.0, 1.0]), optimizer=optimizer, graph=configs.get("hip_graph", False),
-                                   overlap_wgrad=configs.get("overlap_wgrad", True))
+                                   overlap_wgrad=configs.get("overlap_wgrad", True), overlap_lanes=configs.get("overlap_lanes", True))
             step.step(xA.to(dev, non_blocking=True), xB.to(dev, non_blocking=True), mask.to(dev, non_blocking=True))
             metrics.update(step.plan.logits, step.labels)
             loss_acc += step.loss_out
