@@ -345,6 +345,8 @@ def main():
         if solo and solo["n"]:
             hbm = res["roofline"]["bound"] == "hbm"
             s_ach = (solo["bytes"] / 1e9 if hbm else solo["flops"] / 1e12) / (solo["ms"] * 1e-3)
+            res["roofline"]["achieved_solo"] = round(s_ach, 1)
+            res["roofline"]["frac_solo"] = round(s_ach / (HBM_PEAK_GBS if hbm else MFMA_BF16_PEAK_TF), 4)
             res["roofline"]["solo"] = {"avg_launch_ms": round(solo["ms"] / solo["n"], 4), "achieved": round(s_ach, 1),
                                        "frac": round(s_ach / (HBM_PEAK_GBS if hbm else MFMA_BF16_PEAK_TF), 4), "launches_timed": solo["n"],
                                        "how": "same kernel class, single stream, steps run after the timed region"}

@@ -12,7 +12,7 @@ rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${TAG}_stats -o stats -- 
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $R/gpurun_out/prof_${TAG}_fetch -o fetch -- python $R/bench.py $ARGS > $R/gpurun_out/prof_${TAG}_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $R/gpurun_out/prof_${TAG}_write -o write -- python $R/bench.py $ARGS > $R/gpurun_out/prof_${TAG}_write.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $R/gpurun_out/prof_${TAG}_mfma -o mfma -- python $R/bench.py $ARGS > $R/gpurun_out/prof_${TAG}_mfma.log 2>&1
-# the same kernels alone on the machine: weight gradients back on the main stream (roofline.solo of the bench line)
-KSMI_OVERLAP_WGRAD=0 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${TAG}_solo_stats -o stats -- python $R/bench.py $ARGS > $R/gpurun_out/prof_${TAG}_solo.log 2>&1
+# the same kernels alone on the machine: one stream (roofline.solo / frac_solo of the bench line)
+KSMI_OVERLAP_WGRAD=0 KSMI_OVERLAP_LANES=0 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${TAG}_solo_stats -o stats -- python $R/bench.py $ARGS > $R/gpurun_out/prof_${TAG}_solo.log 2>&1
 cd $R
 du -sh gpurun_out/prof_${TAG}_* | head
