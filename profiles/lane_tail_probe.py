@@ -29,3 +29,12 @@ e1.record()
 torch.cuda.synchronize()
 print("step ms", e0.elapsed_time(e1) / 10)
 print("side finishes after main by (ms):", [round(a.elapsed_time(b), 3) for a, b in rec])
+import time
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(10):
+    st.step(xA, xB, y)
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+print("host issue ms/step", (t1 - t0) * 100, " wall ms/step", (t2 - t0) * 100)
