@@ -137,22 +137,23 @@ def _infer_hp(encoder, configs):
 
 
 class FinetunerSegmentation(ArenaModule):
-    """model_utilities.py:51-94 with the `decoder` head (:22-48, the FloodViT configuration of SURVEY.md §8 V5):
-    logits[B, num_classes, 224, 224] = Decoder(rearrange(ViT(x)[:, 1:], "b (h w) c -> b c h w"))."""
+    """model_utilities.py:51-94: logits[B, num_classes, 224, 224] = head(rearrange(ViT(x)[:, 1:], "b (h w) c -> b c h w")) with the
+    `decoder` head (:22-48, the FloodViT configuration of SURVEY.md §8 V5), the `mlp` head or the default 1x1 head (:59-72; both
+    after a bilinear resize to the image size, :88-93)."""
 
     def __init__(self, encoder, configs=None, pool=False, precision="bf16"):
         super().__init__()
         configs = dict(configs or {})
         if pool:
             raise NotImplementedError("pool=True (linear head on the mean token) is not part of the FloodViT path")
-        if not configs.get("decoder", True) or configs.get("mlp", False):
-            raise NotImplementedError("only the `decoder` head (model_utilities.py:66-69) is implemented")
+        # model_utilities.py:59-72: configs["mlp"] wins, then configs["decoder"], else one 1x1 convolution
+        self.head_kind = "mlp" if configs.get("mlp", False) else ("decoder" if configs.get("decoder", True) else "linear")
         self.configs, self.pool, self.precision = configs, pool, precision
         hp = _infer_hp(encoder, configs)
         self.hp = hp
         if hp["dim_head"] != 64:
             raise NotImplementedError("attention kernel is specialised for dim_head = 64 (vision_transformer.py:103)")
-        if hp["dim"] != 1024:
+        if hp["dim"] != 1024 and self.head_kind == "decoder":
             raise ValueError("Decoder.deconv1 hard-codes 1024 input channels (model_utilities.py:27)")
         self.num_classes = int(configs.get("num_classes", 3))
         ph, pw = hp["patch_size"]
@@ -160,12 +161,21 @@ class FinetunerSegmentation(ArenaModule):
         self.grid = (ih // ph, iw // pw)
         spec = vit_param_spec(hp["channels"] * ph * pw, self.grid[0] * self.grid[1], hp["dim"], hp["depth"], hp["heads"],
                               hp["dim_head"], hp["mlp_dim"], None, prefix="model.")
-        spec["head.deconv1.weight"] = (1024, 128, 4, 4)
-        spec["head.deconv1.bias"] = (128,)
-        spec["head.deconv2.weight"] = (128, 64, 4, 4)
-        spec["head.deconv2.bias"] = (64,)
-        spec["head.deconv3.weight"] = (64, self.num_classes, 4, 4)
-        spec["head.deconv3.bias"] = (self.num_classes,)
+        if self.head_kind == "mlp":                      # nn.Sequential(Conv2d(dim, 512, 1), ReLU, Conv2d(512, classes, 1))
+            spec["head.0.weight"] = (512, hp["dim"], 1, 1)
+            spec["head.0.bias"] = (512,)
+            spec["head.2.weight"] = (self.num_classes, 512, 1, 1)
+            spec["head.2.bias"] = (self.num_classes,)
+        elif self.head_kind == "linear":                 # nn.Conv2d(dim, classes, 1)
+            spec["head.weight"] = (self.num_classes, hp["dim"], 1, 1)
+            spec["head.bias"] = (self.num_classes,)
+        else:
+            spec["head.deconv1.weight"] = (1024, 128, 4, 4)
+            spec["head.deconv1.bias"] = (128,)
+            spec["head.deconv2.weight"] = (128, 64, 4, 4)
+            spec["head.deconv2.bias"] = (64,)
+            spec["head.deconv3.weight"] = (64, self.num_classes, 4, 4)
+            spec["head.deconv3.bias"] = (self.num_classes,)
         self._setup_arena(spec)
         # adopt the encoder weights; head: ConvTranspose2d default init (fan_in = weight.size(1) * k * k)
         esd = encoder.state_dict()
@@ -176,7 +186,7 @@ class FinetunerSegmentation(ArenaModule):
                     p.copy_(esd[key[6:]])
                 else:
                     w = spec[key.rsplit(".", 1)[0] + ".weight"]
-                    bound = 1 / math.sqrt(w[1] * 16)
+                    bound = 1 / math.sqrt(w[1] * w[2] * w[3])        # kaiming_uniform(a = sqrt 5): fan_in = weight.size(1) * k * k
                     p.uniform_(-bound, bound)
         if configs.get("linear_eval", False):            # model_utilities.py:160-161
             for key in spec:

@@ -12,8 +12,11 @@ def initialize_cd_model(configs, model_configs, phase="train"):
                             precision=configs.get("precision", "bf16" if configs.get("mixed_precision") else "fp32"))
     elif method == "changeformer":
         from .changeformer import ChangeFormerV6
-        if model_configs.get("multi_scale_train") or model_configs.get("multi_scale_infer"):
-            raise NotImplementedError("changeformer: multi_scale_train / multi_scale_infer (only output[-1] is used, the reference default)")
+        if model_configs.get("multi_scale_train"):
+            # change_detection_trainer.py:155-162 feeds the int64 [B,H,W] mask to F.interpolate(mode="nearest"), which raises
+            # ("compute_indices_weights_nearest" not implemented for 'Long'): the reference cannot run this branch either
+            raise NotImplementedError("changeformer: multi_scale_train (the reference's own branch raises on the int64 mask; "
+                                      "only the last output is differentiable here)")
         model = ChangeFormerV6(embed_dim=model_configs["embed_dim"], input_nc=configs["num_channels"], output_nc=configs["num_classes"],
                                decoder_softmax=model_configs["decoder_softmax"],
                                precision=configs.get("precision", "bf16" if configs.get("mixed_precision") else "fp32"))

@@ -24,6 +24,16 @@ from ..trainer import CDTrainStep
 CLASS_LABELS = {0: "No water", 1: "Permanent Waters", 2: "Floods", 3: "Invalid pixels"}
 
 
+def multi_scale_prediction(outputs):
+    """change_detection_trainer.py:139-146 (`multi_scale_infer`: train-time metric predictions only; the evaluation loop :394-395 always
+    takes output[-1]): the mean of the five ChangeFormer outputs, the coarse ones resized to the last one's size by nearest neighbour."""
+    size = outputs[-1].shape[2]
+    final = torch.zeros_like(outputs[-1])
+    for pred in outputs:
+        final = final + (torch.nn.functional.interpolate(pred, size=size, mode="nearest") if pred.shape[2] != size else pred)
+    return final / len(outputs)
+
+
 def _make_optimizer(model, configs, model_configs):
     if configs["method"] in ("bit-cd", "hfa-net") or model_configs.get("optimizer") == "sgd":
         return FusedSGD(model.parameters(), lr=model_configs["learning_rate"], momentum=model_configs.get("momentum", 0.0),
@@ -70,7 +80,10 @@ def train_change_detection(model, train_loader, val_loader, test_loader, configs
                                    configs.get("class_weights", [1.0, 1.0, 1.0]), optimizer=optimizer, graph=configs.get("hip_graph", False),
                                    overlap_wgrad=configs.get("overlap_wgrad", True), overlap_lanes=configs.get("overlap_lanes", True))
             step.step(xA.to(dev, non_blocking=True), xB.to(dev, non_blocking=True), mask.to(dev, non_blocking=True))
-            metrics.update(step.plan.logits, step.labels)
+            if configs["method"] == "changeformer" and model_configs.get("multi_scale_infer"):
+                metrics.update(multi_scale_prediction(step.plan.outputs), step.labels)
+            else:
+                metrics.update(step.plan.logits, step.labels)
             loss_acc += step.loss_out
             nb += 1
             if configs.get("on_screen_prints") and (index + 1) % configs["print_frequency"] == 0:

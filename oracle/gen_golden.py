@@ -250,21 +250,22 @@ FLOODVIT_GRAD_KEYS = [
 ]
 
 
-def _ref_floodvit(hp):
+def _ref_floodvit(hp, head="decoder"):
     ViT, FinetunerSegmentation = _import_floodvit_reference()
     enc = ViT(image_size=hp["image_size"], patch_size=hp["patch_size"], num_classes=1000, dim=hp["dim"], depth=hp["depth"],
               heads=hp["heads"], mlp_dim=hp["mlp_dim"], channels=hp["channels"])
-    cfg = {"mlp": False, "decoder": True, "num_classes": 3, "image_size": 224, "finetuning_patch_size": hp["patch_size"]}
+    cfg = {"mlp": head == "mlp", "decoder": head == "decoder", "num_classes": 3, "image_size": 224, "finetuning_patch_size": hp["patch_size"]}
     model = FinetunerSegmentation(encoder=enc, configs=cfg)
     seeded_fill_(model.state_dict())
     return model
 
 
-def gen_floodvit(tag, hp, B):
+def gen_floodvit(tag, hp, B, head="decoder"):
+    """head = "mlp" / "linear": the other two heads of FinetunerSegmentation (model_utilities.py:59-72) on the small encoder"""
     out = {}
     x = sar_like(f"floodvit.{tag}.x", (B, hp["channels"], 224, 224))
     lbl = seeded_labels(f"floodvit.{tag}.lbl", (B, 224, 224))
-    model = _ref_floodvit(hp)
+    model = _ref_floodvit(hp, head)
     model.train()
     out["state_dict_keys"] = np.array(list(model.state_dict().keys()))
     tokens = model.model(x)                                   # [B,196,1024] = ViT.forward with pool False
@@ -281,7 +282,7 @@ def gen_floodvit(tag, hp, B):
     for k, p in model.named_parameters():
         g = p.grad.detach().double()
         out[f"gstat.{k}"] = np.array([float(g.norm()), float(g.sum()), float(g.abs().max())])
-        if k in FLOODVIT_GRAD_KEYS:
+        if k in FLOODVIT_GRAD_KEYS or (head != "decoder" and k.startswith("head.")):
             out[f"grad.{k}"] = p.grad.detach().numpy().copy()
     print(f"floodvit_{tag} loss", float(loss), "logits absmax", float(logits.abs().max()))
     np.savez_compressed(os.path.join(OUT, f"floodvit_{tag}.npz"), **out)
@@ -689,6 +690,9 @@ if __name__ == "__main__":
     if not only or "floodvit" in only:
         gen_floodvit("small", FLOODVIT_SMALL, 2)
         gen_floodvit("full", FLOODVIT_FULL, 1)
+    if not only or "floodvit_heads" in only:
+        gen_floodvit("small_mlp", FLOODVIT_SMALL, 1, head="mlp")
+        gen_floodvit("small_linear", FLOODVIT_SMALL, 1, head="linear")
     if not only or "changeformer" in only:
         gen_changeformer()
     if not only or "changeformer_slc" in only:

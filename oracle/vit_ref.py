@@ -9,6 +9,7 @@ A functional, state-dict driven fp32 restatement on stock PyTorch-CPU ops of wha
   ViT.forward (pool False) vision_transformer.py:139-151   -> cls/pos, x[:, 1:]
   FinetunerSegmentation    model_utilities.py:80-94        -> rearrange b (h w) c -> b c h w
   Decoder.forward          model_utilities.py:36-48        -> _decoder
+  `mlp` / default heads    model_utilities.py:59-72,88-93  -> _head_1x1 (bilinear to 224^2 FIRST, then the 1x1 convolutions)
 
 Pinned to the real reference by tests/golden/floodvit_*.npz (oracle/gen_golden.py imports
 /root/reference/models/vision_transformer.py and model_utilities.py here).  Only tests/, smoke() and
@@ -21,8 +22,9 @@ import torch.nn.functional as F
 
 
 def floodvit_state_dict_spec(channels=6, image_size=224, patch_size=16, dim=1024, depth=24, heads=16, dim_head=64,
-                             mlp_dim=2048, num_classes=3):
-    """Keys/shapes of FinetunerSegmentation(ViT(...), {'decoder': True}).state_dict() (mlp_head is nn.Identity)."""
+                             mlp_dim=2048, num_classes=3, head="decoder"):
+    """Keys/shapes of FinetunerSegmentation(ViT(...), {'decoder': True}).state_dict() (mlp_head is nn.Identity); head = "mlp" /
+    "linear": the configs {'mlp': True} / {'mlp': False, 'decoder': False} of model_utilities.py:59-72."""
     inner = heads * dim_head
     npatch = (image_size // patch_size) ** 2
     pd = channels * patch_size * patch_size
@@ -50,6 +52,16 @@ def floodvit_state_dict_spec(channels=6, image_size=224, patch_size=16, dim=1024
         s[f"{f}.net.1.bias"] = (mlp_dim,)
         s[f"{f}.net.4.weight"] = (dim, mlp_dim)
         s[f"{f}.net.4.bias"] = (dim,)
+    if head == "mlp":
+        s["head.0.weight"] = (512, dim, 1, 1)
+        s["head.0.bias"] = (512,)
+        s["head.2.weight"] = (num_classes, 512, 1, 1)
+        s["head.2.bias"] = (num_classes,)
+        return s
+    if head == "linear":
+        s["head.weight"] = (num_classes, dim, 1, 1)
+        s["head.bias"] = (num_classes,)
+        return s
     s["head.deconv1.weight"] = (1024, 128, 4, 4)
     s["head.deconv1.bias"] = (128,)
     s["head.deconv2.weight"] = (128, 64, 4, 4)
@@ -103,6 +115,19 @@ def _decoder(sd, x):
     return F.conv_transpose2d(x, sd["head.deconv3.weight"], sd["head.deconv3.bias"], stride=2, padding=1)
 
 
+def _head_1x1(sd, x, size, masks=None, inter=None):
+    """model_utilities.py:88-93: nn.Upsample(size, mode='bilinear') on the [B,1024,14,14] map, then `head` = Conv1x1 -> ReLU -> Conv1x1
+    (`mlp`) or one Conv1x1 (default).  masks = {"h": bool} replaces the ReLU by x * mask (see floodvit_forward)."""
+    x = F.interpolate(x, size=size, mode="bilinear")
+    if "head.0.weight" in sd:
+        h = F.conv2d(x, sd["head.0.weight"], sd["head.0.bias"])
+        if inter is not None:
+            inter["h"] = h
+        h = F.relu(h) if masks is None else h * masks["h"]
+        return F.conv2d(h, sd["head.2.weight"], sd["head.2.bias"])
+    return F.conv2d(x, sd["head.weight"], sd["head.bias"])
+
+
 def floodvit_forward(sd, img, heads, patch_size=16, return_tokens=False, inter=None, masks=None):
     """`inter` (optional dict) receives the intermediate activations the GPU tests compare against.  `masks` (optional
     {"d1": bool, "d2": bool}) replaces the two Decoder ReLUs by x * mask: a pre-activation within rounding distance of 0
@@ -125,6 +150,10 @@ def floodvit_forward(sd, img, heads, patch_size=16, return_tokens=False, inter=N
         return x
     g = img.shape[2] // patch_size
     x = x.reshape(B, g, img.shape[3] // patch_size, D).permute(0, 3, 1, 2)
+    if "head.deconv1.weight" not in sd:
+        if inter is not None:
+            inter["feat"] = x
+        return _head_1x1(sd, x, tuple(img.shape[2:]), masks, inter)
     if inter is None and masks is None:
         return _decoder(sd, x)
     d1 = F.conv_transpose2d(x, sd["head.deconv1.weight"], sd["head.deconv1.bias"], stride=2, padding=1)

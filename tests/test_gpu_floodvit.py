@@ -19,14 +19,14 @@ def sar_like(name, shape):
     return seeded_tensor(name, shape).clamp_(-2.23, 5.75)
 
 
-def build(hp, precision):
+def build(hp, precision, head="decoder"):
     from kurosiwo_amd.floodvit import FinetunerSegmentation, ViT
     from oracle import vit_ref as V
     from oracle.seeded import seeded_fill_
     enc = ViT(image_size=hp["image_size"], patch_size=hp["patch_size"], num_classes=1000, dim=hp["dim"], depth=hp["depth"],
               heads=hp["heads"], mlp_dim=hp["mlp_dim"], channels=hp["channels"])
-    model = FinetunerSegmentation(enc, CFG, precision=precision)
-    sd = seeded_fill_(V.new_state_dict(**hp))
+    model = FinetunerSegmentation(enc, dict(CFG, mlp=head == "mlp", decoder=head == "decoder"), precision=precision)
+    sd = seeded_fill_(V.new_state_dict(**hp, head=head))
     assert list(model.state_dict().keys()) == list(sd.keys())
     model.load_state_dict(sd)
     return model.cuda().train(), sd
@@ -152,3 +152,49 @@ def test_main_entry_finetune_end_to_end_tiny(tmp_path, monkeypatch):
     miou = entry.main(["--method", "finetune", "--inputs", "pre_event_1", "pre_event_2", "post_event", "--batch_size", "4"])
     assert 0.0 <= miou <= 100.0
     assert (tmp_path / "checkpoints" / "vit" / "best_segmentation.pt").exists()
+
+
+@pytest.mark.parametrize("head,precision", [("mlp", "fp32"), ("mlp", "bf16"), ("linear", "fp32"), ("linear", "bf16")])
+def test_mlp_and_default_heads_vs_oracle_and_golden(golden_dir, head, precision):
+    """FinetunerSegmentation's other heads (model_utilities.py:59-72,88-93: bilinear to 224^2, then Conv1x1 [-> ReLU -> Conv1x1]).  The
+    HIP path runs the first 1x1 convolution BEFORE the interpolation (they commute); the oracle keeps the reference's order."""
+    from oracle import vit_ref as V
+    from oracle.seeded import seeded_labels
+    hp, B = SMALL, 1
+    gold = np.load(os.path.join(golden_dir, f"floodvit_small_{head}.npz"))
+    model, sd = build(hp, precision, head)
+    assert list(gold["state_dict_keys"]) == list(model.state_dict().keys())
+    x = sar_like(f"floodvit.small_{head}.x", (B, 6, 224, 224))
+    lbl = seeded_labels(f"floodvit.small_{head}.lbl", (B, 224, 224))
+    inter = {}
+    with torch.no_grad():
+        ref_logits = V.floodvit_forward(sd, x, hp["heads"], inter=inter)
+    logits = model(x.cuda())
+    plan = model.plan(B, True, True)
+    assert relerr(logits.detach().float().cpu(), ref_logits) < (2e-4 if precision == "fp32" else 6e-2)
+    if precision == "fp32":
+        assert np.abs(logits.detach().cpu()[:, :, ::8, ::8].numpy() - gold["logits_sub"]).max() < 2e-3
+    loss = torch.nn.functional.cross_entropy(logits, lbl.cuda(), weight=torch.tensor(CLASS_WEIGHTS, device="cuda"), ignore_index=3)
+    loss.backward()
+    masks = None
+    if head == "mlp":          # the oracle backward runs on the GPU's ReLU active set (oracle/vit_ref.py: masks)
+        masks = {"h": (to_nchw(plan.named["h"]) > 0).float()}
+    _, ref_loss, ref_grads = V.loss_and_grads(sd, x, lbl, hp["heads"], CLASS_WEIGHTS, masks=masks)
+    assert abs(float(loss) - ref_loss) < (1e-4 if precision == "fp32" else 3e-2)
+    if precision == "fp32":
+        assert abs(ref_loss - float(gold["loss"])) < 1e-5
+    worst = {}
+    for k, p in model.named_parameters():
+        g, r = p.grad.detach().float().cpu(), ref_grads[k]
+        if precision == "fp32":
+            e = float((g - r).abs().max() / (r.abs().max() + 1e-12))
+            l2 = float((g - r).double().norm() / (r.double().norm() + 1e-30))
+            if not (l2 < 1e-3 and e < 2e-3):
+                worst[k] = (e, l2)
+            ref = gold[f"gstat.{k}"]
+            assert abs(float(g.double().norm()) - ref[0]) <= 2e-3 * ref[0] + 1e-7, k
+        else:
+            cos = float((g.double() * r.double()).sum() / (g.double().norm() * r.double().norm() + 1e-30))
+            if not cos > 0.98:
+                worst[k] = cos
+    assert not worst, f"{head} {precision}: {worst}"

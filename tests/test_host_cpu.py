@@ -118,3 +118,21 @@ def test_mae_learning_rate_schedule_and_config():
     mc = load_json5(os.path.join(root, "configs/method/mae/mae.json"))
     assert (mc["dim"], mc["depth"], mc["heads"], mc["mlp_dim"], mc["decoder_dim"], mc["decoder_depth"], mc["decoder_heads"]) == (1024, 24, 16, 2048, 512, 8, 16)
     assert mc["masked_ratio"] == 0.75 and mc["accumulate_gradients"] == 4 and mc["warmup_epochs"] == 10
+
+
+def test_multi_scale_prediction_and_factory_guards():
+    """change_detection_trainer.py:139-146: mean of the five outputs, coarse ones nearest-resized; `multi_scale_train` is refused with the
+    reason (the reference branch :155-162 raises on the int64 mask), `multi_scale_infer` is accepted."""
+    import torch
+    from kurosiwo_amd.training.change_detection_trainer import multi_scale_prediction
+    g = torch.Generator().manual_seed(3)
+    outs = [torch.randn(2, 3, s, s, generator=g) for s in (7, 14, 28, 56, 224)]
+    got = multi_scale_prediction(outs)
+    want = sum(o.repeat_interleave(224 // o.shape[2], 2).repeat_interleave(224 // o.shape[3], 3) for o in outs) / 5    # nearest at integer factors
+    assert got.shape == (2, 3, 224, 224) and torch.allclose(got, want, atol=1e-6)
+    with pytest.raises(NotImplementedError, match="Long|int64"):     # what the reference's multi_scale_train line does
+        torch.nn.functional.interpolate(torch.zeros(2, 8, 8, dtype=torch.long), size=4, mode="nearest")
+    from kurosiwo_amd.model_utilities import initialize_cd_model
+    with pytest.raises(NotImplementedError, match="multi_scale_train"):
+        initialize_cd_model({"method": "changeformer", "num_channels": 2, "num_classes": 3, "device": "cpu"},
+                            {"embed_dim": 256, "decoder_softmax": False, "multi_scale_train": True, "multi_scale_infer": False})

@@ -29,13 +29,15 @@ def test_state_dict_inventory():
     assert n == enc + 1024 * 128 * 16 + 128 + 128 * 64 * 16 + 64 + 64 * 3 * 16 + 3
 
 
-@pytest.mark.parametrize("tag,hp,B", [("small", SMALL, 2), ("full", FULL, 1)])
-def test_oracle_matches_reference_golden(golden_dir, tag, hp, B):
+@pytest.mark.parametrize("tag,hp,B,head", [("small", SMALL, 2, "decoder"), ("full", FULL, 1, "decoder"),
+                                           ("small_mlp", SMALL, 1, "mlp"), ("small_linear", SMALL, 1, "linear")])
+def test_oracle_matches_reference_golden(golden_dir, tag, hp, B, head):
+    """head = "mlp" / "linear": FinetunerSegmentation's other two heads (model_utilities.py:59-72; bilinear to 224^2, then 1x1 convs)"""
     torch.set_num_threads(min(8, torch.get_num_threads()))      # many small ops: more threads only add sync overhead
     gold = np.load(os.path.join(golden_dir, f"floodvit_{tag}.npz"))
-    spec = V.floodvit_state_dict_spec(**hp)
+    spec = V.floodvit_state_dict_spec(**hp, head=head)
     assert list(gold["state_dict_keys"]) == list(spec.keys())
-    sd = seeded_fill_(V.new_state_dict(**hp))
+    sd = seeded_fill_(V.new_state_dict(**hp, head=head))
     x = sar_like(f"floodvit.{tag}.x", (B, hp["channels"], 224, 224))
     lbl = seeded_labels(f"floodvit.{tag}.lbl", (B, 224, 224))
     with torch.no_grad():
