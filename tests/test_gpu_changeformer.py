@@ -80,7 +80,11 @@ def test_eval_forward_vs_oracle_and_golden(golden_dir):
         assert np.abs(outs[i].cpu().numpy() - gold[f"eval.out{i}"]).max() < 1e-3
     assert np.abs(outs[4].cpu()[:, :, ::8, ::8].numpy() - gold["eval.out4_sub"]).max() < 1e-3
     confident = gold["eval.margin"].astype(np.float32) > 2e-3
-    assert (outs[4].argmax(1).cpu().numpy().astype(np.uint8) == gold["eval.argmax"])[confident].all()
+    am = outs[4].argmax(1).cpu().numpy().astype(np.uint8)
+    assert (am == gold["eval.argmax"])[confident].all()
+    mism, inband = int((am != gold["eval.argmax"]).sum()), int((~confident).sum())
+    print(f"changeformer eval argmax: {mism} mismatches of {am.size}, all among the {inband} pixels inside the 2e-3 margin")
+    assert mism <= 8, (mism, inband, am.size)   # bounded, not just excluded
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])

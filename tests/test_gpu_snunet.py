@@ -120,7 +120,9 @@ def test_fp32_full_size_golden(dev, golden_dir):
     decisive = margin > 1e-3 * scale
     mism = int((am != gold["eval_argmax"]).sum())
     assert (am[decisive] == gold["eval_argmax"][decisive]).all()
-    print(f"full-size: logits rel err {rel:.2e}; argmax mismatches {mism} of {am.size} (all inside the {1e-3 * scale:.1e} margin)")
+    inband = int((~decisive).sum())
+    print(f"full-size: logits rel err {rel:.2e}; argmax mismatches {mism} of {am.size} (all inside the {1e-3 * scale:.1e} margin, {inband} pixels)")
+    assert mism <= 8, (mism, inband, am.size)   # in-band disagreements: bounded, not just printed
 
 
 def test_fp32_full_size_train_golden(dev, golden_dir):
