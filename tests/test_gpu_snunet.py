@@ -46,7 +46,7 @@ def test_fp32_eval_logits(dev, c, bc, B, H, W):
     assert rel < 5e-5, rel
 
 
-@pytest.mark.parametrize("c,bc,B,H,W", [(2, 16, 2, 32, 32), (3, 16, 2, 32, 48)])
+@pytest.mark.parametrize("c,bc,B,H,W", [(2, 16, 2, 32, 32), (3, 16, 2, 32, 48), (3, 32, 1, 224, 224)])   # the last: configs[2] (VV, VH, DEM) at tile size
 def test_fp32_train_step_matches_oracle(dev, c, bc, B, H, W):
     from kurosiwo_amd.loss import BCEandDiceLoss
     from kurosiwo_amd.optim import FusedAdam
@@ -150,7 +150,7 @@ def test_fp32_full_size_train_golden(dev, golden_dir):
         assert np.abs(g - gold[f"grad.{k}"]).max() < 5e-3 * np.abs(gold[f"grad.{k}"]).max() + 1e-7, k
 
 
-@pytest.mark.parametrize("c,bc,B,H,W", [(2, 32, 2, 64, 64)])
+@pytest.mark.parametrize("c,bc,B,H,W", [(2, 32, 2, 64, 64), (3, 32, 2, 224, 224)])      # the second: BASELINE.json configs[2] (VV, VH, DEM) at tile size
 def test_bf16_train_step_close_to_oracle(dev, c, bc, B, H, W):
     from kurosiwo_amd.loss import BCEandDiceLoss
     tag = f"bf{c}{bc}{B}{H}{W}"
@@ -171,7 +171,9 @@ def test_bf16_train_step_close_to_oracle(dev, c, bc, B, H, W):
         g, r = p.grad.cpu().flatten().double(), ref_grads[k].flatten().double()
         if float(r.norm()) > 1e-6:
             cos.append(float((g @ r) / (g.norm() * r.norm() + 1e-30)))
-    assert np.median(cos) > 0.98, np.median(cos)
+    # (two tiles per BatchNorm batch at 224^2: the statistics of the deep 14^2 maps amplify bf16 rounding; bs=32 is pinned to the
+    # reference golden in test_bf16_at_the_benchmarked_size_vs_reference_golden with min cosine > 0.97)
+    assert np.median(cos) > (0.98 if H <= 64 else 0.96), np.median(cos)
     print(f"bf16: logits rel err {rel:.3e}, median grad cosine {np.median(cos):.4f}, min {min(cos):.4f}")
 
 
