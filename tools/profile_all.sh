@@ -17,7 +17,7 @@ for m in changeformer floodvit; do
   rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $R/gpurun_out/prof_${TAG}_${m}_mfma -o mfma -- python $R/bench.py --model $m --steps 3 --warmup 2 --no-cpu-baseline --no-solo >> $R/gpurun_out/prof_${TAG}_$m.log 2>&1
 done
 cd $R
-python profiles/summarize.py gpurun_out/prof_${TAG} gpurun_out/${TAG}_snunet_summary.md "SNUNet-ECAM bs=32 bf16 train step" "python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-solo" gpurun_out/${TAG}_snunet_traffic.json >> gpurun_out/prof_${TAG}.log 2>&1
+python profiles/summarize.py gpurun_out/prof_${TAG} gpurun_out/${TAG}_snunet_summary.md "SNUNet-ECAM bs=32 bf16 train step on THREE HIP streams (kernel durations overlap: their sum exceeds the step; single-stream durations: r02_snunet_solo_summary.md)" "python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-solo" gpurun_out/${TAG}_snunet_traffic.json >> gpurun_out/prof_${TAG}.log 2>&1
 python profiles/summarize.py gpurun_out/prof_${TAG}_solo gpurun_out/${TAG}_snunet_solo_summary.md "SNUNet-ECAM bs=32 bf16 train step on ONE stream (KSMI_OVERLAP_WGRAD=0 KSMI_OVERLAP_LANES=0)" "KSMI_OVERLAP_WGRAD=0 KSMI_OVERLAP_LANES=0 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-solo" >> gpurun_out/prof_${TAG}.log 2>&1
 for m in changeformer floodvit unet mae; do
   python profiles/summarize.py gpurun_out/prof_${TAG}_$m gpurun_out/${TAG}_${m}_summary.md "$m train step (bench.py --model $m)" "python bench.py --model $m --steps 3 --warmup 2 --no-cpu-baseline --no-solo" >> gpurun_out/prof_${TAG}.log 2>&1
