@@ -281,7 +281,7 @@ def main():
         for _ in range(timer_steps):
             step.run()
         sync()
-    # With the side lane on (trainer.py overlap_wgrad) the launches timed above shared the machine with the weight-gradient lane, so
+    # With more than one stream (trainer.py overlap_wgrad / overlap_lanes) the launches timed above shared the machine with the other streams, so
     # their durations -- and the roofline block below, which is defined over the timed region -- describe the overlapped step, not
     # the kernel.  A few more steps with the lane off give the same kernel class alone on the machine ("solo").
     solo = None

@@ -12,7 +12,7 @@ LN_EPS = 1e-5
 
 
 class PlanBase:
-    # Weight-gradient launches may run on the train step's side lane (trainer.py overlap_wgrad) only in plans where (a) every user of
+    # Weight-gradient launches may run on the train step's side stream (trainer.py overlap_wgrad, snunet_plan.StepStreams) only in plans where (a) every user of
     # the "wgrad" scratch goes through _wgrad (true here: the lane keeps them in order) and (b) no operand of a weight gradient is
     # rewritten by a later launch of the same backward pass.  (b) holds for the convolutional plans, whose activations and gradients
     # are dedicated buffers; the token plans (ChangeFormer encoder, FloodViT, MAE) recycle their per-block gradient buffers.
@@ -116,7 +116,7 @@ class PlanBase:
         meta = {"kind": f"igemm_wgrad<{d.KH}x{d.KW}s{d.stride}>", "bytes": (pin * ktot + pout * d.N) * es + taps * ktot * d.N * 4,
                 "flops": 2 * pout * d.N * ktot * taps, "tag": f"{key} K={ktot} N={d.N} M={pout}"}
         if self.side_wgrad:
-            meta["side"] = True              # snunet_plan.LaunchList.run: eligible for the side lane
+            meta["side"] = True              # snunet_plan.LaunchList.run: eligible for the side stream
         self.bwd.add("ksmi_conv_wgrad", lambda: (C.byref(d), self.dt), meta)
         self._mark(key)
 

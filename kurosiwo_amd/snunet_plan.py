@@ -326,7 +326,7 @@ class SNUNetPlan:
         meta = {"kind": f"igemm_wgrad<{d.KH}x{d.KW}s{d.stride}>", "bytes": (pin * ktot + pout * d.N) * es + taps * ktot * d.N * 4,
                 "flops": 2 * pout * d.N * ktot * taps}
         meta["tag"] = f"{keys[0] if keys else '?'} K={ktot} N={d.N} {d.Hout}x{d.Wout}"
-        meta["side"] = True                  # off the critical path: eligible for the side lane (LaunchList.run)
+        meta["side"] = True                  # off the critical path: eligible for the side stream (LaunchList.run)
         self.bwd.add("ksmi_conv_wgrad", lambda: (C.byref(d), self.dt), meta)
         self._mark(*keys)
 
