@@ -73,13 +73,20 @@ TRAFFIC_KERNELS = {
     "igemm_wgrad<3x3s1>": ("wgrad3_kernel", "wgrad3_reduce_kernel", "igemm_wgrad_kernel<bf16, 2, 3, 3", "wgrad_reduce_kernel"),
     "igemm_fwd<3x3s1,BN32>": ("igemm2_fwd_kernel<bf16, 2, 3, 3", "igemm3_kernel<3, 3"),
     "igemm_dgrad<3x3s1,BN32>": ("igemm2_fwd_kernel<bf16, 2, 3, 3", "igemm3_kernel<3, 3"),
+    # the other families (profiles/r02_<model>_traffic.json)
+    # ("igemm_conv3x3<3x3s1>" of ChangeFormer / BIT-CD is left unmapped: its forward launches share kernel names with the input
+    # gradients of very different sizes, so a per-kernel-name mean does not describe the class; per-kernel bytes are in the summary)
+    "igemm_conv3x3_dgrad<3x3s1>": ("igemm2_fwd_kernel<bf16, 2, 3, 3", "igemm3_kernel<3, 3"),
+    "igemm_wgrad<1x1s1>": ("gemm2_tn_kernel", "tn_reduce_kernel", "igemm_wgrad_kernel<bf16, 4, 1, 1", "igemm_wgrad_kernel<bf16, 2, 1, 1", "wgrad_reduce_kernel"),
 }
+TRAFFIC_FILE = {"snunet": "snunet", "changeformer": "changeformer", "floodvit": "floodvit", "unet": "unet", "mae": "mae"}
 
 
-def measured_traffic(kind):
-    """HBM bytes per launch of the dominant kernel class from the committed PMC table (None when there is none for this class):
-    call-weighted mean of 2 x FETCH_SIZE + WRITE_SIZE over the class's kernels (x2: the guide's gfx950 FETCH_SIZE correction)."""
-    path = os.path.join(ROOT, "profiles", "r02_snunet_traffic.json")
+def measured_traffic(kind, model="snunet"):
+    """HBM bytes per launch of the dominant kernel class from the committed PMC table of the model family (None when there is none for
+    this class): call-weighted mean of 2 x FETCH_SIZE + WRITE_SIZE over the class's kernels (x2: the guide's gfx950 FETCH_SIZE
+    correction)."""
+    path = os.path.join(ROOT, "profiles", f"r02_{TRAFFIC_FILE.get(model, model)}_traffic.json")
     if kind not in TRAFFIC_KERNELS or not os.path.exists(path):
         return None
     tab = json.load(open(path))["kernels"]
@@ -329,7 +336,7 @@ def main():
                           "unit": "GB/s", "frac": round(ach_gbs / HBM_PEAK_GBS, 4)}) | {
                          # HBM bytes per launch by the PMC counters (2 x FETCH_SIZE + WRITE_SIZE, profiles/r02_snunet_traffic.json; the forward
                          # and input-gradient classes share their kernels, so the table row is their common mean) next to the algorithmic bytes
-                         "traffic": measured_traffic(dominant), "traffic_unit": "bytes/launch",
+                         "traffic": measured_traffic(dominant, args.model), "traffic_unit": "bytes/launch",
                          "algorithmic_bytes_per_launch": round(d["bytes"] / max(d["n"], 1)),
                          "launches_timed": d["n"], "avg_launch_ms": round(avg_ms, 4),
                          "share_of_step": round((d["ms"] / timer_steps) / (dt * 1e3 / args.steps), 3),

@@ -12,20 +12,25 @@ cd /tmp && export TMPDIR=/tmp
 for m in changeformer floodvit unet mae; do
   rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${TAG}_${m}_stats -o stats -- python $R/bench.py --model $m --steps 3 --warmup 2 --no-cpu-baseline --no-solo > $R/gpurun_out/prof_${TAG}_$m.log 2>&1
 done
-# MFMA-busy counters of the two transformer-heavy families (own pass: --pmc only with --kernel-trace)
-for m in changeformer floodvit; do
+# HBM traffic counters of the other families (own passes: --pmc only with --kernel-trace; FETCH_SIZE and WRITE_SIZE do not fit one pass)
+for m in changeformer floodvit unet mae; do
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $R/gpurun_out/prof_${TAG}_${m}_fetch -o fetch -- python $R/bench.py --model $m --steps 3 --warmup 2 --no-cpu-baseline --no-solo >> $R/gpurun_out/prof_${TAG}_$m.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $R/gpurun_out/prof_${TAG}_${m}_write -o write -- python $R/bench.py --model $m --steps 3 --warmup 2 --no-cpu-baseline --no-solo >> $R/gpurun_out/prof_${TAG}_$m.log 2>&1
+done
+# MFMA-busy counters (own pass)
+for m in changeformer floodvit unet mae; do
   rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $R/gpurun_out/prof_${TAG}_${m}_mfma -o mfma -- python $R/bench.py --model $m --steps 3 --warmup 2 --no-cpu-baseline --no-solo >> $R/gpurun_out/prof_${TAG}_$m.log 2>&1
 done
 cd $R
 python profiles/summarize.py gpurun_out/prof_${TAG} gpurun_out/${TAG}_snunet_summary.md "SNUNet-ECAM bs=32 bf16 train step on THREE HIP streams (kernel durations overlap: their sum exceeds the step; single-stream durations: r02_snunet_solo_summary.md)" "python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-solo" gpurun_out/${TAG}_snunet_traffic.json >> gpurun_out/prof_${TAG}.log 2>&1
 python profiles/summarize.py gpurun_out/prof_${TAG}_solo gpurun_out/${TAG}_snunet_solo_summary.md "SNUNet-ECAM bs=32 bf16 train step on ONE stream (KSMI_OVERLAP_WGRAD=0 KSMI_OVERLAP_LANES=0)" "KSMI_OVERLAP_WGRAD=0 KSMI_OVERLAP_LANES=0 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-solo" >> gpurun_out/prof_${TAG}.log 2>&1
 for m in changeformer floodvit unet mae; do
-  python profiles/summarize.py gpurun_out/prof_${TAG}_$m gpurun_out/${TAG}_${m}_summary.md "$m train step (bench.py --model $m)" "python bench.py --model $m --steps 3 --warmup 2 --no-cpu-baseline --no-solo" >> gpurun_out/prof_${TAG}.log 2>&1
+  python profiles/summarize.py gpurun_out/prof_${TAG}_$m gpurun_out/${TAG}_${m}_summary.md "$m train step (bench.py --model $m)" "python bench.py --model $m --steps 3 --warmup 2 --no-cpu-baseline --no-solo" gpurun_out/${TAG}_${m}_traffic.json >> gpurun_out/prof_${TAG}.log 2>&1
 done
 python $R/profiles/stream_probe.py 2>&1 | grep MiB > $R/gpurun_out/${TAG}_stream_probe.txt
 python $R/profiles/gemm_probe.py 2>&1 | grep rows > $R/gpurun_out/${TAG}_gemm_probe.txt
 python $R/tools/gemm_durations.py gpurun_out/prof_${TAG}_floodvit_stats/stats_results.db > $R/gpurun_out/${TAG}_floodvit_gemm_durations.txt 2>&1
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29519 $R/bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline --no-solo > $R/gpurun_out/${TAG}_torchrun_stdout.txt 2> $R/gpurun_out/${TAG}_torchrun_stderr.txt
 # the raw rocpd databases are tens of MiB each and gpurun merges at most 64 MiB back: keep the summaries, drop the databases
-rm -rf gpurun_out/prof_${TAG}_solo_stats gpurun_out/prof_${TAG}_stats gpurun_out/prof_${TAG}_fetch gpurun_out/prof_${TAG}_write gpurun_out/prof_${TAG}_mfma gpurun_out/prof_${TAG}_*_stats gpurun_out/prof_${TAG}_*_mfma
+rm -rf gpurun_out/prof_${TAG}_*_fetch gpurun_out/prof_${TAG}_*_write gpurun_out/prof_${TAG}_solo_stats gpurun_out/prof_${TAG}_stats gpurun_out/prof_${TAG}_fetch gpurun_out/prof_${TAG}_write gpurun_out/prof_${TAG}_mfma gpurun_out/prof_${TAG}_*_stats gpurun_out/prof_${TAG}_*_mfma
 du -sh gpurun_out; ls gpurun_out | grep ${TAG}_ | head -40
