@@ -13,6 +13,7 @@
 #include "igemm_epilogue.h"
 #include "wgrad3.h"
 #include "igemm3.h"
+#include "igemm4.h"
 
 namespace {
 
@@ -933,6 +934,8 @@ int ksmi_conv_stats_rows(const ksmi_conv_desc* d, int dtype) {
   if (!c.stats) c.stats = (float*)(uintptr_t)16;     // the answer is for the launch WITH statistics
   ksmi_igemm3_geom_t g3;
   if (ksmi_igemm3_geom(&c, dtype, &g3)) return g3.gx;
+  ksmi_igemm4_geom_t g4;
+  if (ksmi_igemm4_geom(&c, dtype, &g4)) return g4.gx;
   return ksmi_conv_grid_m(d);
 }
 
@@ -946,6 +949,10 @@ int ksmi_conv_forward(const ksmi_conv_desc* d, int dtype, void* stream) {
     ksmi_igemm3_geom_t g3;
     if (!force_v1 && ksmi_igemm3_geom(d, dtype, &g3) && (d->stats == nullptr || d->stats_rows == g3.gx))
       return ksmi_igemm3_launch(d, &g3, (hipStream_t)stream);
+    // long K, >= 64 output channels, 3x3: persistent workgroups with halo / weight rings (igemm4.hip); same statistics-row rule
+    ksmi_igemm4_geom_t g4;
+    if (!force_v1 && ksmi_igemm4_geom(d, dtype, &g4) && (d->stats == nullptr || d->stats_rows == g4.gx))
+      return ksmi_igemm4_launch(d, &g4, (hipStream_t)stream);
   }
   if (d->stats && d->stats_rows != 0 && d->stats_rows != ksmi_conv_grid_m(d))
     return ksmi_fail(KSMI_E_ARG, "conv: stats_rows does not match the kernel this descriptor runs on (set it from ksmi_conv_stats_rows)");

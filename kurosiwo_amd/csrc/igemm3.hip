@@ -20,6 +20,7 @@
 #include "errors.h"
 #include "igemm_epilogue.h"
 #include "igemm3.h"
+#include "dma.h"
 
 namespace {
 
@@ -33,34 +34,6 @@ struct Ig3Args {
   int ns;                          // LDS stages: 3 (two tiles in flight) when they fit, else 2
   const unsigned char* zero;       // >= 16 zero bytes (positions outside the image read them)
 };
-
-// LDS-DMA from inline asm (lane i lands at dst_wave_base + 16 * i): the compiler does not see it, so it neither drains it at a
-// barrier nor in front of an unrelated global load, and TWO tiles can stay in flight; completion is waited for with a counted
-// vmcnt (every tile issues the same number of DMA instructions per wave: positions outside the image read the zero page).
-__device__ __forceinline__ void glds16_flat(const unsigned char* src, unsigned dst_wave_base) {
-  unsigned keep;
-  dst_wave_base = __builtin_amdgcn_readfirstlane(dst_wave_base);
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(src), "s"(dst_wave_base) : "memory");
-}
-// wait until at most n vector-memory operations of this wave are outstanding (n = DMA instructions of the tiles issued later)
-__device__ __forceinline__ void vm_wait(int n) {
-#define KSMI_VMW(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
-  switch (n) {
-    KSMI_VMW(1) KSMI_VMW(2) KSMI_VMW(3) KSMI_VMW(4) KSMI_VMW(5) KSMI_VMW(6) KSMI_VMW(7) KSMI_VMW(8) KSMI_VMW(9) KSMI_VMW(10)
-    KSMI_VMW(11) KSMI_VMW(12) KSMI_VMW(13) KSMI_VMW(14) KSMI_VMW(15) KSMI_VMW(16) KSMI_VMW(17) KSMI_VMW(18) KSMI_VMW(19) KSMI_VMW(20)
-    KSMI_VMW(21) KSMI_VMW(22) KSMI_VMW(23) KSMI_VMW(24) KSMI_VMW(25) KSMI_VMW(26) KSMI_VMW(27) KSMI_VMW(28) KSMI_VMW(29) KSMI_VMW(30)
-    KSMI_VMW(31) KSMI_VMW(32)
-    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-  }
-#undef KSMI_VMW
-}
-// workgroup barrier that does NOT drain vector memory: LDS operations of this wave complete, then s_barrier
-__device__ __forceinline__ void lds_barrier() {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-}
 
 template <int KH, int KW, int NCH, int WN, bool AFF, int NTI, bool MASK>
 __global__ __launch_bounds__(256 * WN, (WN == 1 && NCH * KH * KW * NTI <= 9) ? 2 : 1) void igemm3_kernel(const Ig3Args ka) {

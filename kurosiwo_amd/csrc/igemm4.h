@@ -1,0 +1,16 @@
+// igemm4.hip: persistent implicit-GEMM 3x3 convolution for LONG K (>= 2 k-chunks) and >= 64 output channels, bf16:
+// halo ring + weight ring filled by asm LDS-DMA with counted vmcnt, one raw barrier per kernel row of taps.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/ksmi.h"
+
+struct ksmi_igemm4_geom_t {
+  int WM, NF;           // pixel groups of 64 (4 | 8; column groups = 8 / WM); 16-column MFMA fragments per wave (2 | 4)
+  int th, tw;           // output patch of a workgroup (the descriptor's for WM = 4, chosen by the kernel for WM = 8)
+  int hslot, nh, nhs;   // halo ring: bytes per slot, DMA pieces per wave and slot, slots
+  int tiles, gx, gy;    // pixel tiles; persistent workgroups along the pixel axis (= rows of `stats`); column tiles
+  size_t lds;
+};
+// false: the descriptor does not qualify (the caller uses igemm2)
+bool ksmi_igemm4_geom(const ksmi_conv_desc* d, int dtype, ksmi_igemm4_geom_t* g);
+int ksmi_igemm4_launch(const ksmi_conv_desc* d, const ksmi_igemm4_geom_t* g, hipStream_t st);

@@ -33,9 +33,11 @@ def _pack(weight, table, taps, N, n_mod, sK, sN, sD, sT, flip, dtype):
     return out
 
 
-def conv3x3(xs, weight, bias=None, affine=None, want_stats=False, alpha=0.0, relu_out=0, resid=None):
+def conv3x3(xs, weight, bias=None, affine=None, want_stats=False, alpha=0.0, relu_out=0, resid=None, mask=None, out=None, accumulate=0):
     """xs: list of NHWC tensors (virtual concat); weight [N, sum C, 3, 3] fp32; affine=(scale, shift, relu)
-    applies to a single source; out = [relu](alpha*(conv + bias) + resid).  Returns (out NHWC, stats[rows,2,Npad] or None)."""
+    applies to a single source; out = [relu](alpha*(conv + bias) + resid).  mask = (m NHWC, mean, rstd, scale, shift): the
+    ReLU-mask + BatchNorm-backward epilogue of ksmi_conv_desc (result zeroed where m*scale+shift <= 0; stats = (sum v, sum v*xhat)).
+    out / accumulate: destination tensor and dst += result.  Returns (out NHWC, stats[rows,2,Npad] or None)."""
     dtype = xs[0].dtype
     B, H, W, _ = xs[0].shape
     N = weight.shape[0]
@@ -43,9 +45,10 @@ def conv3x3(xs, weight, bias=None, affine=None, want_stats=False, alpha=0.0, rel
     srcs = [SrcSpec(x, x.shape[3]) for x in xs]
     if affine is not None:
         srcs[0].scale, srcs[0].shift, srcs[0].relu = affine
-    out = torch.empty((B, H, W, N), dtype=dtype, device=xs[0].device)
-    d, table = make_conv(srcs, [(out, N, 0, 0, N, 0)], out, bias, None, B, H, W, H, W, 3, 3, 1, 1, N, dtype,
-                         alpha=alpha, relu_out=relu_out, resid=None if resid is None else (resid, resid.shape[3]))
+    if out is None:
+        out = torch.empty((B, H, W, N), dtype=dtype, device=xs[0].device)
+    d, table = make_conv(srcs, [(out, N, 0, 0, N, accumulate)], out, bias, None, B, H, W, H, W, 3, 3, 1, 1, N, dtype,
+                         alpha=alpha, relu_out=relu_out, resid=None if resid is None else (resid, resid.shape[3]), mask=mask)
     wpk = _pack(weight.contiguous(), table, 9, N, N, 9, Ktot * 9, 0, 1, 0, dtype)
     d.wpk = wpk.data_ptr()
     stats = None

@@ -28,6 +28,7 @@ def test_eval_change_detection_returns_the_oracle_metrics(tmp_path, monkeypatch,
     configs = load_json5("configs/config.json")
     model_configs = load_json5("configs/method/snunet/snunet.json")
     configs.update(model_configs)
+    configs.update(task="cd", method="snunet")           # (the shipped defaults are the reference's: segmentation / unet)
 
     class A:
         inputs, dem, slope = ["pre_event_1", "post_event"], False, False

@@ -1,0 +1,129 @@
+"""GPU parity of the persistent long-K convolution kernel (csrc/igemm4.hip: halo ring + weight ring by counted LDS-DMA, one
+statistics row per workgroup) against stock torch-CPU fp32 convolutions on the same bf16-quantised operands.
+KSMI_IGEMM4_CUS shrinks the persistent grid so that every workgroup walks several tiles (ring wrap across tile boundaries, the
+tail of the ring); KSMI_IGEMM4_NF forces the 64- / 128-column workgroup tile."""
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle.seeded import seeded_tensor
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from kurosiwo_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def q(t):
+    return t.to(torch.bfloat16).float()
+
+
+def _variants(N):
+    """(KSMI_IGEMM4_CUS, KSMI_IGEMM4_VAR) settings that apply to a layer with N output channels: the default choice on the full
+    machine, then every workgroup shape (pixel groups, column fragments per wave) on a tiny grid (many tiles per workgroup)"""
+    v = [("256", None)]
+    if N % 128 == 0:
+        v.append(("5", "4,4"))
+    if N % 64 == 0:
+        v += [("3", "8,4"), ("4", "4,2")]
+    if N == 32:
+        v.append(("3", "8,2"))
+    return v
+
+
+class _Env:
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kv}
+        for k, v in self.kv.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+CFGS = [
+    dict(B=2, H=40, W=40, cs=[96], N=64),                     # three chunks, 64-column tile
+    dict(B=1, H=33, W=50, cs=[32, 32, 64], N=128),            # virtual concat, ragged map, 128 columns
+    dict(B=3, H=28, W=28, cs=[128], N=128, aff=True),         # fused BN-apply + ReLU operand, transformed in LDS
+    dict(B=2, H=30, W=22, cs=[64], N=64, mask=True),          # ReLU-mask + BN-backward sums epilogue
+    dict(B=2, H=14, W=14, cs=[256], N=256, mask=True),
+    dict(B=2, H=24, W=24, cs=[64, 64], N=64, acc=True),       # dst += result
+    dict(B=1, H=56, W=56, cs=[96], N=192),                    # three chunks; three column tiles of 64
+    dict(B=4, H=16, W=16, cs=[160], N=64, aff=True),          # odd chunk count through the 3-slot rings
+    dict(B=2, H=48, W=40, cs=[32, 64], N=32),                 # 32 output channels: 512-pixel patches, 64 x 32 wave tiles
+    dict(B=1, H=64, W=64, cs=[64], N=32, mask=True),
+]
+
+
+@pytest.mark.parametrize("cfg", CFGS)
+def test_igemm4_conv3x3(dev, cfg):
+    from kurosiwo_amd import functional as Fk
+    dtype = torch.bfloat16
+    B, H, W, cs, N = cfg["B"], cfg["H"], cfg["W"], cfg["cs"], cfg["N"]
+    tag = f"ig4.{B}{H}{W}{cs}{N}"
+    xs = [seeded_tensor(f"{tag}.x{i}", (B, c, H, W)) for i, c in enumerate(cs)]
+    K = sum(cs)
+    w = seeded_tensor(tag + ".w", (N, K, 3, 3)) * (2.0 / (K * 9)) ** 0.5
+    bias = seeded_tensor(tag + ".b", (N,)) * 0.1
+    xq = torch.cat([q(x) for x in xs], 1)
+    aff = None
+    if cfg.get("aff"):
+        sc, sh = 1.0 + 0.3 * seeded_tensor(tag + ".sc", (K,)), 0.2 * seeded_tensor(tag + ".sh", (K,))
+        xq = q(torch.relu(xq * sc[None, :, None, None] + sh[None, :, None, None]))
+        aff = (sc.to(dev), sh.to(dev), 1)
+    y_ref = F.conv2d(xq, q(w), bias, padding=1)
+    s0_ref, s1_ref = y_ref.sum((0, 2, 3)), (y_ref ** 2).sum((0, 2, 3))
+    mask = None
+    if cfg.get("mask"):
+        m = q(seeded_tensor(tag + ".m", (B, N, H, W)))
+        mean, rstd = 0.1 * seeded_tensor(tag + ".mm", (N,)), 1.0 + 0.2 * seeded_tensor(tag + ".mr", (N,)).abs()
+        msc, msh = 1.0 + 0.3 * seeded_tensor(tag + ".ms", (N,)), 0.2 * seeded_tensor(tag + ".mh", (N,))
+        keep = (m * msc[None, :, None, None] + msh[None, :, None, None]) > 0
+        y_ref = torch.where(keep, y_ref, torch.zeros_like(y_ref))
+        xh = (m - mean[None, :, None, None]) * rstd[None, :, None, None]
+        s0_ref, s1_ref = y_ref.sum((0, 2, 3)), (y_ref * xh).sum((0, 2, 3))
+        mask = (Fk.to_nhwc(m.to(dev), dtype), mean.to(dev), rstd.to(dev), msc.to(dev), msh.to(dev))
+    old = q(seeded_tensor(tag + ".old", (B, N, H, W))) if cfg.get("acc") else None
+    xd = [Fk.to_nhwc(x.to(dev), dtype) for x in xs]
+    for cus, var in _variants(N):
+        out = Fk.to_nhwc(old.to(dev), dtype) if old is not None else None
+        with _Env(KSMI_IGEMM4_CUS=cus, KSMI_IGEMM4_VAR=var):
+            y, stats = Fk.conv3x3(xd, w.to(dev), bias.to(dev), affine=aff, want_stats=True, mask=mask, out=out,
+                                  accumulate=1 if old is not None else 0)
+        yn = Fk.to_nchw(y).cpu()
+        y_chk = y_ref + old if old is not None else y_ref
+        assert (yn - y_chk).abs().max() < 2.5e-2 * y_chk.abs().max(), (cus, var)
+        s = stats.sum(0).cpu()
+        assert (s[0, :N] - s0_ref).abs().max() < 1e-3 * max(1.0, float(y_ref.abs().sum((0, 2, 3)).max())), (cus, var)
+        assert (s[1, :N] - s1_ref).abs().max() < 2e-3 * max(1.0, float((y_ref ** 2).sum((0, 2, 3)).max())), (cus, var)
+        if var is not None:     # the persistent kernel ran: one statistics row per pixel-axis workgroup (a tile kernel writes B * tiles rows)
+            assert stats.shape[0] <= 8, (cus, var, stats.shape)
+
+
+def test_igemm4_matches_igemm2_bitwise_inputs(dev):
+    """same descriptor with and without statistics: the output tensor must not depend on the statistics epilogue"""
+    from kurosiwo_amd import functional as Fk
+    dtype = torch.bfloat16
+    x = Fk.to_nhwc(seeded_tensor("ig4.same.x", (2, 96, 32, 32)).to(dev), dtype)
+    w = seeded_tensor("ig4.same.w", (64, 96, 3, 3)).to(dev) * 0.05
+    y0, _ = Fk.conv3x3([x], w, None, want_stats=False)
+    y1, st = Fk.conv3x3([x], w, None, want_stats=True)
+    assert torch.equal(y0, y1)
+    assert st is not None and torch.isfinite(st).all()
