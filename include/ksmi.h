@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define KSMI_ABI_VERSION 2   /* 2: round 2 (stats_rows, stochastic layers, bias_grad in ksmi_wgrad_desc, ...) */
+#define KSMI_ABI_VERSION 3   /* 2: round 2 (stats_rows, stochastic layers, bias_grad in ksmi_wgrad_desc, ...); 3: round 3 (gate epilogue, ksmi_desc_size) */
 #define KSMI_F32 0
 #define KSMI_BF16 1
 #define KSMI_E_ARG (-1)
@@ -108,8 +108,19 @@ typedef struct ksmi_conv_desc {
    * layout of the non-persistent kernels).  Short-K bf16 convolutions run on persistent workgroups (csrc/igemm3.hip) that emit one
    * row per workgroup; that kernel is only chosen for a descriptor with statistics when stats_rows announces its row count. */
   int32_t stats_rows;
+  /* BatchNorm2-backward GATE of conv_block_nested's output gradient (models/snunet.py:26-29: out = relu(bn2(z) + identity)).  With
+   * gate_src != NULL the epilogue forms the TOTAL gradient v = result (+ the old destination when dst.accumulate), zeroes it where
+   * gate_src (the block output `out`, N channels) is <= 0, stores it, and `stats` receives (sum v, sum v * xhat) with
+   * xhat = (xhat_src - g_mean) * g_rstd (z and the saved statistics of bn2): the separate reduction pass over (d out, out, z) of the
+   * block backward disappears into the launch that writes d out.  Only the persistent long-K kernel implements it
+   * (ksmi_conv_gate_supported); mutually exclusive with mask_src. */
+  const void* gate_src; const void* xhat_src; const float* g_mean; const float* g_rstd;
 } ksmi_conv_desc;
 
+/* sizeof of a descriptor struct as the library was compiled (0 conv, 1 wgrad, 2 pack, 3 rowsum): bindings check their mirror */
+size_t ksmi_desc_size(int which);
+/* 1: ksmi_conv_forward(d, dtype) runs on a kernel that implements the gate epilogue (gate_src) for this descriptor */
+int ksmi_conv_gate_supported(const ksmi_conv_desc* d, int dtype);
 /* number of M-tiles (= rows of `stats` when stats_rows == 0) a descriptor launches */
 int ksmi_conv_grid_m(const ksmi_conv_desc* d);
 /* rows of `stats` ksmi_conv_forward(d, dtype) will write when d->stats_rows is set to the returned value */
@@ -221,6 +232,10 @@ int ksmi_reduce_rows_batched(const ksmi_rowsum_desc* descs_device, int n, void* 
 int ksmi_bnrelu_bwd_apply(void* dout_g, const void* out, const void* z, const float* mean, const float* rstd,
                           const float* gamma, const float* sums, void* dz, double count,
                           int64_t npix, int C, int dtype, void* stream);
+/* pass 2 behind a convolution with the gate epilogue (ksmi_conv_desc.gate_src: g is already d out * (out > 0) and `sums` come from
+ * that launch's statistics rows): dz = gamma*rstd*(g - s0/n - zhat*s1/n); g is read only */
+int ksmi_bn_bwd_apply_gated(const void* g, const void* z, const float* mean, const float* rstd, const float* gamma, const float* sums,
+                            void* dz, double count, int64_t npix, int C, int dtype, void* stream);
 /* di = g + gamma*rstd*(r - t0/n - xhat*t1/n), xhat=(i-mean)*rstd; written over r; also
  * partial[rows][1][C] = sum di (conv1 bias gradient). */
 int ksmi_bn_bwd_apply_add(void* r_di, const void* g, const void* i, const float* mean, const float* rstd,

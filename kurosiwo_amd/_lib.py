@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libksmi.so")
 
 KSMI_F32, KSMI_BF16 = 0, 1
 MAX_SRC, MAX_CHUNKS = 6, 72
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class KsmiError(RuntimeError):
@@ -42,7 +42,8 @@ class ConvDesc(C.Structure):
                 ("out_ox", C.c_int32), ("out_H", C.c_int32), ("out_W", C.c_int32),
                 ("uniform_kc", C.c_int32), ("in_sy", C.c_int32), ("in_sx", C.c_int32), ("in_oy", C.c_int32), ("in_ox", C.c_int32),
                 ("in_H", C.c_int32), ("in_W", C.c_int32), ("alpha", C.c_float), ("relu_out", C.c_int32), ("residC", C.c_int32),
-                ("resid", C.c_void_p), ("stats_rows", C.c_int32)]
+                ("resid", C.c_void_p), ("stats_rows", C.c_int32),
+                ("gate_src", C.c_void_p), ("xhat_src", C.c_void_p), ("g_mean", C.c_void_p), ("g_rstd", C.c_void_p)]
 
 
 class PackDesc(C.Structure):
@@ -91,6 +92,8 @@ SIGNATURES = {
     "ksmi_conv_wgrad": (_i, [C.POINTER(WgradDesc), _i, _vp]),
     "ksmi_conv_wgrad_fuses_bias": (_i, [C.POINTER(WgradDesc), _i]),
     "ksmi_conv_stats_rows": (_i, [C.POINTER(ConvDesc), _i]),
+    "ksmi_conv_gate_supported": (_i, [C.POINTER(ConvDesc), _i]),
+    "ksmi_desc_size": (C.c_size_t, [_i]),
     "ksmi_conv_first_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ksmi_conv_first_stats_rows": (_i, [_i, _i, _i]),
     "ksmi_im2col3x3": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
@@ -102,6 +105,7 @@ SIGNATURES = {
     "ksmi_reduce_rows": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp]),
     "ksmi_reduce_rows_batched": (_i, [_vp, _i, _vp]),
     "ksmi_bnrelu_bwd_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _i64, _i, _i, _vp]),
+    "ksmi_bn_bwd_apply_gated": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _i64, _i, _i, _vp]),
     "ksmi_bn_bwd_apply_add": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _d, _i64, _i, _i, _vp]),
     "ksmi_channel_sum": (_i, [_vp, _vp, _i, _i64, _i, _i, _vp]),
     "ksmi_colsum": (_i, [_vp, _i64, _i, _vp, _i, _i, _vp]),
@@ -214,6 +218,9 @@ def load():
         fn.argtypes = args
     if lib.ksmi_abi_version() != ABI_VERSION:
         raise KsmiError(f"libksmi ABI {lib.ksmi_abi_version()} != binding {ABI_VERSION}")
+    for which, cls in enumerate((ConvDesc, WgradDesc, PackDesc, RowsumDesc)):        # the ctypes mirrors match the compiled structs
+        if lib.ksmi_desc_size(which) != C.sizeof(cls):
+            raise KsmiError(f"libksmi {cls.__name__}: {lib.ksmi_desc_size(which)} bytes in the library, {C.sizeof(cls)} in the binding")
     _lib = lib
     return lib
 

@@ -308,6 +308,25 @@ __global__ void bn_bwd_apply_add_kernel(T* r, const T* g, const T* iv, const flo
   block_channel_reduce<1, VEC>(acc, w, CV, C, partial, blockIdx.x);
 }
 
+// pass 2 when the producer of d out already gated it (conv gate epilogue, ksmi.h): dz = gamma*rstd*(g - s0/n - zhat*s1/n); g is only read
+template <typename T>
+__global__ void bn_bwd_apply_gated_kernel(const T* g, const T* z, const float* mean, const float* rstd, const float* gamma,
+                                          const float* sums, T* dz, float inv_n, int64_t nvec, int CV, int C) {
+  constexpr int VEC = ElemTraits<T>::kVec;
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(v % CV) * VEC;
+    float gg[VEC], zz[VEC];
+    vec_unpack<T>(*(const u32x4*)(g + v * VEC), gg);
+    vec_unpack<T>(*(const u32x4*)(z + v * VEC), zz);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const float zh = (zz[j] - mean[c + j]) * rstd[c + j];
+      zz[j] = gamma[c + j] * rstd[c + j] * (gg[j] - sums[c + j] * inv_n - zh * sums[C + c + j] * inv_n);
+    }
+    *(u32x4*)(dz + v * VEC) = vec_pack<T>(zz);
+  }
+}
+
 template <typename T>
 __global__ void channel_sum_kernel(const T* x, float* partial, int64_t npix, int C) {
   constexpr int VEC = ElemTraits<T>::kVec;
@@ -821,6 +840,20 @@ int ksmi_bnrelu_bwd_apply(void* dout_g, const void* out, const void* z, const fl
                           const float* gamma, const float* sums, void* dz, double count, int64_t npix, int C, int dtype,
                           void* stream) {
   return ksmi_bnrelu_bwd_apply_scaled(dout_g, out, z, mean, rstd, gamma, sums, dz, count, npix, C, 1.f, dtype, stream);
+}
+
+int ksmi_bn_bwd_apply_gated(const void* g, const void* z, const float* mean, const float* rstd, const float* gamma, const float* sums,
+                            void* dz, double count, int64_t npix, int C, int dtype, void* stream) {
+  if (!chan_ok(C, dtype)) return ksmi_fail(KSMI_E_ARG, "bn_bwd_apply_gated: bad C");
+  const int vec = dtype == KSMI_BF16 ? 8 : 4;
+  const int64_t nvec = npix * C / vec;
+  const float inv_n = (float)(1.0 / count);
+  KSMI_DT(dtype,
+          hipLaunchKernelGGL(bn_bwd_apply_gated_kernel<bf16_t>, dim3(grid_for(nvec, 8192)), dim3(256), 0, (hipStream_t)stream,
+                             (const bf16_t*)g, (const bf16_t*)z, mean, rstd, gamma, sums, (bf16_t*)dz, inv_n, nvec, C / vec, C),
+          hipLaunchKernelGGL(bn_bwd_apply_gated_kernel<float>, dim3(grid_for(nvec, 8192)), dim3(256), 0, (hipStream_t)stream,
+                             (const float*)g, (const float*)z, mean, rstd, gamma, sums, (float*)dz, inv_n, nvec, C / vec, C));
+  return ksmi_check_launch("bn_bwd_apply_gated");
 }
 
 int ksmi_bn_bwd_apply_add(void* r_di, const void* g, const void* i, const float* mean, const float* rstd, const float* gamma,

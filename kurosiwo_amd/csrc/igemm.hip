@@ -928,12 +928,31 @@ int ksmi_conv_grid_m(const ksmi_conv_desc* d) {
   return d->B * tilesX * tilesY;
 }
 
+size_t ksmi_desc_size(int which) {
+  switch (which) {
+    case 0: return sizeof(ksmi_conv_desc);
+    case 1: return sizeof(ksmi_wgrad_desc);
+    case 2: return sizeof(ksmi_pack_desc);
+    case 3: return sizeof(ksmi_rowsum_desc);
+    default: return 0;
+  }
+}
+
+int ksmi_conv_gate_supported(const ksmi_conv_desc* d, int dtype) {
+  if (!d) return 0;
+  ksmi_conv_desc c = *d;
+  if (!c.stats) c.stats = (float*)(uintptr_t)16;
+  if (!c.gate_src) { c.gate_src = (const void*)(uintptr_t)16; c.xhat_src = c.gate_src; c.g_mean = (const float*)(uintptr_t)16; c.g_rstd = c.g_mean; }
+  ksmi_igemm4_geom_t g4;
+  return ksmi_igemm4_geom(&c, dtype, &g4) ? 1 : 0;
+}
+
 int ksmi_conv_stats_rows(const ksmi_conv_desc* d, int dtype) {
   if (!d) return 0;
   ksmi_conv_desc c = *d;
   if (!c.stats) c.stats = (float*)(uintptr_t)16;     // the answer is for the launch WITH statistics
   ksmi_igemm3_geom_t g3;
-  if (ksmi_igemm3_geom(&c, dtype, &g3)) return g3.gx;
+  if (!c.gate_src && ksmi_igemm3_geom(&c, dtype, &g3)) return g3.gx;
   ksmi_igemm4_geom_t g4;
   if (ksmi_igemm4_geom(&c, dtype, &g4)) return g4.gx;
   return ksmi_conv_grid_m(d);
@@ -947,12 +966,13 @@ int ksmi_conv_forward(const ksmi_conv_desc* d, int dtype, void* stream) {
   static const bool force_v1 = getenv("KSMI_IGEMM_V1") != nullptr;      // A/B switch for profiling
   {   // short K, bf16: persistent workgroups with register-resident weights (its statistics rows = workgroups, not tiles)
     ksmi_igemm3_geom_t g3;
-    if (!force_v1 && ksmi_igemm3_geom(d, dtype, &g3) && (d->stats == nullptr || d->stats_rows == g3.gx))
+    if (!force_v1 && !d->gate_src && ksmi_igemm3_geom(d, dtype, &g3) && (d->stats == nullptr || d->stats_rows == g3.gx))
       return ksmi_igemm3_launch(d, &g3, (hipStream_t)stream);
     // long K, >= 64 output channels, 3x3: persistent workgroups with halo / weight rings (igemm4.hip); same statistics-row rule
     ksmi_igemm4_geom_t g4;
     if (!force_v1 && ksmi_igemm4_geom(d, dtype, &g4) && (d->stats == nullptr || d->stats_rows == g4.gx))
       return ksmi_igemm4_launch(d, &g4, (hipStream_t)stream);
+    if (d->gate_src) return ksmi_fail(KSMI_E_UNSUPPORTED, "conv: the gate epilogue needs the persistent long-K kernel (ksmi_conv_gate_supported)");
   }
   if (d->stats && d->stats_rows != 0 && d->stats_rows != ksmi_conv_grid_m(d))
     return ksmi_fail(KSMI_E_ARG, "conv: stats_rows does not match the kernel this descriptor runs on (set it from ksmi_conv_stats_rows)");

@@ -62,9 +62,12 @@ constexpr int IG4_NHMAX = 5;       // halo pieces per wave at most: 40 KiB slot 
 // `swz` of igemm_epilogue.h is conflict-free only for aligned rows (4 -> 6.7 LDS cycles per read on the 16 x 16 patch).
 __device__ __forceinline__ int swz_h(int hx) { return ((hx >> 2) & 1) << 1; }
 
-template <int WM, int NF, bool AFF, bool MASK, bool DBG = false>
+// EPI: 0 plain, 1 ReLU-mask + BatchNorm1-backward sums (mask_src), 2 gate: total gradient, ReLU gate of the block output and
+// BatchNorm2-backward sums (gate_src / xhat_src; ksmi.h)
+template <int WM, int NF, bool AFF, int EPI, bool DBG = false>
 __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Ig4Args ka) {
   typedef bf16_t T;
+  constexpr bool MASK = EPI == 1, GATE = EPI == 2;
   const ksmi_conv_desc& d = ka.d;
   constexpr int WN = 8 / WM;
   constexpr int BNW = 16 * NF;                 // columns per wave
@@ -384,61 +387,98 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Ig4Args ka) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
           }
-          u32x4 mv[MASK ? 4 : 1], ov[4];
-#pragma unroll
-          for (int mf = 0; mf < 4; ++mf) {
-            if constexpr (MASK) {
-              mv[mf] = (u32x4){0u, 0u, 0u, 0u};
-              if (nv && okp[mf]) mv[mf] = *(const u32x4*)(mbase + (size_t)opix[mf] * d.N);
-            }
-            ov[mf] = (u32x4){0u, 0u, 0u, 0u};
-            if (accum && nv && okp[mf]) ov[mf] = *(const u32x4*)(obase + (size_t)opix[mf] * dC);
-          }
-          float mm[MASK ? 8 : 1], mr[MASK ? 8 : 1], mg[MASK ? 8 : 1], mb[MASK ? 8 : 1];
-          if constexpr (MASK) {
+          float mm[(MASK || GATE) ? 8 : 1], mr[(MASK || GATE) ? 8 : 1], mg[MASK ? 8 : 1], mb[MASK ? 8 : 1];
+          if constexpr (MASK || GATE) {
             auto ld8 = [&](const float* qp, float* o, int at) {
               const f32x4 a = *(const f32x4*)(qp + at), c = *(const f32x4*)(qp + at + 4);
 #pragma unroll
               for (int j = 0; j < 4; ++j) { o[j] = a[j]; o[4 + j] = c[j]; }
             };
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { mm[j] = 0.f; mr[j] = 0.f; mg[j] = 0.f; mb[j] = 0.f; }
-            if (nv) { ld8(d.m_mean, mm, nc); ld8(d.m_rstd, mr, nc); ld8(d.m_scale, mg, nc); ld8(d.m_shift, mb, nc); }
-          }
-#pragma unroll
-          for (int mf = 0; mf < 4; ++mf) {
-            const bool ok = nv && okp[mf];
-            float v[8];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { v[r] = acc[mf][2 * gi][r] + bias8[r]; v[4 + r] = acc[mf][2 * gi + 1][r] + bias8[4 + r]; }
+            for (int j = 0; j < 8; ++j) { mm[j] = 0.f; mr[j] = 0.f; }
             if constexpr (MASK) {
-              float m[8];
-              vec_unpack<T>(mv[MASK ? mf : 0], m);
 #pragma unroll
-              for (int j = 0; j < 8; ++j) {
-                const float xh = (m[j] - mm[j]) * mr[j];
-                if (!(m[j] * mg[j] + mb[j] > 0.f)) v[j] = 0.f;
-                if (ok) { ssum[j] += v[j]; ssq[j] += v[j] * xh; }
-              }
+              for (int j = 0; j < 8; ++j) { mg[j] = 0.f; mb[j] = 0.f; }
+              if (nv) { ld8(d.m_mean, mm, nc); ld8(d.m_rstd, mr, nc); ld8(d.m_scale, mg, nc); ld8(d.m_shift, mb, nc); }
             } else {
-#pragma unroll
-              for (int j = 0; j < 8; ++j) if (ok) { ssum[j] += v[j]; ssq[j] += v[j] * v[j]; }
+              if (nv) { ld8(d.g_mean, mm, nc); ld8(d.g_rstd, mr, nc); }
             }
-            if (accum) {
-              float o[8];
-              vec_unpack<T>(ov[mf], o);
+          }
+          // two pixel fragments at a time: the loads of a pair are in flight together (mask / gate / old destination: up to 3 x 16 B)
 #pragma unroll
-              for (int j = 0; j < 8; ++j) v[j] += o[j];
+          for (int mh = 0; mh < 4; mh += 2) {
+            u32x4 mv[2], zv[2], ov[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              const int mf = mh + u;
+              mv[u] = (u32x4){0u, 0u, 0u, 0u}; zv[u] = mv[u]; ov[u] = mv[u];
+              if constexpr (MASK) { if (nv && okp[mf]) mv[u] = *(const u32x4*)(mbase + (size_t)opix[mf] * d.N); }
+              if constexpr (GATE) {
+                if (nv && okp[mf]) {
+                  mv[u] = *(const u32x4*)((const T*)d.gate_src + nc + (size_t)opix[mf] * d.N);
+                  zv[u] = *(const u32x4*)((const T*)d.xhat_src + nc + (size_t)opix[mf] * d.N);
+                }
+              }
+              if (accum && nv && okp[mf]) ov[u] = *(const u32x4*)(obase + (size_t)opix[mf] * dC);
             }
-            if (ok && !(DBG && (dbg & 4))) *(u32x4*)(obase + (size_t)opix[mf] * dC) = vec_pack<T>(v);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              const int mf = mh + u;
+              const bool ok = nv && okp[mf];
+              float v[8];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) { v[r] = acc[mf][2 * gi][r] + bias8[r]; v[4 + r] = acc[mf][2 * gi + 1][r] + bias8[4 + r]; }
+              if constexpr (GATE) {
+                // total gradient first (the other producers of d out wrote before this launch), then the gate and the BN2 sums
+                float o[8], m[8], z[8];
+                vec_unpack<T>(ov[u], o); vec_unpack<T>(mv[u], m); vec_unpack<T>(zv[u], z);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                  if (accum) v[j] += o[j];
+                  if (!(m[j] > 0.f)) v[j] = 0.f;
+                  // statistics of the value the later passes READ (the stored bf16), like bn_bwd_apply_add does for its sums
+                }
+                const u32x4 pk = vec_pack<T>(v);
+                float vr[8];
+                vec_unpack<T>(pk, vr);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (ok) { ssum[j] += vr[j]; ssq[j] += vr[j] * ((z[j] - mm[j]) * mr[j]); }
+                if (ok && !(DBG && (dbg & 4))) *(u32x4*)(obase + (size_t)opix[mf] * dC) = pk;
+              } else {
+                if constexpr (MASK) {
+                  float m[8];
+                  vec_unpack<T>(mv[u], m);
+#pragma unroll
+                  for (int j = 0; j < 8; ++j) {
+                    const float xh = (m[j] - mm[j]) * mr[j];
+                    if (!(m[j] * mg[j] + mb[j] > 0.f)) v[j] = 0.f;
+                    if (ok) { ssum[j] += v[j]; ssq[j] += v[j] * xh; }
+                  }
+                } else {
+#pragma unroll
+                  for (int j = 0; j < 8; ++j) if (ok) { ssum[j] += v[j]; ssq[j] += v[j] * v[j]; }
+                }
+                if (accum) {
+                  float o[8];
+                  vec_unpack<T>(ov[u], o);
+#pragma unroll
+                  for (int j = 0; j < 8; ++j) v[j] += o[j];
+                }
+                if (ok && !(DBG && (dbg & 4))) *(u32x4*)(obase + (size_t)opix[mf] * dC) = vec_pack<T>(v);
+              }
+            }
           }
           if (want_stats) {                                             // fold the tile into the wave's statistics row
             float* row = st_tab + (size_t)(wave * 2) * BNW + gi * 32 + g * 8;
+            // (all 16 old values are read before the first is written back: one LDS round trip instead of sixteen)
+            const f32x4 o0 = *(const f32x4*)row, o1 = *(const f32x4*)(row + 4), o2 = *(const f32x4*)(row + BNW), o3 = *(const f32x4*)(row + BNW + 4);
+            f32x4 n0v, n1v, n2v, n3v;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              const float a = row16_sum(ssum[j]), q = row16_sum(ssq[j]);
-              if (l15 == 0) { row[j] += a; row[BNW + j] += q; }
+            for (int j = 0; j < 4; ++j) {
+              n0v[j] = o0[j] + row16_sum(ssum[j]); n1v[j] = o1[j] + row16_sum(ssum[4 + j]);
+              n2v[j] = o2[j] + row16_sum(ssq[j]); n3v[j] = o3[j] + row16_sum(ssq[4 + j]);
             }
+            if (l15 == 0) { *(f32x4*)row = n0v; *(f32x4*)(row + 4) = n1v; *(f32x4*)(row + BNW) = n2v; *(f32x4*)(row + BNW + 4) = n3v; }
           }
         }
       }
@@ -518,7 +558,10 @@ bool ksmi_igemm4_geom(const ksmi_conv_desc* d, int dtype, ksmi_igemm4_geom_t* g)
   }
   if ((size_t)d->B * d->Hout * d->Wout >= ((size_t)1 << 31)) return false;
   const bool aff = d->src[0].scale != nullptr;
-  if (aff && d->mask_src) return false;
+  if (aff && (d->mask_src || d->gate_src)) return false;
+  if (d->mask_src && d->gate_src) return false;
+  if (d->gate_src && (!d->xhat_src || !d->g_mean || !d->g_rstd || !al16(d->gate_src) || !al16(d->xhat_src) || !al16(d->g_mean) || !al16(d->g_rstd)))
+    return false;
   if (aff && d->nchunks > 64) return false;                         // affine table: 8 KB
   const char* v_env = getenv("KSMI_IGEMM4_VAR");                    // (read per call: the tests force each variant) "wm,nf"
   int wm_force = 0, nf_force = 0;
@@ -585,7 +628,7 @@ int ksmi_igemm4_launch(const ksmi_conv_desc* d, const ksmi_igemm4_geom_t* g, hip
   if (!zero_page && hipGetSymbolAddress(&zero_page, HIP_SYMBOL(ig4_zero_page)) != hipSuccess) return ksmi_fail(KSMI_E_UNSUPPORTED, "igemm4: zero page");
   ka.zero = (const unsigned char*)zero_page;
   const dim3 grid(g->gx * g->gy);
-  const bool aff = d->src[0].scale != nullptr, mask = d->mask_src != nullptr;
+  const bool aff = d->src[0].scale != nullptr, mask = d->mask_src != nullptr, gate = d->gate_src != nullptr;
 #define KSMI_G4(WM_, NF_, AFF_, MASK_)                                                               \
   do {                                                                                               \
     auto kfn = igemm4_kernel<WM_, NF_, AFF_, MASK_>;                                                 \
@@ -595,14 +638,14 @@ int ksmi_igemm4_launch(const ksmi_conv_desc* d, const ksmi_igemm4_geom_t* g, hip
     return ksmi_check_launch("igemm4");                                                              \
   } while (0)
 #define KSMI_G4V(WM_, NF_)                                                                           \
-  do { if (aff) KSMI_G4(WM_, NF_, true, false); else if (mask) KSMI_G4(WM_, NF_, false, true); else KSMI_G4(WM_, NF_, false, false); } while (0)
-  if (ka.dbg && !aff && !mask && g->NF == 4) {                       // profiling switches: separate instantiations of the plain kernels
+  do { if (aff) KSMI_G4(WM_, NF_, true, 0); else if (mask) KSMI_G4(WM_, NF_, false, 1); else if (gate) KSMI_G4(WM_, NF_, false, 2); else KSMI_G4(WM_, NF_, false, 0); } while (0)
+  if (ka.dbg && !aff && !mask && !gate && g->NF == 4) {                       // profiling switches: separate instantiations of the plain kernels
     if (g->WM == 4) {
-      auto kfn = igemm4_kernel<4, 4, false, false, true>;
+      auto kfn = igemm4_kernel<4, 4, false, 0, true>;
       (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       hipLaunchKernelGGL(kfn, grid, dim3(512), g->lds, st, ka);
     } else {
-      auto kfn = igemm4_kernel<8, 4, false, false, true>;
+      auto kfn = igemm4_kernel<8, 4, false, 0, true>;
       (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       hipLaunchKernelGGL(kfn, grid, dim3(512), g->lds, st, ka);
     }

@@ -33,11 +33,14 @@ def _pack(weight, table, taps, N, n_mod, sK, sN, sD, sT, flip, dtype):
     return out
 
 
-def conv3x3(xs, weight, bias=None, affine=None, want_stats=False, alpha=0.0, relu_out=0, resid=None, mask=None, out=None, accumulate=0):
+def conv3x3(xs, weight, bias=None, affine=None, want_stats=False, alpha=0.0, relu_out=0, resid=None, mask=None, out=None, accumulate=0,
+            gate=None):
     """xs: list of NHWC tensors (virtual concat); weight [N, sum C, 3, 3] fp32; affine=(scale, shift, relu)
     applies to a single source; out = [relu](alpha*(conv + bias) + resid).  mask = (m NHWC, mean, rstd, scale, shift): the
     ReLU-mask + BatchNorm-backward epilogue of ksmi_conv_desc (result zeroed where m*scale+shift <= 0; stats = (sum v, sum v*xhat)).
-    out / accumulate: destination tensor and dst += result.  Returns (out NHWC, stats[rows,2,Npad] or None)."""
+    out / accumulate: destination tensor and dst += result.  gate = (out_block NHWC, z NHWC, mean, rstd): the gate epilogue of
+    ksmi_conv_desc (total = result + old destination, zeroed where out_block <= 0; stats = (sum v, sum v*zhat)).
+    Returns (out NHWC, stats[rows,2,Npad] or None)."""
     dtype = xs[0].dtype
     B, H, W, _ = xs[0].shape
     N = weight.shape[0]
@@ -51,6 +54,10 @@ def conv3x3(xs, weight, bias=None, affine=None, want_stats=False, alpha=0.0, rel
                          alpha=alpha, relu_out=relu_out, resid=None if resid is None else (resid, resid.shape[3]), mask=mask)
     wpk = _pack(weight.contiguous(), table, 9, N, N, 9, Ktot * 9, 0, 1, 0, dtype)
     d.wpk = wpk.data_ptr()
+    if gate is not None:
+        d.gate_src, d.xhat_src, d.g_mean, d.g_rstd = (t.data_ptr() for t in gate)
+        if not _lib.load().ksmi_conv_gate_supported(C.byref(d), DT[dtype]):
+            raise _lib.KsmiError("conv3x3: the gate epilogue is not available for this shape")
     stats = None
     if want_stats:
         stats = torch.zeros((conv_stats_rows(d, dtype), 2, d.Npad), dtype=torch.float32, device=out.device)

@@ -8,6 +8,7 @@ Reference computation: /root/reference/models/snunet.py:118-153 (forward graph),
 :11-29 (conv_block_nested), :32-46 (up), :49-62 + :146-151 (ECAM head).
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -318,8 +319,11 @@ class SNUNetPlan:
 
     def _wgrad(self, d, ws, *keys):
         self.keep.append(d)
-        self.need("wgrad", ws)
-        self.patch(d, "partial", "wgrad")
+        # the partial-slab scratch is per compute lane: with the side stream off (or a timed launch) the weight gradients of the two
+        # lanes run concurrently on their lanes' streams
+        sW = self._sname("wgrad")
+        self.need(sW, ws)
+        self.patch(d, "partial", sW)
         taps, es = d.KH * d.KW, self._es()
         ktot = sum(d.src[i].c_len for i in range(d.nsrc))
         pin, pout = d.B * d.Hin * d.Win, d.B * d.Hout * d.Wout
@@ -331,7 +335,7 @@ class SNUNetPlan:
         self._mark(*keys)
 
     # ---------------------------------------------------------------- "virtual sum" input gradient
-    def _emit_dgrad(self, act, bias_key=None):
+    def _emit_dgrad(self, act, bias_key=None, gate=None):
         """d act = sum over the 3x3 convs that read `act` of convT(di_j, W_j[:, slice_j]) as ONE implicit GEMM
         whose K axis walks the consumers' `di` tensors (the dual of the forward's virtual concat): every
         gradient tensor is written once instead of read-modify-written per consumer, and K grows from
@@ -361,6 +365,18 @@ class SNUNetPlan:
             ch0 += nch
         d.wpk = wpk.data_ptr()
         self.keep.append(wpk)
+        gated = None
+        if gate is not None:
+            g_out, g_z, g_sv = gate
+            d.gate_src, d.xhat_src, d.g_mean, d.g_rstd = g_out.data_ptr(), g_z.data_ptr(), g_sv.mean, g_sv.rstd
+            if self.lib.ksmi_conv_gate_supported(C.byref(d), self.dt):
+                rows_g = conv_stats_rows(d, self.dtype)
+                st = torch.empty(rows_g * 2 * Npad, dtype=torch.float32, device=self.dev)
+                d.stats = st.data_ptr()
+                self.keep.append(st)
+                gated = (st, rows_g, Npad)
+            else:
+                d.gate_src = d.xhat_src = d.g_mean = d.g_rstd = None
         if bias_key is not None:
             # `act` is the output of a ConvTranspose2d whose bias gradient is sum_pixels d act: the statistics epilogue of this launch
             # emits the per-tile sums (was: one more pass over the gradient tensor, ksmi_channel_sum)
@@ -369,7 +385,7 @@ class SNUNetPlan:
             d.stats = st.data_ptr()
             self._defer_rowsum(bias_key, st, rows_g, 2, 0, Npad, Cc)
         self._conv(self.bwd, d, "dgrad")
-        return True
+        return gated if gated is not None else True
 
     # ---------------------------------------------------------------- nn.MaxPool2d(2,2)  (snunet.py:73)
     def _pool(self, x, name):
@@ -493,7 +509,10 @@ class SNUNetPlan:
 
         # ---- backward ----------------------------------------------------------------------------
         def build_bwd():
-            self._emit_dgrad(out)
+            # (the virtual-sum input gradient below is the last writer of d out: the other producers -- pool / Up input gradients, the
+            # ECAM head -- belong to modules later in the forward order, i.e. earlier in this list)
+            gated = self._emit_dgrad(out, gate=(out.t, z_act.t, sv2)) if os.environ.get("KSMI_NO_GATE") is None else self._emit_dgrad(out)
+            gated = gated if isinstance(gated, tuple) else None
             rows = self._rows(npix)
             self.need(sR, rows * 2 * Cc * 4)
             sums1 = torch.zeros((2, Cc), dtype=torch.float32, device=self.dev)
@@ -504,12 +523,20 @@ class SNUNetPlan:
             gout = out.grad().data_ptr()
             s1p, s2p = sums1.data_ptr(), sums2.data_ptr()
             a_bn2 = self._acc_param(f"{name}.bn2")
-            self.bwd.add("ksmi_bnrelu_bwd_reduce", lambda: (gout, out.t.data_ptr(), z_act.t.data_ptr(), sv2.mean, sv2.rstd,
-                                                            self.scr(sR), rows, npix, Cc, dt))
-            self.bwd.add("ksmi_reduce_rows", lambda: (self.scr(sR), rows, 2, Cc, Cc, s2p, G("bn2.weight"), G("bn2.bias"), a_bn2))
-            self._mark(f"{name}.bn2.weight", f"{name}.bn2.bias")
-            self.bwd.add("ksmi_bnrelu_bwd_apply", lambda: (gout, out.t.data_ptr(), z_act.t.data_ptr(), sv2.mean, sv2.rstd,
-                                                           P("bn2.weight"), s2p, dz.data_ptr(), float(npix), npix, Cc, dt))
+            if gated is not None:
+                # d out arrives gated (x (out > 0)) with the BatchNorm2-backward sums in the statistics rows of its producer
+                gst, grows, gpad = gated
+                self.bwd.add("ksmi_reduce_rows", lambda: (gst.data_ptr(), grows, 2, gpad, Cc, s2p, G("bn2.weight"), G("bn2.bias"), a_bn2))
+                self._mark(f"{name}.bn2.weight", f"{name}.bn2.bias")
+                self.bwd.add("ksmi_bn_bwd_apply_gated", lambda: (gout, z_act.t.data_ptr(), sv2.mean, sv2.rstd, P("bn2.weight"), s2p,
+                                                                 dz.data_ptr(), float(npix), npix, Cc, dt))
+            else:
+                self.bwd.add("ksmi_bnrelu_bwd_reduce", lambda: (gout, out.t.data_ptr(), z_act.t.data_ptr(), sv2.mean, sv2.rstd,
+                                                                self.scr(sR), rows, npix, Cc, dt))
+                self.bwd.add("ksmi_reduce_rows", lambda: (self.scr(sR), rows, 2, Cc, Cc, s2p, G("bn2.weight"), G("bn2.bias"), a_bn2))
+                self._mark(f"{name}.bn2.weight", f"{name}.bn2.bias")
+                self.bwd.add("ksmi_bnrelu_bwd_apply", lambda: (gout, out.t.data_ptr(), z_act.t.data_ptr(), sv2.mean, sv2.rstd,
+                                                               P("bn2.weight"), s2p, dz.data_ptr(), float(npix), npix, Cc, dt))
             # conv2.bias feeds a train-mode BatchNorm: its gradient sum(dz) is analytically 0 (the reference holds
             # ~1e-6 of rounding noise there); write exact zeros instead of two reduction launches.
             if training:

@@ -117,6 +117,45 @@ def test_igemm4_conv3x3(dev, cfg):
             assert stats.shape[0] <= 8, (cus, var, stats.shape)
 
 
+@pytest.mark.parametrize("cfg", [dict(B=2, H=40, W=36, cs=[32, 32, 32], N=32), dict(B=1, H=28, W=28, cs=[128, 128], N=128),
+                                 dict(B=2, H=24, W=24, cs=[64], N=64, first=True)])
+def test_igemm4_gate_epilogue(dev, cfg):
+    """total gradient (+ old destination), ReLU gate of the block output, BatchNorm2-backward sums (ksmi_conv_desc.gate_src)"""
+    from kurosiwo_amd import functional as Fk
+    dtype = torch.bfloat16
+    B, H, W, cs, N = cfg["B"], cfg["H"], cfg["W"], cfg["cs"], cfg["N"]
+    tag = f"ig4g.{B}{H}{W}{cs}{N}"
+    xs = [seeded_tensor(f"{tag}.x{i}", (B, c, H, W)) for i, c in enumerate(cs)]
+    K = sum(cs)
+    w = seeded_tensor(tag + ".w", (N, K, 3, 3)) * (2.0 / (K * 9)) ** 0.5
+    old = q(seeded_tensor(tag + ".old", (B, N, H, W))) * 0.5
+    outb = q(seeded_tensor(tag + ".out", (B, N, H, W)))
+    z = q(seeded_tensor(tag + ".z", (B, N, H, W)))
+    mean, rstd = 0.1 * seeded_tensor(tag + ".mm", (N,)), 1.0 + 0.2 * seeded_tensor(tag + ".mr", (N,)).abs()
+    y = F.conv2d(torch.cat([q(x) for x in xs], 1), q(w), None, padding=1)
+    first = cfg.get("first", False)
+    tot = y if first else y + old
+    g_ref = q(torch.where(outb > 0, tot, torch.zeros_like(tot)))
+    zh = (z - mean[None, :, None, None]) * rstd[None, :, None, None]
+    s0_ref, s1_ref = g_ref.sum((0, 2, 3)), (g_ref * zh).sum((0, 2, 3))
+    xd = [Fk.to_nhwc(x.to(dev), dtype) for x in xs]
+    gate = (Fk.to_nhwc(outb.to(dev), dtype), Fk.to_nhwc(z.to(dev), dtype), mean.to(dev), rstd.to(dev))
+    for cus, var in _variants(N):
+        dst = Fk.to_nhwc(old.to(dev), dtype)
+        with _Env(KSMI_IGEMM4_CUS=cus, KSMI_IGEMM4_VAR=var):
+            try:
+                g, stats = Fk.conv3x3(xd, w.to(dev), None, want_stats=True, out=dst, accumulate=0 if first else 1, gate=gate)
+            except Exception as e:      # the default choice leaves maps with < 64 patches to the tile kernel, which has no gate epilogue
+                assert var is None and "gate epilogue is not available" in str(e)
+                continue
+        gn = Fk.to_nchw(g).cpu()
+        assert (gn - g_ref).abs().max() < 2.5e-2 * g_ref.abs().max(), (cus, var)
+        assert ((gn != 0) & (outb <= 0)).sum() == 0                      # the gate is exact
+        s = stats.sum(0).cpu()
+        assert (s[0, :N] - s0_ref).abs().max() < 2e-3 * max(1.0, float(g_ref.abs().sum((0, 2, 3)).max())), (cus, var)
+        assert (s[1, :N] - s1_ref).abs().max() < 2e-3 * max(1.0, float((g_ref * zh).abs().sum((0, 2, 3)).max())), (cus, var)
+
+
 def test_igemm4_matches_igemm2_bitwise_inputs(dev):
     """same descriptor with and without statistics: the output tensor must not depend on the statistics epilogue"""
     from kurosiwo_amd import functional as Fk
