@@ -258,6 +258,10 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Ig4Args ka) {
   // ---- epilogue state ---------------------------------------------------------------------------------------------------
   const int dC = d.dst[0].C;
   const bool accum = d.dst[0].accumulate != 0;
+  // epilogue extras of the plain variant (ResidualBlock of models/changeformer.py:471-483): v = alpha * (acc + bias) + resid, ReLU
+  const float alpha = (EPI == 0 && d.alpha != 0.f) ? d.alpha : 1.f;
+  const bool has_resid = EPI == 0 && d.resid != nullptr;
+  const bool relu_out = EPI == 0 && d.relu_out != 0;
   // statistics and bias live in LDS (a wave owns its statistics row: plain read-modify-write, fixed order = deterministic)
   for (int i = tid; i < 8 * 2 * BNW; i += 512) st_tab[i] = 0.f;
   if (tid < BN) bias_tab[tid] = (d.bias && n0 + tid < d.N) ? d.bias[n0 + tid] : 0.f;
@@ -413,6 +417,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Ig4Args ka) {
               const int mf = mh + u;
               mv[u] = (u32x4){0u, 0u, 0u, 0u}; zv[u] = mv[u]; ov[u] = mv[u];
               if constexpr (MASK) { if (nv && okp[mf]) mv[u] = *(const u32x4*)(mbase + (size_t)opix[mf] * d.N); }
+              if constexpr (EPI == 0) { if (has_resid && nv && okp[mf]) mv[u] = *(const u32x4*)((const T*)d.resid + nc + (size_t)opix[mf] * d.residC); }
               if constexpr (GATE) {
                 if (nv && okp[mf]) {
                   mv[u] = *(const u32x4*)((const T*)d.gate_src + nc + (size_t)opix[mf] * d.N);
@@ -428,6 +433,15 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Ig4Args ka) {
               float v[8];
 #pragma unroll
               for (int r = 0; r < 4; ++r) { v[r] = acc[mf][2 * gi][r] + bias8[r]; v[4 + r] = acc[mf][2 * gi + 1][r] + bias8[4 + r]; }
+              if constexpr (EPI == 0) {
+                float rs[8];
+                vec_unpack<T>(mv[u], rs);                                // (zeros without a residual)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                  v[j] = v[j] * alpha + rs[j];
+                  if (relu_out) v[j] = fmaxf(v[j], 0.f);
+                }
+              }
               if constexpr (GATE) {
                 // total gradient first (the other producers of d out wrote before this launch), then the gate and the BN2 sums
                 float o[8], m[8], z[8];
@@ -544,7 +558,9 @@ bool ksmi_igemm4_geom(const ksmi_conv_desc* d, int dtype, ksmi_igemm4_geom_t* g)
   if (d->nchunks < 2) return false;
   if (d->nchunks > KSMI_MAX_CHUNKS) return false;                   // (source table in LDS)
   if (d->ndst != 1 || d->dst[0].n_begin != 0) return false;
-  if (d->alpha != 0.f || d->resid || d->relu_out || d->out_sy || d->in_sy || d->ps_cout) return false;
+  if (d->out_sy || d->in_sy || d->ps_cout) return false;
+  if ((d->alpha != 0.f || d->resid || d->relu_out) && (d->mask_src || d->gate_src)) return false;      // extras: plain epilogue only
+  if (d->resid && (((uintptr_t)d->resid & 15) || (d->residC % 8))) return false;
   if ((d->N % 8) || (d->dst[0].C % 8) || (d->dst[0].c_off % 8)) return false;
   if (d->Npad != 32 && (d->Npad % 64)) return false;
   auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };

@@ -156,6 +156,26 @@ def test_igemm4_gate_epilogue(dev, cfg):
         assert (s[1, :N] - s1_ref).abs().max() < 2e-3 * max(1.0, float((g_ref * zh).abs().sum((0, 2, 3)).max())), (cus, var)
 
 
+def test_igemm4_residual_block_epilogues(dev):
+    """ResidualBlock of models/changeformer.py:471-483 on the persistent kernel: relu(conv1(x) + b), then 0.1 * (conv2(r) + b) + x"""
+    from kurosiwo_amd import functional as Fk
+    dtype = torch.bfloat16
+    B, H, W, E = 2, 32, 32, 128
+    x = q(seeded_tensor("ig4r.x", (B, E, H, W)))
+    w1 = seeded_tensor("ig4r.w1", (E, E, 3, 3)) * (2.0 / (E * 9)) ** 0.5
+    w2 = seeded_tensor("ig4r.w2", (E, E, 3, 3)) * (2.0 / (E * 9)) ** 0.5
+    b1, b2 = 0.1 * seeded_tensor("ig4r.b1", (E,)), 0.1 * seeded_tensor("ig4r.b2", (E,))
+    r_ref = q(torch.relu(F.conv2d(x, q(w1), b1, padding=1)))
+    y_ref = 0.1 * F.conv2d(r_ref, q(w2), b2, padding=1) + x
+    xd = Fk.to_nhwc(x.to(dev), dtype)
+    for cus, var in _variants(E):
+        with _Env(KSMI_IGEMM4_CUS=cus, KSMI_IGEMM4_VAR=var):
+            r, _ = Fk.conv3x3([xd], w1.to(dev), b1.to(dev), relu_out=1)
+            y, _ = Fk.conv3x3([r], w2.to(dev), b2.to(dev), alpha=0.1, resid=xd)
+        assert (Fk.to_nchw(r).cpu() - r_ref).abs().max() < 2.5e-2 * r_ref.abs().max(), (cus, var)
+        assert (Fk.to_nchw(y).cpu() - y_ref).abs().max() < 2.5e-2 * y_ref.abs().max(), (cus, var)
+
+
 def test_igemm4_matches_igemm2_bitwise_inputs(dev):
     """same descriptor with and without statistics: the output tensor must not depend on the statistics epilogue"""
     from kurosiwo_amd import functional as Fk
