@@ -140,7 +140,12 @@ class ArenaModule(nn.Module):
         dev = self.flat_params.device
         if getattr(self, "_rng_state", None) is None or self._rng_state.device != dev:
             if getattr(self, "_rng_init", None) is None:
-                self._rng_init = (torch.initial_seed() & 0xFFFFFFFF, 0)
+                # every rank runs with the same torch seed (same loader shuffle): fold the rank into the stream so that sample i of
+                # rank 0 and sample i of rank 1 draw different Dropout / DropPath masks
+                rank = 0
+                if torch.distributed.is_available() and torch.distributed.is_initialized():
+                    rank = torch.distributed.get_rank()
+                self._rng_init = ((torch.initial_seed() ^ (0x9E3779B1 * rank)) & 0xFFFFFFFF, 0)
             self._rng_state = _as_i32(self._rng_init).to(dev)
         return self._rng_state
 

@@ -18,14 +18,6 @@ int ksmi_attn_mfma_sr(int backward, const void* q, const void* kv, void* out, fl
                       void* workspace, int B, int Nq, int Nk, int H, int C, float scale, uint32_t drop_thr, float drop_inv,
                       uint32_t drop_site, const uint32_t* rng, void* stream);
 
-// gemm_lt.hip: plain nn.Linear GEMMs above a size threshold on hipBLASLt (bound at run time); 0 = launched, 1 = not taken
-int ksmi_lt_linear_forward(const void* x, int x_rs, const void* w, int w_rs, const float* bias, const void* resid, int r_rs, void* y, int y_rs,
-                           int rows, int K, int N, hipStream_t st);
-int ksmi_lt_linear_dgrad(const void* dy, int dy_rs, const void* w, int w_rs, void* dx, int dx_rs, int rows, int K, int N, int accumulate,
-                         hipStream_t st);
-int ksmi_lt_linear_wgrad(const void* x, int x_rs, const void* dy, int dy_rs, float* grad, int g_rs, int rows, int K, int N, int accumulate,
-                         hipStream_t st);
-
 // gemm2.hip: LDS-DMA token GEMMs; 0 = launched, 1 = shape not covered (fall back to gemm.hip), < 0 = error
 int ksmi_gemm2_nt(const void* x, int x_rs, const void* w, int w_rs, const float* bias, const void* resid, int r_rs, void* y, int y_rs,
                   int rows, int K, int N, hipStream_t st);

@@ -265,7 +265,6 @@ static int gemm_args_ok(int a_rs, int w_rs, int o_rs, int r_rs, int K, int N) {
 int ksmi_gemm_nt(const void* x, int x_rs, const void* w, int w_rs, const float* bias, const void* resid, int r_rs, void* y, int y_rs,
                  int rows, int K, int N, void* stream) {
   if (!gemm_args_ok(x_rs, w_rs, y_rs, r_rs, K, N) || rows < 1) return ksmi_fail(KSMI_E_ARG, "gemm_nt: strides, K and N must be multiples of 8");
-  if (ksmi_lt_linear_forward(x, x_rs, w, w_rs, bias, resid, r_rs, y, y_rs, rows, K, N, (hipStream_t)stream) == 0) return 0;   // opt-in comparison route
   { const int r2 = ksmi_gemm2_nt(x, x_rs, w, w_rs, bias, resid, r_rs, y, y_rs, rows, K, N, (hipStream_t)stream); if (r2 <= 0) return r2; }
   GemmP p = {(const bf16_t*)x, x_rs, (const bf16_t*)w, w_rs, bias, (const bf16_t*)resid, r_rs, (bf16_t*)y, y_rs, rows, K, N, 0};
   const int mtiles = (rows + 127) / 128;
@@ -276,7 +275,6 @@ int ksmi_gemm_nt(const void* x, int x_rs, const void* w, int w_rs, const float* 
 
 int ksmi_gemm_nn(const void* dy, int dy_rs, const void* w, int w_rs, void* dx, int dx_rs, int rows, int K, int N, int accumulate, void* stream) {
   if (!gemm_args_ok(dy_rs, w_rs, dx_rs, 0, K, N) || rows < 1) return ksmi_fail(KSMI_E_ARG, "gemm_nn: strides, K and N must be multiples of 8");
-  if (ksmi_lt_linear_dgrad(dy, dy_rs, w, w_rs, dx, dx_rs, rows, K, N, accumulate, (hipStream_t)stream) == 0) return 0;          // opt-in comparison route
   { const int r2 = ksmi_gemm2_nn(dy, dy_rs, w, w_rs, dx, dx_rs, rows, K, N, accumulate, (hipStream_t)stream); if (r2 <= 0) return r2; }
   GemmP p = {(const bf16_t*)dy, dy_rs, (const bf16_t*)w, w_rs, nullptr, nullptr, 0, (bf16_t*)dx, dx_rs, rows, K, N, accumulate};
   const int mtiles = (rows + 127) / 128;

@@ -830,13 +830,10 @@ int launch_wgrad(const ksmi_wgrad_desc* d, hipStream_t st) {
     return ksmi_wgrad3_reduce(d, &g.g3, st);
   }
   if (g.tn) {
-    // plain row-major nn.Linear gradient (unit K stride, one tap at offset 0, contiguous k rows): large problems go to hipBLASLt
+    // plain row-major nn.Linear gradient (unit K stride, one tap at offset 0, contiguous k rows)
     bool plain = d->gK == 1 && (!d->use_tap_off || d->tap_off[0] == 0) && d->gN >= d->src[0].c_len && d->gN < ((int64_t)1 << 31);
     if (plain && !d->uniform_kc)
       for (int i = 0; i < d->nchunks; ++i) plain = plain && d->k_off[i] == i * g.kc;
-    if (plain && ksmi_lt_linear_wgrad((const bf16_t*)d->src[0].ptr + d->src[0].c_off, d->src[0].C, (const bf16_t*)d->dy + d->dy_c_off, d->dyC,
-                                      d->grad, (int)d->gN, d->B * d->Hout * d->Wout, d->src[0].c_len, d->N, d->accumulate, st) == 0)
-      return 0;
     {
       const int rows = d->B * d->Hout * d->Wout;
       const bool direct = plain && g.nsplit == 1;
@@ -1011,9 +1008,8 @@ size_t ksmi_conv_wgrad_workspace(const ksmi_wgrad_desc* d, int dtype) {
 // 1: ksmi_conv_wgrad(d) also writes d->bias_grad (the token-GEMM path of gemm2.hip in its one-split, direct-write mode)
 int ksmi_conv_wgrad_fuses_bias(const ksmi_wgrad_desc* d, int dtype) {
   if (!d || dtype != KSMI_BF16 || d->nsrc != 1) return 0;
-  static const bool lt = getenv("KSMI_USE_HIPBLASLT") != nullptr;
   static const bool off = getenv("KSMI_NO_FUSED_BIAS_GRAD") != nullptr;
-  if (lt || off) return 0;
+  if (off) return 0;
   WgradGeom g = wgrad_geom<bf16_t>(d);
   if (!g.tn || g.v3 || g.nsplit != 1) return 0;
   bool plain = d->gK == 1 && (!d->use_tap_off || d->tap_off[0] == 0) && d->gN >= d->src[0].c_len && d->gN < ((int64_t)1 << 31);

@@ -368,7 +368,11 @@ bool ksmi_igemm3_geom(const ksmi_conv_desc* d, int dtype, ksmi_igemm3_geom_t* g)
   if (d->alpha != 0.f || d->resid || d->relu_out || d->out_sy || d->in_sy) return false;
   if ((d->N % 8) || (d->dst[0].C % 8) || (d->dst[0].c_off % 8) || d->Npad < 32) return false;
   if (d->ps_cout && (d->ps_cout % 8)) return false;
-  if (d->mask_src) return false;                                    // (ReLU-mask epilogue: igemm2's lean kernel is already HBM-bound)
+  // ReLU-mask + BN-backward sums epilogue: instances exist for 3x3 (KSMI_IGEMM3_MASK=1) but measured slower than the tile kernel /
+  // igemm4 (K = 32: 154 vs 89 us, the mask loads spill 45 VGPRs next to the register-resident weights; K = 64: 72 vs 64 us): off
+  static const bool mask_on = getenv("KSMI_IGEMM3_MASK") ? atoi(getenv("KSMI_IGEMM3_MASK")) != 0 : false;
+  if (d->mask_src && !(mask_on && taps == 9)) return false;
+  if (d->gate_src) return false;
   auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
   if (!al16(d->dst[0].ptr) || !al16(d->bias)) return false;
   for (int i = 0; i < d->nsrc; ++i) {
@@ -388,7 +392,9 @@ bool ksmi_igemm3_geom(const ksmi_conv_desc* d, int dtype, ksmi_igemm3_geom_t* g)
   g->NTI = 1;
   if (taps == 9) {
     if (d->nchunks > 2) return false;
-    if (d->nchunks == 2) { if (aff) return false; g->WN = 1; }       // (fused-operand K = 64: igemm2's register staging is as fast)
+    // (fused-operand K = 64 on this kernel, KSMI_IGEMM3_AFF2=1: 99 us against 68 us on igemm4, one 4-wave workgroup per CU)
+    static const bool aff2_on = getenv("KSMI_IGEMM3_AFF2") ? atoi(getenv("KSMI_IGEMM3_AFF2")) != 0 : false;
+    if (d->nchunks == 2) { if (aff && !aff2_on) return false; g->WN = 1; }
   } else if (taps == 4) {
     if (aff || (d->nchunks != 1 && d->nchunks != 2 && d->nchunks != 4)) return false;
     if (d->nchunks == 4) g->WN = 1;
@@ -446,6 +452,13 @@ int ksmi_igemm3_launch(const ksmi_conv_desc* d, const ksmi_igemm3_geom_t* g, hip
   const dim3 grid(g->gx, g->gy);
   const bool aff = d->src[0].scale != nullptr;
   const int taps = d->KH * d->KW;
+#define KSMI_G3M(KH_, KW_, NCH_, WN_, AFF_, NTI_, MASK_)                                             \
+  do {                                                                                               \
+    auto kfn = igemm3_kernel<KH_, KW_, NCH_, WN_, AFF_, NTI_, MASK_>;                                \
+    if (g->lds > 65536) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g->lds); \
+    hipLaunchKernelGGL(kfn, grid, dim3(256 * WN_), g->lds, st, ka);                                  \
+    return ksmi_check_launch("igemm3");                                                              \
+  } while (0)
 #define KSMI_G3(KH_, KW_, NCH_, WN_, AFF_, NTI_)                                                     \
   do {                                                                                               \
     auto kfn = igemm3_kernel<KH_, KW_, NCH_, WN_, AFF_, NTI_, false>;                                \
@@ -455,6 +468,11 @@ int ksmi_igemm3_launch(const ksmi_conv_desc* d, const ksmi_igemm3_geom_t* g, hip
   } while (0)
 #define KSMI_G3W(KH_, KW_, NCH_, AFF_, NTI_)                                                         \
   do { if (g->WN == 2) KSMI_G3(KH_, KW_, NCH_, 2, AFF_, NTI_); else KSMI_G3(KH_, KW_, NCH_, 1, AFF_, NTI_); } while (0)
+  if (taps == 9 && d->mask_src) {
+    if (aff) return ksmi_fail(KSMI_E_UNSUPPORTED, "igemm3: fused operand and mask epilogue together");
+    if (d->nchunks == 1) { if (g->WN == 2) KSMI_G3M(3, 3, 1, 2, false, 1, true); else KSMI_G3M(3, 3, 1, 1, false, 1, true); }
+    if (d->nchunks == 2) KSMI_G3M(3, 3, 2, 1, false, 1, true);
+  }
   if (taps == 9) {
     if (d->nchunks == 1) { if (aff) KSMI_G3W(3, 3, 1, true, 1); else KSMI_G3W(3, 3, 1, false, 1); }
     if (d->nchunks == 2) { if (aff) KSMI_G3(3, 3, 2, 1, true, 1); else KSMI_G3(3, 3, 2, 1, false, 1); }
@@ -469,5 +487,6 @@ int ksmi_igemm3_launch(const ksmi_conv_desc* d, const ksmi_igemm3_geom_t* g, hip
   }
 #undef KSMI_G3W
 #undef KSMI_G3
+#undef KSMI_G3M
   return ksmi_fail(KSMI_E_UNSUPPORTED, "igemm3: no instance (geometry / launch mismatch)");
 }

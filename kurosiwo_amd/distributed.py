@@ -65,13 +65,19 @@ def shard_batch(batch, rank=None, world=None, even=True):
     if world == 1:
         return batch
 
+    nb = next((t.shape[0] for t in batch if torch.is_tensor(t) and t.dim() > 0), None)     # samples in the global batch
+
     def cut(t):
         if torch.is_tensor(t):
+            if t.dim() == 0:
+                return t
             n = t.shape[0]
             if even and n % world:
                 raise ValueError(f"global batch {n} is not divisible by world size {world}")
             return t[n * rank // world:n * (rank + 1) // world]
         if isinstance(t, (list, tuple)):
+            if nb is not None and len(t) == nb and not any(torch.is_tensor(x) or isinstance(x, (list, tuple)) for x in t):
+                return type(t)(t[nb * rank // world:nb * (rank + 1) // world])      # per-sample python values (names, ids)
             return type(t)(cut(x) for x in t)
         return t
     return tuple(cut(t) for t in batch)

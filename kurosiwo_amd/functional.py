@@ -286,6 +286,8 @@ def _drop_args(p, site, rng_state):
     """(thr, inv_keep, site, state pointer) of one stochastic layer; p = 0 -> off (see ksmi.h: ksmi_dropout_apply)"""
     if p <= 0.0:
         return 0, 1.0, 0, None
+    if p >= 1.0:
+        raise ValueError("dropout probability must be < 1 (nn.Dropout(1.0) zeroes everything: drop the branch instead)")
     if rng_state is None or rng_state.dtype != torch.int32 or rng_state.numel() != 2:
         raise ValueError("rng_state: int32[2] device tensor {seed, step}")
     return min(0xFFFFFFFF, int(round(p * 4294967296.0))), 1.0 / (1.0 - p), site, rng_state.data_ptr()

@@ -98,13 +98,23 @@ class _PlanTrainStep:
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             self._run_eager()
-        self._graph, self._graph_lr = g, self.optimizer.param_groups[0]["lr"]
+        self._graph, self._graph_hp = g, self._baked_hyper()
         return self
+
+    def _baked_hyper(self):
+        """every optimiser scalar a captured step bakes into its kernel arguments (a change of any of them re-captures)"""
+        keys = ("lr", "betas", "eps", "weight_decay", "momentum", "dampening", "nesterov", "amsgrad")
+        return tuple(tuple((k, g[k]) for k in keys if k in g) for g in self.optimizer.param_groups) + (self.world,)
 
     def run(self):
         """One train step on the batch currently resident in the plan's input buffers."""
         if self._graph is not None and self.timer is None:
-            if self.optimizer.param_groups[0]["lr"] != self._graph_lr:
+            if self._baked_hyper() != self._graph_hp:
+                self._recaptures = getattr(self, "_recaptures", 0) + 1
+                if self._recaptures == 8:
+                    import warnings
+                    warnings.warn("hip_graph: the optimiser hyper-parameters changed in 8 steps (a per-iteration LR schedule?); every "
+                                  "change costs one eager step + a capture -- run such schedules without hip_graph")
                 self.capture_graph()
                 return
             self._graph.replay()

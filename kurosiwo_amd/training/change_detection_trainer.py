@@ -93,23 +93,30 @@ def train_change_detection(model, train_loader, val_loader, test_loader, configs
         _print_metrics(f"Epoch {epoch} train", metrics.compute(), loss_val)
         if main and (epoch + 1) % configs.get("train_save_checkpoint_freq", 1) == 0:
             torch.save({"epoch": epoch, "model_state_dict": model.state_dict(), "optimizer_state_dict": optimizer.state_dict(),
-                        "lr_scheduler_state_dict": lr_scheduler.state_dict(), "loss": loss_val},
+                        "lr_scheduler_state_dict": lr_scheduler.state_dict(), "loss": loss_val, "rng_state": _rng_words(model)},
                        Path(configs["checkpoint_path"]) / f"checkpoint_epoch={epoch}.pt")
         lr_scheduler.step()
         val_acc, val_score, miou = eval_change_detection(model, val_loader, settype="Validation", configs=configs,
                                                          model_configs=model_configs)
-        if miou > best_val:
+        improved = miou > best_val                   # strict, as change_detection_trainer.py:305 (a tie keeps the earlier checkpoint)
+        if improved:
             best_val = miou
-        if miou >= best_val and main:               # (every rank holds the same all-reduced metrics; rank 0 writes)
+        if improved and main:                        # (every rank holds the same all-reduced metrics; rank 0 writes)
             print(f"New best validation mIoU: {miou}")
             print(f'Saving model to: {configs["checkpoint_path"]}/best_segmentation.pt')
             torch.save({"epoch": epoch, "model_state_dict": model.state_dict(), "optimizer_state_dict": optimizer.state_dict(),
-                        "lr_scheduler_state_dict": lr_scheduler.state_dict(), "loss": loss_val},
+                        "lr_scheduler_state_dict": lr_scheduler.state_dict(), "loss": loss_val, "rng_state": _rng_words(model)},
                        Path(configs["checkpoint_path"]) / "best_segmentation.pt")
             with open(Path(configs["checkpoint_path"]) / "best_segmentation.txt", "w") as f:
                 f.write(f"{epoch}\n")
                 f.write(f"{miou}")
         D.barrier()                                 # checkpoints of this epoch are on disk before any rank moves on
+
+
+def _rng_words(model):
+    """{seed, step} of the counter-based Dropout / DropPath stream (a new key next to the reference's checkpoint keys: a resumed run
+    continues the stream instead of replaying the masks of the first steps)"""
+    return [int(v) & 0xFFFFFFFF for v in model.rng_state().cpu().tolist()] if hasattr(model, "rng_state") else None
 
 
 def eval_change_detection(model, loader, settype, configs=None, model_configs=None):

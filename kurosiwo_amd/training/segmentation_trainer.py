@@ -56,10 +56,11 @@ def train_semantic_segmentation(model, train_loader, val_loader, test_loader, co
         model.eval()
         val_acc, val_score, miou = eval_semantic_segmentation(model, val_loader, settype="Val", configs=configs,
                                                               model_configs=model_configs)
-        if miou > best_val:
+        improved = miou > best_val                   # strict, as segmentation_trainer.py:243 (a tie keeps the earlier checkpoint)
+        if improved:
             best_val = miou
             best_stats["miou"], best_stats["epoch"] = best_val, epoch
-        if miou >= best_val and main:
+        if improved and main:
             print("Epoch: ", epoch)
             print("New best validation mIOU: ", float(miou))
             print("Saving model to: ", configs["checkpoint_path"] + "/" + "best_segmentation.pt")

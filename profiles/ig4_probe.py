@@ -32,6 +32,8 @@ def rnd(*shape):
 
 
 SHAPES = [  # name, H, cs, N, mode
+    ("L0 conv2 32->32 aff", 224, [32], 32, "aff"),
+    ("L0 dgrad2 32->32 mask", 224, [32], 32, "mask"),
     ("L0 conv0_1 128->32", 224, [32, 32, 64], 32, ""),
     ("L0 conv0_4 224->32", 224, [32] * 5 + [64], 32, ""),
     ("L0 dx0_0 128->32", 224, [32] * 4, 32, ""),

@@ -117,3 +117,28 @@ def test_side_lane_equals_single_stream(family, graph):
         assert torch.equal(a, b), (a.tolist(), b.tolist())
     assert torch.equal(out[0][2], out[1][2])
     assert torch.equal(out[0][1], out[1][1])
+
+
+def test_lanes_without_the_side_stream_equal_single_stream():
+    """overlap_lanes on, overlap_wgrad off (configs["overlap_wgrad"] = False / KSMI_OVERLAP_WGRAD=0): the weight gradients of the two compute
+    lanes then run concurrently on their lanes' streams, so their partial-slab scratch must be per lane (round-2 advisor finding: one
+    shared `wgrad` scratch was only safe while every weight gradient serialised on the side stream).  Bitwise-equal trajectory."""
+    from kurosiwo_amd.snunet import SNUNet_ECAM
+    from kurosiwo_amd.trainer import CDTrainStep
+    B, S = 4, 224
+    data = _batches(4, B, 2, S, 33)
+    out = []
+    for lanes in (False, True):
+        torch.manual_seed(5)
+        m = SNUNet_ECAM(2, 3, base_channel=32, precision="bf16").cuda().train()
+        st = CDTrainStep(m, B, S, S, "ce+dice", (1.0, 2.0, 3.0), lr=1e-3, overlap_wgrad=False, overlap_lanes=lanes)
+        losses = [st.step(xA.cuda(), xB.cuda(), y.cuda()).clone() for xA, xB, y in data]
+        torch.cuda.synchronize()
+        if lanes:
+            assert st._ss is not None and st._ss.lanes and not st._ss.use_side
+            names = set(st.plan._need)
+            assert "wgrad" in names and "wgrad@1" in names          # one partial-slab scratch per lane
+        out.append((losses, m.flat_params.clone(), m.flat_grads.clone()))
+    for a, b in zip(out[0][0], out[1][0]):
+        assert torch.equal(a, b), (a.tolist(), b.tolist())
+    assert torch.equal(out[0][2], out[1][2]) and torch.equal(out[0][1], out[1][1])

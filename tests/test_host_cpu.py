@@ -136,3 +136,16 @@ def test_multi_scale_prediction_and_factory_guards():
     with pytest.raises(NotImplementedError, match="multi_scale_train"):
         initialize_cd_model({"method": "changeformer", "num_channels": 2, "num_classes": 3, "device": "cpu"},
                             {"embed_dim": 256, "decoder_softmax": False, "multi_scale_train": True, "multi_scale_infer": False})
+
+
+def test_shard_batch_python_lists_and_scalars():
+    """per-sample python values (tile names) are cut with the tensors; 0-dim tensors and the per-channel scale lists pass through"""
+    import torch
+    from kurosiwo_amd.distributed import shard_batch
+    x = torch.arange(8 * 3).reshape(8, 3)
+    names = [f"tile{i}" for i in range(8)]
+    scales = [torch.arange(8.0), torch.arange(8.0) + 10]        # list of per-channel [B] tensors (Dataset.py:844-858)
+    flag = torch.tensor(7)
+    a = shard_batch((x, names, scales, flag), rank=1, world=4)
+    assert a[0].tolist() == x[2:4].tolist() and a[1] == ["tile2", "tile3"]
+    assert [t.tolist() for t in a[2]] == [[2.0, 3.0], [12.0, 13.0]] and int(a[3]) == 7

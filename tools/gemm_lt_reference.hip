@@ -1,3 +1,5 @@
+// NOT part of libksmi.so since round 3 (the product library holds hand-written kernels only): kept as the record of the round-1/2
+// hipBLASLt comparison route.  The library-vs-hand-written comparison is profiles/gemm_probe.py (torch.matmul = hipBLASLt).
 // OPTIONAL comparison path, off by default: plain nn.Linear GEMMs (vision_transformer.py:22-31,47-50; changeformer.py:110-113,157-161)
 // above a size threshold can be sent to hipBLASLt with KSMI_USE_HIPBLASLT=1, to time the library next to the hand-written
 // LDS-DMA kernels of gemm2.hip, which are the product path (FloodViT step, MI355X: 949 tiles/s hand-written, 976 with the
