@@ -288,6 +288,39 @@ def gen_floodvit(tag, hp, B, head="decoder"):
     np.savez_compressed(os.path.join(OUT, f"floodvit_{tag}.npz"), **out)
 
 
+def gen_floodvit_bench():
+    """BASELINE.json configs[4] per-GPU shard exactly as benchmarked (full-depth ViT d1024 L24 h16 mlp2048 + Decoder head, batch 16,
+    224 x 224, the synthetic 3-date SAR tiles of bench.py) on the REAL reference in fp32: encoder tokens, logits, weighted-CE loss,
+    gradient statistics of every parameter -- what the bf16 HIP path is held to at the size and on the data it is timed on."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from kurosiwo_amd.synthetic import make_batch, seg_inputs
+    out = {}
+    B = 16
+    x, lbl = seg_inputs(make_batch(B, 224, 224, seed=1234))           # [post, pre1, pre2] = 3 dates x 2 ch
+    model = _ref_floodvit(FLOODVIT_FULL, "decoder")
+    model.train()
+    tokens = model.model(x)
+    out["tokens_sub"] = tokens[::4, ::7, ::16].detach().numpy().copy()
+    out["tokens_absmax"] = np.array(float(tokens.detach().abs().max()))
+    logits = model(x)
+    crit = torch.nn.CrossEntropyLoss(weight=torch.tensor(CLASS_WEIGHTS), ignore_index=3)
+    loss = crit(logits, lbl)
+    loss.backward()
+    out["logits_sub"] = logits[:, :, ::8, ::8].detach().numpy().copy()
+    out["logits_absmax"] = np.array(float(logits.detach().abs().max()))
+    out["argmax_sub"] = logits[::4].detach().argmax(1).numpy().astype(np.uint8)
+    top2 = logits[::4].detach().topk(2, dim=1).values
+    out["margin_sub"] = (top2[:, 0] - top2[:, 1]).numpy().astype(np.float16)
+    out["loss"] = np.array(float(loss))
+    for k, p in model.named_parameters():
+        g = p.grad.detach().double()
+        out[f"gstat.{k}"] = np.array([float(g.norm()), float(g.sum()), float(g.abs().max())])
+        if k in FLOODVIT_GRAD_KEYS or k in ("model.transformer.layers.23.1.net.4.bias", "model.transformer.layers.12.0.to_out.0.bias"):
+            out[f"grad.{k}"] = p.grad.detach().numpy().copy()
+    print("floodvit_bench loss", float(loss), "logits absmax", float(logits.abs().max()))
+    np.savez_compressed(os.path.join(OUT, "floodvit_bench.npz"), **out)
+
+
 MAE_SMALL = dict(channels=2, image_size=224, patch_size=16, dim=1024, depth=2, heads=4, mlp_dim=512, decoder_dim=512, decoder_depth=2,
                  decoder_heads=4)
 MAE_GRAD_KEYS = ["mask_token", "encoder.to_patch_embedding.2.bias", "encoder.transformer.norm.weight", "encoder.transformer.layers.0.0.to_out.0.bias",
@@ -499,17 +532,11 @@ def gen_changeformer_slc():
 DROP_SEED, DROP_STEP = 20240607, 1
 
 
-def gen_changeformer_drop():
-    """Train-mode step of the REFERENCE ChangeFormerV6 with its stochastic layers ON (drop_rate = attn_drop = drop_path_rate = 0.1,
-    changeformer.py:651-653).  The module graph, the places and probabilities of every nn.Dropout / DropPath are the reference's;
-    only the source of the Bernoulli draws is replaced: each module instance draws from the counter-based stream of
-    oracle/rng_ref.py (site = 8 * block index + role, element index = position in the 2B-image batch the HIP path runs), which is
-    what the HIP kernels regenerate.  The k-th call of a module tells the role: Tenc_x2 runs date 1 then date 2 (:666-670), Mlp.drop
-    is called after the activation and after fc2 (:130,132), Block.drop_path for the attention and the Mlp branch (:246-247)."""
+def _changeformer_drop_model(c, B):
+    """the REFERENCE ChangeFormerV6 in train mode with every nn.Dropout / DropPath drawing from the counter-based stream (see
+    gen_changeformer_drop); B = images per date"""
     from oracle import rng_ref as G
     ChangeFormerV6 = _import_changeformer_reference()
-    out = {}
-    c, B = 2, 2
     model = ChangeFormerV6(input_nc=c, output_nc=3, decoder_softmax=True, embed_dim=256)
     seeded_fill_(model.state_dict())
     model.train()
@@ -549,6 +576,19 @@ def gen_changeformer_drop():
                 install(blk.drop_path, gi, [G.SITE_PATH_ATTN, G.SITE_PATH_MLP], 2, True)
             gi += 1
     assert ndrop == sum(isinstance(m, torch.nn.Dropout) for m in model.modules()), "an nn.Dropout outside the encoder blocks"
+    return model
+
+
+def gen_changeformer_drop():
+    """Train-mode step of the REFERENCE ChangeFormerV6 with its stochastic layers ON (drop_rate = attn_drop = drop_path_rate = 0.1,
+    changeformer.py:651-653).  The module graph, the places and probabilities of every nn.Dropout / DropPath are the reference's;
+    only the source of the Bernoulli draws is replaced: each module instance draws from the counter-based stream of
+    oracle/rng_ref.py (site = 8 * block index + role, element index = position in the 2B-image batch the HIP path runs), which is
+    what the HIP kernels regenerate.  The k-th call of a module tells the role: Tenc_x2 runs date 1 then date 2 (:666-670), Mlp.drop
+    is called after the activation and after fc2 (:130,132), Block.drop_path for the attention and the Mlp branch (:246-247)."""
+    out = {}
+    c, B = 2, 2
+    model = _changeformer_drop_model(c, B)
     x1 = sar_like("changeformer.drop.x1", (B, c, 224, 224))
     x2 = sar_like("changeformer.drop.x2", (B, c, 224, 224))
     lbl = seeded_labels("changeformer.drop.lbl", (B, 224, 224))
@@ -571,6 +611,40 @@ def gen_changeformer_drop():
             out[f"grad.{k}"] = p.grad.detach().numpy().copy()
     print("changeformer drop train loss", float(loss.detach()))
     np.savez_compressed(os.path.join(OUT, "changeformer_drop.npz"), **out)
+
+
+def gen_changeformer_bench():
+    """BASELINE.json configs[3] as benchmarked, at batch 8: ChangeFormerV6(input_nc = 4: SLC tiles), 224 x 224, stochastic layers ON (on
+    the counter-based stream, as gen_changeformer_drop), the synthetic SAR tiles of bench.py, ce+dice on the sigmoid map, on the REAL
+    reference in fp32: the five outputs (sub-sampled), the loss, gradient statistics of every parameter."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from kurosiwo_amd.synthetic import cd_inputs, make_batch
+    out = {}
+    c, B = 4, 8
+    (x1, x2), lbl = cd_inputs(make_batch(B, 224, 224, seed=1234, channels=c), ("pre_event_1", "post_event"))
+    model = _changeformer_drop_model(c, B)
+    crit = BCEandDiceLoss(weights=[1.0, 1.0, 1.0], ignore_index=3, use_softmax=True)
+    outs = model(x1, x2)
+    loss = crit(outs[-1], lbl)
+    loss.backward()
+    out["seed_step"] = np.array([DROP_SEED, DROP_STEP])
+    for i, o in enumerate(outs[:4]):
+        out[f"train.out{i}"] = o.detach().numpy().copy()
+    out["train.out4_sub"] = outs[4][:, :, ::8, ::8].detach().numpy().copy()
+    out["train.argmax_sub"] = outs[4][::2].detach().argmax(1).numpy().astype(np.uint8)
+    top2 = outs[4][::2].detach().topk(2, dim=1).values
+    out["train.margin_sub"] = (top2[:, 0] - top2[:, 1]).numpy().astype(np.float16)
+    out["train.loss"] = np.array(float(loss.detach()))
+    for k, p in model.named_parameters():
+        if p.grad is None:
+            out[f"gstat.{k}"] = np.zeros(3)
+            continue
+        g = p.grad.detach().double()
+        out[f"gstat.{k}"] = np.array([float(g.norm()), float(g.sum()), float(g.abs().max())])
+        if k in CHANGEFORMER_GRAD_KEYS:
+            out[f"grad.{k}"] = p.grad.detach().numpy().copy()
+    print("changeformer bench train loss", float(loss.detach()))
+    np.savez_compressed(os.path.join(OUT, "changeformer_bench.npz"), **out)
 
 
 def gen_fcsiam():
@@ -699,6 +773,10 @@ if __name__ == "__main__":
         gen_changeformer_slc()
     if not only or "changeformer_drop" in only:
         gen_changeformer_drop()
+    if not only or "changeformer_bench" in only:
+        gen_changeformer_bench()
+    if not only or "floodvit_bench" in only:
+        gen_floodvit_bench()
     if not only or "fcsiam" in only:
         gen_fcsiam()
     if not only or "bitcd" in only:
