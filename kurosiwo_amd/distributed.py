@@ -24,7 +24,9 @@ def init_distributed(configs=None):
     and, when `configs` is given, records them and points configs['device'] at this rank's GPU."""
     world = env_world()
     rank, local = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    # KSMI_DP_FORCE=1: join a ONE-rank group as well, so that the collective path (RCCL communicator, device_id binding, bucket hooks,
+    # stream joins) runs on a single GPU -- tests/test_gpu_dp.py::test_main_entry_on_the_rccl_backend_one_rank
+    if (world > 1 or os.environ.get("KSMI_DP_FORCE")) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         # KSMI_DIST_BACKEND=gloo: several ranks on ONE GPU (the single-GPU test box; RCCL refuses duplicate devices)

@@ -9,7 +9,7 @@ import torch
 import torch.distributed as dist
 
 from . import _lib
-from .dp import BucketedAllReduce, make_buckets
+from .dp import BucketedAllReduce, default_grad_dtype, make_buckets
 from .optim import FusedAdam
 from .runtime import stream_ptr
 
@@ -18,7 +18,7 @@ class _PlanTrainStep:
     """zero_grad -> forward -> criterion -> backward (+ bucketed all-reduce) -> optimizer.step over a model plan."""
 
     def __init__(self, model, plan, B, H, W, loss_function="ce+dice", class_weights=(1.0, 1.0, 1.0), optimizer=None, lr=1e-3,
-                 bucket_mb=8.0, group=None, graph=False, overlap_wgrad=True, overlap_lanes=True):
+                 bucket_mb=8.0, group=None, graph=False, overlap_wgrad=True, overlap_lanes=True, grad_dtype=None):
         if loss_function not in ("ce+dice", "cross_entropy"):
             raise NotImplementedError(loss_function)
         self.model = model
@@ -36,7 +36,8 @@ class _PlanTrainStep:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         ready = {k: self.plan.param_ready.get(k, -1) for k in model._poff}
         buckets = make_buckets(ready, model._poff, None, n, int(bucket_mb * 1e6 / 4))
-        self.reducer = BucketedAllReduce(model.flat_grads, buckets, group)
+        self.grad_dtype = grad_dtype or default_grad_dtype(n)          # wire format of the gradient buckets (dp.py)
+        self.reducer = BucketedAllReduce(model.flat_grads, buckets, group, self.grad_dtype if self.world > 1 or os.environ.get("KSMI_DP_FORCE") else "fp32")
         self.timer = None          # optional kernel timer (bench.py)
         self.use_graph = bool(graph) and self.world == 1     # replay the step as one captured HIP graph (configs["hip_graph"])
         self.overlap_wgrad = bool(overlap_wgrad) and os.environ.get("KSMI_OVERLAP_WGRAD", "1") != "0"
@@ -183,7 +184,7 @@ class MAETrainStep:
     """training/train_mae.py:62-122 on the MAE plan: step(image) = zero_grad -> mae(image) (fresh random permutation,
     models/mae.py:73) -> backward (+ bucketed all-reduce) -> Adam, as one launch sequence.  loss_out[0] = reconstruction loss."""
 
-    def __init__(self, model, B, optimizer=None, lr=1e-5, bucket_mb=32.0, group=None, loss_scale=1.0):
+    def __init__(self, model, B, optimizer=None, lr=1e-5, bucket_mb=32.0, group=None, loss_scale=1.0, grad_dtype=None):
         self.model, self.B = model, B
         self.lib = _lib.load()
         self.plan = model.plan(B, True)
@@ -191,7 +192,9 @@ class MAETrainStep:
         n = model.flat_params.numel()
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         ready = {k: self.plan.param_ready.get(k, -1) for k in model._poff}
-        self.reducer = BucketedAllReduce(model.flat_grads, make_buckets(ready, model._poff, None, n, int(bucket_mb * 1e6 / 4)), group)
+        self.grad_dtype = grad_dtype or default_grad_dtype(n)
+        self.reducer = BucketedAllReduce(model.flat_grads, make_buckets(ready, model._poff, None, n, int(bucket_mb * 1e6 / 4)), group,
+                                         self.grad_dtype if self.world > 1 or os.environ.get("KSMI_DP_FORCE") else "fp32")
         self.loss_out = self.plan.loss
         self.plan.dloss.fill_(loss_scale)
         self.timer = None

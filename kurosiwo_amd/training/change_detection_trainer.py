@@ -78,7 +78,7 @@ def train_change_detection(model, train_loader, val_loader, test_loader, configs
             if step is None or step.B != xA.shape[0]:
                 step = CDTrainStep(model, xA.shape[0], xA.shape[2], xA.shape[3], configs["loss_function"],
                                    configs.get("class_weights", [1.0, 1.0, 1.0]), optimizer=optimizer, graph=configs.get("hip_graph", False),
-                                   overlap_wgrad=configs.get("overlap_wgrad", True), overlap_lanes=configs.get("overlap_lanes", True))
+                                   overlap_wgrad=configs.get("overlap_wgrad", True), grad_dtype=configs.get("dp_grad_dtype"), overlap_lanes=configs.get("overlap_lanes", True))
             step.step(xA.to(dev, non_blocking=True), xB.to(dev, non_blocking=True), mask.to(dev, non_blocking=True))
             if configs["method"] == "changeformer" and model_configs.get("multi_scale_infer"):
                 metrics.update(multi_scale_prediction(step.plan.outputs), step.labels)

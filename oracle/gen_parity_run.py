@@ -6,7 +6,10 @@ by tests/golden/snunet_*.npz) -- fp32, 40 Adam steps of ce+dice on batches of 4 
 held-out tiles after 20 and after 40 steps -- and stores the loss trajectory, the 4x4 confusion matrix, per-class IoU and mIoU in tests/golden/snunet_parity_run.npz.
 The GPU test (tests/test_gpu_parity_gate.py) repeats the run on the HIP path in bf16 and in fp32 from the same weights and tiles.
 
-    python oracle/gen_parity_run.py          # ~3 minutes on 8 CPU threads
+    python oracle/gen_parity_run.py              # the oracle's run, ~3 minutes on 8 CPU threads
+    python oracle/gen_parity_run.py --reference  # the SAME protocol on the imported reference (/root/reference/models/snunet.py,
+                                                 # utilities/bce_and_dice.py, torch.optim.Adam as change_detection_trainer.py:45-66
+                                                 # builds it): tests/golden/snunet_parity_run_ref.npz -- the vectors the gate uses
 """
 import os
 import sys
@@ -57,5 +60,50 @@ def main():
                         protocol=np.array([K_STEPS, TRAIN_TILES, BATCH, HELD_OUT, HELD_OUT_SEED, TRAIN_SEED]), **out)
 
 
+def main_reference():
+    """the protocol of main() driven through the REAL reference modules (build container only): model(xA, xB) -> BCEandDiceLoss ->
+    backward -> Adam.step as training/change_detection_trainer.py:135-180 does; eval-mode inference + the integer metrics of
+    oracle/metrics_ref.py (torchmetrics is not installed) on the held-out tiles"""
+    sys.path.insert(0, "/root/reference")
+    sys.dont_write_bytecode = True
+    from models.snunet import SNUNet_ECAM                      # (reference)
+    from utilities.bce_and_dice import BCEandDiceLoss          # (reference)
+    torch.set_num_threads(8)
+    (xA, xB, mask), (eA, eB, emask) = protocol_tiles()
+    model = SNUNet_ECAM(2, 3, base_channel=32)
+    seeded_fill_(model.state_dict())
+    optimizer = torch.optim.Adam(model.parameters(), lr=1e-3)
+    criterion = BCEandDiceLoss(weights=[1.0, 1.0, 1.0], ignore_index=3, use_softmax=True)
+    losses, out = [], {}
+
+    def evaluate(tag):
+        cm = np.zeros((4, 4), np.int64)
+        model.eval()
+        with torch.no_grad():
+            for s in range(0, HELD_OUT, 8):
+                logits = model(eA[s:s + 8], eB[s:s + 8])
+                cm += metrics_ref.confusion_matrix(metrics_ref.argmax_lowest_index(logits.numpy()), emask[s:s + 8].numpy())
+        model.train()
+        m = metrics_ref.metrics_from_cm(cm)
+        print(tag, "cm\n", cm, "\niou", m["iou"], "miou", m["miou"], flush=True)
+        out[f"cm{tag}"], out[f"iou{tag}"], out[f"miou{tag}"], out[f"f1{tag}"] = cm, m["iou"], np.array(m["miou"]), m["f1"]
+    model.train()
+    for k in range(K_STEPS):
+        s = (k % (TRAIN_TILES // BATCH)) * BATCH
+        optimizer.zero_grad()
+        loss = criterion(model(xA[s:s + BATCH], xB[s:s + BATCH]), mask[s:s + BATCH])
+        loss.backward()
+        optimizer.step()
+        losses.append(float(loss.detach()))
+        print(f"step {k}: loss {losses[-1]:.6f}", flush=True)
+        if k + 1 in CHECKPOINTS:
+            evaluate(str(k + 1))
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "snunet_parity_run_ref.npz"), losses=np.array(losses),
+                        protocol=np.array([K_STEPS, TRAIN_TILES, BATCH, HELD_OUT, HELD_OUT_SEED, TRAIN_SEED]), **out)
+
+
 if __name__ == "__main__":
-    main()
+    if "--reference" in sys.argv[1:]:
+        main_reference()
+    else:
+        main()

@@ -31,7 +31,7 @@ def test_make_buckets_cover_arena_in_order():
     assert make_buckets(ready, offsets, None, 1200, 10 ** 9) == [(0, 1200, 9)]
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, grad_dtype="fp32"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -39,7 +39,7 @@ def _worker(rank, world, port, q):
     flat = torch.zeros(n)
     offsets = {"a": 0, "b": 100, "c": 300, "d": 1000}
     ready = {"a": 9, "b": 7, "c": 3, "d": 1}          # backward finishes the arena tail first
-    red = BucketedAllReduce(flat, make_buckets(ready, offsets, None, n, 250))
+    red = BucketedAllReduce(flat, make_buckets(ready, offsets, None, n, 250), grad_dtype=grad_dtype)
     order = []
     for launch in range(10):                          # the "backward launch list"
         if launch == 1:
@@ -61,11 +61,14 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_bucketed_allreduce_world2_gloo():
+@pytest.mark.parametrize("grad_dtype", ["fp32", "bf16"])
+def test_bucketed_allreduce_world2_gloo(grad_dtype):
+    """grad_dtype = "bf16": the buckets travel as bf16 (staging buffer, SUM on the wire format, cast back into the fp32 arena in wait());
+    the test values are exactly representable, so both wire formats give the same sums"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, grad_dtype)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]
@@ -75,6 +78,15 @@ def test_bucketed_allreduce_world2_gloo():
     for rank, ok, order in res:
         assert ok, rank
         assert order == [(1, 1000, 1200), (3, 300, 1000), (9, 0, 300)], order
+
+
+def test_default_wire_format_by_arena_size(monkeypatch):
+    from kurosiwo_amd.dp import default_grad_dtype
+    monkeypatch.delenv("KSMI_DP_GRAD_DTYPE", raising=False)
+    assert default_grad_dtype(12_034_819) == "fp32" and default_grad_dtype(41_035_255) == "fp32"      # SNUNet, ChangeFormer
+    assert default_grad_dtype(205_600_000) == "bf16"                                                   # FloodViT: 822 MB of fp32 gradients
+    monkeypatch.setenv("KSMI_DP_GRAD_DTYPE", "fp32")
+    assert default_grad_dtype(205_600_000) == "fp32"
 
 
 def test_single_process_is_a_noop():

@@ -135,3 +135,37 @@ def test_main_entry_under_torchrun_two_ranks(tmp_path):
     assert len(runs) == 1, runs                      # one time-stamped directory, named by rank 0
     assert (runs[0] / "best_segmentation.pt").exists()
     assert out.stdout.count("Samples in Train Set") >= 1
+
+
+@pytest.mark.parametrize("wire", ["fp32", "bf16"])
+def test_main_entry_on_the_rccl_backend_one_rank(tmp_path, wire):
+    """The REAL backend on the one GPU of the test box: `KSMI_DP_FORCE=1 python main.py --method snunet` joins a one-rank "nccl" (= RCCL)
+    group (init_process_group with device_id), and every gradient bucket goes through the bucket hooks, the join of the step's three
+    streams and an RCCL all-reduce issued during backward.  A SUM over one rank is the identity: with fp32 buckets the run must end at
+    exactly the mIoU of the run without collectives; with bf16 buckets (the wire format FloodViT defaults to) the gradients are rounded
+    to bf16 once, so the run only has to stay healthy."""
+    import re
+    import shutil
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    wrapper = tmp_path / "run_main.py"
+    wrapper.write_text("import sys\nsys.path.insert(0, %r)\nimport main\nm = main.main(sys.argv[1:])\n"
+                       "import torch.distributed as dist\n"
+                       "print('BACKEND', dist.get_backend() if dist.is_initialized() else 'none', 'MIOU', repr(float(m)), flush=True)\n" % root)
+    res = {}
+    for tag, extra in (("plain", {}), ("rccl", {"KSMI_DP_FORCE": "1", "KSMI_DP_GRAD_DTYPE": wire, "MASTER_PORT": str(_free_port())})):
+        wd = tmp_path / tag
+        wd.mkdir()
+        shutil.copytree(os.path.join(root, "configs"), wd / "configs")
+        env = dict(os.environ, KSMI_SYNTHETIC_TILES="8,4,4", PYTHONPATH=root, MASTER_ADDR="127.0.0.1", **extra)
+        env.pop("KSMI_DIST_BACKEND", None)
+        out = subprocess.run([sys.executable, str(wrapper), "--method", "snunet", "--inputs", "pre_event_1", "post_event", "--batch_size", "4"],
+                             cwd=wd, env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+        res[tag] = re.findall(r"BACKEND (\w+) MIOU ([0-9.e+-]+)", out.stdout)[-1]
+    assert res["plain"][0] == "none" and res["rccl"][0] == "nccl", res
+    if wire == "fp32":
+        assert res["plain"][1] == res["rccl"][1], res
+    else:
+        assert 0.0 <= float(res["rccl"][1]) <= 100.0 and abs(float(res["rccl"][1]) - float(res["plain"][1])) < 15.0, res

@@ -1,9 +1,11 @@
 """The bf16 parity gate of SURVEY.md §8(d)(ii): after an identical K-step training run from identical weights, the mIoU of the HIP
 path on the 64 held-out synthetic tiles (seed 424242) is within +-0.002 of the CPU fp32 run.
 
-The CPU side is the oracle's run (oracle/gen_parity_run.py -> tests/golden/snunet_parity_run.npz: 40 Adam steps of ce+dice on
-batches of 4 tiles, eval-mode inference on the held-out tiles after 20 and after 40 steps; 130 s on 8 CPU threads, so it is a
-committed fixture rather than recomputed here).  The HIP side repeats the protocol through the fused train step in bf16 (the
+The CPU side is a run of the IMPORTED REFERENCE (oracle/gen_parity_run.py --reference -> tests/golden/snunet_parity_run_ref.npz:
+/root/reference/models/snunet.py + utilities/bce_and_dice.py + torch.optim.Adam driven as change_detection_trainer.py:135-180 does,
+40 Adam steps of ce+dice on batches of 4 tiles, eval-mode inference on the held-out tiles after 20 and after 40 steps; minutes on 8
+CPU threads, so it is a committed fixture rather than recomputed here).  The oracle's own run of the protocol
+(snunet_parity_run.npz) is held to it in tests/test_oracle_snunet.py (mIoU within 1e-5 at both checkpoints).  The HIP side repeats the protocol through the fused train step in bf16 (the
 benchmarked dtype) and in fp32.
 
 What is asserted, and why two checkpoints.  K = 40 is on the plateau of the learning curve (mIoU 0.986): there the gate is the
@@ -22,13 +24,13 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
-def test_kstep_run_miou_matches_cpu_fp32_oracle(golden_dir, precision):
+def test_kstep_run_miou_matches_cpu_fp32_reference_run(golden_dir, precision):
     from kurosiwo_amd.snunet import SNUNet_ECAM
     from kurosiwo_amd.trainer import CDTrainStep
     from oracle import metrics_ref, snunet_ref as R
     from oracle.gen_parity_run import BATCH, CHECKPOINTS, HELD_OUT, K_STEPS, TRAIN_TILES, protocol_tiles
     from oracle.seeded import seeded_fill_
-    gold = np.load(os.path.join(golden_dir, "snunet_parity_run.npz"))
+    gold = np.load(os.path.join(golden_dir, "snunet_parity_run_ref.npz"))
     assert list(gold["protocol"][:4]) == [K_STEPS, TRAIN_TILES, BATCH, HELD_OUT] and CHECKPOINTS == (20, 40)
     dev = torch.device("cuda:0")
     (xA, xB, mask), (eA, eB, emask) = protocol_tiles()

@@ -85,3 +85,18 @@ def test_full_size_eval_logits_and_argmax(golden_dir):
     decisive = margin > 1e-3 * scale
     assert (am[decisive] == gold["eval_argmax"][decisive]).all()
     assert decisive.mean() > 0.99
+
+
+def test_oracle_kstep_run_equals_the_reference_kstep_run(golden_dir):
+    """the 40-step training protocol of the parity gate (oracle/gen_parity_run.py) run on the CPU oracle and on the imported reference
+    modules + torch.optim.Adam: the same trajectory (losses to 1e-4 relative, held-out mIoU to 1e-5, a handful of pixels in other
+    confusion-matrix cells)"""
+    import os
+    import numpy as np
+    a = np.load(os.path.join(golden_dir, "snunet_parity_run.npz"))
+    b = np.load(os.path.join(golden_dir, "snunet_parity_run_ref.npz"))
+    assert list(a["protocol"]) == list(b["protocol"])
+    assert np.abs(a["losses"] - b["losses"]).max() < 1e-4 * a["losses"].max()
+    for k in ("20", "40"):
+        assert abs(float(a["miou" + k]) - float(b["miou" + k])) < 1e-5
+        assert int(np.abs(a["cm" + k] - b["cm" + k]).sum()) // 2 <= 64
