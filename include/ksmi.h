@@ -115,6 +115,11 @@ typedef struct ksmi_conv_desc {
    * block backward disappears into the launch that writes d out.  Only the persistent long-K kernel implements it
    * (ksmi_conv_gate_supported); mutually exclusive with mask_src. */
   const void* gate_src; const void* xhat_src; const float* g_mean; const float* g_rstd;
+  /* profiling tag: 1 = this launch is an INPUT GRADIENT.  No effect on the result: the persistent kernels select an identically
+   * compiled instantiation whose name carries the direction, so that a rocprofv3 trace / PMC pass separates forward and
+   * input-gradient launches of the same tile shape (profiles/summarize.py, bench.py roofline.traffic). */
+  int32_t dir;
+  int32_t pad2_;
 } ksmi_conv_desc;
 
 /* sizeof of a descriptor struct as the library was compiled (0 conv, 1 wgrad, 2 pack, 3 rowsum): bindings check their mirror */

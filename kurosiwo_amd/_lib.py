@@ -43,7 +43,8 @@ class ConvDesc(C.Structure):
                 ("uniform_kc", C.c_int32), ("in_sy", C.c_int32), ("in_sx", C.c_int32), ("in_oy", C.c_int32), ("in_ox", C.c_int32),
                 ("in_H", C.c_int32), ("in_W", C.c_int32), ("alpha", C.c_float), ("relu_out", C.c_int32), ("residC", C.c_int32),
                 ("resid", C.c_void_p), ("stats_rows", C.c_int32),
-                ("gate_src", C.c_void_p), ("xhat_src", C.c_void_p), ("g_mean", C.c_void_p), ("g_rstd", C.c_void_p)]
+                ("gate_src", C.c_void_p), ("xhat_src", C.c_void_p), ("g_mean", C.c_void_p), ("g_rstd", C.c_void_p),
+                ("dir", C.c_int32), ("pad2_", C.c_int32)]
 
 
 class PackDesc(C.Structure):

@@ -35,7 +35,8 @@ struct Ig3Args {
   const unsigned char* zero;       // >= 16 zero bytes (positions outside the image read them)
 };
 
-template <int KH, int KW, int NCH, int WN, bool AFF, int NTI, bool MASK>
+// DIR: 1 = input-gradient launch (ksmi_conv_desc.dir): a name tag for profilers, no code difference
+template <int KH, int KW, int NCH, int WN, bool AFF, int NTI, bool MASK, int DIR = 0>
 __global__ __launch_bounds__(256 * WN, (WN == 1 && NCH * KH * KW * NTI <= 9) ? 2 : 1) void igemm3_kernel(const Ig3Args ka) {
   typedef bf16_t T;
   const ksmi_conv_desc& d = ka.d;
@@ -473,6 +474,18 @@ int ksmi_igemm3_launch(const ksmi_conv_desc* d, const ksmi_igemm3_geom_t* g, hip
     if (d->nchunks == 1) { if (g->WN == 2) KSMI_G3M(3, 3, 1, 2, false, 1, true); else KSMI_G3M(3, 3, 1, 1, false, 1, true); }
     if (d->nchunks == 2) KSMI_G3M(3, 3, 2, 1, false, 1, true);
   }
+#define KSMI_G3D(NCH_, WN_)                                                                          \
+  do {                                                                                               \
+    auto kfn = igemm3_kernel<3, 3, NCH_, WN_, false, 1, false, 1>;                                   \
+    if (g->lds > 65536) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g->lds); \
+    hipLaunchKernelGGL(kfn, grid, dim3(256 * WN_), g->lds, st, ka);                                  \
+    return ksmi_check_launch("igemm3");                                                              \
+  } while (0)
+  if (taps == 9 && d->dir == 1 && !aff && !d->mask_src) {
+    if (d->nchunks == 1) { if (g->WN == 2) KSMI_G3D(1, 2); else KSMI_G3D(1, 1); }
+    if (d->nchunks == 2) KSMI_G3D(2, 1);
+  }
+#undef KSMI_G3D
   if (taps == 9) {
     if (d->nchunks == 1) { if (aff) KSMI_G3W(3, 3, 1, true, 1); else KSMI_G3W(3, 3, 1, false, 1); }
     if (d->nchunks == 2) { if (aff) KSMI_G3(3, 3, 2, 1, true, 1); else KSMI_G3(3, 3, 2, 1, false, 1); }

@@ -64,7 +64,8 @@ __device__ __forceinline__ int swz_h(int hx) { return ((hx >> 2) & 1) << 1; }
 
 // EPI: 0 plain, 1 ReLU-mask + BatchNorm1-backward sums (mask_src), 2 gate: total gradient, ReLU gate of the block output and
 // BatchNorm2-backward sums (gate_src / xhat_src; ksmi.h)
-template <int WM, int NF, bool AFF, int EPI, bool DBG = false>
+// DIR: 1 = input-gradient launch of the plain variant (ksmi_conv_desc.dir): a name tag for profilers, no code difference
+template <int WM, int NF, bool AFF, int EPI, bool DBG = false, int DIR = 0>
 __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Ig4Args ka) {
   typedef bf16_t T;
   constexpr bool MASK = EPI == 1, GATE = EPI == 2;
@@ -653,8 +654,17 @@ int ksmi_igemm4_launch(const ksmi_conv_desc* d, const ksmi_igemm4_geom_t* g, hip
     hipLaunchKernelGGL(kfn, grid, dim3(512), g->lds, st, ka);                                        \
     return ksmi_check_launch("igemm4");                                                              \
   } while (0)
+#define KSMI_G4D(WM_, NF_)                                                                           \
+  do {                                                                                               \
+    auto kfn = igemm4_kernel<WM_, NF_, false, 0, false, 1>;                                          \
+    static bool attr_set = false;                                                                    \
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; } \
+    hipLaunchKernelGGL(kfn, grid, dim3(512), g->lds, st, ka);                                        \
+    return ksmi_check_launch("igemm4");                                                              \
+  } while (0)
 #define KSMI_G4V(WM_, NF_)                                                                           \
-  do { if (aff) KSMI_G4(WM_, NF_, true, 0); else if (mask) KSMI_G4(WM_, NF_, false, 1); else if (gate) KSMI_G4(WM_, NF_, false, 2); else KSMI_G4(WM_, NF_, false, 0); } while (0)
+  do { if (aff) KSMI_G4(WM_, NF_, true, 0); else if (mask) KSMI_G4(WM_, NF_, false, 1); else if (gate) KSMI_G4(WM_, NF_, false, 2);   \
+       else if (d->dir == 1) KSMI_G4D(WM_, NF_); else KSMI_G4(WM_, NF_, false, 0); } while (0)
   if (ka.dbg && !aff && !mask && !gate && g->NF == 4) {                       // profiling switches: separate instantiations of the plain kernels
     if (g->WM == 4) {
       auto kfn = igemm4_kernel<4, 4, false, 0, true>;
@@ -672,6 +682,7 @@ int ksmi_igemm4_launch(const ksmi_conv_desc* d, const ksmi_igemm4_geom_t* g, hip
   if (g->WM == 8 && g->NF == 4) KSMI_G4V(8, 4);
   if (g->WM == 8 && g->NF == 2) KSMI_G4V(8, 2);
 #undef KSMI_G4V
+#undef KSMI_G4D
 #undef KSMI_G4
   return ksmi_fail(KSMI_E_UNSUPPORTED, "igemm4: no instance");
 }

@@ -96,6 +96,7 @@ class PlanBase:
 
     def _conv(self, ll, d, tag, name=""):
         self.keep.append(d)
+        d.dir = 1 if "dgrad" in tag else 0            # (profiling tag: kernel names carry the direction, ksmi.h)
         taps, es = d.KH * d.KW, self._es()
         ktot = sum(d.src[i].c_len for i in range(d.nsrc))
         pin, pout = d.B * d.Hin * d.Win, d.B * d.Hout * d.Wout

@@ -102,8 +102,60 @@ def main_reference():
                         protocol=np.array([K_STEPS, TRAIN_TILES, BATCH, HELD_OUT, HELD_OUT_SEED, TRAIN_SEED]), **out)
 
 
+def main_changeformer():
+    """The same protocol for ChangeFormerV6 (2-band tiles) on the imported reference: the shipped optimiser of the method
+    (configs/method/changeformer/changeformer.json: SGD lr 6e-4, momentum 0.99, weight decay 1e-5; change_detection_trainer.py:45-66),
+    ce+dice on the sigmoid map (decoder_softmax), the stochastic layers at p = 0 on both sides (their draws come from different
+    generators: tests/golden/changeformer_bench.npz pins them on the counter-based stream instead).
+    -> tests/golden/changeformer_parity_run_ref.npz"""
+    sys.path.insert(0, "/root/reference")
+    sys.dont_write_bytecode = True
+    from oracle.gen_golden import _import_changeformer_reference
+    from utilities.bce_and_dice import BCEandDiceLoss          # (reference)
+    ChangeFormerV6 = _import_changeformer_reference()
+    torch.set_num_threads(8)
+    (xA, xB, mask), (eA, eB, emask) = protocol_tiles()
+    model = ChangeFormerV6(input_nc=2, output_nc=3, decoder_softmax=True, embed_dim=256)
+    seeded_fill_(model.state_dict())
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+        if hasattr(m, "drop_prob"):
+            m.drop_prob = 0.0
+    optimizer = torch.optim.SGD(model.parameters(), lr=6e-4, momentum=0.99, weight_decay=1e-5)
+    criterion = BCEandDiceLoss(weights=[1.0, 1.0, 1.0], ignore_index=3, use_softmax=True)
+    losses, out = [], {}
+
+    def evaluate(tag):
+        cm = np.zeros((4, 4), np.int64)
+        model.eval()
+        with torch.no_grad():
+            for s in range(0, HELD_OUT, 8):
+                prob = model(eA[s:s + 8], eB[s:s + 8])[-1]
+                cm += metrics_ref.confusion_matrix(metrics_ref.argmax_lowest_index(prob.numpy()), emask[s:s + 8].numpy())
+        model.train()
+        m = metrics_ref.metrics_from_cm(cm)
+        print(tag, "cm\n", cm, "\niou", m["iou"], "miou", m["miou"], flush=True)
+        out[f"cm{tag}"], out[f"iou{tag}"], out[f"miou{tag}"], out[f"f1{tag}"] = cm, m["iou"], np.array(m["miou"]), m["f1"]
+    model.train()
+    for k in range(K_STEPS):
+        s = (k % (TRAIN_TILES // BATCH)) * BATCH
+        optimizer.zero_grad()
+        loss = criterion(model(xA[s:s + BATCH], xB[s:s + BATCH])[-1], mask[s:s + BATCH])
+        loss.backward()
+        optimizer.step()
+        losses.append(float(loss.detach()))
+        print(f"step {k}: loss {losses[-1]:.6f}", flush=True)
+        if k + 1 in CHECKPOINTS:
+            evaluate(str(k + 1))
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "changeformer_parity_run_ref.npz"), losses=np.array(losses),
+                        protocol=np.array([K_STEPS, TRAIN_TILES, BATCH, HELD_OUT, HELD_OUT_SEED, TRAIN_SEED]), **out)
+
+
 if __name__ == "__main__":
-    if "--reference" in sys.argv[1:]:
+    if "--changeformer" in sys.argv[1:]:
+        main_changeformer()
+    elif "--reference" in sys.argv[1:]:
         main_reference()
     else:
         main()
