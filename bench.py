@@ -25,6 +25,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_MEASURED_GBS = 6290.0    # ... and the copy rate it measures on the part (6.29 TB/s, 79 %): roofline.frac_of_measured_hbm
 MFMA_BF16_PEAK_TF = 2500.0   # dense bf16
 
 
@@ -67,37 +68,48 @@ class KernelTimer:
         return out
 
 
-# bench kernel class -> the rocprofv3 kernel names that make up one "launch" of it (profiles/<tag>_traffic.json, written by
-# profiles/summarize.py from the --pmc FETCH_SIZE / WRITE_SIZE passes of this same command)
+# bench kernel class -> regular expressions over the rocprofv3 kernel names that make up one "launch" of it.  The table they are
+# looked up in (profiles/r03_<model>_traffic.json) is written by profiles/summarize.py from the --pmc FETCH_SIZE / WRITE_SIZE passes of
+# THIS command (tools/profile.sh) and is keyed by the full kernel name; the persistent kernels carry the direction of a launch in their
+# name (ksmi_conv_desc.dir: igemm4_kernel<WM, NF, AFF, EPI, DBG, DIR>, igemm3_kernel<.., MASK, DIR>; AFF = forward with the fused BN
+# operand, EPI 1 / 2 = the two input-gradient epilogues), so forward and input-gradient launches are separate rows.
+IG4 = r"igemm4_kernel<\d, \d, "
 TRAFFIC_KERNELS = {
-    "igemm_wgrad<3x3s1>": ("wgrad3_kernel", "wgrad3_reduce_kernel", "igemm_wgrad_kernel<bf16, 2, 3, 3", "wgrad_reduce_kernel"),
-    "igemm_fwd<3x3s1,BN32>": ("igemm2_fwd_kernel<bf16, 2, 3, 3", "igemm3_kernel<3, 3"),
-    "igemm_dgrad<3x3s1,BN32>": ("igemm2_fwd_kernel<bf16, 2, 3, 3", "igemm3_kernel<3, 3"),
-    # the other families (profiles/r02_<model>_traffic.json)
-    # ("igemm_conv3x3<3x3s1>" of ChangeFormer / BIT-CD is left unmapped: its forward launches share kernel names with the input
-    # gradients of very different sizes, so a per-kernel-name mean does not describe the class; per-kernel bytes are in the summary)
-    "igemm_conv3x3_dgrad<3x3s1>": ("igemm2_fwd_kernel<bf16, 2, 3, 3", "igemm3_kernel<3, 3"),
-    "igemm_wgrad<1x1s1>": ("gemm2_tn_kernel", "tn_reduce_kernel", "igemm_wgrad_kernel<bf16, 4, 1, 1", "igemm_wgrad_kernel<bf16, 2, 1, 1", "wgrad_reduce_kernel"),
+    "igemm_fwd<3x3s1,BN32>": (IG4 + r"true, 0, false, 0>", IG4 + r"false, 0, false, 0>", r"igemm3_kernel<3, 3, \d, \d, true, 1, false, 0>",
+                              r"igemm3_kernel<3, 3, \d, \d, false, 1, false, 0>"),
+    "igemm_dgrad<3x3s1,BN32>": (IG4 + r"false, [12], false, 0>", IG4 + r"false, 0, false, 1>", r"igemm3_kernel<3, 3, \d, \d, false, 1, false, 1>",
+                                r"igemm2_fwd_kernel<bf16, 2, 3, 3, false, false, 1, true, 1>"),      # (the lean tile kernel: K = 32 mask epilogue)
+    "igemm_wgrad<3x3s1>": (r"wgrad3_kernel<", r"wgrad3_reduce_kernel", r"igemm_wgrad_kernel<bf16, 2, 3, 3", r"wgrad_reduce_kernel"),
+    # ChangeFormer / BIT-CD: plain 3x3 convolutions of the decoder (forward: ReLU / residual epilogues included) and their input gradients
+    "igemm_conv3x3<3x3s1>": (IG4 + r"(true|false), 0, false, 0>", r"igemm2_fwd_kernel<bf16, 2, 3, 3, (true|false), true"),
+    "igemm_conv3x3_dgrad<3x3s1>": (IG4 + r"false, [12], false, 0>", IG4 + r"false, 0, false, 1>"),
+    "igemm_wgrad<1x1s1>": (r"gemm2_tn_kernel", r"tn_reduce_kernel", r"igemm_wgrad_kernel<bf16, [24], 1, 1", r"wgrad_reduce_kernel"),
+    "gemm_nt": (r"gemm2_kernel<\d+, false>", r"gemm_nt_kernel"),
+    "gemm_nn": (r"gemm2_kernel<\d+, true>", r"gemm_nn_kernel"),
 }
 TRAFFIC_FILE = {"snunet": "snunet", "changeformer": "changeformer", "floodvit": "floodvit", "unet": "unet", "mae": "mae"}
+TRAFFIC_ROUND = "r03"
 
 
 def measured_traffic(kind, model="snunet"):
-    """HBM bytes per launch of the dominant kernel class from the committed PMC table of the model family (None when there is none for
-    this class): call-weighted mean of 2 x FETCH_SIZE + WRITE_SIZE over the class's kernels (x2: the guide's gfx950 FETCH_SIZE
-    correction)."""
-    path = os.path.join(ROOT, "profiles", f"r02_{TRAFFIC_FILE.get(model, model)}_traffic.json")
+    """HBM bytes per launch of the dominant kernel class by the PMC counters (None when no table / no mapping): call-weighted mean of
+    2 x FETCH_SIZE + WRITE_SIZE over the kernels of the class (x2: the guide's gfx950 FETCH_SIZE correction), plus the rows it used."""
+    import re
+    path = os.path.join(ROOT, "profiles", f"{TRAFFIC_ROUND}_{TRAFFIC_FILE.get(model, model)}_traffic.json")
     if kind not in TRAFFIC_KERNELS or not os.path.exists(path):
-        return None
+        return None, []
     tab = json.load(open(path))["kernels"]
-    tot, calls = 0.0, 0
-    main_calls = 0
+    pats = [re.compile(p) for p in TRAFFIC_KERNELS[kind]]
+    tot, main_calls, rows = 0.0, 0, []
     for name, row in tab.items():
-        if any(name.startswith(p) for p in TRAFFIC_KERNELS[kind]) and row.get("fetch_kb_raw") is not None and row.get("write_kb_raw") is not None:
-            tot += row["calls"] * (2.0 * row["fetch_kb_raw"] + row["write_kb_raw"]) * 1024.0
+        if any(p.match(name) for p in pats) and row.get("fetch_kb_raw") is not None and row.get("write_kb_raw") is not None:
+            b = (2.0 * row["fetch_kb_raw"] + row["write_kb_raw"]) * 1024.0
+            tot += row["calls"] * b
+            rows.append({"kernel": name, "calls": row["calls"], "bytes_per_launch": round(b), "avg_us": round(row["avg_us"], 1),
+                         "mfma_busy_pct": None if row.get("mfma_busy_pct") is None else round(row["mfma_busy_pct"], 1)})
             if "reduce" not in name:
                 main_calls += row["calls"]
-    return round(tot / main_calls) if main_calls else None
+    return (round(tot / main_calls) if main_calls else None), rows
 
 
 def cpu_baseline(budget_s=20.0):
@@ -316,6 +328,7 @@ def main():
         avg_ms = d["ms"] / d["n"]
         ach_gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9
         ach_tf = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        traffic, traffic_rows = measured_traffic(dominant, args.model)
         step_flops = sum(c[3]["flops"] for c in step.plan.fwd.calls + step.plan.bwd.calls)
         step_bytes = sum(c[3]["bytes"] for c in step.plan.fwd.calls + step.plan.bwd.calls)
         res = {
@@ -336,7 +349,10 @@ def main():
                           "unit": "GB/s", "frac": round(ach_gbs / HBM_PEAK_GBS, 4)}) | {
                          # HBM bytes per launch by the PMC counters (2 x FETCH_SIZE + WRITE_SIZE, profiles/r02_snunet_traffic.json; the forward
                          # and input-gradient classes share their kernels, so the table row is their common mean) next to the algorithmic bytes
-                         "traffic": measured_traffic(dominant, args.model), "traffic_unit": "bytes/launch",
+                         "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_rows": traffic_rows,
+                         "traffic_source": f"profiles/{TRAFFIC_ROUND}_{TRAFFIC_FILE.get(args.model, args.model)}_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                           "passes of this command, tools/profile.sh; rows keyed by kernel name incl. direction)",
+                         "frac_of_measured_hbm": round(ach_gbs / HBM_MEASURED_GBS, 4), "measured_hbm_peak_GBs": HBM_MEASURED_GBS,
                          "algorithmic_bytes_per_launch": round(d["bytes"] / max(d["n"], 1)),
                          "launches_timed": d["n"], "avg_launch_ms": round(avg_ms, 4),
                          "share_of_step": round((d["ms"] / timer_steps) / (dt * 1e3 / args.steps), 3),
@@ -344,6 +360,7 @@ def main():
                          "tflops": round(ach_tf, 1), "mfma_frac": round(ach_tf / MFMA_BF16_PEAK_TF, 4),
                          "step_algorithmic_GB": round(step_bytes / 1e9, 3), "step_GFLOP": round(step_flops / 1e9, 1),
                          "step_hbm_frac": round(step_bytes / dt * args.steps / 1e9 / HBM_PEAK_GBS, 4),
+                         "step_frac_of_measured_hbm": round(step_bytes / dt * args.steps / 1e9 / HBM_MEASURED_GBS, 4),
                          "step_mfma_frac": round(step_flops / dt * args.steps / 1e12 / MFMA_BF16_PEAK_TF, 4)},
         }
         if two_streams:
@@ -354,6 +371,8 @@ def main():
             s_ach = (solo["bytes"] / 1e9 if hbm else solo["flops"] / 1e12) / (solo["ms"] * 1e-3)
             res["roofline"]["achieved_solo"] = round(s_ach, 1)
             res["roofline"]["frac_solo"] = round(s_ach / (HBM_PEAK_GBS if hbm else MFMA_BF16_PEAK_TF), 4)
+            if hbm:
+                res["roofline"]["frac_solo_of_measured_hbm"] = round(s_ach / HBM_MEASURED_GBS, 4)
             res["roofline"]["solo"] = {"avg_launch_ms": round(solo["ms"] / solo["n"], 4), "achieved": round(s_ach, 1),
                                        "frac": round(s_ach / (HBM_PEAK_GBS if hbm else MFMA_BF16_PEAK_TF), 4), "launches_timed": solo["n"],
                                        "how": "same kernel class, single stream, steps run after the timed region"}

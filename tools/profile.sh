@@ -4,7 +4,7 @@
 # (--pmc never together with a trace domain other than --kernel-trace; FETCH_SIZE and WRITE_SIZE do not fit one TCC pass).
 # usage: bash tools/profile.sh <tag> [bench args...]
 set -u
-TAG=${1:-r02}; shift || true
+TAG=${1:-r03}; shift || true
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 5 --warmup 2 --no-cpu-baseline --no-solo $*"
@@ -13,6 +13,14 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $R/gpurun_out/prof_${TAG}_fetch -o 
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $R/gpurun_out/prof_${TAG}_write -o write -- python $R/bench.py $ARGS > $R/gpurun_out/prof_${TAG}_write.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $R/gpurun_out/prof_${TAG}_mfma -o mfma -- python $R/bench.py $ARGS > $R/gpurun_out/prof_${TAG}_mfma.log 2>&1
 # the same kernels alone on the machine: one stream (roofline.solo / frac_solo of the bench line)
-KSMI_OVERLAP_WGRAD=0 KSMI_OVERLAP_LANES=0 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${TAG}_solo_stats -o stats -- python $R/bench.py $ARGS > $R/gpurun_out/prof_${TAG}_solo.log 2>&1
+# (PROFILE_SOLO=0 skips them: single-stream models)
+if [ "${PROFILE_SOLO:-1}" = "1" ]; then
+export KSMI_OVERLAP_WGRAD=0 KSMI_OVERLAP_LANES=0
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${TAG}_solo_stats -o stats -- python $R/bench.py $ARGS > $R/gpurun_out/prof_${TAG}_solo.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $R/gpurun_out/prof_${TAG}_solo_fetch -o fetch -- python $R/bench.py $ARGS > $R/gpurun_out/prof_${TAG}_solo_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $R/gpurun_out/prof_${TAG}_solo_write -o write -- python $R/bench.py $ARGS > $R/gpurun_out/prof_${TAG}_solo_write.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $R/gpurun_out/prof_${TAG}_solo_mfma -o mfma -- python $R/bench.py $ARGS > $R/gpurun_out/prof_${TAG}_solo_mfma.log 2>&1
+unset KSMI_OVERLAP_WGRAD KSMI_OVERLAP_LANES
+fi
 cd $R
 du -sh gpurun_out/prof_${TAG}_* | head
