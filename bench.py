@@ -71,18 +71,18 @@ class KernelTimer:
 # bench kernel class -> regular expressions over the rocprofv3 kernel names that make up one "launch" of it.  The table they are
 # looked up in (profiles/r03_<model>_traffic.json) is written by profiles/summarize.py from the --pmc FETCH_SIZE / WRITE_SIZE passes of
 # THIS command (tools/profile.sh) and is keyed by the full kernel name; the persistent kernels carry the direction of a launch in their
-# name (ksmi_conv_desc.dir: igemm4_kernel<WM, NF, AFF, EPI, DBG, DIR>, igemm3_kernel<.., MASK, DIR>; AFF = forward with the fused BN
+# name (ksmi_conv_desc.dir: igemm4_kernel<WM, NF, AFF, EPI, DBG, DIR, ROT>, igemm3_kernel<.., MASK, DIR>; AFF = forward with the fused BN
 # operand, EPI 1 / 2 = the two input-gradient epilogues), so forward and input-gradient launches are separate rows.
 IG4 = r"igemm4_kernel<\d, \d, "
 TRAFFIC_KERNELS = {
-    "igemm_fwd<3x3s1,BN32>": (IG4 + r"true, 0, false, 0>", IG4 + r"false, 0, false, 0>", r"igemm3_kernel<3, 3, \d, \d, true, 1, false, 0>",
+    "igemm_fwd<3x3s1,BN32>": (IG4 + r"true, 0, false, 0, (true|false)>", IG4 + r"false, 0, false, 0, (true|false)>", r"igemm3_kernel<3, 3, \d, \d, true, 1, false, 0>",
                               r"igemm3_kernel<3, 3, \d, \d, false, 1, false, 0>"),
-    "igemm_dgrad<3x3s1,BN32>": (IG4 + r"false, [12], false, 0>", IG4 + r"false, 0, false, 1>", r"igemm3_kernel<3, 3, \d, \d, false, 1, false, 1>",
+    "igemm_dgrad<3x3s1,BN32>": (IG4 + r"false, [12], false, 0, (true|false)>", IG4 + r"false, 0, false, 1, (true|false)>", r"igemm3_kernel<3, 3, \d, \d, false, 1, false, 1>",
                                 r"igemm2_fwd_kernel<bf16, 2, 3, 3, false, false, 1, true, 1>"),      # (the lean tile kernel: K = 32 mask epilogue)
     "igemm_wgrad<3x3s1>": (r"wgrad3_kernel<", r"wgrad3_reduce_kernel", r"igemm_wgrad_kernel<bf16, 2, 3, 3", r"wgrad_reduce_kernel"),
     # ChangeFormer / BIT-CD: plain 3x3 convolutions of the decoder (forward: ReLU / residual epilogues included) and their input gradients
-    "igemm_conv3x3<3x3s1>": (IG4 + r"(true|false), 0, false, 0>", r"igemm2_fwd_kernel<bf16, 2, 3, 3, (true|false), true"),
-    "igemm_conv3x3_dgrad<3x3s1>": (IG4 + r"false, [12], false, 0>", IG4 + r"false, 0, false, 1>"),
+    "igemm_conv3x3<3x3s1>": (IG4 + r"(true|false), 0, false, 0, (true|false)>", r"igemm2_fwd_kernel<bf16, 2, 3, 3, (true|false), true"),
+    "igemm_conv3x3_dgrad<3x3s1>": (IG4 + r"false, [12], false, 0, (true|false)>", IG4 + r"false, 0, false, 1, (true|false)>"),
     "igemm_wgrad<1x1s1>": (r"gemm2_tn_kernel", r"tn_reduce_kernel", r"igemm_wgrad_kernel<bf16, [24], 1, 1", r"wgrad_reduce_kernel"),
     "gemm_nt": (r"gemm2_kernel<\d+, false>", r"gemm_nt_kernel"),
     "gemm_nn": (r"gemm2_kernel<\d+, true>", r"gemm_nn_kernel"),

@@ -46,6 +46,7 @@ struct Ig4Args {
   int th, tw;                      // output patch of a workgroup (th * tw <= 64 * WM pixels)
   int hslot, nh, nhs;              // halo ring: bytes per slot (8 KiB granules = one DMA piece per wave), pieces per wave, slots (2 | 3)
   int tiles, gx, gy;
+  int rot;                         // rotated schedule: the step barrier sits in front of the previous step's last tap (see run_tiles_rot)
   int stagger;                     // waves 4-7 issue their DMA pieces after the first tap of a step instead of at its top
   int dbg;                         // KSMI_IG4_DBG profiling switches (wrong results): 1 no MFMA / fragment reads, 2 no DMA in the loop, 4 no
                                    // epilogue stores, 8 broadcast fragment reads (no LDS bandwidth), 16 no step barrier
@@ -65,7 +66,9 @@ __device__ __forceinline__ int swz_h(int hx) { return ((hx >> 2) & 1) << 1; }
 // EPI: 0 plain, 1 ReLU-mask + BatchNorm1-backward sums (mask_src), 2 gate: total gradient, ReLU gate of the block output and
 // BatchNorm2-backward sums (gate_src / xhat_src; ksmi.h)
 // DIR: 1 = input-gradient launch of the plain variant (ksmi_conv_desc.dir): a name tag for profilers, no code difference
-template <int WM, int NF, bool AFF, int EPI, bool DBG = false, int DIR = 0>
+// ROT: the rotated K-loop schedule (run_tiles_rot) instead of the per-role one (one schedule per instantiation: both in one kernel
+// spill hundreds of registers)
+template <int WM, int NF, bool AFF, int EPI, bool DBG = false, int DIR = 0, bool ROT = false>
 __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Ig4Args ka) {
   typedef bf16_t T;
   constexpr bool MASK = EPI == 1, GATE = EPI == 2;
@@ -270,100 +273,8 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Ig4Args ka) {
   const bool late = ka.stagger && wave >= 4;                            // (wave-uniform)
   constexpr int LA = NHS - 1;                                           // halo chunks in flight beyond the current one
 
-  // The persistent tile loop, instantiated per DMA role (LATE = the wave refills the rings after the first tap of a step instead of
-  // at its top: the two waves of a SIMD then do not queue their DMA issue and their MFMAs at the same moments); one uniform branch
-  // per workgroup life instead of one per step.
-  auto run_tiles = [&](auto late_tag) {
-    constexpr bool LATE = decltype(late_tag)::value;
-    int t = pxw;
-    int go_c[NHM], go_n[NHM];
-    tile_goff(t, go_c);
-    tile_goff(t + ka.gx, go_n);
-    __syncthreads();                                                  // tables visible; nothing in flight yet
-    // ---- prologue: the first LA halo chunks and weight steps 0, 1 of the first tile --------------------------------------------
-    issue_H(go_c, src_tab[0], 0);
-    if constexpr (LA > 1) issue_H(go_c, src_tab[1], 1);
-    issue_W(0, 0, 0);
-    issue_W(0, 1, 1);
-    if constexpr (AFF) {
-      vm_wait_c<(LA > 1 ? nh : 0) + 2 * nW>();                        // chunk 0 landed (this wave's pieces) ...
-      lds_barrier();                                                  // ... and everybody's
-      transform(go_c, 0, 0);
-    }
-    int hs = 0;                                                       // halo slot of the current chunk
-    STAMP();
-    if (DBG && (dbg & 64)) { vm_wait_c<0>(); return; }                // (profiling: setup + ring prologue only)
-    for (;;) {
-      f32x4 acc[4][NF];
-#pragma unroll
-      for (int mf = 0; mf < 4; ++mf)
-#pragma unroll
-        for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      for (int c = 0; c < nch; ++c) {
-        const int c1 = c + 1 == nch ? 0 : c + 1;                      // chunk of the next two weight steps after this chunk's rows
-        const unsigned char* lds_h = smem + hs * HSLOT;
-        const int hprev = hs == 0 ? NHS - 1 : hs - 1;                 // slot of chunk - 1 = slot of chunk + LA
-        const int hnext = hs + 1 == NHS ? 0 : hs + 1;
-        // source scalars and pixel offsets of the halo chunk issued in step r = 0 (LA chunks ahead: the next tile's near the end)
-        int c2 = c + LA;
-        const bool nextt = c2 >= nch;
-        if (nextt) c2 -= nch;
-        const u32x4 ent = src_tab[c2];
-        int go_i[NHM];
-#pragma unroll
-        for (int k = 0; k < NHM; ++k) go_i[k] = nextt ? go_n[k] : go_c[k];
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-          // the weights of this step (and every older DMA) landed; AFF with one halo chunk of lookahead transforms the NEXT chunk
-          // in step r = 2: that chunk was issued after this step's weights, so only the youngest nW pieces may be outstanding
-          if constexpr (AFF && LA == 1) { if (r == 2) vm_wait_c<nW>(); else if (r == 1) vm_wait_c<nW + nh>(); else vm_wait_c<nW>(); }
-          else { if (r == 0) vm_wait_c<nW>(); else vm_wait_c<nW + nh>(); }
-          if (!(DBG && (dbg & 16))) lds_barrier();                    // ... for every wave; the slots refilled below are free
-          auto refill = [&]() {
-            if (DBG && (dbg & 2)) return;
-            if (r == 0) {
-              issue_W(c, 2, 2);
-              issue_H(go_i, ent, hprev);
-            } else if (r == 1) {
-              issue_W(c1, 0, 0);
-            } else {
-              issue_W(c1, 1, 1);
-            }
-          };
-          if constexpr (!LATE) refill();
-          if constexpr (AFF) {
-            if (r == 2) {                                             // next chunk: landed (see the wait above), published by the next barrier
-              if (c + 1 == nch) transform(go_n, 0, hnext); else transform(go_c, c + 1, hnext);
-            }
-          }
-          const unsigned char* lds_w = wring + r * WSLOT;
-          if (!(DBG && (dbg & 1))) {
-            // fragments of tap j+1 are requested before the MFMAs of tap j
-            u32x4 fa[2][4], fb[2][NF];
-#pragma unroll
-            for (int mf = 0; mf < 4; ++mf) fa[0][mf] = *(const u32x4*)(lds_h + r * pitch + a_addr[mf][0]);
-#pragma unroll
-            for (int nf = 0; nf < NF; ++nf) fb[0][nf] = *(const u32x4*)(lds_w + b_addr[nf]);
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-              const int cur = j & 1, nxt = cur ^ 1;
-              if (j + 1 < 3) {
-#pragma unroll
-                for (int mf = 0; mf < 4; ++mf) fa[nxt][mf] = *(const u32x4*)(lds_h + r * pitch + a_addr[mf][j + 1]);
-#pragma unroll
-                for (int nf = 0; nf < NF; ++nf) fb[nxt][nf] = *(const u32x4*)(lds_w + (j + 1) * BN * 64 + b_addr[nf]);
-              }
-#pragma unroll
-              for (int mf = 0; mf < 4; ++mf)
-#pragma unroll
-                for (int nf = 0; nf < NF; ++nf) mma16<T>(acc[mf][nf], fb[cur][nf], fa[cur][mf]);   // D = W * X^T
-              if constexpr (LATE) { if (j == 0) refill(); }
-            }
-          } else if constexpr (LATE) refill();
-        }
-        hs = hnext;
-      }
-      STAMP();
+  // ---- epilogue of one tile (both schedules) --------------------------------------------------------------------------------
+  auto tile_epilogue = [&](int t, f32x4 (&acc)[4][NF]) {
       // ---- epilogue of the tile: lane (g, l15) owns channels nc .. nc+7 of pixel l15 of each 16-pixel row group ---------------
       {
         int b, oy0, ox0;
@@ -497,6 +408,103 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Ig4Args ka) {
           }
         }
       }
+  };
+
+  // The persistent tile loop, instantiated per DMA role (LATE = the wave refills the rings after the first tap of a step instead of
+  // at its top: the two waves of a SIMD then do not queue their DMA issue and their MFMAs at the same moments); one uniform branch
+  // per workgroup life instead of one per step.
+  auto run_tiles = [&](auto late_tag) {
+    constexpr bool LATE = decltype(late_tag)::value;
+    int t = pxw;
+    int go_c[NHM], go_n[NHM];
+    tile_goff(t, go_c);
+    tile_goff(t + ka.gx, go_n);
+    __syncthreads();                                                  // tables visible; nothing in flight yet
+    // ---- prologue: the first LA halo chunks and weight steps 0, 1 of the first tile --------------------------------------------
+    issue_H(go_c, src_tab[0], 0);
+    if constexpr (LA > 1) issue_H(go_c, src_tab[1], 1);
+    issue_W(0, 0, 0);
+    issue_W(0, 1, 1);
+    if constexpr (AFF) {
+      vm_wait_c<(LA > 1 ? nh : 0) + 2 * nW>();                        // chunk 0 landed (this wave's pieces) ...
+      lds_barrier();                                                  // ... and everybody's
+      transform(go_c, 0, 0);
+    }
+    int hs = 0;                                                       // halo slot of the current chunk
+    STAMP();
+    if (DBG && (dbg & 64)) { vm_wait_c<0>(); return; }                // (profiling: setup + ring prologue only)
+    for (;;) {
+      f32x4 acc[4][NF];
+#pragma unroll
+      for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int c = 0; c < nch; ++c) {
+        const int c1 = c + 1 == nch ? 0 : c + 1;                      // chunk of the next two weight steps after this chunk's rows
+        const unsigned char* lds_h = smem + hs * HSLOT;
+        const int hprev = hs == 0 ? NHS - 1 : hs - 1;                 // slot of chunk - 1 = slot of chunk + LA
+        const int hnext = hs + 1 == NHS ? 0 : hs + 1;
+        // source scalars and pixel offsets of the halo chunk issued in step r = 0 (LA chunks ahead: the next tile's near the end)
+        int c2 = c + LA;
+        const bool nextt = c2 >= nch;
+        if (nextt) c2 -= nch;
+        const u32x4 ent = src_tab[c2];
+        int go_i[NHM];
+#pragma unroll
+        for (int k = 0; k < NHM; ++k) go_i[k] = nextt ? go_n[k] : go_c[k];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          // the weights of this step (and every older DMA) landed; AFF with one halo chunk of lookahead transforms the NEXT chunk
+          // in step r = 2: that chunk was issued after this step's weights, so only the youngest nW pieces may be outstanding
+          if constexpr (AFF && LA == 1) { if (r == 2) vm_wait_c<nW>(); else if (r == 1) vm_wait_c<nW + nh>(); else vm_wait_c<nW>(); }
+          else { if (r == 0) vm_wait_c<nW>(); else vm_wait_c<nW + nh>(); }
+          if (!(DBG && (dbg & 16))) lds_barrier();                    // ... for every wave; the slots refilled below are free
+          auto refill = [&]() {
+            if (DBG && (dbg & 2)) return;
+            if (r == 0) {
+              issue_W(c, 2, 2);
+              issue_H(go_i, ent, hprev);
+            } else if (r == 1) {
+              issue_W(c1, 0, 0);
+            } else {
+              issue_W(c1, 1, 1);
+            }
+          };
+          if constexpr (!LATE) refill();
+          if constexpr (AFF) {
+            if (r == 2) {                                             // next chunk: landed (see the wait above), published by the next barrier
+              if (c + 1 == nch) transform(go_n, 0, hnext); else transform(go_c, c + 1, hnext);
+            }
+          }
+          const unsigned char* lds_w = wring + r * WSLOT;
+          if (!(DBG && (dbg & 1))) {
+            // fragments of tap j+1 are requested before the MFMAs of tap j
+            u32x4 fa[2][4], fb[2][NF];
+#pragma unroll
+            for (int mf = 0; mf < 4; ++mf) fa[0][mf] = *(const u32x4*)(lds_h + r * pitch + a_addr[mf][0]);
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) fb[0][nf] = *(const u32x4*)(lds_w + b_addr[nf]);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+              const int cur = j & 1, nxt = cur ^ 1;
+              if (j + 1 < 3) {
+#pragma unroll
+                for (int mf = 0; mf < 4; ++mf) fa[nxt][mf] = *(const u32x4*)(lds_h + r * pitch + a_addr[mf][j + 1]);
+#pragma unroll
+                for (int nf = 0; nf < NF; ++nf) fb[nxt][nf] = *(const u32x4*)(lds_w + (j + 1) * BN * 64 + b_addr[nf]);
+              }
+#pragma unroll
+              for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+                for (int nf = 0; nf < NF; ++nf) mma16<T>(acc[mf][nf], fb[cur][nf], fa[cur][mf]);   // D = W * X^T
+              if constexpr (LATE) { if (j == 0) refill(); }
+            }
+          } else if constexpr (LATE) refill();
+        }
+        hs = hnext;
+      }
+      STAMP();
+      tile_epilogue(t, acc);
       STAMP();
       if (t + ka.gx >= ka.tiles) break;
       t += ka.gx;
@@ -506,10 +514,132 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Ig4Args ka) {
     }
     vm_wait_c<0>();                                                   // the ring's tail (zero-page reads) has landed: LDS is ours again
   };
+  // ROTATED schedule (ka.rot): the step barrier sits between the MFMAs of tap 1 and tap 2 of the PREVIOUS step.  The fragments of that
+  // tap 2 are read before the barrier (their slots may then be refilled), so a wave leaves the barrier with 4 * NF MFMAs to issue at
+  // once; they cover the LDS latency of the new step's first fragments and the DMA issue of the refill, which sit right behind them.
+  // Same data flow, slots and wait counts as above; the two fragment register sets swap roles every step (3 steps per chunk: the
+  // chunk body exists for both parities).
+  auto run_tiles_rot = [&](auto) {
+    int t = pxw;
+    int go_c[NHM], go_n[NHM];
+    tile_goff(t, go_c);
+    tile_goff(t + ka.gx, go_n);
+    __syncthreads();
+    issue_H(go_c, src_tab[0], 0);
+    if constexpr (LA > 1) issue_H(go_c, src_tab[1], 1);
+    issue_W(0, 0, 0);
+    issue_W(0, 1, 1);
+    if constexpr (AFF) {
+      vm_wait_c<(LA > 1 ? nh : 0) + 2 * nW>();
+      lds_barrier();
+      transform(go_c, 0, 0);
+    }
+    int hs = 0;
+    for (;;) {
+      f32x4 acc[4][NF];
+#pragma unroll
+      for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      // the two fragment register sets live inside a tile only (nothing is held across the epilogue)
+      u32x4 fa[2][4], fb[2][NF];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+#pragma unroll
+        for (int mf = 0; mf < 4; ++mf) fa[u][mf] = (u32x4){0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) fb[u][nf] = (u32x4){0u, 0u, 0u, 0u};
+      }
+      bool have = false;                                              // a held tap 2 of the previous step (not at the first step of a tile)
+      auto mma_set = [&](auto set_tag) {
+        constexpr int S = decltype(set_tag)::value;
+#pragma unroll
+        for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+          for (int nf = 0; nf < NF; ++nf) mma16<T>(acc[mf][nf], fb[S][nf], fa[S][mf]);
+      };
+      auto chunk = [&](auto par_tag, int c) {
+        constexpr int PAR = decltype(par_tag)::value;
+        const int c1 = c + 1 == nch ? 0 : c + 1;
+        const unsigned char* lds_h = smem + hs * HSLOT;
+        const int hprev = hs == 0 ? NHS - 1 : hs - 1;
+        const int hnext = hs + 1 == NHS ? 0 : hs + 1;
+        int c2 = c + LA;
+        const bool nextt = c2 >= nch;
+        if (nextt) c2 -= nch;
+        const u32x4 ent = src_tab[c2];
+        int go_i[NHM];
+#pragma unroll
+        for (int k = 0; k < NHM; ++k) go_i[k] = nextt ? go_n[k] : go_c[k];
+        auto step = [&](auto r_tag) {
+          constexpr int r = decltype(r_tag)::value;
+          constexpr int Hs = (PAR + r) & 1, Os = Hs ^ 1;               // held set (tap 2 of the previous step) / the other one
+          if constexpr (AFF && LA == 1) { if (r == 2) vm_wait_c<nW>(); else if (r == 1) vm_wait_c<nW + nh>(); else vm_wait_c<nW>(); }
+          else { if (r == 0) vm_wait_c<nW>(); else vm_wait_c<nW + nh>(); }
+          if (!(DBG && (dbg & 16))) lds_barrier();
+          const unsigned char* lds_w = wring + r * WSLOT;
+#pragma unroll
+          for (int mf = 0; mf < 4; ++mf) fa[Os][mf] = *(const u32x4*)(lds_h + r * pitch + a_addr[mf][0]);
+#pragma unroll
+          for (int nf = 0; nf < NF; ++nf) fb[Os][nf] = *(const u32x4*)(lds_w + b_addr[nf]);
+          if (have) mma_set(std::integral_constant<int, Hs>{});
+          __builtin_amdgcn_sched_barrier(0);                            // (the reads of tap 1 below reuse set Hs: keep them behind these MFMAs instead of a third register set)
+          if (!(DBG && (dbg & 2))) {
+            if (r == 0) { issue_W(c, 2, 2); issue_H(go_i, ent, hprev); }
+            else if (r == 1) issue_W(c1, 0, 0);
+            else issue_W(c1, 1, 1);
+          }
+          if constexpr (AFF) {
+            if (r == 2) { if (c + 1 == nch) transform(go_n, 0, hnext); else transform(go_c, c + 1, hnext); }
+          }
+#pragma unroll
+          for (int mf = 0; mf < 4; ++mf) fa[Hs][mf] = *(const u32x4*)(lds_h + r * pitch + a_addr[mf][1]);
+#pragma unroll
+          for (int nf = 0; nf < NF; ++nf) fb[Hs][nf] = *(const u32x4*)(lds_w + 1 * BN * 64 + b_addr[nf]);
+          mma_set(std::integral_constant<int, Os>{});      // tap 0
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int mf = 0; mf < 4; ++mf) fa[Os][mf] = *(const u32x4*)(lds_h + r * pitch + a_addr[mf][2]);
+#pragma unroll
+          for (int nf = 0; nf < NF; ++nf) fb[Os][nf] = *(const u32x4*)(lds_w + 2 * BN * 64 + b_addr[nf]);
+          mma_set(std::integral_constant<int, Hs>{});      // tap 1; set Os now holds tap 2
+          __builtin_amdgcn_sched_barrier(0);
+          have = true;
+        };
+        step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
+        hs = hnext;
+      };
+      // three steps per chunk: the held set changes sides every chunk -> chunk pairs as straight-line code (no parity to merge)
+      int c = 0;
+      for (; c + 1 < nch; c += 2) {
+        chunk(std::integral_constant<int, 0>{}, c);
+        chunk(std::integral_constant<int, 1>{}, c + 1);
+      }
+      // the tap 2 of the tile's last step: held in set 0 after an even number of chunks, in set 1 after the odd tail chunk
+      if (c < nch) {
+        chunk(std::integral_constant<int, 0>{}, c);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        mma_set(std::integral_constant<int, 1>{});
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        mma_set(std::integral_constant<int, 0>{});
+      }
+      STAMP();
+      tile_epilogue(t, acc);
+      STAMP();
+      if (t + ka.gx >= ka.tiles) break;
+      t += ka.gx;
+#pragma unroll
+      for (int k = 0; k < NHM; ++k) go_c[k] = go_n[k];
+      tile_goff(t + ka.gx, go_n);
+    }
+    vm_wait_c<0>();
+  };
   STAMP();
   if (DBG && (dbg & 32)) return;                                        // (profiling: table setup only)
   if (pxw < ka.tiles) {
-    if (late) run_tiles(std::true_type{}); else run_tiles(std::false_type{});
+    if constexpr (ROT) run_tiles_rot(0);
+    else { if (late) run_tiles(std::true_type{}); else run_tiles(std::false_type{}); }
   }
   if (DBG && (dbg & 128)) {
     STAMP();
@@ -639,6 +769,8 @@ int ksmi_igemm4_launch(const ksmi_conv_desc* d, const ksmi_igemm4_geom_t* g, hip
   ka.dbg = dbg_env ? atoi(dbg_env) : 0;
   static const int stag = getenv("KSMI_IG4_STAGGER") ? atoi(getenv("KSMI_IG4_STAGGER")) : 1;
   ka.stagger = stag;
+  static const int rot = getenv("KSMI_IG4_ROT") ? atoi(getenv("KSMI_IG4_ROT")) : 1;      // (rotated schedule: +3-7 % on the long-K shapes)
+  ka.rot = rot;
   ka.hslot = g->hslot; ka.nh = g->nh; ka.nhs = g->nhs;
   ka.tiles = g->tiles; ka.gx = g->gx; ka.gy = g->gy;
   static void* zero_page = nullptr;
@@ -662,8 +794,17 @@ int ksmi_igemm4_launch(const ksmi_conv_desc* d, const ksmi_igemm4_geom_t* g, hip
     hipLaunchKernelGGL(kfn, grid, dim3(512), g->lds, st, ka);                                        \
     return ksmi_check_launch("igemm4");                                                              \
   } while (0)
+#define KSMI_G4R(WM_, NF_, AFF_, EPI_)                                                               \
+  do {                                                                                               \
+    auto kfn = igemm4_kernel<WM_, NF_, AFF_, EPI_, false, 0, true>;                                  \
+    static bool attr_set = false;                                                                    \
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; } \
+    hipLaunchKernelGGL(kfn, grid, dim3(512), g->lds, st, ka);                                        \
+    return ksmi_check_launch("igemm4");                                                              \
+  } while (0)
 #define KSMI_G4V(WM_, NF_)                                                                           \
-  do { if (aff) KSMI_G4(WM_, NF_, true, 0); else if (mask) KSMI_G4(WM_, NF_, false, 1); else if (gate) KSMI_G4(WM_, NF_, false, 2);   \
+  do { if (ka.rot) { if (aff) KSMI_G4R(WM_, NF_, true, 0); else if (mask) KSMI_G4R(WM_, NF_, false, 1); else if (gate) KSMI_G4R(WM_, NF_, false, 2); else KSMI_G4R(WM_, NF_, false, 0); } \
+       if (aff) KSMI_G4(WM_, NF_, true, 0); else if (mask) KSMI_G4(WM_, NF_, false, 1); else if (gate) KSMI_G4(WM_, NF_, false, 2);   \
        else if (d->dir == 1) KSMI_G4D(WM_, NF_); else KSMI_G4(WM_, NF_, false, 0); } while (0)
   if (ka.dbg && !aff && !mask && !gate && g->NF == 4) {                       // profiling switches: separate instantiations of the plain kernels
     if (g->WM == 4) {
@@ -682,6 +823,7 @@ int ksmi_igemm4_launch(const ksmi_conv_desc* d, const ksmi_igemm4_geom_t* g, hip
   if (g->WM == 8 && g->NF == 4) KSMI_G4V(8, 4);
   if (g->WM == 8 && g->NF == 2) KSMI_G4V(8, 2);
 #undef KSMI_G4V
+#undef KSMI_G4R
 #undef KSMI_G4D
 #undef KSMI_G4
   return ksmi_fail(KSMI_E_UNSUPPORTED, "igemm4: no instance");
