@@ -183,25 +183,34 @@ __global__ void pack_weights_kernel(const ksmi_pack_desc d) {
 // all packs of a plan in ONE launch: descs live in device memory, blockIdx.y selects the descriptor
 template <typename T>
 __global__ void pack_weights_batched_kernel(const ksmi_pack_desc* descs) {
-  constexpr int KC = ElemTraits<T>::kVec * 4;
+  // one 16-byte vector (8 bf16 / 4 fp32 consecutive k of one packed row) per thread and trip, 32-bit index arithmetic (a packed
+  // tensor has < 2^31 elements; the first version walked single elements with 64-bit div / mod: 188 us per SNUNet step)
+  constexpr int VEC = ElemTraits<T>::kVec;
+  constexpr int KC = VEC * 4;
   const ksmi_pack_desc& d = descs[blockIdx.y];
   const int nchunks = d.nchunks, taps = d.taps, Npad = d.Npad, N = d.N, n_mod = d.n_mod, flip = d.flip;
   const int64_t sK = d.sK, sN = d.sN, sD = d.sD, sT = d.sT;
   const float* w = d.w; T* out = (T*)d.out;
-  const size_t total = (size_t)nchunks * taps * Npad * KC;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int kk = i % KC; size_t r = i / KC;
-    const int j = r % Npad; r /= Npad;
-    const int tap = r % taps; const int ch = r / taps;
-    float v = 0.f;
-    const int koff = d.uniform_kc ? ch * d.uniform_kc : d.k_off[ch];
+  const uint32_t nvec = (uint32_t)nchunks * (uint32_t)taps * (uint32_t)Npad * 4u;
+  for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += gridDim.x * blockDim.x) {
+    const uint32_t q = v & 3u; uint32_t r = v >> 2;
+    const uint32_t j = r % (uint32_t)Npad; r /= (uint32_t)Npad;
+    const uint32_t tap = r % (uint32_t)taps; const uint32_t ch = r / (uint32_t)taps;
+    float f[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) f[e] = 0.f;
+    const int koff = d.uniform_kc ? (int)ch * d.uniform_kc : d.k_off[ch];
     const int klen = d.uniform_kc ? min(d.uniform_kc, d.k_total - koff) : d.k_len[ch];
-    if (j < N && kk < klen) {
-      const int64_t k = koff + kk;
-      const int tp = d.use_tap_map ? d.tap_map[tap] : (flip ? (taps - 1 - tap) : tap);
-      if (tp >= 0) v = w[k * sK + (int64_t)(j % n_mod) * sN + (int64_t)(j / n_mod) * sD + tp * sT];
+    const int tp = d.use_tap_map ? d.tap_map[tap] : (flip ? (taps - 1 - (int)tap) : (int)tap);
+    if ((int)j < N && tp >= 0) {
+      const float* base = w + (int64_t)(j % (uint32_t)n_mod) * sN + (int64_t)(j / (uint32_t)n_mod) * sD + (int64_t)tp * sT;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const int kk = (int)q * VEC + e;
+        if (kk < klen) f[e] = base[(int64_t)(koff + kk) * sK];
+      }
     }
-    ElemTraits<T>::st(out + i, v);
+    *(u32x4*)(out + (size_t)v * VEC) = vec_pack<T>(f);
   }
 }
 

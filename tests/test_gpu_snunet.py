@@ -190,7 +190,8 @@ def test_main_entry_end_to_end_tiny(dev, tmp_path, monkeypatch):
     ck = list((tmp_path / "checkpoints" / "snunet").glob("*/best_segmentation.pt"))
     assert ck, "best checkpoint missing"
     d = torch.load(ck[0], map_location="cpu")
-    assert set(d) == {"epoch", "model_state_dict", "optimizer_state_dict", "lr_scheduler_state_dict", "loss"}
+    # the reference's keys (change_detection_trainer.py:206-213) + the {seed, step} words of the counter-based Dropout stream
+    assert set(d) == {"epoch", "model_state_dict", "optimizer_state_dict", "lr_scheduler_state_dict", "loss", "rng_state"}
     assert len(d["model_state_dict"]) == 236
 
 
