@@ -190,10 +190,19 @@ int ksmi_conv_wgrad_fuses_bias(const ksmi_wgrad_desc* d, int dtype);
  * wgrad writes fp32 dW (OIHW) and db. */
 int ksmi_conv_first_forward(const float* x_nchw, const float* w, const float* bias, void* out, float* stats,
                             int B, int Cin, int H, int W, int Cout, int dtype, void* stream);
+/* The same on RAW tiles: the Dataset's per-tile pipeline (dataset/Dataset.py:164-168 clamp to [0, clamp_input] then
+ * nan_to_num(nan = clamp_input); :193-198 Normalize(mean, std)) applied in the image load.  mean / std / clamp: [Cin] fp32
+ * device arrays, all three or none (none = ksmi_conv_first_forward); clamp[c] < 0: channel c is not clamped and its NaNs become
+ * the mean (DEM / slope).  Bit-identical to ksmi_sar_preprocess followed by ksmi_conv_first_forward. */
+int ksmi_conv_first_forward_raw(const float* x_nchw, const float* w, const float* bias, void* out, float* stats,
+                                int B, int Cin, int H, int W, int Cout, const float* mean, const float* stdv,
+                                const float* clamp, int dtype, void* stream);
 int ksmi_conv_first_stats_rows(int B, int H, int W);
 /* im2col of the raw image: out[b,y,x,c*9+t] (NHWC `dtype`, Kpad channels, zero padded); the first conv and its
  * weight gradient then run on the MFMA implicit-GEMM kernels as a 1x1 conv (k = c*9+t = OIHW flattening). */
 int ksmi_im2col3x3(const float* x_nchw, void* out, int B, int Cin, int H, int W, int Kpad, int dtype, void* stream);
+int ksmi_im2col3x3_raw(const float* x_nchw, void* out, int B, int Cin, int H, int W, int Kpad, const float* mean,
+                       const float* stdv, const float* clamp, int dtype, void* stream);
 int ksmi_conv_first_wgrad(const float* x_nchw, const void* dy, float* dw, float* workspace, size_t ws_bytes,
                           int B, int Cin, int H, int W, int Cout, int accumulate, int dtype, void* stream);
 size_t ksmi_conv_first_wgrad_workspace(int B, int Cin, int H, int W, int Cout);

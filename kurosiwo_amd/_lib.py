@@ -96,8 +96,10 @@ SIGNATURES = {
     "ksmi_conv_gate_supported": (_i, [C.POINTER(ConvDesc), _i]),
     "ksmi_desc_size": (C.c_size_t, [_i]),
     "ksmi_conv_first_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "ksmi_conv_first_forward_raw": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp]),
     "ksmi_conv_first_stats_rows": (_i, [_i, _i, _i]),
     "ksmi_im2col3x3": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "ksmi_im2col3x3_raw": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp]),
     "ksmi_conv_first_wgrad": (_i, [_vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "ksmi_conv_first_wgrad_workspace": (_sz, [_i, _i, _i, _i, _i]),
     "ksmi_bn_finalize": (_i, [_vp, _i, _i, _i, _d, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _vp]),

@@ -443,6 +443,18 @@ __global__ void maxpool_bwd_kernel(const T* x, const T* dy, T* dx, int accumulat
   }
 }
 
+// The Dataset's per-tile pipeline folded into the image load of the first layer (dataset/Dataset.py:164-168 clamp to
+// [0, clamp_input] + nan_to_num(clamp_input), :193-198 Normalize): nmean == nullptr -> the image is already normalised.  nclamp[c] < 0
+// marks a channel without clamp (DEM / slope: NaN -> the mean, i.e. 0 after normalisation).  Same fp32 operations, same order as
+// sar_preprocess_kernel (cformer.hip): the fused path is bit-identical to preprocess-then-convolve.
+__device__ __forceinline__ float raw_tile_value(float v, int c, const float* nmean, const float* nstd, const float* nclamp) {
+  if (nmean == nullptr) return v;
+  const float hi = nclamp[c];
+  if (hi >= 0.f) v = (v != v) ? hi : fminf(fmaxf(v, 0.f), hi);
+  else if (v != v) v = nmean[c];
+  return (v - nmean[c]) / nstd[c];
+}
+
 // ------------------------------------------------------------------------------------------------
 // first-layer conv (raw image NCHW fp32, Cin <= 8) -> NHWC T, + BN partial stats
 // one 16x16 output patch per block, one pixel per thread
@@ -450,7 +462,8 @@ __global__ void maxpool_bwd_kernel(const T* x, const T* dy, T* dx, int accumulat
 template <typename T, int CIN>
 __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                              const float* __restrict__ bias, T* out, float* stats, int B,
-                                                             int H, int W, int Cout) {
+                                                             int H, int W, int Cout, const float* __restrict__ nmean,
+                                                             const float* __restrict__ nstd, const float* __restrict__ nclamp) {
   constexpr int VEC = ElemTraits<T>::kVec;
   constexpr int KT = CIN * 9;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -464,7 +477,9 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const float* __rest
   for (int i = tid; i < CIN * 324; i += 256) {
     const int c = i / 324, r = i - c * 324, hy = r / 18, hx = r - hy * 18;
     const int iy = ty * 16 - 1 + hy, ix = tx * 16 - 1 + hx;
-    xs[i] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? x[(((int64_t)b * CIN + c) * H + iy) * W + ix] : 0.f;
+    float v = 0.f;
+    if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = raw_tile_value(x[(((int64_t)b * CIN + c) * H + iy) * W + ix], c, nmean, nstd, nclamp);
+    xs[i] = v;
   }
   __syncthreads();
   const int oy = ty * 16 + ly, ox = tx * 16 + lx;
@@ -509,7 +524,9 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const float* __rest
 // channels >= Cin*9 zero).  The first conv and its weight gradient then run on the MFMA implicit-GEMM kernels
 // as a 1x1 convolution over these Kpad "channels" (k = c*9 + t matches the OIHW flattening of the weight).
 template <typename T>
-__global__ __launch_bounds__(256) void im2col3x3_kernel(const float* __restrict__ x, T* out, int B, int Cin, int H, int W, int Kpad) {
+__global__ __launch_bounds__(256) void im2col3x3_kernel(const float* __restrict__ x, T* out, int B, int Cin, int H, int W, int Kpad,
+                                                        const float* __restrict__ nmean, const float* __restrict__ nstd,
+                                                        const float* __restrict__ nclamp) {
   constexpr int VEC = ElemTraits<T>::kVec;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* xs = (float*)smem;                       // [Cin][18][18]
@@ -521,7 +538,9 @@ __global__ __launch_bounds__(256) void im2col3x3_kernel(const float* __restrict_
   for (int i = tid; i < Cin * 324; i += 256) {
     const int c = i / 324, r = i - c * 324, hy = r / 18, hx = r - hy * 18;
     const int iy = ty * 16 - 1 + hy, ix = tx * 16 - 1 + hx;
-    xs[i] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? x[(((int64_t)b * Cin + c) * H + iy) * W + ix] : 0.f;
+    float v = 0.f;
+    if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = raw_tile_value(x[(((int64_t)b * Cin + c) * H + iy) * W + ix], c, nmean, nstd, nclamp);
+    xs[i] = v;
   }
   __syncthreads();
   const int KV = Kpad / VEC;                      // vectors per pixel
@@ -918,8 +937,10 @@ int ksmi_maxpool2x2_backward(const void* x, const void* dy, void* dx, int accumu
 
 int ksmi_conv_first_stats_rows(int B, int H, int W) { return B * ((H + 15) / 16) * ((W + 15) / 16); }
 
-int ksmi_conv_first_forward(const float* x, const float* w, const float* bias, void* out, float* stats, int B, int Cin, int H,
-                            int W, int Cout, int dtype, void* stream) {
+int ksmi_conv_first_forward_raw(const float* x, const float* w, const float* bias, void* out, float* stats, int B, int Cin, int H,
+                                int W, int Cout, const float* nmean, const float* nstd, const float* nclamp, int dtype, void* stream) {
+  if ((nmean != nullptr) != (nstd != nullptr) || (nmean != nullptr) != (nclamp != nullptr))
+    return ksmi_fail(KSMI_E_ARG, "conv_first: mean, std and clamp come together");
   const int vec = dtype == KSMI_BF16 ? 8 : 4;
   if (Cin < 1 || Cin > 8 || Cout % vec || Cout > 256) return ksmi_fail(KSMI_E_ARG, "conv_first: Cin<=8, Cout multiple of vector, <=256");
   const int grid = ksmi_conv_first_stats_rows(B, H, W);
@@ -927,13 +948,18 @@ int ksmi_conv_first_forward(const float* x, const float* w, const float* bias, v
   hipStream_t st = (hipStream_t)stream;
 #define KSMI_CF(CIN_)                                                                                                     \
   case CIN_:                                                                                                              \
-    if (dtype == KSMI_BF16) hipLaunchKernelGGL((conv_first_fwd_kernel<bf16_t, CIN_>), dim3(grid), dim3(256), lds, st, x, w, bias, (bf16_t*)out, stats, B, H, W, Cout); \
-    else hipLaunchKernelGGL((conv_first_fwd_kernel<float, CIN_>), dim3(grid), dim3(256), lds, st, x, w, bias, (float*)out, stats, B, H, W, Cout);                    \
+    if (dtype == KSMI_BF16) hipLaunchKernelGGL((conv_first_fwd_kernel<bf16_t, CIN_>), dim3(grid), dim3(256), lds, st, x, w, bias, (bf16_t*)out, stats, B, H, W, Cout, nmean, nstd, nclamp); \
+    else hipLaunchKernelGGL((conv_first_fwd_kernel<float, CIN_>), dim3(grid), dim3(256), lds, st, x, w, bias, (float*)out, stats, B, H, W, Cout, nmean, nstd, nclamp);                    \
     break;
   if (dtype != KSMI_BF16 && dtype != KSMI_F32) return ksmi_fail(KSMI_E_ARG, "bad dtype");
   switch (Cin) { KSMI_CF(1) KSMI_CF(2) KSMI_CF(3) KSMI_CF(4) KSMI_CF(5) KSMI_CF(6) KSMI_CF(7) KSMI_CF(8) }
 #undef KSMI_CF
   return ksmi_check_launch("conv_first_fwd");
+}
+
+int ksmi_conv_first_forward(const float* x, const float* w, const float* bias, void* out, float* stats, int B, int Cin, int H,
+                            int W, int Cout, int dtype, void* stream) {
+  return ksmi_conv_first_forward_raw(x, w, bias, out, stats, B, Cin, H, W, Cout, nullptr, nullptr, nullptr, dtype, stream);
 }
 
 static int conv_first_wgrad_blocks(int B, int H, int W) {
@@ -970,15 +996,20 @@ int ksmi_conv_first_wgrad(const float* x, const void* dy, float* dw, float* work
   return ksmi_check_launch("conv_first_wgrad_reduce");
 }
 
-int ksmi_im2col3x3(const float* x_nchw, void* out, int B, int Cin, int H, int W, int Kpad, int dtype, void* stream) {
+int ksmi_im2col3x3_raw(const float* x_nchw, void* out, int B, int Cin, int H, int W, int Kpad, const float* nmean, const float* nstd,
+                       const float* nclamp, int dtype, void* stream) {
   const int vec = dtype == KSMI_BF16 ? 8 : 4;
   if (Cin < 1 || Cin * 9 > Kpad || Kpad % vec || Cin > 32) return ksmi_fail(KSMI_E_ARG, "im2col3x3: need Cin*9 <= Kpad, Kpad multiple of the vector");
   const int grid = B * ((H + 15) / 16) * ((W + 15) / 16);
   const size_t lds = (size_t)Cin * 324 * sizeof(float);
   KSMI_DT(dtype,
-          hipLaunchKernelGGL(im2col3x3_kernel<bf16_t>, dim3(grid), dim3(256), lds, (hipStream_t)stream, x_nchw, (bf16_t*)out, B, Cin, H, W, Kpad),
-          hipLaunchKernelGGL(im2col3x3_kernel<float>, dim3(grid), dim3(256), lds, (hipStream_t)stream, x_nchw, (float*)out, B, Cin, H, W, Kpad));
+          hipLaunchKernelGGL(im2col3x3_kernel<bf16_t>, dim3(grid), dim3(256), lds, (hipStream_t)stream, x_nchw, (bf16_t*)out, B, Cin, H, W, Kpad, nmean, nstd, nclamp),
+          hipLaunchKernelGGL(im2col3x3_kernel<float>, dim3(grid), dim3(256), lds, (hipStream_t)stream, x_nchw, (float*)out, B, Cin, H, W, Kpad, nmean, nstd, nclamp));
   return ksmi_check_launch("im2col3x3");
+}
+
+int ksmi_im2col3x3(const float* x_nchw, void* out, int B, int Cin, int H, int W, int Kpad, int dtype, void* stream) {
+  return ksmi_im2col3x3_raw(x_nchw, out, B, Cin, H, W, Kpad, nullptr, nullptr, nullptr, dtype, stream);
 }
 
 int ksmi_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int64_t* step_count, float lr, float beta1,

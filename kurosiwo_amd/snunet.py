@@ -85,6 +85,35 @@ class SNUNet_ECAM(nn.Module):
         self._init_parameters()
         self._plans = {}
         self._anchor = None
+        self._raw_norm = None
+
+    # ------------------------------------------------------------------ raw-tile input
+    def set_input_pipeline(self, mean=None, std=None, clamp=None):
+        """Fold the Dataset's per-tile pipeline (dataset/Dataset.py:164-168 clamp to [0, clamp_input] + nan_to_num(clamp_input),
+        :193-198 Normalize) into the image load of conv0_0.conv1: after this call forward() takes RAW tiles (NaNs included).
+        `mean`, `std`: per input channel; `clamp`: a float (every channel) or per channel, a negative entry = no clamp for that
+        channel (DEM: NaN -> mean).  set_input_pipeline() with no arguments returns to normalised inputs."""
+        if mean is None:
+            self._raw_norm = None
+            return self
+        mean = [float(v) for v in mean]
+        std = [float(v) for v in std]
+        clamp = [float(clamp)] * len(mean) if not hasattr(clamp, "__len__") else [float(v) for v in clamp]
+        if not (len(mean) == len(std) == len(clamp) == self.in_channels):
+            raise ValueError(f"set_input_pipeline: {self.in_channels} input channels, got {len(mean)} means, {len(std)} stds, {len(clamp)} clamps")
+        if any(v == 0.0 for v in std):
+            raise ValueError("set_input_pipeline: a zero standard deviation")
+        self._raw_norm = torch.tensor([mean, std, clamp], dtype=torch.float32)
+        return self
+
+    def _raw_ptrs(self, dev):
+        """(mean, std, clamp) device pointers for the first conv, or three nulls"""
+        if self._raw_norm is None:
+            return 0, 0, 0
+        if self._raw_norm.device != dev:
+            self._raw_norm = self._raw_norm.to(dev)
+        base, step = self._raw_norm.data_ptr(), self.in_channels * 4
+        return base, base + step, base + 2 * step
 
     # ------------------------------------------------------------------ arenas
     @staticmethod
@@ -213,7 +242,7 @@ class SNUNet_ECAM(nn.Module):
     # ------------------------------------------------------------------ forward
     def plan(self, B, H, W, training, with_backward):
         self._ensure_arena()
-        key = (B, H, W, self.act_dtype(), bool(training), bool(with_backward))
+        key = (B, H, W, self.act_dtype(), bool(training), bool(with_backward), None if self._raw_norm is None else id(self._raw_norm))
         if key not in self._plans:
             from .snunet_plan import SNUNetPlan
             self._plans[key] = SNUNetPlan(self, B, H, W, self.act_dtype(), training, with_backward)

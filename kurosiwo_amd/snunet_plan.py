@@ -465,12 +465,14 @@ class SNUNetPlan:
             Kpad = -(-(cin * 9) // kc) * kc
             rows1, cpad1, Ktot = self.lib.ksmi_conv_first_stats_rows(B, H, W), Cc, cin
             self.need(sS, rows1 * 2 * Cc * 4)
-            self.fwd.add("ksmi_conv_first_forward", lambda: (x_img.data_ptr(), P("conv1.weight"), P("conv1.bias"),
-                                                             i_act.t.data_ptr(), stats(), B, cin, H, W, Cc, dt))
+            # raw tiles (model.set_input_pipeline): clamp / NaN / Normalize happen in the image load of both kernels
+            raw = m._raw_ptrs(self.dev)
+            self.fwd.add("ksmi_conv_first_forward_raw", lambda: (x_img.data_ptr(), P("conv1.weight"), P("conv1.bias"),
+                                                                 i_act.t.data_ptr(), stats(), B, cin, H, W, Cc, *raw, dt))
             if self.with_backward:
                 col = torch.empty((B, H, W, Kpad), dtype=dtype, device=self.dev)
                 self.keep.append(col)
-                self.fwd.add("ksmi_im2col3x3", lambda: (x_img.data_ptr(), col.data_ptr(), B, cin, H, W, Kpad, dt))
+                self.fwd.add("ksmi_im2col3x3_raw", lambda: (x_img.data_ptr(), col.data_ptr(), B, cin, H, W, Kpad, *raw, dt))
                 src1 = [SrcSpec(col, Kpad)]
         else:
             srcs = [SrcSpec(a.t, a.C) for a in sources]
