@@ -122,7 +122,7 @@ typedef struct ksmi_conv_desc {
   int32_t pad2_;
 } ksmi_conv_desc;
 
-/* sizeof of a descriptor struct as the library was compiled (0 conv, 1 wgrad, 2 pack, 3 rowsum): bindings check their mirror */
+/* sizeof of a descriptor struct as the library was compiled (0 conv, 1 wgrad, 2 pack, 3 rowsum, 4 tiff_info): bindings check their mirror */
 size_t ksmi_desc_size(int which);
 /* 1: ksmi_conv_forward(d, dtype) runs on a kernel that implements the gate epilogue (gate_src) for this descriptor */
 int ksmi_conv_gate_supported(const ksmi_conv_desc* d, int dtype);
@@ -192,17 +192,19 @@ int ksmi_conv_first_forward(const float* x_nchw, const float* w, const float* bi
                             int B, int Cin, int H, int W, int Cout, int dtype, void* stream);
 /* The same on RAW tiles: the Dataset's per-tile pipeline (dataset/Dataset.py:164-168 clamp to [0, clamp_input] then
  * nan_to_num(nan = clamp_input); :193-198 Normalize(mean, std)) applied in the image load.  mean / std / clamp: [Cin] fp32
- * device arrays, all three or none (none = ksmi_conv_first_forward); clamp[c] < 0: channel c is not clamped and its NaNs become
- * the mean (DEM / slope).  Bit-identical to ksmi_sar_preprocess followed by ksmi_conv_first_forward. */
-int ksmi_conv_first_forward_raw(const float* x_nchw, const float* w, const float* bias, void* out, float* stats,
-                                int B, int Cin, int H, int W, int Cout, const float* mean, const float* stdv,
-                                const float* clamp, int dtype, void* stream);
+ * device arrays, all three or none (none = already normalised); clamp[c] < 0: channel c is not clamped and its NaNs become
+ * the mean (DEM / slope).  Bit-identical to ksmi_sar_preprocess followed by ksmi_conv_first_forward.
+ * x_tail != NULL: the trainer's torch.cat((image, dem), dim=1) (training/change_detection_trainer.py:117-133) as an address
+ * choice: channels [0, c_head) are read from x_nchw [B,c_head,H,W], channels [c_head, Cin) from x_tail [B,Cin-c_head,H,W]. */
+int ksmi_conv_first_forward_raw(const float* x_nchw, const float* x_tail, int c_head, const float* w, const float* bias,
+                                void* out, float* stats, int B, int Cin, int H, int W, int Cout, const float* mean,
+                                const float* stdv, const float* clamp, int dtype, void* stream);
 int ksmi_conv_first_stats_rows(int B, int H, int W);
 /* im2col of the raw image: out[b,y,x,c*9+t] (NHWC `dtype`, Kpad channels, zero padded); the first conv and its
  * weight gradient then run on the MFMA implicit-GEMM kernels as a 1x1 conv (k = c*9+t = OIHW flattening). */
 int ksmi_im2col3x3(const float* x_nchw, void* out, int B, int Cin, int H, int W, int Kpad, int dtype, void* stream);
-int ksmi_im2col3x3_raw(const float* x_nchw, void* out, int B, int Cin, int H, int W, int Kpad, const float* mean,
-                       const float* stdv, const float* clamp, int dtype, void* stream);
+int ksmi_im2col3x3_raw(const float* x_nchw, const float* x_tail, int c_head, void* out, int B, int Cin, int H, int W,
+                       int Kpad, const float* mean, const float* stdv, const float* clamp, int dtype, void* stream);
 int ksmi_conv_first_wgrad(const float* x_nchw, const void* dy, float* dw, float* workspace, size_t ws_bytes,
                           int B, int Cin, int H, int W, int Cout, int accumulate, int dtype, void* stream);
 size_t ksmi_conv_first_wgrad_workspace(int B, int Cin, int H, int W, int Cout);
@@ -485,6 +487,32 @@ int ksmi_gemm_nn(const void* dy, int dy_rs, const void* w, int w_rs, void* dx, i
 /* GPU-side input pipeline: the Dataset's per-tile clamp -> nan_to_num -> Normalize (dataset/Dataset.py:164-168,
  * 193-198) on raw backscatter tiles already in HBM; x, y NCHW fp32 (y may alias x) */
 int ksmi_sar_preprocess(const float* x, const float* mean, const float* stdv, float* y, int B, int C, int64_t HW, float clamp_input, void* stream);
+
+/* Host half of N4: reader for the archive's GeoTIFF tiles.  The reference decodes each file in a DataLoader worker with
+ * cv2.imread(path, cv2.IMREAD_ANYDEPTH) (dataset/Dataset.py:664-728: MS1_IVV/IVH, SL1_*, SL2_*, MK0_MLU, MK0_MNA) and rioxarray
+ * for MK0_DEM (:730-737).  Host-only (no GPU needed): TIFF 6.0 + BigTIFF, both byte orders, strips / tiles, chunky / planar,
+ * compression none / LZW / Deflate / PackBits, predictor 1 / 2 / 3, 8..64-bit unsigned / signed / IEEE samples. */
+typedef struct ksmi_tiff_info {
+  int32_t width, height, bands;
+  int32_t bits, sample_format;     /* bits per sample; 1 unsigned, 2 signed, 3 IEEE */
+  int32_t compression, predictor;  /* TIFF tag values */
+  int32_t tiled, big_endian, bigtiff;
+  int32_t has_geo;                 /* bit 0: pixel_scale valid (ModelPixelScale 33550); bit 1: origin valid (ModelTiepoint 33922) */
+  int32_t has_nodata;              /* GDAL_NODATA (42113) present */
+  double pixel_scale[2];           /* x, y size of a pixel in model units */
+  double origin[2], tie_pixel[2];  /* model position `origin` of raster position `tie_pixel` */
+  double nodata;
+} ksmi_tiff_info;
+/* header of the first image of the file */
+int ksmi_tiff_info_read(const char* path, ksmi_tiff_info* info);
+/* the first image as fp32, band-sequential [bands][height][width] (what cv2 returns for a float32 tile; integer masks are
+ * converted exactly); cap_elems = capacity of `out` in elements; info may be NULL */
+int ksmi_tiff_read_f32(const char* path, float* out, int64_t cap_elems, ksmi_tiff_info* info);
+/* the same in the file's own sample type (host byte order) */
+int ksmi_tiff_read_native(const char* path, void* out, int64_t cap_elems, ksmi_tiff_info* info);
+/* n single-band H x W tiles decoded by `threads` host threads into out[n][H][W] fp32 (one pinned staging buffer -> one copy to the
+ * GPU): the body of Dataset.__getitem__'s file loop for a whole batch.  A tile of another size or band count is an error. */
+int ksmi_tile_batch_read(const char* const* paths, int n, float* out, int H, int W, int threads);
 
 /* plumbing */
 int ksmi_fill_zero(void* p, size_t bytes, void* stream);

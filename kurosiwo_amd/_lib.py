@@ -56,6 +56,13 @@ class PackDesc(C.Structure):
                 ("use_tap_map", C.c_int32), ("tap_map", C.c_int32 * 16), ("uniform_kc", C.c_int32), ("k_total", C.c_int32)]
 
 
+class TiffInfo(C.Structure):
+    """ksmi_tiff_info (include/ksmi.h)"""
+    _fields_ = [(k, C.c_int32) for k in ("width", "height", "bands", "bits", "sample_format", "compression", "predictor", "tiled",
+                                         "big_endian", "bigtiff", "has_geo", "has_nodata")] + [
+        ("pixel_scale", C.c_double * 2), ("origin", C.c_double * 2), ("tie_pixel", C.c_double * 2), ("nodata", C.c_double)]
+
+
 class RowsumDesc(C.Structure):
     _fields_ = [("partial", C.c_void_p), ("dst", C.c_void_p), ("rows", C.c_int32), ("K", C.c_int32), ("k", C.c_int32),
                 ("Cstride", C.c_int32), ("C", C.c_int32), ("accumulate", C.c_int32), ("head", C.c_int32), ("next", C.c_int32)]
@@ -96,10 +103,10 @@ SIGNATURES = {
     "ksmi_conv_gate_supported": (_i, [C.POINTER(ConvDesc), _i]),
     "ksmi_desc_size": (C.c_size_t, [_i]),
     "ksmi_conv_first_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
-    "ksmi_conv_first_forward_raw": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp]),
+    "ksmi_conv_first_forward_raw": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp]),
     "ksmi_conv_first_stats_rows": (_i, [_i, _i, _i]),
     "ksmi_im2col3x3": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
-    "ksmi_im2col3x3_raw": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp]),
+    "ksmi_im2col3x3_raw": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp]),
     "ksmi_conv_first_wgrad": (_i, [_vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "ksmi_conv_first_wgrad_workspace": (_sz, [_i, _i, _i, _i, _i]),
     "ksmi_bn_finalize": (_i, [_vp, _i, _i, _i, _d, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _vp]),
@@ -143,6 +150,10 @@ SIGNATURES = {
     "ksmi_relu_backward": (_i, [_vp, _vp, _vp, _i64, _i, _vp]),
     "ksmi_relu_forward": (_i, [_vp, _vp, _i64, _i, _vp]),
     "ksmi_sar_preprocess": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i64, C.c_float, _vp]),
+    "ksmi_tiff_info_read": (_i, [C.c_char_p, C.POINTER(TiffInfo)]),
+    "ksmi_tiff_read_f32": (_i, [C.c_char_p, _vp, _i64, C.POINTER(TiffInfo)]),
+    "ksmi_tiff_read_native": (_i, [C.c_char_p, _vp, _i64, C.POINTER(TiffInfo)]),
+    "ksmi_tile_batch_read": (_i, [C.POINTER(C.c_char_p), _i, _vp, _i, _i, _i]),
     "ksmi_cast_bf16": (_i, [_vp, _vp, _i64, _vp]),
     "ksmi_gemm_nt": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
     "ksmi_gemm_nn": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
@@ -221,7 +232,7 @@ def load():
         fn.argtypes = args
     if lib.ksmi_abi_version() != ABI_VERSION:
         raise KsmiError(f"libksmi ABI {lib.ksmi_abi_version()} != binding {ABI_VERSION}")
-    for which, cls in enumerate((ConvDesc, WgradDesc, PackDesc, RowsumDesc)):        # the ctypes mirrors match the compiled structs
+    for which, cls in enumerate((ConvDesc, WgradDesc, PackDesc, RowsumDesc, TiffInfo)):        # the ctypes mirrors match the compiled structs
         if lib.ksmi_desc_size(which) != C.sizeof(cls):
             raise KsmiError(f"libksmi {cls.__name__}: {lib.ksmi_desc_size(which)} bytes in the library, {C.sizeof(cls)} in the binding")
     _lib = lib

@@ -455,6 +455,13 @@ __device__ __forceinline__ float raw_tile_value(float v, int c, const float* nme
   return (v - nmean[c]) / nstd[c];
 }
 
+// Channel concat of the trainer's input assembly (change_detection_trainer.py:117-133: torch.cat((image, dem), dim=1)) as an address
+// choice: channels [0, chead) come from x [B,chead,H,W], the rest from xtail [B,Cin-chead,H,W] (xtail == nullptr: chead = Cin).
+__device__ __forceinline__ float image_value(const float* __restrict__ x, const float* __restrict__ xtail, int chead, int Cin, int b,
+                                             int c, int H, int W, int iy, int ix) {
+  return c < chead ? x[(((int64_t)b * chead + c) * H + iy) * W + ix] : xtail[(((int64_t)b * (Cin - chead) + (c - chead)) * H + iy) * W + ix];
+}
+
 // ------------------------------------------------------------------------------------------------
 // first-layer conv (raw image NCHW fp32, Cin <= 8) -> NHWC T, + BN partial stats
 // one 16x16 output patch per block, one pixel per thread
@@ -463,7 +470,8 @@ template <typename T, int CIN>
 __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                              const float* __restrict__ bias, T* out, float* stats, int B,
                                                              int H, int W, int Cout, const float* __restrict__ nmean,
-                                                             const float* __restrict__ nstd, const float* __restrict__ nclamp) {
+                                                             const float* __restrict__ nstd, const float* __restrict__ nclamp,
+                                                             const float* __restrict__ xtail, int chead) {
   constexpr int VEC = ElemTraits<T>::kVec;
   constexpr int KT = CIN * 9;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -478,7 +486,7 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const float* __rest
     const int c = i / 324, r = i - c * 324, hy = r / 18, hx = r - hy * 18;
     const int iy = ty * 16 - 1 + hy, ix = tx * 16 - 1 + hx;
     float v = 0.f;
-    if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = raw_tile_value(x[(((int64_t)b * CIN + c) * H + iy) * W + ix], c, nmean, nstd, nclamp);
+    if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = raw_tile_value(image_value(x, xtail, chead, CIN, b, c, H, W, iy, ix), c, nmean, nstd, nclamp);
     xs[i] = v;
   }
   __syncthreads();
@@ -526,7 +534,7 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const float* __rest
 template <typename T>
 __global__ __launch_bounds__(256) void im2col3x3_kernel(const float* __restrict__ x, T* out, int B, int Cin, int H, int W, int Kpad,
                                                         const float* __restrict__ nmean, const float* __restrict__ nstd,
-                                                        const float* __restrict__ nclamp) {
+                                                        const float* __restrict__ nclamp, const float* __restrict__ xtail, int chead) {
   constexpr int VEC = ElemTraits<T>::kVec;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* xs = (float*)smem;                       // [Cin][18][18]
@@ -539,7 +547,7 @@ __global__ __launch_bounds__(256) void im2col3x3_kernel(const float* __restrict_
     const int c = i / 324, r = i - c * 324, hy = r / 18, hx = r - hy * 18;
     const int iy = ty * 16 - 1 + hy, ix = tx * 16 - 1 + hx;
     float v = 0.f;
-    if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = raw_tile_value(x[(((int64_t)b * Cin + c) * H + iy) * W + ix], c, nmean, nstd, nclamp);
+    if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = raw_tile_value(image_value(x, xtail, chead, Cin, b, c, H, W, iy, ix), c, nmean, nstd, nclamp);
     xs[i] = v;
   }
   __syncthreads();
@@ -937,10 +945,18 @@ int ksmi_maxpool2x2_backward(const void* x, const void* dy, void* dx, int accumu
 
 int ksmi_conv_first_stats_rows(int B, int H, int W) { return B * ((H + 15) / 16) * ((W + 15) / 16); }
 
-int ksmi_conv_first_forward_raw(const float* x, const float* w, const float* bias, void* out, float* stats, int B, int Cin, int H,
-                                int W, int Cout, const float* nmean, const float* nstd, const float* nclamp, int dtype, void* stream) {
+static int first_conv_sources(const float* xtail, int* chead, int Cin, const float* nmean, const float* nstd, const float* nclamp) {
   if ((nmean != nullptr) != (nstd != nullptr) || (nmean != nullptr) != (nclamp != nullptr))
     return ksmi_fail(KSMI_E_ARG, "conv_first: mean, std and clamp come together");
+  if (xtail == nullptr) *chead = Cin;
+  else if (*chead < 1 || *chead >= Cin) return ksmi_fail(KSMI_E_ARG, "conv_first: a tail image needs 1 <= c_head < Cin");
+  return 0;
+}
+
+int ksmi_conv_first_forward_raw(const float* x, const float* xtail, int chead, const float* w, const float* bias, void* out, float* stats,
+                                int B, int Cin, int H, int W, int Cout, const float* nmean, const float* nstd, const float* nclamp,
+                                int dtype, void* stream) {
+  if (int rc = first_conv_sources(xtail, &chead, Cin, nmean, nstd, nclamp)) return rc;
   const int vec = dtype == KSMI_BF16 ? 8 : 4;
   if (Cin < 1 || Cin > 8 || Cout % vec || Cout > 256) return ksmi_fail(KSMI_E_ARG, "conv_first: Cin<=8, Cout multiple of vector, <=256");
   const int grid = ksmi_conv_first_stats_rows(B, H, W);
@@ -948,8 +964,8 @@ int ksmi_conv_first_forward_raw(const float* x, const float* w, const float* bia
   hipStream_t st = (hipStream_t)stream;
 #define KSMI_CF(CIN_)                                                                                                     \
   case CIN_:                                                                                                              \
-    if (dtype == KSMI_BF16) hipLaunchKernelGGL((conv_first_fwd_kernel<bf16_t, CIN_>), dim3(grid), dim3(256), lds, st, x, w, bias, (bf16_t*)out, stats, B, H, W, Cout, nmean, nstd, nclamp); \
-    else hipLaunchKernelGGL((conv_first_fwd_kernel<float, CIN_>), dim3(grid), dim3(256), lds, st, x, w, bias, (float*)out, stats, B, H, W, Cout, nmean, nstd, nclamp);                    \
+    if (dtype == KSMI_BF16) hipLaunchKernelGGL((conv_first_fwd_kernel<bf16_t, CIN_>), dim3(grid), dim3(256), lds, st, x, w, bias, (bf16_t*)out, stats, B, H, W, Cout, nmean, nstd, nclamp, xtail, chead); \
+    else hipLaunchKernelGGL((conv_first_fwd_kernel<float, CIN_>), dim3(grid), dim3(256), lds, st, x, w, bias, (float*)out, stats, B, H, W, Cout, nmean, nstd, nclamp, xtail, chead);                    \
     break;
   if (dtype != KSMI_BF16 && dtype != KSMI_F32) return ksmi_fail(KSMI_E_ARG, "bad dtype");
   switch (Cin) { KSMI_CF(1) KSMI_CF(2) KSMI_CF(3) KSMI_CF(4) KSMI_CF(5) KSMI_CF(6) KSMI_CF(7) KSMI_CF(8) }
@@ -959,7 +975,7 @@ int ksmi_conv_first_forward_raw(const float* x, const float* w, const float* bia
 
 int ksmi_conv_first_forward(const float* x, const float* w, const float* bias, void* out, float* stats, int B, int Cin, int H,
                             int W, int Cout, int dtype, void* stream) {
-  return ksmi_conv_first_forward_raw(x, w, bias, out, stats, B, Cin, H, W, Cout, nullptr, nullptr, nullptr, dtype, stream);
+  return ksmi_conv_first_forward_raw(x, nullptr, Cin, w, bias, out, stats, B, Cin, H, W, Cout, nullptr, nullptr, nullptr, dtype, stream);
 }
 
 static int conv_first_wgrad_blocks(int B, int H, int W) {
@@ -996,20 +1012,21 @@ int ksmi_conv_first_wgrad(const float* x, const void* dy, float* dw, float* work
   return ksmi_check_launch("conv_first_wgrad_reduce");
 }
 
-int ksmi_im2col3x3_raw(const float* x_nchw, void* out, int B, int Cin, int H, int W, int Kpad, const float* nmean, const float* nstd,
-                       const float* nclamp, int dtype, void* stream) {
+int ksmi_im2col3x3_raw(const float* x_nchw, const float* xtail, int chead, void* out, int B, int Cin, int H, int W, int Kpad,
+                       const float* nmean, const float* nstd, const float* nclamp, int dtype, void* stream) {
+  if (int rc = first_conv_sources(xtail, &chead, Cin, nmean, nstd, nclamp)) return rc;
   const int vec = dtype == KSMI_BF16 ? 8 : 4;
   if (Cin < 1 || Cin * 9 > Kpad || Kpad % vec || Cin > 32) return ksmi_fail(KSMI_E_ARG, "im2col3x3: need Cin*9 <= Kpad, Kpad multiple of the vector");
   const int grid = B * ((H + 15) / 16) * ((W + 15) / 16);
   const size_t lds = (size_t)Cin * 324 * sizeof(float);
   KSMI_DT(dtype,
-          hipLaunchKernelGGL(im2col3x3_kernel<bf16_t>, dim3(grid), dim3(256), lds, (hipStream_t)stream, x_nchw, (bf16_t*)out, B, Cin, H, W, Kpad, nmean, nstd, nclamp),
-          hipLaunchKernelGGL(im2col3x3_kernel<float>, dim3(grid), dim3(256), lds, (hipStream_t)stream, x_nchw, (float*)out, B, Cin, H, W, Kpad, nmean, nstd, nclamp));
+          hipLaunchKernelGGL(im2col3x3_kernel<bf16_t>, dim3(grid), dim3(256), lds, (hipStream_t)stream, x_nchw, (bf16_t*)out, B, Cin, H, W, Kpad, nmean, nstd, nclamp, xtail, chead),
+          hipLaunchKernelGGL(im2col3x3_kernel<float>, dim3(grid), dim3(256), lds, (hipStream_t)stream, x_nchw, (float*)out, B, Cin, H, W, Kpad, nmean, nstd, nclamp, xtail, chead));
   return ksmi_check_launch("im2col3x3");
 }
 
 int ksmi_im2col3x3(const float* x_nchw, void* out, int B, int Cin, int H, int W, int Kpad, int dtype, void* stream) {
-  return ksmi_im2col3x3_raw(x_nchw, out, B, Cin, H, W, Kpad, nullptr, nullptr, nullptr, dtype, stream);
+  return ksmi_im2col3x3_raw(x_nchw, nullptr, Cin, out, B, Cin, H, W, Kpad, nullptr, nullptr, nullptr, dtype, stream);
 }
 
 int ksmi_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int64_t* step_count, float lr, float beta1,

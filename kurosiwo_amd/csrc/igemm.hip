@@ -940,6 +940,7 @@ size_t ksmi_desc_size(int which) {
     case 1: return sizeof(ksmi_wgrad_desc);
     case 2: return sizeof(ksmi_pack_desc);
     case 3: return sizeof(ksmi_rowsum_desc);
+    case 4: return sizeof(ksmi_tiff_info);
     default: return 0;
   }
 }

@@ -240,39 +240,45 @@ class SNUNet_ECAM(nn.Module):
         return torch.bfloat16 if self.precision == "bf16" else torch.float32
 
     # ------------------------------------------------------------------ forward
-    def plan(self, B, H, W, training, with_backward):
+    def plan(self, B, H, W, training, with_backward, tail=0):
         self._ensure_arena()
-        key = (B, H, W, self.act_dtype(), bool(training), bool(with_backward), None if self._raw_norm is None else id(self._raw_norm))
+        key = (B, H, W, self.act_dtype(), bool(training), bool(with_backward), None if self._raw_norm is None else id(self._raw_norm), tail)
         if key not in self._plans:
             from .snunet_plan import SNUNetPlan
-            self._plans[key] = SNUNetPlan(self, B, H, W, self.act_dtype(), training, with_backward)
+            self._plans[key] = SNUNetPlan(self, B, H, W, self.act_dtype(), training, with_backward, tail=tail)
         return self._plans[key]
 
-    def forward(self, xA, xB):
+    def forward(self, xA, xB, dem=None):
+        """xA, xB: the two dates [B,C,H,W].  dem (optional, [B,Cd,H,W]): channels shared by both dates; forward(xA, xB, dem) equals
+        forward(cat(xA, dem), cat(xB, dem)) (the trainer's input assembly, change_detection_trainer.py:117-133) without the copies."""
         require_gpu(xA)
-        if xA.shape != xB.shape or xA.dim() != 4 or xA.shape[1] != self.in_channels:
-            raise ValueError(f"expected two [B,{self.in_channels},H,W] tensors, got {tuple(xA.shape)} {tuple(xB.shape)}")
+        tail = 0 if dem is None else dem.shape[1]
+        if xA.shape != xB.shape or xA.dim() != 4 or xA.shape[1] + tail != self.in_channels or (dem is not None and (
+                dem.dim() != 4 or dem.shape[0] != xA.shape[0] or dem.shape[2:] != xA.shape[2:])):
+            raise ValueError(f"expected two [B,{self.in_channels - tail},H,W] tensors" + (f" and a [B,{tail},H,W] tail" if tail else "") +
+                             f", got {tuple(xA.shape)} {tuple(xB.shape)}" + (f" {tuple(dem.shape)}" if tail else ""))
         B, _, H, W = xA.shape
         if H % 16 or W % 16:
             raise ValueError("H and W must be multiples of 16 (four 2x2 max-pools)")
         want_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
-        plan = self.plan(B, H, W, self.training, want_grad)
+        plan = self.plan(B, H, W, self.training, want_grad, tail)
         xA = xA.contiguous().float()
         xB = xB.contiguous().float()
+        dem = None if dem is None else dem.contiguous().float()
         if not want_grad:
-            return plan.run_forward(xA, xB).clone()
+            return plan.run_forward(xA, xB, dem).clone()
         if self._anchor is None or self._anchor.device != xA.device:
             self._anchor = torch.zeros(1, device=xA.device, requires_grad=True)
-        return _SNUNetFn.apply(self._anchor, xA, xB, self, plan)
+        return _SNUNetFn.apply(self._anchor, xA, xB, dem, self, plan)
 
 
 class _SNUNetFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, anchor, xA, xB, model, plan):
+    def forward(ctx, anchor, xA, xB, dem, model, plan):
         from .arena import stamp_forward
         ctx.model, ctx.plan = model, plan
         ctx.gen = stamp_forward(plan)
-        return plan.run_forward(xA, xB).clone()
+        return plan.run_forward(xA, xB, dem).clone()
 
     @staticmethod
     def backward(ctx, dlogits):
@@ -292,6 +298,6 @@ class _SNUNetFn(torch.autograd.Function):
             p = mod._parameters[parts[-1]]
             if p.requires_grad:
                 p.grad = model._g(key).view(model._pspec[key])
-        return None, None, None, None, None
+        return None, None, None, None, None, None
 
 

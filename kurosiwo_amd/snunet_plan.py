@@ -139,7 +139,7 @@ class SNUNetPlan:
     side_wgrad = True          # weight gradients on the train step's side stream (see LaunchList.run; plan_base.PlanBase.side_wgrad)
     two_lanes = True           # the decoder launches carry lane tags and hand-over entries (StepStreams)
 
-    def __init__(self, model, B, H, W, dtype, training, with_backward):
+    def __init__(self, model, B, H, W, dtype, training, with_backward, tail=0):
         self.m, self.B, self.H, self.W, self.dtype = model, B, H, W, dtype
         self.training, self.with_backward = training, with_backward
         self.dev = model.flat_params.device
@@ -155,8 +155,12 @@ class SNUNetPlan:
         n, c = model.base_channel, model.in_channels
         self.n = n
         f = [n, 2 * n, 4 * n, 8 * n, 16 * n]
-        self.xA = torch.empty((B, c, H, W), dtype=torch.float32, device=self.dev)
+        # `tail` trailing input channels (the DEM) are shared by both dates and live in their own buffer: the first conv reads
+        # channels [0, c - tail) from xA / xB and the rest from xtail (the trainer's torch.cat((image, dem), 1) as an address choice)
+        self.tail = tail
+        self.xA = torch.empty((B, c - tail, H, W), dtype=torch.float32, device=self.dev)
         self.xB = torch.empty_like(self.xA)
+        self.xtail = torch.empty((B, tail, H, W), dtype=torch.float32, device=self.dev) if tail else None
         self.logits = torch.empty((B, 3, H, W), dtype=torch.float32, device=self.dev)
         self.dlogits = torch.empty_like(self.logits) if with_backward else None
         self.bwd_builders = []
@@ -460,19 +464,20 @@ class SNUNetPlan:
             # the input image to bf16 costs ~2 points of gradient cosine downstream).  For the weight gradient
             # the image is also laid out as im2col [B,H,W,Kpad] (k = c*9+t) so dW runs on the MFMA wgrad kernel.
             x_img = sources[0]
-            cin = x_img.shape[1]
+            chead, cin = x_img.shape[1], m.in_channels
+            x_tail = self.xtail.data_ptr() if self.tail else None
             kc = 32 if dtype == torch.bfloat16 else 16
             Kpad = -(-(cin * 9) // kc) * kc
             rows1, cpad1, Ktot = self.lib.ksmi_conv_first_stats_rows(B, H, W), Cc, cin
             self.need(sS, rows1 * 2 * Cc * 4)
             # raw tiles (model.set_input_pipeline): clamp / NaN / Normalize happen in the image load of both kernels
             raw = m._raw_ptrs(self.dev)
-            self.fwd.add("ksmi_conv_first_forward_raw", lambda: (x_img.data_ptr(), P("conv1.weight"), P("conv1.bias"),
+            self.fwd.add("ksmi_conv_first_forward_raw", lambda: (x_img.data_ptr(), x_tail, chead, P("conv1.weight"), P("conv1.bias"),
                                                                  i_act.t.data_ptr(), stats(), B, cin, H, W, Cc, *raw, dt))
             if self.with_backward:
                 col = torch.empty((B, H, W, Kpad), dtype=dtype, device=self.dev)
                 self.keep.append(col)
-                self.fwd.add("ksmi_im2col3x3_raw", lambda: (x_img.data_ptr(), col.data_ptr(), B, cin, H, W, Kpad, *raw, dt))
+                self.fwd.add("ksmi_im2col3x3_raw", lambda: (x_img.data_ptr(), x_tail, chead, col.data_ptr(), B, cin, H, W, Kpad, *raw, dt))
                 src1 = [SrcSpec(col, Kpad)]
         else:
             srcs = [SrcSpec(a.t, a.C) for a in sources]
@@ -640,11 +645,15 @@ class SNUNetPlan:
         self.bwd_builders.append((self.fwd.cur_lane, build_bwd))
 
     # ---------------------------------------------------------------- execution
-    def run_forward(self, xA, xB):
+    def run_forward(self, xA, xB, tail=None):
         if xA.data_ptr() != self.xA.data_ptr():
             self.xA.copy_(xA)
         if xB.data_ptr() != self.xB.data_ptr():
             self.xB.copy_(xB)
+        if (tail is None) != (self.xtail is None):
+            raise _lib.KsmiError("plan and call disagree about the shared tail channels (DEM)")
+        if tail is not None and tail.data_ptr() != self.xtail.data_ptr():
+            self.xtail.copy_(tail)
         self.packs.run()
         self.fwd.run()
         return self.logits

@@ -95,6 +95,25 @@ def test_raw_tiles_with_a_dem_channel_that_is_not_clamped():
     assert torch.equal(out0, out1)
     for k in g0:
         assert torch.equal(g0[k], g1[k]), k
+    # the DEM as a shared tail: forward(xA, xB, dem) == forward(cat(xA, dem), cat(xB, dem)), no concatenated copies
+    demA = rA[:, 2:3].clone()
+    rB[:, 2:3] = demA
+    out2, g2 = _step(model, rA.cuda(), rB.cuda(), lbl)
+
+    def step_tail():
+        for p in model.parameters():
+            p.grad = None
+        out = model(rA[:, :2].cuda(), rB[:, :2].cuda(), demA.cuda())
+        torch.nn.functional.cross_entropy(out, lbl, ignore_index=3).backward()
+        return out.detach().clone(), {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+    out3, g3 = step_tail()
+    assert torch.equal(out2, out3)
+    for k in g2:
+        assert torch.equal(g2[k], g3[k]), k
+    with pytest.raises(ValueError):
+        model(rA[:, :2].cuda(), rB[:, :2].cuda())                  # a channel short
+    with pytest.raises(ValueError):
+        model(rA.cuda(), rB.cuda(), demA.cuda())                   # a channel too many
 
 
 def test_argument_errors_are_loud():
@@ -111,6 +130,9 @@ def test_argument_errors_are_loud():
     b = torch.zeros(32, device="cuda")
     out = torch.zeros(1, 16, 16, 32, device="cuda")
     m = torch.zeros(2, device="cuda")
-    rc = lib.ksmi_conv_first_forward_raw(x.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(), None, 1, 2, 16, 16, 32,
+    rc = lib.ksmi_conv_first_forward_raw(x.data_ptr(), None, 2, w.data_ptr(), b.data_ptr(), out.data_ptr(), None, 1, 2, 16, 16, 32,
                                          m.data_ptr(), None, None, DT[torch.float32], None)
     assert rc != 0 and b"come together" in lib.ksmi_last_error()
+    rc = lib.ksmi_conv_first_forward_raw(x.data_ptr(), x.data_ptr(), 2, w.data_ptr(), b.data_ptr(), out.data_ptr(), None, 1, 2, 16, 16, 32,
+                                         None, None, None, DT[torch.float32], None)
+    assert rc != 0 and b"c_head" in lib.ksmi_last_error()
