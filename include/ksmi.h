@@ -513,6 +513,10 @@ int ksmi_tiff_read_native(const char* path, void* out, int64_t cap_elems, ksmi_t
 /* n single-band H x W tiles decoded by `threads` host threads into out[n][H][W] fp32 (one pinned staging buffer -> one copy to the
  * GPU): the body of Dataset.__getitem__'s file loop for a whole batch.  A tile of another size or band count is an error. */
 int ksmi_tile_batch_read(const char* const* paths, int n, float* out, int H, int W, int threads);
+/* DEM gaps: every NaN of each of the n H x W tiles takes the value of the nearest valid pixel (Euclidean, pixel grid), in place:
+ * rioxarray's interpolate_na(method="nearest") of dataset/Dataset.py:733-735.  Tiles without NaN (or without a valid pixel) are
+ * left as they are. */
+int ksmi_tiles_fill_nodata(float* tiles, int n, int H, int W, int threads);
 
 /* plumbing */
 int ksmi_fill_zero(void* p, size_t bytes, void* stream);

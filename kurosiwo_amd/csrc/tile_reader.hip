@@ -10,6 +10,7 @@
 #include <zlib.h>
 
 #include <atomic>
+#include <climits>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -211,47 +212,63 @@ const char* parse(const Reader& r0, Layout* L) {
 
 // ---- decoders ---------------------------------------------------------------------------------
 // TIFF LZW (TIFF 6.0 §13): MSB-first codes of 9..12 bits, Clear = 256, EOI = 257, code width grows one code early.
+// A table entry is (where in the OUTPUT its string was first written, length): a code is expanded by a forward copy from earlier
+// output instead of a walk along a prefix chain, and the entry a code creates (previous string + first byte of this one) is simply
+// the previous string's position with one more byte, because this string is written right behind it.
 int64_t lzw_decode(const uint8_t* src, int64_t n, uint8_t* dst, int64_t cap) {
-  struct Node { uint16_t prefix; uint8_t last, first; uint32_t len; };
-  static thread_local std::vector<Node> tab(4096);
-  for (int i = 0; i < 256; ++i) tab[i] = {0xffff, (uint8_t)i, (uint8_t)i, 1};
-  int next = 258, bits = 9, prev = -1;
-  uint32_t acc = 0;
+  struct Ent { uint32_t pos, len; };
+  Ent tab[4096];
+  int next = 258, bits = 9;
+  int64_t prev_pos = -1;          // start of the previous code's string in dst (-1: none since the last Clear)
+  uint32_t prev_len = 0;
+  uint64_t acc = 0;
   int have = 0;
   int64_t sp = 0, dp = 0;
   for (;;) {
-    while (have < bits && sp < n) { acc = (acc << 8) | src[sp++]; have += 8; }
-    if (have < bits) break;                                   // ran out without EOI: what was decoded stands
-    const int code = (acc >> (have - bits)) & ((1u << bits) - 1);
+    if (have < bits) {
+      if (sp + 4 <= n) { acc = (acc << 32) | ((uint32_t)src[sp] << 24 | (uint32_t)src[sp + 1] << 16 | (uint32_t)src[sp + 2] << 8 | src[sp + 3]); sp += 4; have += 32; }
+      else {
+        while (have < bits && sp < n) { acc = (acc << 8) | src[sp++]; have += 8; }
+        if (have < bits) break;                               // ran out without EOI: what was decoded stands
+      }
+    }
+    const int code = (int)((acc >> (have - bits)) & ((1u << bits) - 1));
     have -= bits;
     if (code == 257) break;
-    if (code == 256) { next = 258; bits = 9; prev = -1; continue; }
-    if (prev < 0) {
-      if (code > 255) return -1;
-      if (dp < cap) dst[dp] = (uint8_t)code;
-      ++dp; prev = code;
-      continue;
-    }
+    if (code == 256) { next = 258; bits = 9; prev_pos = -1; continue; }
     uint32_t len;
-    uint8_t first;
-    if (code < next) { len = tab[code].len; first = tab[code].first; }
-    else if (code == next) { len = tab[prev].len + 1; first = tab[prev].first; }
-    else return -1;
-    // write the string backwards
-    {
-      int64_t e = dp + len;
-      int c = code;
-      if (code == next) { --e; if (e < cap) dst[e] = first; c = prev; }
-      while (c != 0xffff && e > dp) { --e; if (e < cap) dst[e] = tab[c].last; c = tab[c].prefix; }
+    if (code < 256) {
+      if (dp >= cap) break;
+      dst[dp] = (uint8_t)code;
+      len = 1;
+    } else {
+      int64_t from;
+      if (prev_pos < 0) return -1;
+      if (code < next) { from = tab[code].pos; len = tab[code].len; }
+      else if (code == next) { from = prev_pos; len = prev_len + 1; }
+      else return -1;
+      if (dp + len > cap) {                                   // the strip is full: copy what fits, the rest is padding
+        for (int64_t k = 0; dp + k < cap; ++k) dst[dp + k] = dst[from + k];
+        dp = cap;
+        break;
+      }
+      const uint8_t* f = dst + from;
+      uint8_t* t = dst + dp;
+      if (dp - from >= 8 && len >= 8) {
+        uint32_t k = 0;
+        for (; k + 8 <= len; k += 8) memcpy(t + k, f + k, 8);
+        for (; k < len; ++k) t[k] = f[k];
+      } else {
+        for (uint32_t k = 0; k < len; ++k) t[k] = f[k];       // may overlap its own output (the KwKwK case): forward, byte by byte
+      }
     }
-    dp += len;
-    if (next < 4096) {
-      tab[next] = {(uint16_t)prev, first, tab[prev].first, tab[prev].len + 1};
+    if (prev_pos >= 0 && next < 4096) {
+      tab[next] = {(uint32_t)prev_pos, prev_len + 1};
       ++next;
       if (next == (1 << bits) - 1 && bits < 12) ++bits;
     }
-    prev = code;
-    if (dp >= cap) { dp = dp > cap ? cap : dp; break; }       // the strip is full: trailing codes are padding
+    prev_pos = dp; prev_len = len;
+    dp += len;
   }
   return dp;
 }
@@ -285,6 +302,11 @@ inline void swap_bytes(uint8_t* p, int64_t count, int size) {
 template <typename T>
 void undo_hdiff(uint8_t* row, int64_t samples, int stride) {
   T* v = (T*)row;
+  if (stride == 1) {                                   // running sum in a register (no store-to-load chain through memory)
+    T acc = v[0];
+    for (int64_t i = 1; i < samples; ++i) { acc = (T)(acc + v[i]); v[i] = acc; }
+    return;
+  }
   for (int64_t i = stride; i < samples; ++i) v[i] = (T)(v[i] + v[i - stride]);
 }
 
@@ -292,8 +314,19 @@ void undo_hdiff(uint8_t* row, int64_t samples, int stride) {
 // then the row holds byte planes, most significant first
 void undo_fpred(uint8_t* row, uint8_t* tmp, int64_t samples, int stride, int bps) {
   const int64_t rb = samples * bps;
-  for (int64_t i = (int64_t)stride; i < rb; ++i) row[i] = (uint8_t)(row[i] + row[i - stride]);
+  if (stride == 1) {
+    uint8_t acc = row[0];
+    for (int64_t i = 1; i < rb; ++i) { acc = (uint8_t)(acc + row[i]); row[i] = acc; }
+  } else {
+    for (int64_t i = (int64_t)stride; i < rb; ++i) row[i] = (uint8_t)(row[i] + row[i - stride]);
+  }
   memcpy(tmp, row, (size_t)rb);
+  if (bps == 4) {
+    const uint8_t *p0 = tmp, *p1 = tmp + samples, *p2 = tmp + 2 * samples, *p3 = tmp + 3 * samples;
+    uint32_t* o = (uint32_t*)row;
+    for (int64_t i = 0; i < samples; ++i) o[i] = (uint32_t)p0[i] << 24 | (uint32_t)p1[i] << 16 | (uint32_t)p2[i] << 8 | p3[i];
+    return;
+  }
   for (int64_t i = 0; i < samples; ++i)
     for (int b = 0; b < bps; ++b) row[i * bps + (bps - 1 - b)] = tmp[(int64_t)b * samples + i];     // little-endian host
 }
@@ -396,7 +429,10 @@ std::string decode_file_(const char* path, float* out_f32, uint8_t* out_raw, int
           for (int s = 0; s < spp; ++s) {
             const int64_t band = L.planar == 2 ? pl : s;
             const int64_t o = (band * H + oy) * W + x0;
-            if (out_f32)
+            if (out_f32 && spp == 1 && I.sample_format == 3 && I.bits == 32) memcpy(out_f32 + o, row, (size_t)xs * 4);
+            else if (out_f32 && spp == 1 && I.sample_format == 1 && I.bits == 8)
+              for (int64_t x = 0; x < xs; ++x) out_f32[o + x] = (float)row[x];
+            else if (out_f32)
               for (int64_t x = 0; x < xs; ++x) out_f32[o + x] = sample_f32(row + (x * spp + s) * bps, I.bits, I.sample_format);
             else
               for (int64_t x = 0; x < xs; ++x) memcpy(out_raw + (o + x) * bps, row + (x * spp + s) * bps, (size_t)bps);
@@ -413,6 +449,41 @@ std::string decode_file(const char* path, float* out_f32, uint8_t* out_raw, int6
   } catch (const std::exception& e) {                       // allocation failure on a damaged header: an error, not a crash
     return std::string(e.what()) + ": " + path;
   }
+}
+
+// every NaN of a tile takes the value of the nearest valid pixel (exact Euclidean distance on the pixel grid; ties: the smaller
+// row offset, rows above before rows below, left before right).  Per row the nearest valid column to the left / right of every x
+// is tabulated once; a NaN pixel then scans rows outward until the row offset alone exceeds the best distance.
+void fill_nodata_tile(float* a, int H, int W, std::vector<int>& left, std::vector<int>& right, std::vector<float>& src) {
+  bool any = false, all = true;
+  for (int64_t i = 0; i < (int64_t)H * W; ++i) { const bool bad = a[i] != a[i]; any |= bad; all &= bad; }
+  if (!any || all) return;
+  src.assign(a, a + (int64_t)H * W);
+  left.resize((size_t)H * W); right.resize((size_t)H * W);
+  for (int y = 0; y < H; ++y) {
+    const float* r = src.data() + (int64_t)y * W;
+    int last = -1;
+    for (int x = 0; x < W; ++x) { if (r[x] == r[x]) last = x; left[(size_t)y * W + x] = last; }
+    last = -1;
+    for (int x = W - 1; x >= 0; --x) { if (r[x] == r[x]) last = x; right[(size_t)y * W + x] = last; }
+  }
+  for (int y = 0; y < H; ++y)
+    for (int x = 0; x < W; ++x) {
+      if (src[(int64_t)y * W + x] == src[(int64_t)y * W + x]) continue;
+      int64_t best = INT64_MAX;
+      float val = 0.f;
+      for (int d = 0; d < H; ++d) {
+        if ((int64_t)d * d >= best) break;
+        for (int sgn = 0; sgn < (d ? 2 : 1); ++sgn) {
+          const int yy = sgn ? y + d : y - d;
+          if (yy < 0 || yy >= H) continue;
+          const int l = left[(size_t)yy * W + x], r = right[(size_t)yy * W + x];
+          if (l >= 0) { const int64_t q = (int64_t)d * d + (int64_t)(x - l) * (x - l); if (q < best) { best = q; val = src[(int64_t)yy * W + l]; } }
+          if (r >= 0) { const int64_t q = (int64_t)d * d + (int64_t)(r - x) * (r - x); if (q < best) { best = q; val = src[(int64_t)yy * W + r]; } }
+        }
+      }
+      a[(int64_t)y * W + x] = val;
+    }
 }
 
 }  // namespace
@@ -463,6 +534,33 @@ int ksmi_tile_batch_read(const char* const* paths, int n, float* out, int H, int
     for (auto& t : pool) t.join();
   }
   return failed.load() ? ksmi_fail(KSMI_E_ARG, first_error.c_str()) : 0;
+}
+
+int ksmi_tiles_fill_nodata(float* tiles, int n, int H, int W, int threads) {
+  if (n < 0 || (n && !tiles) || H <= 0 || W <= 0) return ksmi_fail(KSMI_E_ARG, "tiles_fill_nodata: bad argument");
+  if (threads < 1) threads = 1;
+  if (threads > n) threads = n > 0 ? n : 1;
+  std::atomic<int> next{0};
+  auto work = [&]() {
+    std::vector<int> left, right;
+    std::vector<float> src;
+    for (;;) {
+      const int i = next.fetch_add(1);
+      if (i >= n) return;
+      fill_nodata_tile(tiles + (int64_t)i * H * W, H, W, left, right, src);
+    }
+  };
+  try {
+    if (threads == 1) work();
+    else {
+      std::vector<std::thread> pool;
+      for (int t = 0; t < threads; ++t) pool.emplace_back(work);
+      for (auto& t : pool) t.join();
+    }
+  } catch (const std::exception& e) {
+    return ksmi_fail(KSMI_E_ARG, e.what());
+  }
+  return 0;
 }
 
 }  // extern "C"

@@ -1,7 +1,8 @@
-"""Loaders.  The reference's Dataset classes (dataset/Dataset.py) need the Kuro Siwo archive,
-cv2/rioxarray and grid pickles that are not part of this build (out of scope);
-`prepare_loaders` keeps the reference signature (utilities/utilities.py:73-126) and serves
-synthetic tiles with the exact collated-batch layout (kurosiwo_amd/synthetic.py)."""
+"""Loaders.  `prepare_loaders` keeps the reference signature (utilities/utilities.py:73-126).  With the Kuro Siwo archive on disk
+(configs["root_path"]/data + the grid pickles, or configs["slc_root_path"] + the json indices) it serves the archive through
+kurosiwo_amd/dataset.py (native GeoTIFF reader; GRD + "normalize": the batch-level TileBatchLoader with the GPU-side preprocess);
+without it, synthetic tiles with the exact collated-batch layout (kurosiwo_amd/synthetic.py; there is no archive in the build
+image)."""
 import torch
 
 from .synthetic import make_batch
@@ -39,9 +40,65 @@ def prepare_loaders(configs):
         print("No such track! We currently support only RandomEvents")
         raise SystemExit(2)
     bs, workers = configs["batch_size"], configs.get("num_workers", 0)
+    archive = archive_kind(configs)
+    if archive is not None:
+        return _archive_loaders(configs, archive, bs, workers)
     ds = {m: SyntheticCDDataset(m, configs) for m in ("train", "val", "test")}
     mk = lambda m, shuffle, drop: torch.utils.data.DataLoader(ds[m], batch_size=bs, shuffle=shuffle, num_workers=workers,
                                                               pin_memory=True, drop_last=drop)
+    tr, va, te = mk("train", True, True), mk("val", False, False), mk("test", False, False)
+    print("Samples in Train Set: ", len(ds["train"]))
+    print("Samples in Val Set: ", len(ds["val"]))
+    print("Samples in Test Set: ", len(ds["test"]))
+    return tr, va, te
+
+
+def archive_kind(configs):
+    """"slc" / "grd" when the archive the configs point to is on disk, else None (-> synthetic tiles); KSMI_DATA=synthetic forces
+    None, KSMI_DATA=archive makes a missing archive an error instead of a silent switch"""
+    import os
+    want = os.environ.get("KSMI_DATA", "")
+    if want == "synthetic":
+        return None
+    kind = None
+    if configs.get("slc"):
+        if configs.get("slc_root_path") and os.path.isdir(configs["slc_root_path"]) and os.path.isfile(str(configs.get("train_json"))):
+            kind = "slc"
+    elif configs.get("root_path") and os.path.isdir(os.path.join(configs["root_path"], "data")) and os.path.isfile(str(configs.get("train_pickle"))):
+        kind = "grd"
+    if kind is None and want == "archive":
+        raise FileNotFoundError("KSMI_DATA=archive but the archive / grid index of the configs is not on disk")
+    return kind
+
+
+def _loader_threads(configs, world):
+    """decode threads of a rank's TileBatchLoader: configs["loader_threads"], else 32 (measured on the 256-core MI355X host,
+    profiles/r03_loader_probe.jsonl: 4.3 k grid cells/s per process) capped at this rank's share of the host cores"""
+    import os
+    want = configs.get("loader_threads")
+    return int(want) if want else max(1, min(32, (os.cpu_count() or 8) // max(1, world)))
+
+
+def _archive_loaders(configs, kind, bs, workers):
+    """utilities/utilities.py:87-121 on the archive"""
+    from . import dataset as DS
+    from . import distributed as D
+    print("=" * 20)
+    print("Initializing ", configs["track"])
+    print("=" * 20)
+    cls = DS.SLCDataset if kind == "slc" else DS.Dataset
+    ds = {m: cls(mode=m, configs=configs) for m in ("train", "val", "test")}
+    batch_level = (kind == "grd" and configs.get("scale_input") == "normalize" and configs.get("clamp_input") is not None
+                   and not configs.get("uint8") and not configs.get("slope") and not configs.get("oversampling")
+                   and configs.get("gpu_input_pipeline", True) and str(configs.get("device", "cuda")).startswith("cuda")
+                   and torch.cuda.is_available())
+    if batch_level:
+        mk = lambda m, shuffle, drop: DS.TileBatchLoader(ds[m], bs, shuffle=shuffle, drop_last=drop, device=configs.get("device", "cuda"),
+                                                         threads=_loader_threads(configs, D.world_size()), rank=D.get_rank(), world=D.world_size(),
+                                                         seed=configs.get("seed", 999) if shuffle else None)
+    else:
+        mk = lambda m, shuffle, drop: torch.utils.data.DataLoader(ds[m], batch_size=bs, shuffle=shuffle, num_workers=workers,
+                                                                  pin_memory=True, drop_last=drop)
     tr, va, te = mk("train", True, True), mk("val", False, False), mk("test", False, False)
     print("Samples in Train Set: ", len(ds["train"]))
     print("Samples in Val Set: ", len(ds["val"]))

@@ -64,7 +64,7 @@ def shard_batch(batch, rank=None, world=None, even=True):
     world size; even=False (evaluation: the last batch is ragged): rank r takes [n*r//W, n*(r+1)//W), possibly empty."""
     rank = get_rank() if rank is None else rank
     world = world_size() if world is None else world
-    if world == 1:
+    if world == 1 or type(batch).__name__ == "ShardedBatch":        # (dataset.TileBatchLoader reads only this rank's slice)
         return batch
 
     nb = next((t.shape[0] for t in batch if torch.is_tensor(t) and t.dim() > 0), None)     # samples in the global batch

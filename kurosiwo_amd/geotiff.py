@@ -72,6 +72,23 @@ def read_batch(paths, H, W, out=None, threads=8):
     return out
 
 
+def fill_nodata(tiles, threads=1):
+    """In place: every NaN of each [H, W] tile of `tiles` ([..., H, W] contiguous float32, numpy or CPU torch) takes the value of the
+    nearest valid pixel (rioxarray interpolate_na(method="nearest"), dataset/Dataset.py:733-735)."""
+    H, W = tiles.shape[-2:]
+    if hasattr(tiles, "data_ptr"):
+        import torch
+        if tiles.dtype != torch.float32 or not tiles.is_contiguous() or tiles.device.type != "cpu":
+            raise ValueError("fill_nodata: contiguous float32 CPU tensor")
+        ptr, n = tiles.data_ptr(), tiles.numel() // (H * W)
+    else:
+        if tiles.dtype != np.float32 or not tiles.flags["C_CONTIGUOUS"]:
+            raise ValueError("fill_nodata: C-contiguous float32 array")
+        ptr, n = tiles.ctypes.data, tiles.size // (H * W)
+    _lib.check(_lib.load().ksmi_tiles_fill_nodata(ptr, n, H, W, int(threads)), "tiles_fill_nodata")
+    return tiles
+
+
 # ------------------------------------------------------------------------------------------------ writer (fixtures, synthetic archives)
 def _lzw_encode(data):
     """TIFF 6.0 §13 LZW: MSB-first, 9..12 bits, early change"""

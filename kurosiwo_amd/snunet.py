@@ -103,7 +103,9 @@ class SNUNet_ECAM(nn.Module):
             raise ValueError(f"set_input_pipeline: {self.in_channels} input channels, got {len(mean)} means, {len(std)} stds, {len(clamp)} clamps")
         if any(v == 0.0 for v in std):
             raise ValueError("set_input_pipeline: a zero standard deviation")
-        self._raw_norm = torch.tensor([mean, std, clamp], dtype=torch.float32)
+        new = torch.tensor([mean, std, clamp], dtype=torch.float32)
+        if self._raw_norm is None or not torch.equal(self._raw_norm.cpu(), new):       # (same values: the plans built on them stay valid)
+            self._raw_norm = new
         return self
 
     def _raw_ptrs(self, dev):

@@ -155,12 +155,19 @@ class _PlanTrainStep:
 class CDTrainStep(_PlanTrainStep):
     """change_detection_trainer.py:135-180 on SNUNet_ECAM: step(xA, xB, labels)."""
 
-    def __init__(self, model, B, H, W, loss_function="ce+dice", class_weights=(1.0, 1.0, 1.0), **kw):
-        super().__init__(model, model.plan(B, H, W, True, True), B, H, W, loss_function, class_weights, **kw)
+    def __init__(self, model, B, H, W, loss_function="ce+dice", class_weights=(1.0, 1.0, 1.0), tail=0, **kw):
+        """tail > 0 (SNUNet_ECAM only): step(xA, xB, dem, labels) with `tail` channels shared by both dates read straight from their own
+        buffer by the first convolution (snunet.SNUNet_ECAM.forward's `dem`)"""
+        plan = model.plan(B, H, W, True, True, tail) if tail else model.plan(B, H, W, True, True)
+        super().__init__(model, plan, B, H, W, loss_function, class_weights, **kw)
 
-    def _set_inputs(self, xA, xB):
+    def _set_inputs(self, xA, xB, tail=None):
         self.plan.xA.copy_(xA, non_blocking=True)
         self.plan.xB.copy_(xB, non_blocking=True)
+        if (tail is None) != (getattr(self.plan, "xtail", None) is None):
+            raise _lib.KsmiError("CDTrainStep: built with / without tail channels, called the other way")
+        if tail is not None:
+            self.plan.xtail.copy_(tail, non_blocking=True)
 
 
 class SegTrainStep(_PlanTrainStep):

@@ -54,10 +54,43 @@ def _print_metrics(prefix, m, loss):
                        f"IoU {100 * float(m['iou'][c]):.2f}" for c in range(3)))
 
 
+def fuse_input_pipeline(model, loaders, configs):
+    """with archive tiles coming from dataset.TileBatchLoader and a model that normalises inside its first
+    convolution (SNUNet_ECAM.set_input_pipeline), the loaders hand out RAW tiles and clamp / nan_to_num / Normalize / the DEM concat
+    (dataset/Dataset.py:164-168,193-198; the torch.cat of :117-133 here) never exist as separate passes.  Returns True when on;
+    configs["fuse_input_pipeline"] = false or KSMI_FUSE_INPUT=0 keeps the loaders normalising (ksmi_sar_preprocess)."""
+    import os
+    from ..dataset import TileBatchLoader
+    if not (hasattr(model, "set_input_pipeline") and all(isinstance(ld, TileBatchLoader) for ld in loaders)
+            and configs.get("fuse_input_pipeline", True) and os.environ.get("KSMI_FUSE_INPUT", "1") != "0"):
+        return False
+    ndem = 1 if configs["dem"] else 0        # the DEM arrives standardised (its gap filling is host work): identity for that channel
+    model.set_input_pipeline(list(configs["data_mean"]) + [0.0] * ndem, list(configs["data_std"]) + [1.0] * ndem,
+                             [configs["clamp_input"]] * len(configs["data_mean"]) + [-1.0] * ndem)
+    for ld in loaders:
+        ld.raw = True
+    return True
+
+
+def _eval_fusion(model, loader, configs):
+    """evaluation may run on a freshly loaded model (main.py: best checkpoint -> test): settle model and loader on the same side"""
+    fused = fuse_input_pipeline(model, (loader,), configs)
+    if not fused and hasattr(loader, "raw"):
+        loader.raw = False
+    return fused
+
+
+def _fused_inputs(batch, configs):
+    """cd_inputs without the concat: (xA, xB, dem or None), mask"""
+    (xA, xB), mask = cd_inputs(batch, configs["inputs"], False)
+    return (xA, xB, batch[10] if configs["dem"] else None), mask
+
+
 def train_change_detection(model, train_loader, val_loader, test_loader, configs, model_configs):
     assert len(configs["inputs"]) == 2, f'Model {model_configs["method"]} requires exactly 2 input images.'
     dev = torch.device(configs["device"])
     model.to(dev)
+    fused = fuse_input_pipeline(model, (train_loader, val_loader, test_loader), configs)
     D.broadcast_model_(model)                       # identical weights / BatchNorm statistics on every rank (rank 0's)
     main = D.is_main()
     optimizer = _make_optimizer(model, configs, model_configs)
@@ -74,12 +107,17 @@ def train_change_detection(model, train_loader, val_loader, test_loader, configs
         nb = 0
         for index, batch in enumerate(train_loader):
             batch = D.shard_batch(batch)            # this rank's contiguous slice of the global batch (§8(e))
-            (xA, xB), mask = cd_inputs(batch, configs["inputs"], bool(configs["dem"]))
+            if fused:
+                (xA, xB, xdem), mask = _fused_inputs(batch, configs)
+            else:
+                ((xA, xB), mask), xdem = cd_inputs(batch, configs["inputs"], bool(configs["dem"])), None
             if step is None or step.B != xA.shape[0]:
                 step = CDTrainStep(model, xA.shape[0], xA.shape[2], xA.shape[3], configs["loss_function"],
                                    configs.get("class_weights", [1.0, 1.0, 1.0]), optimizer=optimizer, graph=configs.get("hip_graph", False),
-                                   overlap_wgrad=configs.get("overlap_wgrad", True), grad_dtype=configs.get("dp_grad_dtype"), overlap_lanes=configs.get("overlap_lanes", True))
-            step.step(xA.to(dev, non_blocking=True), xB.to(dev, non_blocking=True), mask.to(dev, non_blocking=True))
+                                   overlap_wgrad=configs.get("overlap_wgrad", True), grad_dtype=configs.get("dp_grad_dtype"), overlap_lanes=configs.get("overlap_lanes", True),
+                                   **({"tail": xdem.shape[1]} if xdem is not None else {}))
+            ins = (xA, xB) + ((xdem,) if xdem is not None else ())
+            step.step(*[t.to(dev, non_blocking=True) for t in ins], mask.to(dev, non_blocking=True))
             if configs["method"] == "changeformer" and model_configs.get("multi_scale_infer"):
                 metrics.update(multi_scale_prediction(step.plan.outputs), step.labels)
             else:
@@ -127,17 +165,21 @@ def eval_change_detection(model, loader, settype, configs=None, model_configs=No
     criterion = create_loss(configs, mode="val")
     model.to(dev)
     model.eval()
+    fused = _eval_fusion(model, loader, configs)
     total_loss = torch.zeros((), dtype=torch.float32, device=dev)
     nsamples = 0
     with torch.no_grad():
         for batch in loader:
             batch = D.shard_batch(batch, even=False)
-            (xA, xB), mask = cd_inputs(batch, configs["inputs"], bool(configs["dem"]))
+            if fused:
+                (xA, xB, xdem), mask = _fused_inputs(batch, configs)
+            else:
+                ((xA, xB), mask), xdem = cd_inputs(batch, configs["inputs"], bool(configs["dem"])), None
             if xA.shape[0] == 0:
                 continue
             xA, xB, mask = xA.to(dev), xB.to(dev), mask.to(dev)
             clz, activ = batch[-2], batch[-1]
-            output = model(xA, xB)
+            output = model(xA, xB) if xdem is None else model(xA, xB, xdem.to(dev))
             if configs["method"] == "changeformer":
                 output = output[-1]
             total_loss += criterion(output, mask) * xA.size(0)
