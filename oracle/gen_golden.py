@@ -749,6 +749,52 @@ def gen_bitcd():
     np.savez_compressed(os.path.join(OUT, "bitcd.npz"), **out)
 
 
+def gen_bitcd_transformer():
+    """The three BASE_Transformer variants of the REFERENCE define_G (models/bit_cd.py:690-700, 802-934): seeded weights, eval output,
+    one train-mode step (loss, gradient statistics + the full gradients of the token-path parameters, BatchNorm running statistics)."""
+    from models.bit_cd import define_G
+    c, B, S = 2, 2, 64
+    for net_G in ("base_transformer_pos_s4", "base_transformer_pos_s4_dd8", "base_transformer_pos_s4_dd8_dedim8"):
+        out = {}
+        model = define_G({"net_G": net_G, "init_type": "normal", "init_gain": 0.02}, c)
+        seeded_fill_(model.state_dict())
+        sd = model.state_dict()
+        out["state_dict_keys"] = np.array(list(sd.keys()))
+        out["state_dict_shapes"] = np.array([",".join(str(d) for d in v.shape) for v in sd.values()])
+        x1 = sar_like("bitcd.eval.x1", (1, c, S, S))
+        x2 = sar_like("bitcd.eval.x2", (1, c, S, S))
+        model.eval()
+        with torch.no_grad():
+            out["eval.out"] = model(x1, x2).numpy().copy()
+            out["eval.tokens"] = model.tokens.numpy().copy()                  # the encoder's output (BASE_Transformer keeps it, :919)
+        model.train()
+        x1 = sar_like("bitcd.train.x1", (B, c, S, S))
+        x2 = sar_like("bitcd.train.x2", (B, c, S, S))
+        lbl = seeded_labels("bitcd.train.lbl", (B, S, S))
+        crit = BCEandDiceLoss(weights=CLASS_WEIGHTS, ignore_index=3, use_softmax=True)
+        o = model(x1, x2)
+        loss = crit(o, lbl)
+        loss.backward()
+        out["train.out"] = o.detach().numpy().copy()
+        out["train.loss"] = np.array(float(loss.detach()))
+        for k, p in model.named_parameters():
+            if p.grad is None:
+                out[f"gstat.{k}"] = np.zeros(3)
+                continue
+            g = p.grad.detach().double()
+            out[f"gstat.{k}"] = np.array([float(g.norm()), float(g.sum()), float(g.abs().max())])
+            if k.startswith(("pos_embedding", "conv_a", "transformer.", "transformer_decoder.layers.0.", "conv_pred")) or k in (
+                    "resnet.conv1.weight", "classifier.3.bias", "resnet.layer3.0.bn2.bias"):
+                out[f"grad.{k}"] = p.grad.detach().numpy().copy()
+        sd = model.state_dict()
+        for k in ("resnet.bn1", "resnet.layer3.1.bn2", "resnet.layer4.1.bn2", "classifier.1"):
+            out[f"bn.{k}.running_mean"] = sd[f"{k}.running_mean"].numpy().copy()
+            out[f"bn.{k}.running_var"] = sd[f"{k}.running_var"].numpy().copy()
+            out[f"bn.{k}.num_batches_tracked"] = sd[f"{k}.num_batches_tracked"].numpy().copy()
+        print(net_G, "train loss", float(loss.detach()), "keys", len(sd))
+        np.savez_compressed(os.path.join(OUT, f"bitcd_{net_G}.npz"), **out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -781,5 +827,7 @@ if __name__ == "__main__":
         gen_fcsiam()
     if not only or "bitcd" in only:
         gen_bitcd()
+    if not only or "bitcd_transformer" in only:
+        gen_bitcd_transformer()
     if not only or "mae" in only:
         gen_mae()
