@@ -484,6 +484,39 @@ int ksmi_gemm_nt(const void* x, int x_rs, const void* w, int w_rs, const float* 
 /* dx[rows][K] (+)= dy[rows][N] w */
 int ksmi_gemm_nn(const void* dy, int dy_rs, const void* w, int w_rs, void* dx, int dx_rs, int rows, int K, int N, int accumulate, void* stream);
 
+/* ---------------------------------------------------------------------------------
+ * BIT-CD BASE_Transformer, the token path (models/bit_cd.py:802-934).  Pixels are [images][N][32] in `dtype` with
+ * images = dates * B in date-major order; everything on the token side (2 * token_len tokens per image pair) is fp32.
+ * ------------------------------------------------------------------------------- */
+/* Strided batched product, fp32: c[b1][b2][m][n] = alpha * sum_k a[b1][b2][m][k] * b[b1][b2][k][n] + bias[n] (+ c if accumulate).
+ * a_strides = element strides of a over {b1, b2, m, k}, b_strides over {b1, b2, k, n}, c_strides over {b1, b2, m, n} (a stride of
+ * 0 broadcasts; transposes are strides).  The token-side Linear layers (nn.Linear :469-472, to_qkv :534, to_q/k/v :484-486), the
+ * per-head products of Attention (:542,:555) and the folded matrices of ksmi_token_cross_forward are all instances. */
+int ksmi_bmm_f32(const float* a, const float* b, const float* bias, float* c, int nb1, int nb2, int M, int N, int K,
+                 const int64_t* a_strides, const int64_t* b_strides, const int64_t* c_strides, float alpha, int accumulate, void* stream);
+/* y = softmax(scale * x) over rows of n <= 64 values (dots.softmax(dim=-1), :552); dx = scale * y * (dy - sum(y * dy)) */
+int ksmi_softmax_rows_f32(const float* x, float* y, int64_t rows, int n, float scale, void* stream);
+int ksmi_softmax_rows_backward_f32(const float* y, const float* dy, float* dx, int64_t rows, int n, float scale, void* stream);
+/* _forward_semantic_tokens (:857-865) of both dates + the position table (:880-881): tokens[b][date*L + l][c] = pos[date*L + l][c] +
+ * sum_n softmax_n(x[date*B+b][n] . wa[l]) x[date*B+b][n][c]; wa = conv_a.weight [L][32]; stats[images][L][2] = {max, sum of exp}
+ * for the backward, which adds the gradient into dx (accumulate) and writes dwa_partial[images][L*32] (sum the rows for conv_a). */
+int ksmi_semantic_tokens_forward(const void* x, const float* wa, const float* pos, float* tokens, float* stats, int B, int dates, int N,
+                                 int C, int L, int dtype, void* stream);
+int ksmi_semantic_tokens_backward(const void* x, const float* wa, const float* stats, const float* dtokens, void* dx, float* dwa_partial,
+                                  int B, int dates, int N, int C, int L, int accumulate, int dtype, void* stream);
+/* One TransformerDecoder attention sub-layer on the pixels (Residual2(PreNorm2(Cross_Attention)), :436-459, :476-524):
+ *   y = x + to_out(softmax(scale * to_q(LN(x)) . to_k(LN(m))) to_v(LN(m)))
+ * with the token side folded into A[b][date][j][hd][c] = sum_d to_q.weight[hd*D+d][c] * k[b][date*L+j][hd*D+d] and
+ * Bv[b][date][j][hd][c] = sum_d to_out.weight[c][hd*D+d] * v[b][date*L+j][hd*D+d] (32 floats per (token, head): the head dimension D
+ * does not exist on the pixel side).  The backward updates g (gradient of the residual stream) in place and writes dA, dBv ("="),
+ * dgamma / dbeta (LayerNorm over the pixels) and dbo (to_out bias) ("=" or "+="); workspace = ksmi_token_cross_bwd_workspace bytes. */
+int ksmi_token_cross_forward(const void* x, const float* gamma, const float* beta, const float* A, const float* Bv, const float* bo, void* y,
+                             int B, int dates, int N, int C, int heads, int L, float scale, int dtype, void* stream);
+size_t ksmi_token_cross_bwd_workspace(int B, int dates, int N);
+int ksmi_token_cross_backward(const void* x, const float* gamma, const float* beta, const float* A, const float* Bv, void* g, float* dA,
+                              float* dBv, float* dgamma, float* dbeta, float* dbo, int accumulate_ln, int accumulate_bo, float* workspace,
+                              int B, int dates, int N, int C, int heads, int L, float scale, int dtype, void* stream);
+
 /* GPU-side input pipeline: the Dataset's per-tile clamp -> nan_to_num -> Normalize (dataset/Dataset.py:164-168,
  * 193-198) on raw backscatter tiles already in HBM; x, y NCHW fp32 (y may alias x) */
 int ksmi_sar_preprocess(const float* x, const float* mean, const float* stdv, float* y, int B, int C, int64_t HW, float clamp_input, void* stream);

@@ -150,6 +150,14 @@ SIGNATURES = {
     "ksmi_relu_backward": (_i, [_vp, _vp, _vp, _i64, _i, _vp]),
     "ksmi_relu_forward": (_i, [_vp, _vp, _i64, _i, _vp]),
     "ksmi_sar_preprocess": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i64, C.c_float, _vp]),
+    "ksmi_bmm_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_float, _i, _vp]),
+    "ksmi_softmax_rows_f32": (_i, [_vp, _vp, _i64, _i, C.c_float, _vp]),
+    "ksmi_softmax_rows_backward_f32": (_i, [_vp, _vp, _vp, _i64, _i, C.c_float, _vp]),
+    "ksmi_semantic_tokens_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "ksmi_semantic_tokens_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "ksmi_token_cross_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, C.c_float, _i, _vp]),
+    "ksmi_token_cross_bwd_workspace": (_sz, [_i, _i, _i]),
+    "ksmi_token_cross_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, C.c_float, _i, _vp]),
     "ksmi_tiff_info_read": (_i, [C.c_char_p, C.POINTER(TiffInfo)]),
     "ksmi_tiff_read_f32": (_i, [C.c_char_p, _vp, _i64, C.POINTER(TiffInfo)]),
     "ksmi_tiff_read_native": (_i, [C.c_char_p, _vp, _i64, C.POINTER(TiffInfo)]),
