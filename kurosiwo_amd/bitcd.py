@@ -2,8 +2,9 @@
 `define_G` builds `ResNet(input_nc, output_nc=3, output_sigmoid=False)` (/root/reference/models/bit_cd.py:686-688, 715-797): a siamese
 ResNet-18 whose layer3 / layer4 keep stride 1 (`replace_stride_with_dilation=[False, True, True]`; the BasicBlock of that file resets
 the dilation to 1, :97-98, so every 3x3 convolution is dense), nearest x2 upsampling, a 3x3 `conv_pred` to 32 channels per date,
-|f1 - f2|, bilinear x4 upsampling and the two-layer classifier (conv3x3 -> BN -> ReLU -> conv3x3).  The transformer variants
-(`BASE_Transformer`) are not selected by any shipped config and are not built.
+|f1 - f2|, bilinear x4 upsampling and the two-layer classifier (conv3x3 -> BN -> ReLU -> conv3x3).  `BASE_Transformer` (:802-934,
+the other three `net_G` values of define_G): the same backbone cut after layer3, a semantic tokenizer, a token encoder and a
+per-date token decoder in front of the same head (kernels: csrc/bitcd.hip, plan: bitcd_plan.BitCDTransformerPlan).
 
 Drop-in: same constructor, the same state-dict keys in the same order (including the unused `resnet.fc.*` of the torchvision-style
 backbone: they receive no gradient; the fused optimizer still applies its weight decay to them, which the reference's optimizer skips
@@ -102,10 +103,94 @@ class ResNet(ArenaModule):
         return PlanFn.apply(self._anchor, self, plan, x1, x2)
 
 
+def transformer_specs(input_nc, output_nc, token_len, enc_depth, dec_depth, dim_head, decoder_dim_head, with_pos):
+    """parameters in the reference's registration order: the root's own pos_embedding, resnet, classifier, conv_pred, conv_a,
+    transformer, transformer_decoder (bit_cd.py:806-855; Transformer :564-572, TransformerDecoder :581-591)"""
+    p0, b, c = bitcd_specs(input_nc, output_nc)
+    p0["conv_pred.weight"] = (32, 256, 3, 3)              # resnet_stages_num = 4 (:753-754)
+    p = OrderedDict()
+    if with_pos:
+        p["pos_embedding"] = (1, 2 * token_len, 32)
+    p.update(p0)
+    p["conv_a.weight"] = (token_len, 32, 1, 1)
+
+    def ff(f):
+        p[f"{f}.norm.weight"], p[f"{f}.norm.bias"] = (32,), (32,)
+        p[f"{f}.fn.net.0.weight"], p[f"{f}.fn.net.0.bias"] = (64, 32), (64,)
+        p[f"{f}.fn.net.3.weight"], p[f"{f}.fn.net.3.bias"] = (32, 64), (32,)
+    for li in range(enc_depth):
+        a = f"transformer.layers.{li}.0.fn"
+        p[f"{a}.norm.weight"], p[f"{a}.norm.bias"] = (32,), (32,)
+        p[f"{a}.fn.to_qkv.weight"] = (3 * 8 * dim_head, 32)
+        p[f"{a}.fn.to_out.0.weight"], p[f"{a}.fn.to_out.0.bias"] = (32, 8 * dim_head), (32,)
+        ff(f"transformer.layers.{li}.1.fn")
+    for li in range(dec_depth):
+        a = f"transformer_decoder.layers.{li}.0.fn"
+        p[f"{a}.norm.weight"], p[f"{a}.norm.bias"] = (32,), (32,)
+        for w in ("to_q", "to_k", "to_v"):
+            p[f"{a}.fn.{w}.weight"] = (8 * decoder_dim_head, 32)
+        p[f"{a}.fn.to_out.0.weight"], p[f"{a}.fn.to_out.0.bias"] = (32, 8 * decoder_dim_head), (32,)
+        ff(f"transformer_decoder.layers.{li}.1.fn")
+    return p, b, c
+
+
+class BASE_Transformer(ResNet):
+    """bit_cd.py:802-934 with the settings define_G uses: tokenizer, token_trans, with_decoder, decoder_softmax, no decoder position
+    table, x2 upsampling.  Anything else raises."""
+
+    def __init__(self, input_nc, output_nc, with_pos, resnet_stages_num=5, token_len=4, token_trans=True, enc_depth=1, dec_depth=1, dim_head=64,
+                 decoder_dim_head=64, tokenizer=True, if_upsample_2x=True, pool_mode="max", pool_size=2, backbone="resnet18", decoder_softmax=True,
+                 with_decoder_pos=None, with_decoder=True, precision="bf16", init_gain=0.02):
+        ArenaModule.__init__(self)
+        if (backbone != "resnet18" or resnet_stages_num != 4 or not tokenizer or not token_trans or not with_decoder or not decoder_softmax
+                or with_decoder_pos is not None or not if_upsample_2x or with_pos not in (None, "learned")):
+            raise NotImplementedError("BIT-CD (HIP): BASE_Transformer as define_G builds it (resnet18, 4 stages, tokenizer, token encoder and decoder)")
+        if token_len != 4 or dim_head < 1 or decoder_dim_head < 1 or enc_depth < 1 or dec_depth < 1:
+            raise _lib.KsmiError("BIT-CD (HIP): token_len 4 (csrc/bitcd.hip), depths >= 1")
+        if output_nc > 8:
+            raise _lib.KsmiError("BIT-CD (HIP): output_nc <= 8")
+        self.input_nc, self.output_nc, self.precision = input_nc, output_nc, precision
+        self.with_pos, self.token_len, self.enc_depth, self.dec_depth = with_pos, token_len, enc_depth, dec_depth
+        self.dim_head, self.decoder_dim_head = dim_head, decoder_dim_head
+        ps, bs, cs = transformer_specs(input_nc, output_nc, token_len, enc_depth, dec_depth, dim_head, decoder_dim_head, with_pos)
+        self._setup_arena(ps, bs, cs)
+        with torch.no_grad():
+            # nn.Parameter(torch.randn(...)) for the position table (:836), nn.LayerNorm defaults (weight 1, bias 0: init_weights only
+            # touches Conv / Linear / BatchNorm2d, :654-683), then init_weights as for the base network
+            for key, shp in self._pspec.items():
+                v = self._p(key).view(shp)
+                if key == "pos_embedding":
+                    v.normal_(0.0, 1.0)
+                elif ".norm." in key:
+                    v.fill_(1.0 if key.endswith("weight") else 0.0)
+                elif key.endswith("bias"):
+                    v.zero_()
+                elif len(shp) == 1:
+                    v.normal_(1.0, init_gain)
+                else:
+                    v.normal_(0.0, init_gain)
+            for key in self._bspec:
+                self._b(key).fill_(1.0 if key.endswith("running_var") else 0.0)
+
+    def plan(self, B, H, W, training, with_backward):
+        self._ensure_arena()
+        key = (B, H, W, self.act_dtype(), bool(training), bool(with_backward))
+        if key not in self._plans:
+            from .bitcd_plan import BitCDTransformerPlan
+            self._plans[key] = BitCDTransformerPlan(self, B, H, W, self.act_dtype(), training, with_backward)
+        return self._plans[key]
+
+
 def define_G(args, in_channels, precision="bf16"):
-    """bit_cd.py:686-707 for the shipped `net_G`"""
-    if args["net_G"] != "base_resnet18":
-        raise _lib.KsmiError(f'BIT-CD (HIP): net_G {args["net_G"]!r} is not built (the shipped config uses base_resnet18)')
+    """bit_cd.py:686-707"""
     if args.get("init_type", "normal") != "normal":
         raise NotImplementedError("BIT-CD (HIP): init_type normal")
-    return ResNet(input_nc=in_channels, output_nc=3, output_sigmoid=False, precision=precision, init_gain=args.get("init_gain", 0.02))
+    gain = args.get("init_gain", 0.02)
+    if args["net_G"] == "base_resnet18":
+        return ResNet(input_nc=in_channels, output_nc=3, output_sigmoid=False, precision=precision, init_gain=gain)
+    variants = {"base_transformer_pos_s4": {}, "base_transformer_pos_s4_dd8": dict(enc_depth=1, dec_depth=8),
+                "base_transformer_pos_s4_dd8_dedim8": dict(enc_depth=1, dec_depth=8, decoder_dim_head=8)}
+    if args["net_G"] in variants:
+        return BASE_Transformer(input_nc=in_channels, output_nc=3, token_len=4, resnet_stages_num=4, with_pos="learned", precision=precision,
+                                init_gain=gain, **variants[args["net_G"]])
+    raise NotImplementedError("Generator model name [%s] is not recognized" % args["net_G"])

@@ -5,6 +5,8 @@ runs once per date through the BasicBlock builder of the U1 row (kurosiwo_amd/un
 consumers' operand loads and input-gradient epilogues); weight gradients of the second pass accumulate, BatchNorm statistics are
 per date.  Head: nearest x2, conv_pred, |f1 - f2|, bilinear x4, conv3x3 -> BN -> ReLU -> conv3x3.
 """
+import ctypes as C
+
 import torch
 
 from .bitcd import LAYERS
@@ -85,41 +87,48 @@ class BitCDPlan(UnetPlan):
         return dbuf
 
     # ---------------------------------------------------------------- the graph
-    def _build_bitcd(self):
-        m, B, H, W, dt, nc = self.m, self.B, self.H, self.W, self.dt, self.nc
-        preds = []
-        for date in range(2):
-            t, h, w = self._stem(date)
-            cin = 64
-            for li, (ch, stride) in enumerate(LAYERS):
-                for bi in range(2):
-                    s_ = stride if bi == 0 else 1
-                    t = self._basic_block(f"resnet.layer{li + 1}.{bi}", t, cin, ch, h, w, s_)
-                    h, w, cin = h // s_, w // s_, ch
-                self.named[f"layer{li + 1}_{date + 1}"] = t
-            # nn.Upsample(scale_factor=2) (nearest) -> conv_pred
-            U = self.buf(B, 2 * h, 2 * w, 512)
-            self.fwd.add("ksmi_upsample2_forward", lambda t=t, U=U, h=h, w=w: (t.data_ptr(), U.data_ptr(), B, h, w, 512, 0, dt),
-                         self._elt_meta("upsample2", 5 * B * h * w * 512))
-            h2, w2 = 2 * h, 2 * w
-            Pd = self.buf(B, h2, w2, 32)
-            self._cv(self.fwd, "conv_pred", [SrcSpec(U, 512)], [(Pd, 32, 0, 0, 32, 0)], "conv_pred.weight", h2, w2, h2, w2, 3, 1, 1, 32, 512,
-                     bias=m._p("conv_pred.bias"))
-            self.named[f"pred_{date + 1}"] = Pd
+    def _backbone(self, date, stages=4, pred=None):
+        """forward_single (bit_cd.py:780-797) of one date: stem, layer1..`stages`, nearest x2, conv_pred -> (prediction map, h, w).
+        `pred`: destination of conv_pred (a view of a buffer both dates share), else a new buffer."""
+        m, B, dt = self.m, self.B, self.dt
+        t, h, w = self._stem(date)
+        cin = 64
+        for li, (ch, stride) in enumerate(LAYERS[:stages]):
+            for bi in range(2):
+                s_ = stride if bi == 0 else 1
+                t = self._basic_block(f"resnet.layer{li + 1}.{bi}", t, cin, ch, h, w, s_)
+                h, w, cin = h // s_, w // s_, ch
+            self.named[f"layer{li + 1}_{date + 1}"] = t
+        # nn.Upsample(scale_factor=2) (nearest) -> conv_pred
+        U = self.buf(B, 2 * h, 2 * w, cin)
+        self.fwd.add("ksmi_upsample2_forward", lambda t=t, U=U, h=h, w=w: (t.data_ptr(), U.data_ptr(), B, h, w, cin, 0, dt),
+                     self._elt_meta("upsample2", 5 * B * h * w * cin))
+        h2, w2 = 2 * h, 2 * w
+        Pd = self.buf(B, h2, w2, 32) if pred is None else pred
+        self._cv(self.fwd, "conv_pred", [SrcSpec(U, cin)], [(Pd, 32, 0, 0, 32, 0)], "conv_pred.weight", h2, w2, h2, w2, 3, 1, 1, 32, cin,
+                 bias=m._p("conv_pred.bias"))
+        self.named[f"pred_{date + 1}"] = Pd
 
-            def bwd(t=t, U=U, Pd=Pd, h=h, w=w, h2=h2, w2=w2):
-                dPd, dU = self.gbuf(Pd), self.buf(B, h2, w2, 512)
-                self._wg([SrcSpec(U, 512)], dPd, 32, "conv_pred.weight", h2, w2, h2, w2, 3, 1, 1, 512)
-                self._conv3(self.bwd, "conv_pred", [SrcSpec(dPd, 32)], [(dU, 512, 0, 0, 512, 0)], "conv_pred.weight", None, B, h2, w2, 512, 32, dgrad=True)
-                self._bias_grad(dPd, B * h2 * w2, 32, "conv_pred.bias")
-                dt_ = self.gbuf(t)
-                if self.gacc(t):
-                    raise RuntimeError("unexpected second writer of a backbone output gradient")
-                self.bwd.add("ksmi_upsample2_backward", lambda: (dU.data_ptr(), None, dt_.data_ptr(), B, h, w, 512, 0, dt),
-                             self._elt_meta("upsample2_bwd", 5 * B * h * w * 512))
-            self._bwd.append(bwd)
-            preds.append((Pd, h2, w2))
-        (f1, h2, w2), (f2, _, _) = preds
+        def bwd(t=t, U=U, Pd=Pd, h=h, w=w, h2=h2, w2=w2, cin=cin):
+            dPd, dU = self.gbuf(Pd), self.buf(B, h2, w2, cin)
+            self._wg([SrcSpec(U, cin)], dPd, 32, "conv_pred.weight", h2, w2, h2, w2, 3, 1, 1, cin)
+            self._conv3(self.bwd, "conv_pred", [SrcSpec(dPd, 32)], [(dU, cin, 0, 0, cin, 0)], "conv_pred.weight", None, B, h2, w2, cin, 32, dgrad=True)
+            self._bias_grad(dPd, B * h2 * w2, 32, "conv_pred.bias")
+            dt_ = self.gbuf(t)
+            if self.gacc(t):
+                raise RuntimeError("unexpected second writer of a backbone output gradient")
+            self.bwd.add("ksmi_upsample2_backward", lambda: (dU.data_ptr(), None, dt_.data_ptr(), B, h, w, cin, 0, dt),
+                         self._elt_meta("upsample2_bwd", 5 * B * h * w * cin))
+        self._bwd.append(bwd)
+        return Pd, h2, w2
+
+    def _build_bitcd(self):
+        (f1, h2, w2), (f2, _, _) = self._backbone(0), self._backbone(1)
+        self._head(f1, f2, h2, w2, ("resnet.fc.weight", "resnet.fc.bias"))
+
+    def _head(self, f1, f2, h2, w2, unused_keys):
+        """|f1 - f2| -> bilinear x4 -> classifier (bit_cd.py:766-771, 416-424)"""
+        m, B, H, W, dt, nc = self.m, self.B, self.H, self.W, self.dt, self.nc
         D = self._absdiff(f1, f2, 32, h2, w2)
         X = self.buf(B, H, W, 32)
         self.fwd.add("ksmi_bilinear_forward", lambda: (D.data_ptr(), None, X.data_ptr(), B, h2, w2, H, W, 32, dt), self._elt_meta("bilinear", 2 * B * H * W * 32))
@@ -167,7 +176,7 @@ class BitCDPlan(UnetPlan):
             self._wg([SrcSpec(X, 32)], dz, 32, "classifier.0.weight", H, W, H, W, 3, 1, 1, 32)
             dX = self.gbuf(X)
             self._conv3(self.bwd, "classifier.0", [SrcSpec(dz, 32)], [(dX, 32, 0, 0, 32, self.gacc(X))], "classifier.0.weight", None, B, H, W, 32, 32, dgrad=True)
-            for key in ("resnet.fc.weight", "resnet.fc.bias"):       # the unused ImageNet head of the backbone: no gradient
+            for key in unused_keys:       # the unused ImageNet head of the backbone (and what resnet_stages_num cuts off): no gradient
                 self._zero_grad_key(key)
         self._bwd.append(head_bwd)
 
@@ -180,3 +189,241 @@ class BitCDPlan(UnetPlan):
         self.packs.run()
         self.fwd.run()
         return self.logits
+
+
+class BitCDTransformerPlan(BitCDPlan):
+    """`BASE_Transformer` (bit_cd.py:802-934; the three transformer variants of define_G :690-700): ResNet-18 cut after layer3, semantic
+    tokenizer, token encoder, per-date token decoder, then the head of the base network.
+
+    Pixel side ([2B * h * w][32] rows in the plan's dtype, both dates stacked date-major): ksmi_semantic_tokens_*, ksmi_token_cross_*
+    (csrc/bitcd.hip) and the LayerNorm / Linear / GELU launches of the token rows of the FloodViT path for the decoder's feed-forward.
+    Token side (2 * token_len tokens per image pair, fp32): LayerNorm + strided batched products (ksmi_bmm_f32) + row softmax."""
+
+    F32 = 0        # KSMI_F32
+
+    def _build_bitcd(self):
+        m, B = self.m, self.B
+        h2, w2 = self.H // 4, self.W // 4                    # stem /4, layer2 /2, layer3 stride 1, nearest x2
+        PP = self.buf(2 * B, h2, w2, 32)
+        P1, P2 = PP[:B], PP[B:]
+        self.keep += [P1, P2]
+        (f1, _, _), (f2, _, _) = self._backbone(0, 3, P1), self._backbone(1, 3, P2)
+        N = h2 * w2
+        Y = self._tokens(PP, N)
+        Y1, Y2 = Y[:B], Y[B:]
+        gY = self.buf(2 * B, h2, w2, 32) if self.with_backward else None      # ONE gradient buffer: d|y1 - y2| lands here, every decoder
+        if self.with_backward:                                               # layer updates it in place, the tokenizer adds to it,
+            self._gbuf[id(Y1)], self._gbuf[id(Y2)] = gY[:B], gY[B:]          # conv_pred's backward reads it per date
+            self._gbuf[id(P1)], self._gbuf[id(P2)] = gY[:B], gY[B:]
+            self._gx = gY
+            self.keep += [Y1, Y2]
+        self.named["dec_1"], self.named["dec_2"] = Y1, Y2
+        unused = [k for k in m._pspec if k.startswith(("resnet.layer4.", "resnet.fc."))]
+        self._head(Y1, Y2, h2, w2, unused)
+
+    # ---------------------------------------------------------------- small fp32 helpers (token side)
+    def _st(self, *v):
+        a = (C.c_int64 * 4)(*v)
+        self.keep.append(a)
+        return a
+
+    def _bmm(self, ll, a, b, c, nb1, nb2, M, N, K, sa, sb, sc, bias=None, alpha=1.0, acc=0, tag="bmm"):
+        """a, b, c: data pointers (ints); strides as in ksmi_bmm_f32"""
+        sa, sb, sc = self._st(*sa), self._st(*sb), self._st(*sc)
+        ll.add("ksmi_bmm_f32", lambda: (a, b, bias, c, nb1, nb2, M, N, K, sa, sb, sc, alpha, acc),
+               {"kind": "bmm_f32", "bytes": 4 * nb1 * nb2 * (M * K + K * N + M * N), "flops": 2 * nb1 * nb2 * M * N * K, "tag": tag})
+
+    def _lin32(self, name, x, rows, Cin, wkey, bkey, out, N):
+        """out[rows][N] = x[rows][Cin] W^T + b (fp32 token rows)"""
+        bp = self.m._p(bkey).data_ptr() if bkey else None
+        self._bmm(self.fwd, x.data_ptr(), self.m._p(wkey).data_ptr(), out.data_ptr(), 1, 1, rows, N, Cin, (0, 0, Cin, 1), (0, 0, 1, Cin), (0, 0, N, 1),
+                  bias=bp, tag=name)
+
+    def _lin32_bwd(self, name, x, rows, Cin, wkey, bkey, dy, N, dx, dx_acc=0):
+        """dx (+)= dy W ; dW (+)= dy^T x ; db (+)= colsum(dy)"""
+        w, gw = self.m._p(wkey).data_ptr(), self.m._g(wkey).data_ptr()
+        if dx is not None:
+            self._bmm(self.bwd, dy.data_ptr(), w, dx.data_ptr(), 1, 1, rows, Cin, N, (0, 0, N, 1), (0, 0, Cin, 1), (0, 0, Cin, 1), acc=dx_acc, tag=f"{name}.dx")
+        self._bmm(self.bwd, dy.data_ptr(), x.data_ptr(), gw, 1, 1, N, Cin, rows, (0, 0, 1, N), (0, 0, Cin, 1), (0, 0, Cin, 1), acc=self._acc_param(wkey),
+                  tag=f"{name}.dW")
+        self._mark(wkey)
+        if bkey:
+            acc = self._acc_param(bkey)
+            gb = self.m._g(bkey).data_ptr()
+            self.bwd.add("ksmi_colsum", lambda: (dy.data_ptr(), rows, N, gb, acc, self.F32), {"kind": "colsum", "bytes": 4 * rows * N, "flops": 0})
+            self._mark(bkey)
+
+    def _ln32(self, x, wkey, bkey, y, rows):
+        st = self.fbuf(2, rows)
+        g, b = self.m._p(wkey).data_ptr(), self.m._p(bkey).data_ptr()
+        self.fwd.add("ksmi_layernorm_forward", lambda: (x.data_ptr(), g, b, y.data_ptr(), st[0].data_ptr(), st[1].data_ptr(), rows, 32, 1e-5, self.F32),
+                     {"kind": "layernorm_fwd", "bytes": 8 * rows * 32, "flops": 0})
+        return st
+
+    def _ln32_bwd(self, dy, x, st, wkey, bkey, dx, accumulate, rows):
+        nblk = self.lib.ksmi_layernorm_bwd_blocks(rows)
+        self.need("lnp", nblk * 2 * 32 * 4)
+        g = self.m._p(wkey).data_ptr()
+        self.bwd.add("ksmi_layernorm_backward", lambda: (dy.data_ptr(), x.data_ptr(), st[0].data_ptr(), st[1].data_ptr(), g, dx.data_ptr(), accumulate,
+                                                         self.scr("lnp"), rows, 32, self.F32), {"kind": "layernorm_bwd", "bytes": 16 * rows * 32, "flops": 0})
+        a1, a2 = self._acc_param(wkey), self._acc_param(bkey)
+        assert a1 == a2
+        gw, gb = self.m._g(wkey).data_ptr(), self.m._g(bkey).data_ptr()
+        self.bwd.add("ksmi_reduce_rows", lambda: (self.scr("lnp"), nblk, 2, 32, 32, None, gw, gb, a1))
+        self._mark(wkey, bkey)
+
+    # ---------------------------------------------------------------- tokenizer -> encoder -> decoder
+    def _tokens(self, PP, N):
+        m, B, dt, F32 = self.m, self.B, self.dt, self.F32
+        L, H = m.token_len, 8
+        R8, Rp = B * 2 * L, 2 * B * N                       # token rows, pixel rows
+        scale = 32 ** -0.5                                  # Attention / Cross_Attention: dim ** -0.5 with dim = 32 (bit_cd.py:481,531)
+        wb = self.with_backward
+        steps = []                                          # backward closures of this stage, forward order
+        P, G = (lambda k: m._p(k).data_ptr()), (lambda k: m._g(k).data_ptr())
+
+        # ---- semantic tokens of both dates + position table (:857-865, :880-881)
+        T0, tstats = self.fbuf(B, 2 * L, 32), self.fbuf(2 * B, L, 2)
+        pos = P("pos_embedding") if m.with_pos else None
+        self.fwd.add("ksmi_semantic_tokens_forward", lambda: (PP.data_ptr(), P("conv_a.weight"), pos, T0.data_ptr(), tstats.data_ptr(), B, 2, N, 32, L, dt),
+                     {"kind": "semantic_tokens", "bytes": 2 * Rp * 32 * self._es(), "flops": 4 * Rp * 32 * L})
+        gT = self.fbuf(B, 2 * L, 32) if wb else None         # gradient of the token residual stream (encoder output ... encoder input)
+
+        def tokenizer_bwd():
+            if m.with_pos:
+                gp = G("pos_embedding")
+                acc = self._acc_param("pos_embedding")
+                self.bwd.add("ksmi_batch_sum", lambda: (gT.data_ptr(), gp, B, 2 * L * 32, acc, F32), {"kind": "batch_sum", "bytes": 4 * R8 * 32, "flops": 0})
+                self._mark("pos_embedding")
+            part = self.fbuf(2 * B, L * 32)
+            gx = self._gx
+            self.bwd.add("ksmi_semantic_tokens_backward", lambda: (PP.data_ptr(), P("conv_a.weight"), tstats.data_ptr(), gT.data_ptr(), gx.data_ptr(),
+                                                                   part.data_ptr(), B, 2, N, 32, L, 1, dt),
+                         {"kind": "semantic_tokens_bwd", "bytes": 4 * Rp * 32 * self._es(), "flops": 10 * Rp * 32 * L})
+            acc = self._acc_param("conv_a.weight")
+            ga = G("conv_a.weight")
+            self.bwd.add("ksmi_reduce_rows", lambda: (part.data_ptr(), 2 * B, 1, L * 32, L * 32, None, None, ga, acc))
+            self._mark("conv_a.weight")
+        steps.append(tokenizer_bwd)
+
+        # ---- token encoder (:564-578, Attention :527-561): fp32, 2L tokens per pair
+        T = T0
+        n, Dh = 2 * L, m.dim_head
+        I = H * Dh
+        for li in range(m.enc_depth):
+            a, f = f"transformer.layers.{li}.0.fn", f"transformer.layers.{li}.1.fn"
+            x_in = T
+            h1, qkv, dots, attn, att = self.fbuf(R8, 32), self.fbuf(R8, 3 * I), self.fbuf(B, H, n, n), self.fbuf(B, H, n, n), self.fbuf(R8, I)
+            tmp, x_mid, h2_, u, g, x_out = self.fbuf(R8, 32), self.fbuf(R8, 32), self.fbuf(R8, 32), self.fbuf(R8, 64), self.fbuf(R8, 64), self.fbuf(R8, 32)
+            st1 = self._ln32(x_in, f"{a}.norm.weight", f"{a}.norm.bias", h1, R8)
+            self._lin32(f"enc{li}.to_qkv", h1, R8, 32, f"{a}.fn.to_qkv.weight", None, qkv, 3 * I)
+            q, k, v = qkv.data_ptr(), qkv.data_ptr() + 4 * I, qkv.data_ptr() + 8 * I
+            rs = 3 * I
+            self._bmm(self.fwd, q, k, dots.data_ptr(), B, H, n, n, Dh, (n * rs, Dh, rs, 1), (n * rs, Dh, 1, rs), (H * n * n, n * n, n, 1), tag=f"enc{li}.qk")
+            self.fwd.add("ksmi_softmax_rows_f32", lambda dots=dots, attn=attn: (dots.data_ptr(), attn.data_ptr(), B * H * n, n, scale))
+            self._bmm(self.fwd, attn.data_ptr(), v, att.data_ptr(), B, H, n, Dh, n, (H * n * n, n * n, n, 1), (n * rs, Dh, rs, 1), (n * I, Dh, I, 1), tag=f"enc{li}.pv")
+            self._lin32(f"enc{li}.to_out", att, R8, I, f"{a}.fn.to_out.0.weight", f"{a}.fn.to_out.0.bias", tmp, 32)
+            self.fwd.add("ksmi_add", lambda tmp=tmp, x_in=x_in, x_mid=x_mid: (tmp.data_ptr(), x_in.data_ptr(), x_mid.data_ptr(), R8 * 32, F32))
+            st2 = self._ln32(x_mid, f"{f}.norm.weight", f"{f}.norm.bias", h2_, R8)
+            self._lin32(f"enc{li}.ff1", h2_, R8, 32, f"{f}.fn.net.0.weight", f"{f}.fn.net.0.bias", u, 64)
+            self.fwd.add("ksmi_gelu_forward", lambda u=u, g=g: (u.data_ptr(), g.data_ptr(), R8 * 64, F32))
+            self._lin32(f"enc{li}.ff2", g, R8, 64, f"{f}.fn.net.3.weight", f"{f}.fn.net.3.bias", tmp, 32)
+            self.fwd.add("ksmi_add", lambda tmp=tmp, x_mid=x_mid, x_out=x_out: (tmp.data_ptr(), x_mid.data_ptr(), x_out.data_ptr(), R8 * 32, F32))
+            T = x_out
+
+            def enc_bwd(li=li, a=a, f=f, x_in=x_in, h1=h1, qkv=qkv, attn=attn, att=att, x_mid=x_mid, h2_=h2_, u=u, g=g, st1=st1, st2=st2):
+                tM, tD, tI, dqkv, dat, ds = self.fbuf(R8, 64), self.fbuf(R8, 32), self.fbuf(R8, I), self.fbuf(R8, 3 * I), self.fbuf(B, H, n, n), self.fbuf(B, H, n, n)
+                q, k, v = qkv.data_ptr(), qkv.data_ptr() + 4 * I, qkv.data_ptr() + 8 * I
+                dq, dk, dv = dqkv.data_ptr(), dqkv.data_ptr() + 4 * I, dqkv.data_ptr() + 8 * I
+                self._lin32_bwd(f"enc{li}.ff2", g, R8, 64, f"{f}.fn.net.3.weight", f"{f}.fn.net.3.bias", gT, 32, tM)
+                self.bwd.add("ksmi_gelu_backward", lambda: (tM.data_ptr(), u.data_ptr(), tM.data_ptr(), R8 * 64, F32))
+                self._lin32_bwd(f"enc{li}.ff1", h2_, R8, 32, f"{f}.fn.net.0.weight", f"{f}.fn.net.0.bias", tM, 64, tD)
+                self._ln32_bwd(tD, x_mid, st2, f"{f}.norm.weight", f"{f}.norm.bias", gT, 1, R8)
+                self._lin32_bwd(f"enc{li}.to_out", att, R8, I, f"{a}.fn.to_out.0.weight", f"{a}.fn.to_out.0.bias", gT, 32, tI)
+                ti = tI.data_ptr()
+                self._bmm(self.bwd, ti, v, dat.data_ptr(), B, H, n, n, Dh, (n * I, Dh, I, 1), (n * rs, Dh, 1, rs), (H * n * n, n * n, n, 1), tag=f"enc{li}.dP")
+                self._bmm(self.bwd, attn.data_ptr(), ti, dv, B, H, n, Dh, n, (H * n * n, n * n, 1, n), (n * I, Dh, I, 1), (n * rs, Dh, rs, 1), tag=f"enc{li}.dV")
+                self.bwd.add("ksmi_softmax_rows_backward_f32", lambda: (attn.data_ptr(), dat.data_ptr(), ds.data_ptr(), B * H * n, n, scale))
+                self._bmm(self.bwd, ds.data_ptr(), k, dq, B, H, n, Dh, n, (H * n * n, n * n, n, 1), (n * rs, Dh, rs, 1), (n * rs, Dh, rs, 1), tag=f"enc{li}.dQ")
+                self._bmm(self.bwd, ds.data_ptr(), q, dk, B, H, n, Dh, n, (H * n * n, n * n, 1, n), (n * rs, Dh, rs, 1), (n * rs, Dh, rs, 1), tag=f"enc{li}.dK")
+                self._lin32_bwd(f"enc{li}.to_qkv", h1, R8, 32, f"{a}.fn.to_qkv.weight", None, dqkv, 3 * I, tD)
+                self._ln32_bwd(tD, x_in, st1, f"{a}.norm.weight", f"{a}.norm.bias", gT, 1, R8)
+            steps.append(enc_bwd)
+        self.named["tokens"] = T
+
+        # ---- token decoder on the pixels of both dates (:581-598; Cross_Attention :476-524 behind PreNorm2 / Residual2)
+        Dd = m.decoder_dim_head
+        Id = H * Dd
+        X = PP.view(Rp, 32)
+        if wb:
+            tD_, tM_ = self.buf(Rp, 32), self.buf(Rp, 64)
+            self.need("cross", self.lib.ksmi_token_cross_bwd_workspace(B, 2, N))
+        mem_steps = []
+        for li in range(m.dec_depth):
+            a, f = f"transformer_decoder.layers.{li}.0.fn", f"transformer_decoder.layers.{li}.1.fn"
+            nk, wq, wk_, wv, wo, bo = f"{a}.norm", f"{a}.fn.to_q.weight", f"{a}.fn.to_k.weight", f"{a}.fn.to_v.weight", f"{a}.fn.to_out.0.weight", f"{a}.fn.to_out.0.bias"
+            # token side: k, v of the normalised tokens, folded with to_q / to_out
+            mn, K_, V_, A_, Bv = self.fbuf(R8, 32), self.fbuf(R8, Id), self.fbuf(R8, Id), self.fbuf(R8, H, 32), self.fbuf(R8, H, 32)
+            stm = self._ln32(T, f"{nk}.weight", f"{nk}.bias", mn, R8)
+            self._lin32(f"dec{li}.to_k", mn, R8, 32, wk_, None, K_, Id)
+            self._lin32(f"dec{li}.to_v", mn, R8, 32, wv, None, V_, Id)
+            self._bmm(self.fwd, K_.data_ptr(), P(wq), A_.data_ptr(), 1, H, R8, 32, Dd, (0, Dd, Id, 1), (0, Dd * 32, 32, 1), (0, 32, H * 32, 1), tag=f"dec{li}.A")
+            self._bmm(self.fwd, V_.data_ptr(), P(wo), Bv.data_ptr(), 1, H, R8, 32, Dd, (0, Dd, Id, 1), (0, Dd, 1, Id), (0, 32, H * 32, 1), tag=f"dec{li}.Bv")
+            # pixel side
+            x_in, x_mid, h2_, u, g, x_out = X, self.buf(Rp, 32), self.buf(Rp, 32), self.buf(Rp, 64), self.buf(Rp, 64), self.buf(Rp, 32)
+            self.fwd.add("ksmi_token_cross_forward", lambda x_in=x_in, x_mid=x_mid, A_=A_, Bv=Bv, nk=nk, bo=bo: (
+                x_in.data_ptr(), P(f"{nk}.weight"), P(f"{nk}.bias"), A_.data_ptr(), Bv.data_ptr(), P(bo), x_mid.data_ptr(), B, 2, N, 32, H, L, scale, dt),
+                {"kind": "token_cross_fwd", "bytes": 2 * Rp * 32 * self._es(), "flops": 4 * Rp * 32 * 32})
+            st2 = self._ln(x_mid, f"{f}.norm.weight", f"{f}.norm.bias", h2_, Rp, 32, eps=1e-5)
+            self._linear(f"dec{li}.ff1", h2_, 32, f"{f}.fn.net.0.weight", f"{f}.fn.net.0.bias", u, 64, Rp)
+            self.fwd.add("ksmi_gelu_forward", lambda u=u, g=g: (u.data_ptr(), g.data_ptr(), Rp * 64, dt), self._elt_meta("gelu", 2 * Rp * 64))
+            self._linear(f"dec{li}.ff2", g, 64, f"{f}.fn.net.3.weight", f"{f}.fn.net.3.bias", x_out, 32, Rp, resid=x_mid)
+            X = x_out
+
+            def dec_bwd(li=li, f=f, nk=nk, wq=wq, wk_=wk_, wv=wv, wo=wo, bo=bo, mn=mn, K_=K_, V_=V_, A_=A_, Bv=Bv, stm=stm, x_in=x_in, x_mid=x_mid,
+                        h2_=h2_, u=u, g=g, st2=st2):
+                gx = self._gx.view(Rp, 32)
+                # feed-forward on the pixels: x_out = x_mid + W2 gelu(W1 LN(x_mid) + b1) + b2
+                self._linear_bwd(f"dec{li}.ff2", g, 64, f"{f}.fn.net.3.weight", f"{f}.fn.net.3.bias", gx, 32, Rp, tM_)
+                self.bwd.add("ksmi_gelu_backward", lambda: (tM_.data_ptr(), u.data_ptr(), tM_.data_ptr(), Rp * 64, dt), self._elt_meta("gelu_bwd", 3 * Rp * 64))
+                self._linear_bwd(f"dec{li}.ff1", h2_, 32, f"{f}.fn.net.0.weight", f"{f}.fn.net.0.bias", tM_, 64, Rp, tD_)
+                self._ln_bwd(tD_, x_mid, st2, f"{f}.norm.weight", f"{f}.norm.bias", gx, 1, Rp, 32)
+                # cross-attention: pixels (gx in place, LayerNorm / to_out bias gradients) and the folded matrices
+                dA, dBv = self.fbuf(R8, H, 32), self.fbuf(R8, H, 32)
+                a_ln, a_bo = self._acc_param(f"{nk}.weight"), self._acc_param(bo)
+                assert self._acc_param(f"{nk}.bias") == a_ln
+                self.bwd.add("ksmi_token_cross_backward", lambda: (
+                    x_in.data_ptr(), P(f"{nk}.weight"), P(f"{nk}.bias"), A_.data_ptr(), Bv.data_ptr(), gx.data_ptr(), dA.data_ptr(), dBv.data_ptr(),
+                    G(f"{nk}.weight"), G(f"{nk}.bias"), G(bo), a_ln, a_bo, self.scr("cross"), B, 2, N, 32, H, L, scale, dt),
+                    {"kind": "token_cross_bwd", "bytes": 3 * Rp * 32 * self._es(), "flops": 12 * Rp * 32 * 32})
+                self._mark(bo)
+                # token side: unfold dA -> (dWq, dK), dBv -> (dWo, dV); to_k / to_v; the LayerNorm of the tokens (same parameters as the pixels')
+                dK, dV, dmn = self.fbuf(R8, Id), self.fbuf(R8, Id), self.fbuf(R8, 32)
+                self._bmm(self.bwd, dA.data_ptr(), P(wq), dK.data_ptr(), 1, H, R8, Dd, 32, (0, 32, H * 32, 1), (0, Dd * 32, 1, 32), (0, Dd, Id, 1), tag=f"dec{li}.dK")
+                self._bmm(self.bwd, K_.data_ptr(), dA.data_ptr(), G(wq), 1, H, Dd, 32, R8, (0, Dd, 1, Id), (0, 32, H * 32, 1), (0, Dd * 32, 32, 1),
+                          acc=self._acc_param(wq), tag=f"dec{li}.dWq")
+                self._mark(wq)
+                self._bmm(self.bwd, dBv.data_ptr(), P(wo), dV.data_ptr(), 1, H, R8, Dd, 32, (0, 32, H * 32, 1), (0, Dd, Id, 1), (0, Dd, Id, 1), tag=f"dec{li}.dV")
+                self._bmm(self.bwd, dBv.data_ptr(), V_.data_ptr(), G(wo), 1, H, 32, Dd, R8, (0, 32, 1, H * 32), (0, Dd, Id, 1), (0, Dd, Id, 1),
+                          acc=self._acc_param(wo), tag=f"dec{li}.dWo")
+                self._mark(wo)
+                self._lin32_bwd(f"dec{li}.to_k", mn, R8, 32, wk_, None, dK, Id, dmn, 0)
+                self._lin32_bwd(f"dec{li}.to_v", mn, R8, 32, wv, None, dV, Id, dmn, 1)
+                self._ln32_bwd(dmn, T, stm, f"{nk}.weight", f"{nk}.bias", gT, self._gT_started(), R8)
+            mem_steps.append(dec_bwd)
+        self._gT_acc = 0
+        # backward order: decoder layers (last first), then encoder (last first), then the tokenizer
+        if wb:
+            def token_stage_bwd():
+                for fn in reversed(mem_steps):
+                    fn()
+                for fn in reversed(steps):
+                    fn()
+            self._bwd.append(token_stage_bwd)
+        return X.view(2 * B, PP.shape[1], PP.shape[2], 32)
+
+    def _gT_started(self):
+        """accumulate flag of the token gradient: the first decoder layer of the backward pass writes it, the others add"""
+        a = self._gT_acc
+        self._gT_acc = 1
+        return a

@@ -100,3 +100,103 @@ def test_main_entry_bit_cd_end_to_end_tiny(tmp_path, monkeypatch):
     assert 0.0 <= miou <= 100.0
     ck = list((tmp_path / "checkpoints" / "bit-cd").glob("*/best_segmentation.pt"))
     assert ck and len(torch.load(ck[0], map_location="cpu")["model_state_dict"]) == 132
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("net_G", ["base_transformer_pos_s4", "base_transformer_pos_s4_dd8", "base_transformer_pos_s4_dd8_dedim8"])
+def test_base_transformer_vs_reference_golden(golden_dir, net_G, precision):
+    """BASE_Transformer (bit_cd.py:802-934), the three variants of define_G: eval output + encoder tokens and one train step against vectors
+    of the REAL reference network (tests/golden/bitcd_<net_G>.npz) and, for intermediates / every gradient, the oracle pinned on them."""
+    from kurosiwo_amd.bitcd import define_G
+    from kurosiwo_amd.loss import BCEandDiceLoss
+    from oracle import bitcd_ref as R
+    from oracle.seeded import seeded_fill_, seeded_labels
+    gold = np.load(os.path.join(golden_dir, f"bitcd_{net_G}.npz"))
+    model = define_G({"net_G": net_G, "init_type": "normal", "init_gain": 0.02}, 2, precision=precision)
+    sd = seeded_fill_(R.new_transformer_state_dict(net_G, 2, 3))
+    assert list(model.state_dict().keys()) == list(gold["state_dict_keys"])
+    assert [",".join(str(d) for d in v.shape) for v in model.state_dict().values()] == list(gold["state_dict_shapes"])
+    model.load_state_dict(sd)
+    model = model.cuda()
+    f32 = precision == "fp32"
+    S = gold["eval.out"].shape[-1]
+    model.eval()
+    with torch.no_grad():
+        out = model(sar_like("bitcd.eval.x1", (1, 2, S, S)).cuda(), sar_like("bitcd.eval.x2", (1, 2, S, S)).cuda())
+    tok = model.plan(1, S, S, False, False).named["tokens"].float().cpu().reshape(1, 8, 32).numpy()
+    tscale = float(np.abs(gold["eval.tokens"]).max())
+    assert np.abs(tok - gold["eval.tokens"]).max() < (2e-4 if f32 else 6e-2) * tscale
+    scale = max(1.0, float(np.abs(gold["eval.out"]).max()))
+    assert np.abs(out.cpu().numpy() - gold["eval.out"]).max() < (1e-3 if f32 else 0.1) * scale
+    B = 2
+    x1, x2 = sar_like("bitcd.train.x1", (B, 2, S, S)), sar_like("bitcd.train.x2", (B, 2, S, S))
+    lbl = seeded_labels("bitcd.train.lbl", (B, S, S))
+    model.train()
+    out = model(x1.cuda(), x2.cuda())
+    plan = model.plan(B, S, S, True, True)
+    inter = {}
+    with torch.no_grad():
+        R.transformer_forward(sd, net_G, x1, x2, True, {}, inter)
+    for name in ("pred_1", "pred_2", "dec_1", "dec_2", "cls"):
+        got = nchw(plan.named[name], B, *inter[name].shape[-2:])
+        err = float((got - inter[name]).abs().max() / (inter[name].abs().max() + 1e-12))
+        assert err < (5e-4 if f32 else 0.15), (name, err)
+    terr = float((plan.named["tokens"].cpu().reshape(B, 8, 32) - inter["tokens"]).abs().max() / inter["tokens"].abs().max())
+    assert terr < (2e-4 if f32 else 6e-2), terr
+    tsc = max(1.0, float(np.abs(gold["train.out"]).max()))
+    assert np.abs(out.detach().cpu().numpy() - gold["train.out"]).max() < (1e-3 if f32 else 0.15) * tsc
+    loss = BCEandDiceLoss(weights=CLASS_WEIGHTS, ignore_index=3, use_softmax=True)(out, lbl.cuda())
+    loss.backward()
+    assert abs(float(loss) - float(gold["train.loss"])) < (2e-4 if f32 else 5e-2)
+    _, _, ref_grads, _ = R.transformer_loss_and_grads(sd, net_G, x1, x2, lbl, CLASS_WEIGHTS)
+    worst, coss = {}, {}
+    for k, p in model.named_parameters():
+        g, r = p.grad.detach().float().cpu(), ref_grads[k]
+        if float(r.abs().max()) == 0.0:
+            # resnet.layer4.*, resnet.fc.*: cut off by resnet_stages_num = 4 (exactly zero); the last decoder layer's output bias: added
+            # to both dates and cancelled by |y1 - y2| (the two halves of the sum cancel to rounding)
+            assert float(g.abs().max()) == 0.0 if k.startswith("resnet.") else float(g.abs().max()) < (1e-7 if f32 else 1e-3), k
+            continue
+        cos = float((g.double() * r.double()).sum() / (g.double().norm() * r.double().norm() + 1e-30))
+        coss[k] = cos
+        if f32:
+            l2 = float((g - r).double().norm() / (r.double().norm() + 1e-30))
+            gn = gold[f"gstat.{k}"][0]
+            if not (l2 < 3e-2 and abs(float(g.double().norm()) - gn) <= 5e-3 * gn + 1e-7):
+                worst[k] = (l2, float(g.double().norm()), gn)
+        elif not cos > 0.5:
+            worst[k] = cos
+    token_keys = [k for k in coss if k.startswith(("pos_embedding", "conv_a", "transformer"))]
+    assert len(token_keys) == len([k for k in ref_grads if k.startswith(("pos_embedding", "conv_a", "transformer"))]) - 1    # (the cancelled bias)
+    print(f"{net_G} {precision}: gradient cosines median {np.median(list(coss.values())):.5f} min {min(coss.values()):.5f}; "
+          f"token-path parameters min {min(coss[k] for k in token_keys):.5f}")
+    if f32:
+        assert min(coss[k] for k in token_keys) > 0.9995
+    else:
+        assert float(np.median(list(coss.values()))) > 0.85
+    assert not worst, f"{precision}: {len(worst)} params: {dict(list(worst.items())[:10])}"
+    msd = model.state_dict()
+    for k in ("resnet.bn1", "resnet.layer3.1.bn2", "resnet.layer4.1.bn2", "classifier.1"):
+        rt = 1e-3 if f32 else 5e-2
+        assert np.abs(msd[f"{k}.running_mean"].cpu().numpy() - gold[f"bn.{k}.running_mean"]).max() < rt * max(1.0, np.abs(gold[f"bn.{k}.running_mean"]).max())
+        assert int(msd[f"{k}.num_batches_tracked"]) == int(gold[f"bn.{k}.num_batches_tracked"])
+
+
+def test_main_entry_bit_cd_transformer_end_to_end_tiny(tmp_path, monkeypatch):
+    """main.py --method bit-cd with net_G = base_transformer_pos_s4_dd8 in the method config: train, checkpoint, reload, test"""
+    import json
+    import shutil
+    import main as entry
+    from kurosiwo_amd.config import load_json5
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    shutil.copytree(os.path.join(root, "configs"), tmp_path / "configs")
+    mc = tmp_path / "configs" / "method" / "bit-cd" / "bit_cd.json"
+    cfg = load_json5(mc)
+    cfg["net_G"] = "base_transformer_pos_s4_dd8"
+    json.dump(cfg, open(mc, "w"))
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv("KSMI_SYNTHETIC_TILES", "8,4,4")
+    miou = entry.main(["--method", "bit-cd", "--inputs", "pre_event_1", "post_event", "--batch_size", "4"])
+    assert 0.0 <= miou <= 100.0
+    ck = list((tmp_path / "checkpoints" / "bit-cd").glob("*/best_segmentation.pt"))
+    assert ck and len(torch.load(ck[0], map_location="cpu")["model_state_dict"]) == 249
