@@ -147,6 +147,7 @@ def main():
     ap.add_argument("--base-channel", type=int, default=32)
     ap.add_argument("--channels", type=int, default=2, help="bands per date: 2 = GRD (VV, VH), 4 = SLC (BASELINE.json configs[3] as written)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--net-g", default="base_resnet18", help="--model bit-cd: net_G of define_G (models/bit_cd.py:686-707)")
     ap.add_argument("--time-all", action="store_true", help="HIP-event time every kernel class (diagnostic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-solo", action="store_true",
@@ -210,9 +211,10 @@ def main():
         if args.model == "bit-cd":
             from kurosiwo_amd.bitcd import define_G
             from kurosiwo_amd.optim import FusedSGD
-            model = define_G({"net_G": "base_resnet18"}, args.channels, precision=args.precision).to(dev).train()
+            model = define_G({"net_G": args.net_g}, args.channels, precision=args.precision).to(dev).train()
             opt = FusedSGD(model.parameters(), lr=1e-5, momentum=0.9, weight_decay=5e-4)       # configs/method/bit-cd/bit_cd.json
-            desc = "BIT-CD (net_G base_resnet18: siamese ResNet-18 + difference head), SGD(0.9, wd 5e-4)"
+            desc = (f"BIT-CD (net_G {args.net_g}: " + ("siamese ResNet-18 + difference head" if args.net_g == "base_resnet18" else
+                    "ResNet-18 to layer3 + semantic tokenizer + token encoder / decoder") + "), SGD(0.9, wd 5e-4)")
         else:
             from kurosiwo_amd.fcsiam import SiamUnet_conc, SiamUnet_diff
             from kurosiwo_amd.optim import FusedAdam
