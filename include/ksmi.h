@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define KSMI_ABI_VERSION 3   /* 2: round 2 (stats_rows, stochastic layers, bias_grad in ksmi_wgrad_desc, ...); 3: round 3 (gate epilogue, ksmi_desc_size) */
+#define KSMI_ABI_VERSION 4   /* 2: round 2 (stats_rows, stochastic layers, bias_grad in ksmi_wgrad_desc, ...); 3: round 3 (gate epilogue, ksmi_desc_size); 4: first conv on raw tiles, tile reader, BIT token path */
 #define KSMI_F32 0
 #define KSMI_BF16 1
 #define KSMI_E_ARG (-1)
@@ -121,6 +121,7 @@ typedef struct ksmi_conv_desc {
   int32_t dir;
   int32_t pad2_;
 } ksmi_conv_desc;
+
 
 /* sizeof of a descriptor struct as the library was compiled (0 conv, 1 wgrad, 2 pack, 3 rowsum, 4 tiff_info): bindings check their mirror */
 size_t ksmi_desc_size(int which);
