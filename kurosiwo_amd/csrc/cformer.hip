@@ -195,7 +195,10 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const T* x, const float*
     for (int t = 0; t < 9; ++t) wr[t][j] = w[(c0 + j) * 9 + (MODE == 0 ? t : 8 - t)];
   }
   const int64_t npix = (int64_t)B * H * W;
-  const int64_t p0 = (int64_t)blockIdx.x * pix_per_block, p1 = min(npix, p0 + pix_per_block);
+  // consecutive pixel slabs share their halo rows: keep them on ONE XCD (workgroups go round-robin over the 8 XCDs, each with its own
+  // L2; gridDim.x is a multiple of 8) -- measured 2.3x the algorithmic fetch without this mapping
+  const int64_t slab = (int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int64_t p0 = slab * pix_per_block, p1 = min(npix, p0 + pix_per_block);
   for (int64_t p = p0 + pl; p < p1; p += 8) {
     const int px = p % W; const int64_t r = p / W;
     const int py = r % H;
@@ -222,23 +225,27 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const T* x, const float*
 }
 
 // weight/bias gradient partials: partial[row][c*9 + t] = sum_p x[p + off_t][c] * dz[p][c] ; partial[row][9C + c] = sum_p dz[p][c]
-// grid (rows, ceil(CV/64)); thread = (pixel lane t>>6, channel vector t&63)
-template <typename T>
+// grid (rows, ceil(CV/CVB)); thread = (pixel lane t / CVB, channel vector t % CVB); CVB = 32 for <= 32 channel vectors (stage 1 of the
+// encoder, the largest map: all 256 threads busy instead of half of them), else 64
+template <typename T, int CVB>
 __global__ void dwconv3x3_wgrad_kernel(const T* x, const T* dz, float* partial, int B, int H, int W, int C) {
   constexpr int VEC = ElemTraits<T>::kVec;
-  __shared__ float red[4][64][VEC + 1];
+  constexpr int PL = 256 / CVB;
+  __shared__ float red[PL][CVB][VEC + 1];
   const int CV = C / VEC;
-  const int cvl = threadIdx.x & 63, cv = blockIdx.y * 64 + cvl, pl = threadIdx.x >> 6;
+  const int cvl = threadIdx.x % CVB, cv = blockIdx.y * CVB + cvl, pl = threadIdx.x / CVB;
   const int64_t npix = (int64_t)B * H * W;
   const int64_t per = (npix + gridDim.x - 1) / gridDim.x;
-  const int64_t p0 = per * blockIdx.x, p1 = min(npix, p0 + per);
+  // (XCD-aware slab order as in dwconv3x3_kernel when the row count allows it; the partial row index stays blockIdx.x)
+  const int64_t slab = (gridDim.x & 7) == 0 ? (int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : (int64_t)blockIdx.x;
+  const int64_t p0 = per * slab, p1 = min(npix, p0 + per);
   float acc[10][VEC];
 #pragma unroll
   for (int t = 0; t < 10; ++t)
 #pragma unroll
     for (int j = 0; j < VEC; ++j) acc[t][j] = 0.f;
   if (cv < CV) {
-    for (int64_t p = p0 + pl; p < p1; p += 4) {
+    for (int64_t p = p0 + pl; p < p1; p += PL) {
       const int px = p % W; const int64_t r = p / W;
       const int py = r % H;
       float d[VEC];
@@ -266,7 +273,9 @@ __global__ void dwconv3x3_wgrad_kernel(const T* x, const T* dz, float* partial, 
     if (pl == 0 && cv < CV) {
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
-        const float s = red[0][cvl][j] + red[1][cvl][j] + red[2][cvl][j] + red[3][cvl][j];
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < PL; ++k) s += red[k][cvl][j];
         const int c = cv * VEC + j;
         if (t < 9) prow[c * 9 + t] = s; else prow[9 * C + c] = s;
       }
@@ -913,8 +922,9 @@ int ksmi_dwconv3x3_gelu_forward(const void* x, const float* w, const float* bias
   const int vec = dtype == KSMI_BF16 ? 8 : 4;
   if (C % vec) return ksmi_fail(KSMI_E_ARG, "dwconv: C must be a multiple of the 16-byte vector");
   hipStream_t st = (hipStream_t)stream;
-  const int ppb = 128;
-  const dim3 grid((unsigned)(((int64_t)B * H * W + ppb - 1) / ppb), (C / vec + 31) / 32);
+  static const int ppb_env = getenv("KSMI_DW_PPB") ? atoi(getenv("KSMI_DW_PPB")) : 0;
+  const int ppb = ppb_env > 0 ? ppb_env : 32;       // measured (KSMI_DW_PPB sweep): 128 -> 110 / 69 us, 32 -> 90 / 49 us (forward / adjoint)
+  const dim3 grid((unsigned)((((int64_t)B * H * W + ppb - 1) / ppb + 7) / 8 * 8), (C / vec + 31) / 32);
   KSMI_DT(dtype,
           hipLaunchKernelGGL((dwconv3x3_kernel<bf16_t, 0>), grid, dim3(256), 0, st, (const bf16_t*)x, w, bias, (bf16_t*)z, (bf16_t*)g, B, H, W, C, ppb),
           hipLaunchKernelGGL((dwconv3x3_kernel<float, 0>), grid, dim3(256), 0, st, (const float*)x, w, bias, (float*)z, (float*)g, B, H, W, C, ppb));
@@ -925,8 +935,9 @@ int ksmi_dwconv3x3_backward_input(const void* dz, const float* w, void* dx, int 
   const int vec = dtype == KSMI_BF16 ? 8 : 4;
   if (C % vec) return ksmi_fail(KSMI_E_ARG, "dwconv: C must be a multiple of the 16-byte vector");
   hipStream_t st = (hipStream_t)stream;
-  const int ppb = 128;
-  const dim3 grid((unsigned)(((int64_t)B * H * W + ppb - 1) / ppb), (C / vec + 31) / 32);
+  static const int ppb_env = getenv("KSMI_DW_PPB") ? atoi(getenv("KSMI_DW_PPB")) : 0;
+  const int ppb = ppb_env > 0 ? ppb_env : 32;       // measured (KSMI_DW_PPB sweep): 128 -> 110 / 69 us, 32 -> 90 / 49 us (forward / adjoint)
+  const dim3 grid((unsigned)((((int64_t)B * H * W + ppb - 1) / ppb + 7) / 8 * 8), (C / vec + 31) / 32);
   KSMI_DT(dtype,
           hipLaunchKernelGGL((dwconv3x3_kernel<bf16_t, 1>), grid, dim3(256), 0, st, (const bf16_t*)dz, w, (const float*)nullptr, (bf16_t*)dx, (bf16_t*)nullptr, B, H, W, C, ppb),
           hipLaunchKernelGGL((dwconv3x3_kernel<float, 1>), grid, dim3(256), 0, st, (const float*)dz, w, (const float*)nullptr, (float*)dx, (float*)nullptr, B, H, W, C, ppb));
@@ -936,11 +947,17 @@ int ksmi_dwconv3x3_backward_input(const void* dz, const float* w, void* dx, int 
 int ksmi_dwconv3x3_wgrad(const void* x, const void* dz, float* partial, int rows, int B, int H, int W, int C, int dtype, void* stream) {
   const int vec = dtype == KSMI_BF16 ? 8 : 4;
   if (C % vec || rows < 1) return ksmi_fail(KSMI_E_ARG, "dwconv_wgrad: bad args");
-  const dim3 grid(rows, (C / vec + 63) / 64);
+  const int cvb = C / vec <= 32 ? 32 : 64;
+  const dim3 grid(rows, (C / vec + cvb - 1) / cvb);
   hipStream_t st = (hipStream_t)stream;
-  KSMI_DT(dtype,
-          hipLaunchKernelGGL(dwconv3x3_wgrad_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dz, partial, B, H, W, C),
-          hipLaunchKernelGGL(dwconv3x3_wgrad_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (const float*)dz, partial, B, H, W, C));
+  if (cvb == 32)
+    KSMI_DT(dtype,
+            hipLaunchKernelGGL((dwconv3x3_wgrad_kernel<bf16_t, 32>), grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dz, partial, B, H, W, C),
+            hipLaunchKernelGGL((dwconv3x3_wgrad_kernel<float, 32>), grid, dim3(256), 0, st, (const float*)x, (const float*)dz, partial, B, H, W, C));
+  else
+    KSMI_DT(dtype,
+            hipLaunchKernelGGL((dwconv3x3_wgrad_kernel<bf16_t, 64>), grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dz, partial, B, H, W, C),
+            hipLaunchKernelGGL((dwconv3x3_wgrad_kernel<float, 64>), grid, dim3(256), 0, st, (const float*)x, (const float*)dz, partial, B, H, W, C));
   return ksmi_check_launch("dwconv3x3_wgrad");
 }
 
