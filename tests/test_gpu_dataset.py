@@ -122,3 +122,32 @@ def test_main_entry_trains_from_the_archive(archive, tmp_path, monkeypatch):
     import time
     time.sleep(1.1)                                                          # (checkpoint folders are stamped to the second)
     assert entry.main(argv) == miou and seen["fused"] == 0
+
+
+def test_segmentation_entry_trains_from_the_archive(archive, tmp_path, monkeypatch):
+    """the segmentation route (main.py --method unet: segmentation_trainer.py:54-171) on the same loaders: [post, dem, pre1, pre2] concat
+    of device tensors coming from the batch loader"""
+    import shutil
+    import main as entry
+    from kurosiwo_amd.config import load_json5
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    shutil.copytree(os.path.join(root, "configs"), tmp_path / "configs")
+    dc = load_json5(tmp_path / "configs" / "train" / "data_config.json")
+    dc.update(train_acts=TRAIN, val_acts=VAL, test_acts=TEST, train_pickle=os.path.join(archive, "pickle", "train.gz"),
+              test_pickle=os.path.join(archive, "pickle", "test.gz"))
+    json.dump(dc, open(tmp_path / "configs" / "train" / "data_config.json", "w"))
+    cc = load_json5(tmp_path / "configs" / "config.json")
+    cc["root_path"] = archive
+    json.dump(cc, open(tmp_path / "configs" / "config.json", "w"))
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv("KSMI_DATA", "archive")
+    import kurosiwo_amd.dataset as DS
+    seen = {"n": 0}
+    orig = DS.TileBatchLoader._load
+
+    def spy(self, idx):
+        seen["n"] += 1
+        return orig(self, idx)
+    monkeypatch.setattr(DS.TileBatchLoader, "_load", spy)
+    miou = entry.main(["--method", "unet", "--batch_size", "4", "--dem"])
+    assert 0.0 <= miou <= 100.0 and seen["n"] >= 4
