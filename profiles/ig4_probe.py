@@ -37,6 +37,12 @@ SHAPES = [  # name, H, cs, N, mode
     ("L0 conv0_1 128->32", 224, [32, 32, 64], 32, ""),
     ("L0 conv0_4 224->32", 224, [32] * 5 + [64], 32, ""),
     ("L0 dx0_0 128->32", 224, [32] * 4, 32, ""),
+    ("X0 one source 224->32", 224, [224], 32, ""),            # over-fetch experiments: the same K as conv0_4 from one / seven tensors
+    ("X0 six x32 192->32", 224, [32] * 6, 32, ""),
+    ("X0 three x64 192->32", 224, [64] * 3, 32, ""),
+    ("X0 one x192 192->32", 224, [192], 32, ""),
+    ("X1 two x32 64->64", 112, [32, 32], 64, ""),
+    ("X1 one x64 64->64", 112, [64], 64, ""),
     ("L1 conv2 64->64 aff", 112, [64], 64, "aff"),
     ("L1 dgrad2 64->64 mask", 112, [64], 64, "mask"),
     ("L1 conv1_1 256->64", 112, [64, 64, 128], 64, ""),
