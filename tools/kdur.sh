@@ -16,5 +16,5 @@ pat = re.compile(sys.argv[2])
 for r in rows:
     if pat.search(r["Name"]):
         name = re.sub(r"\(.*", "", r["Name"].replace("(anonymous namespace)::", "").replace("void ", ""))
-        print(f'{name[:60]:60s} calls {r["Calls"]:>5s} avg_us {float(r["AverageNs"]) / 1e3:8.1f}')
+        print(f'{name[:90]:90s} calls {r["Calls"]:>5s} avg_us {float(r["AverageNs"]) / 1e3:8.1f}')
 PY
