@@ -519,7 +519,8 @@ int ksmi_token_cross_backward(const void* x, const float* gamma, const float* be
                               int B, int dates, int N, int C, int heads, int L, float scale, int dtype, void* stream);
 
 /* GPU-side input pipeline: the Dataset's per-tile clamp -> nan_to_num -> Normalize (dataset/Dataset.py:164-168,
- * 193-198) on raw backscatter tiles already in HBM; x, y NCHW fp32 (y may alias x) */
+ * 193-198) on raw backscatter tiles already in HBM; x, y NCHW fp32 (y may alias x).  clamp_input < 0: Normalize only (the SLC class,
+ * dataset/Dataset.py:1081-1085, neither clamps nor replaces NaNs) */
 int ksmi_sar_preprocess(const float* x, const float* mean, const float* stdv, float* y, int B, int C, int64_t HW, float clamp_input, void* stream);
 
 /* Host half of N4: reader for the archive's GeoTIFF tiles.  The reference decodes each file in a DataLoader worker with
@@ -547,6 +548,8 @@ int ksmi_tiff_read_native(const char* path, void* out, int64_t cap_elems, ksmi_t
 /* n single-band H x W tiles decoded by `threads` host threads into out[n][H][W] fp32 (one pinned staging buffer -> one copy to the
  * GPU): the body of Dataset.__getitem__'s file loop for a whole batch.  A tile of another size or band count is an error. */
 int ksmi_tile_batch_read(const char* const* paths, int n, float* out, int H, int W, int threads);
+/* the same for multi-band tiles (the 4-band SLC products, dataset/Dataset.py:1110-1129): out[n][bands][H][W] */
+int ksmi_tile_batch_read_bands(const char* const* paths, int n, float* out, int bands, int H, int W, int threads);
 /* DEM gaps: every NaN of each of the n H x W tiles takes the value of the nearest valid pixel (Euclidean, pixel grid), in place:
  * rioxarray's interpolate_na(method="nearest") of dataset/Dataset.py:733-735.  Tiles without NaN (or without a valid pixel) are
  * left as they are. */

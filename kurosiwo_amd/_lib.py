@@ -162,6 +162,7 @@ SIGNATURES = {
     "ksmi_tiff_read_f32": (_i, [C.c_char_p, _vp, _i64, C.POINTER(TiffInfo)]),
     "ksmi_tiff_read_native": (_i, [C.c_char_p, _vp, _i64, C.POINTER(TiffInfo)]),
     "ksmi_tile_batch_read": (_i, [C.POINTER(C.c_char_p), _i, _vp, _i, _i, _i]),
+    "ksmi_tile_batch_read_bands": (_i, [C.POINTER(C.c_char_p), _i, _vp, _i, _i, _i, _i]),
     "ksmi_tiles_fill_nodata": (_i, [_vp, _i, _i, _i, _i]),
     "ksmi_cast_bf16": (_i, [_vp, _vp, _i64, _vp]),
     "ksmi_gemm_nt": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),

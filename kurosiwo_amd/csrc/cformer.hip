@@ -641,7 +641,7 @@ __global__ void sar_preprocess_kernel(const float* x, const float* mean, const f
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const int c = (int)((i / HW) % C);
     float v = x[i];
-    v = (v != v) ? clampv : fminf(fmaxf(v, 0.f), clampv);
+    if (clampv >= 0.f) v = (v != v) ? clampv : fminf(fmaxf(v, 0.f), clampv);
     y[i] = (v - mean[c]) / stdv[c];
   }
 }

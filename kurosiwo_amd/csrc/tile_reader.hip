@@ -509,7 +509,11 @@ int ksmi_tiff_read_native(const char* path, void* out, int64_t cap_elems, ksmi_t
 }
 
 int ksmi_tile_batch_read(const char* const* paths, int n, float* out, int H, int W, int threads) {
-  if (n < 0 || (n && (!paths || !out)) || H <= 0 || W <= 0) return ksmi_fail(KSMI_E_ARG, "tile_batch_read: bad argument");
+  return ksmi_tile_batch_read_bands(paths, n, out, 1, H, W, threads);
+}
+
+int ksmi_tile_batch_read_bands(const char* const* paths, int n, float* out, int bands, int H, int W, int threads) {
+  if (n < 0 || (n && (!paths || !out)) || H <= 0 || W <= 0 || bands < 1) return ksmi_fail(KSMI_E_ARG, "tile_batch_read: bad argument");
   if (threads < 1) threads = 1;
   if (threads > n) threads = n > 0 ? n : 1;
   std::atomic<int> next{0}, failed{0};
@@ -519,7 +523,8 @@ int ksmi_tile_batch_read(const char* const* paths, int n, float* out, int H, int
     for (;;) {
       const int i = next.fetch_add(1);
       if (i >= n || failed.load()) return;
-      const std::string e = paths[i] ? decode_file(paths[i], out + (int64_t)i * H * W, nullptr, (int64_t)H * W, nullptr, H, W, 1) : "null path";
+      const std::string e = paths[i] ? decode_file(paths[i], out + (int64_t)i * bands * H * W, nullptr, (int64_t)bands * H * W, nullptr, H, W, bands)
+                                     : "null path";
       if (!e.empty()) {
         while (lock.test_and_set()) {}
         if (!failed.exchange(1)) first_error = e;

@@ -88,7 +88,7 @@ def _archive_loaders(configs, kind, bs, workers):
     print("=" * 20)
     cls = DS.SLCDataset if kind == "slc" else DS.Dataset
     ds = {m: cls(mode=m, configs=configs) for m in ("train", "val", "test")}
-    batch_level = (kind == "grd" and configs.get("scale_input") == "normalize" and configs.get("clamp_input") is not None
+    batch_level = ((kind == "slc" or configs.get("clamp_input") is not None) and configs.get("scale_input") == "normalize"
                    and not configs.get("uint8") and not configs.get("slope") and not configs.get("oversampling")
                    and configs.get("gpu_input_pipeline", True) and str(configs.get("device", "cuda")).startswith("cuda")
                    and torch.cuda.is_available())

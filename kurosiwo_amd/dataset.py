@@ -324,11 +324,13 @@ class SLCDataset(_Records, torch.utils.data.Dataset):
         if nodata is not None and nodata == nodata:
             a = np.where(a == np.float32(nodata), np.float32("nan"), a)
         a = np.stack([fill_nodata_nearest(b) for b in a])
-        if cfg["dem"] and cfg.get("slope"):
+        if not cfg["dem"]:
+            return torch.from_numpy(a)               # (read and dropped, as the reference does for a cell that ships a DEM)
+        if cfg.get("slope"):
             out, mean, std = torch.from_numpy(slope_riserun(a[0], nodata)[None]), cfg["slc_slope_mean"], cfg["slc_slope_std"]
         else:
             out, mean, std = torch.from_numpy(a), cfg["slc_dem_mean"], cfg["slc_dem_std"]
-        if cfg["dem"] and cfg["scale_input"] is not None:
+        if cfg["scale_input"] is not None:
             out = (out - torch.as_tensor(mean, dtype=torch.float32).view(-1, 1, 1)) / torch.as_tensor(std, dtype=torch.float32).view(-1, 1, 1)
         return out
 
@@ -377,6 +379,22 @@ class SLCDataset(_Records, torch.utils.data.Dataset):
         return (flood, mask, sec1, sec2) + tail
 
 
+class _Ragged(Exception):
+    pass
+
+
+def _lib_error():
+    from ._lib import KsmiError
+    return KsmiError
+
+
+def _collate_to(items, dev, sharded):
+    """torch's default collate of per-sample tuples, tensors moved to `dev` (the slow path of a batch the native reader refuses)"""
+    from torch.utils.data import default_collate
+    out = [t.to(dev) if torch.is_tensor(t) and t.dim() > 1 else t for t in default_collate(items)]
+    return ShardedBatch(out) if sharded else tuple(out)
+
+
 class ShardedBatch(tuple):
     """a collated batch that already holds only this rank's samples (distributed.shard_batch passes it through)"""
 
@@ -394,9 +412,10 @@ class TileBatchLoader:
     def __init__(self, dataset, batch_size, shuffle=False, drop_last=False, device="cuda", threads=8, raw=False, rank=0, world=1, seed=None,
                  prefetch=2):
         cfg = dataset.configs
-        if not isinstance(dataset, Dataset) or cfg["scale_input"] != "normalize" or cfg.get("uint8") or cfg.get("slope"):
-            raise ValueError("TileBatchLoader: GRD Dataset with scale_input 'normalize' (no uint8, no slope)")
-        if cfg["clamp_input"] is None:
+        self.slc = isinstance(dataset, SLCDataset)
+        if not isinstance(dataset, (Dataset, SLCDataset)) or cfg["scale_input"] != "normalize" or cfg.get("uint8") or cfg.get("slope"):
+            raise ValueError("TileBatchLoader: Dataset / SLCDataset with scale_input 'normalize' (no uint8, no slope)")
+        if not self.slc and cfg["clamp_input"] is None:
             raise ValueError("TileBatchLoader: clamp_input is required (the GPU preprocess clamps)")
         if batch_size % world:
             raise ValueError(f"global batch {batch_size} is not divisible by world size {world}")
@@ -408,7 +427,7 @@ class TileBatchLoader:
         per = batch_size // world
         pin = self.device.type == "cuda"
         self.prefetch = max(0, int(prefetch))
-        self.stage = torch.empty((per * (6 + 1 + (1 if cfg["dem"] else 0)), TILE, TILE), dtype=torch.float32, pin_memory=pin)
+        self.stage = torch.empty((per * ((12 if self.slc else 6) + 1 + (1 if cfg["dem"] else 0)), TILE, TILE), dtype=torch.float32, pin_memory=pin)
         self.copy_stream = torch.cuda.Stream(self.device) if pin else None
 
     def __len__(self):
@@ -479,6 +498,56 @@ class TileBatchLoader:
         return out
 
     def _load(self, indices):
+        if self.slc:
+            return self._load_slc(indices)
+        return self._load_grd(indices)
+
+    def _load_slc(self, indices):
+        """4-band tiles (dataset/Dataset.py:1087-1228): [n x (MS1, SL1, SL2) x 4 bands][DEM][masks] in the staging buffer, Normalize on the
+        device.  A batch with a ragged tile (smaller than 224 x 224: padded by the reference, :1173-1207) takes the per-sample path."""
+        from .data import preprocess_gpu
+        ds, cfg, dev, n = self.ds, self.ds.configs, self.device, len(indices)
+        dem = bool(cfg["dem"])
+        samples, files = zip(*[ds.sample_files(i) for i in indices]) if n else ((), ())
+        stage = self.stage
+        try:
+            sar = geotiff.read_batch([f[p] for f in files for p in ("MS1", "SL1", "SL2")], TILE, TILE, out=stage[:12 * n].view(3 * n, 4, TILE, TILE),
+                                     threads=self.threads, bands=4).view(n, 12, TILE, TILE)
+            k = 12 * n
+            dems = None
+            if dem:
+                dtl = geotiff.read_batch([f["MK0_DEM"] for f in files], TILE, TILE, out=stage[k:k + n], threads=self.threads)
+                nodata = geotiff.info(files[0]["MK0_DEM"])["nodata"] if n else None
+                if nodata is not None and nodata == nodata:
+                    dtl[dtl == float(np.float32(nodata))] = float("nan")
+                dems = geotiff.fill_nodata(dtl, threads=self.threads).view(n, 1, TILE, TILE).to(dev, non_blocking=True)
+                k += n
+            with_mask = [j for j, f in enumerate(files) if "MK0_MLU" in f]
+            if len(with_mask) != n:
+                raise _Ragged()                      # (the SLC class has no mask default: leave such a cell to __getitem__)
+            mask = geotiff.read_batch([f["MK0_MLU"] for f in files], TILE, TILE, out=stage[k:k + n], threads=self.threads).to(dev, non_blocking=True).long()
+        except (_Ragged, _lib_error()) as e:
+            if not isinstance(e, _Ragged) and "expected" not in str(e):
+                raise
+            items = [ds[i] for i in indices]
+            return _collate_to(items, dev, self.world > 1)
+        sar = sar.to(dev, non_blocking=True)
+        means, stds = cfg["slc_mean"], cfg["slc_std"]
+        dates = [sar[:, a:a + 4].contiguous() for a in (0, 4, 8)]
+        if not self.raw:
+            if dev.type != "cuda":
+                raise RuntimeError("TileBatchLoader normalises on the GPU (raw=True hands out raw tiles on any device)")
+            dates = [preprocess_gpu(d, means, stds, -1.0) for d in dates]
+        flood, sec1, sec2 = dates
+        sv = lambda v: [torch.full((n,), float(x), dtype=torch.float64) for x in v]
+        out = [sv(means), sv(stds), flood, mask, sv(means), sv(stds), sec1, sv(means), sv(stds), sec2]
+        if dem:
+            out.append((dems - torch.as_tensor(cfg["slc_dem_mean"], dtype=torch.float32, device=dev).view(1, -1, 1, 1)) /
+                       torch.as_tensor(cfg["slc_dem_std"], dtype=torch.float32, device=dev).view(1, -1, 1, 1))
+        out += [torch.tensor([s["clz"] for s in samples], dtype=torch.int64), torch.tensor([s["activation"] for s in samples], dtype=torch.int64)]
+        return ShardedBatch(out) if self.world > 1 else tuple(out)
+
+    def _load_grd(self, indices):
         from .data import preprocess_gpu
         ds, cfg, dev, n = self.ds, self.ds.configs, self.device, len(indices)
         dem = bool(cfg["dem"])

@@ -51,24 +51,24 @@ def read(path, dtype=None, squeeze=True):
     return (out[0] if squeeze and shape[0] == 1 else out), meta
 
 
-def read_batch(paths, H, W, out=None, threads=8):
-    """n single-band H x W tiles -> float32 [n, H, W], decoded by `threads` native threads into `out` (a torch tensor or numpy array,
-    e.g. one pinned staging buffer) or a new numpy array."""
+def read_batch(paths, H, W, out=None, threads=8, bands=1):
+    """n H x W tiles of `bands` bands -> float32 [n, H, W] ([n, bands, H, W] for bands > 1), decoded by `threads` native threads into
+    `out` (a torch tensor or numpy array, e.g. one pinned staging buffer) or a new numpy array."""
     lib = _lib.load()
     n = len(paths)
     if out is None:
-        out = np.empty((n, H, W), np.float32)
+        out = np.empty((n, H, W) if bands == 1 else (n, bands, H, W), np.float32)
     if hasattr(out, "data_ptr"):
         import torch
-        if out.dtype != torch.float32 or not out.is_contiguous() or out.numel() < n * H * W or out.device.type != "cpu":
+        if out.dtype != torch.float32 or not out.is_contiguous() or out.numel() < n * bands * H * W or out.device.type != "cpu":
             raise ValueError("read_batch: `out` must be a contiguous float32 CPU tensor of at least n*H*W elements")
         ptr = out.data_ptr()
     else:
-        if out.dtype != np.float32 or not out.flags["C_CONTIGUOUS"] or out.size < n * H * W:
+        if out.dtype != np.float32 or not out.flags["C_CONTIGUOUS"] or out.size < n * bands * H * W:
             raise ValueError("read_batch: `out` must be a C-contiguous float32 array of at least n*H*W elements")
         ptr = out.ctypes.data
     arr = (C.c_char_p * max(n, 1))(*[str(p).encode() for p in paths])
-    _lib.check(lib.ksmi_tile_batch_read(arr, n, ptr, H, W, int(threads)), "tile_batch_read")
+    _lib.check(lib.ksmi_tile_batch_read_bands(arr, n, ptr, int(bands), H, W, int(threads)), "tile_batch_read")
     return out
 
 

@@ -61,7 +61,7 @@ def fuse_input_pipeline(model, loaders, configs):
     configs["fuse_input_pipeline"] = false or KSMI_FUSE_INPUT=0 keeps the loaders normalising (ksmi_sar_preprocess)."""
     import os
     from ..dataset import TileBatchLoader
-    if not (hasattr(model, "set_input_pipeline") and all(isinstance(ld, TileBatchLoader) for ld in loaders)
+    if not (hasattr(model, "set_input_pipeline") and all(isinstance(ld, TileBatchLoader) and not ld.slc for ld in loaders)
             and configs.get("fuse_input_pipeline", True) and os.environ.get("KSMI_FUSE_INPUT", "1") != "0"):
         return False
     ndem = 1 if configs["dem"] else 0        # the DEM arrives standardised (its gap filling is host work): identity for that channel

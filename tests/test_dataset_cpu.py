@@ -213,3 +213,34 @@ def test_slc_dataset_with_ragged_tiles(tmp_path):
         assert torch.isfinite(item[10]).all()                                   # the 3.4e38 no-data cells were filled
         padded += int((h, w) != (224, 224))
     assert padded == 2
+
+
+def test_slc_batch_loader_raw_mode_and_ragged_fallback(tmp_path):
+    """the 4-band batch path (ksmi_tile_batch_read_bands): raw tiles of a batch equal what was written; a batch holding a ragged tile
+    falls back to the per-sample path (the reference pads such tiles, dataset/Dataset.py:1173-1207) and yields the same tuple"""
+    from make_synthetic_archive import make
+    from kurosiwo_amd.dataset import SLCDataset, TileBatchLoader
+    root = str(tmp_path)
+    grids, truth = make(root, TRAIN, tiles_per_act=3, seed=4, slc=True, ragged=True)
+    os.makedirs(os.path.join(root, "pickle"))
+    json.dump(grids, open(os.path.join(root, "pickle", "train.json"), "w"))
+    slc_mean, slc_std = [0.022367, 39.242, 81.13, 0.043526], [1.2843, 25.6152, 58.0151, 1.2844]
+    cfg = _configs(root, slc=True, slc_root_path=root, train_json=os.path.join(root, "pickle", "train.json"),
+                   test_json=os.path.join(root, "pickle", "train.json"), slc_mean=slc_mean, slc_std=slc_std, dem=False)
+    ds = SLCDataset("train", cfg)
+    sizes = [truth[r["id"]]["MS1"].shape[1:] for r in ds.records]
+    assert sizes.count((224, 224)) == 4 and len(sizes) == 6
+    full = [i for i, s in enumerate(sizes) if s == (224, 224)]
+    ld = TileBatchLoader(ds, 2, device="cpu", raw=True, prefetch=0)
+    b = ld.load(full[:2])
+    for j, i in enumerate(full[:2]):
+        t = truth[ds.records[i]["id"]]
+        for pos, key in ((2, "MS1"), (6, "SL1"), (9, "SL2")):
+            assert np.array_equal(b[pos][j].numpy(), t[key])
+        assert torch.equal(b[3][j], torch.from_numpy(t["mask"]).long())
+    ragged = [i for i, s in enumerate(sizes) if s != (224, 224)][0]
+    b = ld.load([full[0], ragged])                                           # -> per-sample path: normalised, padded
+    want = torch.utils.data.default_collate([ds[full[0]], ds[ragged]])
+    assert len(b) == len(want) == 12
+    for pos in (2, 3, 6, 9):
+        assert torch.equal(b[pos], want[pos])

@@ -151,3 +151,49 @@ def test_segmentation_entry_trains_from_the_archive(archive, tmp_path, monkeypat
     monkeypatch.setattr(DS.TileBatchLoader, "_load", spy)
     miou = entry.main(["--method", "unet", "--batch_size", "4", "--dem"])
     assert 0.0 <= miou <= 100.0 and seen["n"] >= 4
+
+
+def test_slc_batch_loader_and_changeformer_from_an_slc_archive(tmp_path, monkeypatch):
+    """4-band SLC tiles (BASELINE.json configs[3]): the batch loader (normalised on the GPU, DEM gaps filled natively) equals the collated
+    per-sample SLCDataset bit for bit; main.py --method changeformer trains from the SLC archive"""
+    import shutil
+    import main as entry
+    from make_synthetic_archive import make
+    from kurosiwo_amd.config import load_json5
+    from kurosiwo_amd.dataset import SLCDataset, TileBatchLoader
+    root = str(tmp_path / "slc")
+    os.makedirs(os.path.join(root, "pickle"))
+    tr, _ = make(root, TRAIN, tiles_per_act=4, seed=5, slc=True)
+    te, _ = make(root, VAL + TEST, tiles_per_act=4, seed=6, slc=True)
+    json.dump(tr, open(os.path.join(root, "pickle", "train.json"), "w"))
+    json.dump(te, open(os.path.join(root, "pickle", "test.json"), "w"))
+    slc = dict(slc=True, slc_root_path=root, train_json=os.path.join(root, "pickle", "train.json"), test_json=os.path.join(root, "pickle", "test.json"),
+               slc_mean=[0.022367, 39.242, 81.13, 0.043526], slc_std=[1.2843, 25.6152, 58.0151, 1.2844], slc_dem_mean=82.96, slc_dem_std=153.71)
+    cfg = _configs(root, dem=True, device="cuda", **slc)
+    ds = SLCDataset("train", cfg)
+    ref = list(torch.utils.data.DataLoader(ds, batch_size=4, shuffle=False))
+    got = list(TileBatchLoader(ds, 4, device="cuda", threads=4))
+    assert len(ref) == len(got) == 2
+    for r, g in zip(ref, got):
+        assert len(r) == len(g) == 13
+        for pos in (2, 6, 9, 10):
+            assert g[pos].is_cuda and torch.equal(g[pos].cpu(), r[pos]), pos
+        assert torch.equal(g[3].cpu(), r[3]) and torch.equal(g[11], r[11]) and torch.equal(g[12], r[12])
+    # end to end
+    work = tmp_path / "run"
+    shutil.copytree(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "configs"), work / "configs")
+    dc = load_json5(work / "configs" / "train" / "data_config.json")
+    dc.update(train_acts=TRAIN, val_acts=VAL, test_acts=TEST, **{k: v for k, v in slc.items() if k not in ("slc_dem_mean", "slc_dem_std")})
+    json.dump(dc, open(work / "configs" / "train" / "data_config.json", "w"))
+    monkeypatch.chdir(work)
+    monkeypatch.setenv("KSMI_DATA", "archive")
+    import kurosiwo_amd.dataset as DS
+    seen = {"n": 0}
+    orig = DS.TileBatchLoader._load_slc
+
+    def spy(self, idx):
+        seen["n"] += 1
+        return orig(self, idx)
+    monkeypatch.setattr(DS.TileBatchLoader, "_load_slc", spy)
+    miou = entry.main(["--method", "changeformer", "--inputs", "pre_event_1", "post_event", "--batch_size", "4"])
+    assert 0.0 <= miou <= 100.0 and seen["n"] >= 4
