@@ -359,16 +359,34 @@ class BitCDTransformerPlan(BitCDPlan):
             tD_, tM_ = self.buf(Rp, 32), self.buf(Rp, 64)
             self.need("cross", self.lib.ksmi_token_cross_bwd_workspace(B, 2, N))
         mem_steps = []
-        for li in range(m.dec_depth):
+        # token side of ALL decoder layers at once: every layer reads the same encoder output T, so k, v and the folded matrices of
+        # the dec_depth layers are batched products over a layer axis (the layers' parameters sit at one constant stride in the arena:
+        # same keys, same order), ahead of the pixel loop; the backward unfolds the layers' dA / dBv the same way behind it
+        Ld = m.dec_depth
+        dkey = lambda li, sfx: f"transformer_decoder.layers.{li}.0.fn.{sfx}"
+        lstride = (m._poff[dkey(1, "fn.to_q.weight")] - m._poff[dkey(0, "fn.to_q.weight")]) if Ld > 1 else 0
+        for sfx in ("norm.weight", "fn.to_q.weight", "fn.to_k.weight", "fn.to_v.weight", "fn.to_out.0.weight", "fn.to_out.0.bias"):
+            for li in range(1, Ld):
+                assert m._poff[dkey(li, sfx)] - m._poff[dkey(li - 1, sfx)] == lstride, "decoder layers are not at a constant arena stride"
+        W0 = lambda sfx: m._p(dkey(0, sfx)).data_ptr()
+        G0 = lambda sfx: m._g(dkey(0, sfx)).data_ptr()
+        mn_all, K_all, V_all = self.fbuf(Ld, R8, 32), self.fbuf(Ld, R8, Id), self.fbuf(Ld, R8, Id)
+        A_all, Bv_all = self.fbuf(Ld, R8, H, 32), self.fbuf(Ld, R8, H, 32)
+        stms = [self._ln32(T, dkey(li, "norm.weight"), dkey(li, "norm.bias"), mn_all[li], R8) for li in range(Ld)]
+        self._bmm(self.fwd, mn_all.data_ptr(), W0("fn.to_k.weight"), K_all.data_ptr(), Ld, 1, R8, Id, 32, (R8 * 32, 0, 32, 1), (lstride, 0, 1, 32),
+                  (R8 * Id, 0, Id, 1), tag="dec.to_k")
+        self._bmm(self.fwd, mn_all.data_ptr(), W0("fn.to_v.weight"), V_all.data_ptr(), Ld, 1, R8, Id, 32, (R8 * 32, 0, 32, 1), (lstride, 0, 1, 32),
+                  (R8 * Id, 0, Id, 1), tag="dec.to_v")
+        self._bmm(self.fwd, K_all.data_ptr(), W0("fn.to_q.weight"), A_all.data_ptr(), Ld, H, R8, 32, Dd, (R8 * Id, Dd, Id, 1), (lstride, Dd * 32, 32, 1),
+                  (R8 * H * 32, 32, H * 32, 1), tag="dec.A")
+        self._bmm(self.fwd, V_all.data_ptr(), W0("fn.to_out.0.weight"), Bv_all.data_ptr(), Ld, H, R8, 32, Dd, (R8 * Id, Dd, Id, 1), (lstride, Dd, 1, Id),
+                  (R8 * H * 32, 32, H * 32, 1), tag="dec.Bv")
+        dA_all = self.fbuf(Ld, R8, H, 32) if wb else None
+        dBv_all = self.fbuf(Ld, R8, H, 32) if wb else None
+        for li in range(Ld):
             a, f = f"transformer_decoder.layers.{li}.0.fn", f"transformer_decoder.layers.{li}.1.fn"
-            nk, wq, wk_, wv, wo, bo = f"{a}.norm", f"{a}.fn.to_q.weight", f"{a}.fn.to_k.weight", f"{a}.fn.to_v.weight", f"{a}.fn.to_out.0.weight", f"{a}.fn.to_out.0.bias"
-            # token side: k, v of the normalised tokens, folded with to_q / to_out
-            mn, K_, V_, A_, Bv = self.fbuf(R8, 32), self.fbuf(R8, Id), self.fbuf(R8, Id), self.fbuf(R8, H, 32), self.fbuf(R8, H, 32)
-            stm = self._ln32(T, f"{nk}.weight", f"{nk}.bias", mn, R8)
-            self._lin32(f"dec{li}.to_k", mn, R8, 32, wk_, None, K_, Id)
-            self._lin32(f"dec{li}.to_v", mn, R8, 32, wv, None, V_, Id)
-            self._bmm(self.fwd, K_.data_ptr(), P(wq), A_.data_ptr(), 1, H, R8, 32, Dd, (0, Dd, Id, 1), (0, Dd * 32, 32, 1), (0, 32, H * 32, 1), tag=f"dec{li}.A")
-            self._bmm(self.fwd, V_.data_ptr(), P(wo), Bv.data_ptr(), 1, H, R8, 32, Dd, (0, Dd, Id, 1), (0, Dd, 1, Id), (0, 32, H * 32, 1), tag=f"dec{li}.Bv")
+            nk, bo = f"{a}.norm", f"{a}.fn.to_out.0.bias"
+            A_, Bv = A_all[li], Bv_all[li]
             # pixel side
             x_in, x_mid, h2_, u, g, x_out = X, self.buf(Rp, 32), self.buf(Rp, 32), self.buf(Rp, 64), self.buf(Rp, 64), self.buf(Rp, 32)
             self.fwd.add("ksmi_token_cross_forward", lambda x_in=x_in, x_mid=x_mid, A_=A_, Bv=Bv, nk=nk, bo=bo: (
@@ -380,16 +398,15 @@ class BitCDTransformerPlan(BitCDPlan):
             self._linear(f"dec{li}.ff2", g, 64, f"{f}.fn.net.3.weight", f"{f}.fn.net.3.bias", x_out, 32, Rp, resid=x_mid)
             X = x_out
 
-            def dec_bwd(li=li, f=f, nk=nk, wq=wq, wk_=wk_, wv=wv, wo=wo, bo=bo, mn=mn, K_=K_, V_=V_, A_=A_, Bv=Bv, stm=stm, x_in=x_in, x_mid=x_mid,
-                        h2_=h2_, u=u, g=g, st2=st2):
+            def dec_bwd(li=li, f=f, nk=nk, bo=bo, A_=A_, Bv=Bv, x_in=x_in, x_mid=x_mid, h2_=h2_, u=u, g=g, st2=st2):
                 gx = self._gx.view(Rp, 32)
                 # feed-forward on the pixels: x_out = x_mid + W2 gelu(W1 LN(x_mid) + b1) + b2
                 self._linear_bwd(f"dec{li}.ff2", g, 64, f"{f}.fn.net.3.weight", f"{f}.fn.net.3.bias", gx, 32, Rp, tM_)
                 self.bwd.add("ksmi_gelu_backward", lambda: (tM_.data_ptr(), u.data_ptr(), tM_.data_ptr(), Rp * 64, dt), self._elt_meta("gelu_bwd", 3 * Rp * 64))
                 self._linear_bwd(f"dec{li}.ff1", h2_, 32, f"{f}.fn.net.0.weight", f"{f}.fn.net.0.bias", tM_, 64, Rp, tD_)
                 self._ln_bwd(tD_, x_mid, st2, f"{f}.norm.weight", f"{f}.norm.bias", gx, 1, Rp, 32)
-                # cross-attention: pixels (gx in place, LayerNorm / to_out bias gradients) and the folded matrices
-                dA, dBv = self.fbuf(R8, H, 32), self.fbuf(R8, H, 32)
+                # cross-attention: pixels (gx in place, LayerNorm / to_out bias gradients) and the layer's folded-matrix gradients
+                dA, dBv = dA_all[li], dBv_all[li]
                 a_ln, a_bo = self._acc_param(f"{nk}.weight"), self._acc_param(bo)
                 assert self._acc_param(f"{nk}.bias") == a_ln
                 self.bwd.add("ksmi_token_cross_backward", lambda: (
@@ -397,26 +414,42 @@ class BitCDTransformerPlan(BitCDPlan):
                     G(f"{nk}.weight"), G(f"{nk}.bias"), G(bo), a_ln, a_bo, self.scr("cross"), B, 2, N, 32, H, L, scale, dt),
                     {"kind": "token_cross_bwd", "bytes": 3 * Rp * 32 * self._es(), "flops": 12 * Rp * 32 * 32})
                 self._mark(bo)
-                # token side: unfold dA -> (dWq, dK), dBv -> (dWo, dV); to_k / to_v; the LayerNorm of the tokens (same parameters as the pixels')
-                dK, dV, dmn = self.fbuf(R8, Id), self.fbuf(R8, Id), self.fbuf(R8, 32)
-                self._bmm(self.bwd, dA.data_ptr(), P(wq), dK.data_ptr(), 1, H, R8, Dd, 32, (0, 32, H * 32, 1), (0, Dd * 32, 1, 32), (0, Dd, Id, 1), tag=f"dec{li}.dK")
-                self._bmm(self.bwd, K_.data_ptr(), dA.data_ptr(), G(wq), 1, H, Dd, 32, R8, (0, Dd, 1, Id), (0, 32, H * 32, 1), (0, Dd * 32, 32, 1),
-                          acc=self._acc_param(wq), tag=f"dec{li}.dWq")
-                self._mark(wq)
-                self._bmm(self.bwd, dBv.data_ptr(), P(wo), dV.data_ptr(), 1, H, R8, Dd, 32, (0, 32, H * 32, 1), (0, Dd, Id, 1), (0, Dd, Id, 1), tag=f"dec{li}.dV")
-                self._bmm(self.bwd, dBv.data_ptr(), V_.data_ptr(), G(wo), 1, H, 32, Dd, R8, (0, 32, 1, H * 32), (0, Dd, Id, 1), (0, Dd, Id, 1),
-                          acc=self._acc_param(wo), tag=f"dec{li}.dWo")
-                self._mark(wo)
-                self._lin32_bwd(f"dec{li}.to_k", mn, R8, 32, wk_, None, dK, Id, dmn, 0)
-                self._lin32_bwd(f"dec{li}.to_v", mn, R8, 32, wv, None, dV, Id, dmn, 1)
-                self._ln32_bwd(dmn, T, stm, f"{nk}.weight", f"{nk}.bias", gT, self._gT_started(), R8)
             mem_steps.append(dec_bwd)
+
+        def dec_tokens_bwd():
+            """behind the pixel loop: unfold dA -> (dWq, dK), dBv -> (dWo, dV), to_k / to_v, for all layers at once; then the LayerNorm of
+            the tokens layer by layer (its parameters are the ones the pixels use: the pixel kernel wrote their gradients, these add)"""
+            dK_all, dV_all, dmn_all = self.fbuf(Ld, R8, Id), self.fbuf(Ld, R8, Id), self.fbuf(Ld, R8, 32)
+            accs = {sfx: {self._acc_param(dkey(li, sfx)) for li in range(Ld)} for sfx in ("fn.to_q.weight", "fn.to_k.weight", "fn.to_v.weight", "fn.to_out.0.weight")}
+            assert all(len(v) == 1 for v in accs.values())
+            acc = {k: v.pop() for k, v in accs.items()}
+            da, dbv, dk, dv, dmn = dA_all.data_ptr(), dBv_all.data_ptr(), dK_all.data_ptr(), dV_all.data_ptr(), dmn_all.data_ptr()
+            sA = (R8 * H * 32, 32, H * 32, 1)
+            self._bmm(self.bwd, da, W0("fn.to_q.weight"), dk, Ld, H, R8, Dd, 32, sA, (lstride, Dd * 32, 1, 32), (R8 * Id, Dd, Id, 1), tag="dec.dK")
+            self._bmm(self.bwd, K_all.data_ptr(), da, G0("fn.to_q.weight"), Ld, H, Dd, 32, R8, (R8 * Id, Dd, 1, Id), sA, (lstride, Dd * 32, 32, 1),
+                      acc=acc["fn.to_q.weight"], tag="dec.dWq")
+            self._bmm(self.bwd, dbv, W0("fn.to_out.0.weight"), dv, Ld, H, R8, Dd, 32, sA, (lstride, Dd, Id, 1), (R8 * Id, Dd, Id, 1), tag="dec.dV")
+            self._bmm(self.bwd, dbv, V_all.data_ptr(), G0("fn.to_out.0.weight"), Ld, H, 32, Dd, R8, (R8 * H * 32, 32, 1, H * 32), (R8 * Id, Dd, Id, 1),
+                      (lstride, Dd, Id, 1), acc=acc["fn.to_out.0.weight"], tag="dec.dWo")
+            # to_k / to_v: d LN(T) = dK Wk + dV Wv ; dWk = dK^T LN(T) ; dWv = dV^T LN(T)
+            sM, sKV = (R8 * 32, 0, 32, 1), (R8 * Id, 0, Id, 1)
+            self._bmm(self.bwd, dk, W0("fn.to_k.weight"), dmn, Ld, 1, R8, 32, Id, sKV, (lstride, 0, 32, 1), sM, tag="dec.to_k.dx")
+            self._bmm(self.bwd, dv, W0("fn.to_v.weight"), dmn, Ld, 1, R8, 32, Id, sKV, (lstride, 0, 32, 1), sM, acc=1, tag="dec.to_v.dx")
+            self._bmm(self.bwd, dk, mn_all.data_ptr(), G0("fn.to_k.weight"), Ld, 1, Id, 32, R8, (R8 * Id, 0, 1, Id), sM, (lstride, 0, 32, 1),
+                      acc=acc["fn.to_k.weight"], tag="dec.to_k.dW")
+            self._bmm(self.bwd, dv, mn_all.data_ptr(), G0("fn.to_v.weight"), Ld, 1, Id, 32, R8, (R8 * Id, 0, 1, Id), sM, (lstride, 0, 32, 1),
+                      acc=acc["fn.to_v.weight"], tag="dec.to_v.dW")
+            for li in range(Ld):
+                self._mark(*[dkey(li, sfx) for sfx in ("fn.to_q.weight", "fn.to_k.weight", "fn.to_v.weight", "fn.to_out.0.weight")])
+            for li in reversed(range(Ld)):
+                self._ln32_bwd(dmn_all[li], T, stms[li], dkey(li, "norm.weight"), dkey(li, "norm.bias"), gT, self._gT_started(), R8)
         self._gT_acc = 0
-        # backward order: decoder layers (last first), then encoder (last first), then the tokenizer
+        # backward order: pixel side of the decoder layers (last first), their token side, encoder (last first), tokenizer
         if wb:
             def token_stage_bwd():
                 for fn in reversed(mem_steps):
                     fn()
+                dec_tokens_bwd()
                 for fn in reversed(steps):
                     fn()
             self._bwd.append(token_stage_bwd)
