@@ -107,13 +107,13 @@ def test_full_depth_forward_and_grad_norms_vs_golden(golden_dir):
     lbl = seeded_labels("floodvit.full.lbl", (B, 224, 224))
     logits = model(x.cuda())
     sub = logits.detach().cpu()[:, :, ::8, ::8].numpy()
-    assert np.abs(sub - gold["logits_sub"]).max() < 5e-3 * np.abs(gold["logits_sub"]).max()
+    assert np.abs(sub - gold["logits_sub"]).max() < 1e-4 * np.abs(gold["logits_sub"]).max()        # measured 2.8e-6 (fp32, exact-fp32 MFMA)
     am = logits.argmax(1).cpu().numpy().astype(np.uint8)
-    confident = gold["margin"].astype(np.float32) > 5e-2
+    confident = gold["margin"].astype(np.float32) > 1e-3                                          # logit units; the logits span +-9.6
     assert (am == gold["argmax"])[confident].all()
     mism, inband = int((am != gold["argmax"]).sum()), int((~confident).sum())
-    print(f"floodvit full argmax: {mism} mismatches of {am.size}, all among the {inband} pixels inside the 5e-2 margin")
-    assert mism <= 8, (mism, inband, am.size)     # bounded, not just excluded
+    print(f"floodvit full argmax: {mism} mismatches of {am.size}, all among the {inband} pixels inside the 1e-3 margin")
+    assert mism <= 2, (mism, inband, am.size)     # bounded, not just excluded: measured 0
     loss = torch.nn.functional.cross_entropy(logits, lbl.cuda(), weight=torch.tensor(CLASS_WEIGHTS, device="cuda"), ignore_index=3)
     loss.backward()
     assert abs(float(loss) - float(gold["loss"])) < 1e-3
