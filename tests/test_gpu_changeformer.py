@@ -111,7 +111,9 @@ def test_train_forward_backward_vs_oracle(golden_dir, precision):
         else:       # bf16 storage through 13 blocks + BatchNorm over as few as 98 pixels: bound the mean, sanity-bound the max
             # (the maximum over 3 x 10^5 probabilities moves with the summation order of the GEMMs: 0.21-0.26 observed)
             q = float(torch.quantile(err.flatten()[::7].float(), 0.999))
-            assert float(err.mean()) < 2e-2 and q < 0.12 and float(err.max()) < 0.35, (i, float(err.mean()), q, float(err.max()))
+            print(f"bf16 train step out{i}: mean {float(err.mean()):.4f} q999 {q:.4f} max {float(err.max()):.4f}")
+            # measured on MI355X: mean <= 0.0103, q999 <= 0.0585, max <= 0.21 (one 14 x 14 pixel)
+            assert float(err.mean()) < 2e-2 and q < 0.09 and float(err.max()) < 0.35, (i, float(err.mean()), q, float(err.max()))
     if precision == "fp32":
         assert np.abs(outs[4].detach().cpu()[:, :, ::8, ::8].numpy() - gold["train.out4_sub"]).max() < 1e-3
     # BatchNorm running statistics after the step
@@ -200,7 +202,8 @@ def test_train_step_with_stochastic_layers_vs_reference_golden(golden_dir, preci
     else:
         for i in range(5):
             err = (outs[i].detach().cpu() - ref[i]).abs()
-            assert float(err.mean()) < 2e-2 and float(err.max()) < 0.35, (i, float(err.mean()), float(err.max()))
+            print(f"bf16 stochastic step out{i}: mean {float(err.mean()):.4f} max {float(err.max()):.4f}")
+            assert float(err.mean()) < 1.7e-2 and float(err.max()) < 0.16, (i, float(err.mean()), float(err.max()))     # measured <= 0.0085 / 0.079
     crit = BCEandDiceLoss(weights=CLASS_WEIGHTS, ignore_index=3, use_softmax=True)
     loss = crit(outs[-1], lbl.cuda())
     loss.backward()
@@ -313,16 +316,19 @@ def test_slc_four_band_inputs_vs_reference_golden(golden_dir, precision):
         if precision == "fp32":
             assert e.max() < 1e-3, (what, e.max())
         else:                       # bf16 storage through 13 blocks: bound the mean tightly, the maximum loosely
-            assert e.mean() < 1e-2 and e.max() < 0.15, (what, e.mean(), e.max())
+            print(f"bf16 slc eval {what}: mean {e.mean():.4f} max {e.max():.4f}")
+            assert e.mean() < 8e-3 and e.max() < 0.11, (what, e.mean(), e.max())            # measured <= 0.0039 / 0.054
     for i in range(4):
         close(outs[i].cpu().numpy(), gold[f"eval.out{i}"], i)
     close(outs[4].cpu()[:, :, ::8, ::8].numpy(), gold["eval.out4_sub"], 4)
     margin = gold["eval.margin"].astype(np.float32)
-    band = 2e-3 if precision == "fp32" else 0.12
+    band = 2e-3 if precision == "fp32" else 0.06                                            # measured: no flip above a margin of 0.029
     am = outs[4].argmax(1).cpu().numpy().astype(np.uint8)
     assert (am == gold["eval.argmax"])[margin > band].all()
     inband = int((am != gold["eval.argmax"]).sum())
-    assert inband <= (50 if precision == "fp32" else 0.02 * am.size), inband      # bounded, not just printed
+    mm = margin[am != gold["eval.argmax"]]
+    print(f"slc eval argmax: {inband} flips of {am.size}, largest margin among them {float(mm.max()) if mm.size else 0.0:.4f}")
+    assert inband <= (50 if precision == "fp32" else 700), inband      # bounded, not just printed (bf16 measured 340 of 50176)
     # train step: loss + gradients (stochastic layers at p = 0 on both sides)
     model.train()
     x1 = sar_like("changeformer.slc.train.x1", (2, 4, 224, 224))
@@ -331,14 +337,17 @@ def test_slc_four_band_inputs_vs_reference_golden(golden_dir, precision):
     outs = model(x1.cuda(), x2.cuda())
     loss = BCEandDiceLoss(weights=CLASS_WEIGHTS, ignore_index=3, use_softmax=True)(outs[-1], lbl.cuda())
     loss.backward()
-    assert abs(float(loss) - float(gold["train.loss"])) < (3e-4 if precision == "fp32" else 3e-2)
-    assert np.abs(outs[4].detach().cpu()[:, :, ::8, ::8].numpy() - gold["train.out4_sub"]).max() < (1e-3 if precision == "fp32" else 0.35)
+    print(f"slc train: loss diff {abs(float(loss) - float(gold['train.loss'])):.5f} out4 max "
+          f"{np.abs(outs[4].detach().cpu()[:, :, ::8, ::8].numpy() - gold['train.out4_sub']).max():.4f}")
+    assert abs(float(loss) - float(gold["train.loss"])) < (3e-4 if precision == "fp32" else 1e-3)               # bf16 measured 2e-5
+    assert np.abs(outs[4].detach().cpu()[:, :, ::8, ::8].numpy() - gold["train.out4_sub"]).max() < (1e-3 if precision == "fp32" else 0.07)   # 0.035
     k = "Tenc_x2.patch_embed1.proj.weight"
     g = dict(model.named_parameters())[k].grad.detach().float().cpu().numpy()
     assert g.shape == (64, 4, 7, 7)
     ref = gold[f"grad.{k}"]
     cos = float((g.astype(np.float64) * ref).sum() / (np.linalg.norm(g.astype(np.float64)) * np.linalg.norm(ref.astype(np.float64)) + 1e-30))
-    assert cos > (0.999 if precision == "fp32" else 0.9), cos
+    print(f"slc patch-embed grad cosine {cos:.5f}")
+    assert cos > (0.999 if precision == "fp32" else 0.95), cos                                                   # bf16 measured 0.974
     if precision == "fp32":
         bad = {}
         for kk, p in model.named_parameters():
