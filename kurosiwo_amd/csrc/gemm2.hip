@@ -57,6 +57,9 @@ __device__ __forceinline__ void lds_barrier() {
 //   B side (pieces adjacent: 2 units): the row's low two bits go to unit bits 1 and 2
 __device__ __forceinline__ int sw_a(int row) { return (row & 1) | ((row & 2) << 2); }
 __device__ __forceinline__ int sw_b(int row) { return (row & 3) << 1; }
+// B-side image of the weight-gradient kernel, by row length: 192-byte rows (96 columns) of 4 consecutive reduction rows already start
+// in 4 different 64-byte bank groups (and a 12-unit row has no room for a 3-bit XOR), the 128- / 256-byte rows take sw_b
+template <int MT> __device__ __forceinline__ int sw_bt(int row) { return MT == 3 ? 0 : sw_b(row); }
 
 // lane's 16 consecutive outputs (acc[t][mt][r], t = 0..3) of row m -> two 16-byte stores
 template <int MT>
@@ -88,9 +91,9 @@ __device__ __forceinline__ void store_row2(const Gemm2P& p, const f32x4 (&acc)[4
 
 // MT: 16-row MFMA tiles per wave along the token axis (WG = 2 x 2 waves: 32*MT token rows x 128 output columns)
 // TRW: the W operand is stored reduction-major (input gradient: W[n][k], n = reduction) and read transposed (ds_read_b64_tr_b16)
-template <int MT, bool TRW>
+template <int MT, bool TRW, int NS>
 __global__ __launch_bounds__(256, 1) void gemm2_kernel(const Gemm2P p) {
-  constexpr int TM = 32 * MT, KS = 64, XB = TM * 128, WB = 128 * 128, STAGE = XB + WB, NS = 3;
+  constexpr int TM = 32 * MT, KS = 64, XB = TM * 128, WB = 128 * 128, STAGE = XB + WB;
   constexpr int NQ = STAGE / 1024, NI = NQ / 4;              // DMA instructions per stage (1 KiB each) / per wave
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
@@ -206,9 +209,9 @@ __global__ __launch_bounds__(256, 1) void gemm2_kernel(const Gemm2P p) {
     __builtin_amdgcn_sched_barrier(0);
     mma_all(acc, fwA, fxA);
     __builtin_amdgcn_sched_barrier(0);
-    // stage s+1 has landed once at most the DMAs of stage s+2 are outstanding; after the barrier every wave holds its fragments
-    // of stage s in registers, so that buffer is free for stage s+3
-    if (s + 2 < nsteps) vm_wait(NI); else vm_wait(0);
+    // stage s+1 has landed once at most the DMAs of stages s+2 .. s+NS-1 are outstanding; after the barrier every wave holds its
+    // fragments of stage s in registers, so that buffer is free for stage s+NS
+    if (s + NS <= nsteps) vm_wait((NS - 2) * NI); else vm_wait((nsteps - s - 2) * NI);
     lds_barrier();
     if (s + NS < nsteps) issue(s + NS, cur);
     cur = cur + 1 == NS ? 0 : cur + 1;
@@ -234,44 +237,66 @@ __global__ __launch_bounds__(256, 1) void gemm2_kernel(const Gemm2P p) {
   for (int mt = 0; mt < MT; ++mt) store_row2<MT>(p, acc, mt, m0 + wm * 16 * MT + mt * 16 + l15, c0, bias16);
 }
 
-template <int MT, bool TRW>
-int launch2(const Gemm2P& p, hipStream_t st) {
-  constexpr int lds = 3 * (32 * MT * 128 + 128 * 128);
-  auto kfn = gemm2_kernel<MT, TRW>;
+template <int MT, bool TRW, int NS>
+int launch2n(const Gemm2P& p, hipStream_t st) {
+  constexpr int lds = NS * (32 * MT * 128 + 128 * 128);
+  static_assert(lds <= 160 * 1024, "LDS ring");
+  auto kfn = gemm2_kernel<MT, TRW, NS>;
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
   hipLaunchKernelGGL(kfn, dim3(p.mtiles * p.ntiles), dim3(256), lds, st, p);
   return ksmi_check_launch(TRW ? "gemm2_nn" : "gemm2_nt");
 }
 
-// row-tile height: whole rounds of the 256 CUs cost rounds x TM; pick the cheapest (ties -> the taller tile)
-int pick_mt(int rows, int ntiles) {
-  static const int cand[] = {8, 7, 6, 5, 4, 3, 2};
-  static const int forced = getenv("KSMI_GEMM2_MT") ? atoi(getenv("KSMI_GEMM2_MT")) : 0;
-  if (forced) return forced;
-  long best = -1; int bm = 4;
-  for (int mt : cand) {
-    const int tm = 32 * mt;
-    const long wgs = (long)((rows + tm - 1) / tm) * ntiles;
-    const long cost = ((wgs + 255) / 256) * (tm + 24);          // + fixed per-tile prologue / epilogue
-    if (best < 0 || cost < best) { best = cost; bm = mt; }
+// Tile height x ring depth, chosen from IN-SITU durations (FloodViT step under rocprofv3, tools/gemm_insitu.sh ->
+// profiles/r03_gemm_insitu.txt; back-to-back launches on L2-resident operands, profiles/r03_gemm2_sweep*.txt, rank the choices
+// differently: there a deeper ring buys nothing, in the step -- weights cold in HBM -- a workgroup that is alone on its CU needs the
+// third stage).  One workgroup is a lock-step of DMA wait -> barrier -> fragment reads -> MFMA; a co-resident one fills the gaps.
+// Registers (140 / 184 / 248 for MT 2 / 3 / 4, 312+ above) and LDS decide who can share a CU:
+//   MT 2: three stages = 72 KB, two per CU, or two stages = 48 KB, three per CU;  MT 3 / 4: two stages = 56 / 64 KB, two per CU;
+//   MT 4 with three stages and MT >= 5: alone.
+// Cost = whole rounds of the 256 x occupancy slots x the measured round time in us at K = 1024 (only the ratios matter).
+struct Tile2 { int mt, ns; };
+inline Tile2 pick_tile(int rows, int ntiles) {
+  static const int f_mt = getenv("KSMI_GEMM2_MT") ? atoi(getenv("KSMI_GEMM2_MT")) : 0;     // probes / tests: pin the instance
+  static const int f_ns = getenv("KSMI_GEMM2_NS") ? atoi(getenv("KSMI_GEMM2_NS")) : 0;
+  static const struct { int mt, ns, slots; double round_us; } cand[] = {
+      {2, 3, 512, 13.0}, {4, 3, 256, 13.8}, {2, 2, 768, 15.5}, {3, 2, 512, 16.0}, {5, 3, 256, 16.3}, {6, 3, 256, 18.0},
+      {4, 2, 512, 19.0}, {7, 3, 256, 21.0}, {8, 3, 256, 23.0}};
+  Tile2 best = {4, 3}; double bc = 1e30;
+  for (const auto& c : cand) {
+    if ((f_mt && c.mt != f_mt) || (f_ns && f_ns <= 3 && c.ns != f_ns)) continue;
+    const long wgs = (long)((rows + 32 * c.mt - 1) / (32 * c.mt)) * ntiles;
+    const double cost = (double)((wgs + c.slots - 1) / c.slots) * c.round_us;
+    if (cost < bc) { bc = cost; best = {c.mt, c.ns}; }
   }
-  return bm;
+  if (f_mt && bc == 1e30) best = {f_mt, f_mt >= 5 ? 3 : 2};
+  if (f_ns) best.ns = f_ns;
+  return best;
+}
+
+template <int MT, bool TRW>
+int launch2(const Gemm2P& p, int ns, hipStream_t st) {
+  constexpr int stage = 32 * MT * 128 + 128 * 128;
+  if (ns <= 2) return launch2n<MT, TRW, 2>(p, st);
+  if constexpr (5 * stage <= 160 * 1024) { if (ns >= 5) return launch2n<MT, TRW, 5>(p, st); }
+  if constexpr (4 * stage <= 160 * 1024) { if (ns >= 4) return launch2n<MT, TRW, 4>(p, st); }
+  return launch2n<MT, TRW, 3>(p, st);
 }
 
 template <bool TRW>
 int dispatch2(Gemm2P& p, hipStream_t st) {
   p.ntiles = p.cols / 128;
-  const int mt = pick_mt(p.rows, p.ntiles);
-  p.mtiles = (p.rows + 32 * mt - 1) / (32 * mt);
-  switch (mt) {
-    case 2: return launch2<2, TRW>(p, st);
-    case 3: return launch2<3, TRW>(p, st);
-    case 4: return launch2<4, TRW>(p, st);
-    case 5: return launch2<5, TRW>(p, st);
-    case 6: return launch2<6, TRW>(p, st);
-    case 7: return launch2<7, TRW>(p, st);
-    default: return launch2<8, TRW>(p, st);
+  const Tile2 t = pick_tile(p.rows, p.ntiles);
+  p.mtiles = (p.rows + 32 * t.mt - 1) / (32 * t.mt);
+  switch (t.mt) {
+    case 2: return launch2<2, TRW>(p, t.ns, st);
+    case 3: return launch2<3, TRW>(p, t.ns, st);
+    case 4: return launch2<4, TRW>(p, t.ns, st);
+    case 5: return launch2<5, TRW>(p, t.ns, st);
+    case 6: return launch2<6, TRW>(p, t.ns, st);
+    case 7: return launch2<7, TRW>(p, t.ns, st);
+    default: return launch2<8, TRW>(p, t.ns, st);
   }
 }
 
@@ -290,9 +315,9 @@ struct Gemm2T {
 };
 __device__ __attribute__((aligned(64))) unsigned char gemm2_zero_page[64];
 
-template <int MT>
+template <int MT, int NS>
 __global__ __launch_bounds__(256, 1) void gemm2_tn_kernel(const Gemm2T p) {
-  constexpr int TB = 32 * MT, KS = 64, AB = 64 * 256, BROW = TB * 2, BB = 64 * BROW, STAGE = AB + BB, NS = 3;
+  constexpr int TB = 32 * MT, KS = 64, AB = 64 * 256, BROW = TB * 2, BB = 64 * BROW, STAGE = AB + BB;
   constexpr int NQ = STAGE / 1024, NI = NQ / 4, BGM = BROW / 32 - 1, AU = 16, BU = BROW / 16;
   static_assert(NQ % 4 == 0, "whole DMA rounds");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -320,7 +345,7 @@ __global__ __launch_bounds__(256, 1) void gemm2_tn_kernel(const Gemm2T p) {
       srow[i] = wr; sstep[i] = KS * p.a_rs * 2;
     } else {
       const int u4 = q * 64 - AB / 16 + lane, wr = u4 / BU, u = u4 % BU;
-      const int cb = (u ^ sw_b(wr)) << 4;
+      const int cb = (u ^ sw_bt<MT>(wr)) << 4;
       int c = b0 + (cb >> 1); if (c + 8 > p.b_cols) c = p.b_cols - 8;
       src[i] = (const unsigned char*)(p.b + (size_t)(m_begin + wr) * p.b_rs + c);
       srow[i] = wr; sstep[i] = KS * p.b_rs * 2;
@@ -356,7 +381,7 @@ __global__ __launch_bounds__(256, 1) void gemm2_tn_kernel(const Gemm2T p) {
 #pragma unroll
     for (int a = 0; a < 4; ++a) fa[a] = tr8(st, 256, sw_a(r0), r0, (wn * 64 + q4 * 16 + a * 4) * 2);         // lane i <-> column wn*64 + (i>>2)*16 + a*4 + (i&3)
 #pragma unroll
-    for (int b = 0; b < MT; ++b) fb[b] = tr8(st + AB, BROW, sw_b(r0), r0, (wm * 16 * MT + b * 16 + q4 * 4) * 2);   // lane i <-> column wm*16*MT + b*16 + i
+    for (int b = 0; b < MT; ++b) fb[b] = tr8(st + AB, BROW, sw_bt<MT>(r0), r0, (wm * 16 * MT + b * 16 + q4 * 4) * 2);   // lane i <-> column wm*16*MT + b*16 + i
   };
   f32x4 acc[4][MT], acc2[4][MT];
 #pragma unroll
@@ -395,7 +420,7 @@ __global__ __launch_bounds__(256, 1) void gemm2_tn_kernel(const Gemm2T p) {
       __builtin_amdgcn_sched_barrier(0);
       mma_all(acc, accb, faA, fbA);
       __builtin_amdgcn_sched_barrier(0);
-      if (s + 2 < nsteps) vm_wait(NI); else vm_wait(0);
+      if (s + NS <= nsteps) vm_wait((NS - 2) * NI); else vm_wait((nsteps - s - 2) * NI);
       lds_barrier();
       if (s + NS < nsteps) issue(s + NS, cur);
       cur = cur + 1 == NS ? 0 : cur + 1;
@@ -457,6 +482,16 @@ int ksmi_gemm2_nn(const void* dy, int dy_rs, const void* w, int w_rs, void* dx, 
   return dispatch2<true>(p, st);
 }
 
+template <int MT, int NS>
+static void launch_tn(dim3 grid, const Gemm2T& p, hipStream_t st) {
+  constexpr int lds = NS * (64 * 256 + 64 * 64 * MT);
+  static_assert(lds <= 160 * 1024, "LDS ring");
+  auto kfn = gemm2_tn_kernel<MT, NS>;
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+  hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, p);
+}
+
 bool ksmi_gemm2_tn_enabled(int K, int N, int rows_per_split) {
   static const bool off = getenv("KSMI_GEMM2_OFF") != nullptr || getenv("KSMI_GEMM2_TN_OFF") != nullptr;
   return !(off || K % 8 || N % 8 || K < 64 || N < 64 || rows_per_split % 64);
@@ -480,18 +515,11 @@ int ksmi_gemm2_tn(const void* x, int x_rs, const void* dy, int dy_rs, float* sla
     p.out = slab; p.o_rs = npad; p.split_stride = (int64_t)Kslab * npad; p.accumulate = 0;
   }
   p.atiles = (p.a_cols + 127) / 128; p.btiles = (p.b_cols + btile - 1) / btile;
-  if (btile == 128) {
-    constexpr int lds = 3 * (64 * 256 + 64 * 256);
-    auto kfn = gemm2_tn_kernel<4>;
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
-    hipLaunchKernelGGL(kfn, dim3(p.atiles * p.btiles, nsplit), dim3(256), lds, st, p);
-  } else if (btile == 64) {
-    constexpr int lds = 3 * (64 * 256 + 64 * 128);
-    auto kfn = gemm2_tn_kernel<2>;
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
-    hipLaunchKernelGGL(kfn, dim3(p.atiles * p.btiles, nsplit), dim3(256), lds, st, p);
-  } else return ksmi_fail(KSMI_E_ARG, "gemm2_tn: B-side tile must be 64 or 128");
+  static const int ns = getenv("KSMI_TN_NS") ? atoi(getenv("KSMI_TN_NS")) : 3;      // probes: ring depth of the weight-gradient kernel
+  const dim3 grid(p.atiles * p.btiles, nsplit);
+  if (btile == 128) { if (ns >= 5) launch_tn<4, 5>(grid, p, st); else if (ns == 4) launch_tn<4, 4>(grid, p, st); else launch_tn<4, 3>(grid, p, st); }
+  else if (btile == 96) { if (ns >= 5) launch_tn<3, 5>(grid, p, st); else if (ns == 4) launch_tn<3, 4>(grid, p, st); else launch_tn<3, 3>(grid, p, st); }
+  else if (btile == 64) { if (ns >= 6) launch_tn<2, 6>(grid, p, st); else if (ns == 5) launch_tn<2, 5>(grid, p, st); else if (ns == 4) launch_tn<2, 4>(grid, p, st); else launch_tn<2, 3>(grid, p, st); }
+  else return ksmi_fail(KSMI_E_ARG, "gemm2_tn: B-side tile must be 64, 96 or 128");
   return ksmi_check_launch("gemm2_tn");
 }

@@ -770,10 +770,13 @@ static void gemm_tn_geom(const ksmi_wgrad_desc* d, int kc, int& nsplit, int& rps
     for (int i = 0; i < d->nchunks; ++i) plain = plain && d->k_off[i] == i * kc;
   const int steps_all = (rows + 63) / 64;
   double best = 1e30; int bs = 1; bt = 128;
-  for (int b = 128; b >= 64; b >>= 1) {
-    const double step_us = b == 128 ? 0.95 : 0.6;
+  static const int f_bt = getenv("KSMI_TN_BT") ? atoi(getenv("KSMI_TN_BT")) : 0, f_s = getenv("KSMI_TN_SPLIT") ? atoi(getenv("KSMI_TN_SPLIT")) : 0;   // probes
+  for (int b = 128; b >= 64; b -= 32) {
+    if (f_bt && b != f_bt) continue;
+    const double step_us = b == 128 ? 0.95 : b == 96 ? 0.78 : 0.6;
     for (int s = 1; s <= 256 && s <= steps_all; s = s < 8 ? s + 1 : s * 2) {
       if (s == 1 && !plain) continue;
+      if (f_s && s != f_s) continue;
       // A-side tiles x B-side tiles (direct: A = k; slabs: A = n)
       const int acols = s == 1 ? K : npad, bcols = s == 1 ? npad : K;
       const int tiles = ((acols + 127) / 128) * ((bcols + b - 1) / b);

@@ -133,36 +133,45 @@ def test_gemm_nt_nn_bf16(dev, rows, K, N):
     assert float((dx2.float() - (refd + base.float())).abs().max() / refd.abs().max()) < 2e-2
 
 
-def _gemm2_row_tile(rows, ntiles):
-    """pick_mt of csrc/gemm2.hip: 32*MT token rows per workgroup, whole rounds of the 256 CUs"""
-    best, bm = None, 4
-    for mt in (8, 7, 6, 5, 4, 3, 2):
-        tm = 32 * mt
-        wgs = -(-rows // tm) * ntiles
-        cost = -(-wgs // 256) * (tm + 24)
-        if best is None or cost < best:
-            best, bm = cost, mt
-    return bm
-
-
-# (rows, K, N): every row-tile instance of gemm2_kernel<MT, .> (forward: N/128 column tiles; input gradient: K/128), ragged last
-# row tiles, reductions that are not a multiple of the 3-stage ring
+# (rows, K, N): forward has N/128 column tiles, the input gradient K/128; ragged last row tiles, reductions of 1 .. 48 K steps
 GEMM2_SHAPES = [(3152, 1024, 3072), (3152, 1024, 2048), (3152, 2048, 1024), (197, 128, 128), (4200, 192, 256), (5000, 256, 128),
                 (3000, 64 * 5, 128 * 3), (2500, 448, 1280), (1000, 128, 640), (40000, 128, 128), (777, 1024, 256),
                 (20000, 128, 128), (45000, 192, 128), (60000, 128, 128)]
 
 
-def test_gemm2_shapes_cover_every_row_tile():
-    seen = set()
-    for rows, K, N in GEMM2_SHAPES:
-        seen.add(_gemm2_row_tile(rows, N // 128))
-        seen.add(_gemm2_row_tile(rows, K // 128))
-    assert seen >= {2, 3, 4, 5, 6, 7, 8}, seen
+def test_gemm2_every_row_tile_and_ring_depth():
+    """Every instance gemm2_kernel<MT, ., NS> the chooser (pick_tile, csrc/gemm2.hip) can reach, and the probe-only ring depths: MT and
+    NS pinned through KSMI_GEMM2_MT / KSMI_GEMM2_NS (read once per process), forward with bias + residual and input gradient with
+    accumulation on ragged rows and on reductions shorter than, equal to and longer than the ring."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import torch\n"
+        "from kurosiwo_amd import functional as Fk\n"
+        "dev = torch.device('cuda:0')\n"
+        "errs = []\n"
+        "for rows, K, N in [(3152, 1024, 384), (777, 64, 128), (1000, 128, 256), (50, 192, 128), (4100, 320, 640)]:\n"
+        "    torch.manual_seed(rows)\n"
+        "    x = (torch.randn(rows, K, device=dev) * 0.5).bfloat16(); w = (torch.randn(N, K, device=dev) * K ** -0.5).bfloat16()\n"
+        "    b = torch.randn(N, device=dev); res = torch.randn(rows, N, device=dev).bfloat16()\n"
+        "    dy = (torch.randn(rows, N, device=dev) * 0.5).bfloat16(); base = torch.randn(rows, K, device=dev).bfloat16()\n"
+        "    ref = x.float() @ w.float().t() + b + res.float(); refd = dy.float() @ w.float() + base.float()\n"
+        "    errs.append(float((Fk.gemm_nt(x, w, b, res).float() - ref).abs().max() / ref.abs().max()))\n"
+        "    errs.append(float((Fk.gemm_nn(dy, w, out=base.clone()).float() - refd).abs().max() / refd.abs().max()))\n"
+        "print('ERR', max(errs))\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    combos = [(mt, ns) for mt in range(2, 9) for ns in (2, 3)] + [(2, 5), (4, 4), (6, 4)]
+    for mt, ns in combos:
+        env = dict(os.environ, PYTHONPATH=root, KSMI_GEMM2_MT=str(mt), KSMI_GEMM2_NS=str(ns))
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        assert float(out.stdout.split("ERR")[1]) < 2e-2, (mt, ns, out.stdout)
 
 
 @pytest.mark.parametrize("rows,K,N", GEMM2_SHAPES)
 def test_gemm2_lds_dma_tiles(dev, rows, K, N):
-    """gemm2.hip (LDS-DMA, 3-stage ring, K step 64): forward with bias / residual, input gradient with and without accumulate,
+    """gemm2.hip (LDS-DMA ring, K step 64; the chooser's own pick per shape): forward with bias / residual, input gradient with and without accumulate,
     weight gradient (direct and split-slab modes) against torch on the same bf16 operands."""
     from kurosiwo_amd import functional as Fk
     torch.manual_seed(rows + K + N)
@@ -184,7 +193,7 @@ def test_gemm2_lds_dma_tiles(dev, rows, K, N):
     assert got.dtype == torch.float32 and rel(got, refw) < 2e-3
 
 
-@pytest.mark.parametrize("rows,K,N", [(3152, 1024, 1024), (3152, 2048, 1024), (1568, 512, 2048)])
+@pytest.mark.parametrize("rows,K,N", [(3152, 1024, 3072), (3152, 1024, 1024), (3152, 2048, 1024), (1568, 512, 2048)])
 def test_linear_wgrad_vit_size(dev, rows, K, N):
     """nn.Linear weight gradient at ViT size (gemm2_tn_kernel: direct fp32 write or split slabs + reducer): against torch on the
     same bf16 operands."""
@@ -223,6 +232,34 @@ def test_hand_written_gemm_generations_agree():
         assert out.returncode == 0, out.stderr[-2000:]
         errs = [float(v) for v in out.stdout.split("ERR")[1].split()]
         assert errs[0] < 1e-2 and errs[1] < 1e-2 and errs[2] < 2e-3, (extra, errs)
+
+
+def test_linear_wgrad_every_tile_and_split():
+    """gemm2_tn_kernel<MT>: every B-side tile (128 / 96 / 64 columns; the 96-column image has its own LDS layout) in direct mode (one
+    split, row-major fp32 gradient) and over split slabs + the reducer, on ragged K / N / rows.  The probe variables KSMI_TN_BT /
+    KSMI_TN_SPLIT pin the chooser (read once per process), and the ring depth KSMI_TN_NS its other instances."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import torch\n"
+        "from kurosiwo_amd import functional as Fk\n"
+        "dev = torch.device('cuda:0')\n"
+        "errs = []\n"
+        "for rows, K, N in [(3152, 1024, 3072), (1000, 200, 328), (777, 136, 104), (4096, 72, 1000)]:\n"
+        "    torch.manual_seed(rows)\n"
+        "    x = (torch.randn(rows, K, device=dev) * 0.5).bfloat16(); dy = (torch.randn(rows, N, device=dev) * 0.5).bfloat16()\n"
+        "    ref = dy.float().t() @ x.float()\n"
+        "    errs.append(float((Fk.linear_wgrad(x, dy) - ref).abs().max() / ref.abs().max()))\n"
+        "print('ERR', *errs)\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for bt in ("128", "96", "64"):
+        for split, ns in (("1", "3"), ("3", "3"), ("1", "4"), ("2", "5")):
+            env = dict(os.environ, PYTHONPATH=root, KSMI_TN_BT=bt, KSMI_TN_SPLIT=split, KSMI_TN_NS=ns)
+            out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+            assert out.returncode == 0, out.stderr[-2000:]
+            errs = [float(v) for v in out.stdout.split("ERR")[1].split()]
+            assert len(errs) == 4 and max(errs) < 1e-5, (bt, split, ns, errs)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
