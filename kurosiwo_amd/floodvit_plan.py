@@ -9,6 +9,8 @@ Reference computation: /root/reference/models/vision_transformer.py:139-153 (ViT
 :19-32 (FeedForward), :69-89 (Transformer); /root/reference/models/model_utilities.py:80-94
 (FinetunerSegmentation.forward), :36-48 (Decoder.forward), :59-72 (the `mlp` and default 1x1 heads).
 """
+import os
+
 import torch
 
 from . import _lib
@@ -17,6 +19,8 @@ from .runtime import SrcSpec, make_conv, make_wgrad
 
 
 class FloodViTPlan(PlanBase):
+    # the nn.Linear weight gradients of the transformer layers on the train step's side stream (plan_base.PlanBase.side_tokens)
+    side_tokens = os.environ.get("KSMI_SIDE_TOKENS", "1") != "0"
     input_names = ("x",)
 
     def __init__(self, model, B, dtype, with_backward):

@@ -14,6 +14,8 @@ patch indices, the rest the visible ones (:73-78), and the gather / scatter kern
   PRED = Linear(DEC1[b][msk])                          to_pixels                      (:115-116)
   loss = mse(PRED, P0[b][msk])                                                        (:82, :122)
 """
+import os
+
 import torch
 
 from . import _lib
@@ -21,6 +23,7 @@ from .plan_base import PlanBase
 
 
 class MAEPlan(PlanBase):
+    side_tokens = os.environ.get("KSMI_SIDE_TOKENS", "1") != "0"      # plan_base.PlanBase.side_tokens (encoder and decoder layers)
     input_names = ("img", "rand_indices")
 
     def __init__(self, model, B, dtype, with_backward):

@@ -17,6 +17,9 @@ class PlanBase:
     # rewritten by a later launch of the same backward pass.  (b) holds for the convolutional plans, whose activations and gradients
     # are dedicated buffers; the token plans (ChangeFormer encoder, FloodViT, MAE) recycle their per-block gradient buffers.
     side_wgrad = False
+    # The token plans instead name the weight gradients that may leave the critical path one by one (side_tokens; _linear_bwd side_tag)
+    # and place a wait (LaunchList.add_wait_side) before every launch that overwrites an operand of one of them.
+    side_tokens = False
 
     def _init_base(self, model, dtype, with_backward):
         self.m, self.dtype, self.with_backward = model, dtype, with_backward
@@ -107,7 +110,9 @@ class PlanBase:
                 "flops": 2 * pout * d.N * ktot * taps, "tag": f"{name} K={ktot} N={d.N} M={pout}"}
         ll.add("ksmi_conv_forward", lambda: (C.byref(d), self.dt), meta)
 
-    def _wgrad(self, d, ws, key):
+    def _wgrad(self, d, ws, key, side_tag=None):
+        if side_tag is None and self.side_tokens:
+            self.bwd.add_wait_side(None)         # shares the split-slab scratch with the side-stream gradients
         self.keep.append(d)
         self.need("wgrad", ws)
         self._later.append(lambda: setattr(d, "partial", self.scr("wgrad")))
@@ -116,8 +121,10 @@ class PlanBase:
         pin, pout = d.B * d.Hin * d.Win, d.B * d.Hout * d.Wout
         meta = {"kind": f"igemm_wgrad<{d.KH}x{d.KW}s{d.stride}>", "bytes": (pin * ktot + pout * d.N) * es + taps * ktot * d.N * 4,
                 "flops": 2 * pout * d.N * ktot * taps, "tag": f"{key} K={ktot} N={d.N} M={pout}"}
-        if self.side_wgrad:
+        if self.side_wgrad or side_tag is not None:
             meta["side"] = True              # snunet_plan.LaunchList.run: eligible for the side stream
+        if side_tag is not None:
+            meta["side_tag"] = side_tag
         self.bwd.add("ksmi_conv_wgrad", lambda: (C.byref(d), self.dt), meta)
         self._mark(key)
 
@@ -158,8 +165,18 @@ class PlanBase:
         self.bwd.add("ksmi_reduce_rows", lambda: (self.scr("red"), r, 1, N, N, None, None, gb, acc))
         self._mark(bkey)
 
-    def _linear_bwd(self, name, x, Cin, wkey, bkey, dy, N, rows, dx, want_w=True, dx_acc=0, k_real=None):
-        """dx (+)= dy @ W (skipped if dx is None) ; dW = dy^T x ; db = colsum(dy)"""
+    def _linear_bwd(self, name, x, Cin, wkey, bkey, dy, N, rows, dx, want_w=True, dx_acc=0, k_real=None, side_tag=None, wait_tag=None):
+        """dx (+)= dy @ W (skipped if dx is None) ; dW = dy^T x ; db = colsum(dy).
+        side_tag (plans with side_tokens): the weight gradient is listed first and may run on the side stream next to its own input
+        gradient; the caller owns the hazards (add_wait_side(side_tag) before x or dy is overwritten).  wait_tag: an earlier
+        side-stream gradient that reads the buffer this input gradient writes."""
+        if not self.side_tokens:
+            side_tag = wait_tag = None
+        if side_tag is not None and want_w:
+            self._linear_wgrad(x, Cin, wkey, bkey, dy, N, rows, k_real, side_tag)
+            want_w = False
+        if wait_tag is not None:
+            self.bwd.add_wait_side(wait_tag)
         kr = Cin if k_real is None else k_real
         if dx is not None and self.wb is not None and kr == Cin and Cin % 8 == 0 and N % 8 == 0:
             wp = self._wb_ptr(wkey)
@@ -172,21 +189,25 @@ class PlanBase:
             d.wpk = self._packed(wkey, table, 1, Cin, Cin, Cin, 1, 0, 0).data_ptr()
             self._conv(self.bwd, d, "linear_dgrad", name)
         if want_w:
-            dw, ws = make_wgrad([SrcSpec(x, Cin, k_real=kr)], dy, N, 0, N, self.m._g(wkey), 1, kr, 0, self._acc_param(wkey),
-                                1, rows, 1, rows, 1, 1, 1, 1, 0, self.dtype)
-            fused = False
-            if bkey:       # the bias gradient rides on the weight-gradient GEMM when that launch holds dY in LDS anyway (gemm2.hip, direct mode)
-                dw.bias_grad = self.m._g(bkey).data_ptr()
-                fused = bool(self.lib.ksmi_conv_wgrad_fuses_bias(C.byref(dw), self.dt))
-                if fused:
-                    dw.bias_accumulate = self._acc_param(bkey)
-                else:
-                    dw.bias_grad = None
-            self._wgrad(dw, ws, wkey)
-            if bkey and fused:
-                self._mark(bkey)
-            elif bkey:
-                self._bias_grad(dy, rows, N, bkey)
+            self._linear_wgrad(x, Cin, wkey, bkey, dy, N, rows, k_real, None)
+
+    def _linear_wgrad(self, x, Cin, wkey, bkey, dy, N, rows, k_real, side_tag):
+        kr = Cin if k_real is None else k_real
+        dw, ws = make_wgrad([SrcSpec(x, Cin, k_real=kr)], dy, N, 0, N, self.m._g(wkey), 1, kr, 0, self._acc_param(wkey),
+                            1, rows, 1, rows, 1, 1, 1, 1, 0, self.dtype)
+        fused = False
+        if bkey:       # the bias gradient rides on the weight-gradient GEMM when that launch holds dY in LDS anyway (gemm2.hip, direct mode)
+            dw.bias_grad = self.m._g(bkey).data_ptr()
+            fused = bool(self.lib.ksmi_conv_wgrad_fuses_bias(C.byref(dw), self.dt))
+            if fused:
+                dw.bias_accumulate = self._acc_param(bkey)
+            else:
+                dw.bias_grad = None
+        self._wgrad(dw, ws, wkey, side_tag)
+        if bkey and fused:
+            self._mark(bkey)
+        elif bkey:
+            self._bias_grad(dy, rows, N, bkey)
 
     # ---------------------------------------------------------------- nn.LayerNorm
     def _ln(self, x, wkey, bkey, y, rows, Cc, eps=LN_EPS):
@@ -246,19 +267,33 @@ class PlanBase:
 
             def layer_bwd(li=li, a=a, f=f, x_in=x_in, h1=h1, qkv=qkv, att=att, x_mid=x_mid, h2=h2, u=u, g=g, lse=lse,
                           st1=st1, st2=st2, aflops=aflops):
+                # Side-stream weight gradients (side_tokens): the per-layer activations they read live until the next forward; the
+                # gradient buffers gx / tM / tQ are shared by all layers, so the launches that overwrite them wait for the reader:
+                #   ff2 (reads gx) before the LayerNorm backward that adds into gx; ff1 (reads tM) before the NEXT layer's ff2 input
+                #   gradient writes tM; to_out (reads gx) before the second LayerNorm backward; to_qkv (reads tQ) before the NEXT
+                #   layer's attention backward writes tQ.
+                nm = lambda k, l=li: f"{tag}{l}.{k}"
+                later = li + 1 < depth                    # the layer processed just before this one in the backward pass
                 # FeedForward: x_out = x_mid + W2 gelu(W1 LN(x_mid) + b1) + b2
-                self._linear_bwd(f"{tag}{li}.ff2", g, M, f"{f}.net.4.weight", f"{f}.net.4.bias", gx, D, R, tM)
+                self._linear_bwd(nm("ff2"), g, M, f"{f}.net.4.weight", f"{f}.net.4.bias", gx, D, R, tM, side_tag=nm("ff2"),
+                                 wait_tag=nm("ff1", li + 1) if later else None)
                 self.bwd.add("ksmi_gelu_backward", lambda: (tM.data_ptr(), u.data_ptr(), tM.data_ptr(), R * M, dt),
                              self._elt_meta("gelu_bwd", 3 * R * M))
-                self._linear_bwd(f"{tag}{li}.ff1", h2, D, f"{f}.net.1.weight", f"{f}.net.1.bias", tM, M, R, tD)
+                self._linear_bwd(nm("ff1"), h2, D, f"{f}.net.1.weight", f"{f}.net.1.bias", tM, M, R, tD, side_tag=nm("ff1"))
+                if self.side_tokens:
+                    self.bwd.add_wait_side(nm("ff2"))
                 self._ln_bwd(tD, x_mid, st2, f"{f}.net.0.weight", f"{f}.net.0.bias", gx, 1, R, D)
                 # Attention: x_mid = x_in + Wo attn(Wqkv LN(x_in)) + bo
-                self._linear_bwd(f"{tag}{li}.to_out", att, I, f"{a}.to_out.0.weight", f"{a}.to_out.0.bias", gx, D, R, tI)
+                self._linear_bwd(nm("to_out"), att, I, f"{a}.to_out.0.weight", f"{a}.to_out.0.bias", gx, D, R, tI, side_tag=nm("to_out"))
                 self.need("attn", self.lib.ksmi_attention_bwd_workspace(B, Ntok, heads, 64, dt))
+                if self.side_tokens and later:
+                    self.bwd.add_wait_side(nm("to_qkv", li + 1))
                 self.bwd.add("ksmi_attention_backward", lambda: (qkv.data_ptr(), att.data_ptr(), lse.data_ptr(), tI.data_ptr(),
                                                                  tQ.data_ptr(), self.scr("attn"), B, Ntok, heads, 64, scale, dt),
                              {"kind": "attention_bwd", "bytes": 8 * R * I * self._es(), "flops": 5 * aflops // 2})
-                self._linear_bwd(f"{tag}{li}.to_qkv", h1, D, f"{a}.to_qkv.weight", None, tQ, 3 * I, R, tD)
+                self._linear_bwd(nm("to_qkv"), h1, D, f"{a}.to_qkv.weight", None, tQ, 3 * I, R, tD, side_tag=nm("to_qkv"))
+                if self.side_tokens:
+                    self.bwd.add_wait_side(nm("to_out"))
                 self._ln_bwd(tD, x_in, st1, f"{a}.norm.weight", f"{a}.norm.bias", gx, 1, R, D)
             bwd_steps.append(layer_bwd)
         return X

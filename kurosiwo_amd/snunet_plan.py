@@ -35,8 +35,13 @@ class LaunchList:
     def add_wait(self, src, dst):
         self.pending.append(("@wait", lambda: (src, dst), {"kind": "wait", "bytes": 0, "flops": 0, "lane": dst}))
 
+    def add_wait_side(self, tag=None):
+        """the issuing lane waits for the side-stream launch that carries meta["side_tag"] == tag (None: for everything handed to the
+        side stream so far): placed before a launch that overwrites an operand of that weight gradient (plans that recycle buffers)"""
+        self.pending.append(("@wait_side", lambda: (tag,), {"kind": "wait", "bytes": 0, "flops": 0, "lane": self.cur_lane}))
+
     def resolve(self, lib):
-        self.calls = [(None if name == "@wait" else getattr(lib, name), tuple(argfn()), name, meta) for name, argfn, meta in self.pending]
+        self.calls = [(None if name.startswith("@") else getattr(lib, name), tuple(argfn()), name, meta) for name, argfn, meta in self.pending]
 
     def run(self, timer=None, hook=None, streams=None):
         """streams = StepStreams or None.  None: every launch on the current stream, in list order (always a valid order; the
@@ -51,7 +56,10 @@ class LaunchList:
         try:
             for idx, (fn, args, name, meta) in enumerate(self.calls):
                 if fn is None:
-                    if streams is not None and streams.lanes:
+                    if name == "@wait_side":
+                        if streams is not None and streams.use_side:
+                            streams.wait_side(args[0])
+                    elif streams is not None and streams.lanes:
                         streams.order(*args)
                     if hook is not None:
                         hook(idx)
@@ -65,6 +73,8 @@ class LaunchList:
                     timer.begin(meta["kind"], meta)
                 if streams is not None and streams.use_side and not timed and meta.get("side"):     # (a timed launch is bracketed by events on its lane's stream)
                     rc = fn(*args, streams.fork_side())
+                    if meta.get("side_tag") is not None:
+                        streams.mark_side(meta["side_tag"])
                 else:
                     rc = fn(*args, st)
                 if timed:
@@ -90,6 +100,8 @@ class StepStreams:
         self.side_ptr = C.c_void_p(self.side.cuda_stream)
         self.main = None
         self.dirty = False
+        self._live = []
+        self.events = {}           # side_tag -> event recorded behind that launch on the side stream (LaunchList.add_wait_side)
 
     def begin(self):
         if self.main is None:
@@ -98,18 +110,30 @@ class StepStreams:
     def stream(self, lane):
         return self.main if lane == 0 else self.lane1
 
-    def order(self, src, dst):
+    def _event(self, stream):
         ev = torch.cuda.Event()
-        ev.record(self.stream(src))
-        self.stream(dst).wait_event(ev)
+        ev.record(stream)
+        self._live.append(ev)          # kept until the step's join: no event is destroyed while a wait on it may still be pending
+        return ev
+
+    def order(self, src, dst):
+        self.stream(dst).wait_event(self._event(self.stream(src)))
         self.dirty = True
 
     def fork_side(self):
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream())
-        self.side.wait_event(ev)
+        self.side.wait_event(self._event(torch.cuda.current_stream()))
         self.dirty = True
         return self.side_ptr
+
+    def mark_side(self, tag):
+        self.events[tag] = self._event(self.side)
+
+    def wait_side(self, tag):
+        if tag is None:
+            if self.dirty:
+                torch.cuda.current_stream().wait_stream(self.side)
+        elif tag in self.events:
+            torch.cuda.current_stream().wait_event(self.events.pop(tag))
 
     def join(self):
         """the current stream waits for every other stream of the step"""
@@ -124,6 +148,8 @@ class StepStreams:
     def end(self):
         self.join()
         self.main = None
+        self.events.clear()
+        self._live.clear()
 
 
 class _Saved:

@@ -53,7 +53,7 @@ class _PlanTrainStep:
     _ss = None
 
     def _streams(self):
-        side = self.overlap_wgrad and getattr(self.plan, "side_wgrad", False)
+        side = self.overlap_wgrad and (getattr(self.plan, "side_wgrad", False) or getattr(self.plan, "side_tokens", False))
         lanes = self.overlap_lanes and getattr(self.plan, "two_lanes", False)
         if not (side or lanes):
             return None
@@ -65,7 +65,7 @@ class _PlanTrainStep:
     def _after_launch(self, idx):
         """bucket hook with more than one stream: a bucket that becomes ready may hold gradients written on any of them, so the
         all-reduce is issued behind all"""
-        if self.reducer.by_launch.get(idx):
+        if self.reducer.by_launch.get(idx) and (self.world > 1 or (os.environ.get("KSMI_DP_FORCE") and dist.is_initialized())):
             self._ss.join()
         self.reducer.after_launch(idx)
 
@@ -206,6 +206,22 @@ class MAETrainStep:
         self.plan.dloss.fill_(loss_scale)
         self.timer = None
 
+    # the nn.Linear weight gradients of the transformer layers on a side stream (plan_base.PlanBase.side_tokens; KSMI_OVERLAP_WGRAD=0: off)
+    _ss = None
+
+    def _streams(self):
+        if not (getattr(self.plan, "side_tokens", False) and os.environ.get("KSMI_OVERLAP_WGRAD", "1") != "0"):
+            return None
+        if self._ss is None:
+            from .snunet_plan import StepStreams
+            self._ss = StepStreams(self.plan.dev, lanes=False, side=True)
+        return self._ss
+
+    def _after_launch(self, idx):
+        if self.reducer.by_launch.get(idx) and (self.world > 1 or (os.environ.get("KSMI_DP_FORCE") and dist.is_initialized())):
+            self._ss.join()
+        self.reducer.after_launch(idx)
+
     def set_batch(self, image, rand_indices=None):
         self.plan.x.copy_(image, non_blocking=True)
         if rand_indices is not None:
@@ -218,7 +234,10 @@ class MAETrainStep:
             p.idx.copy_(torch.rand(self.B, p.N, device=p.dev).argsort(dim=-1))
         p.packs.run(t)
         p.fwd.run(t)
-        p.bwd.run(t, self.reducer.after_launch)
+        ss = self._streams()
+        p.bwd.run(t, self._after_launch if ss is not None else self.reducer.after_launch, ss)
+        if ss is not None:
+            ss.end()
         self.reducer.wait()
         mf = self.model
         on = t is not None and t.wants("optimizer")

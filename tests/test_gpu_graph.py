@@ -85,18 +85,24 @@ def _lane_case(family, B, S, overlap, graph):
         from kurosiwo_amd.bitcd import define_G
         m = define_G({"net_G": "base_resnet18"}, 2, precision="bf16").cuda().train()
         return m, CDTrainStep(m, B, S, S, "ce+dice", (1.0, 2.0, 3.0), **kw)
+    if family == "floodvit":            # token plan: tagged side-stream gradients behind explicit waits (plan_base.side_tokens)
+        from kurosiwo_amd.floodvit import FinetunerSegmentation, ViT
+        enc = ViT(image_size=S, patch_size=16, num_classes=1000, dim=1024, depth=6, heads=16, mlp_dim=2048, channels=2)
+        m = FinetunerSegmentation(enc, {"decoder": True, "num_classes": 3}, precision="bf16").cuda().train()
+        return m, SegTrainStep(m, B, "cross_entropy", (1.0, 2.0, 3.0), **kw)
     from kurosiwo_amd.unet import Unet
     m = Unet("resnet18", encoder_weights=None, in_channels=2, classes=3, precision="bf16").cuda().train()
     return m, SegTrainStep(m, B, "cross_entropy", (1.0, 2.0, 3.0), image_size=(S, S), **kw)
 
 
-@pytest.mark.parametrize("family,graph", [("snunet", False), ("snunet", True), ("bitcd", False), ("unet", False), ("unet", True)])
+@pytest.mark.parametrize("family,graph", [("snunet", False), ("snunet", True), ("bitcd", False), ("unet", False), ("unet", True),
+                                          ("floodvit", False), ("floodvit", True)])
 def test_side_lane_equals_single_stream(family, graph):
     """trainer.py overlap_wgrad / overlap_lanes: the weight-gradient launches run on a side stream and SNUNet's deeper decoder blocks on a
     second compute lane (snunet_plan.StepStreams); every kernel is deterministic, so a missing dependency edge would show up as a
     different trajectory -- it must equal the single-stream one bit for bit, eagerly and as a captured graph (fork / join become graph
     edges).  224 x 224 tiles: launches long enough to really overlap."""
-    B, S = 4, 224
+    B, S = (16, 224) if family == "floodvit" else (4, 224)       # the ViT at the benchmark's token count (3152 rows)
     data = _batches(5, B, 2, S, 21)
     out = []
     for overlap in (False, True):
@@ -104,12 +110,16 @@ def test_side_lane_equals_single_stream(family, graph):
         assert st.overlap_wgrad == overlap
         losses = []
         for xA, xB, y in data:
-            args = (xA.cuda(), y.cuda()) if family == "unet" else (xA.cuda(), xB.cuda(), y.cuda())
+            args = (xA.cuda(), y.cuda()) if family in ("unet", "floodvit") else (xA.cuda(), xB.cuda(), y.cuda())
             losses.append(st.step(*args).clone())
         torch.cuda.synchronize()
         if overlap:
             assert st._ss is not None and (st._graph is not None) == graph
             assert any(meta.get("side") for _, _, _, meta in st.plan.bwd.calls)
+            if family == "floodvit":
+                tags = [meta["side_tag"] for _, _, _, meta in st.plan.bwd.calls if meta.get("side_tag")]
+                waits = [args[0] for fn, args, name, _ in st.plan.bwd.calls if name == "@wait_side"]
+                assert len(tags) == 4 * 6 and set(waits) - {None} <= set(tags) and len([w for w in waits if w]) == 2 * 6 + 2 * 5
             if family == "snunet":
                 assert st._ss.lanes and any(meta["lane"] == 1 for _, _, _, meta in st.plan.fwd.calls + st.plan.bwd.calls)
         out.append((losses, m.flat_params.clone(), m.flat_grads.clone()))

@@ -125,3 +125,30 @@ def test_main_entry_mae_end_to_end_tiny(tmp_path, monkeypatch):
     with torch.no_grad():
         out = model(torch.randn(1, enc.hp["channels"], 224, 224, device="cuda"))
     assert out.shape == (1, 3, 224, 224) and torch.isfinite(out).all()
+
+
+def test_side_stream_weight_gradients_equal_single_stream(monkeypatch):
+    """MAETrainStep: the nn.Linear weight gradients of the encoder and decoder layers run on a side stream behind explicit waits
+    (plan_base.PlanBase.side_tokens); every kernel is deterministic, so a missing wait shows up as a different trajectory.  Same
+    permutations, same tiles, 4 steps at the benchmark's batch: parameters and gradients bit for bit."""
+    from kurosiwo_amd.trainer import MAETrainStep
+    hp = dict(image_size=224, patch_size=16, dim=1024, depth=4, heads=16, mlp_dim=2048, channels=2, decoder_dim=512, decoder_depth=3,
+              decoder_heads=16)
+    B = 32
+    g = torch.Generator().manual_seed(9)
+    data = [(torch.randn(B, 2, 224, 224, generator=g), torch.rand(B, 196, generator=g).argsort(dim=-1)) for _ in range(4)]
+    out = []
+    for overlap in ("0", "1"):
+        monkeypatch.setenv("KSMI_OVERLAP_WGRAD", overlap)
+        model, _ = build(hp, "bf16")
+        st = MAETrainStep(model, B, lr=1e-4)
+        losses = [st.step(x.cuda(), idx.cuda()).clone() for x, idx in data]
+        torch.cuda.synchronize()
+        assert (st._ss is not None) == (overlap == "1")
+        if overlap == "1":
+            tags = [meta["side_tag"] for _, _, _, meta in st.plan.bwd.calls if meta.get("side_tag")]
+            assert len(tags) == 4 * (4 + 3)
+        out.append((losses, model.flat_params.clone(), model.flat_grads.clone()))
+    for a, b in zip(out[0][0], out[1][0]):
+        assert torch.equal(a, b)
+    assert torch.equal(out[0][2], out[1][2]) and torch.equal(out[0][1], out[1][1])
