@@ -101,6 +101,7 @@ class StepStreams:
         self.main = None
         self.dirty = False
         self._live = []
+        self.side_busy = False
         self.events = {}           # side_tag -> event recorded behind that launch on the side stream (LaunchList.add_wait_side)
 
     def begin(self):
@@ -122,7 +123,7 @@ class StepStreams:
 
     def fork_side(self):
         self.side.wait_event(self._event(torch.cuda.current_stream()))
-        self.dirty = True
+        self.dirty = self.side_busy = True
         return self.side_ptr
 
     def mark_side(self, tag):
@@ -130,8 +131,9 @@ class StepStreams:
 
     def wait_side(self, tag):
         if tag is None:
-            if self.dirty:
+            if self.side_busy:                 # (nothing handed to the side stream since the last such wait: nothing to wait for)
                 torch.cuda.current_stream().wait_stream(self.side)
+                self.side_busy = False
         elif tag in self.events:
             torch.cuda.current_stream().wait_event(self.events.pop(tag))
 
@@ -150,6 +152,7 @@ class StepStreams:
         self.main = None
         self.events.clear()
         self._live.clear()
+        self.side_busy = False
 
 
 class _Saved:
