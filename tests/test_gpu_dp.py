@@ -123,7 +123,8 @@ def test_main_entry_under_torchrun_two_ranks(tmp_path):
     env = dict(os.environ, KSMI_SYNTHETIC_TILES="8,4,4", KSMI_DIST_BACKEND="gloo", PYTHONPATH=root, MASTER_ADDR="127.0.0.1")
     wrapper = tmp_path / "run_main.py"
     wrapper.write_text("import os, sys\nsys.path.insert(0, %r)\nimport main\nm = main.main(sys.argv[1:])\n"
-                       "print('RANK', os.environ['RANK'], 'MIOU', repr(float(m)), flush=True)\n" % root)
+                       # one write() per rank: print() issues one per argument and the two ranks share the pipe
+                       "sys.stdout.write('\\nRANK %%s MIOU %%r\\n' %% (os.environ['RANK'], float(m))); sys.stdout.flush()\n" % root)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), str(wrapper), "--method", "snunet", "--inputs", "pre_event_1", "post_event", "--batch_size", "4"]
     out = subprocess.run(cmd, cwd=tmp_path, env=env, capture_output=True, text=True, timeout=900)
