@@ -149,3 +149,65 @@ def test_shard_batch_python_lists_and_scalars():
     a = shard_batch((x, names, scales, flag), rank=1, world=4)
     assert a[0].tolist() == x[2:4].tolist() and a[1] == ["tile2", "tile3"]
     assert [t.tolist() for t in a[2]] == [[2.0, 3.0], [12.0, 13.0]] and int(a[3]) == 7
+
+
+def test_launch_list_orders_side_stream_gradients_behind_tagged_waits(monkeypatch):
+    """snunet_plan.LaunchList / StepStreams without a GPU: a launch tagged "side" goes to the side stream behind a fork and leaves a mark
+    under its side_tag; "@wait_side" entries make the issuing lane wait for exactly that mark (None: for the whole side stream, once);
+    without streams every entry runs in list order on the current stream and the waits are no-ops."""
+    from kurosiwo_amd import snunet_plan as sp
+    monkeypatch.setattr(sp, "stream_ptr", lambda: "MAIN")         # (the current HIP stream: no GPU here)
+
+    log = []
+
+    class Lib:
+        def ksmi_a(self, x, st):
+            log.append(("a", x, st))
+            return 0
+
+        def ksmi_w(self, x, st):
+            log.append(("w", x, st))
+            return 0
+
+    ll = sp.LaunchList()
+    ll.add("ksmi_a", lambda: (1,))
+    ll.add("ksmi_w", lambda: (2,), {"kind": "wgrad", "bytes": 0, "flops": 0, "side": True, "side_tag": "L0.ff2"})
+    ll.add("ksmi_a", lambda: (3,))
+    ll.add_wait_side("L0.ff2")
+    ll.add_wait_side("never-launched")
+    ll.add("ksmi_w", lambda: (4,), {"kind": "wgrad", "bytes": 0, "flops": 0, "side": True})
+    ll.add_wait_side(None)
+    ll.add_wait_side(None)
+    ll.resolve(Lib())
+    assert [c[2] for c in ll.calls] == ["ksmi_a", "ksmi_w", "ksmi_a", "@wait_side", "@wait_side", "ksmi_w", "@wait_side", "@wait_side"]
+    assert [c[0] is None for c in ll.calls] == [False, False, False, True, True, False, True, True]
+
+    class Streams:                       # the StepStreams surface LaunchList.run uses, recording instead of touching HIP
+        lanes, use_side = False, True
+
+        def __init__(self):
+            self.ops = []
+
+        def begin(self):
+            self.ops.append("begin")
+
+        def fork_side(self):
+            self.ops.append("fork")
+            return "SIDE"
+
+        def mark_side(self, tag):
+            self.ops.append(("mark", tag))
+
+        def wait_side(self, tag):
+            self.ops.append(("wait", tag))
+
+    hooked = []
+    ss = Streams()
+    ll.run(None, hooked.append, ss)
+    assert [(k, x) for k, x, _ in log] == [("a", 1), ("w", 2), ("a", 3), ("w", 4)]
+    assert [st for _, _, st in log][1] == "SIDE" and [st for _, _, st in log][3] == "SIDE" and log[0][2] != "SIDE"
+    assert ss.ops == ["begin", "fork", ("mark", "L0.ff2"), ("wait", "L0.ff2"), ("wait", "never-launched"), "fork", ("wait", None), ("wait", None)]
+    assert hooked == list(range(8))                      # the bucket hook sees every entry, waits included
+    del log[:]
+    ll.run()                                             # no streams: list order on the current stream
+    assert [(k, x) for k, x, _ in log] == [("a", 1), ("w", 2), ("a", 3), ("w", 4)] and all(st != "SIDE" for _, _, st in log)
