@@ -1,6 +1,7 @@
-"""Repeat the single-stream vs side-stream comparison of a token train step: python tools/race_probe.py mae|floodvit [repeats] [delay]
-delay: every step first parks the side stream behind a ~10 ms spin kernel, so the main stream runs as far ahead of the weight gradients
-as its waits allow -- a missing wait then shows up as a different trajectory instead of depending on launch timing."""
+"""Repeat the single-stream vs side-stream comparison of a token train step: python tools/race_probe.py mae|floodvit [repeats] [delay] [nowait]
+delay: every step first parks the side stream behind a ~10 ms spin kernel and every side-stream launch behind a ~150 us one, so the
+main stream runs as far ahead of each weight gradient as its waits allow -- a missing wait then shows up as a different trajectory
+instead of depending on launch timing."""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,11 +10,24 @@ import torch
 
 fam, reps = sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 6
 delay = len(sys.argv) > 3
+nowait = len(sys.argv) > 4            # negative control: drop the tagged waits -> the comparison must fail
 
 
 def stepper(st):
     def go(*a):
         ss = st._streams()
+        if delay and ss is not None and not hasattr(ss, "_slow"):
+            # every launch handed to the side stream first spins ~150 us there (and the whole stream ~10 ms at the start of a step)
+            fork = ss.fork_side
+
+            def slow_fork():
+                ptr = fork()
+                with torch.cuda.stream(ss.side):
+                    torch.cuda._sleep(350_000)
+                return ptr
+            ss.fork_side, ss._slow = slow_fork, True
+            if nowait:
+                ss.wait_side = lambda tag: None
         if delay and ss is not None:
             with torch.cuda.stream(ss.side):
                 torch.cuda._sleep(25_000_000)
