@@ -100,7 +100,6 @@ class StepStreams:
         self.side_ptr = C.c_void_p(self.side.cuda_stream)
         self.main = None
         self.dirty = False
-        self._live = []
         self.side_busy = False
         self.events = {}           # side_tag -> event recorded behind that launch on the side stream (LaunchList.add_wait_side)
 
@@ -114,7 +113,6 @@ class StepStreams:
     def _event(self, stream):
         ev = torch.cuda.Event()
         ev.record(stream)
-        self._live.append(ev)          # kept until the step's join: no event is destroyed while a wait on it may still be pending
         return ev
 
     def order(self, src, dst):
@@ -151,7 +149,6 @@ class StepStreams:
         self.join()
         self.main = None
         self.events.clear()
-        self._live.clear()
         self.side_busy = False
 
 
