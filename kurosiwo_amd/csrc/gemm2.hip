@@ -265,12 +265,13 @@ inline Tile2 pick_tile(int rows, int ntiles) {
       {4, 2, 512, 19.0}, {7, 3, 256, 21.0}, {8, 3, 256, 23.0}};
   Tile2 best = {4, 3}; double bc = 1e30;
   for (const auto& c : cand) {
+    // a pinned depth of 2 or 3 selects among the candidates; the deeper, probe-only rings are applied to whatever tile wins
     if ((f_mt && c.mt != f_mt) || (f_ns && f_ns <= 3 && c.ns != f_ns)) continue;
     const long wgs = (long)((rows + 32 * c.mt - 1) / (32 * c.mt)) * ntiles;
     const double cost = (double)((wgs + c.slots - 1) / c.slots) * c.round_us;
     if (cost < bc) { bc = cost; best = {c.mt, c.ns}; }
   }
-  if (f_mt && bc == 1e30) best = {f_mt, f_mt >= 5 ? 3 : 2};
+  if (f_mt && bc == 1e30) best = {f_mt, f_mt >= 5 ? 3 : 2};      // a pinned pair that is not a candidate (tests: every instance)
   if (f_ns) best.ns = f_ns;
   return best;
 }
