@@ -127,8 +127,20 @@ class ArenaModule(nn.Module):
         return self.flat_grads[self._poff[key]:self._poff[key] + _numel(self._pspec[key])]
 
     # ---- random stream of the stochastic layers (nn.Dropout / DropPath / nn.Dropout2d of the reference models; csrc/common.h)
-    def manual_seed(self, seed, step=0):
-        """pin the counter-based stream: the next training forward uses (seed, step + 1)"""
+    @staticmethod
+    def _fold_rank(seed):
+        # every rank runs with the same torch seed (same loader shuffle): fold the rank into the stream so that sample i of
+        # rank 0 and sample i of rank 1 draw different Dropout / DropPath masks (rank 0's folded seed is the base seed itself)
+        rank = 0
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            rank = torch.distributed.get_rank()
+        return (int(seed) ^ (0x9E3779B1 * rank)) & 0xFFFFFFFF
+
+    def manual_seed(self, seed, step=0, fold_rank=False):
+        """pin the counter-based stream: the next training forward uses (seed, step + 1).  fold_rank: `seed` is a BASE seed (what a
+        checkpoint written by rank 0 holds) and this rank's share of the stream is derived from it, as the default seed is"""
+        if fold_rank:
+            seed = self._fold_rank(seed)
         self._rng_init = (int(seed) & 0xFFFFFFFF, int(step) & 0xFFFFFFFF)
         if getattr(self, "_rng_state", None) is not None:
             self._rng_state.copy_(_as_i32(self._rng_init))
@@ -140,12 +152,7 @@ class ArenaModule(nn.Module):
         dev = self.flat_params.device
         if getattr(self, "_rng_state", None) is None or self._rng_state.device != dev:
             if getattr(self, "_rng_init", None) is None:
-                # every rank runs with the same torch seed (same loader shuffle): fold the rank into the stream so that sample i of
-                # rank 0 and sample i of rank 1 draw different Dropout / DropPath masks
-                rank = 0
-                if torch.distributed.is_available() and torch.distributed.is_initialized():
-                    rank = torch.distributed.get_rank()
-                self._rng_init = ((torch.initial_seed() ^ (0x9E3779B1 * rank)) & 0xFFFFFFFF, 0)
+                self._rng_init = (self._fold_rank(torch.initial_seed()), 0)
             self._rng_state = _as_i32(self._rng_init).to(dev)
         return self._rng_state
 

@@ -125,6 +125,7 @@ const char* parse(const Reader& r0, Layout* L) {
     e.count = r.big ? r.u64(o + 4) : r.u32(o + 4);
     const int ts = type_size(e.type);
     if (!ts) continue;                               // unknown field type: skip the field (TIFF 6.0 §2)
+    if (e.count > r.n / (uint64_t)ts) return "a field is larger than the file";       // (also keeps count * size from wrapping)
     const uint64_t bytes = e.count * ts, inl = r.big ? 8 : 4, vpos = o + (r.big ? 12 : 8);
     e.data = bytes <= inl ? vpos : (r.big ? r.u64(vpos) : r.u32(vpos));
     if (!r.ok(e.data, bytes)) return "a field points outside the file";
@@ -166,7 +167,7 @@ const char* parse(const Reader& r0, Layout* L) {
         break;
       case 42113: {
         char buf[64] = {0};
-        const size_t m = e.count < 63 ? (size_t)e.count : 63;
+        const size_t m = bytes < 63 ? (size_t)bytes : 63;   // `bytes` is the length r.ok() validated above
         memcpy(buf, r.p + e.data, m);
         char* end = nullptr;
         const double nd = strtod(buf, &end);                // "nan" parses to NaN
@@ -381,6 +382,7 @@ std::string decode_file_(const char* path, float* out_f32, uint8_t* out_raw, int
     return "tile of " + std::to_string(I.bands) + " x " + std::to_string(I.height) + " x " + std::to_string(I.width) + ", expected " +
            std::to_string(want_bands) + " x " + std::to_string(want_h) + " x " + std::to_string(want_w) + ": " + path;
   const int64_t H = I.height, W = I.width, Bn = I.bands;
+  if (H > (1 << 20) || W > (1 << 20)) return std::string("implausible image size: ") + path;     // (Bn <= 64: the product below cannot wrap)
   if (cap_elems < Bn * H * W) return std::string("output buffer too small: ") + path;
   const int bps = I.bits / 8;
   const int spp = L.planar == 1 ? (int)Bn : 1;                 // samples per pixel inside one chunk

@@ -30,13 +30,15 @@ def make_buckets(ready_index, offsets, numels, total, bucket_elems):
 
 
 def default_grad_dtype(numel):
-    """wire format of the gradient buckets: "bf16" halves the bytes a ring moves over xGMI (7 links x ~153 GB/s per GPU, per-link
-    bound).  Default: bf16 above 256 MB of fp32 gradients (FloodViT 822 MB: ring all-reduce ~9.4 ms fp32 against a ~15 ms step), fp32
-    below (SNUNet 48 MB, ChangeFormer 164 MB: hidden behind backward either way).  KSMI_DP_GRAD_DTYPE=fp32|bf16 overrides."""
+    """wire format of the gradient buckets.  Default fp32 (what the reference's optimiser would see from a DDP reduction); "bf16" is
+    opt-in (configs["dp_grad_dtype"] / KSMI_DP_GRAD_DTYPE=bf16): it halves the bytes a ring moves over xGMI (7 links x ~153 GB/s per
+    GPU, per-link bound; FloodViT 822 MB of fp32 gradients: ring all-reduce ~9.4 ms against a ~14 ms step) but sums in bf16 and
+    overwrites the local fp32 gradients with the rounded sums, so it stays off until a world > 1 K-step gate has passed on hardware
+    (tests/test_gpu_dp.py::test_two_gpu_*).  For large arenas prefer mode="rs_ag" (BucketedAllReduce), which keeps fp32."""
     env = os.environ.get("KSMI_DP_GRAD_DTYPE")
     if env in ("fp32", "bf16"):
         return env
-    return "bf16" if numel * 4 > 256e6 else "fp32"
+    return "fp32"
 
 
 class BucketedAllReduce:

@@ -37,7 +37,8 @@ def initialize_cd_model(configs, model_configs, phase="train"):
         ck = torch.load(configs["resume_checkpoint"], map_location=configs["device"])
         model.load_state_dict(ck["model_state_dict"])
         if ck.get("rng_state") and hasattr(model, "manual_seed"):          # continue the Dropout / DropPath stream of the saved run
-            model.manual_seed(ck["rng_state"][0], ck["rng_state"][1])
+            # (the words were saved by rank 0, whose seed is the base seed: every rank re-derives its own share)
+            model.manual_seed(ck["rng_state"][0], ck["rng_state"][1], fold_rank=True)
     print(model.__class__.__name__, f"({sum(p.numel() for p in model.parameters())} parameters, precision={model.precision})")
     return model
 

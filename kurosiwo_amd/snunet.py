@@ -86,6 +86,7 @@ class SNUNet_ECAM(nn.Module):
         self._plans = {}
         self._anchor = None
         self._raw_norm = None
+        self._raw_version = 0          # bumped whenever the pipeline values change: part of the plan cache key
 
     # ------------------------------------------------------------------ raw-tile input
     def set_input_pipeline(self, mean=None, std=None, clamp=None):
@@ -94,6 +95,8 @@ class SNUNet_ECAM(nn.Module):
         `mean`, `std`: per input channel; `clamp`: a float (every channel) or per channel, a negative entry = no clamp for that
         channel (DEM: NaN -> mean).  set_input_pipeline() with no arguments returns to normalised inputs."""
         if mean is None:
+            if self._raw_norm is not None:
+                self._drop_raw_plans()
             self._raw_norm = None
             return self
         mean = [float(v) for v in mean]
@@ -105,8 +108,14 @@ class SNUNet_ECAM(nn.Module):
             raise ValueError("set_input_pipeline: a zero standard deviation")
         new = torch.tensor([mean, std, clamp], dtype=torch.float32)
         if self._raw_norm is None or not torch.equal(self._raw_norm.cpu(), new):       # (same values: the plans built on them stay valid)
+            self._drop_raw_plans()                 # plans hold raw device pointers into the old tensor
             self._raw_norm = new
+            self._raw_version += 1
         return self
+
+    def _drop_raw_plans(self):
+        for k in [k for k in self._plans if k[6] is not None]:
+            del self._plans[k]
 
     def _raw_ptrs(self, dev):
         """(mean, std, clamp) device pointers for the first conv, or three nulls"""
@@ -244,10 +253,15 @@ class SNUNet_ECAM(nn.Module):
     # ------------------------------------------------------------------ forward
     def plan(self, B, H, W, training, with_backward, tail=0):
         self._ensure_arena()
-        key = (B, H, W, self.act_dtype(), bool(training), bool(with_backward), None if self._raw_norm is None else id(self._raw_norm), tail)
+        # the key carries a version counter, not id(tensor): _raw_ptrs() moves the tensor to the device (a new object), and a freed
+        # tensor's id can be handed out again
+        key = (B, H, W, self.act_dtype(), bool(training), bool(with_backward), None if self._raw_norm is None else self._raw_version, tail)
         if key not in self._plans:
             from .snunet_plan import SNUNetPlan
-            self._plans[key] = SNUNetPlan(self, B, H, W, self.act_dtype(), training, with_backward, tail=tail)
+            plan = SNUNetPlan(self, B, H, W, self.act_dtype(), training, with_backward, tail=tail)
+            if self._raw_norm is not None:
+                plan.keep.append(self._raw_norm)   # the plan's launches hold data_ptr()s into it
+            self._plans[key] = plan
         return self._plans[key]
 
     def forward(self, xA, xB, dem=None):

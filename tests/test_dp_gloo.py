@@ -80,13 +80,14 @@ def test_bucketed_allreduce_world2_gloo(grad_dtype):
         assert order == [(1, 1000, 1200), (3, 300, 1000), (9, 0, 300)], order
 
 
-def test_default_wire_format_by_arena_size(monkeypatch):
+def test_default_wire_format_is_fp32_and_bf16_is_opt_in(monkeypatch):
+    """the reference's optimiser sees fp32 sums; the bf16 wire format changes optimiser numerics and is opt-in only"""
     from kurosiwo_amd.dp import default_grad_dtype
     monkeypatch.delenv("KSMI_DP_GRAD_DTYPE", raising=False)
-    assert default_grad_dtype(12_034_819) == "fp32" and default_grad_dtype(41_035_255) == "fp32"      # SNUNet, ChangeFormer
-    assert default_grad_dtype(205_600_000) == "bf16"                                                   # FloodViT: 822 MB of fp32 gradients
-    monkeypatch.setenv("KSMI_DP_GRAD_DTYPE", "fp32")
-    assert default_grad_dtype(205_600_000) == "fp32"
+    for n in (12_034_819, 41_035_255, 205_600_000):                 # SNUNet, ChangeFormer, FloodViT
+        assert default_grad_dtype(n) == "fp32"
+    monkeypatch.setenv("KSMI_DP_GRAD_DTYPE", "bf16")
+    assert default_grad_dtype(205_600_000) == "bf16"
 
 
 def test_single_process_is_a_noop():
