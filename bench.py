@@ -170,13 +170,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    # KSMI_DIST_BACKEND=gloo: the same ranks with the collectives on the CPU backend (several ranks may then share one GPU): the
+    # comparison run of tests/test_gpu_dp.py::test_two_gpus_* -- never the measured configuration
+    backend = os.environ.get("KSMI_DIST_BACKEND", "nccl")
+    local = local % torch.cuda.device_count() if backend == "gloo" else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
     if world > 1 or os.environ.get("KSMI_DP_FORCE"):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "gloo":
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    cdev = torch.device("cpu") if backend == "gloo" else dev          # where the small bookkeeping collectives live
 
     from kurosiwo_amd.synthetic import cd_inputs, make_batch, seg_inputs
 
@@ -318,10 +326,22 @@ def main():
         sync()
         step.timer, (step.overlap_wgrad, step.overlap_lanes) = timer, keep
         solo = solo_timer.summary().get(dominant)
+    dp_check = None
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax)
+        # data-parallel self-check: every rank started from the same parameters and applied the same averaged gradients, so the
+        # parameter arenas must agree bit for bit (an integer checksum of the fp32 words) although every rank saw different tiles
+        fp = step.model.flat_params
+        mine = torch.stack([fp.view(torch.int32).to(torch.int64).sum(), torch.isfinite(fp).all().to(torch.int64),
+                            step.loss_out.detach().double().mul(1e9).round().to(torch.int64)[0]]).to(cdev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        dp_check = {"ranks": world, "backend": backend, "params_equal": all(int(e[0]) == int(every[0][0]) for e in every),
+                    "params_finite": all(int(e[1]) == 1 for e in every), "param_checksum": int(every[0][0]),
+                    "rank_losses": [int(e[2]) / 1e9 for e in every],
+                    "grad_wire": step.reducer.grad_dtype, "dp_mode": step.reducer.mode}
     loss = step.loss_out.cpu().tolist()
 
     if rank == 0:
@@ -342,7 +362,7 @@ def main():
             "config": {"workload": workload + ("+RCCL all-reduce" if world > 1 else "") + (" [HIP graph replay]" if graph else ""),
                        "global_batch": B * world, "base_channel": args.base_channel, "parallelism": f"dp{world}",
                        "hip_streams": n_streams,
-                       "loss_last": [round(x, 5) for x in loss]},
+                       "loss_last": [round(x, 5) for x in loss]} | ({"dp_check": dp_check} if dp_check else {}),
             # the roofline that bounds the dominant kernel class: the larger of bytes / HBM peak and flops / MFMA peak
             "roofline": ({"kernel": dominant, "bound": "mfma", "achieved": round(ach_tf, 1), "peak": MFMA_BF16_PEAK_TF,
                           "unit": "TFLOP/s", "frac": round(ach_tf / MFMA_BF16_PEAK_TF, 4)}

@@ -43,9 +43,10 @@ def prepare_loaders(configs):
     archive = archive_kind(configs)
     if archive is not None:
         return _archive_loaders(configs, archive, bs, workers)
+    from . import distributed as D
     ds = {m: SyntheticCDDataset(m, configs) for m in ("train", "val", "test")}
-    mk = lambda m, shuffle, drop: torch.utils.data.DataLoader(ds[m], batch_size=bs, shuffle=shuffle, num_workers=workers,
-                                                              pin_memory=True, drop_last=drop)
+    # (world > 1: every rank loads only its slice of each global batch, distributed.RankShardBatchSampler)
+    mk = lambda m, shuffle, drop: D.make_loader(ds[m], bs, shuffle, drop, workers, seed=configs.get("seed", 999))
     tr, va, te = mk("train", True, True), mk("val", False, False), mk("test", False, False)
     print("Samples in Train Set: ", len(ds["train"]))
     print("Samples in Val Set: ", len(ds["val"]))
@@ -97,8 +98,7 @@ def _archive_loaders(configs, kind, bs, workers):
                                                          threads=_loader_threads(configs, D.world_size()), rank=D.get_rank(), world=D.world_size(),
                                                          seed=configs.get("seed", 999) if shuffle else None)
     else:
-        mk = lambda m, shuffle, drop: torch.utils.data.DataLoader(ds[m], batch_size=bs, shuffle=shuffle, num_workers=workers,
-                                                                  pin_memory=True, drop_last=drop)
+        mk = lambda m, shuffle, drop: D.make_loader(ds[m], bs, shuffle, drop, workers, seed=configs.get("seed", 999))
     tr, va, te = mk("train", True, True), mk("val", False, False), mk("test", False, False)
     print("Samples in Train Set: ", len(ds["train"]))
     print("Samples in Val Set: ", len(ds["val"]))

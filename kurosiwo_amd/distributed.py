@@ -85,6 +85,59 @@ def shard_batch(batch, rank=None, world=None, even=True):
     return tuple(cut(t) for t in batch)
 
 
+class RankShardBatchSampler(torch.utils.data.Sampler):
+    """batch_sampler of the DataLoader route under data parallelism: every rank draws the SAME global order (one seeded permutation
+    per epoch when shuffling: what a single process with this seed would iterate) and loads ONLY its contiguous slice
+    [r*B/W, (r+1)*B/W) of every global batch, instead of every rank decoding all B samples and distributed.shard_batch throwing
+    (W-1)/W of them away.  drop_last as utilities/utilities.py:96-103 (train); a ragged last batch (evaluation) is cut the way
+    shard_batch(even=False) cuts it: rank r takes [n*r//W, n*(r+1)//W), possibly empty (the loader then skips nothing: an empty
+    slice still yields an empty list so that every rank runs the same number of iterations)."""
+
+    def __init__(self, n, batch_size, shuffle, drop_last, rank, world, seed=999):
+        self.n, self.bs, self.shuffle, self.drop_last = int(n), int(batch_size), bool(shuffle), bool(drop_last)
+        self.rank, self.world, self.seed, self.epoch = int(rank), int(world), int(seed), 0
+        if self.drop_last and self.bs % self.world:
+            raise ValueError(f"global batch {self.bs} is not divisible by world size {self.world}")
+
+    def set_epoch(self, epoch):
+        self.epoch = int(epoch)
+
+    def __len__(self):
+        return self.n // self.bs if self.drop_last else -(-self.n // self.bs)
+
+    def __iter__(self):
+        if self.shuffle:
+            g = torch.Generator()
+            g.manual_seed(self.seed + self.epoch)
+            order = torch.randperm(self.n, generator=g).tolist()
+            self.epoch += 1
+        else:
+            order = list(range(self.n))
+        for b in range(len(self)):
+            idx = order[b * self.bs:(b + 1) * self.bs]
+            m = len(idx)
+            yield idx[m * self.rank // self.world:m * (self.rank + 1) // self.world]
+
+
+def sharded_collate(samples):
+    """default_collate of this rank's slice, tagged so that shard_batch passes it through"""
+    from .dataset import ShardedBatch
+    if not samples:
+        return ShardedBatch(())
+    return ShardedBatch(torch.utils.data.default_collate(samples))
+
+
+def make_loader(dataset, batch_size, shuffle, drop_last, num_workers=0, seed=999, pin_memory=True):
+    """the reference's DataLoader (utilities/utilities.py:96-121) for one process; under data parallelism the rank-strided form"""
+    world = world_size()
+    if world == 1:
+        return torch.utils.data.DataLoader(dataset, batch_size=batch_size, shuffle=shuffle, num_workers=num_workers,
+                                           pin_memory=pin_memory, drop_last=drop_last)
+    sampler = RankShardBatchSampler(len(dataset), batch_size, shuffle, drop_last, get_rank(), world, seed)
+    return torch.utils.data.DataLoader(dataset, batch_sampler=sampler, num_workers=num_workers, pin_memory=pin_memory,
+                                       collate_fn=sharded_collate)
+
+
 def all_reduce_sum_(*tensors):
     """In-place SUM over the ranks (confusion matrices, loss / sample counters)."""
     if world_size() > 1:

@@ -41,15 +41,34 @@ def default_grad_dtype(numel):
     return "fp32"
 
 
+def default_mode():
+    """collective per bucket: "all_reduce" (default) or "rs_ag" = reduce-scatter + all-gather of the bucket in place (SURVEY.md §5 /
+    §8(e): every rank reduces 1/W of the bucket, so on the fully connected xGMI node both phases can use all 7 links of a GPU instead
+    of a ring's one; fp32 on the wire, same sums).  configs["dp_mode"] / KSMI_DP_MODE select it."""
+    env = os.environ.get("KSMI_DP_MODE")
+    return env if env in ("all_reduce", "rs_ag") else "all_reduce"
+
+
 class BucketedAllReduce:
     """grad_dtype = "bf16": a bucket is cast into a bf16 staging buffer behind its last writer, the staging buffer is all-reduced (SUM
     in bf16 on the wire and in RCCL's reduction), and wait() casts the sums back into the fp32 arena the optimiser reads; the fp32
-    master gradients of the local rank are lost to that rounding too (every rank ends with the same bits)."""
+    master gradients of the local rank are lost to that rounding too (every rank ends with the same bits).
 
-    def __init__(self, flat_grads, buckets, group=None, grad_dtype="fp32"):
+    mode = "rs_ag": reduce_scatter_tensor + all_gather_into_tensor on the bucket in place (the leading len - len % W elements; the
+    < W tail elements ride on a small all-reduce); gloo has no reduce-scatter, there the mode degenerates to all-reduce.
+
+    Streams: a bucket may hold gradients written on any stream of the step (compute lanes, weight-gradient side stream).  With
+    `writer_streams` given (StepStreams.all_streams) the collective is issued from a dedicated issue stream that waits for an event
+    recorded on each of them, so that no compute stream ever waits for another one because a bucket became ready; without it the
+    collective is issued on the current stream (single-stream steps)."""
+
+    def __init__(self, flat_grads, buckets, group=None, grad_dtype="fp32", mode=None):
         self.flat, self.group = flat_grads, group
         self.buckets = buckets
         self.grad_dtype = grad_dtype
+        self.mode = mode or default_mode()
+        if self.mode not in ("all_reduce", "rs_ag"):
+            raise ValueError(f"dp mode {self.mode!r}: all_reduce | rs_ag")
         self.stage = torch.empty(flat_grads.numel(), dtype=torch.bfloat16, device=flat_grads.device) if grad_dtype == "bf16" else None
         self.staged = []
         self.by_launch = {}
@@ -57,16 +76,53 @@ class BucketedAllReduce:
             self.by_launch.setdefault(b[2], []).append(b)
         self.handles = []
         self.issued = []
+        self.issue_stream = None
+        self.writer_streams = None         # callable -> streams whose work a ready bucket may depend on
 
     def world(self):
         return dist.get_world_size(self.group) if dist.is_initialized() else 1
 
+    def active(self):
+        return self.world() > 1 or (_FORCE and dist.is_initialized())
+
+    def _collective(self, t):
+        """SUM of `t` over the ranks, in place, asynchronously; returns the handles"""
+        W = self.world()
+        if self.mode == "rs_ag" and dist.get_backend(self.group) != "gloo":
+            n = t.numel() - t.numel() % W
+            hs = []
+            if n:
+                r = dist.get_rank(self.group)
+                shard = t[r * (n // W):(r + 1) * (n // W)]
+                hs.append(dist.reduce_scatter_tensor(shard, t[:n], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                hs.append(dist.all_gather_into_tensor(t[:n], shard, group=self.group, async_op=True))
+            if n < t.numel():
+                hs.append(dist.all_reduce(t[n:], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            return hs
+        return [dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)]
+
+    def _issue(self, fn):
+        """run fn() (which enqueues the casts / collectives of one bucket) on the issue stream behind every writer stream"""
+        streams = self.writer_streams() if self.writer_streams is not None else None
+        if not streams or not self.flat.is_cuda:
+            return fn()
+        if self.issue_stream is None:
+            self.issue_stream = torch.cuda.Stream(device=self.flat.device)
+        for s in streams:
+            ev = torch.cuda.Event()
+            ev.record(s)
+            self.issue_stream.wait_event(ev)
+        with torch.cuda.stream(self.issue_stream):
+            return fn()
+
     def after_launch(self, idx):
         for (s, e, _) in self.by_launch.get(idx, ()):
             self.issued.append((s, e))
-            if self.world() > 1 or (_FORCE and dist.is_initialized()):
+            if self.active():
                 view = self.flat[s:e]
                 if dist.get_backend(self.group) == "gloo" and view.is_cuda:       # CPU-backend tests with device gradients
+                    for st in (self.writer_streams() if self.writer_streams is not None else ()):
+                        st.synchronize()
                     torch.cuda.current_stream().synchronize()
                     host = view.cpu()
                     if self.stage is not None:                                   # same wire rounding as the device path
@@ -75,11 +131,14 @@ class BucketedAllReduce:
                     view.copy_(host)
                 elif self.stage is not None:
                     st = self.stage[s:e]
-                    st.copy_(view)                                               # fp32 -> bf16 on the issuing stream, behind the last writer
-                    self.handles.append(dist.all_reduce(st, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+                    def go(st=st, view=view):
+                        st.copy_(view)                                           # fp32 -> bf16 behind the last writer
+                        return self._collective(st)
+                    self.handles += self._issue(go)
                     self.staged.append((s, e))
                 else:
-                    self.handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                    self.handles += self._issue(lambda view=view: self._collective(view))
 
     def flush(self):
         """issue every bucket that has not been issued yet (a bucket whose readiness index was never reached: a parameter
@@ -93,9 +152,12 @@ class BucketedAllReduce:
             del self.by_launch[-2]
 
     def wait(self):
+        """the current stream continues behind every collective of the step"""
         self.flush()
         for h in self.handles:
             h.wait()
+        if self.issue_stream is not None and self.handles:
+            torch.cuda.current_stream().wait_stream(self.issue_stream)
         for (s, e) in self.staged:
             self.flat[s:e].copy_(self.stage[s:e])                                # bf16 sums -> the fp32 arena
         self.handles = []

@@ -135,6 +135,10 @@ class StepStreams:
         elif tag in self.events:
             torch.cuda.current_stream().wait_event(self.events.pop(tag))
 
+    def all_streams(self):
+        """every stream a launch of the step may have run on"""
+        return [s for s in (self.main, self.lane1 if self.lanes else None, self.side if self.use_side else None) if s is not None]
+
     def join(self):
         """the current stream waits for every other stream of the step"""
         if self.dirty:

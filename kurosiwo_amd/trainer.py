@@ -18,7 +18,7 @@ class _PlanTrainStep:
     """zero_grad -> forward -> criterion -> backward (+ bucketed all-reduce) -> optimizer.step over a model plan."""
 
     def __init__(self, model, plan, B, H, W, loss_function="ce+dice", class_weights=(1.0, 1.0, 1.0), optimizer=None, lr=1e-3,
-                 bucket_mb=8.0, group=None, graph=False, overlap_wgrad=True, overlap_lanes=True, grad_dtype=None):
+                 bucket_mb=8.0, group=None, graph=False, overlap_wgrad=True, overlap_lanes=True, grad_dtype=None, dp_mode=None):
         if loss_function not in ("ce+dice", "cross_entropy"):
             raise NotImplementedError(loss_function)
         self.model = model
@@ -37,7 +37,11 @@ class _PlanTrainStep:
         ready = {k: self.plan.param_ready.get(k, -1) for k in model._poff}
         buckets = make_buckets(ready, model._poff, None, n, int(bucket_mb * 1e6 / 4))
         self.grad_dtype = grad_dtype or default_grad_dtype(n)          # wire format of the gradient buckets (dp.py)
-        self.reducer = BucketedAllReduce(model.flat_grads, buckets, group, self.grad_dtype if self.world > 1 or os.environ.get("KSMI_DP_FORCE") else "fp32")
+        self.reducer = BucketedAllReduce(model.flat_grads, buckets, group, self.grad_dtype if self.world > 1 or os.environ.get("KSMI_DP_FORCE") else "fp32",
+                                         mode=dp_mode)
+        # a ready bucket may hold gradients written on any stream of the step: the reducer's issue stream waits for an event on each
+        # of them (no compute stream is made to wait for another one because a bucket became ready)
+        self.reducer.writer_streams = self._writer_streams
         self.timer = None          # optional kernel timer (bench.py)
         self.use_graph = bool(graph) and self.world == 1     # replay the step as one captured HIP graph (configs["hip_graph"])
         self.overlap_wgrad = bool(overlap_wgrad) and os.environ.get("KSMI_OVERLAP_WGRAD", "1") != "0"
@@ -62,11 +66,14 @@ class _PlanTrainStep:
             self._ss = StepStreams(self.plan.dev, lanes=lanes, side=side)
         return self._ss
 
+    def _writer_streams(self):
+        ss = self._ss
+        if ss is None or ss.main is None:
+            return [torch.cuda.current_stream()]
+        return ss.all_streams()
+
     def _after_launch(self, idx):
-        """bucket hook with more than one stream: a bucket that becomes ready may hold gradients written on any of them, so the
-        all-reduce is issued behind all"""
-        if self.reducer.by_launch.get(idx) and (self.world > 1 or (os.environ.get("KSMI_DP_FORCE") and dist.is_initialized())):
-            self._ss.join()
+        """bucket hook of the backward launch list (the reducer orders its collective behind every stream of the step itself)"""
         self.reducer.after_launch(idx)
 
     def set_batch(self, *args):
@@ -191,7 +198,7 @@ class MAETrainStep:
     """training/train_mae.py:62-122 on the MAE plan: step(image) = zero_grad -> mae(image) (fresh random permutation,
     models/mae.py:73) -> backward (+ bucketed all-reduce) -> Adam, as one launch sequence.  loss_out[0] = reconstruction loss."""
 
-    def __init__(self, model, B, optimizer=None, lr=1e-5, bucket_mb=32.0, group=None, loss_scale=1.0, grad_dtype=None):
+    def __init__(self, model, B, optimizer=None, lr=1e-5, bucket_mb=32.0, group=None, loss_scale=1.0, grad_dtype=None, dp_mode=None):
         self.model, self.B = model, B
         self.lib = _lib.load()
         self.plan = model.plan(B, True)
@@ -201,7 +208,9 @@ class MAETrainStep:
         ready = {k: self.plan.param_ready.get(k, -1) for k in model._poff}
         self.grad_dtype = grad_dtype or default_grad_dtype(n)
         self.reducer = BucketedAllReduce(model.flat_grads, make_buckets(ready, model._poff, None, n, int(bucket_mb * 1e6 / 4)), group,
-                                         self.grad_dtype if self.world > 1 or os.environ.get("KSMI_DP_FORCE") else "fp32")
+                                         self.grad_dtype if self.world > 1 or os.environ.get("KSMI_DP_FORCE") else "fp32", mode=dp_mode)
+        self.reducer.writer_streams = lambda: ([torch.cuda.current_stream()] if self._ss is None or self._ss.main is None
+                                               else self._ss.all_streams())
         self.loss_out = self.plan.loss
         self.plan.dloss.fill_(loss_scale)
         self.timer = None
@@ -218,8 +227,6 @@ class MAETrainStep:
         return self._ss
 
     def _after_launch(self, idx):
-        if self.reducer.by_launch.get(idx) and (self.world > 1 or (os.environ.get("KSMI_DP_FORCE") and dist.is_initialized())):
-            self._ss.join()
         self.reducer.after_launch(idx)
 
     def set_batch(self, image, rand_indices=None):

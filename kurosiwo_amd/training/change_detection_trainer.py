@@ -114,7 +114,7 @@ def train_change_detection(model, train_loader, val_loader, test_loader, configs
             if step is None or step.B != xA.shape[0]:
                 step = CDTrainStep(model, xA.shape[0], xA.shape[2], xA.shape[3], configs["loss_function"],
                                    configs.get("class_weights", [1.0, 1.0, 1.0]), optimizer=optimizer, graph=configs.get("hip_graph", False),
-                                   overlap_wgrad=configs.get("overlap_wgrad", True), grad_dtype=configs.get("dp_grad_dtype"), overlap_lanes=configs.get("overlap_lanes", True),
+                                   overlap_wgrad=configs.get("overlap_wgrad", True), grad_dtype=configs.get("dp_grad_dtype"), dp_mode=configs.get("dp_mode"), overlap_lanes=configs.get("overlap_lanes", True),
                                    **({"tail": xdem.shape[1]} if xdem is not None else {}))
             ins = (xA, xB) + ((xdem,) if xdem is not None else ())
             step.step(*[t.to(dev, non_blocking=True) for t in ins], mask.to(dev, non_blocking=True))

@@ -43,7 +43,7 @@ def train_semantic_segmentation(model, train_loader, val_loader, test_loader, co
             image, mask = seg_inputs(batch, configs["inputs"], bool(configs["dem"]))
             if step is None or step.B != image.shape[0]:
                 step = SegTrainStep(model, image.shape[0], configs["loss_function"], weights, optimizer=optimizer, graph=configs.get("hip_graph", False),
-                                    overlap_wgrad=configs.get("overlap_wgrad", True), grad_dtype=configs.get("dp_grad_dtype"), **({} if hasattr(model, "hp") else {"image_size": tuple(image.shape[2:])}))
+                                    overlap_wgrad=configs.get("overlap_wgrad", True), grad_dtype=configs.get("dp_grad_dtype"), dp_mode=configs.get("dp_mode"), **({} if hasattr(model, "hp") else {"image_size": tuple(image.shape[2:])}))
             step.step(image.to(dev, non_blocking=True), mask.to(dev, non_blocking=True))
             metrics.update(step.plan.logits, step.labels)
             loss_acc += step.loss_out

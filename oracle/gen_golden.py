@@ -647,6 +647,63 @@ def gen_changeformer_bench():
     np.savez_compressed(os.path.join(OUT, "changeformer_bench.npz"), **out)
 
 
+def gen_changeformer_bench32_eval():
+    """BASELINE.json configs[3] at its STATED batch (32): the GPU plan of that size is held to vectors of the real reference through
+    eval mode, where every sample is independent of the rest of the batch (BatchNorm running statistics, stochastic layers off): the
+    reference runs the first 8 of the 32 benchmark tiles (make_batch(32, seed 1234, 4 SLC bands)), fp32."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from kurosiwo_amd.synthetic import cd_inputs, make_batch
+    ChangeFormerV6 = _import_changeformer_reference()
+    c, B, n = 4, 32, 8
+    (x1, x2), _ = cd_inputs(make_batch(B, 224, 224, seed=1234, channels=c), ("pre_event_1", "post_event"))
+    model = ChangeFormerV6(input_nc=c, output_nc=3, decoder_softmax=True, embed_dim=256)
+    seeded_fill_(model.state_dict())
+    model.eval()
+    out = {}
+    with torch.no_grad():
+        outs = model(x1[:n], x2[:n])
+    for i, o in enumerate(outs[:4]):
+        out[f"eval.out{i}"] = o.numpy().copy()
+    out["eval.out4_sub"] = outs[4][:, :, ::8, ::8].numpy().copy()
+    out["eval.argmax_sub"] = outs[4][::2].argmax(1).numpy().astype(np.uint8)
+    top2 = outs[4][::2].topk(2, dim=1).values
+    out["eval.margin_sub"] = (top2[:, 0] - top2[:, 1]).numpy().astype(np.float16)
+    print("changeformer bench32 eval: out4 mean", float(outs[4].mean()))
+    np.savez_compressed(os.path.join(OUT, "changeformer_bench32_eval.npz"), **out)
+
+
+def gen_snunet_dem_shard():
+    """BASELINE.json configs[2] per-GPU shard: SNUNet-ECAM with 3 channels per date (VV, VH, DEM), batch 8 (global 64 over 8 ranks),
+    224 x 224, on the REAL reference in fp32: train-mode logits, ce+dice loss, gradient statistics.  The DEM plane is a seeded smooth
+    field shared by both dates (the trainer's torch.cat((image, dem), 1), change_detection_trainer.py:117-133)."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from kurosiwo_amd.synthetic import cd_inputs, make_batch
+    out = {}
+    c, bc, B = 3, 32, 8
+    (xA, xB), lbl = cd_inputs(make_batch(B, 224, 224, seed=4321), ("pre_event_1", "post_event"))
+    dem = torch.nn.functional.interpolate(seeded_tensor("snunet_dem_shard.dem", (B, 1, 14, 14)), size=(224, 224), mode="bilinear", align_corners=False)
+    xA, xB = torch.cat((xA, dem), 1), torch.cat((xB, dem), 1)
+    model = _ref_model(c, bc)
+    model.train()
+    crit = BCEandDiceLoss(weights=[1.0, 1.0, 1.0], ignore_index=3, use_softmax=True)
+    logits = model(xA, xB)
+    loss = crit(logits, lbl)
+    loss.backward()
+    out["train_logits_sub"] = logits[:, :, ::8, ::8].detach().numpy().copy()
+    out["train_logits_absmax"] = np.array(float(logits.detach().abs().max()))
+    out["train_argmax_sub"] = logits[::2].detach().argmax(1).numpy().astype(np.uint8)
+    top2 = logits[::2].detach().topk(2, dim=1).values
+    out["train_margin_sub"] = (top2[:, 0] - top2[:, 1]).numpy().astype(np.float16)
+    out["train_loss"] = np.array(float(loss))
+    stats, _ = _grad_stats(model)
+    for k, v in stats.items():
+        out[f"gstat.{k}"] = v
+    for k in ("conv_final.weight", "conv0_0.conv1.weight", "conv0_4.conv1.weight", "Up1_3.up.weight"):
+        out[f"grad.{k}"] = dict(model.named_parameters())[k].grad.numpy().copy()
+    print("snunet_dem_shard loss", float(loss))
+    np.savez_compressed(os.path.join(OUT, "snunet_dem_shard.npz"), **out)
+
+
 def gen_fcsiam():
     """FC-Siam-conc / FC-Siam-diff (N2 row): the REFERENCE modules (models/siam_conc.py, siam_diff.py import with torch alone).  Eval
     outputs, and one train-mode step with every nn.Dropout2d(p=0.2) ON, its plane mask drawn from the counter-based stream of
@@ -823,6 +880,10 @@ if __name__ == "__main__":
         gen_changeformer_bench()
     if not only or "floodvit_bench" in only:
         gen_floodvit_bench()
+    if not only or "changeformer_bench32_eval" in only:
+        gen_changeformer_bench32_eval()
+    if not only or "snunet_dem_shard" in only:
+        gen_snunet_dem_shard()
     if not only or "fcsiam" in only:
         gen_fcsiam()
     if not only or "bitcd" in only:

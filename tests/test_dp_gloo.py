@@ -31,7 +31,7 @@ def test_make_buckets_cover_arena_in_order():
     assert make_buckets(ready, offsets, None, 1200, 10 ** 9) == [(0, 1200, 9)]
 
 
-def _worker(rank, world, port, q, grad_dtype="fp32"):
+def _worker(rank, world, port, q, grad_dtype="fp32", mode=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -39,7 +39,7 @@ def _worker(rank, world, port, q, grad_dtype="fp32"):
     flat = torch.zeros(n)
     offsets = {"a": 0, "b": 100, "c": 300, "d": 1000}
     ready = {"a": 9, "b": 7, "c": 3, "d": 1}          # backward finishes the arena tail first
-    red = BucketedAllReduce(flat, make_buckets(ready, offsets, None, n, 250), grad_dtype=grad_dtype)
+    red = BucketedAllReduce(flat, make_buckets(ready, offsets, None, n, 250), grad_dtype=grad_dtype, mode=mode)
     order = []
     for launch in range(10):                          # the "backward launch list"
         if launch == 1:
@@ -61,14 +61,15 @@ def _worker(rank, world, port, q, grad_dtype="fp32"):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("grad_dtype", ["fp32", "bf16"])
-def test_bucketed_allreduce_world2_gloo(grad_dtype):
+@pytest.mark.parametrize("grad_dtype,mode", [("fp32", None), ("bf16", None), ("fp32", "rs_ag")])
+def test_bucketed_allreduce_world2_gloo(grad_dtype, mode):
     """grad_dtype = "bf16": the buckets travel as bf16 (staging buffer, SUM on the wire format, cast back into the fp32 arena in wait());
-    the test values are exactly representable, so both wire formats give the same sums"""
+    the test values are exactly representable, so both wire formats give the same sums.  mode = "rs_ag": gloo has no reduce-scatter, the
+    mode falls back to the all-reduce there (the RCCL form runs in tests/test_gpu_dp.py)"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, grad_dtype)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, grad_dtype, mode)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]

@@ -4,6 +4,8 @@ checkpoint directory.  The same calls run over RCCL ("nccl") under torchrun on t
 import os
 import socket
 
+import pytest
+
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -74,3 +76,41 @@ def test_world2_gloo_reductions_and_broadcasts():
         assert cm00 == 3 and loss == 3.0                      # SUM over ranks
         assert (p0, b0, c0) == (0.0, 0.5, 0)                  # rank 0's arenas everywhere
         assert path == "checkpoints/run_0"
+
+
+def test_rank_shard_batch_sampler_covers_each_global_batch_once():
+    """the DataLoader route under data parallelism: every rank iterates the same seeded global order and loads only its contiguous
+    slice of each global batch; the slices of one batch tile it exactly (the slices distributed.shard_batch would cut), train
+    (drop_last) and ragged evaluation batches alike"""
+    from kurosiwo_amd.distributed import RankShardBatchSampler
+    n, bs, W = 37, 8, 4
+    per_rank = [list(RankShardBatchSampler(n, bs, True, True, r, W, seed=5)) for r in range(W)]
+    assert all(len(p) == n // bs for p in per_rank)
+    g = torch.Generator(); g.manual_seed(5)
+    order = torch.randperm(n, generator=g).tolist()
+    for b in range(n // bs):
+        glob = order[b * bs:(b + 1) * bs]
+        assert sum((per_rank[r][b] for r in range(W)), []) == glob
+        assert all(len(per_rank[r][b]) == bs // W for r in range(W))
+    # a second epoch reshuffles, identically on every rank
+    s0, s1 = RankShardBatchSampler(n, bs, True, True, 0, W, seed=5), RankShardBatchSampler(n, bs, True, True, 1, W, seed=5)
+    e0a, e1a, e0b, e1b = list(s0), list(s1), list(s0), list(s1)
+    assert e0a != e0b and [a + b for a, b in zip(e0a, e1a)] != [a + b for a, b in zip(e0b, e1b)]
+    # evaluation: no shuffle, ragged last batch cut as shard_batch(even=False) does
+    ev = [list(RankShardBatchSampler(n, bs, False, False, r, W)) for r in range(W)]
+    assert all(len(p) == 5 for p in ev)
+    assert sum((ev[r][4] for r in range(W)), []) == list(range(32, 37))
+    assert [len(ev[r][4]) for r in range(W)] == [5 * (r + 1) // W - 5 * r // W for r in range(W)]
+    with pytest.raises(ValueError):
+        RankShardBatchSampler(n, 6, True, True, 0, W)
+
+
+def test_sharded_loader_batches_pass_through_shard_batch():
+    from kurosiwo_amd import distributed as D
+    ds = torch.utils.data.TensorDataset(torch.arange(20.0).reshape(10, 2), torch.arange(10))
+    samp = D.RankShardBatchSampler(len(ds), 4, False, False, 1, 2)
+    ld = torch.utils.data.DataLoader(ds, batch_sampler=samp, collate_fn=D.sharded_collate)
+    got = [b for b in ld]
+    assert [b[1].tolist() for b in got] == [[2, 3], [6, 7], [9]]
+    assert all(type(b).__name__ == "ShardedBatch" for b in got)
+    assert D.shard_batch(got[0], rank=1, world=2) is got[0]

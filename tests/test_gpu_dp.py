@@ -170,3 +170,92 @@ def test_main_entry_on_the_rccl_backend_one_rank(tmp_path, wire):
         assert res["plain"][1] == res["rccl"][1], res
     else:
         assert 0.0 <= float(res["rccl"][1]) <= 100.0 and abs(float(res["rccl"][1]) - float(res["plain"][1])) < 15.0, res
+
+
+def test_rs_ag_bucket_mode_on_the_rccl_backend_one_rank(tmp_path):
+    """mode = "rs_ag" (reduce_scatter_tensor + all_gather_into_tensor in place, kurosiwo_amd/dp.py) through the REAL backend on the one
+    GPU of the test box: over one rank both collectives are identities, so the run must end at exactly the mIoU of the plain run."""
+    import re
+    import shutil
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    wrapper = tmp_path / "run_main.py"
+    wrapper.write_text("import sys\nsys.path.insert(0, %r)\nimport main\nm = main.main(sys.argv[1:])\n"
+                       "print('MIOU', repr(float(m)), flush=True)\n" % root)
+    res = {}
+    for tag, extra in (("plain", {}), ("rs_ag", {"KSMI_DP_FORCE": "1", "KSMI_DP_MODE": "rs_ag", "MASTER_PORT": str(_free_port())})):
+        wd = tmp_path / tag
+        wd.mkdir()
+        shutil.copytree(os.path.join(root, "configs"), wd / "configs")
+        env = dict(os.environ, KSMI_SYNTHETIC_TILES="8,4,4", PYTHONPATH=root, MASTER_ADDR="127.0.0.1", **extra)
+        env.pop("KSMI_DIST_BACKEND", None)
+        out = subprocess.run([sys.executable, str(wrapper), "--method", "snunet", "--inputs", "pre_event_1", "post_event", "--batch_size", "4"],
+                             cwd=wd, env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+        res[tag] = re.findall(r"MIOU ([0-9.e+-]+)", out.stdout)[-1]
+    assert res["plain"] == res["rs_ag"], res
+
+
+# ---- two or more GPUs: these tests activate themselves the moment a multi-GPU node runs the suite (the single-GPU test box skips them) ----
+needs2 = pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs (RCCL over xGMI); the 1-GPU box covers the same path over gloo / one-rank RCCL")
+
+
+def _torchrun_bench(nproc, extra_env=None, args=()):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", str(nproc), "--steps", "5", "--warmup", "2",
+           "--no-cpu-baseline", "--no-solo", *args]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]                    # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+@needs2
+@pytest.mark.parametrize("model,extra", [("snunet", ()), ("floodvit", ()), ("changeformer", ("--channels", "4"))])
+def test_two_gpus_bench_on_rccl(model, extra):
+    """`torchrun --nproc-per-node 2 bench.py --gpus 2` on the nccl (= RCCL) backend: two ranks, different tiles per rank, and after the
+    timed steps the parameter arenas of the ranks agree bit for bit (bench.py's dp_check: the bucketed all-reduce really averaged the
+    gradients), every value finite, whole-job throughput reported for 2 GPUs."""
+    r = _torchrun_bench(2, args=("--model", model, *extra))
+    assert r["n_gpus"] == 2 and r["config"]["parallelism"] == "dp2"
+    chk = r["config"]["dp_check"]
+    assert chk["ranks"] == 2 and chk["backend"] == "nccl"
+    assert chk["params_equal"] and chk["params_finite"], chk
+    assert chk["rank_losses"][0] != chk["rank_losses"][1], "the ranks must train on different tiles"
+    print(model, "2 x MI355X:", r["value"], r["unit"], r["ms_per_step"], "ms/step", chk)
+
+
+@needs2
+def test_two_gpus_rccl_equals_the_gloo_path():
+    """the same two-rank run with the collectives on gloo (host staging): a SUM of two fp32 values does not depend on the order, so
+    RCCL and gloo must leave the SAME parameter bits (integer checksum) and per-rank losses"""
+    a = _torchrun_bench(2)
+    b = _torchrun_bench(2, {"KSMI_DIST_BACKEND": "gloo"})
+    ca, cb = a["config"]["dp_check"], b["config"]["dp_check"]
+    assert ca["backend"] == "nccl" and cb["backend"] == "gloo"
+    assert ca["params_equal"] and cb["params_equal"]
+    assert ca["param_checksum"] == cb["param_checksum"], (ca, cb)
+    assert ca["rank_losses"] == cb["rank_losses"], (ca, cb)
+
+
+@needs2
+@pytest.mark.parametrize("mode,wire", [("rs_ag", "fp32"), ("all_reduce", "bf16")])
+def test_two_gpus_other_bucket_modes(mode, wire):
+    """reduce-scatter + all-gather buckets give the all-reduce parameters (fp32 sums over two ranks: bit-identical); the opt-in bf16 wire
+    format keeps the ranks identical to each other and the run healthy (the K-step gate for making it a default is a scaling-node job)"""
+    ref = _torchrun_bench(2)
+    r = _torchrun_bench(2, {"KSMI_DP_MODE": mode, "KSMI_DP_GRAD_DTYPE": wire})
+    chk = r["config"]["dp_check"]
+    assert chk["params_equal"] and chk["params_finite"] and chk["dp_mode"] == mode and chk["grad_wire"] == wire, chk
+    if wire == "fp32":
+        assert chk["param_checksum"] == ref["config"]["dp_check"]["param_checksum"], (chk, ref["config"]["dp_check"])
+    else:
+        for x, y in zip(chk["rank_losses"], ref["config"]["dp_check"]["rank_losses"]):
+            assert abs(x - y) < 0.05 * abs(y) + 1e-3, (chk, ref["config"]["dp_check"])
