@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define KSMI_ABI_VERSION 4   /* 2: round 2 (stats_rows, stochastic layers, bias_grad in ksmi_wgrad_desc, ...); 3: round 3 (gate epilogue, ksmi_desc_size); 4: first conv on raw tiles, tile reader, BIT token path */
+#define KSMI_ABI_VERSION 5   /* 5: round 4 (BatchNorm statistics finished inside the consuming pass: ksmi_bn_fin_*, ksmi_bn*_bwd_fin_*); 2: round 2 (stats_rows, stochastic layers, bias_grad in ksmi_wgrad_desc, ...); 3: round 3 (gate epilogue, ksmi_desc_size); 4: first conv on raw tiles, tile reader, BIT token path */
 #define KSMI_F32 0
 #define KSMI_BF16 1
 #define KSMI_E_ARG (-1)
@@ -258,6 +258,33 @@ int ksmi_bn_bwd_apply_gated(const void* g, const void* z, const float* mean, con
 int ksmi_bn_bwd_apply_add(void* r_di, const void* g, const void* i, const float* mean, const float* rstd,
                           const float* gamma, const float* sums, float* partial, int rows, double count,
                           int64_t npix, int C, int dtype, void* stream);
+/* Round 4: the statistics FINISH folded into the pass that needs the finished statistics (csrc/bnfused.hip): one launch where the
+ * forward pass had ksmi_bn_finalize + ksmi_bn_add_relu (+ ksmi_maxpool2x2_forward) and the backward pass ksmi_reduce_rows + an apply
+ * pass (models/snunet.py:16,18,24-29 forward, their autograd backward).  The pass runs on <= 256 workgroups of 1024 threads; each of
+ * them first sums the partial rows itself (fp64, fixed order: every workgroup gets the same bits; lists longer than 512 rows are
+ * folded in place first, `partial` is scratch), workgroup 0 publishes mean / rstd / scale / shift + the running statistics (forward)
+ * or `sums` + dbeta (+)= sums[0], dgamma (+)= sums[1] (backward).  The streaming arithmetic is that of the passes they replace.
+ * ksmi_bn_fused_supported: 1 when (C, row stride, dtype) qualify (C <= 512, multiples of the 16-byte vector). */
+int ksmi_bn_fused_supported(int C, int Cstride, int dtype);
+int ksmi_bn_fused_max_rows(void);     /* most rows of bias_partial ksmi_bn_bwd_fin_apply_add accepts (= its workgroup count) */
+/* out = relu(bn(z) + identity) from the partial rows [rows][2][Cpad] of the convolution that wrote z; pooled != NULL: also
+ * pooled[B,H/2,W/2,C] = maxpool2x2(out) (snunet.py:73, 121-130: every encoder block output is pooled right away) */
+int ksmi_bn_fin_add_relu(float* partial, int rows, int Cpad, int C, double count, const float* gamma, const float* beta,
+                         float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum, float eps,
+                         float* mean, float* rstd, float* scale, float* shift, const void* z, const void* identity, void* out,
+                         void* pooled, int B, int H, int W, int dtype, void* stream);
+/* ksmi_reduce_rows(partial [rows][2][Cstride]) + ksmi_bn_bwd_apply_gated */
+int ksmi_bn_bwd_fin_apply_gated(float* partial, int rows, int Cstride, float* sums, float* dgamma, float* dbeta, int accumulate,
+                                const void* g, const void* z, const float* mean, const float* rstd, const float* gamma, void* dz,
+                                double count, int64_t npix, int C, int dtype, void* stream);
+/* ksmi_reduce_rows + ksmi_bnrelu_bwd_apply */
+int ksmi_bnrelu_bwd_fin_apply(float* partial, int rows, int Cstride, float* sums, float* dgamma, float* dbeta, int accumulate,
+                              void* dout_g, const void* out, const void* z, const float* mean, const float* rstd, const float* gamma,
+                              void* dz, double count, int64_t npix, int C, int dtype, void* stream);
+/* ksmi_reduce_rows + ksmi_bn_bwd_apply_add; bias_partial [bias_rows][C], bias_rows <= ksmi_bn_fused_max_rows() */
+int ksmi_bn_bwd_fin_apply_add(float* partial, int rows, int Cstride, float* sums, float* dgamma, float* dbeta, int accumulate,
+                              void* r_di, const void* g, const void* i, const float* mean, const float* rstd, const float* gamma,
+                              float* bias_partial, int bias_rows, double count, int64_t npix, int C, int dtype, void* stream);
 /* partial[rows][1][C] = per-channel sum of x (bias gradients) */
 int ksmi_channel_sum(const void* x, float* partial, int rows, int64_t npix, int C, int dtype, void* stream);
 /* out[c] (+)= sum_r x[r][c] of a row-major token matrix in one launch (bias gradient of nn.Linear, vision_transformer.py:22-31:

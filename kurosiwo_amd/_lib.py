@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libksmi.so")
 
 KSMI_F32, KSMI_BF16 = 0, 1
 MAX_SRC, MAX_CHUNKS = 6, 72
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class KsmiError(RuntimeError):
@@ -111,6 +111,12 @@ SIGNATURES = {
     "ksmi_conv_first_wgrad_workspace": (_sz, [_i, _i, _i, _i, _i]),
     "ksmi_bn_finalize": (_i, [_vp, _i, _i, _i, _d, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _vp]),
     "ksmi_bn_add_relu": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp]),
+    "ksmi_bn_fused_supported": (_i, [_i, _i, _i]),
+    "ksmi_bn_fused_max_rows": (_i, []),
+    "ksmi_bn_fin_add_relu": (_i, [_vp, _i, _i, _i, _d, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "ksmi_bn_bwd_fin_apply_gated": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _d, _i64, _i, _i, _vp]),
+    "ksmi_bnrelu_bwd_fin_apply": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _i64, _i, _i, _vp]),
+    "ksmi_bn_bwd_fin_apply_add": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _d, _i64, _i, _i, _vp]),
     "ksmi_bnrelu_bwd_reduce": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp]),
     "ksmi_reduce_rows": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp]),
     "ksmi_reduce_rows_batched": (_i, [_vp, _i, _vp]),

@@ -752,6 +752,9 @@ bool chan_ok(int C, int dtype) {
 
 }  // namespace
 
+// (bnfused.hip folds row lists longer than its workgroups sum themselves)
+int ksmi_internal_fold_rows(float* partial, int rows, int K, int Cstride, int C, hipStream_t st) { return fold_rows(partial, rows, K, Cstride, C, st); }
+
 // Column sums of a token matrix in ONE launch (bias gradients of nn.Linear: out[c] (+)= sum_r x[r][c], a few thousand rows):
 // block = 4 adjacent 16-byte column vectors x 256 row lanes; fixed-order tree over the row lanes (deterministic).  The two-stage
 // channel_sum + reduce_rows pair costs two launches (~21 us) per bias on the 3152-row FloodViT matrices.

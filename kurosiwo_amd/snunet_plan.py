@@ -168,6 +168,7 @@ class _Saved:
 class SNUNetPlan:
     side_wgrad = True          # weight gradients on the train step's side stream (see LaunchList.run; plan_base.PlanBase.side_wgrad)
     two_lanes = True           # the decoder launches carry lane tags and hand-over entries (StepStreams)
+    bn_fused = os.environ.get("KSMI_BN_FUSED", "1") != "0"     # statistics finish inside the consuming pass (csrc/bnfused.hip)
 
     def __init__(self, model, B, H, W, dtype, training, with_backward, tail=0):
         self.m, self.B, self.H, self.W, self.dtype = model, B, H, W, dtype
@@ -204,19 +205,19 @@ class SNUNetPlan:
         # (built in reverse) the date-B block writes the shared BatchNorm gradients ("=") before the date-A block accumulates ("+=");
         # the hand-over entries between the two blocks of a level keep exactly that order on two streams.
         L = self._lane
-        L(0); x0_0A = self._block("conv0_0", "A", [self.xA], A("x0_0A", 0, f[0]), first=True)
+        L(0); x0_0A, p0A = self._block("conv0_0", "A", [self.xA], A("x0_0A", 0, f[0]), first=True, pool="p0A")
         self._handover(0, 1, back=(1, 0))
-        L(1); x0_0B = self._block("conv0_0", "B", [self.xB], A("x0_0B", 0, f[0]), first=True)
-        L(0); x1_0A = self._block("conv1_0", "A", [self._pool(x0_0A, "p0A")], A("x1_0A", 1, f[1]))
+        L(1); x0_0B, p0B = self._block("conv0_0", "B", [self.xB], A("x0_0B", 0, f[0]), first=True, pool="p0B")
+        L(0); x1_0A, p1A = self._block("conv1_0", "A", [self._pool_at(x0_0A, p0A, "p0A")], A("x1_0A", 1, f[1]), pool="p1A")
         self._handover(0, 1, back=(1, 0))
-        L(1); x1_0B = self._block("conv1_0", "B", [self._pool(x0_0B, "p0B")], A("x1_0B", 1, f[1]))
-        L(0); x2_0A = self._block("conv2_0", "A", [self._pool(x1_0A, "p1A")], A("x2_0A", 2, f[2]))
+        L(1); x1_0B, p1B = self._block("conv1_0", "B", [self._pool_at(x0_0B, p0B, "p0B")], A("x1_0B", 1, f[1]), pool="p1B")
+        L(0); x2_0A, p2A = self._block("conv2_0", "A", [self._pool_at(x1_0A, p1A, "p1A")], A("x2_0A", 2, f[2]), pool="p2A")
         self._handover(0, 1, back=(1, 0))
-        L(1); x2_0B = self._block("conv2_0", "B", [self._pool(x1_0B, "p1B")], A("x2_0B", 2, f[2]))
-        L(0); x3_0A = self._block("conv3_0", "A", [self._pool(x2_0A, "p2A")], A("x3_0A", 3, f[3]))
+        L(1); x2_0B, p2B = self._block("conv2_0", "B", [self._pool_at(x1_0B, p1B, "p1B")], A("x2_0B", 2, f[2]), pool="p2B")
+        L(0); x3_0A = self._block("conv3_0", "A", [self._pool_at(x2_0A, p2A, "p2A")], A("x3_0A", 3, f[3]))
         self._handover(0, 1, back=(1, 0))
-        L(1); x3_0B = self._block("conv3_0", "B", [self._pool(x2_0B, "p2B")], A("x3_0B", 3, f[3]))
-        x4_0B = self._block("conv4_0", "B", [self._pool(x3_0B, "p3B")], A("x4_0B", 4, f[4]))
+        L(1); x3_0B, p3B = self._block("conv3_0", "B", [self._pool_at(x2_0B, p2B, "p2B")], A("x3_0B", 3, f[3]), pool="p3B")
+        x4_0B = self._block("conv4_0", "B", [self._pool_at(x3_0B, p3B, "p3B")], A("x4_0B", 4, f[4]))
         self._handover(1, 0, back=(0, 1))                  # encoder | decoder: both lanes have everything of the other side
 
         # Decoder on two lanes (LaunchList.run / StepStreams): lane 0 = the level-0 column blocks + the head, lane 1 = every deeper block and the Ups
@@ -426,7 +427,19 @@ class SNUNetPlan:
     def _pool(self, x, name):
         y = Act(name, x.B, x.H // 2, x.W // 2, x.C, self.dtype, self.dev)
         self.fwd.add("ksmi_maxpool2x2_forward", lambda: (x.t.data_ptr(), y.t.data_ptr(), x.B, x.H, x.W, x.C, self.dt))
+        self._pool_bwd(x, y)
+        return y
 
+    def _pool_at(self, x, y, name):
+        """the pooled copy of an encoder block output at this point of the lists: y from the fused block tail (only its backward is
+        registered here, at the place the stand-alone pool has in the launch order), or None -> the stand-alone launch"""
+        if y is None:
+            return self._pool(x, name)
+        self._pool_bwd(x, y)
+        return y
+
+    def _pool_bwd(self, x, y):
+        """backward of y = maxpool2x2(x) (y written by ksmi_maxpool2x2_forward or by the fused block tail)"""
         def build_bwd():
             self._emit_dgrad(y)
             acc = x.take_acc_flag()
@@ -434,7 +447,6 @@ class SNUNetPlan:
             self.bwd.add("ksmi_maxpool2x2_backward", lambda: (x.t.data_ptr(), gy.data_ptr(), gx.data_ptr(), acc,
                                                               x.B, x.H, x.W, x.C, self.dt))
         self.bwd_builders.append((self.fwd.cur_lane, build_bwd))
-        return y
 
     # ---------------------------------------------------------------- up = ConvTranspose2d(k2,s2)  (snunet.py:32-46)
     def _up(self, name, x):
@@ -473,7 +485,9 @@ class SNUNetPlan:
         return y
 
     # ---------------------------------------------------------------- conv_block_nested  (snunet.py:11-29)
-    def _block(self, name, branch, sources, out, first=False):
+    def _block(self, name, branch, sources, out, first=False, pool=None):
+        """pool: name of the max-pooled copy of the block output (encoder blocks, snunet.py:121-130).  With the fused BatchNorm glue
+        (csrc/bnfused.hip) the pooled tensor comes out of the launch that writes the block output; returns (out, pooled) then."""
         m, B, H, W, Cc = self.m, out.B, out.H, out.W, out.C
         npix = B * H * W
         dtype, dt, training = self.dtype, self.dt, self.training
@@ -541,9 +555,23 @@ class SNUNetPlan:
             self.need(sS, rows2 * 2 * Npad * 4)
             self.patch(d2, "stats", sS)
         self._conv(self.fwd, d2)
-        bn_fin("bn2", sv2, rows2, Npad)
-        self.fwd.add("ksmi_bn_add_relu", lambda: (z_act.t.data_ptr(), i_act.t.data_ptr(), sv2.scale, sv2.shift,
-                                                  out.t.data_ptr(), npix, Cc, dt))
+        fused = training and self.bn_fused and bool(self.lib.ksmi_bn_fused_supported(Cc, Npad, dt))
+        pooled = None
+        if fused:
+            # statistics finish + BN2-apply + residual + ReLU (+ the 2x2 max-pool of the encoder blocks) in ONE launch
+            if pool is not None:
+                pooled = Act(pool, B, H // 2, W // 2, Cc, dtype, self.dev)
+            nbt2 = m._c(f"{name}.bn2.num_batches_tracked").data_ptr()
+            pp = pooled.t.data_ptr() if pooled is not None else None
+            self.fwd.add("ksmi_bn_fin_add_relu", lambda: (stats(), rows2, Npad, Cc, float(npix), P("bn2.weight"), P("bn2.bias"),
+                                                          Bf("bn2.running_mean"), Bf("bn2.running_var"), nbt2, BN_MOMENTUM, BN_EPS,
+                                                          sv2.mean, sv2.rstd, sv2.scale, sv2.shift, z_act.t.data_ptr(), i_act.t.data_ptr(),
+                                                          out.t.data_ptr(), pp, B, H, W, dt),
+                         {"kind": "bn_fin_add_relu", "bytes": npix * Cc * self._es() * (3.25 if pooled is not None else 3), "flops": 0})
+        else:
+            bn_fin("bn2", sv2, rows2, Npad)
+            self.fwd.add("ksmi_bn_add_relu", lambda: (z_act.t.data_ptr(), i_act.t.data_ptr(), sv2.scale, sv2.shift,
+                                                      out.t.data_ptr(), npix, Cc, dt))
 
         # ---- backward ----------------------------------------------------------------------------
         def build_bwd():
@@ -561,20 +589,35 @@ class SNUNetPlan:
             gout = out.grad().data_ptr()
             s1p, s2p = sums1.data_ptr(), sums2.data_ptr()
             a_bn2 = self._acc_param(f"{name}.bn2")
+            es = self._es()
             if gated is not None:
                 # d out arrives gated (x (out > 0)) with the BatchNorm2-backward sums in the statistics rows of its producer
                 gst, grows, gpad = gated
-                self.bwd.add("ksmi_reduce_rows", lambda: (gst.data_ptr(), grows, 2, gpad, Cc, s2p, G("bn2.weight"), G("bn2.bias"), a_bn2))
-                self._mark(f"{name}.bn2.weight", f"{name}.bn2.bias")
-                self.bwd.add("ksmi_bn_bwd_apply_gated", lambda: (gout, z_act.t.data_ptr(), sv2.mean, sv2.rstd, P("bn2.weight"), s2p,
-                                                                 dz.data_ptr(), float(npix), npix, Cc, dt))
+                if fused and self.lib.ksmi_bn_fused_supported(Cc, gpad, dt):
+                    self.bwd.add("ksmi_bn_bwd_fin_apply_gated", lambda: (gst.data_ptr(), grows, gpad, s2p, G("bn2.weight"), G("bn2.bias"), a_bn2,
+                                                                         gout, z_act.t.data_ptr(), sv2.mean, sv2.rstd, P("bn2.weight"),
+                                                                         dz.data_ptr(), float(npix), npix, Cc, dt),
+                                 {"kind": "bn_bwd_fin_apply_gated", "bytes": npix * Cc * es * 3, "flops": 0})
+                    self._mark(f"{name}.bn2.weight", f"{name}.bn2.bias")
+                else:
+                    self.bwd.add("ksmi_reduce_rows", lambda: (gst.data_ptr(), grows, 2, gpad, Cc, s2p, G("bn2.weight"), G("bn2.bias"), a_bn2))
+                    self._mark(f"{name}.bn2.weight", f"{name}.bn2.bias")
+                    self.bwd.add("ksmi_bn_bwd_apply_gated", lambda: (gout, z_act.t.data_ptr(), sv2.mean, sv2.rstd, P("bn2.weight"), s2p,
+                                                                     dz.data_ptr(), float(npix), npix, Cc, dt))
             else:
                 self.bwd.add("ksmi_bnrelu_bwd_reduce", lambda: (gout, out.t.data_ptr(), z_act.t.data_ptr(), sv2.mean, sv2.rstd,
                                                                 self.scr(sR), rows, npix, Cc, dt))
-                self.bwd.add("ksmi_reduce_rows", lambda: (self.scr(sR), rows, 2, Cc, Cc, s2p, G("bn2.weight"), G("bn2.bias"), a_bn2))
-                self._mark(f"{name}.bn2.weight", f"{name}.bn2.bias")
-                self.bwd.add("ksmi_bnrelu_bwd_apply", lambda: (gout, out.t.data_ptr(), z_act.t.data_ptr(), sv2.mean, sv2.rstd,
-                                                               P("bn2.weight"), s2p, dz.data_ptr(), float(npix), npix, Cc, dt))
+                if fused:
+                    self.bwd.add("ksmi_bnrelu_bwd_fin_apply", lambda: (self.scr(sR), rows, Cc, s2p, G("bn2.weight"), G("bn2.bias"), a_bn2,
+                                                                       gout, out.t.data_ptr(), z_act.t.data_ptr(), sv2.mean, sv2.rstd,
+                                                                       P("bn2.weight"), dz.data_ptr(), float(npix), npix, Cc, dt),
+                                 {"kind": "bnrelu_bwd_fin_apply", "bytes": npix * Cc * es * 5, "flops": 0})
+                    self._mark(f"{name}.bn2.weight", f"{name}.bn2.bias")
+                else:
+                    self.bwd.add("ksmi_reduce_rows", lambda: (self.scr(sR), rows, 2, Cc, Cc, s2p, G("bn2.weight"), G("bn2.bias"), a_bn2))
+                    self._mark(f"{name}.bn2.weight", f"{name}.bn2.bias")
+                    self.bwd.add("ksmi_bnrelu_bwd_apply", lambda: (gout, out.t.data_ptr(), z_act.t.data_ptr(), sv2.mean, sv2.rstd,
+                                                                   P("bn2.weight"), s2p, dz.data_ptr(), float(npix), npix, Cc, dt))
             # conv2.bias feeds a train-mode BatchNorm: its gradient sum(dz) is analytically 0 (the reference holds
             # ~1e-6 of rounding noise there); write exact zeros instead of two reduction launches.
             if training:
@@ -593,17 +636,30 @@ class SNUNetPlan:
             self.patch(dg2, "stats", sS)
             self._conv(self.bwd, dg2, "dgrad")
             a_bn1 = self._acc_param(f"{name}.bn1")
-            self.bwd.add("ksmi_reduce_rows", lambda: (self.scr(sS), rows_g, 2, Npad, Cc, s1p, G("bn1.weight"), G("bn1.bias"), a_bn1))
-            self._mark(f"{name}.bn1.weight", f"{name}.bn1.bias")
+            if not fused:
+                self.bwd.add("ksmi_reduce_rows", lambda: (self.scr(sS), rows_g, 2, Npad, Cc, s1p, G("bn1.weight"), G("bn1.bias"), a_bn1))
+                self._mark(f"{name}.bn1.weight", f"{name}.bn1.bias")
             # weight gradient of conv2: X = relu(bn1(i)) recomputed on load, dY = dz
             dw2, ws2 = make_wgrad(src2, dz, Cc, 0, Cc, m._g(f"{name}.conv2.weight"), 9, Cc * 9, 1,
                                   self._acc_param(f"{name}.conv2.weight"), B, H, W, H, W, 3, 3, 1, 1, dtype)
             self._wgrad(dw2, ws2, f"{name}.conv2.weight")
             # di = g + BN1 backward (over r, in place); conv1 bias gradient
             pb1 = torch.empty(rows * Cc, dtype=torch.float32, device=self.dev)      # per-block partial sums of di (conv1 bias gradient)
-            self.bwd.add("ksmi_bn_bwd_apply_add", lambda: (r.data_ptr(), gout, i_act.t.data_ptr(), sv1.mean, sv1.rstd,
-                                                           P("bn1.weight"), s1p, pb1.data_ptr(), rows, float(npix), npix, Cc, dt))
-            self._defer_rowsum(f"{name}.conv1.bias", pb1, rows, 1, 0, Cc, Cc)
+            if fused:
+                # the BN1-backward sums are finished from the statistics rows of conv2's input gradient inside the apply pass.  (The
+                # weight gradient of conv2 above runs on the side stream and does not touch `stats`; nothing else of this lane writes
+                # the rows between the two launches.)
+                rows_b = min(rows, self.lib.ksmi_bn_fused_max_rows())
+                self.bwd.add("ksmi_bn_bwd_fin_apply_add", lambda: (self.scr(sS), rows_g, Npad, s1p, G("bn1.weight"), G("bn1.bias"), a_bn1,
+                                                                   r.data_ptr(), gout, i_act.t.data_ptr(), sv1.mean, sv1.rstd, P("bn1.weight"),
+                                                                   pb1.data_ptr(), rows_b, float(npix), npix, Cc, dt),
+                             {"kind": "bn_bwd_fin_apply_add", "bytes": npix * Cc * self._es() * 4, "flops": 0})
+                self._mark(f"{name}.bn1.weight", f"{name}.bn1.bias")
+                self._defer_rowsum(f"{name}.conv1.bias", pb1, rows_b, 1, 0, Cc, Cc)
+            else:
+                self.bwd.add("ksmi_bn_bwd_apply_add", lambda: (r.data_ptr(), gout, i_act.t.data_ptr(), sv1.mean, sv1.rstd,
+                                                               P("bn1.weight"), s1p, pb1.data_ptr(), rows, float(npix), npix, Cc, dt))
+                self._defer_rowsum(f"{name}.conv1.bias", pb1, rows, 1, 0, Cc, Cc)
             a_w1 = self._acc_param(f"{name}.conv1.weight")
             if first:
                 # dW[n][c*9+t] = sum_px im2col[px][c*9+t] * di[px][n]  (1x1 weight-gradient GEMM over the saved im2col)
@@ -624,6 +680,8 @@ class SNUNetPlan:
                                       B, H, W, H, W, 3, 3, 1, 1, dtype)
                 self._wgrad(dw1, ws1, f"{name}.conv1.weight")
         self.bwd_builders.append((self.fwd.cur_lane, build_bwd))
+        if pool is not None:
+            return out, pooled           # pooled = None: the caller's _pool_at() launches the stand-alone max-pool
         return out
 
     # ---------------------------------------------------------------- ECAM head  (snunet.py:49-62,146-151)

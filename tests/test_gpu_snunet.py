@@ -288,3 +288,45 @@ def test_backward_of_an_overwritten_forward_is_refused():
         first.backward()
     second.backward()                       # the latest forward is still differentiable
     assert all(p.grad is not None for p in model.parameters())
+
+
+@pytest.mark.parametrize("precision,B,H,W,bc", [("bf16", 4, 64, 64, 32), ("fp32", 2, 32, 48, 16), ("bf16", 32, 224, 224, 32)])
+def test_fused_batchnorm_glue_equals_the_separate_launches(dev, precision, B, H, W, bc):
+    """csrc/bnfused.hip (statistics finish inside the consuming pass: ksmi_bn_fin_add_relu with the encoder's max-pool,
+    ksmi_bn_bwd_fin_apply_gated, ksmi_bnrelu_bwd_fin_apply, ksmi_bn_bwd_fin_apply_add) against the launch sequence it replaces
+    (ksmi_bn_finalize / ksmi_reduce_rows + the apply passes + ksmi_maxpool2x2_forward): the streaming arithmetic is the same
+    expression and the row sums are fp64 in both, so logits, saved statistics, running statistics and every gradient agree to the last
+    bit except where an fp64 sum lands on a float rounding boundary (bound 1e-6 relative; the count of differing words is printed)."""
+    from kurosiwo_amd.loss import BCEandDiceLoss
+    from kurosiwo_amd.snunet_plan import SNUNetPlan
+    tag = f"fuse{precision}{B}{H}"
+    xA, xB = sar_like(tag + "A", (B, 2, H, W)), sar_like(tag + "B", (B, 2, H, W))
+    lbl = seeded_labels(tag + "L", (B, H, W))
+    sd = seeded_fill_(R.new_state_dict(2, 3, bc))
+    res = {}
+    keep = SNUNetPlan.bn_fused
+    try:
+        for fused in (True, False):
+            SNUNetPlan.bn_fused = fused
+            m = _model(2, bc, precision, sd, dev).train()
+            logits = m(xA.to(dev), xB.to(dev))
+            BCEandDiceLoss(CLASS_WEIGHTS, 3, True)(logits, lbl.to(dev)).backward()
+            torch.cuda.synchronize()
+            plan = m.plan(B, H, W, True, True)
+            names = [c[2] for c in plan.fwd.calls + plan.bwd.calls]
+            assert ("ksmi_bn_fin_add_relu" in names) == fused and ("ksmi_bn_add_relu" in names) != fused
+            assert ("ksmi_maxpool2x2_forward" in names) != fused
+            res[fused] = (logits.detach().float().cpu().clone(), m.flat_grads.detach().cpu().clone(), m.flat_buffers.detach().cpu().clone(),
+                          m.flat_counters.detach().cpu().clone())
+            del m, plan
+    finally:
+        SNUNetPlan.bn_fused = keep
+    (la, ga, ba, ca), (lb, gb, bb, cb) = res[True], res[False]
+    assert torch.equal(ca, cb)
+    ndiff = int((la != lb).sum()) + int((ga != gb).sum()) + int((ba != bb).sum())
+    print(f"fused vs separate BatchNorm glue ({precision}, B={B}, {H}x{W}): {ndiff} differing words; logits max diff "
+          f"{float((la - lb).abs().max()):.3g}, gradients max diff {float((ga - gb).abs().max()):.3g} (scale {float(gb.abs().max()):.3g})")
+    assert float((la - lb).abs().max()) <= 1e-6 * float(lb.abs().max())
+    assert float((ba - bb).abs().max()) <= 1e-6 * float(bb.abs().max())
+    # the bias gradient of conv1 is a sum over the per-workgroup rows of the apply pass: its row partition differs between the two paths
+    assert float((ga - gb).abs().max()) <= 2e-5 * float(gb.abs().max())
