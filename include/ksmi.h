@@ -124,6 +124,11 @@ typedef struct ksmi_conv_desc {
 
 
 /* sizeof of a descriptor struct as the library was compiled (0 conv, 1 wgrad, 2 pack, 3 rowsum, 4 tiff_info): bindings check their mirror */
+/* Names of the convolution / GEMM / attention kernels this THREAD's entry points have launched since the previous call, ';'-separated,
+ * spelled as rocprofv3 demangles them (template arguments included, "(anonymous namespace)::" dropped, bf16 for the 16-bit storage
+ * type); returns their number and resets the list.  Measurement aid: ties a HIP-event-timed launch to its row of a rocprofv3
+ * table (bench.py `roofline.kernel`).  Elementwise kernels are not listed. */
+int ksmi_last_kernels(char* buf, int cap);
 size_t ksmi_desc_size(int which);
 /* 1: ksmi_conv_forward(d, dtype) runs on a kernel that implements the gate epilogue (gate_src) for this descriptor */
 int ksmi_conv_gate_supported(const ksmi_conv_desc* d, int dtype);

@@ -90,6 +90,7 @@ _P4 = C.c_void_p * 4
 # name -> (restype, argtypes).  Every symbol of include/ksmi.h is listed; load fails if one is missing.
 SIGNATURES = {
     "ksmi_abi_version": (_i, []),
+    "ksmi_last_kernels": (_i, [C.c_char_p, _i]),
     "ksmi_last_error": (C.c_char_p, []),
     "ksmi_chunk_elems": (_i, [_i]),
     "ksmi_conv_grid_m": (_i, [C.POINTER(ConvDesc)]),

@@ -290,13 +290,16 @@ def test_backward_of_an_overwritten_forward_is_refused():
     assert all(p.grad is not None for p in model.parameters())
 
 
-@pytest.mark.parametrize("precision,B,H,W,bc", [("bf16", 4, 64, 64, 32), ("fp32", 2, 32, 48, 16), ("bf16", 32, 224, 224, 32)])
+@pytest.mark.parametrize("precision,B,H,W,bc", [("bf16", 4, 64, 64, 32), ("fp32", 2, 32, 48, 16), ("fp32", 8, 224, 224, 32), ("bf16", 32, 224, 224, 32)])
 def test_fused_batchnorm_glue_equals_the_separate_launches(dev, precision, B, H, W, bc):
     """csrc/bnfused.hip (statistics finish inside the consuming pass: ksmi_bn_fin_add_relu with the encoder's max-pool,
     ksmi_bn_bwd_fin_apply_gated, ksmi_bnrelu_bwd_fin_apply, ksmi_bn_bwd_fin_apply_add) against the launch sequence it replaces
-    (ksmi_bn_finalize / ksmi_reduce_rows + the apply passes + ksmi_maxpool2x2_forward): the streaming arithmetic is the same
-    expression and the row sums are fp64 in both, so logits, saved statistics, running statistics and every gradient agree to the last
-    bit except where an fp64 sum lands on a float rounding boundary (bound 1e-6 relative; the count of differing words is printed)."""
+    (ksmi_bn_finalize / ksmi_reduce_rows + the apply passes + ksmi_maxpool2x2_forward).  The streaming arithmetic is the same
+    expression.  Up to 256 statistics rows both paths sum the rows in fp64 and agree to the last bit (small cases: 0 differing words
+    expected, bound 1e-6).  Longer row lists (the 224 x 224 cases) go through an in-place fold in the old path that rounds its 32
+    intermediate sums to fp32, while the fused path stays in fp64: the saved statistics then differ by float ulps, which fp32
+    activations carry as ~1e-6 and bf16 activations turn into occasional flips of a bf16 rounding (2^-9 each) that the 19 blocks
+    spread: the bf16 full-size case is held to a statistical bound instead."""
     from kurosiwo_amd.loss import BCEandDiceLoss
     from kurosiwo_amd.snunet_plan import SNUNetPlan
     tag = f"fuse{precision}{B}{H}"
@@ -318,15 +321,23 @@ def test_fused_batchnorm_glue_equals_the_separate_launches(dev, precision, B, H,
             assert ("ksmi_maxpool2x2_forward" in names) != fused
             res[fused] = (logits.detach().float().cpu().clone(), m.flat_grads.detach().cpu().clone(), m.flat_buffers.detach().cpu().clone(),
                           m.flat_counters.detach().cpu().clone())
-            del m, plan
+            del m, plan, logits
+            torch.cuda.empty_cache()
     finally:
         SNUNetPlan.bn_fused = keep
     (la, ga, ba, ca), (lb, gb, bb, cb) = res[True], res[False]
     assert torch.equal(ca, cb)
     ndiff = int((la != lb).sum()) + int((ga != gb).sum()) + int((ba != bb).sum())
-    print(f"fused vs separate BatchNorm glue ({precision}, B={B}, {H}x{W}): {ndiff} differing words; logits max diff "
-          f"{float((la - lb).abs().max()):.3g}, gradients max diff {float((ga - gb).abs().max()):.3g} (scale {float(gb.abs().max()):.3g})")
-    assert float((la - lb).abs().max()) <= 1e-6 * float(lb.abs().max())
-    assert float((ba - bb).abs().max()) <= 1e-6 * float(bb.abs().max())
-    # the bias gradient of conv1 is a sum over the per-workgroup rows of the apply pass: its row partition differs between the two paths
-    assert float((ga - gb).abs().max()) <= 2e-5 * float(gb.abs().max())
+    lmax, lrms = float((la - lb).abs().max()) / float(lb.abs().max()), float((la - lb).pow(2).mean().sqrt()) / float(lb.abs().max())
+    gcos = float((ga.double() * gb.double()).sum() / (ga.double().norm() * gb.double().norm()))
+    print(f"fused vs separate BatchNorm glue ({precision}, B={B}, {H}x{W}): {ndiff} differing words; logits max diff {lmax:.3g} rms {lrms:.3g} of "
+          f"scale, gradients max diff {float((ga - gb).abs().max()):.3g} (scale {float(gb.abs().max()):.3g}), gradient cosine {gcos:.8f}")
+    assert float((ba - bb).abs().max()) <= 2e-6 * float(bb.abs().max())          # running statistics
+    if H < 224:
+        assert lmax <= 1e-6
+        # the bias gradient of conv1 is a sum over the per-workgroup rows of the apply pass: its row partition differs between the two paths
+        assert float((ga - gb).abs().max()) <= 2e-5 * float(gb.abs().max())
+    elif precision == "fp32":
+        assert lmax <= 2e-5 and gcos > 1 - 1e-8
+    else:
+        assert lmax <= 4e-2 and lrms <= 2e-3 and gcos > 0.999
