@@ -36,17 +36,25 @@ class KernelTimer:
     """HIP events around selected launches on the stream they are launched on (torch's current
     stream == the stream handed to the C-ABI)."""
 
-    def __init__(self, kinds=None):
+    def __init__(self, kinds=None, names=False):
         self.kinds = kinds          # None = every launch
         self.rec = []               # (kind, meta, ev0, ev1)
         self._cur = None
         self.active = True          # the timed region brackets launches in every TIMER_EVERY-th step only (the event pairs cost ~1.7 % of a step)
         self.steps_on = 0
+        self.names = names          # also ask the library which kernel instantiation(s) each launch started (ksmi_last_kernels)
+        self.kernels = []           # parallel to rec: tuple of kernel names ('' for elementwise launches)
+        if names:
+            import ctypes
+            from kurosiwo_amd import _lib
+            self._lib, self._buf = _lib.load(), ctypes.create_string_buffer(2048)
 
     def wants(self, kind):
         return self.active and (self.kinds is None or kind in self.kinds)
 
     def begin(self, kind, meta=None):
+        if self.names:
+            self._lib.ksmi_last_kernels(self._buf, 2048)          # (forget what earlier, untimed launches started)
         e0 = torch.cuda.Event(enable_timing=True)
         e0.record()
         self._cur = (kind, meta or {"bytes": 0, "flops": 0}, e0)
@@ -55,6 +63,9 @@ class KernelTimer:
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
         self.rec.append(self._cur + (e1,))
+        if self.names:
+            n = self._lib.ksmi_last_kernels(self._buf, 2048)
+            self.kernels.append(tuple(self._buf.value.decode().split(";")) if n else ())
         self._cur = None
 
     def summary(self):
@@ -110,6 +121,157 @@ def measured_traffic(kind, model="snunet"):
             if "reduce" not in name:
                 main_calls += row["calls"]
     return (round(tot / main_calls) if main_calls else None), rows
+
+
+def measure_hbm_peaks(dev, gib=1):
+    """Device-memory rates of THIS part, measured here ("measure ... on the box and quote both"): ksmi_hbm_probe
+    passes over 1 GiB operands (4 x the 256 MB memory-side cache), HIP events on the launching stream, best of 3 after a warm-up.
+    GB/s count every byte moved (copy = 2 x n, triad = 3 x n)."""
+    from kurosiwo_amd import _lib
+    from kurosiwo_amd.runtime import stream_ptr
+    lib = _lib.load()
+    n = gib << 30
+    a = torch.empty(n, dtype=torch.uint8, device=dev).fill_(1)
+    b, c = torch.empty_like(a), torch.empty_like(a)
+    b.fill_(2)
+    sink = torch.zeros(4, dtype=torch.int32, device=dev)
+    out = {}
+    for name, mode, moved in (("read_dma", 0, n), ("read_vec", 1, n), ("copy", 2, 2 * n), ("triad", 3, 3 * n), ("fill", 4, n)):
+        best = None
+        for it in range(4):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            _lib.check(lib.ksmi_hbm_probe(mode, (c if mode == 4 else a).data_ptr(), b.data_ptr(), c.data_ptr(), n, sink.data_ptr(), stream_ptr()), "hbm_probe")
+            e1.record()
+            e1.synchronize()
+            ms = e0.elapsed_time(e1)
+            if it and (best is None or ms < best):
+                best = ms
+        out[f"{name}_GBs"] = round(moved / best / 1e6, 1)
+    out["how"] = f"ksmi_hbm_probe over {gib} GiB operands, HIP events, best of 3 (csrc/probe.hip)"
+    del a, b, c
+    torch.cuda.empty_cache()
+    return out
+
+
+PROFILE_ROUNDS = ("r04", "r03")
+
+
+def profile_table(model, solo=True):
+    """per-kernel rows of the committed rocprofv3 passes (profiles/<round>_<model>[_solo]_traffic.json, written by profiles/summarize.py
+    from tools/profile.sh): calls, average duration, FETCH_SIZE / WRITE_SIZE, MFMA-busy; {} when no table is committed"""
+    for rnd in PROFILE_ROUNDS:
+        for tag in (("_solo", "") if solo else ("",)):
+            path = os.path.join(ROOT, "profiles", f"{rnd}_{TRAFFIC_FILE.get(model, model)}{tag}_traffic.json")
+            if os.path.exists(path):
+                return json.load(open(path))["kernels"], os.path.relpath(path, ROOT)
+    return {}, None
+
+
+def _row_bytes(row):
+    if row.get("fetch_kb_raw") is None or row.get("write_kb_raw") is None:
+        return None
+    return (2.0 * row["fetch_kb_raw"] + row["write_kb_raw"]) * 1024.0        # (x2: the guide's gfx950 FETCH_SIZE correction)
+
+
+def build_roofline(args, step, solo_timer, solo_steps, d, dominant, timer_steps, ms_step, step_bytes, step_flops, peaks, hbm_meas, two_streams):
+    """The `roofline` object of the bench line.
+
+    kernel / achieved / frac: ONE kernel instantiation -- the convolution / GEMM kernel with the largest total duration in the
+    single-stream pass -- by its rocprofv3 name; achieved = sum of the algorithmic bytes (or flops) of its launches / sum of their HIP-event
+    durations on one stream (launch metadata: the plans' meta["bytes"] / meta["flops"]); profile_avg_launch_ms = the same
+    kernel's average in the committed rocprofv3 table.  stages[]: every launch of the step grouped by the plan's stage tag (SNUNet:
+    resolution level).  in_step: the dominant kernel CLASS inside the timed (multi-stream) region, the figure earlier rounds reported."""
+    avg_ms = d["ms"] / d["n"]
+    cls_gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+    cls_tf = d["flops"] / (d["ms"] * 1e-3) / 1e12
+    in_step = {"kernel_class": dominant, "avg_launch_ms": round(avg_ms, 4), "launches_timed": d["n"],
+               "algorithmic_GBs": round(cls_gbs, 1), "hbm_frac": round(cls_gbs / HBM_PEAK_GBS, 4), "tflops": round(cls_tf, 1),
+               "mfma_frac": round(cls_tf / MFMA_BF16_PEAK_TF, 4), "share_of_step": round((d["ms"] / timer_steps) / ms_step, 3)}
+    if two_streams:
+        in_step["note"] = ("launches of the timed region share the machine with the other streams of the step (config.hip_streams): "
+                           "durations are per launch, not per machine-second")
+    common = {"measured_peaks": peaks, "measured_hbm_peak_GBs": hbm_meas, "in_step": in_step,
+              "step_algorithmic_GB": round(step_bytes / 1e9, 3), "step_GFLOP": round(step_flops / 1e9, 1),
+              "step_hbm_frac": round(step_bytes / ms_step / 1e6 / HBM_PEAK_GBS, 4),
+              "step_frac_of_measured_hbm": round(step_bytes / ms_step / 1e6 / hbm_meas, 4),
+              "step_mfma_frac": round(step_flops / ms_step / 1e9 / MFMA_BF16_PEAK_TF, 4)}
+    if solo_timer is None or not solo_timer.rec:
+        hbm = not (d["flops"] / MFMA_BF16_PEAK_TF / 1e12 > d["bytes"] / HBM_PEAK_GBS / 1e9 and args.precision == "bf16")
+        traffic, rows = measured_traffic(dominant, args.model)
+        return ({"kernel": dominant, "bound": "hbm", "achieved": round(cls_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(cls_gbs / HBM_PEAK_GBS, 4)}
+                if hbm else
+                {"kernel": dominant, "bound": "mfma", "achieved": round(cls_tf, 1), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": round(cls_tf / MFMA_BF16_PEAK_TF, 4)}
+                ) | {"traffic": traffic, "traffic_rows": rows, "note": "no single-stream pass in this run: kernel = the dominant kernel class of the timed region"} | common
+    table, table_path = profile_table(args.model)
+    by_kernel, stages = {}, {}
+    for (kind, meta, e0, e1), names in zip(solo_timer.rec, solo_timer.kernels):
+        ms = e0.elapsed_time(e1)
+        main = next((n for n in names if "reduce" not in n), None)
+        row = table.get(main) if main else None
+        if main:
+            k = by_kernel.setdefault(main, {"ms": 0.0, "n": 0, "bytes": 0, "flops": 0})
+            k["ms"] += ms; k["n"] += 1; k["bytes"] += meta.get("bytes", 0); k["flops"] += meta.get("flops", 0)
+        st = stages.setdefault(meta.get("stage") or "other", {"ms": 0.0, "n": 0, "conv_bytes": 0, "bytes": 0, "flops": 0, "counted": 0.0, "counted_n": 0,
+                                                               "busy_ms": 0.0, "busy_w": 0.0, "named_ms": 0.0})
+        st["ms"] += ms; st["n"] += 1; st["bytes"] += meta.get("bytes", 0); st["flops"] += meta.get("flops", 0)
+        if main:
+            st["conv_bytes"] += meta.get("bytes", 0)
+            st["named_ms"] += ms
+            if row is not None:
+                rb = sum(filter(None, (_row_bytes(table[n]) for n in names if n in table)))
+                if rb:
+                    st["counted"] += rb; st["counted_n"] += 1
+                if row.get("mfma_busy_pct") is not None:
+                    st["busy_ms"] += ms; st["busy_w"] += ms * row["mfma_busy_pct"]
+    if os.environ.get("BENCH_LAUNCH_MAP"):         # per-launch table of the LAST single-stream step (profiles/summarize.py aligns traces with it)
+        per = len(solo_timer.rec) // max(solo_steps, 1)
+        rows_ = [{"i": i, "kind": kind, "stage": meta.get("stage"), "tag": meta.get("tag", ""), "kernels": list(names), "bytes": meta.get("bytes", 0),
+                  "flops": meta.get("flops", 0), "ms": round(e0.elapsed_time(e1), 5)}
+                 for i, ((kind, meta, e0, e1), names) in enumerate(zip(solo_timer.rec[-per:], solo_timer.kernels[-per:]))]
+        json.dump(rows_, open(os.environ["BENCH_LAUNCH_MAP"], "w"))
+    name = max(by_kernel, key=lambda n: by_kernel[n]["ms"])
+    k = by_kernel[name]
+    gbs, tf = k["bytes"] / (k["ms"] * 1e-3) / 1e9, k["flops"] / (k["ms"] * 1e-3) / 1e12
+    hbm = not (k["flops"] / MFMA_BF16_PEAK_TF / 1e12 > k["bytes"] / HBM_PEAK_GBS / 1e9 and args.precision == "bf16")
+    row = table.get(name)
+    roof = ({"kernel": name, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+             "frac_of_measured_hbm": round(gbs / hbm_meas, 4)} if hbm else
+            {"kernel": name, "bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / MFMA_BF16_PEAK_TF, 4)})
+    roof |= {"traffic": None if row is None or _row_bytes(row) is None else round(_row_bytes(row)), "traffic_unit": "bytes/launch",
+             "algorithmic_bytes_per_launch": round(k["bytes"] / k["n"]), "launches_timed": k["n"], "avg_launch_ms": round(k["ms"] / k["n"], 4),
+             "algorithmic_GBs": round(gbs, 1), "tflops": round(tf, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4), "mfma_frac": round(tf / MFMA_BF16_PEAK_TF, 4),
+             "share_of_solo_step": round(k["ms"] / sum(v["ms"] for v in stages.values()), 3),
+             "how": f"single stream, {solo_steps} steps after the timed region, HIP events around every launch on the launching stream; kernel names from ksmi_last_kernels",
+             "profile": None if row is None else {"table": table_path, "calls": row["calls"], "avg_launch_ms": round(row["avg_us"] / 1e3, 4),
+                                                  "mfma_busy_pct": None if row.get("mfma_busy_pct") is None else round(row["mfma_busy_pct"], 1)},
+             "top_kernels": [{"kernel": n, "launches_per_step": v["n"] // solo_steps, "avg_launch_ms": round(v["ms"] / v["n"], 4),
+                              "ms_per_step": round(v["ms"] / solo_steps, 3), "algorithmic_GBs": round(v["bytes"] / v["ms"] / 1e6, 1),
+                              "tflops": round(v["flops"] / v["ms"] / 1e9, 1)}
+                             for n, v in sorted(by_kernel.items(), key=lambda kv: -kv[1]["ms"])[:8]]}
+    order = sorted(stages, key=lambda t: (not t.startswith("L"), t))
+    roof["stages"] = [{"stage": t, "launches_per_step": stages[t]["n"] // solo_steps, "ms_per_step_solo": round(stages[t]["ms"] / solo_steps, 3),
+                       "conv_algorithmic_GB": round(stages[t]["conv_bytes"] / solo_steps / 1e9, 3), "all_passes_GB": round(stages[t]["bytes"] / solo_steps / 1e9, 3),
+                       "counted_conv_GB": None if not stages[t]["counted_n"] else round(stages[t]["counted"] / solo_steps / 1e9, 3),
+                       "GBs": round(stages[t]["bytes"] / max(stages[t]["ms"], 1e-9) / 1e6, 1),
+                       "hbm_frac": round(stages[t]["bytes"] / max(stages[t]["ms"], 1e-9) / 1e6 / HBM_PEAK_GBS, 4),
+                       "frac_of_measured_hbm": round(stages[t]["bytes"] / max(stages[t]["ms"], 1e-9) / 1e6 / hbm_meas, 4),
+                       "GFLOP": round(stages[t]["flops"] / solo_steps / 1e9, 1), "tflops": round(stages[t]["flops"] / max(stages[t]["ms"], 1e-9) / 1e9, 1),
+                       "mfma_frac": round(stages[t]["flops"] / max(stages[t]["ms"], 1e-9) / 1e9 / MFMA_BF16_PEAK_TF, 4),
+                       "mfma_busy_pct": None if not stages[t]["busy_ms"] else round(stages[t]["busy_w"] / stages[t]["busy_ms"], 1)}
+                      for t in order]
+    roof["stages_note"] = ("all_passes_GB = algorithmic bytes of EVERY launch of the stage (convolutions + BatchNorm / pooling / elementwise passes), "
+                           "conv_algorithmic_GB = the convolution / GEMM launches alone (SURVEY.md §8(d) counts these); counted_conv_GB and mfma_busy_pct "
+                           "use the per-kernel averages of the committed PMC table (a kernel instantiation that serves several stages contributes its "
+                           "average to each), null without a table")
+    if "attention_block" in stages:            # north_star: ">= 40 % of the bf16 MFMA peak on the ChangeFormer attention block"
+        a = stages["attention_block"]
+        roof["attention_block"] = {"what": "Block.forward first half, forward + backward: norm1 -> q / sr-conv / norm / kv linears -> softmax(q k^T) v -> proj -> "
+                                           "dropout / DropPath + residual (models/changeformer.py:148-208, 239-243), all 13 blocks, both dates",
+                                   "launches_per_step": a["n"] // solo_steps, "GFLOP_per_step": round(a["flops"] / solo_steps / 1e9, 1),
+                                   "ms_per_step_solo": round(a["ms"] / solo_steps, 3), "tflops": round(a["flops"] / a["ms"] / 1e9, 1),
+                                   "mfma_frac": round(a["flops"] / a["ms"] / 1e9 / MFMA_BF16_PEAK_TF, 4), "target": 0.40}
+    return roof | common
 
 
 def cpu_baseline(budget_s=20.0):
@@ -310,22 +472,24 @@ def main():
         for _ in range(timer_steps):
             step.run()
         sync()
-    # With more than one stream (trainer.py overlap_wgrad / overlap_lanes) the launches timed above shared the machine with the other streams, so
-    # their durations -- and the roofline block below, which is defined over the timed region -- describe the overlapped step, not
-    # the kernel.  A few more steps with the lane off give the same kernel class alone on the machine ("solo").
-    solo = None
+    # ---- the kernels alone on the machine ("solo"): with more than one stream (trainer.py overlap_wgrad / overlap_lanes) the launches
+    # timed above shared the GPU with the other streams, so their durations describe the overlapped step, not the kernel.  A few more
+    # steps on ONE stream with EVERY launch bracketed by HIP events (on the stream it is launched on) give per-kernel durations that
+    # a rocprofv3 --kernel-trace of a single-stream run reproduces; the library reports which kernel instantiation each launch
+    # started (ksmi_last_kernels), so every record carries the name it has in the rocprofv3 tables under profiles/.
     n_streams = (1 + int(bool(getattr(step, "overlap_wgrad", False) and getattr(step.plan, "side_wgrad", False)))
                  + int(bool(getattr(step, "overlap_lanes", False) and getattr(step.plan, "two_lanes", False))))
     two_streams = n_streams > 1
-    if two_streams and not graph and not args.no_solo:
-        solo_timer = KernelTimer({dominant})
-        keep = (step.overlap_wgrad, step.overlap_lanes)
-        step.timer, step.overlap_wgrad, step.overlap_lanes = solo_timer, False, False
-        for _ in range(min(args.steps, 5)):
+    solo_timer, solo_steps = None, 0
+    if not args.no_solo and hasattr(step, "overlap_wgrad"):
+        solo_timer = KernelTimer(None, names=True)
+        keep = (step.overlap_wgrad, step.overlap_lanes, getattr(step, "_graph", None))
+        step.timer, step.overlap_wgrad, step.overlap_lanes, step._graph = solo_timer, False, False, None
+        solo_steps = min(args.steps, 3)
+        for _ in range(solo_steps):
             step.run()
         sync()
-        step.timer, (step.overlap_wgrad, step.overlap_lanes) = timer, keep
-        solo = solo_timer.summary().get(dominant)
+        step.timer, step.overlap_wgrad, step.overlap_lanes, step._graph = (timer if not graph else None), keep[0], keep[1], keep[2]
     dp_check = None
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
@@ -347,57 +511,24 @@ def main():
     if rank == 0:
         ts = timer.summary()
         d = ts[dominant]
-        avg_ms = d["ms"] / d["n"]
-        ach_gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9
-        ach_tf = d["flops"] / (d["ms"] * 1e-3) / 1e12
-        traffic, traffic_rows = measured_traffic(dominant, args.model)
         step_flops = sum(c[3]["flops"] for c in step.plan.fwd.calls + step.plan.bwd.calls)
         step_bytes = sum(c[3]["bytes"] for c in step.plan.fwd.calls + step.plan.bwd.calls)
+        ms_step = dt / args.steps * 1e3
+        peaks = measure_hbm_peaks(dev) if world == 1 else None
+        hbm_meas = max(peaks["copy_GBs"], peaks["triad_GBs"]) if peaks else HBM_MEASURED_GBS
         res = {
             "metric": metric,
             "value": round(B * world * args.steps / dt, 2), "unit": "tiles/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": workload + ("+RCCL all-reduce" if world > 1 else "") + (" [HIP graph replay]" if graph else ""),
                        "global_batch": B * world, "base_channel": args.base_channel, "parallelism": f"dp{world}",
                        "hip_streams": n_streams,
                        "loss_last": [round(x, 5) for x in loss]} | ({"dp_check": dp_check} if dp_check else {}),
-            # the roofline that bounds the dominant kernel class: the larger of bytes / HBM peak and flops / MFMA peak
-            "roofline": ({"kernel": dominant, "bound": "mfma", "achieved": round(ach_tf, 1), "peak": MFMA_BF16_PEAK_TF,
-                          "unit": "TFLOP/s", "frac": round(ach_tf / MFMA_BF16_PEAK_TF, 4)}
-                         if d["flops"] / MFMA_BF16_PEAK_TF / 1e12 > d["bytes"] / HBM_PEAK_GBS / 1e9 and args.precision == "bf16" else
-                         {"kernel": dominant, "bound": "hbm", "achieved": round(ach_gbs, 1), "peak": HBM_PEAK_GBS,
-                          "unit": "GB/s", "frac": round(ach_gbs / HBM_PEAK_GBS, 4)}) | {
-                         # HBM bytes per launch by the PMC counters (2 x FETCH_SIZE + WRITE_SIZE, profiles/r02_snunet_traffic.json; the forward
-                         # and input-gradient classes share their kernels, so the table row is their common mean) next to the algorithmic bytes
-                         "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_rows": traffic_rows,
-                         "traffic_source": f"profiles/{TRAFFIC_ROUND}_{TRAFFIC_FILE.get(args.model, args.model)}_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
-                                           "passes of this command, tools/profile.sh; rows keyed by kernel name incl. direction)",
-                         "frac_of_measured_hbm": round(ach_gbs / HBM_MEASURED_GBS, 4), "measured_hbm_peak_GBs": HBM_MEASURED_GBS,
-                         "algorithmic_bytes_per_launch": round(d["bytes"] / max(d["n"], 1)),
-                         "launches_timed": d["n"], "avg_launch_ms": round(avg_ms, 4),
-                         "share_of_step": round((d["ms"] / timer_steps) / (dt * 1e3 / args.steps), 3),
-                         "algorithmic_GBs": round(ach_gbs, 1), "hbm_frac": round(ach_gbs / HBM_PEAK_GBS, 4),
-                         "tflops": round(ach_tf, 1), "mfma_frac": round(ach_tf / MFMA_BF16_PEAK_TF, 4),
-                         "step_algorithmic_GB": round(step_bytes / 1e9, 3), "step_GFLOP": round(step_flops / 1e9, 1),
-                         "step_hbm_frac": round(step_bytes / dt * args.steps / 1e9 / HBM_PEAK_GBS, 4),
-                         "step_frac_of_measured_hbm": round(step_bytes / dt * args.steps / 1e9 / HBM_MEASURED_GBS, 4),
-                         "step_mfma_frac": round(step_flops / dt * args.steps / 1e12 / MFMA_BF16_PEAK_TF, 4)},
         }
-        if two_streams:
-            res["roofline"]["overlapped"] = ("the timed launches share the machine with the launches of the other streams of the step "
-                                             "(config.hip_streams; weight gradients, second decoder lane): durations are per launch, not per machine-second")
-        if solo and solo["n"]:
-            hbm = res["roofline"]["bound"] == "hbm"
-            s_ach = (solo["bytes"] / 1e9 if hbm else solo["flops"] / 1e12) / (solo["ms"] * 1e-3)
-            res["roofline"]["achieved_solo"] = round(s_ach, 1)
-            res["roofline"]["frac_solo"] = round(s_ach / (HBM_PEAK_GBS if hbm else MFMA_BF16_PEAK_TF), 4)
-            if hbm:
-                res["roofline"]["frac_solo_of_measured_hbm"] = round(s_ach / HBM_MEASURED_GBS, 4)
-            res["roofline"]["solo"] = {"avg_launch_ms": round(solo["ms"] / solo["n"], 4), "achieved": round(s_ach, 1),
-                                       "frac": round(s_ach / (HBM_PEAK_GBS if hbm else MFMA_BF16_PEAK_TF), 4), "launches_timed": solo["n"],
-                                       "how": "same kernel class, single stream, steps run after the timed region"}
+        res["roofline"] = build_roofline(args, step, solo_timer, solo_steps, d, dominant, timer_steps, ms_step, step_bytes, step_flops,
+                                         peaks, hbm_meas, two_streams)
         if args.time_all:
             tot = sum(v["ms"] for v in ts.values())
             res["kernels"] = {k: {"ms_per_step": round(v["ms"] / args.steps, 3), "launches": v["n"] // args.steps,

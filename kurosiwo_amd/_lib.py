@@ -91,6 +91,7 @@ _P4 = C.c_void_p * 4
 SIGNATURES = {
     "ksmi_abi_version": (_i, []),
     "ksmi_last_kernels": (_i, [C.c_char_p, _i]),
+    "ksmi_hbm_probe": (_i, [_i, _vp, _vp, _vp, C.c_size_t, _vp, _vp]),
     "ksmi_last_error": (C.c_char_p, []),
     "ksmi_chunk_elems": (_i, [_i]),
     "ksmi_conv_grid_m": (_i, [C.POINTER(ConvDesc)]),

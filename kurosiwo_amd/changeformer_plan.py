@@ -140,6 +140,7 @@ class ChangeFormerPlan(PlanBase):
             Hs, Ws = Hi // stride, Wi // stride
             R, Rk = B2 * Hs * Ws, B2 * 49
             pe = f"Tenc_x2.patch_embed{st + 1}"
+            self._stage("patch_embed")
             kc = 32 if self.dtype == torch.bfloat16 else 16
             Kreal = src_c * 49
             Kpad = -(-Kreal // kc) * kc
@@ -164,6 +165,7 @@ class ChangeFormerPlan(PlanBase):
                 rec = dict(k=k, t_in=t, gi=sum(DEPTHS[:st]) + i)
                 gi = rec["gi"]
                 h, q, att, t_mid = self.buf(R, Cc), self.buf(R, Cc), self.buf(R, Cc), self.buf(R, Cc)
+                self._stage("attention_block")          # Block.forward's first half: norm1 -> Attention (q, sr conv, norm, kv, softmax(qk^T)v, proj) -> drop + residual
                 rec["st1"] = self._ln(t, f"{k}.norm1.weight", f"{k}.norm1.bias", h, R, Cc, 1e-6)
                 self._linear(f"{k}.q", h, Cc, f"{k}.attn.q.weight", f"{k}.attn.q.bias", q, Cc, R)
                 if sr > 1:
@@ -198,6 +200,7 @@ class ChangeFormerPlan(PlanBase):
                 else:
                     self._linear(f"{k}.proj", att, Cc, f"{k}.attn.proj.weight", f"{k}.attn.proj.bias", t_mid, Cc, R, resid=t)
                 h2, u, z, g, t_out = self.buf(R, Cc), self.buf(R, 4 * Cc), self.buf(R, 4 * Cc), self.buf(R, 4 * Cc), self.buf(R, Cc)
+                self._stage("mlp_block")
                 rec["st2"] = self._ln(t_mid, f"{k}.norm2.weight", f"{k}.norm2.bias", h2, R, Cc, 1e-6)
                 self._linear(f"{k}.fc1", h2, Cc, f"{k}.mlp.fc1.weight", f"{k}.mlp.fc1.bias", u, 4 * Cc, R)
                 wd, bd = m._p(f"{k}.mlp.dwconv.dwconv.weight").data_ptr(), m._p(f"{k}.mlp.dwconv.dwconv.bias").data_ptr()
@@ -215,12 +218,14 @@ class ChangeFormerPlan(PlanBase):
                 t = t_out
                 self.named[f"s{st + 1}b{i}"] = t
             f = self.buf(R, Cc)
+            self._stage("patch_embed")
             st_n = self._ln(t, f"Tenc_x2.norm{st + 1}.weight", f"Tenc_x2.norm{st + 1}.bias", f, R, Cc, 1e-6)
             self.named[f"f{st + 1}"] = f
             feats.append(dict(f=f, C=Cc, H=Hs, W=Ws, R=R, Rk=Rk, heads=heads, sr=sr, stride=stride, Hi=Hi, Wi=Wi, src=src, src_c=src_c,
                               col=col, Kpad=Kpad, Kreal=Kreal, t0=t0, st_pe=st_pe, pe=pe, blocks=blocks, t_last=t, st_n=st_n, st=st, pe_wtc=pe_wtc))
             src, src_c = f, Cc
         self.feats = feats
+        self._stage("decoder")
         self._build_decoder()
 
     # ---------------------------------------------------------------- decoder (changeformer.py:568-641)
@@ -335,6 +340,7 @@ class ChangeFormerPlan(PlanBase):
 
     def _build_backward(self):
         m, B, E, dt, nc = self.m, self.B, self.E, self.dt, self.nc
+        self._stage("decoder")
         D = "TDec_x2"
         dec = self.dec
         H1, W1, np1 = dec["H1"], dec["W1"], dec["np1"]
@@ -460,6 +466,7 @@ class ChangeFormerPlan(PlanBase):
         gt = self.buf(R, Cc)
         tC, t4, tq, tkv, tk = self.buf(R, Cc), self.buf(R, 4 * Cc), self.buf(R, Cc), self.buf(Rk, 2 * Cc), self.buf(Rk, Cc)
         st = ft["st"]
+        self._stage("patch_embed")
         self._ln_bwd(ft["df"], ft["t_last"], ft["st_n"], f"Tenc_x2.norm{st + 1}.weight", f"Tenc_x2.norm{st + 1}.bias", gt, 0, R, Cc)
         ws_attn = self.lib.ksmi_sr_attention_bwd_workspace(B2, Hs * Ws, 49, heads, Cc)
         self.need("attn", ws_attn)
@@ -469,6 +476,7 @@ class ChangeFormerPlan(PlanBase):
             k, gi = rec["k"], rec["gi"]
             active = self._branch_active(gi)
             # Mlp
+            self._stage("mlp_block")
             gy = gt
             if active:
                 self._drop(self.bwd, gt, None, tD, R, Cc, N, self._site(gi, SITE_MLP2, self.p_drop), self._site(gi, SITE_PATH_MLP, self.dpr[gi]))
@@ -496,6 +504,7 @@ class ChangeFormerPlan(PlanBase):
             self._linear_bwd(f"{k}.fc1", rec["h2"], Cc, f"{k}.mlp.fc1.weight", f"{k}.mlp.fc1.bias", du, 4 * Cc, R, tC)
             self._ln_bwd(tC, rec["t_mid"], rec["st2"], f"{k}.norm2.weight", f"{k}.norm2.bias", gt, 1, R, Cc)
             # Attention
+            self._stage("attention_block")
             gy = gt
             if active:
                 self._drop(self.bwd, gt, None, tD, R, Cc, N, self._site(gi, SITE_PROJ, self.p_drop), self._site(gi, SITE_PATH_ATTN, self.dpr[gi]))
@@ -527,6 +536,7 @@ class ChangeFormerPlan(PlanBase):
                 self._linear_bwd(f"{k}.q", rec["h"], Cc, f"{k}.attn.q.weight", f"{k}.attn.q.bias", tq, Cc, R, dh, dx_acc=1)
             self._ln_bwd(dh, rec["t_in"], rec["st1"], f"{k}.norm1.weight", f"{k}.norm1.bias", gt, 1, R, Cc)
         # patch embedding
+        self._stage("patch_embed")
         pe = ft["pe"]
         dt0 = tC
         self._ln_bwd(gt, ft["t0"], ft["st_pe"], f"{pe}.norm.weight", f"{pe}.norm.bias", dt0, 0, R, Cc)

@@ -1,0 +1,110 @@
+// Device-memory rate probes behind ksmi_hbm_probe (measurement aid of bench.py: `roofline.measured_peaks`).  SURVEY.md §8(d) asks for
+// the achieved fractions against the spec figure AND against what THIS part delivers: the probes stream operands far larger than
+// the 256 MB memory-side cache and are timed with HIP events by the caller.
+//   mode 0  read, LDS-DMA     every wave keeps 8 x 1 KB global_load_lds_dwordx4 in flight into its own LDS slice, nothing consumes
+//                             them: the pure read stream of the persistent convolution kernels (dma.h)
+//   mode 1  read, vector      16-byte non-temporal loads, 8 per lane in flight, xor-folded into one store per workgroup
+//   mode 2  copy              b[i] = a[i]                     (bytes moved = 2 x n)
+//   mode 3  triad             c[i] = a[i] + s * b[i]  (fp32)  (bytes moved = 3 x n)
+//   mode 4  fill              a[i] = s                        (bytes moved = n)
+#include "common.h"
+#include "dma.h"
+#include "../../include/ksmi.h"
+#include "errors.h"
+
+namespace {
+
+constexpr int kT = 512;
+
+__global__ __launch_bounds__(kT) void probe_read_dma(const unsigned char* __restrict__ a, size_t nbytes, unsigned* sink) {
+  extern __shared__ unsigned char smem[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = kT / 64;
+  const size_t chunk = (size_t)1024 * 8;                                    // bytes per wave per trip: 8 DMA instructions of 1 KB
+  const size_t per_wg = chunk * nw;
+  const unsigned lds0 = (unsigned)(uintptr_t)smem + wave * 8192;
+  const size_t trips = nbytes / (per_wg * gridDim.x);
+  const unsigned char* p = a + (size_t)blockIdx.x * per_wg + (size_t)wave * chunk + lane * 16;
+  for (size_t t = 0; t < trips; ++t) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) glds16_flat(p + k * 1024, lds0 + k * 1024);
+    p += per_wg * gridDim.x;
+    vm_wait(8);                                                             // the previous trip has landed; this one stays in flight
+  }
+  vm_wait(0);
+  __syncthreads();
+  if (threadIdx.x == 0 && smem[17] == 0x5a && smem[4097] == 0xa5) sink[0] = 1;   // (keeps the loads observable)
+}
+
+__global__ __launch_bounds__(256) void probe_read_vec(const u32x4* __restrict__ a, size_t nvec, unsigned* sink) {
+  u32x4 acc = {0u, 0u, 0u, 0u};
+  const size_t stride = (size_t)gridDim.x * 256;
+  size_t v = (size_t)blockIdx.x * 256 + threadIdx.x;
+  for (; v + 7 * stride < nvec; v += 8 * stride) {
+    u32x4 r[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r[k] = __builtin_nontemporal_load(a + v + k * stride);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc ^= r[k];
+  }
+  for (; v < nvec; v += stride) acc ^= __builtin_nontemporal_load(a + v);
+  if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345678u) sink[1] = 1;
+}
+
+__global__ __launch_bounds__(256) void probe_copy(const u32x4* __restrict__ a, u32x4* __restrict__ b, size_t nvec) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  size_t v = (size_t)blockIdx.x * 256 + threadIdx.x;
+  for (; v + 3 * stride < nvec; v += 4 * stride) {
+    u32x4 r[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r[k] = a[v + k * stride];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) b[v + k * stride] = r[k];
+  }
+  for (; v < nvec; v += stride) b[v] = a[v];
+}
+
+__global__ __launch_bounds__(256) void probe_triad(const f32x4* __restrict__ a, const f32x4* __restrict__ b, f32x4* __restrict__ c, float s, size_t nvec) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  size_t v = (size_t)blockIdx.x * 256 + threadIdx.x;
+  for (; v + stride < nvec; v += 2 * stride) {
+    const f32x4 a0 = a[v], b0 = b[v], a1 = a[v + stride], b1 = b[v + stride];
+    c[v] = a0 + s * b0;
+    c[v + stride] = a1 + s * b1;
+  }
+  for (; v < nvec; v += stride) c[v] = a[v] + s * b[v];
+}
+
+__global__ __launch_bounds__(256) void probe_fill(f32x4* __restrict__ a, float s, size_t nvec) {
+  const f32x4 val = {s, s, s, s};
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < nvec; v += stride) a[v] = val;
+}
+
+}  // namespace
+
+extern "C" int ksmi_hbm_probe(int mode, const void* a, void* b, void* c, size_t nbytes, unsigned* sink, void* stream) {
+  if (!a || nbytes < ((size_t)1 << 20) || (nbytes & 15) || !sink) return ksmi_fail(KSMI_E_ARG, "hbm_probe: >= 1 MiB, multiple of 16 bytes, a sink word pair");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t nvec = nbytes / 16;
+  switch (mode) {
+    case 0: {
+      const int grid = 512;                                                  // two workgroups per CU: 16 waves x 8 KB in flight each
+      const size_t per = (size_t)1024 * 8 * (kT / 64) * grid;
+      if (nbytes % per) return ksmi_fail(KSMI_E_ARG, "hbm_probe: mode 0 needs a multiple of 32 MiB");
+      hipLaunchKernelGGL(probe_read_dma, dim3(grid), dim3(kT), 8192 * (kT / 64), st, (const unsigned char*)a, nbytes, sink);
+      break;
+    }
+    case 1: hipLaunchKernelGGL(probe_read_vec, dim3(4096), dim3(256), 0, st, (const u32x4*)a, nvec, sink); break;
+    case 2:
+      if (!b) return ksmi_fail(KSMI_E_ARG, "hbm_probe: copy needs b");
+      hipLaunchKernelGGL(probe_copy, dim3(8192), dim3(256), 0, st, (const u32x4*)a, (u32x4*)b, nvec);
+      break;
+    case 3:
+      if (!b || !c) return ksmi_fail(KSMI_E_ARG, "hbm_probe: triad needs b and c");
+      hipLaunchKernelGGL(probe_triad, dim3(8192), dim3(256), 0, st, (const f32x4*)a, (const f32x4*)b, (f32x4*)c, 0.5f, nvec);
+      break;
+    case 4: hipLaunchKernelGGL(probe_fill, dim3(8192), dim3(256), 0, st, (f32x4*)(void*)a, 1.0f, nvec); break;
+    default: return ksmi_fail(KSMI_E_ARG, "hbm_probe: mode 0..4");
+  }
+  return ksmi_check_launch("hbm_probe");
+}

@@ -61,6 +61,10 @@ class PlanBase:
             ll.resolve(self.lib)
 
     # ---------------------------------------------------------------- small helpers
+    def _stage(self, name):
+        """measurement tag of the launches appended from here on (bench.py roofline.stages / attention_block)"""
+        self.fwd.cur_stage = self.bwd.cur_stage = name
+
     def need(self, name, nbytes):
         self._need[name] = max(self._need.get(name, 0), int(nbytes))
 

@@ -26,10 +26,12 @@ class LaunchList:
     def __init__(self):
         self.pending, self.calls = [], []
         self.cur_lane = 0
+        self.cur_stage = None      # measurement tag of the launches appended from here on (bench.py roofline.stages)
 
     def add(self, name, argfn, meta=None):
         meta = dict(meta) if meta else {"kind": name[5:], "bytes": 0, "flops": 0}
         meta["lane"] = self.cur_lane
+        meta.setdefault("stage", self.cur_stage)
         self.pending.append((name, argfn, meta))
 
     def add_wait(self, src, dst):
@@ -280,6 +282,11 @@ class SNUNetPlan:
         """launches appended from here on belong to compute lane `lane`"""
         self.fwd.cur_lane = self.bwd.cur_lane = lane
 
+    def _stage(self, H):
+        """measurement tag: the resolution level of the maps a module works on (L0 = full resolution ... L4 = 1/16)"""
+        lvl = {self.H >> k: k for k in range(5)}.get(H)
+        self.fwd.cur_stage = self.bwd.cur_stage = None if lvl is None else f"L{lvl}"
+
     def _sname(self, name):
         """scratch buffers that live from one launch to the next of the same block are per lane"""
         return name if self.fwd.cur_lane == 0 else f"{name}@{self.fwd.cur_lane}"
@@ -426,6 +433,7 @@ class SNUNetPlan:
     # ---------------------------------------------------------------- nn.MaxPool2d(2,2)  (snunet.py:73)
     def _pool(self, x, name):
         y = Act(name, x.B, x.H // 2, x.W // 2, x.C, self.dtype, self.dev)
+        self._stage(x.H)
         self.fwd.add("ksmi_maxpool2x2_forward", lambda: (x.t.data_ptr(), y.t.data_ptr(), x.B, x.H, x.W, x.C, self.dt))
         self._pool_bwd(x, y)
         return y
@@ -441,6 +449,7 @@ class SNUNetPlan:
     def _pool_bwd(self, x, y):
         """backward of y = maxpool2x2(x) (y written by ksmi_maxpool2x2_forward or by the fused block tail)"""
         def build_bwd():
+            self._stage(x.H)
             self._emit_dgrad(y)
             acc = x.take_acc_flag()
             gy, gx = y.grad(), x.grad()
@@ -452,6 +461,7 @@ class SNUNetPlan:
     def _up(self, name, x):
         Cc, B, H, W = x.C, x.B, x.H, x.W
         y = Act(name, B, 2 * H, 2 * W, Cc, self.dtype, self.dev)
+        self._stage(2 * H)                                   # (an Up is booked on the level it writes)
         wkey, bkey = f"{name}.up.weight", f"{name}.up.bias"
         d, table = make_conv([SrcSpec(x.t, Cc)], [(y.t, Cc, 0, 0, 4 * Cc, 0)], x.t, self.m._p(bkey), None,
                              B, H, W, H, W, 1, 1, 1, 0, 4 * Cc, self.dtype, ps_cout=Cc)
@@ -461,6 +471,7 @@ class SNUNetPlan:
         self._conv(self.fwd, d)
 
         def build_bwd():
+            self._stage(2 * H)
             fused_bias = self._emit_dgrad(y, bias_key=bkey)
             gy = y.grad()
             s2 = [SrcSpec(gy, Cc)]
@@ -491,6 +502,7 @@ class SNUNetPlan:
         m, B, H, W, Cc = self.m, out.B, out.H, out.W, out.C
         npix = B * H * W
         dtype, dt, training = self.dtype, self.dt, self.training
+        self._stage(H)
         i_act = Act(f"{name}{branch}.i", B, H, W, Cc, dtype, self.dev)
         z_act = Act(f"{name}{branch}.z", B, H, W, Cc, dtype, self.dev)
         sv1, sv2 = _Saved(Cc, self.dev), _Saved(Cc, self.dev)
@@ -575,6 +587,7 @@ class SNUNetPlan:
 
         # ---- backward ----------------------------------------------------------------------------
         def build_bwd():
+            self._stage(H)
             # (the virtual-sum input gradient below is the last writer of d out: the other producers -- pool / Up input gradients, the
             # ECAM head -- belong to modules later in the forward order, i.e. earlier in this list)
             gated = self._emit_dgrad(out, gate=(out.t, z_act.t, sv2)) if os.environ.get("KSMI_NO_GATE") is None else self._emit_dgrad(out)
@@ -689,6 +702,7 @@ class SNUNetPlan:
         m, B, n = self.m, self.B, self.n
         HW = self.H * self.W
         dev, dt = self.dev, self.dt
+        self.fwd.cur_stage = self.bwd.cur_stage = "head"
         f32 = dict(dtype=torch.float32, device=dev)
         avg, mx = torch.zeros((B, 5 * n), **f32), torch.zeros((B, 5 * n), **f32)
         argmax = torch.zeros((B, 5 * n), dtype=torch.int32, device=dev)
@@ -708,6 +722,7 @@ class SNUNetPlan:
                                                          P("conv_final.bias"), self.logits.data_ptr(), B, HW, n, 3, dt))
 
         def build_bwd():
+            self.fwd.cur_stage = self.bwd.cur_stage = "head"
             dca, dca1 = torch.zeros((B, 4 * n), **f32), torch.zeros((B, n), **f32)
             davg, dmax = torch.zeros((B, 5 * n), **f32), torch.zeros((B, 5 * n), **f32)
             ws_b = torch.empty(self.lib.ksmi_ecam_bwd_workspace(B, HW, n, 3), dtype=torch.uint8, device=dev)
