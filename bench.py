@@ -136,19 +136,23 @@ def measure_hbm_peaks(dev, gib=1):
     b.fill_(2)
     sink = torch.zeros(4, dtype=torch.int32, device=dev)
     out = {}
-    for name, mode, moved in (("read_dma", 0, n), ("read_vec", 1, n), ("copy", 2, 2 * n), ("triad", 3, 3 * n), ("fill", 4, n)):
-        best = None
-        for it in range(4):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            _lib.check(lib.ksmi_hbm_probe(mode, (c if mode == 4 else a).data_ptr(), b.data_ptr(), c.data_ptr(), n, sink.data_ptr(), stream_ptr()), "hbm_probe")
-            e1.record()
-            e1.synchronize()
-            ms = e0.elapsed_time(e1)
-            if it and (best is None or ms < best):
-                best = ms
+    for name, kind, moved in (("read_dma", 0, n), ("read_vec", 1, n), ("copy", 2, 2 * n), ("triad", 3, 3 * n), ("fill", 4, n)):
+        best, how = None, None
+        variants = [kind] if kind == 0 else [kind | nt << 3 | g << 4 for nt in ((0, 1) if kind > 1 else (0,)) for g in range(4)]
+        for mode in variants:                      # (non-temporal or not, 8192 ... 1024 workgroups: the best variant is the part's rate)
+            for it in range(3):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                _lib.check(lib.ksmi_hbm_probe(mode, (c if kind == 4 else a).data_ptr(), b.data_ptr(), c.data_ptr(), n, sink.data_ptr(), stream_ptr()), "hbm_probe")
+                e1.record()
+                e1.synchronize()
+                ms = e0.elapsed_time(e1)
+                if it and (best is None or ms < best):
+                    best, how = ms, mode
         out[f"{name}_GBs"] = round(moved / best / 1e6, 1)
-    out["how"] = f"ksmi_hbm_probe over {gib} GiB operands, HIP events, best of 3 (csrc/probe.hip)"
+        if kind:
+            out[f"{name}_variant"] = f"{'nt ' if (how >> 3) & 1 else ''}{8192 >> ((how >> 4) & 3)} workgroups"
+    out["how"] = f"ksmi_hbm_probe over {gib} GiB operands, HIP events, best of 2 per variant (csrc/probe.hip)"
     del a, b, c
     torch.cuda.empty_cache()
     return out

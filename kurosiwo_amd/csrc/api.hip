@@ -1,5 +1,11 @@
 // libksmi: ABI version + thread-local error reporting.
 #include <string.h>
+#include <stdlib.h>
+#include <cxxabi.h>
+#include <map>
+#include <mutex>
+#include <string>
+#include <hip/hip_runtime.h>
 #include "../../include/ksmi.h"
 #include "errors.h"
 
@@ -19,30 +25,55 @@ int ksmi_check_launch(const char* what) {
   return ksmi_fail((int)e, buf);
 }
 
-// kernels started by this thread's launchers since the last ksmi_last_kernels() (the __PRETTY_FUNCTION__ of ksmi_kernel_pretty<&kernel>)
-static thread_local const char* g_notes[8];
+// kernels started by this thread's launchers since the last ksmi_last_kernels() (host function pointers, resolved on demand)
+static thread_local const void* g_notes[8];
 static thread_local int g_nnotes = 0;
-void ksmi_note_kernel(const char* pretty) {
-  if (g_nnotes < 8) g_notes[g_nnotes] = pretty;
+void ksmi_note_kernel(const void* fn) {
+  if (g_nnotes < 8) g_notes[g_nnotes] = fn;
   ++g_nnotes;
+}
+
+// pointer -> "name<template args>" as rocprofv3 prints it after profiles/summarize.py's clean-up: demangled, without the return type,
+// the "(anonymous namespace)::" qualifier and the parameter list; the 16-bit storage type spelled bf16
+static const std::string& kernel_name(const void* fn) {
+  static std::mutex mu;
+  static std::map<const void*, std::string> cache;
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = cache.find(fn);
+  if (it != cache.end()) return it->second;
+  std::string out = "?";
+  const char* mangled = hipKernelNameRefByPtr(fn, nullptr);
+  if (mangled) {
+    int status = 0;
+    char* dm = abi::__cxa_demangle(mangled, nullptr, nullptr, &status);
+    std::string s = (status == 0 && dm) ? dm : mangled;
+    free(dm);
+    if (!s.compare(0, 5, "void ")) s.erase(0, 5);
+    for (size_t p; (p = s.find("(anonymous namespace)::")) != std::string::npos;) s.erase(p, 23);
+    for (size_t p; (p = s.find("unsigned short")) != std::string::npos;) s.replace(p, 14, "bf16");
+    // drop the parameter list: the '(' that follows the closing '>' of the template arguments (or the first '(' of a non-template)
+    int depth = 0;
+    size_t cut = std::string::npos;
+    for (size_t i = 0; i < s.size(); ++i) {
+      if (s[i] == '<') ++depth;
+      else if (s[i] == '>') --depth;
+      else if (s[i] == '(' && depth == 0) { cut = i; break; }
+    }
+    if (cut != std::string::npos) s.erase(cut);
+    out = s;
+  }
+  return cache.emplace(fn, out).first->second;
 }
 
 extern "C" {
 int ksmi_last_kernels(char* buf, int cap) {
-  int n = g_nnotes < 8 ? g_nnotes : 8, pos = 0;
+  const int n = g_nnotes < 8 ? g_nnotes : 8;
+  int pos = 0;
   if (buf && cap > 0) buf[0] = 0;
   for (int i = 0; i < n && buf; ++i) {
-    // "... [K = &(anonymous namespace)::name<args>]" -> "name<args>", written the way profiles/summarize.py cleans rocprofv3's names
-    const char* p = strstr(g_notes[i], "K = &");
-    p = p ? p + 5 : g_notes[i];
-    const char* e = strrchr(p, ']');
-    int len = e ? (int)(e - p) : (int)strlen(p);
+    const std::string& nm = kernel_name(g_notes[i]);
     if (i && pos < cap - 1) buf[pos++] = ';';
-    for (int j = 0; j < len && pos < cap - 1;) {
-      if (!strncmp(p + j, "(anonymous namespace)::", 23)) { j += 23; continue; }
-      if (!strncmp(p + j, "unsigned short", 14)) { if (pos + 4 < cap) { memcpy(buf + pos, "bf16", 4); pos += 4; } j += 14; continue; }
-      buf[pos++] = p[j++];
-    }
+    for (size_t j = 0; j < nm.size() && pos < cap - 1; ++j) buf[pos++] = nm[j];
     buf[pos] = 0;
   }
   g_nnotes = 0;

@@ -525,7 +525,7 @@ void set_lds(K kfn, size_t lds) {
 template <int D, int NKT>
 int launch_fwd(const AttnP& p, hipStream_t st) {
   const size_t lds = 2 * (size_t)NKT * 16 * Geo<D>::RS;
-  auto kfn = attn_mfma_fwd_kernel<D, NKT>; KSMI_NOTE(attn_mfma_fwd_kernel<D, NKT>);
+  auto kfn = attn_mfma_fwd_kernel<D, NKT>; KSMI_NOTE(kfn);
   set_lds(kfn, lds);
   hipLaunchKernelGGL(kfn, dim3((p.Nq + 63) / 64, p.H, p.B), dim3(256), lds, st, p);
   return ksmi_check_launch("attn_mfma_fwd");
@@ -593,7 +593,7 @@ int ksmi_attn_mfma_vit(int backward, const void* qkv, void* out, float* lse, con
     static const bool one_wg = getenv("KSMI_ATTN_FWD_ONE_WG") != nullptr;
     if (!one_wg) return launch_fwd<64, 13>(p, (hipStream_t)stream);
     const size_t lds = 2 * (size_t)13 * 16 * Geo<64>::RS;
-    auto kfn = attn_mfma_fwd_kernel<64, 13, 8>; KSMI_NOTE(attn_mfma_fwd_kernel<64, 13, 8>);
+    auto kfn = attn_mfma_fwd_kernel<64, 13, 8>; KSMI_NOTE(kfn);
     set_lds(kfn, lds);
     hipLaunchKernelGGL(kfn, dim3(1, H, B), dim3(512), lds, (hipStream_t)stream, p);
     return ksmi_check_launch("attn_mfma_fwd");
@@ -604,7 +604,7 @@ int ksmi_attn_mfma_vit(int backward, const void* qkv, void* out, float* lse, con
   static const bool split = getenv("KSMI_ATTN_SPLIT") != nullptr;      // A/B: the two-kernel backward
   if (!split && lse) {
     constexpr size_t lds = 4 * (size_t)13 * 16 * Geo<64>::RS + 2 * 13 * 16 * sizeof(float);
-    auto kfn = attn_mfma_bwd_fused_kernel<64, 13>; KSMI_NOTE(attn_mfma_bwd_fused_kernel<64, 13>);
+    auto kfn = attn_mfma_bwd_fused_kernel<64, 13>; KSMI_NOTE(kfn);
     set_lds(kfn, lds);
     hipLaunchKernelGGL(kfn, dim3(H, B), dim3(512), lds, (hipStream_t)stream, p);
     return ksmi_check_launch("attn_mfma_bwd_fused");

@@ -114,8 +114,8 @@ __device__ __forceinline__ uint32_t ksmi_rng_u32(uint32_t key, uint32_t idx) { r
 // element kept with probability 1 - thr / 2^32
 __device__ __forceinline__ bool ksmi_rng_keep(uint32_t key, uint32_t idx, uint32_t thr) { return ksmi_rng_u32(key, idx) >= thr; }
 
-// ---- host: the launchers tell which kernel instantiation they start.  ksmi_last_kernels() (api.hip) hands the names to the caller
-// so that a timed launch can be tied to the row of a rocprofv3 table it appears in (bench.py `roofline`, profiles/summarize.py).
-void ksmi_note_kernel(const char* pretty_function);
-template <auto K> inline const char* ksmi_kernel_pretty() { return __PRETTY_FUNCTION__; }
-#define KSMI_NOTE(...) ksmi_note_kernel(ksmi_kernel_pretty<(__VA_ARGS__)>())
+// ---- host: the launchers tell which kernel instantiation they start (the host-side function pointer).  ksmi_last_kernels() (api.hip)
+// resolves the pointers to names (hipKernelNameRefByPtr + demangling) so that a timed launch can be tied to the row of a rocprofv3
+// table it appears in (bench.py `roofline`, profiles/summarize.py).
+void ksmi_note_kernel(const void* host_function);
+#define KSMI_NOTE(...) ksmi_note_kernel((const void*)(__VA_ARGS__))

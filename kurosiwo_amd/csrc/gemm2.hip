@@ -241,7 +241,7 @@ template <int MT, bool TRW, int NS>
 int launch2n(const Gemm2P& p, hipStream_t st) {
   constexpr int lds = NS * (32 * MT * 128 + 128 * 128);
   static_assert(lds <= 160 * 1024, "LDS ring");
-  auto kfn = gemm2_kernel<MT, TRW, NS>; KSMI_NOTE(gemm2_kernel<MT, TRW, NS>);
+  auto kfn = gemm2_kernel<MT, TRW, NS>; KSMI_NOTE(kfn);
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
   hipLaunchKernelGGL(kfn, dim3(p.mtiles * p.ntiles), dim3(256), lds, st, p);
@@ -487,7 +487,7 @@ template <int MT, int NS>
 static void launch_tn(dim3 grid, const Gemm2T& p, hipStream_t st) {
   constexpr int lds = NS * (64 * 256 + 64 * 64 * MT);
   static_assert(lds <= 160 * 1024, "LDS ring");
-  auto kfn = gemm2_tn_kernel<MT, NS>; KSMI_NOTE(gemm2_tn_kernel<MT, NS>);
+  auto kfn = gemm2_tn_kernel<MT, NS>; KSMI_NOTE(kfn);
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
   hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, p);

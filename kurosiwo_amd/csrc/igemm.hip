@@ -615,7 +615,7 @@ int launch_fwd(const ksmi_conv_desc* d, hipStream_t st) {
   if (lds < 256 * 2 * sizeof(float)) lds = 256 * 2 * sizeof(float);
 #define KSMI_LAUNCH_FWD(NT_, KH_, KW_)                                                              \
   do {                                                                                              \
-    auto kfn = igemm_fwd_kernel<T, NT_, KH_, KW_>; KSMI_NOTE(igemm_fwd_kernel<T, NT_, KH_, KW_>);                                                  \
+    auto kfn = igemm_fwd_kernel<T, NT_, KH_, KW_>; KSMI_NOTE(kfn);                                                  \
     if (lds > 65536) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, *d);                                          \
   } while (0)
@@ -896,11 +896,11 @@ int launch_wgrad(const ksmi_wgrad_desc* d, hipStream_t st) {
 #define KSMI_LAUNCH_WG(NT_, KH_, KW_)                                                               \
   do {                                                                                              \
     if (lin) {                                                                                      \
-      auto kfn = igemm_wgrad_kernel<T, NT_, KH_, KW_, true>; KSMI_NOTE(igemm_wgrad_kernel<T, NT_, KH_, KW_, true>);                                        \
+      auto kfn = igemm_wgrad_kernel<T, NT_, KH_, KW_, true>; KSMI_NOTE(kfn);                                        \
       if (g.lds > 65536) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds); \
       hipLaunchKernelGGL(kfn, grid, dim3(256), g.lds, st, *d, g.patches, g.pps, wdbg);              \
     } else {                                                                                        \
-      auto kfn = igemm_wgrad_kernel<T, NT_, KH_, KW_, false>; KSMI_NOTE(igemm_wgrad_kernel<T, NT_, KH_, KW_, false>);                                       \
+      auto kfn = igemm_wgrad_kernel<T, NT_, KH_, KW_, false>; KSMI_NOTE(kfn);                                       \
       if (g.lds > 65536) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds); \
       hipLaunchKernelGGL(kfn, grid, dim3(256), g.lds, st, *d, g.patches, g.pps, wdbg);              \
     }                                                                                               \

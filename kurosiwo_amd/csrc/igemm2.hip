@@ -441,19 +441,19 @@ int launch2(const ksmi_conv_desc* d, int dbg, hipStream_t st) {
   ka.stages = stages;
 #define KSMI_L2W(NT_, KH_, KW_, AFF_, EX_, WN_)                                                     \
   do {                                                                                              \
-    auto kfn = igemm2_fwd_kernel<T, NT_, KH_, KW_, AFF_, EX_, WN_>; KSMI_NOTE(igemm2_fwd_kernel<T, NT_, KH_, KW_, AFF_, EX_, WN_>);                                 \
+    auto kfn = igemm2_fwd_kernel<T, NT_, KH_, KW_, AFF_, EX_, WN_>; KSMI_NOTE(kfn);                                 \
     if (lds > 65536) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     hipLaunchKernelGGL(kfn, grid, dim3(256 * WN_), lds, st, ka);                                    \
   } while (0)
 #define KSMI_L2MP(NT_, KH_, KW_, EX_)                                                               \
   do {                                                                                              \
-    auto kfn = igemm2_fwd_kernel<T, NT_, KH_, KW_, false, EX_, 2, false, 2>; KSMI_NOTE(igemm2_fwd_kernel<T, NT_, KH_, KW_, false, EX_, 2, false, 2>);                        \
+    auto kfn = igemm2_fwd_kernel<T, NT_, KH_, KW_, false, EX_, 2, false, 2>; KSMI_NOTE(kfn);                        \
     if (lds > 65536) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     hipLaunchKernelGGL(kfn, grid, dim3(512), lds, st, ka);                                          \
   } while (0)
 #define KSMI_L2LEAN(NT_, KH_, KW_, AFF_, EX_)                                                       \
   do {                                                                                              \
-    auto kfn = igemm2_fwd_kernel<T, NT_, KH_, KW_, AFF_, EX_, 1, true>; KSMI_NOTE(igemm2_fwd_kernel<T, NT_, KH_, KW_, AFF_, EX_, 1, true>);                             \
+    auto kfn = igemm2_fwd_kernel<T, NT_, KH_, KW_, AFF_, EX_, 1, true>; KSMI_NOTE(kfn);                             \
     hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, ka);                                          \
   } while (0)
 #define KSMI_L2X(NT_, KH_, KW_, AFF_, EX_)                                                          \

@@ -455,14 +455,14 @@ int ksmi_igemm3_launch(const ksmi_conv_desc* d, const ksmi_igemm3_geom_t* g, hip
   const int taps = d->KH * d->KW;
 #define KSMI_G3M(KH_, KW_, NCH_, WN_, AFF_, NTI_, MASK_)                                             \
   do {                                                                                               \
-    auto kfn = igemm3_kernel<KH_, KW_, NCH_, WN_, AFF_, NTI_, MASK_>; KSMI_NOTE(igemm3_kernel<KH_, KW_, NCH_, WN_, AFF_, NTI_, MASK_>);                                \
+    auto kfn = igemm3_kernel<KH_, KW_, NCH_, WN_, AFF_, NTI_, MASK_>; KSMI_NOTE(kfn);                                \
     if (g->lds > 65536) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g->lds); \
     hipLaunchKernelGGL(kfn, grid, dim3(256 * WN_), g->lds, st, ka);                                  \
     return ksmi_check_launch("igemm3");                                                              \
   } while (0)
 #define KSMI_G3(KH_, KW_, NCH_, WN_, AFF_, NTI_)                                                     \
   do {                                                                                               \
-    auto kfn = igemm3_kernel<KH_, KW_, NCH_, WN_, AFF_, NTI_, false>; KSMI_NOTE(igemm3_kernel<KH_, KW_, NCH_, WN_, AFF_, NTI_, false>);                                \
+    auto kfn = igemm3_kernel<KH_, KW_, NCH_, WN_, AFF_, NTI_, false>; KSMI_NOTE(kfn);                                \
     if (g->lds > 65536) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g->lds); \
     hipLaunchKernelGGL(kfn, grid, dim3(256 * WN_), g->lds, st, ka);                                  \
     return ksmi_check_launch("igemm3");                                                              \
@@ -476,7 +476,7 @@ int ksmi_igemm3_launch(const ksmi_conv_desc* d, const ksmi_igemm3_geom_t* g, hip
   }
 #define KSMI_G3D(NCH_, WN_)                                                                          \
   do {                                                                                               \
-    auto kfn = igemm3_kernel<3, 3, NCH_, WN_, false, 1, false, 1>; KSMI_NOTE(igemm3_kernel<3, 3, NCH_, WN_, false, 1, false, 1>);                                   \
+    auto kfn = igemm3_kernel<3, 3, NCH_, WN_, false, 1, false, 1>; KSMI_NOTE(kfn);                                   \
     if (g->lds > 65536) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g->lds); \
     hipLaunchKernelGGL(kfn, grid, dim3(256 * WN_), g->lds, st, ka);                                  \
     return ksmi_check_launch("igemm3");                                                              \

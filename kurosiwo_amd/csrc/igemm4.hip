@@ -780,7 +780,7 @@ int ksmi_igemm4_launch(const ksmi_conv_desc* d, const ksmi_igemm4_geom_t* g, hip
   const bool aff = d->src[0].scale != nullptr, mask = d->mask_src != nullptr, gate = d->gate_src != nullptr;
 #define KSMI_G4(WM_, NF_, AFF_, MASK_)                                                               \
   do {                                                                                               \
-    auto kfn = igemm4_kernel<WM_, NF_, AFF_, MASK_>; KSMI_NOTE(igemm4_kernel<WM_, NF_, AFF_, MASK_>);                                                 \
+    auto kfn = igemm4_kernel<WM_, NF_, AFF_, MASK_>; KSMI_NOTE(kfn);                                                 \
     static bool attr_set = false;        /* (one driver call per instantiation, not per launch) */  \
     if (!attr_set) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; } \
     hipLaunchKernelGGL(kfn, grid, dim3(512), g->lds, st, ka);                                        \
@@ -788,7 +788,7 @@ int ksmi_igemm4_launch(const ksmi_conv_desc* d, const ksmi_igemm4_geom_t* g, hip
   } while (0)
 #define KSMI_G4D(WM_, NF_)                                                                           \
   do {                                                                                               \
-    auto kfn = igemm4_kernel<WM_, NF_, false, 0, false, 1>; KSMI_NOTE(igemm4_kernel<WM_, NF_, false, 0, false, 1>);                                          \
+    auto kfn = igemm4_kernel<WM_, NF_, false, 0, false, 1>; KSMI_NOTE(kfn);                                          \
     static bool attr_set = false;                                                                    \
     if (!attr_set) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; } \
     hipLaunchKernelGGL(kfn, grid, dim3(512), g->lds, st, ka);                                        \
@@ -796,7 +796,7 @@ int ksmi_igemm4_launch(const ksmi_conv_desc* d, const ksmi_igemm4_geom_t* g, hip
   } while (0)
 #define KSMI_G4R(WM_, NF_, AFF_, EPI_)                                                               \
   do {                                                                                               \
-    auto kfn = igemm4_kernel<WM_, NF_, AFF_, EPI_, false, 0, true>; KSMI_NOTE(igemm4_kernel<WM_, NF_, AFF_, EPI_, false, 0, true>);                                  \
+    auto kfn = igemm4_kernel<WM_, NF_, AFF_, EPI_, false, 0, true>; KSMI_NOTE(kfn);                                  \
     static bool attr_set = false;                                                                    \
     if (!attr_set) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; } \
     hipLaunchKernelGGL(kfn, grid, dim3(512), g->lds, st, ka);                                        \
@@ -808,11 +808,11 @@ int ksmi_igemm4_launch(const ksmi_conv_desc* d, const ksmi_igemm4_geom_t* g, hip
        else if (d->dir == 1) KSMI_G4D(WM_, NF_); else KSMI_G4(WM_, NF_, false, 0); } while (0)
   if (ka.dbg && !aff && !mask && !gate && g->NF == 4) {                       // profiling switches: separate instantiations of the plain kernels
     if (g->WM == 4) {
-      auto kfn = igemm4_kernel<4, 4, false, 0, true>; KSMI_NOTE(igemm4_kernel<4, 4, false, 0, true>);
+      auto kfn = igemm4_kernel<4, 4, false, 0, true>; KSMI_NOTE(kfn);
       (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       hipLaunchKernelGGL(kfn, grid, dim3(512), g->lds, st, ka);
     } else {
-      auto kfn = igemm4_kernel<8, 4, false, 0, true>; KSMI_NOTE(igemm4_kernel<8, 4, false, 0, true>);
+      auto kfn = igemm4_kernel<8, 4, false, 0, true>; KSMI_NOTE(kfn);
       (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       hipLaunchKernelGGL(kfn, grid, dim3(512), g->lds, st, ka);
     }

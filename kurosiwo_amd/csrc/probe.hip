@@ -50,34 +50,46 @@ __global__ __launch_bounds__(256) void probe_read_vec(const u32x4* __restrict__ 
   if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345678u) sink[1] = 1;
 }
 
+template <bool NT, typename V> __device__ __forceinline__ void st16(V* p, const V& v) {
+  if (NT) __builtin_nontemporal_store(v, p); else *p = v;
+}
+
+template <bool NT>
 __global__ __launch_bounds__(256) void probe_copy(const u32x4* __restrict__ a, u32x4* __restrict__ b, size_t nvec) {
   const size_t stride = (size_t)gridDim.x * 256;
   size_t v = (size_t)blockIdx.x * 256 + threadIdx.x;
   for (; v + 3 * stride < nvec; v += 4 * stride) {
     u32x4 r[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) r[k] = a[v + k * stride];
+    for (int k = 0; k < 4; ++k) r[k] = NT ? __builtin_nontemporal_load(a + v + k * stride) : a[v + k * stride];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) b[v + k * stride] = r[k];
+    for (int k = 0; k < 4; ++k) st16<NT>(b + v + k * stride, r[k]);
   }
   for (; v < nvec; v += stride) b[v] = a[v];
 }
 
+template <bool NT>
 __global__ __launch_bounds__(256) void probe_triad(const f32x4* __restrict__ a, const f32x4* __restrict__ b, f32x4* __restrict__ c, float s, size_t nvec) {
   const size_t stride = (size_t)gridDim.x * 256;
   size_t v = (size_t)blockIdx.x * 256 + threadIdx.x;
   for (; v + stride < nvec; v += 2 * stride) {
     const f32x4 a0 = a[v], b0 = b[v], a1 = a[v + stride], b1 = b[v + stride];
-    c[v] = a0 + s * b0;
-    c[v + stride] = a1 + s * b1;
+    st16<NT>(c + v, a0 + s * b0);
+    st16<NT>(c + v + stride, a1 + s * b1);
   }
   for (; v < nvec; v += stride) c[v] = a[v] + s * b[v];
 }
 
+template <bool NT>
 __global__ __launch_bounds__(256) void probe_fill(f32x4* __restrict__ a, float s, size_t nvec) {
   const f32x4 val = {s, s, s, s};
   const size_t stride = (size_t)gridDim.x * 256;
-  for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < nvec; v += stride) a[v] = val;
+  size_t v = (size_t)blockIdx.x * 256 + threadIdx.x;
+  for (; v + 3 * stride < nvec; v += 4 * stride) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) st16<NT>(a + v + k * stride, val);
+  }
+  for (; v < nvec; v += stride) a[v] = val;
 }
 
 }  // namespace
@@ -86,6 +98,11 @@ extern "C" int ksmi_hbm_probe(int mode, const void* a, void* b, void* c, size_t 
   if (!a || nbytes < ((size_t)1 << 20) || (nbytes & 15) || !sink) return ksmi_fail(KSMI_E_ARG, "hbm_probe: >= 1 MiB, multiple of 16 bytes, a sink word pair");
   hipStream_t st = (hipStream_t)stream;
   const size_t nvec = nbytes / 16;
+  // mode = kind | nt << 3 | grid index << 4: non-temporal loads / stores, 8192 / 4096 / 2048 / 1024 workgroups of the streaming kernels
+  const bool nt = (mode >> 3) & 1;
+  static const int grids[4] = {8192, 4096, 2048, 1024};
+  const int G = grids[(mode >> 4) & 3];
+  mode &= 7;
   switch (mode) {
     case 0: {
       const int grid = 512;                                                  // two workgroups per CU: 16 waves x 8 KB in flight each
@@ -94,17 +111,22 @@ extern "C" int ksmi_hbm_probe(int mode, const void* a, void* b, void* c, size_t 
       hipLaunchKernelGGL(probe_read_dma, dim3(grid), dim3(kT), 8192 * (kT / 64), st, (const unsigned char*)a, nbytes, sink);
       break;
     }
-    case 1: hipLaunchKernelGGL(probe_read_vec, dim3(4096), dim3(256), 0, st, (const u32x4*)a, nvec, sink); break;
+    case 1: hipLaunchKernelGGL(probe_read_vec, dim3(G), dim3(256), 0, st, (const u32x4*)a, nvec, sink); break;
     case 2:
       if (!b) return ksmi_fail(KSMI_E_ARG, "hbm_probe: copy needs b");
-      hipLaunchKernelGGL(probe_copy, dim3(8192), dim3(256), 0, st, (const u32x4*)a, (u32x4*)b, nvec);
+      if (nt) hipLaunchKernelGGL(probe_copy<true>, dim3(G), dim3(256), 0, st, (const u32x4*)a, (u32x4*)b, nvec);
+      else hipLaunchKernelGGL(probe_copy<false>, dim3(G), dim3(256), 0, st, (const u32x4*)a, (u32x4*)b, nvec);
       break;
     case 3:
       if (!b || !c) return ksmi_fail(KSMI_E_ARG, "hbm_probe: triad needs b and c");
-      hipLaunchKernelGGL(probe_triad, dim3(8192), dim3(256), 0, st, (const f32x4*)a, (const f32x4*)b, (f32x4*)c, 0.5f, nvec);
+      if (nt) hipLaunchKernelGGL(probe_triad<true>, dim3(G), dim3(256), 0, st, (const f32x4*)a, (const f32x4*)b, (f32x4*)c, 0.5f, nvec);
+      else hipLaunchKernelGGL(probe_triad<false>, dim3(G), dim3(256), 0, st, (const f32x4*)a, (const f32x4*)b, (f32x4*)c, 0.5f, nvec);
       break;
-    case 4: hipLaunchKernelGGL(probe_fill, dim3(8192), dim3(256), 0, st, (f32x4*)(void*)a, 1.0f, nvec); break;
-    default: return ksmi_fail(KSMI_E_ARG, "hbm_probe: mode 0..4");
+    case 4:
+      if (nt) hipLaunchKernelGGL(probe_fill<true>, dim3(G), dim3(256), 0, st, (f32x4*)(void*)a, 1.0f, nvec);
+      else hipLaunchKernelGGL(probe_fill<false>, dim3(G), dim3(256), 0, st, (f32x4*)(void*)a, 1.0f, nvec);
+      break;
+    default: return ksmi_fail(KSMI_E_ARG, "hbm_probe: kind 0..4");
   }
   return ksmi_check_launch("hbm_probe");
 }

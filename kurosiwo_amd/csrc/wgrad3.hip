@@ -439,11 +439,11 @@ int ksmi_wgrad3_launch(const ksmi_wgrad_desc* d, const ksmi_wgrad3_geom_t* g, hi
 #define KSMI_W3(WC_, WN_, NF_)                                                                       \
   do {                                                                                               \
     if (aff) {                                                                                       \
-      auto kfn = wgrad3_kernel<WC_, WN_, NF_, true>; KSMI_NOTE(wgrad3_kernel<WC_, WN_, NF_, true>);                                                 \
+      auto kfn = wgrad3_kernel<WC_, WN_, NF_, true>; KSMI_NOTE(kfn);                                                 \
       if (g->lds > 65536) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g->lds); \
       hipLaunchKernelGGL(kfn, grid, dim3(256), g->lds, st, ka);                                      \
     } else {                                                                                         \
-      auto kfn = wgrad3_kernel<WC_, WN_, NF_, false>; KSMI_NOTE(wgrad3_kernel<WC_, WN_, NF_, false>);                                                \
+      auto kfn = wgrad3_kernel<WC_, WN_, NF_, false>; KSMI_NOTE(kfn);                                                \
       if (g->lds > 65536) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g->lds); \
       hipLaunchKernelGGL(kfn, grid, dim3(256), g->lds, st, ka);                                      \
     }                                                                                                \

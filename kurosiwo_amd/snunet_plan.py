@@ -714,12 +714,15 @@ class SNUNetPlan:
         self.head = dict(avg=avg, mx=mx, argmax=argmax, ca=ca, ca1=ca1)
         P = lambda key: m._p(key).data_ptr()
         G = lambda key: m._g(key).data_ptr()
-        self.fwd.add("ksmi_ecam_pool", lambda: (xarr, avg.data_ptr(), mx.data_ptr(), argmax.data_ptr(), ws_pool.data_ptr(), B, HW, n, dt))
+        T0 = B * HW * n * self._es()             # one [B,H,W,n] map
+        self.fwd.add("ksmi_ecam_pool", lambda: (xarr, avg.data_ptr(), mx.data_ptr(), argmax.data_ptr(), ws_pool.data_ptr(), B, HW, n, dt),
+                     {"kind": "ecam_pool", "bytes": 4 * T0, "flops": 0})
         self.fwd.add("ksmi_ecam_mlp", lambda: (avg.data_ptr(), mx.data_ptr(), P("ca.fc1.weight"), P("ca.fc2.weight"),
                                                P("ca1.fc1.weight"), P("ca1.fc2.weight"), ca.data_ptr(), ca1.data_ptr(),
                                                hidden.data_ptr(), B, n))
         self.fwd.add("ksmi_ecam_final_forward", lambda: (xarr, ca.data_ptr(), ca1.data_ptr(), P("conv_final.weight"),
-                                                         P("conv_final.bias"), self.logits.data_ptr(), B, HW, n, 3, dt))
+                                                         P("conv_final.bias"), self.logits.data_ptr(), B, HW, n, 3, dt),
+                     {"kind": "ecam_final_forward", "bytes": 4 * T0 + B * HW * 3 * 4, "flops": 2 * B * HW * 4 * n * 3})
 
         def build_bwd():
             self.fwd.cur_stage = self.bwd.cur_stage = "head"
@@ -736,7 +739,8 @@ class SNUNetPlan:
             dl = self.dlogits.data_ptr()
             self.bwd.add("ksmi_ecam_final_backward_reduce", lambda: (
                 xarr, dl, ca.data_ptr(), ca1.data_ptr(), P("conv_final.weight"), dca.data_ptr(), dca1.data_ptr(),
-                G("conv_final.weight"), G("conv_final.bias"), ws_b.data_ptr(), B, HW, n, 3, dt))
+                G("conv_final.weight"), G("conv_final.bias"), ws_b.data_ptr(), B, HW, n, 3, dt),
+                {"kind": "ecam_final_backward_reduce", "bytes": 4 * T0 + B * HW * 3 * 4, "flops": 2 * B * HW * 4 * n * 3})
             self._mark("conv_final.weight", "conv_final.bias")
             self.bwd.add("ksmi_ecam_mlp_backward", lambda: (
                 avg.data_ptr(), mx.data_ptr(), hidden.data_ptr(), ca.data_ptr(), ca1.data_ptr(), dca.data_ptr(), dca1.data_ptr(),
@@ -744,7 +748,8 @@ class SNUNetPlan:
                 G("ca.fc1.weight"), G("ca.fc2.weight"), G("ca1.fc1.weight"), G("ca1.fc2.weight"), ws_m.data_ptr(), B, n))
             self._mark("ca.fc1.weight", "ca.fc2.weight", "ca1.fc1.weight", "ca1.fc2.weight")
             self.bwd.add("ksmi_ecam_final_backward_dx", lambda: (
-                garr, dl, ca.data_ptr(), P("conv_final.weight"), davg.data_ptr(), dmax.data_ptr(), argmax.data_ptr(), B, HW, n, 3, dt))
+                garr, dl, ca.data_ptr(), P("conv_final.weight"), davg.data_ptr(), dmax.data_ptr(), argmax.data_ptr(), B, HW, n, 3, dt),
+                {"kind": "ecam_final_backward_dx", "bytes": 4 * T0 + B * HW * 3 * 4, "flops": 2 * B * HW * 4 * n * 3})
         self.bwd_builders.append((self.fwd.cur_lane, build_bwd))
 
     # ---------------------------------------------------------------- execution
