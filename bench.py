@@ -99,7 +99,7 @@ TRAFFIC_KERNELS = {
     "gemm_nn": (r"gemm2_kernel<\d+, true>", r"gemm_nn_kernel"),
 }
 TRAFFIC_FILE = {"snunet": "snunet", "changeformer": "changeformer", "floodvit": "floodvit", "unet": "unet", "mae": "mae"}
-TRAFFIC_ROUND = "r03"
+TRAFFIC_ROUND = "r04"
 
 
 def measured_traffic(kind, model="snunet"):
@@ -139,6 +139,8 @@ def measure_hbm_peaks(dev, gib=1):
     for name, kind, moved in (("read_dma", 0, n), ("read_vec", 1, n), ("copy", 2, 2 * n), ("triad", 3, 3 * n), ("fill", 4, n)):
         best, how = None, None
         variants = [kind] if kind == 0 else [kind | nt << 3 | g << 4 for nt in ((0, 1) if kind > 1 else (0,)) for g in range(4)]
+        if kind > 1:
+            variants += [kind | 64 | g << 4 for g in range(4)]
         for mode in variants:                      # (non-temporal or not, 8192 ... 1024 workgroups: the best variant is the part's rate)
             for it in range(3):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -151,7 +153,19 @@ def measure_hbm_peaks(dev, gib=1):
                     best, how = ms, mode
         out[f"{name}_GBs"] = round(moved / best / 1e6, 1)
         if kind:
-            out[f"{name}_variant"] = f"{'nt ' if (how >> 3) & 1 else ''}{8192 >> ((how >> 4) & 3)} workgroups"
+            out[f"{name}_variant"] = (f"contiguous chunks, {(8192 >> ((how >> 4) & 3)) * 16} workgroups" if how & 64 else
+                                      f"{'nt ' if (how >> 3) & 1 else ''}{8192 >> ((how >> 4) & 3)} workgroups, grid-stride")
+    # the same three operations by torch's own elementwise kernels (a second opinion on the part, not a kernel of this library)
+    for name, fn, moved in (("copy", lambda: b.copy_(a), 2 * n), ("fill", lambda: c.fill_(3), n),
+                            ("triad", lambda: torch.add(a.view(torch.float32), b.view(torch.float32), alpha=0.5, out=c.view(torch.float32)), 3 * n)):
+        best = None
+        for it in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); fn(); e1.record(); e1.synchronize()
+            ms = e0.elapsed_time(e1)
+            if it and (best is None or ms < best):
+                best = ms
+        out[f"{name}_torch_GBs"] = round(moved / best / 1e6, 1)
     out["how"] = f"ksmi_hbm_probe over {gib} GiB operands, HIP events, best of 2 per variant (csrc/probe.hip)"
     del a, b, c
     torch.cuda.empty_cache()
@@ -518,8 +532,8 @@ def main():
         step_flops = sum(c[3]["flops"] for c in step.plan.fwd.calls + step.plan.bwd.calls)
         step_bytes = sum(c[3]["bytes"] for c in step.plan.fwd.calls + step.plan.bwd.calls)
         ms_step = dt / args.steps * 1e3
-        peaks = measure_hbm_peaks(dev) if world == 1 else None
-        hbm_meas = max(peaks["copy_GBs"], peaks["triad_GBs"]) if peaks else HBM_MEASURED_GBS
+        peaks = measure_hbm_peaks(dev) if world == 1 and not args.no_solo else None      # (--no-solo: the rocprofv3 passes trace the step only)
+        hbm_meas = max(peaks["copy_GBs"], peaks["triad_GBs"], peaks["copy_torch_GBs"], peaks["triad_torch_GBs"]) if peaks else HBM_MEASURED_GBS
         res = {
             "metric": metric,
             "value": round(B * world * args.steps / dt, 2), "unit": "tiles/s",

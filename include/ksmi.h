@@ -132,7 +132,7 @@ int ksmi_last_kernels(char* buf, int cap);
 /* Device-memory rate probes (measurement aid: bench.py `roofline.measured_peaks`, SURVEY.md §8(d) "measure ... on the box and quote
  * both"): ONE asynchronous pass over `nbytes` of a (and b, c) on `stream`, timed by the caller with HIP events.  mode 0 read by LDS-DMA
  * (nbytes a multiple of 32 MiB), 1 read by 16-byte non-temporal loads, 2 copy a -> b, 3 fp32 triad c = a + s b, 4 fill a; | 8: non-temporal
- * loads / stores, | 16 * g: 8192 >> g workgroups (the caller keeps the best variant).  `sink`: two device words the read probes may write. */
+ * loads / stores, | 16 * g: 8192 >> g workgroups, | 64: one contiguous chunk per workgroup (the caller keeps the best variant).  `sink`: two device words the read probes may write. */
 int ksmi_hbm_probe(int mode, const void* a, void* b, void* c, size_t nbytes, unsigned* sink, void* stream);
 size_t ksmi_desc_size(int which);
 /* 1: ksmi_conv_forward(d, dtype) runs on a kernel that implements the gate epilogue (gate_src) for this descriptor */
@@ -364,6 +364,10 @@ int ksmi_argmax_confusion(const float* logits, const int64_t* labels, int64_t* p
  * ------------------------------------------------------------------------------- */
 int ksmi_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int64_t* step_count,
                    float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale, void* stream);
+/* torch.optim.AdamW (training/change_detection_trainer.py:55-60, the `adamw` branch: betas and weight_decay of the method json):
+ * decoupled weight decay p *= 1 - lr * weight_decay, then the Adam update; same state and step counter as ksmi_adam_step */
+int ksmi_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, int64_t* step_count,
+                    float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale, void* stream);
 int ksmi_sgd_step(float* p, const float* g, float* mom, int64_t n, int64_t* step_count,
                   float lr, float momentum, float weight_decay, float grad_scale, void* stream);
 

@@ -635,6 +635,8 @@ __global__ void sum_rows_flat_kernel(const float* partial, int rows, int64_t n, 
 __global__ void step_increment_kernel(int64_t* step) { if (threadIdx.x == 0 && blockIdx.x == 0) *step += 1; }
 
 // 16-byte accesses (the arenas are 32-byte aligned; a scalar tail covers n % 4): the 4-byte version moved 2.1 TB/s
+// DECOUPLED: torch.optim.AdamW (p *= 1 - lr * wd before the update); otherwise torch.optim.Adam (wd * p joins the gradient)
+template <bool DECOUPLED>
 __global__ void adam_kernel(float* p, const float* g, float* m, float* v, int64_t n, const int64_t* step,
                             float lr, float b1, float b2, float eps, float wd, float gscale) {
   const double t = (double)*step;
@@ -643,7 +645,8 @@ __global__ void adam_kernel(float* p, const float* g, float* m, float* v, int64_
   const float step_size = lr / bc1;
   auto upd = [&](float gi, float& pi, float& mi, float& vi) {
     gi *= gscale;
-    if (wd != 0.f) gi += wd * pi;
+    if (DECOUPLED) pi = pi * (1.f - lr * wd);
+    else if (wd != 0.f) gi += wd * pi;
     mi = mi + (gi - mi) * (1.f - b1);
     vi = vi * b2 + gi * gi * (1.f - b2);
     const float denom = sqrtf(vi) / bc2s + eps;
@@ -1036,9 +1039,18 @@ int ksmi_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int6
                    float beta2, float eps, float weight_decay, float grad_scale, void* stream) {
   if (!p || !g || !m || !v || !step_count || n < 0) return ksmi_fail(KSMI_E_ARG, "adam: bad args");
   hipLaunchKernelGGL(step_increment_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step_count);
-  hipLaunchKernelGGL(adam_kernel, dim3(grid_for((n + 3) / 4, 8192)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, step_count, lr, beta1,
+  hipLaunchKernelGGL(adam_kernel<false>, dim3(grid_for((n + 3) / 4, 8192)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, step_count, lr, beta1,
                      beta2, eps, weight_decay, grad_scale);
   return ksmi_check_launch("adam");
+}
+
+int ksmi_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, int64_t* step_count, float lr, float beta1,
+                    float beta2, float eps, float weight_decay, float grad_scale, void* stream) {
+  if (!p || !g || !m || !v || !step_count || n < 0) return ksmi_fail(KSMI_E_ARG, "adamw: bad args");
+  hipLaunchKernelGGL(step_increment_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step_count);
+  hipLaunchKernelGGL(adam_kernel<true>, dim3(grid_for((n + 3) / 4, 8192)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, step_count, lr, beta1,
+                     beta2, eps, weight_decay, grad_scale);
+  return ksmi_check_launch("adamw");
 }
 
 int ksmi_sgd_step(float* p, const float* g, float* mom, int64_t n, int64_t* step_count, float lr, float momentum,

@@ -92,6 +92,34 @@ __global__ __launch_bounds__(256) void probe_fill(f32x4* __restrict__ a, float s
   for (; v < nvec; v += stride) a[v] = val;
 }
 
+// contiguous form: workgroup b owns vectors [b * per, (b + 1) * per) and walks them front to back (what a flat elementwise launch does)
+template <int KIND>
+__global__ __launch_bounds__(256) void probe_chunked(const f32x4* __restrict__ a, const f32x4* __restrict__ b, f32x4* __restrict__ c, float s, size_t nvec) {
+  const size_t per = (nvec + gridDim.x - 1) / gridDim.x;
+  const size_t v0 = (size_t)blockIdx.x * per, v1 = v0 + per < nvec ? v0 + per : nvec;
+  const f32x4 val = {s, s, s, s};
+  size_t v = v0 + threadIdx.x;
+  for (; v + 3 * 256 < v1; v += 4 * 256) {
+    if (KIND == 4) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) c[v + k * 256] = val;
+    } else if (KIND == 2) {
+      f32x4 r[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) r[k] = a[v + k * 256];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) c[v + k * 256] = r[k];
+    } else {
+      f32x4 r[4], q[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { r[k] = a[v + k * 256]; q[k] = b[v + k * 256]; }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) c[v + k * 256] = r[k] + s * q[k];
+    }
+  }
+  for (; v < v1; v += 256) c[v] = KIND == 4 ? val : (KIND == 2 ? a[v] : a[v] + s * b[v]);
+}
+
 }  // namespace
 
 extern "C" int ksmi_hbm_probe(int mode, const void* a, void* b, void* c, size_t nbytes, unsigned* sink, void* stream) {
@@ -102,6 +130,14 @@ extern "C" int ksmi_hbm_probe(int mode, const void* a, void* b, void* c, size_t 
   const bool nt = (mode >> 3) & 1;
   static const int grids[4] = {8192, 4096, 2048, 1024};
   const int G = grids[(mode >> 4) & 3];
+  if (mode & 64) {                                    // contiguous chunk per workgroup; 16 x the workgroups of the strided form
+    const int kind = mode & 7, Gc = G * 16;
+    if (kind == 2 && b) hipLaunchKernelGGL(probe_chunked<2>, dim3(Gc), dim3(256), 0, st, (const f32x4*)a, (const f32x4*)nullptr, (f32x4*)b, 0.f, nvec);
+    else if (kind == 3 && b && c) hipLaunchKernelGGL(probe_chunked<3>, dim3(Gc), dim3(256), 0, st, (const f32x4*)a, (const f32x4*)b, (f32x4*)c, 0.5f, nvec);
+    else if (kind == 4) hipLaunchKernelGGL(probe_chunked<4>, dim3(Gc), dim3(256), 0, st, (const f32x4*)nullptr, (const f32x4*)nullptr, (f32x4*)(void*)a, 1.0f, nvec);
+    else return ksmi_fail(KSMI_E_ARG, "hbm_probe: the contiguous form has kinds 2, 3, 4");
+    return ksmi_check_launch("hbm_probe");
+  }
   mode &= 7;
   switch (mode) {
     case 0: {

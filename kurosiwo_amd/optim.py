@@ -81,6 +81,20 @@ class FusedAdam(_FlatOptimizer):
                                               g["weight_decay"], grad_scale, stream_ptr()), "adam_step")
 
 
+class FusedAdamW(FusedAdam):
+    """torch.optim.AdamW on the flat arena (training/change_detection_trainer.py:55-60: betas, weight_decay from the method json)"""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+
+    def step_arena(self, p_ptr, g_ptr, n, device, grad_scale=1.0):
+        g = self.param_groups[0]
+        st = self.flat_state(n, device)
+        _lib.check(_lib.load().ksmi_adamw_step(p_ptr, g_ptr, st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), n,
+                                               st["step"].data_ptr(), g["lr"], g["betas"][0], g["betas"][1], g["eps"],
+                                               g["weight_decay"], grad_scale, stream_ptr()), "adamw_step")
+
+
 class FusedSGD(_FlatOptimizer):
     _names = ("momentum_buffer",)
 

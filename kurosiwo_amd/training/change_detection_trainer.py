@@ -17,7 +17,7 @@ from .. import distributed as D
 from ..config import init_lr_scheduler
 from ..loss import create_loss
 from ..metrics import ConfusionMetrics, metrics_from_cm
-from ..optim import FusedAdam, FusedSGD
+from ..optim import FusedAdam, FusedAdamW, FusedSGD
 from ..synthetic import cd_inputs
 from ..trainer import CDTrainStep
 
@@ -41,8 +41,9 @@ def _make_optimizer(model, configs, model_configs):
     if model_configs["optimizer"] == "adam":
         # the reference ignores betas / weight_decay of the method json for Adam (cd_trainer:52-54)
         return FusedAdam(model.parameters(), lr=model_configs["learning_rate"])
-    if model_configs["optimizer"] == "adamw":
-        raise NotImplementedError("adamw is unused by the in-scope methods")
+    if model_configs["optimizer"] == "adamw":                # cd_trainer:55-60
+        return FusedAdamW(model.parameters(), lr=model_configs["learning_rate"], betas=tuple(model_configs["betas"]),
+                          weight_decay=model_configs["weight_decay"])
     raise NotImplementedError(model_configs["optimizer"])
 
 

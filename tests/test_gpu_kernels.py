@@ -223,16 +223,20 @@ def test_deconv2x2(dev, dtype, shape):
 
 
 def test_adam_and_sgd_match_reference_formulas(dev):
-    """ksmi_adam_step / ksmi_sgd_step on a flat arena vs torch.optim.Adam / SGD (CPU) over 4 steps."""
-    from kurosiwo_amd.optim import FusedAdam, FusedSGD
+    """ksmi_adam_step / ksmi_adamw_step / ksmi_sgd_step on a flat arena vs torch.optim.Adam / AdamW / SGD (CPU) over 4 steps
+    (the three optimiser branches of training/change_detection_trainer.py:45-66)."""
+    from kurosiwo_amd.optim import FusedAdam, FusedAdamW, FusedSGD
     n = 10007
     p0 = seeded_tensor("opt.p", (n,))
     grads = [seeded_tensor(f"opt.g{i}", (n,)) * (10.0 ** (-i)) for i in range(4)]
-    for kind in ("adam", "sgd"):
+    for kind in ("adam", "adamw", "sgd"):
         pr = p0.clone().requires_grad_(True)
-        ref = torch.optim.Adam([pr], lr=1e-3) if kind == "adam" else torch.optim.SGD([pr], lr=6e-4, momentum=0.99, weight_decay=1e-5)
+        ref = (torch.optim.Adam([pr], lr=1e-3) if kind == "adam" else
+               torch.optim.AdamW([pr], lr=1e-3, betas=(0.9, 0.99), weight_decay=0.05) if kind == "adamw" else
+               torch.optim.SGD([pr], lr=6e-4, momentum=0.99, weight_decay=1e-5))
         pd = torch.nn.Parameter(p0.clone().to(dev))
-        opt = FusedAdam([pd], lr=1e-3) if kind == "adam" else FusedSGD([pd], lr=6e-4, momentum=0.99, weight_decay=1e-5)
+        opt = (FusedAdam([pd], lr=1e-3) if kind == "adam" else FusedAdamW([pd], lr=1e-3, betas=(0.9, 0.99), weight_decay=0.05) if kind == "adamw" else
+               FusedSGD([pd], lr=6e-4, momentum=0.99, weight_decay=1e-5))
         for g in grads:
             pr.grad = g.clone()
             ref.step()
