@@ -14,6 +14,7 @@
 //   ksmi_bn_bwd_fin_apply_gated    = ksmi_reduce_rows + ksmi_bn_bwd_apply_gated
 //   ksmi_bnrelu_bwd_fin_apply      = ksmi_reduce_rows + ksmi_bnrelu_bwd_apply
 //   ksmi_bn_bwd_fin_apply_add      = ksmi_reduce_rows + ksmi_bn_bwd_apply_add
+#include <stdlib.h>
 #include "common.h"
 #include "../../include/ksmi.h"
 #include "errors.h"
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(kFat) void bn_bwd_fin_apply_add_kernel(BwdFinArgs f
   __shared__ float s_sum[2 * kMaxC], s_mean[kMaxC], s_rstd[kMaxC], s_gamma[kMaxC];
   bwd_finish(f, red, sums, s_sum, s_mean, s_rstd, s_gamma);
   const int C = f.C, CV = C / VEC;
-  const int npl = kFat / CV;                                     // pixel lanes (CV <= 64)
+  const int npl = kFat / CV;                                     // pixel lanes (CV <= 256)
   const int cv = threadIdx.x % CV, pl = threadIdx.x / CV;
   const bool active = pl < npl;
   float acc[VEC];
@@ -279,12 +280,13 @@ __global__ __launch_bounds__(kFat) void bn_bwd_fin_apply_add_kernel(BwdFinArgs f
 bool fused_ok(int C, int dtype, int Cstride) {
   if (dtype != KSMI_BF16 && dtype != KSMI_F32) return false;
   const int vec = dtype == KSMI_BF16 ? 8 : 4;
-  return C >= vec && C % vec == 0 && C % 4 == 0 && C <= kMaxC && Cstride >= C && Cstride % 4 == 0 && C / vec <= 64;
+  return C >= vec && C % vec == 0 && C % 4 == 0 && C <= kMaxC && Cstride >= C && Cstride % 4 == 0 && C / vec <= 256;
 }
 
 int fat_grid(int64_t work_items) {
+  static const int cap = getenv("KSMI_BN_FAT_GRID") ? atoi(getenv("KSMI_BN_FAT_GRID")) : 256;     // (A/B switch: workgroups of the fused passes)
   int64_t b = (work_items + kFat - 1) / kFat;
-  return (int)(b < 1 ? 1 : (b > 256 ? 256 : b));
+  return (int)(b < 1 ? 1 : (b > cap ? cap : b));
 }
 
 }  // namespace

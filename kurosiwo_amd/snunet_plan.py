@@ -171,6 +171,7 @@ class SNUNetPlan:
     side_wgrad = True          # weight gradients on the train step's side stream (see LaunchList.run; plan_base.PlanBase.side_wgrad)
     two_lanes = True           # the decoder launches carry lane tags and hand-over entries (StepStreams)
     bn_fused = os.environ.get("KSMI_BN_FUSED", "1") != "0"     # statistics finish inside the consuming pass (csrc/bnfused.hip)
+    im2col_late = os.environ.get("KSMI_IM2COL_LATE", "1") != "0"   # first-layer im2col in the backward list, next to its reader
 
     def __init__(self, model, B, H, W, dtype, training, with_backward, tail=0):
         self.m, self.B, self.H, self.W, self.dtype = model, B, H, W, dtype
@@ -531,9 +532,14 @@ class SNUNetPlan:
             self.fwd.add("ksmi_conv_first_forward_raw", lambda: (x_img.data_ptr(), x_tail, chead, P("conv1.weight"), P("conv1.bias"),
                                                                  i_act.t.data_ptr(), stats(), B, cin, H, W, Cc, *raw, dt))
             if self.with_backward:
+                # the im2col image of the raw tile for the first-layer weight gradient is laid out in the BACKWARD list, right in front
+                # of its only reader (the input buffers of the plan stay untouched until the next batch is set): the 103 MB it writes
+                # are still in the 256 MB memory-side cache when the weight gradient reads them, and the forward pass does not carry them
                 col = torch.empty((B, H, W, Kpad), dtype=dtype, device=self.dev)
                 self.keep.append(col)
-                self.fwd.add("ksmi_im2col3x3_raw", lambda: (x_img.data_ptr(), x_tail, chead, col.data_ptr(), B, cin, H, W, Kpad, *raw, dt))
+                im2col_args = lambda: (x_img.data_ptr(), x_tail, chead, col.data_ptr(), B, cin, H, W, Kpad, *raw, dt)
+                if not self.im2col_late:
+                    self.fwd.add("ksmi_im2col3x3_raw", im2col_args)
                 src1 = [SrcSpec(col, Kpad)]
         else:
             srcs = [SrcSpec(a.t, a.C) for a in sources]
@@ -676,6 +682,8 @@ class SNUNetPlan:
             a_w1 = self._acc_param(f"{name}.conv1.weight")
             if first:
                 # dW[n][c*9+t] = sum_px im2col[px][c*9+t] * di[px][n]  (1x1 weight-gradient GEMM over the saved im2col)
+                if self.im2col_late:
+                    self.bwd.add("ksmi_im2col3x3_raw", im2col_args, {"kind": "im2col3x3_raw", "bytes": B * H * W * (cin * 4 + Kpad * self._es()), "flops": 0})
                 dw1, ws1 = make_wgrad(src1, r, Cc, 0, Cc, m._g(f"{name}.conv1.weight"), 1, cin * 9, 0, a_w1,
                                       B, H, W, H, W, 1, 1, 1, 0, dtype)
                 for ci in range(dw1.nchunks):
