@@ -26,3 +26,4 @@ int ksmi_gemm2_nn(const void* dy, int dy_rs, const void* w, int w_rs, void* dx, 
 int ksmi_gemm2_tn(const void* x, int x_rs, const void* dy, int dy_rs, float* slab, int npad, float* grad, int64_t g_rs, int rows, int K, int N,
                   int Kslab, int nsplit, int rows_per_split, int btile, int accumulate, float* bias_grad, int bias_accumulate, hipStream_t st);
 bool ksmi_gemm2_tn_enabled(int K, int N, int rows_per_split);
+bool ksmi_gemm2_tn_spl(int tiles_times_splits, int steps_per_split);     // gemm2_tn_kernel runs two wave groups per workgroup (SPL = 2)

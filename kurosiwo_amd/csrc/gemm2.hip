@@ -316,21 +316,29 @@ struct Gemm2T {
 };
 __device__ __attribute__((aligned(64))) unsigned char gemm2_zero_page[64];
 
-template <int MT, int NS>
-__global__ __launch_bounds__(256, 1) void gemm2_tn_kernel(const Gemm2T p) {
+// SPL = 2 (round 4): the workgroup has two 4-wave groups, each with its own LDS ring, walking one HALF of the workgroup's reduction
+// range; group 1 hands its accumulators to group 0 through LDS at the end (fixed order: deterministic).  A workgroup that is alone on
+// its CU (<= 256 tiles) is a lock-step of DMA wait -> barrier -> fragment reads -> MFMA; the second group doubles the waves per SIMD
+// and halves the serial K loop without partial slabs in memory and without a reducer launch.
+template <int MT, int NS, int SPL>
+__global__ __launch_bounds__(256 * SPL, 1) void gemm2_tn_kernel(const Gemm2T p) {
   constexpr int TB = 32 * MT, KS = 64, AB = 64 * 256, BROW = TB * 2, BB = 64 * BROW, STAGE = AB + BB;
   constexpr int NQ = STAGE / 1024, NI = NQ / 4, BGM = BROW / 32 - 1, AU = 16, BU = BROW / 16;
   static_assert(NQ % 4 == 0, "whole DMA rounds");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
+  const int tid = threadIdx.x, lane = tid & 63, wave_all = tid >> 6, g = lane >> 4, l15 = lane & 15;
+  const int grp = SPL == 1 ? 0 : wave_all >> 2, wave = wave_all & 3;
   const int wn = wave >> 1, wm = wave & 1;
   const int tile = blockIdx.x, split = blockIdx.y;
   const int bt = tile / p.atiles, at = tile - bt * p.atiles;
   const int a0 = at * 128, b0 = bt * TB;
-  const int m_begin = split * p.rows_per_split;
-  const int m_end = min(p.rows, m_begin + p.rows_per_split);
-  const int nsteps = (max(m_end - m_begin, 0) + KS - 1) / KS;
-  const unsigned lds0 = (unsigned)(uintptr_t)smem;
+  const int wg_begin = split * p.rows_per_split;
+  const int wg_end = min(p.rows, wg_begin + p.rows_per_split);
+  const int steps_wg = (max(wg_end - wg_begin, 0) + KS - 1) / KS;
+  const int nsteps = (steps_wg + SPL - 1) / SPL;                  // the same count in every group (common barriers); rows past the group's end read zeros
+  const int m_begin = wg_begin + grp * nsteps * KS;
+  const int m_end = min(wg_end, m_begin + nsteps * KS);
+  const unsigned lds0 = (unsigned)(uintptr_t)smem + (unsigned)(grp * NS * STAGE);
 
   // DMA: instruction q = wave + 4 i; 16-byte unit index within the stage -> (image, reduction row, column granule)
   const unsigned char* src[NI];
@@ -434,6 +442,28 @@ __global__ __launch_bounds__(256, 1) void gemm2_tn_kernel(const Gemm2T p) {
     mma_all(acc, accb, faA, fbA);
     mma_all(acc2, accb2, faB, fbB);
   }
+  if constexpr (SPL == 2) {
+    // group 1 -> group 0: [(a * MT + b)][wave * 64 + lane] float4 (+ the bias rows behind them), in the ring memory
+    __syncthreads();
+    f32x4* xch = (f32x4*)smem;
+    const int slot = wave * 64 + lane;
+    if (grp == 1) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < MT; ++b) xch[(a * MT + b) * 256 + slot] = acc[a][b] + acc2[a][b];
+#pragma unroll
+      for (int b = 0; b < MT; ++b) xch[(4 * MT + b) * 256 + slot] = accb[b] + accb2[b];
+    }
+    __syncthreads();
+    if (grp == 1) return;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < MT; ++b) { acc[a][b] = (acc[a][b] + acc2[a][b]) + xch[(a * MT + b) * 256 + slot]; acc2[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int b = 0; b < MT; ++b) { accb[b] = (accb[b] + accb2[b]) + xch[(4 * MT + b) * 256 + slot]; accb2[b] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  }
   if (do_bias && g == 0) {                                // every accumulator row holds the column sum: take row 0 (g = 0, r = 0)
 #pragma unroll
     for (int b = 0; b < MT; ++b) {
@@ -483,14 +513,27 @@ int ksmi_gemm2_nn(const void* dy, int dy_rs, const void* w, int w_rs, void* dx, 
   return dispatch2<true>(p, st);
 }
 
-template <int MT, int NS>
+template <int MT, int NS, int SPL = 1>
 static void launch_tn(dim3 grid, const Gemm2T& p, hipStream_t st) {
-  constexpr int lds = NS * (64 * 256 + 64 * 64 * MT);
+  constexpr int lds = SPL * NS * (64 * 256 + 64 * 64 * MT);
   static_assert(lds <= 160 * 1024, "LDS ring");
-  auto kfn = gemm2_tn_kernel<MT, NS>; KSMI_NOTE(kfn);
+  static_assert(SPL == 1 || (4 * MT + MT) * 256 * 16 <= lds, "exchange area");
+  auto kfn = gemm2_tn_kernel<MT, NS, SPL>; KSMI_NOTE(kfn);
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
-  hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, p);
+  hipLaunchKernelGGL(kfn, grid, dim3(256 * SPL), lds, st, p);
+}
+
+// two wave groups per workgroup (gemm2_tn_kernel SPL = 2) pay when a workgroup would be alone on its CU and its K loop is long enough
+bool ksmi_gemm2_tn_spl(int tiles_times_splits, int steps_per_split) {
+  // KSMI_TN_SPL = 1: wherever it fits (instance tests), 2: by shape, unset / 0: off.  OFF by default: measured in the FloodViT step
+  // (profiles/r04_tn_spl.txt) the two-group kernels are 11-14 % shorter (38.9 -> 33.4 us, 61.8 -> 54.7 us) and the step is 3.6 % SLOWER
+  // (13.81 -> 14.31 ms): a 512-thread workgroup with 144 KB of LDS owns its CU, while the one-group instance (72 KB) shares it with a
+  // token GEMM of the main stream -- on the side stream co-residency is worth more than the shorter kernel (MAE: +0.9 %).
+  static const int f = getenv("KSMI_TN_SPL") ? atoi(getenv("KSMI_TN_SPL")) : 0;
+  if (f <= 0) return false;
+  if (f == 1) return steps_per_split >= 2;
+  return tiles_times_splits <= 256 && steps_per_split >= 12;
 }
 
 bool ksmi_gemm2_tn_enabled(int K, int N, int rows_per_split) {
@@ -518,6 +561,13 @@ int ksmi_gemm2_tn(const void* x, int x_rs, const void* dy, int dy_rs, float* sla
   p.atiles = (p.a_cols + 127) / 128; p.btiles = (p.b_cols + btile - 1) / btile;
   static const int ns = getenv("KSMI_TN_NS") ? atoi(getenv("KSMI_TN_NS")) : 3;      // probes: ring depth of the weight-gradient kernel
   const dim3 grid(p.atiles * p.btiles, nsplit);
+  if (ns <= 3 && ksmi_gemm2_tn_spl((int)(grid.x * grid.y), (rows_per_split + 63) / 64)) {
+    if (btile == 128) launch_tn<4, 2, 2>(grid, p, st);
+    else if (btile == 96) launch_tn<3, 2, 2>(grid, p, st);
+    else if (btile == 64) launch_tn<2, 3, 2>(grid, p, st);
+    else return ksmi_fail(KSMI_E_ARG, "gemm2_tn: B-side tile must be 64, 96 or 128");
+    return ksmi_check_launch("gemm2_tn");
+  }
   if (btile == 128) { if (ns >= 5) launch_tn<4, 5>(grid, p, st); else if (ns == 4) launch_tn<4, 4>(grid, p, st); else launch_tn<4, 3>(grid, p, st); }
   else if (btile == 96) { if (ns >= 5) launch_tn<3, 5>(grid, p, st); else if (ns == 4) launch_tn<3, 4>(grid, p, st); else launch_tn<3, 3>(grid, p, st); }
   else if (btile == 64) { if (ns >= 6) launch_tn<2, 6>(grid, p, st); else if (ns == 5) launch_tn<2, 5>(grid, p, st); else if (ns == 4) launch_tn<2, 4>(grid, p, st); else launch_tn<2, 3>(grid, p, st); }

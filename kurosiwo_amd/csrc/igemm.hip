@@ -782,7 +782,10 @@ static void gemm_tn_geom(const ksmi_wgrad_desc* d, int kc, int& nsplit, int& rps
       const int tiles = ((acols + 127) / 128) * ((bcols + b - 1) / b);
       const int steps = (steps_all + s - 1) / s;
       const int rounds = (tiles * s + 255) / 256;
-      double t = rounds * (steps * step_us + 3.0);
+      // a workgroup that would be alone on its CU runs as two wave groups on half the steps each (gemm2_tn_kernel SPL = 2): measured
+      // with two co-resident half-range workgroups, a step of the pair costs ~0.73 of two serial ones
+      const bool spl = ksmi_gemm2_tn_spl(tiles * s, steps);
+      double t = rounds * ((spl ? 0.73 : 1.0) * steps * step_us + (spl ? 4.0 : 3.0));
       if (s > 1) t += 2.0 * s * (double)K * npad * 4.0 / 4.0e6 + 3.0 + 0.08 * (s > 16 ? 16 + (s - 16) / 8 : s);   // + the reducer's serial slab walk
       if (t < best) { best = t; bs = s; bt = b; }
     }

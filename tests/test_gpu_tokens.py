@@ -254,12 +254,14 @@ def test_linear_wgrad_every_tile_and_split():
         "print('ERR', *errs)\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for bt in ("128", "96", "64"):
-        for split, ns in (("1", "3"), ("3", "3"), ("1", "4"), ("2", "5")):
-            env = dict(os.environ, PYTHONPATH=root, KSMI_TN_BT=bt, KSMI_TN_SPLIT=split, KSMI_TN_NS=ns)
+        # (spl = "1": the two-wave-group instance of round 4 -- each group walks half of the workgroup's reduction range and the halves
+        # meet in LDS -- forced wherever it fits, in direct mode and over split slabs; spl = "0": the one-group instances)
+        for split, ns, spl in (("1", "3", "0"), ("3", "3", "0"), ("1", "4", "0"), ("2", "5", "0"), ("1", "3", "1"), ("3", "3", "1")):
+            env = dict(os.environ, PYTHONPATH=root, KSMI_TN_BT=bt, KSMI_TN_SPLIT=split, KSMI_TN_NS=ns, KSMI_TN_SPL=spl)
             out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
             assert out.returncode == 0, out.stderr[-2000:]
             errs = [float(v) for v in out.stdout.split("ERR")[1].split()]
-            assert len(errs) == 4 and max(errs) < 1e-5, (bt, split, ns, errs)
+            assert len(errs) == 4 and max(errs) < 1e-5, (bt, split, ns, spl, errs)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
