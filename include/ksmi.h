@@ -520,6 +520,21 @@ int ksmi_dout_to_nhwc(const float* dy, const float* y, void* dx, int B, int C, i
  * fp32 parameter (ksmi_cast_bf16 of the arena once per step), row-major [N][K] with row stride w_rs; strides in elements.
  * ------------------------------------------------------------------------------- */
 int ksmi_cast_bf16(const float* src, void* dst, int64_t n, void* stream);
+/* ConvTranspose2d(k = 2, s = 2) of `up` (models/snunet.py:32-46) as token GEMMs (round 4; bf16, C a multiple of 128): the output pixel
+ * block (2y + dy, 2x + dx), dy, dx < 2, of input pixel m = (b, y, x) is the "depth row" {(d, n)} of 4C values = two contiguous runs of
+ * 2C elements of the [B, 2H, 2W, C] NHWC tensor, which the LDS-DMA loaders / the epilogue of the token GEMM kernels (csrc/gemm2.hip)
+ * address directly: no pixel-shuffle pass, no 2 x 2 window gather.
+ *   forward          y_depth[m][(d, n)] = sum_c x[m][c] Wt[c][n][d] + bias[n]           (GEMM NT, shuffled store)
+ *   input gradient   dx[m][c] (+)= sum_(d, n) dy_depth[m][(d, n)] Wt[c][n][d]           (GEMM NN, depth-row operand)
+ *   weight gradient  dWt[c][n][d] (+)= sum_m x[m][c] dy_depth[m][(d, n)]                (GEMM TN over row splits + permuting reducer)
+ * wb = the [4C][C] bf16 image of Wt written by ksmi_up_pack_weight each step; x, y, dy, dx NHWC bf16 ([B,H,W,C] / [B,2H,2W,C]). */
+int ksmi_up_gemm_supported(int B, int H, int W, int C, int dtype);
+int ksmi_up_pack_weight(const float* wt, void* wb, int C, void* stream);
+int ksmi_up_forward(const void* x, const void* wb, const float* bias, void* y, int B, int H, int W, int C, void* stream);
+int ksmi_up_dgrad(const void* dy, const void* wb, void* dx, int accumulate, int B, int H, int W, int C, void* stream);
+size_t ksmi_up_wgrad_workspace(int B, int H, int W, int C);
+int ksmi_up_wgrad(const void* x, const void* dy, float* workspace, float* grad, int accumulate, int B, int H, int W, int C, void* stream);
+
 /* y[rows][N] = x[rows][K] w^T + bias (+ resid) */
 int ksmi_gemm_nt(const void* x, int x_rs, const void* w, int w_rs, const float* bias, const void* resid, int r_rs, void* y, int y_rs,
                  int rows, int K, int N, void* stream);

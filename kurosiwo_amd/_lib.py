@@ -174,6 +174,12 @@ SIGNATURES = {
     "ksmi_tile_batch_read_bands": (_i, [C.POINTER(C.c_char_p), _i, _vp, _i, _i, _i, _i]),
     "ksmi_tiles_fill_nodata": (_i, [_vp, _i, _i, _i, _i]),
     "ksmi_cast_bf16": (_i, [_vp, _vp, _i64, _vp]),
+    "ksmi_up_gemm_supported": (_i, [_i, _i, _i, _i, _i]),
+    "ksmi_up_pack_weight": (_i, [_vp, _vp, _i, _vp]),
+    "ksmi_up_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "ksmi_up_dgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "ksmi_up_wgrad_workspace": (C.c_size_t, [_i, _i, _i, _i]),
+    "ksmi_up_wgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ksmi_gemm_nt": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
     "ksmi_gemm_nn": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     "ksmi_im2col": (_i, [_vp, _vp] + [_i] * 11 + [_i, _i, _vp]),

@@ -14,6 +14,7 @@
 #include "common.h"
 #include "../../include/ksmi.h"
 #include "errors.h"
+#include "igemm_epilogue.h"      // FastDiv
 
 namespace {
 
@@ -24,7 +25,20 @@ struct Gemm2P {
   bf16_t* out; int o_rs;
   int rows, red, cols, accumulate;    // reduction length, output columns
   int mtiles, ntiles;
+  // ConvTranspose2d(k2, s2) as a token GEMM (round 4, models/snunet.py:32-46): a "depth row" of pixel m = (b, y, x) of the H x W map is the
+  // 4C values {(dy, dx, n)} of the 2 x 2 block (2y + dy, 2x + dx) of a [B, 2H, 2W, C] NHWC tensor = two contiguous runs of 2C elements, one
+  // per image row.  map_a: the A operand's rows are depth rows (input gradient: A = d out); map_o: the output rows are (forward).
+  // up_C = 0: plain row-major matrices.
+  int map_a, map_o, up_H, up_W, up_C, bias_mod;
 };
+
+// element offset of the depth row of pixel m, and of column c (< 4C) inside it
+__device__ __forceinline__ size_t up_row_base(int m, int H, int W, int C) {
+  const int x = m % W, t = m / W, y = t % H, b = t / H;
+  return ((size_t)(b * 2 * H + 2 * y) * (size_t)(2 * W) + (size_t)(2 * x)) * (size_t)C;
+}
+__device__ __forceinline__ size_t up_col_off(int c, int W, int C) { return c < 2 * C ? (size_t)c : (size_t)(c - 2 * C) + (size_t)(2 * W) * (size_t)C; }
+
 
 __device__ __forceinline__ void glds16(const unsigned char* src, unsigned dst_wave_base) {
   unsigned keep;
@@ -70,7 +84,7 @@ __device__ __forceinline__ void store_row2(const Gemm2P& p, const f32x4 (&acc)[4
   for (int t = 0; t < 4; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[t * 4 + r] = acc[t][mt][r] + bias16[t * 4 + r];
-  bf16_t* op = p.out + (size_t)m * p.o_rs + c0;
+  bf16_t* op = p.map_o ? p.out + up_row_base(m, p.up_H, p.up_W, p.up_C) + up_col_off(c0, p.up_W, p.up_C) : p.out + (size_t)m * p.o_rs + c0;
   if (p.resid) {
     float a[8], b[8];
     vec_unpack<bf16_t>(*(const u32x4*)(p.resid + (size_t)m * p.r_rs + c0), a);
@@ -108,15 +122,19 @@ __global__ __launch_bounds__(256, 1) void gemm2_kernel(const Gemm2P p) {
   // ---- DMA sources: instruction q = wave + 4 i covers image rows q*8 .. q*8+7 (X rows first, then the W image)
   const unsigned char* src[NI];
   int step_bytes[NI];
+  size_t jump[NI];
+  const int jump_step = p.map_a ? (2 * p.up_C) / KS : 0x7fffffff;      // first K step of the second run
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
     const int q = wave + 4 * i;
+    jump[i] = 0;
     if (q * 8 < TM) {
       const int row = q * 8 + (lane >> 3), slot = lane & 7;
       const int chunk = slot ^ ((row >> 1) & 7);
       int m = m0 + row; if (m >= p.rows) m = p.rows - 1;
-      src[i] = (const unsigned char*)(p.a + (size_t)m * p.a_rs + chunk * 8);
+      src[i] = (const unsigned char*)(p.a + (p.map_a ? up_row_base(m, p.up_H, p.up_W, p.up_C) : (size_t)m * p.a_rs) + chunk * 8);
       step_bytes[i] = KS * 2;
+      jump[i] = p.map_a ? ((size_t)(2 * p.up_W) * p.up_C - (size_t)(2 * p.up_C)) * 2 : 0;     // (second image row of the 2 x 2 block)
     } else if constexpr (!TRW) {
       const int j = q * 8 - TM + (lane >> 3), slot = lane & 7;   // W image row j holds channel perm(j): see the fragment mapping below
       const int chunk = slot ^ ((j >> 1) & 7);
@@ -137,7 +155,7 @@ __global__ __launch_bounds__(256, 1) void gemm2_kernel(const Gemm2P p) {
   auto issue = [&](int s, int buf) {
     const unsigned base = lds0 + (unsigned)(buf * STAGE);
 #pragma unroll
-    for (int i = 0; i < NI; ++i) glds16(src[i] + (size_t)s * step_bytes[i], base + (unsigned)((wave + 4 * i) * 1024));
+    for (int i = 0; i < NI; ++i) glds16(src[i] + (size_t)s * step_bytes[i] + (s >= jump_step ? jump[i] : 0), base + (unsigned)((wave + 4 * i) * 1024));
   };
 
   // ---- fragment addresses (bytes within a stage) for k-substep 0; substep 1 = chunk + 4
@@ -232,7 +250,7 @@ __global__ __launch_bounds__(256, 1) void gemm2_kernel(const Gemm2P p) {
   if (c0 >= p.cols) return;
   float bias16[16];
 #pragma unroll
-  for (int j = 0; j < 16; ++j) bias16[j] = p.bias ? p.bias[c0 + j] : 0.f;
+  for (int j = 0; j < 16; ++j) bias16[j] = p.bias ? p.bias[p.bias_mod ? (c0 + j) % p.bias_mod : c0 + j] : 0.f;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) store_row2<MT>(p, acc, mt, m0 + wm * 16 * MT + mt * 16 + l15, c0, bias16);
 }
@@ -313,6 +331,7 @@ struct Gemm2T {
   int rows, rows_per_split, atiles, btiles;
   const unsigned char* zero;
   float* bias; int bias_acc;           // direct mode: bias[b column] (+)= sum over the rows of B (the nn.Linear bias gradient)
+  int map_a, up_H, up_W, up_C;         // A-side rows are the depth rows of a ConvTranspose2d(k2, s2) output gradient (Gemm2P.map_a)
 };
 __device__ __attribute__((aligned(64))) unsigned char gemm2_zero_page[64];
 
@@ -343,15 +362,19 @@ __global__ __launch_bounds__(256 * SPL, 1) void gemm2_tn_kernel(const Gemm2T p) 
   // DMA: instruction q = wave + 4 i; 16-byte unit index within the stage -> (image, reduction row, column granule)
   const unsigned char* src[NI];
   int srow[NI], sstep[NI];
+  bool amap[NI];
+  const FastDiv dW(p.up_W > 0 ? p.up_W : 1), dH(p.up_H > 0 ? p.up_H : 1);       // (exact: rows * W < 2^32)
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
     const int q = wave + 4 * i;
+    amap[i] = false;
     if (q * 1024 < AB) {
       const int u4 = q * 64 + lane, wr = u4 / AU, u = u4 % AU;
       const int cb = (u ^ sw_a(wr)) << 4;
       int c = a0 + (cb >> 1); if (c + 8 > p.a_cols) c = p.a_cols - 8;
-      src[i] = (const unsigned char*)(p.a + (size_t)(m_begin + wr) * p.a_rs + c);
-      srow[i] = wr; sstep[i] = KS * p.a_rs * 2;
+      src[i] = p.map_a ? (const unsigned char*)(p.a + up_col_off(c, p.up_W, p.up_C))        // (+ the row base, per step: issue())
+                       : (const unsigned char*)(p.a + (size_t)(m_begin + wr) * p.a_rs + c);
+      srow[i] = wr; sstep[i] = KS * p.a_rs * 2; amap[i] = p.map_a != 0;
     } else {
       const int u4 = q * 64 - AB / 16 + lane, wr = u4 / BU, u = u4 % BU;
       const int cb = (u ^ sw_bt<MT>(wr)) << 4;
@@ -366,7 +389,13 @@ __global__ __launch_bounds__(256 * SPL, 1) void gemm2_tn_kernel(const Gemm2T p) 
     for (int i = 0; i < NI; ++i) {
       // reduction rows past the split's end read the zero page (two 32-bit selects: a pointer select compiles to two masked DMAs)
       const bool ok = m_begin + s * KS + srow[i] < m_end;
-      const uint64_t real = (uint64_t)(uintptr_t)(src[i] + (size_t)s * sstep[i]), zp = (uint64_t)(uintptr_t)p.zero;
+      uint64_t real = (uint64_t)(uintptr_t)(src[i] + (size_t)s * sstep[i]);
+      if (amap[i]) {                    // depth row of pixel m = (b, y, x): two integer divisions by magic numbers per piece
+        const int m = ok ? m_begin + s * KS + srow[i] : 0;
+        const int t = dW.div(m), x = m - t * p.up_W, b = dH.div(t), y = t - b * p.up_H;
+        real = (uint64_t)(uintptr_t)(src[i] + (((size_t)(b * 2 * p.up_H + 2 * y) * (size_t)(2 * p.up_W) + (size_t)(2 * x)) * (size_t)p.up_C) * 2);
+      }
+      const uint64_t zp = (uint64_t)(uintptr_t)p.zero;
       const uint32_t lo = ok ? (uint32_t)real : (uint32_t)zp, hi = ok ? (uint32_t)(real >> 32) : (uint32_t)(zp >> 32);
       glds16((const unsigned char*)(uintptr_t)(((uint64_t)hi << 32) | lo), base + (unsigned)((wave + 4 * i) * 1024));
     }
@@ -513,6 +542,20 @@ int ksmi_gemm2_nn(const void* dy, int dy_rs, const void* w, int w_rs, void* dx, 
   return dispatch2<true>(p, st);
 }
 
+// ConvTranspose2d(k2, s2) forward / input gradient as token GEMMs over depth rows (Gemm2P.map_*): wb = [4C][C] bf16, row (d, n) = Wt[:, n, d]
+int ksmi_gemm2_up_forward(const void* x, const void* wb, const float* bias, void* y, int B, int H, int W, int C, hipStream_t st) {
+  if (C % 64 || C < 128 || B * H * W < 64) return 1;
+  Gemm2P p = {(const bf16_t*)x, C, (const bf16_t*)wb, C, bias, nullptr, 0, (bf16_t*)y, 0, B * H * W, C, 4 * C, 0, 0, 0};
+  p.map_o = 1; p.up_H = H; p.up_W = W; p.up_C = C; p.bias_mod = C;
+  return dispatch2<false>(p, st);
+}
+int ksmi_gemm2_up_dgrad(const void* dy, const void* wb, void* dx, int accumulate, int B, int H, int W, int C, hipStream_t st) {
+  if (C % 128 || C < 128 || B * H * W < 64) return 1;
+  Gemm2P p = {(const bf16_t*)dy, 0, (const bf16_t*)wb, C, nullptr, nullptr, 0, (bf16_t*)dx, C, B * H * W, 4 * C, C, accumulate, 0, 0};
+  p.map_a = 1; p.up_H = H; p.up_W = W; p.up_C = C;
+  return dispatch2<true>(p, st);
+}
+
 template <int MT, int NS, int SPL = 1>
 static void launch_tn(dim3 grid, const Gemm2T& p, hipStream_t st) {
   constexpr int lds = SPL * NS * (64 * 256 + 64 * 64 * MT);
@@ -574,3 +617,93 @@ int ksmi_gemm2_tn(const void* x, int x_rs, const void* dy, int dy_rs, float* sla
   else return ksmi_fail(KSMI_E_ARG, "gemm2_tn: B-side tile must be 64, 96 or 128");
   return ksmi_check_launch("gemm2_tn");
 }
+
+
+// ---------------------------------------------------------------------------------------------- ConvTranspose2d(k2, s2) as token GEMMs
+namespace {
+// wb[(d * C + n) * C + c] = bf16(Wt[c][n][d])   (nn.ConvTranspose2d weight [C_in = C][C_out = C][2][2], d = dy * 2 + dx)
+__global__ void up_pack_kernel(const float* __restrict__ wt, bf16_t* __restrict__ wb, int C) {
+  const int64_t n_el = (int64_t)4 * C * C;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_el; e += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(e % C); const int64_t r = e / C; const int n = (int)(r % C), d = (int)(r / C);
+    wb[e] = f32_to_bf16(wt[((int64_t)c * C + n) * 4 + d]);
+  }
+}
+// grad[c][n][d] (+)= sum_split slab[split][c][d * C + n]   (slab rows k = c, columns n' = (d, n); fixed order)
+__global__ void up_wgrad_reduce_kernel(const float* __restrict__ slab, int nsplit, int C, float* __restrict__ grad, int accumulate) {
+  const int64_t n_el = (int64_t)C * C;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_el; e += (int64_t)gridDim.x * blockDim.x) {
+    const int n = (int)(e % C), c = (int)(e / C);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int sp = 0; sp < nsplit; ++sp) {
+      const float* row = slab + ((int64_t)sp * C + c) * (int64_t)(4 * C);
+#pragma unroll
+      for (int d = 0; d < 4; ++d) s[d] += row[d * C + n];
+    }
+    f32x4* o = (f32x4*)(grad + ((int64_t)c * C + n) * 4);
+    *o = accumulate ? *o + s : s;
+  }
+}
+inline void up_wgrad_geom(int rows, int C, int* nsplit, int* rps) {
+  const int tiles = (4 * C / 128) * (C / 64);
+  int want = (512 + tiles - 1) / tiles;                    // ~two workgroups per CU
+  const int steps_all = (rows + 63) / 64;
+  if (want > steps_all / 8) want = steps_all / 8 > 0 ? steps_all / 8 : 1;      // (>= 8 K steps per split)
+  if (want < 1) want = 1;
+  *rps = ((steps_all + want - 1) / want) * 64;
+  *nsplit = (rows + *rps - 1) / *rps;
+}
+}  // namespace
+
+int ksmi_gemm2_up_pack(const float* wt, void* wb, int C, hipStream_t st) {
+  const int64_t n_el = (int64_t)4 * C * C;
+  hipLaunchKernelGGL(up_pack_kernel, dim3((unsigned)((n_el + 255) / 256 > 2048 ? 2048 : (n_el + 255) / 256)), dim3(256), 0, st, wt, (bf16_t*)wb, C);
+  return ksmi_check_launch("up_pack");
+}
+size_t ksmi_gemm2_up_wgrad_workspace(int B, int H, int W, int C) {
+  int nsplit, rps;
+  up_wgrad_geom(B * H * W, C, &nsplit, &rps);
+  return (size_t)nsplit * C * 4 * C * sizeof(float);
+}
+// dWt[c][n][d] (+)= sum_m x[m][c] dY_depth[m][(d, n)]: slab-mode gemm2_tn (A = the depth rows of d out, B = x) + the permuting reducer
+int ksmi_gemm2_up_wgrad(const void* x, const void* dy, float* slab, float* grad, int accumulate, int B, int H, int W, int C, hipStream_t st) {
+  if (C % 128 || C < 128 || B * H * W < 64) return 1;
+  static void* zero_page = nullptr;
+  if (!zero_page && hipGetSymbolAddress(&zero_page, HIP_SYMBOL(gemm2_zero_page)) != hipSuccess) return ksmi_fail(KSMI_E_UNSUPPORTED, "gemm2: zero page");
+  const int rows = B * H * W;
+  int nsplit, rps;
+  up_wgrad_geom(rows, C, &nsplit, &rps);
+  Gemm2T p = {};
+  p.rows = rows; p.rows_per_split = rps; p.zero = (const unsigned char*)zero_page;
+  p.a = (const bf16_t*)dy; p.a_rs = 0; p.a_cols = 4 * C; p.b = (const bf16_t*)x; p.b_rs = C; p.b_cols = C;
+  p.out = slab; p.o_rs = 4 * C; p.split_stride = (int64_t)C * 4 * C; p.accumulate = 0;
+  p.map_a = 1; p.up_H = H; p.up_W = W; p.up_C = C;
+  p.atiles = 4 * C / 128; p.btiles = C / 64;
+  launch_tn<2, 3>(dim3(p.atiles * p.btiles, nsplit), p, st);
+  int rc = ksmi_check_launch("gemm2_up_wgrad");
+  if (rc) return rc;
+  const int64_t n_el = (int64_t)C * C;
+  hipLaunchKernelGGL(up_wgrad_reduce_kernel, dim3((unsigned)((n_el + 255) / 256)), dim3(256), 0, st, slab, nsplit, C, grad, accumulate);
+  return ksmi_check_launch("up_wgrad_reduce");
+}
+
+extern "C" {
+int ksmi_up_gemm_supported(int B, int H, int W, int C, int dtype) {
+  static const bool off = getenv("KSMI_GEMM2_OFF") != nullptr;
+  return !off && dtype == KSMI_BF16 && C >= 128 && C % 128 == 0 && (int64_t)B * H * W >= 64 && (int64_t)B * H * W * 112 < ((int64_t)1 << 32) ? 1 : 0;
+}
+int ksmi_up_pack_weight(const float* wt, void* wb, int C, void* stream) { return ksmi_gemm2_up_pack(wt, wb, C, (hipStream_t)stream); }
+int ksmi_up_forward(const void* x, const void* wb, const float* bias, void* y, int B, int H, int W, int C, void* stream) {
+  const int rc = ksmi_gemm2_up_forward(x, wb, bias, y, B, H, W, C, (hipStream_t)stream);
+  return rc == 1 ? ksmi_fail(KSMI_E_UNSUPPORTED, "up_forward: shape not covered (ksmi_up_gemm_supported)") : rc;
+}
+int ksmi_up_dgrad(const void* dy, const void* wb, void* dx, int accumulate, int B, int H, int W, int C, void* stream) {
+  const int rc = ksmi_gemm2_up_dgrad(dy, wb, dx, accumulate, B, H, W, C, (hipStream_t)stream);
+  return rc == 1 ? ksmi_fail(KSMI_E_UNSUPPORTED, "up_dgrad: shape not covered (ksmi_up_gemm_supported)") : rc;
+}
+size_t ksmi_up_wgrad_workspace(int B, int H, int W, int C) { return ksmi_gemm2_up_wgrad_workspace(B, H, W, C); }
+int ksmi_up_wgrad(const void* x, const void* dy, float* workspace, float* grad, int accumulate, int B, int H, int W, int C, void* stream) {
+  const int rc = ksmi_gemm2_up_wgrad(x, dy, workspace, grad, accumulate, B, H, W, C, (hipStream_t)stream);
+  return rc == 1 ? ksmi_fail(KSMI_E_UNSUPPORTED, "up_wgrad: shape not covered (ksmi_up_gemm_supported)") : rc;
+}
+}  // extern "C"

@@ -172,6 +172,7 @@ class SNUNetPlan:
     two_lanes = True           # the decoder launches carry lane tags and hand-over entries (StepStreams)
     bn_fused = os.environ.get("KSMI_BN_FUSED", "1") != "0"     # statistics finish inside the consuming pass (csrc/bnfused.hip)
     im2col_late = os.environ.get("KSMI_IM2COL_LATE", "1") != "0"   # first-layer im2col in the backward list, next to its reader
+    up_gemm = os.environ.get("KSMI_UP_GEMM", "1") != "0"           # ConvTranspose2d(k2, s2) with C >= 128 as token GEMMs (ksmi_up_*)
 
     def __init__(self, model, B, H, W, dtype, training, with_backward, tail=0):
         self.m, self.B, self.H, self.W, self.dtype = model, B, H, W, dtype
@@ -458,12 +459,7 @@ class SNUNetPlan:
                                                               x.B, x.H, x.W, x.C, self.dt))
         self.bwd_builders.append((self.fwd.cur_lane, build_bwd))
 
-    # ---------------------------------------------------------------- up = ConvTranspose2d(k2,s2)  (snunet.py:32-46)
-    def _up(self, name, x):
-        Cc, B, H, W = x.C, x.B, x.H, x.W
-        y = Act(name, B, 2 * H, 2 * W, Cc, self.dtype, self.dev)
-        self._stage(2 * H)                                   # (an Up is booked on the level it writes)
-        wkey, bkey = f"{name}.up.weight", f"{name}.up.bias"
+    def _up_conv_forward(self, x, y, wkey, bkey, B, H, W, Cc):
         d, table = make_conv([SrcSpec(x.t, Cc)], [(y.t, Cc, 0, 0, 4 * Cc, 0)], x.t, self.m._p(bkey), None,
                              B, H, W, H, W, 1, 1, 1, 0, 4 * Cc, self.dtype, ps_cout=Cc)
         # Wt[c][n][dy][dx]: GEMM column j = d*C + n, k = c
@@ -471,22 +467,55 @@ class SNUNetPlan:
         d.wpk = wpk.data_ptr()
         self._conv(self.fwd, d)
 
+    # ---------------------------------------------------------------- up = ConvTranspose2d(k2,s2)  (snunet.py:32-46)
+    def _up(self, name, x):
+        Cc, B, H, W = x.C, x.B, x.H, x.W
+        y = Act(name, B, 2 * H, 2 * W, Cc, self.dtype, self.dev)
+        self._stage(2 * H)                                   # (an Up is booked on the level it writes)
+        wkey, bkey = f"{name}.up.weight", f"{name}.up.bias"
+        # levels with C >= 128 (Up2_j, Up3_j, Up4_0): the transposed convolution and both of its gradients as token GEMMs over the
+        # "depth rows" of the output (csrc/gemm2.hip, ksmi_up_*): 400-600 TFLOP/s kernels instead of the 140-240 TFLOP/s the k2 s2
+        # shapes reach on the first-generation convolution kernels
+        up_gemm = (self.up_gemm and self.dtype == torch.bfloat16 and bool(self.lib.ksmi_up_gemm_supported(B, H, W, Cc, self.dt)))
+        es = self._es()
+        if up_gemm:
+            wb = torch.empty(4 * Cc * Cc, dtype=torch.bfloat16, device=self.dev)
+            self.keep.append(wb)
+            self.packs.add("ksmi_up_pack_weight", lambda: (self.m._p(wkey).data_ptr(), wb.data_ptr(), Cc))
+            self.fwd.add("ksmi_up_forward", lambda: (x.t.data_ptr(), wb.data_ptr(), self.m._p(bkey).data_ptr(), y.t.data_ptr(), B, H, W, Cc),
+                         {"kind": "up_gemm_fwd", "bytes": B * H * W * Cc * 5 * es, "flops": 2 * B * H * W * Cc * 4 * Cc, "tag": f"K={Cc} N={4 * Cc} {H}x{W}"})
+        else:
+            self._up_conv_forward(x, y, wkey, bkey, B, H, W, Cc)
+
         def build_bwd():
             self._stage(2 * H)
             fused_bias = self._emit_dgrad(y, bias_key=bkey)
             gy = y.grad()
             s2 = [SrcSpec(gy, Cc)]
             acc = x.take_acc_flag()
-            # input gradient = 2x2 stride-2 conv over dUp: K = n, N = c
-            d2, t2 = make_conv(s2, [(x.grad(), Cc, 0, 0, Cc, acc)], gy, None, None,
-                               B, 2 * H, 2 * W, H, W, 2, 2, 2, 0, Cc, self.dtype)
-            w2 = self._packed(wkey, t2, 4, Cc, Cc, 4, Cc * 4, 0, 1, 0)
-            d2.wpk = w2.data_ptr()
-            self._conv(self.bwd, d2, "dgrad")
-            # weight gradient: G[tap d][k = n][col = c] -> grad[c*(4C) + n*4 + d]
-            dw, ws = make_wgrad(s2, x.t, Cc, 0, Cc, self.m._g(wkey), 4, Cc * 4, 1, self._acc_param(wkey),
-                                B, 2 * H, 2 * W, H, W, 2, 2, 2, 0, self.dtype)
-            self._wgrad(dw, ws, wkey)
+            if up_gemm:
+                gx = x.grad()
+                self.bwd.add("ksmi_up_dgrad", lambda: (gy.data_ptr(), wb.data_ptr(), gx.data_ptr(), acc, B, H, W, Cc),
+                             {"kind": "up_gemm_dgrad", "bytes": B * H * W * Cc * (5 + acc) * es, "flops": 2 * B * H * W * Cc * 4 * Cc,
+                              "tag": f"K={4 * Cc} N={Cc} {H}x{W}"})
+                sW = self._sname("wgrad")
+                self.need(sW, self.lib.ksmi_up_wgrad_workspace(B, H, W, Cc))
+                a_w = self._acc_param(wkey)
+                self.bwd.add("ksmi_up_wgrad", lambda: (x.t.data_ptr(), gy.data_ptr(), self.scr(sW), self.m._g(wkey).data_ptr(), a_w, B, H, W, Cc),
+                             {"kind": "up_gemm_wgrad", "bytes": B * H * W * Cc * 5 * es + 16 * Cc * Cc, "flops": 2 * B * H * W * Cc * 4 * Cc,
+                              "tag": f"{wkey} K={Cc} N={4 * Cc} {H}x{W}", "side": True})
+                self._mark(wkey)
+            else:
+                # input gradient = 2x2 stride-2 conv over dUp: K = n, N = c
+                d2, t2 = make_conv(s2, [(x.grad(), Cc, 0, 0, Cc, acc)], gy, None, None,
+                                   B, 2 * H, 2 * W, H, W, 2, 2, 2, 0, Cc, self.dtype)
+                w2 = self._packed(wkey, t2, 4, Cc, Cc, 4, Cc * 4, 0, 1, 0)
+                d2.wpk = w2.data_ptr()
+                self._conv(self.bwd, d2, "dgrad")
+                # weight gradient: G[tap d][k = n][col = c] -> grad[c*(4C) + n*4 + d]
+                dw, ws = make_wgrad(s2, x.t, Cc, 0, Cc, self.m._g(wkey), 4, Cc * 4, 1, self._acc_param(wkey),
+                                    B, 2 * H, 2 * W, H, W, 2, 2, 2, 0, self.dtype)
+                self._wgrad(dw, ws, wkey)
             if not fused_bias:                                      # (no 3x3 consumer: separate pass over the gradient)
                 npix = B * 4 * H * W
                 rows = self._rows(npix)

@@ -258,3 +258,48 @@ def test_sar_preprocess_matches_dataset_pipeline():
     ref = (ref - torch.tensor(mean).view(1, 2, 1, 1)) / torch.tensor(std).view(1, 2, 1, 1)
     out = preprocess_gpu(x.cuda(), mean, std, cl).cpu()
     assert torch.allclose(out, ref, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("B,H,W,Cc", [(2, 28, 28, 128), (3, 14, 14, 256), (1, 7, 9, 512), (32, 56, 56, 128)])
+def test_up_convtranspose_as_token_gemms(dev, B, H, W, Cc):
+    """ksmi_up_forward / ksmi_up_dgrad / ksmi_up_wgrad (ConvTranspose2d(k2, s2) of `up`, models/snunet.py:32-46, as token GEMMs over
+    "depth rows" of the NHWC output; csrc/gemm2.hip) against torch.nn.functional.conv_transpose2d and its autograd on the same
+    bf16-rounded operands."""
+    import ctypes as C
+    import torch.nn.functional as F
+    from kurosiwo_amd import _lib
+    from kurosiwo_amd.runtime import stream_ptr
+    lib = _lib.load()
+    assert lib.ksmi_up_gemm_supported(B, H, W, Cc, 1) == 1
+    torch.manual_seed(B * 1000 + Cc)
+    x = (torch.randn(B, Cc, H, W, device=dev) * 0.5).bfloat16()
+    wt = torch.randn(Cc, Cc, 2, 2, device=dev) / (Cc ** 0.5)
+    bias = torch.randn(Cc, device=dev)
+    dy = (torch.randn(B, Cc, 2 * H, 2 * W, device=dev) * 0.5).bfloat16()
+    # reference on the bf16-rounded weights (the kernel's operand), fp32 math
+    wr = wt.bfloat16().float().requires_grad_(True)
+    xr = x.float().requires_grad_(True)
+    yr = F.conv_transpose2d(xr, wr, bias, stride=2)
+    yr.backward(dy.float())
+    x_nhwc = x.permute(0, 2, 3, 1).contiguous()
+    dy_nhwc = dy.permute(0, 2, 3, 1).contiguous()
+    wb = torch.empty(4 * Cc * Cc, dtype=torch.bfloat16, device=dev)
+    st = stream_ptr()
+    _lib.check(lib.ksmi_up_pack_weight(wt.data_ptr(), wb.data_ptr(), Cc, st), "pack")
+    y = torch.empty(B, 2 * H, 2 * W, Cc, dtype=torch.bfloat16, device=dev)
+    _lib.check(lib.ksmi_up_forward(x_nhwc.data_ptr(), wb.data_ptr(), bias.data_ptr(), y.data_ptr(), B, H, W, Cc, st), "fwd")
+    ref = yr.detach().permute(0, 2, 3, 1)
+    assert float((y.float() - ref).abs().max() / ref.abs().max()) < 1e-2
+    dx = torch.full((B, H, W, Cc), 7.0, dtype=torch.bfloat16, device=dev)
+    _lib.check(lib.ksmi_up_dgrad(dy_nhwc.data_ptr(), wb.data_ptr(), dx.data_ptr(), 0, B, H, W, Cc, st), "dgrad")
+    refd = xr.grad.permute(0, 2, 3, 1)
+    assert float((dx.float() - refd).abs().max() / refd.abs().max()) < 1e-2
+    base = dx.clone()
+    _lib.check(lib.ksmi_up_dgrad(dy_nhwc.data_ptr(), wb.data_ptr(), dx.data_ptr(), 1, B, H, W, Cc, st), "dgrad+=")
+    assert float((dx.float() - (base.float() + refd)).abs().max() / refd.abs().max()) < 2e-2
+    ws = torch.empty(lib.ksmi_up_wgrad_workspace(B, H, W, Cc), dtype=torch.uint8, device=dev)
+    gw = torch.full((Cc, Cc, 2, 2), 3.0, device=dev)
+    _lib.check(lib.ksmi_up_wgrad(x_nhwc.data_ptr(), dy_nhwc.data_ptr(), ws.data_ptr(), gw.data_ptr(), 0, B, H, W, Cc, st), "wgrad")
+    assert float((gw - wr.grad).abs().max() / wr.grad.abs().max()) < 2e-3
+    _lib.check(lib.ksmi_up_wgrad(x_nhwc.data_ptr(), dy_nhwc.data_ptr(), ws.data_ptr(), gw.data_ptr(), 1, B, H, W, Cc, st), "wgrad+=")
+    assert float((gw - 2 * wr.grad).abs().max() / wr.grad.abs().max()) < 4e-3
