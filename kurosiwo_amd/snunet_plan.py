@@ -477,11 +477,16 @@ class SNUNetPlan:
         # "depth rows" of the output (csrc/gemm2.hip, ksmi_up_*): 400-600 TFLOP/s kernels instead of the 140-240 TFLOP/s the k2 s2
         # shapes reach on the first-generation convolution kernels
         up_gemm = (self.up_gemm and self.dtype == torch.bfloat16 and bool(self.lib.ksmi_up_gemm_supported(B, H, W, Cc, self.dt)))
+        # measured per operation (profiles/r04_up_gemm.txt, one stream): the input gradient (K = 4C) wins from C = 128 on (76 -> 49 us at
+        # 56^2), forward and weight gradient from C = 256 on (77 -> 57 us, 79 -> ~40 us at 28^2); at C = 128 the forward GEMM has two K
+        # steps per tile and loses to the persistent 1x1 kernel (33-45 -> 80 us), the weight gradient ties (73 -> 70 us)
+        up_fwd_gemm = up_wgrad_gemm = up_gemm and Cc >= 256
         es = self._es()
         if up_gemm:
             wb = torch.empty(4 * Cc * Cc, dtype=torch.bfloat16, device=self.dev)
             self.keep.append(wb)
             self.packs.add("ksmi_up_pack_weight", lambda: (self.m._p(wkey).data_ptr(), wb.data_ptr(), Cc))
+        if up_fwd_gemm:
             self.fwd.add("ksmi_up_forward", lambda: (x.t.data_ptr(), wb.data_ptr(), self.m._p(bkey).data_ptr(), y.t.data_ptr(), B, H, W, Cc),
                          {"kind": "up_gemm_fwd", "bytes": B * H * W * Cc * 5 * es, "flops": 2 * B * H * W * Cc * 4 * Cc, "tag": f"K={Cc} N={4 * Cc} {H}x{W}"})
         else:
@@ -498,6 +503,14 @@ class SNUNetPlan:
                 self.bwd.add("ksmi_up_dgrad", lambda: (gy.data_ptr(), wb.data_ptr(), gx.data_ptr(), acc, B, H, W, Cc),
                              {"kind": "up_gemm_dgrad", "bytes": B * H * W * Cc * (5 + acc) * es, "flops": 2 * B * H * W * Cc * 4 * Cc,
                               "tag": f"K={4 * Cc} N={Cc} {H}x{W}"})
+            else:
+                # input gradient = 2x2 stride-2 conv over dUp: K = n, N = c
+                d2, t2 = make_conv(s2, [(x.grad(), Cc, 0, 0, Cc, acc)], gy, None, None,
+                                   B, 2 * H, 2 * W, H, W, 2, 2, 2, 0, Cc, self.dtype)
+                w2 = self._packed(wkey, t2, 4, Cc, Cc, 4, Cc * 4, 0, 1, 0)
+                d2.wpk = w2.data_ptr()
+                self._conv(self.bwd, d2, "dgrad")
+            if up_wgrad_gemm:
                 sW = self._sname("wgrad")
                 self.need(sW, self.lib.ksmi_up_wgrad_workspace(B, H, W, Cc))
                 a_w = self._acc_param(wkey)
@@ -506,12 +519,6 @@ class SNUNetPlan:
                               "tag": f"{wkey} K={Cc} N={4 * Cc} {H}x{W}", "side": True})
                 self._mark(wkey)
             else:
-                # input gradient = 2x2 stride-2 conv over dUp: K = n, N = c
-                d2, t2 = make_conv(s2, [(x.grad(), Cc, 0, 0, Cc, acc)], gy, None, None,
-                                   B, 2 * H, 2 * W, H, W, 2, 2, 2, 0, Cc, self.dtype)
-                w2 = self._packed(wkey, t2, 4, Cc, Cc, 4, Cc * 4, 0, 1, 0)
-                d2.wpk = w2.data_ptr()
-                self._conv(self.bwd, d2, "dgrad")
                 # weight gradient: G[tap d][k = n][col = c] -> grad[c*(4C) + n*4 + d]
                 dw, ws = make_wgrad(s2, x.t, Cc, 0, Cc, self.m._g(wkey), 4, Cc * 4, 1, self._acc_param(wkey),
                                     B, 2 * H, 2 * W, H, W, 2, 2, 2, 0, self.dtype)

@@ -260,7 +260,7 @@ def test_sar_preprocess_matches_dataset_pipeline():
     assert torch.allclose(out, ref, rtol=1e-6, atol=1e-6)
 
 
-@pytest.mark.parametrize("B,H,W,Cc", [(2, 28, 28, 128), (3, 14, 14, 256), (1, 7, 9, 512), (32, 56, 56, 128)])
+@pytest.mark.parametrize("B,H,W,Cc", [(2, 28, 28, 128), (3, 14, 14, 256), (2, 7, 9, 512), (32, 56, 56, 128)])
 def test_up_convtranspose_as_token_gemms(dev, B, H, W, Cc):
     """ksmi_up_forward / ksmi_up_dgrad / ksmi_up_wgrad (ConvTranspose2d(k2, s2) of `up`, models/snunet.py:32-46, as token GEMMs over
     "depth rows" of the NHWC output; csrc/gemm2.hip) against torch.nn.functional.conv_transpose2d and its autograd on the same
