@@ -529,6 +529,7 @@ int ksmi_cast_bf16(const float* src, void* dst, int64_t n, void* stream);
  *   weight gradient  dWt[c][n][d] (+)= sum_m x[m][c] dy_depth[m][(d, n)]                (GEMM TN over row splits + permuting reducer)
  * wb = the [4C][C] bf16 image of Wt written by ksmi_up_pack_weight each step; x, y, dy, dx NHWC bf16 ([B,H,W,C] / [B,2H,2W,C]). */
 int ksmi_up_gemm_supported(int B, int H, int W, int C, int dtype);
+int ksmi_up_wgrad_supported(int B, int H, int W, int C, int dtype);      /* the weight gradient alone also takes C = 64 */
 int ksmi_up_pack_weight(const float* wt, void* wb, int C, void* stream);
 int ksmi_up_forward(const void* x, const void* wb, const float* bias, void* y, int B, int H, int W, int C, void* stream);
 int ksmi_up_dgrad(const void* dy, const void* wb, void* dx, int accumulate, int B, int H, int W, int C, void* stream);

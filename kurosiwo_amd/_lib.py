@@ -175,6 +175,7 @@ SIGNATURES = {
     "ksmi_tiles_fill_nodata": (_i, [_vp, _i, _i, _i, _i]),
     "ksmi_cast_bf16": (_i, [_vp, _vp, _i64, _vp]),
     "ksmi_up_gemm_supported": (_i, [_i, _i, _i, _i, _i]),
+    "ksmi_up_wgrad_supported": (_i, [_i, _i, _i, _i, _i]),
     "ksmi_up_pack_weight": (_i, [_vp, _vp, _i, _vp]),
     "ksmi_up_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ksmi_up_dgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

@@ -667,7 +667,7 @@ size_t ksmi_gemm2_up_wgrad_workspace(int B, int H, int W, int C) {
 }
 // dWt[c][n][d] (+)= sum_m x[m][c] dY_depth[m][(d, n)]: slab-mode gemm2_tn (A = the depth rows of d out, B = x) + the permuting reducer
 int ksmi_gemm2_up_wgrad(const void* x, const void* dy, float* slab, float* grad, int accumulate, int B, int H, int W, int C, hipStream_t st) {
-  if (C % 128 || C < 128 || B * H * W < 64) return 1;
+  if (C % 64 || C < 64 || B * H * W < 64) return 1;          // (a 128-column A tile stays inside one 2C-element run of the depth row)
   static void* zero_page = nullptr;
   if (!zero_page && hipGetSymbolAddress(&zero_page, HIP_SYMBOL(gemm2_zero_page)) != hipSuccess) return ksmi_fail(KSMI_E_UNSUPPORTED, "gemm2: zero page");
   const int rows = B * H * W;
@@ -691,6 +691,10 @@ extern "C" {
 int ksmi_up_gemm_supported(int B, int H, int W, int C, int dtype) {
   static const bool off = getenv("KSMI_GEMM2_OFF") != nullptr;
   return !off && dtype == KSMI_BF16 && C >= 128 && C % 128 == 0 && (int64_t)B * H * W >= 64 && (int64_t)B * H * W * 112 < ((int64_t)1 << 32) ? 1 : 0;
+}
+int ksmi_up_wgrad_supported(int B, int H, int W, int C, int dtype) {
+  static const bool off = getenv("KSMI_GEMM2_OFF") != nullptr;
+  return !off && dtype == KSMI_BF16 && C >= 64 && C % 64 == 0 && (int64_t)B * H * W >= 64 && (int64_t)B * H * W * 112 < ((int64_t)1 << 32) ? 1 : 0;
 }
 int ksmi_up_pack_weight(const float* wt, void* wb, int C, void* stream) { return ksmi_gemm2_up_pack(wt, wb, C, (hipStream_t)stream); }
 int ksmi_up_forward(const void* x, const void* wb, const float* bias, void* y, int B, int H, int W, int C, void* stream) {

@@ -260,6 +260,26 @@ def test_sar_preprocess_matches_dataset_pipeline():
     assert torch.allclose(out, ref, rtol=1e-6, atol=1e-6)
 
 
+def test_up_weight_gradient_c64(dev):
+    """the weight gradient of the level-0 Ups (C = 64: a 128-column tile is exactly one 2C run of the depth row) on ksmi_up_wgrad"""
+    import torch.nn.functional as F
+    from kurosiwo_amd import _lib
+    from kurosiwo_amd.runtime import stream_ptr
+    lib = _lib.load()
+    B, H, W, Cc = 4, 24, 20, 64
+    assert lib.ksmi_up_wgrad_supported(B, H, W, Cc, 1) == 1 and lib.ksmi_up_gemm_supported(B, H, W, Cc, 1) == 0
+    torch.manual_seed(64)
+    x = (torch.randn(B, Cc, H, W, device=dev) * 0.5).bfloat16()
+    dy = (torch.randn(B, Cc, 2 * H, 2 * W, device=dev) * 0.5).bfloat16()
+    wr = torch.zeros(Cc, Cc, 2, 2, device=dev, requires_grad=True)
+    F.conv_transpose2d(x.float(), wr, None, stride=2).backward(dy.float())
+    ws = torch.empty(lib.ksmi_up_wgrad_workspace(B, H, W, Cc), dtype=torch.uint8, device=dev)
+    gw = torch.full((Cc, Cc, 2, 2), 3.0, device=dev)
+    _lib.check(lib.ksmi_up_wgrad(x.permute(0, 2, 3, 1).contiguous().data_ptr(), dy.permute(0, 2, 3, 1).contiguous().data_ptr(), ws.data_ptr(),
+                                 gw.data_ptr(), 0, B, H, W, Cc, stream_ptr()), "wgrad")
+    assert float((gw - wr.grad).abs().max() / wr.grad.abs().max()) < 2e-3
+
+
 @pytest.mark.parametrize("B,H,W,Cc", [(2, 28, 28, 128), (3, 14, 14, 256), (2, 7, 9, 512), (32, 56, 56, 128)])
 def test_up_convtranspose_as_token_gemms(dev, B, H, W, Cc):
     """ksmi_up_forward / ksmi_up_dgrad / ksmi_up_wgrad (ConvTranspose2d(k2, s2) of `up`, models/snunet.py:32-46, as token GEMMs over
