@@ -267,6 +267,13 @@ def build_roofline(args, step, solo_timer, solo_steps, d, dominant, timer_steps,
                               "ms_per_step": round(v["ms"] / solo_steps, 3), "algorithmic_GBs": round(v["bytes"] / v["ms"] / 1e6, 1),
                               "tflops": round(v["flops"] / v["ms"] / 1e9, 1)}
                              for n, v in sorted(by_kernel.items(), key=lambda kv: -kv[1]["ms"])[:8]]}
+    # exact per-stage counters of one single-stream step (profiles/stage_traffic.py: per-dispatch PMC rows aligned with this plan's launches)
+    stage_pmc, stage_pmc_path = {}, None
+    for rnd in PROFILE_ROUNDS:
+        sp = os.path.join(ROOT, "profiles", f"{rnd}_{TRAFFIC_FILE.get(args.model, args.model)}_stage_traffic.json")
+        if os.path.exists(sp):
+            stage_pmc, stage_pmc_path = json.load(open(sp))["stages"], os.path.relpath(sp, ROOT)
+            break
     order = sorted(stages, key=lambda t: (not t.startswith("L"), t))
     roof["stages"] = [{"stage": t, "launches_per_step": stages[t]["n"] // solo_steps, "ms_per_step_solo": round(stages[t]["ms"] / solo_steps, 3),
                        "conv_algorithmic_GB": round(stages[t]["conv_bytes"] / solo_steps / 1e9, 3), "all_passes_GB": round(stages[t]["bytes"] / solo_steps / 1e9, 3),
@@ -277,11 +284,16 @@ def build_roofline(args, step, solo_timer, solo_steps, d, dominant, timer_steps,
                        "GFLOP": round(stages[t]["flops"] / solo_steps / 1e9, 1), "tflops": round(stages[t]["flops"] / max(stages[t]["ms"], 1e-9) / 1e9, 1),
                        "mfma_frac": round(stages[t]["flops"] / max(stages[t]["ms"], 1e-9) / 1e9 / MFMA_BF16_PEAK_TF, 4),
                        "mfma_busy_pct": None if not stages[t]["busy_ms"] else round(stages[t]["busy_w"] / stages[t]["busy_ms"], 1)}
+                      | ({"counted_GB": stage_pmc[t]["counted_GB"], "counted_over_all_passes": round(stage_pmc[t]["counted_GB"] / max(stages[t]["bytes"] / solo_steps / 1e9, 1e-9), 3),
+                          "mfma_busy_pct": stage_pmc[t]["mfma_busy_pct"]} if t in stage_pmc else {})
                       for t in order]
+    if stage_pmc_path:
+        roof["stages_counters"] = stage_pmc_path
     roof["stages_note"] = ("all_passes_GB = algorithmic bytes of EVERY launch of the stage (convolutions + BatchNorm / pooling / elementwise passes), "
                            "conv_algorithmic_GB = the convolution / GEMM launches alone (SURVEY.md §8(d) counts these); counted_conv_GB and mfma_busy_pct "
                            "use the per-kernel averages of the committed PMC table (a kernel instantiation that serves several stages contributes its "
-                           "average to each), null without a table")
+                           "average to each), null without a table; with `stages_counters`, counted_GB (every pass of the stage) and mfma_busy_pct are "
+                           "the per-dispatch counters of one single-stream step aligned with the launches (profiles/stage_traffic.py)")
     if "attention_block" in stages:            # north_star: ">= 40 % of the bf16 MFMA peak on the ChangeFormer attention block"
         a = stages["attention_block"]
         roof["attention_block"] = {"what": "Block.forward first half, forward + backward: norm1 -> q / sr-conv / norm / kv linears -> softmax(q k^T) v -> proj -> "

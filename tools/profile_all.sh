@@ -21,6 +21,9 @@ done
 cd $R
 python profiles/summarize.py gpurun_out/prof_${TAG} gpurun_out/${TAG}_snunet_summary.md "SNUNet-ECAM bs=32 bf16 train step on THREE HIP streams (kernel durations overlap: their sum exceeds the step; single-stream durations and counters: ${TAG}_snunet_solo_summary.md)" "python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-solo" gpurun_out/${TAG}_snunet_traffic.json >> gpurun_out/prof_${TAG}.log 2>&1
 python profiles/summarize.py gpurun_out/prof_${TAG}_solo gpurun_out/${TAG}_snunet_solo_summary.md "SNUNet-ECAM bs=32 bf16 train step on ONE stream (KSMI_OVERLAP_WGRAD=0 KSMI_OVERLAP_LANES=0)" "KSMI_OVERLAP_WGRAD=0 KSMI_OVERLAP_LANES=0 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-solo" gpurun_out/${TAG}_snunet_solo_traffic.json >> gpurun_out/prof_${TAG}.log 2>&1
+# per-stage counted traffic / MFMA-busy of one single-stream step: per-dispatch PMC rows aligned with the launch table of the same plan
+KSMI_OVERLAP_WGRAD=0 KSMI_OVERLAP_LANES=0 BENCH_LAUNCH_MAP=$R/gpurun_out/${TAG}_snunet_launch_map.json python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline > /dev/null 2>> $R/gpurun_out/prof_${TAG}.log
+python profiles/stage_traffic.py gpurun_out/prof_${TAG}_solo gpurun_out/${TAG}_snunet_launch_map.json gpurun_out/${TAG}_snunet_stage_traffic.json >> gpurun_out/prof_${TAG}.log 2>&1
 for m in changeformer floodvit unet mae; do
   python profiles/summarize.py gpurun_out/prof_${TAG}_$m gpurun_out/${TAG}_${m}_summary.md "$m train step (bench.py --model $m)" "python bench.py --model $m --steps 3 --warmup 2 --no-cpu-baseline --no-solo" gpurun_out/${TAG}_${m}_traffic.json >> gpurun_out/prof_${TAG}.log 2>&1
 done
