@@ -284,7 +284,7 @@ def build_roofline(args, step, solo_timer, solo_steps, d, dominant, timer_steps,
                        "GFLOP": round(stages[t]["flops"] / solo_steps / 1e9, 1), "tflops": round(stages[t]["flops"] / max(stages[t]["ms"], 1e-9) / 1e9, 1),
                        "mfma_frac": round(stages[t]["flops"] / max(stages[t]["ms"], 1e-9) / 1e9 / MFMA_BF16_PEAK_TF, 4),
                        "mfma_busy_pct": None if not stages[t]["busy_ms"] else round(stages[t]["busy_w"] / stages[t]["busy_ms"], 1)}
-                      | ({"counted_GB": stage_pmc[t]["counted_GB"], "counted_over_all_passes": round(stage_pmc[t]["counted_GB"] / max(stages[t]["bytes"] / solo_steps / 1e9, 1e-9), 3),
+                      | ({"counted_GB": stage_pmc[t]["counted_GB"], "counted_over_all_passes": round(stage_pmc[t]["counted_GB"] / (stages[t]["bytes"] / solo_steps / 1e9), 3) if stages[t]["bytes"] else None,
                           "mfma_busy_pct": stage_pmc[t]["mfma_busy_pct"]} if t in stage_pmc else {})
                       for t in order]
     if stage_pmc_path:
