@@ -255,6 +255,9 @@ typedef struct ksmi_rowsum_desc {
   int32_t head, next;
 } ksmi_rowsum_desc;
 int ksmi_reduce_rows_batched(const ksmi_rowsum_desc* descs_device, int n, void* stream);
+/* The same launch for destinations wider than 512 columns (the 9*4C depthwise-convolution weight gradients of the MiT blocks,
+ * reference models/changeformer/ChangeFormer.py DWConv): max_c = the widest C of the table. */
+int ksmi_reduce_rows_batched_wide(const ksmi_rowsum_desc* descs_device, int n, int max_c, void* stream);
 /* pass 2: g = dout*(out>0) -> dout (in place); dz = gamma*rstd*(g - s0/n - zhat*s1/n) */
 int ksmi_bnrelu_bwd_apply(void* dout_g, const void* out, const void* z, const float* mean, const float* rstd,
                           const float* gamma, const float* sums, void* dz, double count,

@@ -122,6 +122,7 @@ SIGNATURES = {
     "ksmi_bnrelu_bwd_reduce": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp]),
     "ksmi_reduce_rows": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp]),
     "ksmi_reduce_rows_batched": (_i, [_vp, _i, _vp]),
+    "ksmi_reduce_rows_batched_wide": (_i, [_vp, _i, _i, _vp]),
     "ksmi_bnrelu_bwd_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _i64, _i, _i, _vp]),
     "ksmi_bn_bwd_apply_gated": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _i64, _i, _i, _vp]),
     "ksmi_bn_bwd_apply_add": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _d, _i64, _i, _i, _vp]),

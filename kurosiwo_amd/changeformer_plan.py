@@ -361,12 +361,10 @@ class ChangeFormerPlan(PlanBase):
         self.keep.append(gview)
         self._wgrad(dw, ws, wk)
         rr = max(1, min(512, B * HW // 256))
-        self.need("red", rr * CSB * 4)
-        accb = self._acc_param(bk)
-        gb = m._g(bk).data_ptr()
-        self.bwd.add("ksmi_channel_sum", lambda: (dP.data_ptr(), self.scr("red"), rr, B * HW, CSB, dt), self._elt_meta("channel_sum", B * HW * CSB))
-        self.bwd.add("ksmi_reduce_rows", lambda: (self.scr("red"), rr, 1, CSB, nc, None, None, gb, accb))
-        self._mark(bk)
+        slot = self._rs_slot(rr * CSB * 4)
+        self.bwd.add("ksmi_channel_sum", lambda: (dP.data_ptr(), self.scr(slot), rr, B * HW, CSB, dt), self._elt_meta("channel_sum", B * HW * CSB))
+        self._defer_rowsum(bk, slot, 0, rr, 1, 0, CSB, nc)
+        self._rs_tick()
         # dense_1x, convd1x, dense_2x, convd2x
         self._res_block_bwd("dense_1x.0", dec["X1"], dec["Rb"], dY1, 4 * H1, 4 * W1)            # dY1 now holds dX1
         self._deconv_bwd("convd1x", dec["Y2"], E, E, 2 * H1, 2 * W1, dY1, E, dY2, prefix=f"{D}.", suffix=".conv2d")
@@ -491,16 +489,14 @@ class ChangeFormerPlan(PlanBase):
             self.bwd.add("ksmi_dwconv3x3_backward_input", lambda du=du, wd=wd: (t4.data_ptr(), wd, du.data_ptr(), B2, Hs, Ws, 4 * Cc, dt),
                          self._elt_meta("dwconv_bwd", 2 * R * 4 * Cc))
             rows = max(1, min(1024 // max(1, -(-(4 * Cc // (8 if self.dtype == torch.bfloat16 else 4)) // 64)), R // 16))
-            self.need("dwp", rows * 10 * 4 * Cc * 4)
             kw, kb = f"{k}.mlp.dwconv.dwconv.weight", f"{k}.mlp.dwconv.dwconv.bias"
-            gw, gb = m._g(kw).data_ptr(), m._g(kb).data_ptr()
-            aw, ab = self._acc_param(kw), self._acc_param(kb)
             C4 = 4 * Cc
-            self.bwd.add("ksmi_dwconv3x3_wgrad", lambda u=rec["u"], rows=rows: (u.data_ptr(), t4.data_ptr(), self.scr("dwp"), rows, B2, Hs, Ws, C4, dt),
+            slot = self._rs_slot(rows * 10 * C4 * 4)
+            self.bwd.add("ksmi_dwconv3x3_wgrad", lambda u=rec["u"], rows=rows, slot=slot: (u.data_ptr(), t4.data_ptr(), self.scr(slot), rows, B2, Hs, Ws, C4, dt),
                          self._elt_meta("dwconv_wgrad", 2 * R * C4))
-            self.bwd.add("ksmi_reduce_rows", lambda rows=rows, gw=gw, aw=aw: (self.scr("dwp"), rows, 1, 10 * C4, 9 * C4, None, None, gw, aw))
-            self.bwd.add("ksmi_reduce_rows", lambda rows=rows, gb=gb, ab=ab: (self.scr("dwp") + 9 * C4 * 4, rows, 1, 10 * C4, C4, None, None, gb, ab))
-            self._mark(kw, kb)
+            self._defer_rowsum(kw, slot, 0, rows, 1, 0, 10 * C4, 9 * C4)           # partial rows [rows][9*C4 | C4]
+            self._defer_rowsum(kb, slot, 9 * C4 * 4, rows, 1, 0, 10 * C4, C4)
+            self._rs_tick()
             self._linear_bwd(f"{k}.fc1", rec["h2"], Cc, f"{k}.mlp.fc1.weight", f"{k}.mlp.fc1.bias", du, 4 * Cc, R, tC)
             self._ln_bwd(tC, rec["t_mid"], rec["st2"], f"{k}.norm2.weight", f"{k}.norm2.bias", gt, 1, R, Cc)
             # Attention

@@ -829,6 +829,12 @@ int ksmi_reduce_rows_batched(const ksmi_rowsum_desc* descs_device, int n, void* 
   return ksmi_check_launch("reduce_rows_batched");
 }
 
+int ksmi_reduce_rows_batched_wide(const ksmi_rowsum_desc* descs_device, int n, int max_c, void* stream) {
+  if (!descs_device || n < 1 || max_c < 1 || (max_c + 15) / 16 > 65535) return ksmi_fail(KSMI_E_ARG, "reduce_rows_batched_wide: bad args");
+  hipLaunchKernelGGL(reduce_rows_batched_kernel, dim3(n, (max_c + 15) / 16), dim3(256), 0, (hipStream_t)stream, descs_device);
+  return ksmi_check_launch("reduce_rows_batched_wide");
+}
+
 int ksmi_bn_add_relu(const void* z, const void* identity, const float* scale, const float* shift, void* out, int64_t npix,
                      int C, int dtype, void* stream) {
   if (!chan_ok(C, dtype)) return ksmi_fail(KSMI_E_ARG, "bn_add_relu: C must be a multiple of the 16-byte vector");

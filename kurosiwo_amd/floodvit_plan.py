@@ -161,11 +161,10 @@ class FloodViTPlan(PlanBase):
                             self.dtype)
         self._wgrad(dw, ws, wkey)
         r = max(1, min(512, rows // 256))
-        self.need("red", r * dyC * 4)
-        acc, gb = self._acc_param(bkey), self.m._g(bkey).data_ptr()
-        self.bwd.add("ksmi_channel_sum", lambda: (dy.data_ptr(), self.scr("red"), r, rows, dyC, self.dt), self._elt_meta("channel_sum", rows * dyC))
-        self.bwd.add("ksmi_reduce_rows", lambda: (self.scr("red"), r, 1, dyC, N, None, None, gb, acc))
-        self._mark(bkey)
+        slot = self._rs_slot(r * dyC * 4)
+        self.bwd.add("ksmi_channel_sum", lambda: (dy.data_ptr(), self.scr(slot), r, rows, dyC, self.dt), self._elt_meta("channel_sum", rows * dyC))
+        self._defer_rowsum(bkey, slot, 0, r, 1, 0, dyC, N)
+        self._rs_tick()
 
     def _head_linear(self, F, L, dL, dF):
         """default head: nn.Upsample(224^2, bilinear) then Conv1x1(1024 -> classes) (model_utilities.py:70-72,88-93).  A 1x1 convolution

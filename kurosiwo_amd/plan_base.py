@@ -31,6 +31,9 @@ class PlanBase:
         self.param_ready = {}
         self.named = {}            # debug/test access to intermediate activations
         self._need, self._bufs, self._later = {}, {}, []
+        # deferred row reductions (LayerNorm dgamma / dbeta, long-axis bias and depthwise weight gradients): one batched launch per
+        # `rowsum_batch` producer launches instead of one tiny launch each (single-stream plans pay every launch in full)
+        self._rs_entries, self._rs_slots = [], 0
         # bf16 mirror of the parameter arena for the token GEMMs (gemm.hip): one cast launch per step
         import os
         self.wb = None
@@ -44,7 +47,10 @@ class PlanBase:
     def _wb_ptr(self, key):
         return self.wb.data_ptr() + 2 * self.m._poff[key]
 
+    rowsum_batch = max(1, int(__import__("os").environ.get("KSMI_ROWSUM_BATCH", "16")))
+
     def _finish(self):
+        self._flush_rowsums()
         if self._pack_descs:
             n = len(self._pack_descs)
             arr = (_lib.PackDesc * n)(*self._pack_descs)
@@ -84,7 +90,9 @@ class PlanBase:
     def _es(self):
         return 2 if self.dtype == torch.bfloat16 else 4
 
-    def _acc_param(self, key):
+    def _acc_param(self, key, deferred=False):
+        if not deferred and any(e["key"] == key for e in self._rs_entries):
+            self._flush_rowsums()                          # a direct writer behind a deferred one: the deferred sum lands first
         acc = 1 if key in self._pinit else 0
         self._pinit.add(key)
         return acc
@@ -92,6 +100,49 @@ class PlanBase:
     def _mark(self, *keys):
         for k in keys:
             self.param_ready[k] = len(self.bwd.pending) - 1
+
+    def _rs_slot(self, nbytes):
+        """scratch of the next deferred row reduction's partial rows; recycled after the batched launch that consumes it"""
+        name = f"rs{self._rs_slots}"
+        self._rs_slots += 1
+        self.need(name, nbytes)
+        return name
+
+    def _defer_rowsum(self, key, slot, off, rows, K, k, Cstride, Cc):
+        """grad[key][c] (+)= sum_r partial[(r*K + k)*Cstride + c], partial = scratch `slot` + off bytes (written by the launch just
+        appended to self.bwd), in the next batched reduction.  Entries of one key inside a batch chain behind the first."""
+        acc = self._acc_param(key, deferred=True)
+        prev = [i for i, e in enumerate(self._rs_entries) if e["key"] == key]
+        self._rs_entries.append(dict(key=key, slot=slot, off=off, rows=rows, K=K, k=k, Cstride=Cstride, C=Cc,
+                                     accumulate=0 if prev else acc, head=0 if prev else 1, next=-1))
+        if prev:
+            self._rs_entries[prev[-1]]["next"] = len(self._rs_entries) - 1
+
+    def _rs_tick(self):
+        if self._rs_slots >= self.rowsum_batch:
+            self._flush_rowsums()
+
+    def _flush_rowsums(self):
+        ents, self._rs_entries, self._rs_slots = self._rs_entries, [], 0
+        if not ents:
+            return
+        n, max_c = len(ents), max(e["C"] for e in ents)
+        holder = {}
+
+        def build():
+            arr = (_lib.RowsumDesc * n)()
+            for r, e in zip(arr, ents):
+                r.partial, r.dst = self.scr(e["slot"]) + e["off"], self.m._g(e["key"]).data_ptr()
+                r.rows, r.K, r.k, r.Cstride, r.C = e["rows"], e["K"], e["k"], e["Cstride"], e["C"]
+                r.accumulate, r.head, r.next = e["accumulate"], e["head"], e["next"]
+            raw = bytes(C.string_at(C.addressof(arr), C.sizeof(arr)))
+            holder["t"] = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.dev)
+            self.keep.append(holder["t"])
+        self._later.append(build)
+        nbytes = sum(e["rows"] * e["C"] * 4 for e in ents)
+        self.bwd.add("ksmi_reduce_rows_batched_wide", lambda: (holder["t"].data_ptr(), n, max_c),
+                     {"kind": "reduce_rows", "bytes": nbytes, "flops": 0})
+        self._mark(*[e["key"] for e in ents])
 
     def _packed(self, key, table, taps, N, n_mod, sK, sN, sD, sT, flip=0, tap_map=None):
         Npad = (N + 15) // 16 * 16
@@ -161,13 +212,11 @@ class PlanBase:
             self._mark(bkey)
             return
         r = max(1, min(512, rows // 64))                   # (256 would save the fold launch but halves the streaming kernel's grid: slower)
-        self.need("red", r * N * 4)
-        acc = self._acc_param(bkey)
-        gb = self.m._g(bkey).data_ptr()
-        self.bwd.add("ksmi_channel_sum", lambda: (dy.data_ptr(), self.scr("red"), r, rows, N, self.dt),
+        slot = self._rs_slot(r * N * 4)
+        self.bwd.add("ksmi_channel_sum", lambda: (dy.data_ptr(), self.scr(slot), r, rows, N, self.dt),
                      self._elt_meta("channel_sum", rows * N))
-        self.bwd.add("ksmi_reduce_rows", lambda: (self.scr("red"), r, 1, N, N, None, None, gb, acc))
-        self._mark(bkey)
+        self._defer_rowsum(bkey, slot, 0, r, 1, 0, N, N)
+        self._rs_tick()
 
     def _linear_bwd(self, name, x, Cin, wkey, bkey, dy, N, rows, dx, want_w=True, dx_acc=0, k_real=None, side_tag=None, wait_tag=None):
         """dx (+)= dy @ W (skipped if dx is None) ; dW = dy^T x ; db = colsum(dy).
@@ -223,17 +272,19 @@ class PlanBase:
 
     def _ln_bwd(self, dy, x, st, wkey, bkey, dx, accumulate, rows, Cc, want_w=True):
         nblk = self.lib.ksmi_layernorm_bwd_blocks(rows)
-        self.need("lnp", nblk * 2 * Cc * 4)
+        if want_w:
+            slot = self._rs_slot(nblk * 2 * Cc * 4)
+        else:
+            slot = "lnp"
+            self.need("lnp", nblk * 2 * Cc * 4)
         g = self.m._p(wkey).data_ptr()
         self.bwd.add("ksmi_layernorm_backward", lambda: (dy.data_ptr(), x.data_ptr(), st[0].data_ptr(), st[1].data_ptr(), g,
-                                                         dx.data_ptr(), accumulate, self.scr("lnp"), rows, Cc, self.dt),
+                                                         dx.data_ptr(), accumulate, self.scr(slot), rows, Cc, self.dt),
                      self._elt_meta("layernorm_bwd", (3 + accumulate) * rows * Cc))
-        if want_w:
-            a1, a2 = self._acc_param(wkey), self._acc_param(bkey)
-            assert a1 == a2
-            gw, gb = self.m._g(wkey).data_ptr(), self.m._g(bkey).data_ptr()
-            self.bwd.add("ksmi_reduce_rows", lambda: (self.scr("lnp"), nblk, 2, Cc, Cc, None, gw, gb, a1))
-            self._mark(wkey, bkey)
+        if want_w:                                       # partial rows [nblk][2][C]: k = 0 -> dbeta, k = 1 -> dgamma
+            self._defer_rowsum(bkey, slot, 0, nblk, 2, 0, Cc, Cc)
+            self._defer_rowsum(wkey, slot, 0, nblk, 2, 1, Cc, Cc)
+            self._rs_tick()
 
     # ---------------------------------------------------------------- pre-norm transformer layers
     def _transformer_layers(self, X, depth, prefix, B, Ntok, D, heads, dim_head, M, gx, bwd_steps, tag="L"):
@@ -378,11 +429,9 @@ class PlanBase:
         # bias gradient over the real channels only
         rows = B * 4 * H * W
         r = max(1, min(512, rows // 256))
-        self.need("red", r * doutC * 4)
-        acc = self._acc_param(bkey)
-        gb = self.m._g(bkey).data_ptr()
-        self.bwd.add("ksmi_channel_sum", lambda: (dout.data_ptr(), self.scr("red"), r, rows, doutC, self.dt),
+        slot = self._rs_slot(r * doutC * 4)
+        self.bwd.add("ksmi_channel_sum", lambda: (dout.data_ptr(), self.scr(slot), r, rows, doutC, self.dt),
                      self._elt_meta("channel_sum", rows * doutC))
-        self.bwd.add("ksmi_reduce_rows", lambda: (self.scr("red"), r, 1, doutC, N, None, None, gb, acc))
-        self._mark(bkey)
+        self._defer_rowsum(bkey, slot, 0, r, 1, 0, doutC, N)
+        self._rs_tick()
 
