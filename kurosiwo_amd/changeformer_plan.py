@@ -34,6 +34,9 @@ def drop_threshold(p):
 
 class ChangeFormerPlan(PlanBase):
     input_names = ("x1", "x2")
+    # the encoder's nn.Linear / sr-conv weight gradients on the train step's side stream (plan_base.PlanBase.side_tokens; waits in
+    # _encoder_stage_bwd).  KSMI_CF_SIDE_TOKENS=0: the single-stream list.
+    side_tokens = __import__("os").environ.get("KSMI_CF_SIDE_TOKENS", "1") != "0"
 
     def __init__(self, model, B, H, W, dtype, training, with_backward):
         self._init_base(model, dtype, with_backward)
@@ -470,16 +473,29 @@ class ChangeFormerPlan(PlanBase):
         self.need("attn", ws_attn)
         N = Hs * Ws
         tD = self.buf(R, Cc) if self.stochastic else None           # gradient of a branch output behind Dropout / DropPath
+        # Side-stream weight gradients (side_tokens): fc2 / fc1 / proj / kv / sr / q of a block may run next to the rest of its
+        # backward pass.  Their operands are either per-block forward activations (live until the next forward) or the stage buffers
+        # tD / tDa / tq / tkv / dxr, which the NEXT block overwrites: a tagged wait stands before each of those writes.  A gradient
+        # whose dY is gt itself (block without Dropout / DropPath: gt is accumulated into further down the block) stays in line.
+        S = self.side_tokens
+        tDa = self.buf(R, Cc) if (self.stochastic and S) else tD    # own buffer for the attention branch: proj's dY outlives the Mlp's
+        dxr_s = self.buf(Rk, Cc) if S else None
+        dh_s = self.buf(R, Cc) if S else None
+        prev = None
         for rec in reversed(ft["blocks"]):
             k, gi = rec["k"], rec["gi"]
             active = self._branch_active(gi)
+            sd = S and active
             # Mlp
             self._stage("mlp_block")
             gy = gt
             if active:
+                if S and prev:
+                    self.bwd.add_wait_side(f"{prev}.fc2")
                 self._drop(self.bwd, gt, None, tD, R, Cc, N, self._site(gi, SITE_MLP2, self.p_drop), self._site(gi, SITE_PATH_MLP, self.dpr[gi]))
                 gy = tD
-            self._linear_bwd(f"{k}.fc2", rec["g"], 4 * Cc, f"{k}.mlp.fc2.weight", f"{k}.mlp.fc2.bias", gy, Cc, R, t4)
+            self._linear_bwd(f"{k}.fc2", rec["g"], 4 * Cc, f"{k}.mlp.fc2.weight", f"{k}.mlp.fc2.bias", gy, Cc, R, t4,
+                             side_tag=f"{k}.fc2" if sd else None)
             if active and self.p_drop > 0:
                 self._drop(self.bwd, t4, None, t4, R, 4 * Cc, N, self._site(gi, SITE_MLP1, self.p_drop), NO_SITE)
             self.bwd.add("ksmi_gelu_backward", lambda z=rec["z"]: (t4.data_ptr(), z.data_ptr(), t4.data_ptr(), R * 4 * Cc, dt),
@@ -497,40 +513,56 @@ class ChangeFormerPlan(PlanBase):
             self._defer_rowsum(kw, slot, 0, rows, 1, 0, 10 * C4, 9 * C4)           # partial rows [rows][9*C4 | C4]
             self._defer_rowsum(kb, slot, 9 * C4 * 4, rows, 1, 0, 10 * C4, C4)
             self._rs_tick()
-            self._linear_bwd(f"{k}.fc1", rec["h2"], Cc, f"{k}.mlp.fc1.weight", f"{k}.mlp.fc1.bias", du, 4 * Cc, R, tC)
+            self._linear_bwd(f"{k}.fc1", rec["h2"], Cc, f"{k}.mlp.fc1.weight", f"{k}.mlp.fc1.bias", du, 4 * Cc, R, tC,
+                             side_tag=f"{k}.fc1" if S else None)       # h2 and z belong to this block: nothing overwrites them (dh_s below)
             self._ln_bwd(tC, rec["t_mid"], rec["st2"], f"{k}.norm2.weight", f"{k}.norm2.bias", gt, 1, R, Cc)
             # Attention
             self._stage("attention_block")
             gy = gt
             if active:
-                self._drop(self.bwd, gt, None, tD, R, Cc, N, self._site(gi, SITE_PROJ, self.p_drop), self._site(gi, SITE_PATH_ATTN, self.dpr[gi]))
-                gy = tD
-            self._linear_bwd(f"{k}.proj", rec["att"], Cc, f"{k}.attn.proj.weight", f"{k}.attn.proj.bias", gy, Cc, R, tC)
+                if S and prev:
+                    self.bwd.add_wait_side(f"{prev}.proj")
+                self._drop(self.bwd, gt, None, tDa, R, Cc, N, self._site(gi, SITE_PROJ, self.p_drop), self._site(gi, SITE_PATH_ATTN, self.dpr[gi]))
+                gy = tDa
+            self._linear_bwd(f"{k}.proj", rec["att"], Cc, f"{k}.attn.proj.weight", f"{k}.attn.proj.bias", gy, Cc, R, tC,
+                             side_tag=f"{k}.proj" if sd else None)
             ad = self._site(gi, SITE_ATTN, self.p_attn)
+            if S and prev:                                        # tq / tkv are rewritten by the attention backward below
+                self.bwd.add_wait_side(f"{prev}.q")
+                self.bwd.add_wait_side(f"{prev}.kv")
             self.bwd.add("ksmi_sr_attention_backward_drop", lambda q=rec["q"], kv=rec["kv"], att=rec["att"], scale=rec["scale"], ad=ad: (
                 q.data_ptr(), kv.data_ptr(), att.data_ptr(), tC.data_ptr(), tq.data_ptr(), tkv.data_ptr(), self.scr("attn"), B2, Hs * Ws, 49, heads, Cc, scale,
                 ad[0], ad[1], ad[2], self.rng_ptr, dt),
                 {"kind": "sr_attention_bwd", "bytes": (6 * R * Cc + 4 * Rk * Cc) * self._es(), "flops": 5 * rec["aflops"] // 2})
-            dh = self.buf(R, Cc) if False else rec["h2"]         # h2 is dead here (fc1 wgrad done): reuse as d(norm1 output)
+            dh = dh_s if S else rec["h2"]                         # single stream: h2 is dead here (fc1 wgrad done), reuse as d(norm1 output)
             if sr > 1:
                 Ksr = rec["Ksr"]
-                self._linear_bwd(f"{k}.kv", rec["xn"], Cc, f"{k}.attn.kv.weight", f"{k}.attn.kv.bias", tkv, 2 * Cc, Rk, tk)
-                dxr = rec["xn"]                                   # xn is dead after the kv weight gradient
+                self._linear_bwd(f"{k}.kv", rec["xn"], Cc, f"{k}.attn.kv.weight", f"{k}.attn.kv.bias", tkv, 2 * Cc, Rk, tk,
+                                 side_tag=f"{k}.kv" if S else None)
+                dxr = dxr_s if S else rec["xn"]                   # single stream: xn is dead after the kv weight gradient
+                if S and prev:
+                    self.bwd.add_wait_side(f"{prev}.sr")
                 self._ln_bwd(tk, rec["xr"], rec["st_sr"], f"{k}.attn.norm.weight", f"{k}.attn.norm.bias", dxr, 0, Rk, Cc)
                 dcol2 = self.buf(Rk, Ksr)
                 if "sr_wtc" in rec:
-                    self._linear_tc_bwd(f"{k}.sr", rec["col2"], Ksr, f"{k}.attn.sr.weight", f"{k}.attn.sr.bias", dxr, Cc, Rk, dcol2, rec["sr_wtc"], Cc, sr * sr)
+                    self._linear_tc_bwd(f"{k}.sr", rec["col2"], Ksr, f"{k}.attn.sr.weight", f"{k}.attn.sr.bias", dxr, Cc, Rk, dcol2, rec["sr_wtc"], Cc, sr * sr,
+                                        side_tag=f"{k}.sr" if S else None)
                     self.bwd.add("ksmi_col2im_tc", lambda dcol2=dcol2, dh=dh, Ksr=Ksr: (dcol2.data_ptr(), dh.data_ptr(), 0, B2, Cc, Hs, Ws, Hs // sr, Ws // sr,
                                                                                          sr, sr, sr, 0, Ksr, dt), self._elt_meta("col2im", 2 * Rk * Ksr))
                 else:
-                    self._linear_bwd(f"{k}.sr", rec["col2"], Ksr, f"{k}.attn.sr.weight", f"{k}.attn.sr.bias", dxr, Cc, Rk, dcol2)
+                    self._linear_bwd(f"{k}.sr", rec["col2"], Ksr, f"{k}.attn.sr.weight", f"{k}.attn.sr.bias", dxr, Cc, Rk, dcol2,
+                                     side_tag=f"{k}.sr" if S else None)
                     self.bwd.add("ksmi_col2im", lambda dcol2=dcol2, dh=dh, Ksr=Ksr: (dcol2.data_ptr(), dh.data_ptr(), 0, B2, Cc, Hs, Ws, Hs // sr, Ws // sr,
                                                                                       sr, sr, sr, 0, Ksr, dt), self._elt_meta("col2im", 2 * Rk * Ksr))
-                self._linear_bwd(f"{k}.q", rec["h"], Cc, f"{k}.attn.q.weight", f"{k}.attn.q.bias", tq, Cc, R, dh, dx_acc=1)
+                self._linear_bwd(f"{k}.q", rec["h"], Cc, f"{k}.attn.q.weight", f"{k}.attn.q.bias", tq, Cc, R, dh, dx_acc=1,
+                                 side_tag=f"{k}.q" if S else None)
             else:
-                self._linear_bwd(f"{k}.kv", rec["xn"], Cc, f"{k}.attn.kv.weight", f"{k}.attn.kv.bias", tkv, 2 * Cc, Rk, dh)
-                self._linear_bwd(f"{k}.q", rec["h"], Cc, f"{k}.attn.q.weight", f"{k}.attn.q.bias", tq, Cc, R, dh, dx_acc=1)
+                self._linear_bwd(f"{k}.kv", rec["xn"], Cc, f"{k}.attn.kv.weight", f"{k}.attn.kv.bias", tkv, 2 * Cc, Rk, dh,
+                                 side_tag=f"{k}.kv" if S else None)
+                self._linear_bwd(f"{k}.q", rec["h"], Cc, f"{k}.attn.q.weight", f"{k}.attn.q.bias", tq, Cc, R, dh, dx_acc=1,
+                                 side_tag=f"{k}.q" if S else None)
             self._ln_bwd(dh, rec["t_in"], rec["st1"], f"{k}.norm1.weight", f"{k}.norm1.bias", gt, 1, R, Cc)
+            prev = k
         # patch embedding
         self._stage("patch_embed")
         pe = ft["pe"]
@@ -566,17 +598,20 @@ class ChangeFormerPlan(PlanBase):
         self.fwd.add("ksmi_gemm_nt", lambda: (col.data_ptr(), Kpad, wtc.data_ptr(), Kpad, bp, None, N, out.data_ptr(), N, rows, Kpad, N), meta)
         return wtc
 
-    def _linear_tc_bwd(self, name, col, Kpad, wkey, bkey, dy, N, rows, dcol, wtc, Cin, taps):
+    def _linear_tc_bwd(self, name, col, Kpad, wkey, bkey, dy, N, rows, dcol, wtc, Cin, taps, side_tag=None):
         if dcol is not None:
             meta = {"kind": "gemm_nn", "bytes": (rows * N + rows * Kpad + N * Kpad) * 2, "flops": 2 * rows * N * Kpad, "tag": f"{name} K={N} N={Kpad} M={rows}"}
             self.bwd.add("ksmi_gemm_nn", lambda: (dy.data_ptr(), N, wtc.data_ptr(), Kpad, dcol.data_ptr(), Kpad, rows, Kpad, N, 0), meta)
         gtc = torch.empty((N, Kpad), dtype=torch.float32, device=self.dev)
         self.keep.append(gtc)
         dw, ws = make_wgrad([SrcSpec(col, Kpad)], dy, N, 0, N, gtc, 1, Kpad, 0, 0, 1, rows, 1, rows, 1, 1, 1, 1, 0, self.dtype)
-        self._wgrad(dw, ws, wkey)
+        self._wgrad(dw, ws, wkey, None if side_tag is None else side_tag + ".tc")
         acc = self._acc_param(wkey)
         g = self.m._g(wkey).data_ptr()
-        self.bwd.add("ksmi_grad_from_tc", lambda: (gtc.data_ptr(), g, N, Cin, taps, Kpad, acc), {"kind": "grad_from_tc", "bytes": 8 * N * Kpad, "flops": 0})
+        meta = {"kind": "grad_from_tc", "bytes": 8 * N * Kpad, "flops": 0}
+        if side_tag is not None:                     # behind its GEMM on the side stream; the tag marks the pair's end
+            meta |= {"side": True, "side_tag": side_tag}
+        self.bwd.add("ksmi_grad_from_tc", lambda: (gtc.data_ptr(), g, N, Cin, taps, Kpad, acc), meta)
         self._mark(wkey)
         if bkey:
             self._bias_grad(dy, rows, N, bkey)

@@ -19,6 +19,7 @@ from .unet import DECODER_CHANNELS, LAYERS
 class UnetPlan(ChangeFormerPlan):
     input_names = ("x",)
 
+    side_tokens = False        # (ChangeFormerPlan's encoder switch: no MiT encoder here)
     side_wgrad = True          # plan_base.PlanBase.side_wgrad: dedicated buffers throughout (self.buf), conv weight gradients only
 
     def __init__(self, model, B, H, W, dtype, training, with_backward):

@@ -90,13 +90,17 @@ def _lane_case(family, B, S, overlap, graph):
         enc = ViT(image_size=S, patch_size=16, num_classes=1000, dim=1024, depth=6, heads=16, mlp_dim=2048, channels=2)
         m = FinetunerSegmentation(enc, {"decoder": True, "num_classes": 3}, precision="bf16").cuda().train()
         return m, SegTrainStep(m, B, "cross_entropy", (1.0, 2.0, 3.0), **kw)
+    if family == "changeformer":        # MiT encoder: tagged side-stream gradients of every block's linears (changeformer_plan._encoder_stage_bwd)
+        from kurosiwo_amd.changeformer import ChangeFormerV6
+        m = ChangeFormerV6(input_nc=2, output_nc=3, decoder_softmax=True, embed_dim=256, precision="bf16").cuda().train()
+        return m, CDTrainStep(m, B, S, S, "ce+dice", (1.0, 2.0, 3.0), **kw)
     from kurosiwo_amd.unet import Unet
     m = Unet("resnet18", encoder_weights=None, in_channels=2, classes=3, precision="bf16").cuda().train()
     return m, SegTrainStep(m, B, "cross_entropy", (1.0, 2.0, 3.0), image_size=(S, S), **kw)
 
 
 @pytest.mark.parametrize("family,graph", [("snunet", False), ("snunet", True), ("bitcd", False), ("unet", False), ("unet", True),
-                                          ("floodvit", False), ("floodvit", True)])
+                                          ("floodvit", False), ("floodvit", True), ("changeformer", False), ("changeformer", True)])
 def test_side_lane_equals_single_stream(family, graph):
     """trainer.py overlap_wgrad / overlap_lanes: the weight-gradient launches run on a side stream and SNUNet's deeper decoder blocks on a
     second compute lane (snunet_plan.StepStreams); every kernel is deterministic, so a missing dependency edge would show up as a
@@ -120,6 +124,9 @@ def test_side_lane_equals_single_stream(family, graph):
                 tags = [meta["side_tag"] for _, _, _, meta in st.plan.bwd.calls if meta.get("side_tag")]
                 waits = [args[0] for fn, args, name, _ in st.plan.bwd.calls if name == "@wait_side"]
                 assert len(tags) == 4 * 6 and set(waits) - {None} <= set(tags) and len([w for w in waits if w]) == 2 * 6 + 2 * 5
+            if family == "changeformer":
+                tags = [meta["side_tag"] for _, _, _, meta in st.plan.bwd.calls if meta.get("side_tag")]
+                assert len([t for t in tags if t.endswith((".fc1", ".q", ".kv"))]) == 3 * 13, tags     # depths 3 + 3 + 4 + 3
             if family == "snunet":
                 assert st._ss.lanes and any(meta["lane"] == 1 for _, _, _, meta in st.plan.fwd.calls + st.plan.bwd.calls)
         out.append((losses, m.flat_params.clone(), m.flat_grads.clone()))

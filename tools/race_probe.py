@@ -1,4 +1,4 @@
-"""Repeat the single-stream vs side-stream comparison of a token train step: python tools/race_probe.py mae|floodvit [repeats] [delay] [nowait]
+"""Repeat the single-stream vs side-stream comparison of a token train step: python tools/race_probe.py mae|floodvit|changeformer [repeats] [delay] [nowait]
 delay: every step first parks the side stream behind a ~10 ms spin kernel and every side-stream launch behind a ~150 us one, so the
 main stream runs as far ahead of each weight gradient as its waits allow -- a missing wait then shows up as a different trajectory
 instead of depending on launch timing."""
@@ -46,6 +46,13 @@ def run(overlap, data):
         st = MAETrainStep(model, 32, lr=1e-4)
         go = stepper(st)
         losses = [go(x.cuda(), idx.cuda()) for x, idx, _ in data]
+    elif fam == "changeformer":
+        from kurosiwo_amd.changeformer import ChangeFormerV6
+        from kurosiwo_amd.trainer import CDTrainStep
+        model = ChangeFormerV6(input_nc=2, output_nc=3, decoder_softmax=True, embed_dim=256, precision="bf16").cuda().train()
+        st = CDTrainStep(model, 4, 224, 224, "ce+dice", (1.0, 2.0, 3.0), lr=1e-3)
+        go = stepper(st)
+        losses = [go(x[:4].cuda(), x[4:8].cuda(), y[:4].cuda()) for x, _, y in data]
     else:
         from kurosiwo_amd.floodvit import FinetunerSegmentation, ViT
         from kurosiwo_amd.trainer import SegTrainStep
