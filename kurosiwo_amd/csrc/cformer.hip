@@ -224,6 +224,179 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const T* x, const float*
   }
 }
 
+// Row-walking form of the two kernels around this comment (the default; KSMI_DW_ROW=0 selects the per-pixel forms).  A thread owns
+// (channel vector, row segment of `seg` pixels) and slides a 3x3 window along the row: 3 new 16-byte loads per output instead of 9,
+// the window and the 9 x VEC tap weights in registers, the loads of the next two columns in flight.  The per-pixel forms
+// spend their time in the VALU (9 unpacks + 9 address computations per output vector): 1.6 TB/s on the stage-1 map of the MiT
+// encoder (models/changeformer.py:85-96 DWConv inside Mlp :119-133).  Same tap order and fp32 operations as dwconv3x3_kernel
+// (out-of-image taps contribute +0 instead of being skipped), so both forms give the same bits.
+template <typename T>
+struct DwCol {                                                  // one window column: three rows of one pixel, raw 16-byte vectors
+  u32x4 r[3];
+};
+template <typename T>
+__device__ __forceinline__ DwCol<T> dw_load_col(const T* const* rp, const bool* rv, int ix, int W, int C) {
+  DwCol<T> c;
+  const bool in = ix >= 0 && ix < W;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) c.r[d] = (in && rv[d]) ? *(const u32x4*)(rp[d] + (int64_t)ix * C) : (u32x4){0u, 0u, 0u, 0u};
+  return c;
+}
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void dwconv3x3_row_kernel(const T* x, const float* w, const float* bias, T* z, T* g, int B, int H, int W, int C,
+                                                            int seg, int nseg, int64_t units) {
+  constexpr int VEC = ElemTraits<T>::kVec;
+  const int CV = C / VEC;
+  const int cv = blockIdx.y * 32 + (threadIdx.x & 31), pl = threadIdx.x >> 5;
+  if (cv >= CV) return;
+  const int c0 = cv * VEC;
+  // consecutive units are neighbouring rows of one image (shared halo rows): keep them on ONE XCD (gridDim.x is a multiple of 8)
+  const int64_t u = ((int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) * 8 + pl;
+  if (u >= units) return;
+  float wr[9][VEC], br[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    br[j] = (MODE == 0 && bias) ? bias[c0 + j] : 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wr[t][j] = w[(c0 + j) * 9 + (MODE == 0 ? t : 8 - t)];
+  }
+  const int sgi = (int)(u % nseg);
+  const int64_t row = u / nseg;                                 // b * H + y
+  const int y = (int)(row % H);
+  const int x0 = sgi * seg, x1 = min(W, x0 + seg);
+  const T* rp[3]; bool rv[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) { rv[d] = y + d - 1 >= 0 && y + d - 1 < H; rp[d] = x + (row + d - 1) * (int64_t)W * C + c0; }
+  float win[3][3][VEC];                                         // [column slot][row][channel]
+  {
+    const DwCol<T> a = dw_load_col<T>(rp, rv, x0 - 1, W, C), b = dw_load_col<T>(rp, rv, x0, W, C);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { vec_unpack<T>(a.r[d], win[0][d]); vec_unpack<T>(b.r[d], win[1][d]); }
+  }
+  DwCol<T> nxt[2] = {dw_load_col<T>(rp, rv, x0 + 1, W, C), dw_load_col<T>(rp, rv, x0 + 2, W, C)};     // two columns in flight
+  T* zo = z + (row * W) * (int64_t)C + c0;
+  T* go = MODE == 0 ? g + (row * W) * (int64_t)C + c0 : nullptr;
+  // slot roles rotate with the pixel: (left, mid, right) = (k, k+1, k+2) mod 3, prefetch slot k mod 2 -- unrolled by 6 so that
+  // the indices are constants
+#define KSMI_DW_STEP(L, M, R_, A)                                                                                \
+  if (px < x1) {                                                                                                 \
+    _Pragma("unroll") for (int d = 0; d < 3; ++d) vec_unpack<T>(nxt[A].r[d], win[R_][d]);                        \
+    nxt[A] = dw_load_col<T>(rp, rv, px + 3, W, C);                                                               \
+    float acc[VEC];                                                                                              \
+    _Pragma("unroll") for (int j = 0; j < VEC; ++j) acc[j] = br[j];                                              \
+    _Pragma("unroll") for (int d = 0; d < 3; ++d) {                                                              \
+      _Pragma("unroll") for (int j = 0; j < VEC; ++j) acc[j] += win[L][d][j] * wr[d * 3 + 0][j];                 \
+      _Pragma("unroll") for (int j = 0; j < VEC; ++j) acc[j] += win[M][d][j] * wr[d * 3 + 1][j];                 \
+      _Pragma("unroll") for (int j = 0; j < VEC; ++j) acc[j] += win[R_][d][j] * wr[d * 3 + 2][j];                \
+    }                                                                                                            \
+    *(u32x4*)(zo + (int64_t)px * C) = vec_pack<T>(acc);                                                          \
+    if (MODE == 0) {                                                                                             \
+      _Pragma("unroll") for (int j = 0; j < VEC; ++j) acc[j] = gelu_f(ElemTraits<T>::cvt(acc[j]));               \
+      *(u32x4*)(go + (int64_t)px * C) = vec_pack<T>(acc);                                                        \
+    }                                                                                                            \
+    ++px;                                                                                                        \
+  }
+  for (int px = x0; px < x1;) {
+    KSMI_DW_STEP(0, 1, 2, 0)
+    KSMI_DW_STEP(1, 2, 0, 1)
+    KSMI_DW_STEP(2, 0, 1, 0)
+    KSMI_DW_STEP(0, 1, 2, 1)
+    KSMI_DW_STEP(1, 2, 0, 0)
+    KSMI_DW_STEP(2, 0, 1, 1)
+  }
+#undef KSMI_DW_STEP
+}
+
+// partial[blockIdx.x][...] over the block's slab of row segments; thread = (segment lane t / CVB, channel vector t % CVB)
+template <typename T, int CVB>
+__global__ __launch_bounds__(256) void dwconv3x3_wgrad_row_kernel(const T* x, const T* dz, float* partial, int B, int H, int W, int C,
+                                                                  int seg, int nseg, int64_t units) {
+  constexpr int VEC = ElemTraits<T>::kVec;
+  constexpr int PL = 256 / CVB;
+  __shared__ float red[256 * 5 * VEC];
+  const int CV = C / VEC;
+  const int cvl = threadIdx.x % CVB, cv = blockIdx.y * CVB + cvl, pl = threadIdx.x / CVB;
+  const int64_t per = (units + gridDim.x - 1) / gridDim.x;
+  const int64_t slab = (gridDim.x & 7) == 0 ? (int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : (int64_t)blockIdx.x;
+  const int64_t u0 = per * slab, u1 = min(units, u0 + per);
+  float acc[10][VEC];
+#pragma unroll
+  for (int t = 0; t < 10; ++t)
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[t][j] = 0.f;
+  if (cv < CV) {
+    const int c0 = cv * VEC;
+    for (int64_t u = u0 + pl; u < u1; u += PL) {
+      const int sgi = (int)(u % nseg);
+      const int64_t row = u / nseg;
+      const int y = (int)(row % H);
+      const int x0 = sgi * seg, x1 = min(W, x0 + seg);
+      const T* rp[3]; bool rv[3];
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { rv[d] = y + d - 1 >= 0 && y + d - 1 < H; rp[d] = x + (row + d - 1) * (int64_t)W * C + c0; }
+      const T* dr = dz + (row * W) * (int64_t)C + c0;
+      float win[3][3][VEC];
+      {
+        const DwCol<T> a = dw_load_col<T>(rp, rv, x0 - 1, W, C), b = dw_load_col<T>(rp, rv, x0, W, C);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { vec_unpack<T>(a.r[d], win[0][d]); vec_unpack<T>(b.r[d], win[1][d]); }
+      }
+      DwCol<T> nxt[2] = {dw_load_col<T>(rp, rv, x0 + 1, W, C), dw_load_col<T>(rp, rv, x0 + 2, W, C)};
+      u32x4 dn[2];
+      dn[0] = *(const u32x4*)(dr + (int64_t)x0 * C);
+      dn[1] = x0 + 1 < x1 ? *(const u32x4*)(dr + (int64_t)(x0 + 1) * C) : (u32x4){0u, 0u, 0u, 0u};
+#define KSMI_DW_STEP(L, M, R_, A)                                                                                \
+  if (px < x1) {                                                                                                 \
+    _Pragma("unroll") for (int d = 0; d < 3; ++d) vec_unpack<T>(nxt[A].r[d], win[R_][d]);                        \
+    float dv[VEC];                                                                                               \
+    vec_unpack<T>(dn[A], dv);                                                                                    \
+    nxt[A] = dw_load_col<T>(rp, rv, px + 3, W, C);                                                               \
+    if (px + 2 < x1) dn[A] = *(const u32x4*)(dr + (int64_t)(px + 2) * C);                                        \
+    _Pragma("unroll") for (int j = 0; j < VEC; ++j) acc[9][j] += dv[j];                                          \
+    _Pragma("unroll") for (int d = 0; d < 3; ++d) {                                                              \
+      _Pragma("unroll") for (int j = 0; j < VEC; ++j) acc[d * 3 + 0][j] += win[L][d][j] * dv[j];                 \
+      _Pragma("unroll") for (int j = 0; j < VEC; ++j) acc[d * 3 + 1][j] += win[M][d][j] * dv[j];                 \
+      _Pragma("unroll") for (int j = 0; j < VEC; ++j) acc[d * 3 + 2][j] += win[R_][d][j] * dv[j];                \
+    }                                                                                                            \
+    ++px;                                                                                                        \
+  }
+      for (int px = x0; px < x1;) {
+        KSMI_DW_STEP(0, 1, 2, 0)
+        KSMI_DW_STEP(1, 2, 0, 1)
+        KSMI_DW_STEP(2, 0, 1, 0)
+        KSMI_DW_STEP(0, 1, 2, 1)
+        KSMI_DW_STEP(1, 2, 0, 0)
+        KSMI_DW_STEP(2, 0, 1, 1)
+      }
+#undef KSMI_DW_STEP
+    }
+  }
+  // block reduction over the PL segment lanes: two rounds of five accumulator rows through LDS, every thread sums some outputs
+  float* prow = partial + (size_t)blockIdx.x * 10 * C;
+  constexpr int RW = 5 * VEC;                                   // floats per thread and round
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    __syncthreads();
+    float* mine = red + (pl * CVB + cvl) * RW;
+#pragma unroll
+    for (int t = 0; t < 5; ++t)
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) mine[t * VEC + j] = acc[r * 5 + t][j];
+    __syncthreads();
+    for (int o = threadIdx.x; o < CVB * RW; o += 256) {
+      const int cl = o / RW, k = o - cl * RW, t = r * 5 + k / VEC, jj = k % VEC;
+      const int cvo = blockIdx.y * CVB + cl;
+      if (cvo >= CV) continue;
+      float sum = 0.f;
+#pragma unroll
+      for (int q = 0; q < PL; ++q) sum += red[(q * CVB + cl) * RW + k];
+      const int c = cvo * VEC + jj;
+      if (t < 9) prow[c * 9 + t] = sum; else prow[9 * C + c] = sum;
+    }
+  }
+}
+
 // weight/bias gradient partials: partial[row][c*9 + t] = sum_p x[p + off_t][c] * dz[p][c] ; partial[row][9C + c] = sum_p dz[p][c]
 // grid (rows, ceil(CV/CVB)); thread = (pixel lane t / CVB, channel vector t % CVB); CVB = 32 for <= 32 channel vectors (stage 1 of the
 // encoder, the largest map: all 256 threads busy instead of half of them), else 64
@@ -917,11 +1090,34 @@ int ksmi_col2im(const void* dcol, void* dx, int accumulate, int B, int Cin, int 
   return ksmi_check_launch("col2im");
 }
 
+struct DwRowGeom { int seg, nseg; int64_t units; };
+static DwRowGeom dw_row_geom(int B, int H, int W) {
+  static const int want = getenv("KSMI_DW_SEG") ? atoi(getenv("KSMI_DW_SEG")) : 14;
+  DwRowGeom q;
+  q.nseg = W <= want ? 1 : (W + want / 2) / want;
+  q.seg = (W + q.nseg - 1) / q.nseg;
+  q.nseg = (W + q.seg - 1) / q.seg;
+  q.units = (int64_t)B * H * q.nseg;
+  return q;
+}
+static bool dw_row_form() {
+  static const bool on = !(getenv("KSMI_DW_ROW") && atoi(getenv("KSMI_DW_ROW")) == 0);
+  return on;
+}
+
 int ksmi_dwconv3x3_gelu_forward(const void* x, const float* w, const float* bias, void* z, void* g, int B, int H, int W, int C,
                                 int dtype, void* stream) {
   const int vec = dtype == KSMI_BF16 ? 8 : 4;
   if (C % vec) return ksmi_fail(KSMI_E_ARG, "dwconv: C must be a multiple of the 16-byte vector");
   hipStream_t st = (hipStream_t)stream;
+  if (dw_row_form()) {
+    const DwRowGeom q = dw_row_geom(B, H, W);
+    const dim3 grid((unsigned)(((q.units + 7) / 8 + 7) / 8 * 8), (C / vec + 31) / 32);
+    KSMI_DT(dtype,
+            hipLaunchKernelGGL((dwconv3x3_row_kernel<bf16_t, 0>), grid, dim3(256), 0, st, (const bf16_t*)x, w, bias, (bf16_t*)z, (bf16_t*)g, B, H, W, C, q.seg, q.nseg, q.units),
+            hipLaunchKernelGGL((dwconv3x3_row_kernel<float, 0>), grid, dim3(256), 0, st, (const float*)x, w, bias, (float*)z, (float*)g, B, H, W, C, q.seg, q.nseg, q.units));
+    return ksmi_check_launch("dwconv3x3_gelu_fwd");
+  }
   static const int ppb_env = getenv("KSMI_DW_PPB") ? atoi(getenv("KSMI_DW_PPB")) : 0;
   const int ppb = ppb_env > 0 ? ppb_env : 32;       // measured (KSMI_DW_PPB sweep): 128 -> 110 / 69 us, 32 -> 90 / 49 us (forward / adjoint)
   const dim3 grid((unsigned)((((int64_t)B * H * W + ppb - 1) / ppb + 7) / 8 * 8), (C / vec + 31) / 32);
@@ -935,6 +1131,14 @@ int ksmi_dwconv3x3_backward_input(const void* dz, const float* w, void* dx, int 
   const int vec = dtype == KSMI_BF16 ? 8 : 4;
   if (C % vec) return ksmi_fail(KSMI_E_ARG, "dwconv: C must be a multiple of the 16-byte vector");
   hipStream_t st = (hipStream_t)stream;
+  if (dw_row_form()) {
+    const DwRowGeom q = dw_row_geom(B, H, W);
+    const dim3 grid((unsigned)(((q.units + 7) / 8 + 7) / 8 * 8), (C / vec + 31) / 32);
+    KSMI_DT(dtype,
+            hipLaunchKernelGGL((dwconv3x3_row_kernel<bf16_t, 1>), grid, dim3(256), 0, st, (const bf16_t*)dz, w, (const float*)nullptr, (bf16_t*)dx, (bf16_t*)nullptr, B, H, W, C, q.seg, q.nseg, q.units),
+            hipLaunchKernelGGL((dwconv3x3_row_kernel<float, 1>), grid, dim3(256), 0, st, (const float*)dz, w, (const float*)nullptr, (float*)dx, (float*)nullptr, B, H, W, C, q.seg, q.nseg, q.units));
+    return ksmi_check_launch("dwconv3x3_bwd_input");
+  }
   static const int ppb_env = getenv("KSMI_DW_PPB") ? atoi(getenv("KSMI_DW_PPB")) : 0;
   const int ppb = ppb_env > 0 ? ppb_env : 32;       // measured (KSMI_DW_PPB sweep): 128 -> 110 / 69 us, 32 -> 90 / 49 us (forward / adjoint)
   const dim3 grid((unsigned)((((int64_t)B * H * W + ppb - 1) / ppb + 7) / 8 * 8), (C / vec + 31) / 32);
@@ -950,6 +1154,18 @@ int ksmi_dwconv3x3_wgrad(const void* x, const void* dz, float* partial, int rows
   const int cvb = C / vec <= 32 ? 32 : 64;
   const dim3 grid(rows, (C / vec + cvb - 1) / cvb);
   hipStream_t st = (hipStream_t)stream;
+  if (dw_row_form()) {
+    const DwRowGeom q = dw_row_geom(B, H, W);
+    if (cvb == 32)
+      KSMI_DT(dtype,
+              hipLaunchKernelGGL((dwconv3x3_wgrad_row_kernel<bf16_t, 32>), grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dz, partial, B, H, W, C, q.seg, q.nseg, q.units),
+              hipLaunchKernelGGL((dwconv3x3_wgrad_row_kernel<float, 32>), grid, dim3(256), 0, st, (const float*)x, (const float*)dz, partial, B, H, W, C, q.seg, q.nseg, q.units));
+    else
+      KSMI_DT(dtype,
+              hipLaunchKernelGGL((dwconv3x3_wgrad_row_kernel<bf16_t, 64>), grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dz, partial, B, H, W, C, q.seg, q.nseg, q.units),
+              hipLaunchKernelGGL((dwconv3x3_wgrad_row_kernel<float, 64>), grid, dim3(256), 0, st, (const float*)x, (const float*)dz, partial, B, H, W, C, q.seg, q.nseg, q.units));
+    return ksmi_check_launch("dwconv3x3_wgrad");
+  }
   if (cvb == 32)
     KSMI_DT(dtype,
             hipLaunchKernelGGL((dwconv3x3_wgrad_kernel<bf16_t, 32>), grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dz, partial, B, H, W, C),

@@ -68,10 +68,12 @@ def test_patch_embed_from_nchw_image():
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_dwconv_gelu_forward_backward(dtype):
+@pytest.mark.parametrize("B,Cc,H,W", [(2, 256, 28, 28), (3, 64, 7, 7), (2, 40, 10, 33), (2, 256, 56, 56), (1, 2048, 7, 7), (2, 1280, 14, 14), (1, 8, 5, 1)])
+def test_dwconv_gelu_forward_backward(dtype, B, Cc, H, W):
+    """the row-walking kernels (cformer.hip dwconv3x3_row_kernel / dwconv3x3_wgrad_row_kernel): the four maps of the MiT encoder plus
+    ragged widths (segment tails, a single column, more channel vectors than one block column)"""
     from kurosiwo_amd import functional as KF
     torch.manual_seed(2)
-    B, Cc, H, W = 2, 256, 28, 28
     x = torch.randn(B, Cc, H, W, device="cuda")
     w = (torch.randn(Cc, 1, 3, 3, device="cuda") * 0.4).requires_grad_(True)
     b = torch.randn(Cc, device="cuda").requires_grad_(True)
