@@ -363,7 +363,7 @@ class ChangeFormerPlan(PlanBase):
         dw, ws = make_wgrad(psrc, dec["Y1"], E, 0, E, gview, E * 9, 9, -1, self._acc_param(wk), B, 4 * H1, 4 * W1, 4 * H1, 4 * W1, 3, 3, 1, 1, self.dtype)
         self.keep.append(gview)
         self._wgrad(dw, ws, wk)
-        rr = max(1, min(512, B * HW // 256))
+        rr = max(1, min(self.csum_rows, B * HW // 256))
         slot = self._rs_slot(rr * CSB * 4)
         self.bwd.add("ksmi_channel_sum", lambda: (dP.data_ptr(), self.scr(slot), rr, B * HW, CSB, dt), self._elt_meta("channel_sum", B * HW * CSB))
         self._defer_rowsum(bk, slot, 0, rr, 1, 0, CSB, nc)

@@ -4,6 +4,7 @@
 //
 // Round-1 note: attention here is a straightforward VALU kernel (N = 197 keys live in LDS, one query row
 // per lane, online softmax); it is ~5 % of the ViT FLOPs.  The MFMA flash-style version is a later step.
+#include <cstdlib>
 #include "common.h"
 #include "../../include/ksmi.h"
 #include "errors.h"
@@ -661,7 +662,14 @@ int ksmi_layernorm_forward(const void* x, const float* gamma, const float* beta,
 }
 
 // at most 256 partial rows: one workgroup per CU and the parameter-gradient reduction stays a single launch (no fold pass)
-int ksmi_layernorm_bwd_blocks(int rows) { int b = (rows + 7) / 8; return b > 256 ? 256 : (b < 1 ? 1 : b); }
+int ksmi_layernorm_bwd_blocks(int rows) {
+  // 256 workgroups (one per CU) up to ViT-sized token matrices (measured faster there than 512 / 1024); the 200 k-row maps of the MiT
+  // encoder's first stage need more waves in flight to stream (1024: ChangeFormer +0.5 %)
+  static const int env = getenv("KSMI_LN_BWD_BLOCKS") ? atoi(getenv("KSMI_LN_BWD_BLOCKS")) : 0;
+  const int cap = env > 0 ? env : (rows >= 100000 ? 1024 : 256);
+  int b = (rows + 7) / 8;
+  return b > cap ? cap : (b < 1 ? 1 : b);
+}
 
 int ksmi_layernorm_backward(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma, void* dx,
                             int accumulate, float* partial, int rows, int C, int dtype, void* stream) {

@@ -47,6 +47,7 @@ class PlanBase:
     def _wb_ptr(self, key):
         return self.wb.data_ptr() + 2 * self.m._poff[key]
 
+    csum_rows = max(1, int(__import__("os").environ.get("KSMI_CSUM_ROWS", "512")))
     rowsum_batch = max(1, int(__import__("os").environ.get("KSMI_ROWSUM_BATCH", "16")))
 
     def _finish(self):
@@ -211,7 +212,7 @@ class PlanBase:
             self.bwd.add("ksmi_colsum", lambda: (dy.data_ptr(), rows, N, gb, acc, self.dt), self._elt_meta("colsum", rows * N))
             self._mark(bkey)
             return
-        r = max(1, min(512, rows // 64))                   # (256 would save the fold launch but halves the streaming kernel's grid: slower)
+        r = max(1, min(self.csum_rows, rows // 64))        # partial rows = workgroups of the streaming kernel (the batched reducer takes any count)
         slot = self._rs_slot(r * N * 4)
         self.bwd.add("ksmi_channel_sum", lambda: (dy.data_ptr(), self.scr(slot), r, rows, N, self.dt),
                      self._elt_meta("channel_sum", rows * N))
@@ -401,7 +402,11 @@ class PlanBase:
             if mask is not None:
                 mk = (mask, self.const[0], self.const[1], self.const[1], self.const[0])
             import os
-            if os.environ.get("KSMI_DECONV_DGRAD_4X4"):
+            # one 4x4 stride-2 convolution for the narrow decoders (FloodViT head, N <= 128 output channels of the deconv: the four
+            # phase launches each re-read and re-write dx; measured 160 against 4 x 80 us on the 64 <- 3 layer, level on the others),
+            # four dense 2x2 phase convolutions for ChangeFormer's 256-channel decoder.  KSMI_DECONV_DGRAD_4X4=0/1 forces one form.
+            force = os.environ.get("KSMI_DECONV_DGRAD_4X4")
+            if force == "1" or (force is None and N <= 128):
                 d, table = make_conv(src, [(dx, Cin, 0, 0, Cin, 0)], dx, None, None, B, 2 * H, 2 * W, H, W, 4, 4, 2, 1, Cin,
                                      self.dtype, mask=mk)
                 d.wpk = self._packed(wkey, table, 16, Cin, Cin, 16, N * 16, 0, 1, 0).data_ptr()
@@ -428,7 +433,7 @@ class PlanBase:
         self._deconv_wgrad(src, x, Cin, N, H, W, wkey, B)
         # bias gradient over the real channels only
         rows = B * 4 * H * W
-        r = max(1, min(512, rows // 256))
+        r = max(1, min(self.csum_rows, rows // 256))
         slot = self._rs_slot(r * doutC * 4)
         self.bwd.add("ksmi_channel_sum", lambda: (dout.data_ptr(), self.scr(slot), r, rows, doutC, self.dt),
                      self._elt_meta("channel_sum", rows * doutC))
