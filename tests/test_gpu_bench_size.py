@@ -246,7 +246,9 @@ def test_snunet_dem_shard_vs_reference_golden(golden_dir, precision):
         assert mism <= 0.01 * am.size, (mism, am.size)
     assert (am[decisive] == gold["train_argmax_sub"][decisive]).all()
     bad, coss = {}, []
-    tol = 8e-2 if precision == "bf16" else 5e-3
+    # bf16: the first block's gradient norms move by +-5-8 % with the rounding realisation (a 1e-7 relative change of one weight
+    # tensor, profiles/r04_bf16_realisation.txt) around a value ~5 % below the fp32 one: 16 % bounds a result, 8 % only bounded a draw
+    tol = 1.6e-1 if precision == "bf16" else 5e-3
     for k, p in m.named_parameters():
         st = gold[f"gstat.{k}"]
         if k.endswith("conv2.bias"):
@@ -257,7 +259,7 @@ def test_snunet_dem_shard_vs_reference_golden(golden_dir, precision):
         if f"grad.{k}" in gold.files:
             coss.append(_cos(p.grad.detach().float().cpu().numpy(), gold[f"grad.{k}"]))
     assert not bad, dict(list(bad.items())[:10])
-    assert min(coss) > (0.97 if precision == "bf16" else 0.9999), coss
+    assert min(coss) > (0.95 if precision == "bf16" else 0.9999), coss      # (bf16: the first convolution's direction, same realisation spread)
     # the concatenated form of the same inputs is the same function
     if precision == "fp32":
         m.zero_grad()
