@@ -705,7 +705,6 @@ __global__ void bilinear_bwd_kernel(const T* dy, T* dx, int B, int Hi, int Wi, i
   constexpr int VEC = ElemTraits<T>::kVec;
   const int CV = C / VEC;
   const float ry = (float)Hi / (float)Ho, rx = (float)Wi / (float)Wo;
-  const int sy = (Ho + Hi - 1) / Hi, sx = (Wo + Wi - 1) / Wi;          // upscale factors (ceil)
   const int64_t n = (int64_t)B * Hi * Wi * CV;
   for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (int64_t)gridDim.x * blockDim.x) {
     const int cv = v % CV; int64_t r = v / CV;
@@ -714,9 +713,11 @@ __global__ void bilinear_bwd_kernel(const T* dy, T* dx, int B, int Hi, int Wi, i
     float s[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) s[j] = 0.f;
-    // output rows whose two taps can include iy: src in (iy-1, iy+1)  ->  o in [(iy-1)*s - s, (iy+1)*s + s]
-    const int oy_lo = max(0, (iy - 1) * sy - sy), oy_hi = min(Ho - 1, (iy + 2) * sy + sy);
-    const int ox_lo = max(0, (ix - 1) * sx - sx), ox_hi = min(Wo - 1, (ix + 2) * sx + sx);
+    // output rows whose two taps can include iy: src = (o + 0.5) * r - 0.5 in (iy - 1, iy + 1)  ->  o in ((iy - 0.5) / r - 0.5,
+    // (iy + 1.5) / r - 0.5), one more on each side for the rounding of r (2 s + 2 candidates per axis; the first version walked 5 s:
+    // 1600 candidates per input pixel on the 7 -> 56 map, 190 us)
+    const int oy_lo = max(0, (int)floorf(((float)iy - 0.5f) / ry - 0.5f) - 1), oy_hi = min(Ho - 1, (int)ceilf(((float)iy + 1.5f) / ry - 0.5f) + 1);
+    const int ox_lo = max(0, (int)floorf(((float)ix - 0.5f) / rx - 0.5f) - 1), ox_hi = min(Wo - 1, (int)ceilf(((float)ix + 1.5f) / rx - 0.5f) + 1);
     for (int oy = oy_lo; oy <= oy_hi; ++oy) {
       int y0, y1; float ly;
       bil_src(oy, ry, Hi, y0, y1, ly);

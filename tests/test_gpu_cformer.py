@@ -183,7 +183,7 @@ def test_sr_attention_with_attention_dropout(dtype, Cc, heads, Nq):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("hi,ho", [(7, 14), (7, 56), (14, 56), (28, 56)])
+@pytest.mark.parametrize("hi,ho", [(7, 14), (7, 56), (14, 56), (28, 56), (5, 13), (9, 9)])
 def test_bilinear_forward_backward(dtype, hi, ho):
     from kurosiwo_amd import functional as KF
     torch.manual_seed(4)
