@@ -807,13 +807,27 @@ __global__ __launch_bounds__(1024) void colsum_kernel(const T* x, int64_t rows, 
   float a[VEC];
 #pragma unroll
   for (int j = 0; j < VEC; ++j) a[j] = 0.f;
-  if (c < C)
-    for (int64_t r = rl; r < rows; r += 256) {
+  if (c < C) {
+    int64_t r = rl;
+    for (; r + 3 * 256 < rows; r += 4 * 256) {                     // four rows in flight, summed in the order of the plain loop
+      u32x4 v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = *(const u32x4*)(x + (r + k * 256) * C + c);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float f[VEC];
+        vec_unpack<T>(v[k], f);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) a[j] += f[j];
+      }
+    }
+    for (; r < rows; r += 256) {
       float f[VEC];
       vec_unpack<T>(*(const u32x4*)(x + r * C + c), f);
 #pragma unroll
       for (int j = 0; j < VEC; ++j) a[j] += f[j];
     }
+  }
 #pragma unroll
   for (int j = 0; j < VEC; ++j) red[rl][q * VEC + j] = a[j];
   __syncthreads();

@@ -7,7 +7,7 @@
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kPoolSplit = 16;       // pixel splits per image for the global pools
+constexpr int kPoolSplit = 64;       // pixel splits per image for the global pools (16 left 2 workgroups per CU at batch 32: 132 us for 411 MB)
 constexpr int kBwdSplit = 64;        // pixel splits of the phase-A reduction (the finish kernel is one block per sample)
 
 // ------------------------------------------------------------------------------------------------
@@ -235,6 +235,36 @@ __global__ __launch_bounds__(256) void ecam_bwd_reduce_kernel(const T* x0, const
         for (int j = 0; j < VEC; ++j) g[k][j] += d * v[j];
       }
     }
+  // lanes with the same channel vector are CV4 apart: when CV4 is a power of two dividing 64 the 64 / CV4 pixel lanes of a wave
+  // combine by xor-shuffles and only the 4 wave results meet in LDS (one barrier instead of 2 x NCLS x (VEC + 1), as in ecam_pool_kernel)
+  if ((CV4 & (CV4 - 1)) == 0 && CV4 <= 32) {
+    __shared__ float wsum[4][NCLS * VEC * 32 + NCLS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NCLS; ++k) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        float a = g[k][j];
+        for (int o = CV4; o < 64; o <<= 1) a += __shfl_xor(a, o, 64);
+        if (lane < CV4) wsum[wave][(k * VEC + j) * CV4 + lane] = a;
+      }
+      float a = cv == 0 ? dsum[k] : 0.f;
+      for (int o = CV4; o < 64; o <<= 1) a += __shfl_xor(a, o, 64);
+      if (lane == 0) wsum[wave][NCLS * VEC * CV4 + k] = a;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < NCLS * VEC * CV4 + NCLS; e += kThreads) {
+      const float a = (wsum[0][e] + wsum[1][e]) + (wsum[2][e] + wsum[3][e]);
+      if (e < NCLS * VEC * CV4) {
+        const int kj = e / CV4, cvv = e - kj * CV4;
+        const int k = kj / VEC, j = kj - k * VEC;
+        pg[(((size_t)b * S + sp) * NCLS + k) * C4 + cvv * VEC + j] = a;
+      } else {
+        pd[((size_t)b * S + sp) * NCLS + (e - NCLS * VEC * CV4)] = a;
+      }
+    }
+    return;
+  }
   __shared__ float red[kThreads];
 #pragma unroll
   for (int k = 0; k < NCLS; ++k) {
