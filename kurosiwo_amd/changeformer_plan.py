@@ -7,6 +7,7 @@ two dates: run here once over 2B images), Block :245-248, Attention :186-208, Ml
 Layouts: token tensors are [rows = 2B*H_s*W_s][C] = NHWC; decoder tensors are NHWC over the B tiles.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -36,7 +37,7 @@ class ChangeFormerPlan(PlanBase):
     input_names = ("x1", "x2")
     # the encoder's nn.Linear / sr-conv weight gradients on the train step's side stream (plan_base.PlanBase.side_tokens; waits in
     # _encoder_stage_bwd).  KSMI_CF_SIDE_TOKENS=0: the single-stream list.
-    side_tokens = __import__("os").environ.get("KSMI_CF_SIDE_TOKENS", "1") != "0"
+    side_tokens = os.environ.get("KSMI_CF_SIDE_TOKENS", "1") != "0"
 
     def __init__(self, model, B, H, W, dtype, training, with_backward):
         self._init_base(model, dtype, with_backward)
@@ -585,7 +586,6 @@ class ChangeFormerPlan(PlanBase):
     # ---------------------------------------------------------------- convolutions as GEMMs over a channel-fastest im2col
     def _tc_ok(self, Cin):
         """bf16 performance mode: im2col matrices in (tap, channel) order (ksmi_im2col_tc), weights re-ordered per step."""
-        import os
         return self.dtype == torch.bfloat16 and self.wb is not None and Cin % 8 == 0 and not os.environ.get("KSMI_IM2COL_CT")
 
     def _linear_tc(self, name, col, Kpad, wkey, bkey, out, N, rows, Cin, taps):

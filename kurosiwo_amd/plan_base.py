@@ -1,6 +1,7 @@
 """Shared machinery of the static launch plans (FloodViT, ChangeFormer): scratch bookkeeping, weight packing, the
 launch-list wrappers around ksmi_conv_forward / ksmi_conv_wgrad for nn.Linear, nn.LayerNorm and ConvTranspose2d(k4,s2,p1)."""
 import ctypes as C
+import os
 
 import torch
 
@@ -35,7 +36,6 @@ class PlanBase:
         # `rowsum_batch` producer launches instead of one tiny launch each (single-stream plans pay every launch in full)
         self._rs_entries, self._rs_slots = [], 0
         # bf16 mirror of the parameter arena for the token GEMMs (gemm.hip): one cast launch per step
-        import os
         self.wb = None
         if dtype == torch.bfloat16 and not os.environ.get("KSMI_LINEAR_IGEMM"):
             n = model.flat_params.numel()
@@ -47,8 +47,8 @@ class PlanBase:
     def _wb_ptr(self, key):
         return self.wb.data_ptr() + 2 * self.m._poff[key]
 
-    csum_rows = max(1, int(__import__("os").environ.get("KSMI_CSUM_ROWS", "512")))
-    rowsum_batch = max(1, int(__import__("os").environ.get("KSMI_ROWSUM_BATCH", "16")))
+    csum_rows = max(1, int(os.environ.get("KSMI_CSUM_ROWS", "512")))
+    rowsum_batch = max(1, int(os.environ.get("KSMI_ROWSUM_BATCH", "16")))
 
     def _finish(self):
         self._flush_rowsums()
@@ -378,7 +378,6 @@ class PlanBase:
     def _deconv_wgrad(self, src, x, Cin, N, H, W, wkey, B):
         """dW[c][n][ky][kx] = sum x[iy,ix,c] dOut[2iy-1+ky, 2ix-1+kx, n] as four 2x2 stride-1 weight-gradient GEMMs over the parity
         sub-images of dOut (tap (a,b) of phase (py,px) <-> ky = 2a | 1+2a, kx = 2b | 1+2b), each writing its 4 of the 16 taps"""
-        import os
         acc = self._acc_param(wkey)
         if os.environ.get("KSMI_DECONV_WGRAD_4X4"):
             dw, ws = make_wgrad(src, x, Cin, 0, Cin, self.m._g(wkey), 16, N * 16, 1, acc, B, 2 * H, 2 * W, H, W, 4, 4, 2, 1, self.dtype)
@@ -401,7 +400,6 @@ class PlanBase:
             mk = None
             if mask is not None:
                 mk = (mask, self.const[0], self.const[1], self.const[1], self.const[0])
-            import os
             # one 4x4 stride-2 convolution for the narrow decoders (FloodViT head, N <= 128 output channels of the deconv: the four
             # phase launches each re-read and re-write dx; measured 160 against 4 x 80 us on the 64 <- 3 layer, level on the others),
             # four dense 2x2 phase convolutions for ChangeFormer's 256-channel decoder.  KSMI_DECONV_DGRAD_4X4=0/1 forces one form.
