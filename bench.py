@@ -244,7 +244,8 @@ def build_roofline(args, step, solo_timer, solo_steps, d, dominant, timer_steps,
                     st["busy_ms"] += ms; st["busy_w"] += ms * row["mfma_busy_pct"]
     if os.environ.get("BENCH_LAUNCH_MAP"):         # per-launch table of the LAST single-stream step (profiles/summarize.py aligns traces with it)
         per = len(solo_timer.rec) // max(solo_steps, 1)
-        rows_ = [{"i": i, "kind": kind, "stage": meta.get("stage"), "tag": meta.get("tag", ""), "kernels": list(names), "bytes": meta.get("bytes", 0),
+        rows_ = [{"i": i, "kind": kind, "stage": meta.get("stage"), "tag": meta.get("tag", ""), "lane": meta.get("lane", 0), "side": bool(meta.get("side")),
+                  "kernels": list(names), "bytes": meta.get("bytes", 0),
                   "flops": meta.get("flops", 0), "ms": round(e0.elapsed_time(e1), 5)}
                  for i, ((kind, meta, e0, e1), names) in enumerate(zip(solo_timer.rec[-per:], solo_timer.kernels[-per:]))]
         json.dump(rows_, open(os.environ["BENCH_LAUNCH_MAP"], "w"))
