@@ -7,7 +7,7 @@
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kPoolSplit = 64;       // pixel splits per image for the global pools (16 left 2 workgroups per CU at batch 32: 132 us for 411 MB)
+constexpr int kPoolSplit = 64;       // most pixel splits per image of the global pools (workspace size); pool_split() picks the count
 constexpr int kBwdSplit = 64;        // pixel splits of the phase-A reduction (the finish kernel is one block per sample)
 
 // ------------------------------------------------------------------------------------------------
@@ -626,23 +626,29 @@ bool ecam_c_ok(int C, int dtype) {
 
 extern "C" {
 
+static int pool_split() {
+  static const int s = getenv("KSMI_ECAM_POOL_SPLIT") ? atoi(getenv("KSMI_ECAM_POOL_SPLIT")) : 16;
+  return s < 1 ? 1 : (s > kPoolSplit ? kPoolSplit : s);
+}
+
 size_t ksmi_ecam_pool_workspace(int B, int HW, int C) { (void)HW; return (size_t)B * kPoolSplit * 5 * C * 3 * sizeof(float); }
 
 int ksmi_ecam_pool(const void* const x[4], float* avg, float* mx, int32_t* argmax, float* workspace, int B, int HW, int C,
                    int dtype, void* stream) {
   if (!ecam_c_ok(C, dtype)) return ksmi_fail(KSMI_E_ARG, "ecam_pool: unsupported C");
-  const size_t n = (size_t)B * kPoolSplit * 5 * C;
+  const int S = pool_split();
+  const size_t n = (size_t)B * S * 5 * C;
   float* psum = workspace; float* pmax = workspace + n; int* pidx = (int*)(workspace + 2 * n);
   KSMI_DT(dtype,
-          hipLaunchKernelGGL(ecam_pool_kernel<bf16_t>, dim3(kPoolSplit, B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x[0],
+          hipLaunchKernelGGL(ecam_pool_kernel<bf16_t>, dim3(S, B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x[0],
                              (const bf16_t*)x[1], (const bf16_t*)x[2], (const bf16_t*)x[3], psum, pmax, pidx, HW, C),
-          hipLaunchKernelGGL(ecam_pool_kernel<float>, dim3(kPoolSplit, B), dim3(256), 0, (hipStream_t)stream, (const float*)x[0],
+          hipLaunchKernelGGL(ecam_pool_kernel<float>, dim3(S, B), dim3(256), 0, (hipStream_t)stream, (const float*)x[0],
                              (const float*)x[1], (const float*)x[2], (const float*)x[3], psum, pmax, pidx, HW, C));
   int rc = ksmi_check_launch("ecam_pool");
   if (rc) return rc;
   const int tot = B * 5 * C;
   hipLaunchKernelGGL(ecam_pool_final_kernel, dim3((tot + 255) / 256), dim3(256), 0, (hipStream_t)stream, psum, pmax, pidx, avg, mx,
-                     argmax, B, kPoolSplit, 5 * C, HW);
+                     argmax, B, S, 5 * C, HW);
   return ksmi_check_launch("ecam_pool_final");
 }
 
