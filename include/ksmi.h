@@ -534,6 +534,9 @@ int ksmi_cast_bf16(const float* src, void* dst, int64_t n, void* stream);
 int ksmi_up_gemm_supported(int B, int H, int W, int C, int dtype);
 int ksmi_up_wgrad_supported(int B, int H, int W, int C, int dtype);      /* the weight gradient alone also takes C = 64 */
 int ksmi_up_pack_weight(const float* wt, void* wb, int C, void* stream);
+/* the same pack for up to KSMI_UP_PACK_MAX tensors in one launch (host arrays of n pointers / channel counts) */
+#define KSMI_UP_PACK_MAX 16
+int ksmi_up_pack_weights_batched(const float* const* wt, void* const* wb, const int* C, int n, void* stream);
 int ksmi_up_forward(const void* x, const void* wb, const float* bias, void* y, int B, int H, int W, int C, void* stream);
 int ksmi_up_dgrad(const void* dy, const void* wb, void* dx, int accumulate, int B, int H, int W, int C, void* stream);
 size_t ksmi_up_wgrad_workspace(int B, int H, int W, int C);

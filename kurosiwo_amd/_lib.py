@@ -178,6 +178,7 @@ SIGNATURES = {
     "ksmi_up_gemm_supported": (_i, [_i, _i, _i, _i, _i]),
     "ksmi_up_wgrad_supported": (_i, [_i, _i, _i, _i, _i]),
     "ksmi_up_pack_weight": (_i, [_vp, _vp, _i, _vp]),
+    "ksmi_up_pack_weights_batched": (_i, [_vp, _vp, _vp, _i, _vp]),
     "ksmi_up_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ksmi_up_dgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ksmi_up_wgrad_workspace": (C.c_size_t, [_i, _i, _i, _i]),

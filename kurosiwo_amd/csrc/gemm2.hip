@@ -629,6 +629,18 @@ __global__ void up_pack_kernel(const float* __restrict__ wt, bf16_t* __restrict_
     wb[e] = f32_to_bf16(wt[((int64_t)c * C + n) * 4 + d]);
   }
 }
+// every `up` weight of a plan in one launch (blockIdx.y = tensor; the six SNUNet packs were six 6-10 us launches)
+struct UpPackBatch { const float* wt[KSMI_UP_PACK_MAX]; bf16_t* wb[KSMI_UP_PACK_MAX]; int C[KSMI_UP_PACK_MAX]; };
+__global__ void up_pack_batched_kernel(const UpPackBatch b) {
+  const float* __restrict__ wt = b.wt[blockIdx.y];
+  bf16_t* __restrict__ wb = b.wb[blockIdx.y];
+  const int C = b.C[blockIdx.y];
+  const int64_t n_el = (int64_t)4 * C * C;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_el; e += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(e % C); const int64_t r = e / C; const int n = (int)(r % C), d = (int)(r / C);
+    wb[e] = f32_to_bf16(wt[((int64_t)c * C + n) * 4 + d]);
+  }
+}
 // grad[c][n][d] (+)= sum_split slab[split][c][d * C + n]   (slab rows k = c, columns n' = (d, n); fixed order)
 __global__ void up_wgrad_reduce_kernel(const float* __restrict__ slab, int nsplit, int C, float* __restrict__ grad, int accumulate) {
   const int64_t n_el = (int64_t)C * C;
@@ -697,6 +709,16 @@ int ksmi_up_wgrad_supported(int B, int H, int W, int C, int dtype) {
   return !off && dtype == KSMI_BF16 && C >= 64 && C % 64 == 0 && (int64_t)B * H * W >= 64 && (int64_t)B * H * W * 112 < ((int64_t)1 << 32) ? 1 : 0;
 }
 int ksmi_up_pack_weight(const float* wt, void* wb, int C, void* stream) { return ksmi_gemm2_up_pack(wt, wb, C, (hipStream_t)stream); }
+int ksmi_up_pack_weights_batched(const float* const* wt, void* const* wb, const int* C, int n, void* stream) {
+  if (!wt || !wb || !C || n < 1 || n > KSMI_UP_PACK_MAX) return ksmi_fail(KSMI_E_ARG, "up_pack_weights_batched: 1 .. KSMI_UP_PACK_MAX tensors");
+  UpPackBatch b = {};
+  for (int i = 0; i < n; ++i) {
+    if (!wt[i] || !wb[i] || C[i] < 1) return ksmi_fail(KSMI_E_ARG, "up_pack_weights_batched: bad entry");
+    b.wt[i] = wt[i]; b.wb[i] = (bf16_t*)wb[i]; b.C[i] = C[i];
+  }
+  hipLaunchKernelGGL(up_pack_batched_kernel, dim3(256, n), dim3(256), 0, (hipStream_t)stream, b);
+  return ksmi_check_launch("up_pack_weights_batched");
+}
 int ksmi_up_forward(const void* x, const void* wb, const float* bias, void* y, int B, int H, int W, int C, void* stream) {
   const int rc = ksmi_gemm2_up_forward(x, wb, bias, y, B, H, W, C, (hipStream_t)stream);
   return rc == 1 ? ksmi_fail(KSMI_E_UNSUPPORTED, "up_forward: shape not covered (ksmi_up_gemm_supported)") : rc;

@@ -1008,7 +1008,11 @@ int ksmi_pack_weights(const ksmi_pack_desc* d, int dtype, void* stream) {
 
 int ksmi_pack_weights_batched(const ksmi_pack_desc* descs_device, int n, int dtype, void* stream) {
   if (!descs_device || n < 1) return ksmi_fail(KSMI_E_ARG, "pack_batched: bad args");
-  const dim3 grid(48, n);
+  // x = workgroups per descriptor: the large tensors (512 x 512 x 9: 295 k vectors) decide the duration, so they get enough to fill
+  // the machine on their own; workgroups beyond a small tensor's vectors fall through the loop at once (48 per descriptor: 108 us
+  // per SNUNet step with ~200 workgroups alive in the tail)
+  static const int gx = getenv("KSMI_PACK_GRID") ? atoi(getenv("KSMI_PACK_GRID")) : 512;
+  const dim3 grid(gx < 1 ? 1 : gx, n);
   if (dtype == KSMI_BF16) hipLaunchKernelGGL(pack_weights_batched_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, descs_device);
   else if (dtype == KSMI_F32) hipLaunchKernelGGL(pack_weights_batched_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, descs_device);
   else return ksmi_fail(KSMI_E_ARG, "pack_batched: bad dtype");

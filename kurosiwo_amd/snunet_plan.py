@@ -185,6 +185,7 @@ class SNUNetPlan:
         self.keep = []
         self._pinit = set()
         self._pack_descs = []      # every weight-pack descriptor of the plan -> ONE batched launch per step
+        self._up_packs = []        # (ConvTranspose weight, its [4C][C] bf16 image, C) of the `up` layers on the token-GEMM path
         self.param_ready = {}      # parameter key -> index of the last backward launch writing its gradient
         self._need, self._bufs, self._later = {}, {}, []
         self._rowsums = []         # deferred row reductions (bias gradients): (RowsumDesc, parameter key) -> ONE launch ending the backward
@@ -263,6 +264,15 @@ class SNUNetPlan:
                 self.keep.append(rtable)
                 self.bwd.add("ksmi_reduce_rows_batched", lambda: (rtable.data_ptr(), nr))
                 self._mark(*[k for _, k in self._rowsums])
+        for i in range(0, len(self._up_packs), 16):           # KSMI_UP_PACK_MAX tensors per launch
+            grp = self._up_packs[i:i + 16]
+            import ctypes
+            wt_a = (ctypes.c_void_p * len(grp))(*[w.data_ptr() for w, _, _ in grp])
+            wb_a = (ctypes.c_void_p * len(grp))(*[b.data_ptr() for _, b, _ in grp])
+            c_a = (ctypes.c_int * len(grp))(*[c for _, _, c in grp])
+            self.keep += [wt_a, wb_a, c_a]
+            self.packs.add("ksmi_up_pack_weights_batched", lambda wt_a=wt_a, wb_a=wb_a, c_a=c_a, k=len(grp): (wt_a, wb_a, c_a, k),
+                           {"kind": "up_pack_weight", "bytes": sum(4 * c * c * 6 for _, _, c in grp), "flops": 0})
         # all weight packs of the step as one launch over a device-resident descriptor table
         if self._pack_descs:
             import ctypes
@@ -488,7 +498,7 @@ class SNUNetPlan:
         if up_gemm:
             wb = torch.empty(4 * Cc * Cc, dtype=torch.bfloat16, device=self.dev)
             self.keep.append(wb)
-            self.packs.add("ksmi_up_pack_weight", lambda: (self.m._p(wkey).data_ptr(), wb.data_ptr(), Cc))
+            self._up_packs.append((self.m._p(wkey), wb, Cc))        # one batched launch for all of them (end of __init__)
         if up_fwd_gemm:
             self.fwd.add("ksmi_up_forward", lambda: (x.t.data_ptr(), wb.data_ptr(), self.m._p(bkey).data_ptr(), y.t.data_ptr(), B, H, W, Cc),
                          {"kind": "up_gemm_fwd", "bytes": B * H * W * Cc * 5 * es, "flops": 2 * B * H * W * Cc * 4 * Cc, "tag": f"K={Cc} N={4 * Cc} {H}x{W}"})

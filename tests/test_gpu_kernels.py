@@ -306,6 +306,15 @@ def test_up_convtranspose_as_token_gemms(dev, B, H, W, Cc):
     wb = torch.empty(4 * Cc * Cc, dtype=torch.bfloat16, device=dev)
     st = stream_ptr()
     _lib.check(lib.ksmi_up_pack_weight(wt.data_ptr(), wb.data_ptr(), Cc, st), "pack")
+    # the batched form (one launch for all `up` weights of a plan) writes the same images
+    import ctypes
+    w2 = torch.randn(64, 64, 2, 2, device=dev)
+    wb_b, wb2_b = torch.zeros_like(wb), torch.zeros(4 * 64 * 64, dtype=torch.bfloat16, device=dev)
+    wb2 = torch.empty_like(wb2_b)
+    _lib.check(lib.ksmi_up_pack_weight(w2.data_ptr(), wb2.data_ptr(), 64, st), "pack")
+    _lib.check(lib.ksmi_up_pack_weights_batched((ctypes.c_void_p * 2)(wt.data_ptr(), w2.data_ptr()), (ctypes.c_void_p * 2)(wb_b.data_ptr(), wb2_b.data_ptr()),
+                                                (ctypes.c_int * 2)(Cc, 64), 2, st), "pack_batched")
+    assert torch.equal(wb_b, wb) and torch.equal(wb2_b, wb2)
     y = torch.empty(B, 2 * H, 2 * W, Cc, dtype=torch.bfloat16, device=dev)
     _lib.check(lib.ksmi_up_forward(x_nhwc.data_ptr(), wb.data_ptr(), bias.data_ptr(), y.data_ptr(), B, H, W, Cc, st), "fwd")
     ref = yr.detach().permute(0, 2, 3, 1)
