@@ -9,6 +9,7 @@ struct ksmi_wgrad3_geom_t {
   int KT, NTt;                       // tiles along K and N
   int patches, pps, nsplit;          // patches, patches per split, splits (= partial slabs)
   int xpl, stage;                    // LDS bytes of one X plane / one stage
+  int nst;                           // stages of the LDS ring (2: two workgroups per CU; up to 4 when the workgroup owns the CU)
   size_t lds;
 };
 // false: the descriptor does not qualify (the caller uses igemm_wgrad_kernel)

@@ -20,6 +20,7 @@
 #include "errors.h"
 #include "igemm_epilogue.h"
 #include "wgrad3.h"
+#include "dma.h"
 
 namespace {
 
@@ -33,20 +34,18 @@ struct Wg3Args {
   int kstride;                     // bytes between k-steps inside an X plane
   int hymask;                      // 1: the swizzle term of the X image includes the halo row parity (TW == 8)
   int lds_bytes;
+  int nst;                         // stages of the LDS ring (2 .. 4): patches i+1 .. i+nst-1 are in flight during the MFMAs of patch i
+  const unsigned char* zero;       // >= 16 zero bytes (positions outside the image / the tile read it: every wave issues a FIXED
+                                   // number of DMA instructions per stage, so the ring is waited for with counted vmcnt, dma.h)
 };
 
-// LDS-DMA issued from inline asm: hipcc (ROCm 7.2) puts `s_waitcnt vmcnt(0)` in front of every ds_read_b64_tr_b16 that follows a
-// __builtin_amdgcn_global_load_lds (the transposed-read intrinsic carries no memory operand, so it may alias the DMA), which
-// serialises the DMA of patch i+1 with the MFMAs of patch i.  An asm DMA is invisible to that pass; its completion is waited for
-// by hand (dma_wait) in front of the barrier that publishes the stage.  lane i lands at dst_wave_base + 16 * i.
-__device__ __forceinline__ void glds16(const unsigned char* base, uint32_t off, unsigned dst_wave_base) {
-  unsigned keep;
-  dst_wave_base = __builtin_amdgcn_readfirstlane(dst_wave_base);    // provably uniform for the "s" constraint
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(off), "s"(base), "s"(dst_wave_base) : "memory");
-}
-__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __attribute__((aligned(64))) unsigned char wg3_zero_page[64];     // zero-initialised device memory
 
+// LDS-DMA issued from inline asm (dma.h): hipcc (ROCm 7.2) puts `s_waitcnt vmcnt(0)` in front of every ds_read_b64_tr_b16 that
+// follows a __builtin_amdgcn_global_load_lds (the transposed-read intrinsic carries no memory operand, so it may alias the DMA),
+// which serialises the DMA of the next patches with the MFMAs of this one.  An asm DMA is invisible to that pass; its completion
+// is waited for by hand (vm_wait with the per-wave instruction count of the stages issued later) in front of the barrier that
+// publishes the stage.
 __device__ __forceinline__ u32x4 tr_frag(unsigned a0, unsigned a1) {
   const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(uintptr_t)a0);
   const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(uintptr_t)a1);
@@ -64,7 +63,7 @@ __device__ __forceinline__ int wg_chunk_src(const ksmi_wgrad_desc& d, int ch) {
   return (int)((((const uint32_t*)d.chunk_src)[ch >> 2] >> ((ch & 3) * 8)) & 0xffu);
 }
 
-template <int WC, int WN, int NF, bool AFF>
+template <int WC, int WN, int NF, bool AFF, bool DEEP>
 __global__ __launch_bounds__(256, 2) void wgrad3_kernel(const Wg3Args ka) {
   typedef bf16_t T;
   const ksmi_wgrad_desc& d = ka.d;
@@ -112,7 +111,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3_kernel(const Wg3Args ka) {
 
   // ---- zero the whole LDS allocation once (rows of the k padding, slack rows: everything an MFMA may touch is finite) ----
   for (int i = tid * 16; i < ka.lds_bytes; i += 256 * 16) *(u32x4*)(smem + i) = (u32x4){0u, 0u, 0u, 0u};
-  float* aff_tab = (float*)(smem + 2 * stage);                      // AFF: [CPT*32][2] scale, shift of the tile's channels
+  float* aff_tab = (float*)(smem + ka.nst * stage);                      // AFF: [CPT*32][2] scale, shift of the tile's channels
   if constexpr (AFF) {
     __syncthreads();
     if (tid < CPT * 32) {
@@ -164,10 +163,20 @@ __global__ __launch_bounds__(256, 2) void wgrad3_kernel(const Wg3Args ka) {
     const int ty = q1 - b * ka.tilesY;
     oy0 = ty * TH; ox0 = tx * TW;
   };
+  // One stage = the X halo planes + the dY planes of a patch.  Every wave issues the SAME instructions for every patch: a slot
+  // outside the image (or a column beyond N) reads the zero page, lanes beyond the halo are exec-masked but never a whole
+  // instruction (the `wave_in` test is wave-uniform), so `dma_cnt` instructions per stage and wave is exact.
+  const uint32_t zlo = (uint32_t)(uintptr_t)ka.zero, zhi = (uint32_t)((uint64_t)(uintptr_t)ka.zero >> 32);
+  int nvalid = 0;
+#pragma unroll
+  for (int c = 0; c < CPT; ++c) nvalid += cvalid[c] ? 1 : 0;
+  int dma_cnt = 2 * NPL;
+#pragma unroll
+  for (int it = 0; it < XIT; ++it) dma_cnt += (it * 256 + wave * 64 < ka.HPv * 4) ? nvalid : 0;
+  dma_cnt = __builtin_amdgcn_readfirstlane(dma_cnt);
   auto issue_loads = [&](int patch, int stg) {
     int b, oy0, ox0;
     patch_origin(patch, b, oy0, ox0);
-    unsigned char* const sb = smem + stg * stage;
 #pragma unroll
     for (int it = 0; it < XIT; ++it) {
       const int v = it * 256 + tid;
@@ -179,16 +188,17 @@ __global__ __launch_bounds__(256, 2) void wgrad3_kernel(const Wg3Args ka) {
       const int f = ((hx >> 3) ^ (hy & ka.hymask)) & 1;
       const uint32_t pix = (uint32_t)((b * d.Hin + iy) * d.Win + ix);
       const uint32_t slb = (uint32_t)((s ^ (f << 1)) * 16);
-      if (it * 256 < ka.HPv * 4) {
+      if (it * 256 + wave * 64 < ka.HPv * 4) {                       // wave-uniform: this wave has halo slots in this iteration
 #pragma unroll
         for (int c = 0; c < CPT; ++c) {
           if (!cvalid[c]) continue;
-          if (ok) glds16(sp[c], pix * cb[c] + slb, lds0 + (unsigned)(stg * stage + c * xpl + (it * 256 + wave * 64) * 16));
-          else if (inr) *(u32x4*)(sb + c * xpl + v * 16) = (u32x4){0u, 0u, 0u, 0u};
+          const uint64_t av = (uint64_t)(uintptr_t)sp[c] + (uint64_t)(pix * cb[c] + slb);
+          const uint32_t lo = ok ? (uint32_t)av : zlo, hi = ok ? (uint32_t)(av >> 32) : zhi;
+          if (inr) glds16_flat((const unsigned char*)(uintptr_t)(((uint64_t)hi << 32) | lo),
+                               lds0 + (unsigned)(stg * stage + c * xpl + (it * 256 + wave * 64) * 16));
         }
       }
     }
-    unsigned char* const db = sb + CPT * xpl;
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
       const int v = it * 256 + tid;
@@ -200,8 +210,11 @@ __global__ __launch_bounds__(256, 2) void wgrad3_kernel(const Wg3Args ka) {
 #pragma unroll
       for (int j = 0; j < NPL; ++j) {
         const int n = n0 + j * 32 + sl * 8;
-        if (pv && n < d.N) glds16(dyp, pix * dycb + (uint32_t)(n * 2), lds0 + (unsigned)(stg * stage + CPT * xpl + j * 8192 + (it * 256 + wave * 64) * 16));
-        else *(u32x4*)(db + j * 8192 + v * 16) = (u32x4){0u, 0u, 0u, 0u};
+        const bool okn = pv && n < d.N;
+        const uint64_t av = (uint64_t)(uintptr_t)dyp + (uint64_t)(pix * dycb + (uint32_t)(n * 2));
+        const uint32_t lo = okn ? (uint32_t)av : zlo, hi = okn ? (uint32_t)(av >> 32) : zhi;
+        glds16_flat((const unsigned char*)(uintptr_t)(((uint64_t)hi << 32) | lo),
+                    lds0 + (unsigned)(stg * stage + CPT * xpl + j * 8192 + (it * 256 + wave * 64) * 16));
       }
     }
   };
@@ -241,40 +254,55 @@ __global__ __launch_bounds__(256, 2) void wgrad3_kernel(const Wg3Args ka) {
 
   const int p_begin = split * ka.pps;
   const int p_end = min(ka.patches, p_begin + ka.pps);
+  const int npat = p_end - p_begin;
+  const int NST = ka.nst;
   const bool mine = cvalid[cfi >> 1];                               // this wave's channel fragment exists
-  __syncthreads();                                                  // zero fill (and the affine table) visible
-  if (p_begin < p_end) issue_loads(p_begin, 0);
-  for (int patch = p_begin; patch < p_end; ++patch) {
-    const int stg = (patch - p_begin) & 1;
-    dma_wait();                                                     // this wave's DMA of stage `stg` has landed ...
-    __syncthreads();                                                // ... and everybody's; the other stage is free (its MFMAs are done)
+  __syncthreads();                                                  // zero fill (and the affine table) visible; no DMA is in flight yet
+  for (int j = 0; j < NST - 1 && j < npat; ++j) issue_loads(p_begin + j, j);
+  int stg = 0;
+  for (int i = 0; i < npat; ++i) {
+    const int patch = p_begin + i;
+    const int ahead = min(NST - 2, npat - 1 - i);                   // stages issued after this patch's
+    vm_wait(ahead * dma_cnt);                                       // this wave's DMA of stage `stg` has landed ...
+    lds_barrier();                                                  // ... and everybody's; the stage of patch i-1 is free (its MFMAs are done)
+    if (i + NST - 1 < npat) issue_loads(patch + NST - 1, stg == 0 ? NST - 1 : stg - 1);
     if constexpr (AFF) {
       transform(patch, stg);
-      __syncthreads();
+      lds_barrier();
     }
-    if (patch + 1 < p_end) issue_loads(patch + 1, stg ^ 1);         // in flight during the MFMAs below
-    if (!mine) continue;
     const unsigned so = (unsigned)(stg * stage);
-    // flat (k-step, tap) sequence with the NEXT tap's X fragment requested before the MFMAs of the current one
-    u32x4 af = tr_frag(a_tab[0][0][0] + so, a_tab[0][0][1] + so);
+    stg = stg + 1 == NST ? 0 : stg + 1;
+    if (!mine) continue;
+    // flat (k-step, tap) sequence q = 9 ks + t.  A wave that is alone on its SIMD gets its transposed fragments back after the
+    // LDS latency (MI355X_MICROARCH.md, LDS: one wave reaches a fifth of the ds_read_b64 rate), and one tap is only NF MFMAs
+    // (16 cycles each): the X fragment of tap q + AD is requested right after the MFMAs of tap q have issued (ring of AD
+    // fragments), the dY fragments of the next k-step during the second half of this one (two sets).
+    constexpr int AD = !DEEP ? 1 : NF >= 4 ? 4 : (NF == 2 ? 6 : 9);   // (DEEP = false: the one-tap schedule of rounds 2-4, kept for A/B)
+    auto a_frag = [&](int q) {
+      const int ks = q / 9, t = q % 9, ty = t / 3, tx = t % 3;
+      const unsigned o = so + (unsigned)(ks * ka.kstride) + (ty == 2 ? row2 : 0u);
+      return tr_frag(a_tab[ty & 1][tx][0] + o, a_tab[ty & 1][tx][1] + o);
+    };
+    u32x4 af[AD], bf[2][NF];
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) bf[0][nf] = tr_frag(b_tab[nf][0] + so, b_tab[nf][1] + so);
+#pragma unroll
+    for (int q = 0; q < AD; ++q) af[q] = a_frag(q);
+    if constexpr (DEEP) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      const unsigned ao = so + (unsigned)(ks * ka.kstride), bo = so + (unsigned)(ks * 2048);
-      u32x4 bf[NF];
-#pragma unroll
-      for (int nf = 0; nf < NF; ++nf) bf[nf] = tr_frag(b_tab[nf][0] + bo, b_tab[nf][1] + bo);
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
-        u32x4 afn = af;
-        if (t + 1 < 9 || ks + 1 < 4) {
-          const int t1 = (t + 1) % 9;
-          const int ty = t1 / 3, tx = t1 % 3;
-          const unsigned o = (t + 1 < 9 ? ao : ao + (unsigned)ka.kstride) + (ty == 2 ? row2 : 0u);
-          afn = tr_frag(a_tab[ty & 1][tx][0] + o, a_tab[ty & 1][tx][1] + o);
+        const int q = ks * 9 + t;
+        if (t == 4 && ks + 1 < 4) {
+          const unsigned bo = so + (unsigned)((ks + 1) * 2048);
+#pragma unroll
+          for (int nf = 0; nf < NF; ++nf) bf[(ks + 1) & 1][nf] = tr_frag(b_tab[nf][0] + bo, b_tab[nf][1] + bo);
         }
 #pragma unroll
-        for (int nf = 0; nf < NF; ++nf) mma16<T>(acc[t][nf], af, bf[nf]);
-        af = afn;
+        for (int nf = 0; nf < NF; ++nf) mma16<T>(acc[t][nf], af[q % AD], bf[ks & 1][nf]);
+        if (q + AD < 36) af[q % AD] = a_frag(q + AD);
+        if constexpr (DEEP) __builtin_amdgcn_sched_barrier(0);        // (the scheduler sinks the requests back to one tap ahead otherwise)
       }
     }
   }
@@ -379,19 +407,27 @@ bool ksmi_wgrad3_geom(const ksmi_wgrad_desc* d, int dtype, ksmi_wgrad3_geom_t* g
   const int hh_alloc = 128 / g->TW + 2;
   g->xpl = hh_alloc * g->HWc * 64;
   g->stage = (g->WC / 2) * g->xpl + (g->NTL / 32) * 8192;
-  g->lds = 2 * g->stage + 1024;                                    // slack: AFF table
-  if (g->lds > 160 * 1024) return false;
+  if (2 * (size_t)g->stage + 1024 > 160 * 1024) return false;
+  // LDS ring: KSMI_WGRAD3_NST = 3 / 4 lets a workgroup that owns its CU (at most 256 workgroups) keep up to that many stages
+  // (patches i+1 .. i+nst-1 in flight during the MFMAs of patch i); the default is two stages and two workgroups per CU.
+  const char* nst_env = getenv("KSMI_WGRAD3_NST");                  // (read per call: the tests force each depth)
+  const int nst_want = nst_env && atoi(nst_env) >= 2 ? atoi(nst_env) : 2;
+  int nst_max = (int)((160 * 1024 - 1024) / g->stage);
+  if (nst_max > 4) nst_max = 4;
+  if (nst_want < nst_max) nst_max = nst_want;
   // number of workgroups: every workgroup dumps its 9 x CT x NTL fp32 tile once, so small gradients pay for many splits in slab
   // traffic (K = N = 64 at 512 workgroups: 75 MB of slabs against 103 MB of operands), while too few workgroups cannot keep
-  // HBM busy (one stage in flight each).  Pick the count that minimises, in microseconds with coarse measured constants,
-  //   max(MFMA time, operand bytes / min(4.5 TB/s, workgroups x stage / 5 us)) + slab write + slab read.
-  static const int wg_force = getenv("KSMI_WGRAD3_WGS") ? atoi(getenv("KSMI_WGRAD3_WGS")) : 0;
+  // HBM busy.  Pick the count that minimises, in microseconds with coarse measured constants,
+  //   max(MFMA time, operand bytes / min(4.5 TB/s, workgroups x stages in flight / 5 us)) + slab write + slab read.
+  const char* wg_env = getenv("KSMI_WGRAD3_WGS");                   // (read per call: the tests shrink the grid so that the ring wraps)
+  const int wg_force = wg_env ? atoi(wg_env) : 0;
   const int tiles = g->KT * g->NTt;
   const int nfw = (g->NTL / 16) / (4 / g->WC);                      // column fragments per wave
   const double t_patch = 4.0 * 9.0 * nfw * 16.0 / 2100.0;           // one 128-pixel patch on one wave at the MFMA rate
   const double tile_mb = 9.0 * (g->WC * 16) * g->NTL * 4.0 / 1e6;
   const double op_bytes = (double)d->B * H * W * (d->nchunks * 32.0 + npad) * 2.0;
-  const int max_per_cu = (int)(160 * 1024 / g->lds) < 4 ? (int)(160 * 1024 / g->lds) : 4;
+  const size_t lds2 = 2 * (size_t)g->stage + 1024;
+  const int max_per_cu = (int)(160 * 1024 / lds2) < 4 ? (int)(160 * 1024 / lds2) : 4;
   static const double eff[5] = {0.0, 0.55, 0.8, 0.85, 0.9};         // MFMA-phase efficiency by workgroups per CU (DMA waits overlap)
   double best_t = 1e30;
   static const int cand[] = {128, 192, 256, 384, 512, 768, 1024};
@@ -405,13 +441,16 @@ bool ksmi_wgrad3_geom(const ksmi_wgrad_desc* d, int dtype, ksmi_wgrad3_geom_t* g
     const int ns = (g->patches + pps - 1) / pps;
     int per_cu = (ns * tiles + 255) / 256;
     if (per_cu > 4) per_cu = 4;
-    double t_main = pps * t_patch * per_cu / eff[per_cu];
-    double bw = (double)ns * tiles * g->stage / 5.0;                 // bytes per microsecond in flight
+    const int nst = per_cu == 1 ? nst_max : 2;
+    const double e = (per_cu == 1 && nst > 2) ? 0.8 : eff[per_cu];
+    double t_main = pps * t_patch * per_cu / e;
+    double bw = (double)ns * tiles * g->stage * (nst - 1) / 5.0;     // bytes per microsecond in flight
     if (bw > 4.5e6) bw = 4.5e6;
     if (t_main < op_bytes / bw) t_main = op_bytes / bw;
     const double t = t_main + 7.0 + 2.0 * ns * tiles * tile_mb / 4.0;
-    if (t < best_t) { best_t = t; g->pps = pps; g->nsplit = ns; }
+    if (t < best_t) { best_t = t; g->pps = pps; g->nsplit = ns; g->nst = nst; }
   }
+  g->lds = (size_t)g->nst * g->stage + 1024;                        // slack: AFF table
   return true;
 }
 
@@ -433,25 +472,30 @@ int ksmi_wgrad3_launch(const ksmi_wgrad_desc* d, const ksmi_wgrad3_geom_t* g, hi
   ka.kstride = (32 / g->TW) * g->HWc * 64;
   ka.hymask = g->TW == 8 ? 1 : 0;
   ka.lds_bytes = (int)g->lds;
+  ka.nst = g->nst;
+  static void* zero_page = nullptr;
+  if (!zero_page && hipGetSymbolAddress(&zero_page, HIP_SYMBOL(wg3_zero_page)) != hipSuccess) return ksmi_fail(KSMI_E_UNSUPPORTED, "wgrad3: zero page");
+  ka.zero = (const unsigned char*)zero_page;
   if ((size_t)g->patches * 1 >= ((size_t)1 << 31) / 1024) return ksmi_fail(KSMI_E_UNSUPPORTED, "wgrad3: too many patches");
   const dim3 grid(g->nsplit * g->KT * g->NTt);
   const bool aff = d->src[0].scale != nullptr;
+  static const bool deep = !(getenv("KSMI_WGRAD3_DEEP") && atoi(getenv("KSMI_WGRAD3_DEEP")) == 0);   // fragment requests AD taps ahead (default)
+#define KSMI_W3_(WC_, WN_, NF_, AFF_, DEEP_)                                                          \
+  do {                                                                                               \
+    auto kfn = wgrad3_kernel<WC_, WN_, NF_, AFF_, DEEP_>; KSMI_NOTE(kfn);                            \
+    if (g->lds > 65536) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g->lds); \
+    hipLaunchKernelGGL(kfn, grid, dim3(256), g->lds, st, ka);                                        \
+  } while (0)
 #define KSMI_W3(WC_, WN_, NF_)                                                                       \
   do {                                                                                               \
-    if (aff) {                                                                                       \
-      auto kfn = wgrad3_kernel<WC_, WN_, NF_, true>; KSMI_NOTE(kfn);                                                 \
-      if (g->lds > 65536) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g->lds); \
-      hipLaunchKernelGGL(kfn, grid, dim3(256), g->lds, st, ka);                                      \
-    } else {                                                                                         \
-      auto kfn = wgrad3_kernel<WC_, WN_, NF_, false>; KSMI_NOTE(kfn);                                                \
-      if (g->lds > 65536) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g->lds); \
-      hipLaunchKernelGGL(kfn, grid, dim3(256), g->lds, st, ka);                                      \
-    }                                                                                                \
+    if (aff) { if (deep) KSMI_W3_(WC_, WN_, NF_, true, true); else KSMI_W3_(WC_, WN_, NF_, true, false); }   \
+    else { if (deep) KSMI_W3_(WC_, WN_, NF_, false, true); else KSMI_W3_(WC_, WN_, NF_, false, false); }     \
   } while (0)
   if (g->WC == 4 && g->NTL == 64) KSMI_W3(4, 1, 4);
   else if (g->WC == 4) KSMI_W3(4, 1, 2);
   else if (g->NTL == 64) KSMI_W3(2, 2, 2);
   else KSMI_W3(2, 2, 1);
 #undef KSMI_W3
+#undef KSMI_W3_
   return ksmi_check_launch("wgrad3");
 }

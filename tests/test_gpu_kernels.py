@@ -179,6 +179,53 @@ def test_wgrad3_channel_owner_kernel(dev, cfg):
     assert err < 2e-3, err            # operands are identical bf16 values; fp32 accumulation order differs
 
 
+@pytest.mark.parametrize("nst", ["2", "3", "4"])
+@pytest.mark.parametrize("cfg", [
+    dict(B=4, H=56, W=56, cs=[64], N=64, aff=True, wgs="3"),       # 112 patches on 3 workgroups: the ring wraps ~12 times
+    dict(B=2, H=33, W=19, cs=[64, 32], N=48, wgs="2"),             # ragged map (masked halo / columns read the zero page), 2 K tiles
+    dict(B=3, H=40, W=72, cs=[32], N=32, aff=True, wgs="5"),       # single chunk (2 x 2 waves), uneven split tail
+    dict(B=1, H=224, W=224, cs=[32, 32, 64, 32], N=32, wgs="16"),  # level-0 shape: virtual concat, 4 K tiles x 4 splits
+])
+def test_wgrad3_ring_depths(dev, cfg, nst):
+    """The LDS ring of csrc/wgrad3.hip at every depth (KSMI_WGRAD3_NST) with the grid shrunk (KSMI_WGRAD3_WGS) so that every
+    workgroup walks many patches: counted-vmcnt waits, stage reuse after the barrier, the drain at the end of a split.  The result
+    is the same fixed-order sum for every depth, so the three depths must agree BITWISE with each other and match conv2d."""
+    import os
+    from kurosiwo_amd import functional as Fk
+    dtype = torch.bfloat16
+    B, H, W, cs, N = cfg["B"], cfg["H"], cfg["W"], cfg["cs"], cfg["N"]
+    tag = f"wg3r{B}{H}{W}{cs}{N}"
+    xs = [seeded_tensor(f"{tag}.x{i}", (B, c, H, W)) for i, c in enumerate(cs)]
+    dy = seeded_tensor(tag + ".dy", (B, N, H, W))
+    q = (lambda t: t.to(dtype).float())
+    K = sum(cs)
+    aff = None
+    xq = torch.cat([q(x) for x in xs], 1)
+    if cfg.get("aff"):
+        sc, sh = 1.0 + 0.3 * seeded_tensor(tag + ".sc", (K,)), 0.2 * seeded_tensor(tag + ".sh", (K,))
+        xq = q(torch.relu(xq * sc[None, :, None, None] + sh[None, :, None, None]))
+        aff = (sc.to(dev), sh.to(dev), 1)
+    wr = torch.zeros((N, K, 3, 3)).requires_grad_(True)
+    F.conv2d(xq, wr, None, padding=1).backward(q(dy))
+    xd = [Fk.to_nhwc(x.to(dev), dtype) for x in xs]
+    dyd = Fk.to_nhwc(dy.to(dev), dtype)
+
+    def run(depth):
+        old = {k: os.environ.get(k) for k in ("KSMI_WGRAD3_NST", "KSMI_WGRAD3_WGS")}
+        os.environ["KSMI_WGRAD3_NST"], os.environ["KSMI_WGRAD3_WGS"] = depth, cfg["wgs"]
+        try:
+            return Fk.conv3x3_wgrad(xd, dyd, affine=aff).cpu()
+        finally:
+            for k, v in old.items():
+                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+
+    dw = run(nst)
+    err = float((dw - wr.grad).abs().max() / wr.grad.abs().max())
+    assert err < 2e-3, err
+    assert torch.equal(dw, run(nst)), "run-to-run difference: a stage was read before its DMA landed"
+    assert torch.equal(dw, run("2")), "ring depth changed the sum"
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_conv3x3_fused_affine_relu_operand(dev, dtype):
     from kurosiwo_amd import functional as Fk
