@@ -641,20 +641,41 @@ __global__ void up_pack_batched_kernel(const UpPackBatch b) {
     wb[e] = f32_to_bf16(wt[((int64_t)c * C + n) * 4 + d]);
   }
 }
-// grad[c][n][d] (+)= sum_split slab[split][c][d * C + n]   (slab rows k = c, columns n' = (d, n); fixed order)
-__global__ void up_wgrad_reduce_kernel(const float* __restrict__ slab, int nsplit, int C, float* __restrict__ grad, int accumulate) {
-  const int64_t n_el = (int64_t)C * C;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_el; e += (int64_t)gridDim.x * blockDim.x) {
-    const int n = (int)(e % C), c = (int)(e / C);
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    for (int sp = 0; sp < nsplit; ++sp) {
-      const float* row = slab + ((int64_t)sp * C + c) * (int64_t)(4 * C);
+// grad[c][n][d] (+)= sum_split slab[split][c][d * C + n]   (slab rows k = c, columns n' = (d, n); fixed order => deterministic)
+// The gradient is small (C x C x 4) and the splits are many (C = 64: 256 slabs), so one thread per (c, n) walking every split is a
+// 16-workgroup launch of 256 dependent strided reads (40-58 us, round-4 profiles).  Here a workgroup owns one input channel c and NB
+// output channels: its threads are SL slab lanes x 4 depths x NQ float4 columns; slab lane sl sums the splits sl, sl + SL, ... (two
+// accumulators), the lanes are combined through LDS in ascending order and written with d innermost.
+template <int SL>
+__global__ __launch_bounds__(256) void up_wgrad_reduce_kernel(const float* __restrict__ slab, int nsplit, int C, float* __restrict__ grad, int accumulate) {
+  constexpr int NQ = 64 / SL;                              // float4 columns per depth (SL * 4 * NQ = 256 threads)
+  constexpr int NB = NQ * 4;                               // output channels per workgroup (16 | 64; C % 64 == 0)
+  __shared__ f32x4 red[SL][4][NQ];
+  const int tid = threadIdx.x;
+  const int q = tid % NQ, d = (tid / NQ) & 3, sl = tid / (NQ * 4);
+  const int nblk = C / NB;
+  const int c = blockIdx.x / nblk, n0 = (blockIdx.x - c * nblk) * NB;
+  const int64_t ss = (int64_t)C * 4 * C;
+  const float* p = slab + (int64_t)c * 4 * C + d * C + n0 + 4 * q;
+  f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+  int sp = sl;
+  for (; sp + SL < nsplit; sp += 2 * SL) { a0 += *(const f32x4*)(p + (int64_t)sp * ss); a1 += *(const f32x4*)(p + (int64_t)(sp + SL) * ss); }
+  if (sp < nsplit) a0 += *(const f32x4*)(p + (int64_t)sp * ss);
+  red[sl][d][q] = a0 + a1;
+  __syncthreads();
+  if (tid < NB) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int d = 0; d < 4; ++d) s[d] += row[d * C + n];
-    }
-    f32x4* o = (f32x4*)(grad + ((int64_t)c * C + n) * 4);
-    *o = accumulate ? *o + s : s;
+    for (int l = 0; l < SL; ++l)
+#pragma unroll
+      for (int dd = 0; dd < 4; ++dd) v[dd] += red[l][dd][tid >> 2][tid & 3];
+    f32x4* o = (f32x4*)(grad + ((int64_t)c * C + n0 + tid) * 4);
+    *o = accumulate ? *o + v : v;
   }
+}
+static void launch_up_wgrad_reduce(const float* slab, int nsplit, int C, float* grad, int accumulate, hipStream_t st) {
+  if (nsplit >= 16) hipLaunchKernelGGL(up_wgrad_reduce_kernel<16>, dim3((unsigned)(C * (C / 16))), dim3(256), 0, st, slab, nsplit, C, grad, accumulate);
+  else hipLaunchKernelGGL(up_wgrad_reduce_kernel<4>, dim3((unsigned)(C * (C / 64))), dim3(256), 0, st, slab, nsplit, C, grad, accumulate);
 }
 inline void up_wgrad_geom(int rows, int C, int* nsplit, int* rps) {
   const int tiles = (4 * C / 128) * (C / 64);
@@ -694,8 +715,7 @@ int ksmi_gemm2_up_wgrad(const void* x, const void* dy, float* slab, float* grad,
   launch_tn<2, 3>(dim3(p.atiles * p.btiles, nsplit), p, st);
   int rc = ksmi_check_launch("gemm2_up_wgrad");
   if (rc) return rc;
-  const int64_t n_el = (int64_t)C * C;
-  hipLaunchKernelGGL(up_wgrad_reduce_kernel, dim3((unsigned)((n_el + 255) / 256)), dim3(256), 0, st, slab, nsplit, C, grad, accumulate);
+  launch_up_wgrad_reduce(slab, nsplit, C, grad, accumulate, st);
   return ksmi_check_launch("up_wgrad_reduce");
 }
 

@@ -174,6 +174,7 @@ class SNUNetPlan:
     im2col_late = os.environ.get("KSMI_IM2COL_LATE", "1") != "0"   # first-layer im2col in the backward list, next to its reader
     up_gemm = os.environ.get("KSMI_UP_GEMM", "1") != "0"           # ConvTranspose2d(k2, s2) with C >= 128 as token GEMMs (ksmi_up_*)
     up_wgrad64 = os.environ.get("KSMI_UP_WGRAD64", "1") != "0"     # ... and the level-0 Up weight gradients (C = 64)
+    up_wgrad128 = os.environ.get("KSMI_UP_WGRAD128", "1") != "0"   # ... and the level-1 ones (C = 128; after the reducer was parallelised)
 
     def __init__(self, model, B, H, W, dtype, training, with_backward, tail=0):
         self.m, self.B, self.H, self.W, self.dtype = model, B, H, W, dtype
@@ -492,8 +493,8 @@ class SNUNetPlan:
         # 56^2), forward and weight gradient from C = 256 on (77 -> 57 us, 79 -> ~40 us at 28^2); at C = 128 the forward GEMM has two K
         # steps per tile and loses to the persistent 1x1 kernel (33-45 -> 80 us), the weight gradient ties (73 -> 70 us)
         up_fwd_gemm = up_gemm and Cc >= 256
-        up_wgrad_gemm = up_fwd_gemm or (self.up_gemm and self.up_wgrad64 and Cc == 64 and self.dtype == torch.bfloat16
-                                        and bool(self.lib.ksmi_up_wgrad_supported(B, H, W, Cc, self.dt)))
+        up_wgrad_gemm = up_fwd_gemm or (self.up_gemm and ((self.up_wgrad64 and Cc == 64) or (self.up_wgrad128 and Cc == 128))
+                                        and self.dtype == torch.bfloat16 and bool(self.lib.ksmi_up_wgrad_supported(B, H, W, Cc, self.dt)))
         es = self._es()
         if up_gemm:
             wb = torch.empty(4 * Cc * Cc, dtype=torch.bfloat16, device=self.dev)

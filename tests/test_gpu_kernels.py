@@ -307,13 +307,14 @@ def test_sar_preprocess_matches_dataset_pipeline():
     assert torch.allclose(out, ref, rtol=1e-6, atol=1e-6)
 
 
-def test_up_weight_gradient_c64(dev):
+@pytest.mark.parametrize("B,H,W", [(4, 24, 20), (8, 112, 112)])      # 3 splits (4 slab lanes) / 196 splits (16 slab lanes, two accumulators)
+def test_up_weight_gradient_c64(dev, B, H, W):
     """the weight gradient of the level-0 Ups (C = 64: a 128-column tile is exactly one 2C run of the depth row) on ksmi_up_wgrad"""
     import torch.nn.functional as F
     from kurosiwo_amd import _lib
     from kurosiwo_amd.runtime import stream_ptr
     lib = _lib.load()
-    B, H, W, Cc = 4, 24, 20, 64
+    Cc = 64
     assert lib.ksmi_up_wgrad_supported(B, H, W, Cc, 1) == 1 and lib.ksmi_up_gemm_supported(B, H, W, Cc, 1) == 0
     torch.manual_seed(64)
     x = (torch.randn(B, Cc, H, W, device=dev) * 0.5).bfloat16()
@@ -325,6 +326,10 @@ def test_up_weight_gradient_c64(dev):
     _lib.check(lib.ksmi_up_wgrad(x.permute(0, 2, 3, 1).contiguous().data_ptr(), dy.permute(0, 2, 3, 1).contiguous().data_ptr(), ws.data_ptr(),
                                  gw.data_ptr(), 0, B, H, W, Cc, stream_ptr()), "wgrad")
     assert float((gw - wr.grad).abs().max() / wr.grad.abs().max()) < 2e-3
+    first = gw.clone()
+    _lib.check(lib.ksmi_up_wgrad(x.permute(0, 2, 3, 1).contiguous().data_ptr(), dy.permute(0, 2, 3, 1).contiguous().data_ptr(), ws.data_ptr(),
+                                 gw.data_ptr(), 0, B, H, W, Cc, stream_ptr()), "wgrad")
+    assert torch.equal(gw, first)                 # fixed summation order
 
 
 @pytest.mark.parametrize("B,H,W,Cc", [(2, 28, 28, 128), (3, 14, 14, 256), (2, 7, 9, 512), (32, 56, 56, 128)])
