@@ -428,7 +428,10 @@ bool ksmi_wgrad3_geom(const ksmi_wgrad_desc* d, int dtype, ksmi_wgrad3_geom_t* g
   const double op_bytes = (double)d->B * H * W * (d->nchunks * 32.0 + npad) * 2.0;
   const size_t lds2 = 2 * (size_t)g->stage + 1024;
   const int max_per_cu = (int)(160 * 1024 / lds2) < 4 ? (int)(160 * 1024 / lds2) : 4;
-  static const double eff[5] = {0.0, 0.55, 0.8, 0.85, 0.9};         // MFMA-phase efficiency by workgroups per CU (DMA waits overlap)
+  // MFMA-phase efficiency by workgroups per CU.  One workgroup per CU = one wave per SIMD: nothing covers its barriers, DMA issue and
+  // operand transform (measured 3.9 us per patch against 1.1 us of MFMAs: profiles/r04_wgrad3_wgs.txt, K = N = 128 at 56^2:
+  // 76 us on 256 workgroups, 66 us on 512 in spite of twice the slab traffic)
+  static const double eff[5] = {0.0, 0.35, 0.8, 0.85, 0.9};
   double best_t = 1e30;
   static const int cand[] = {128, 192, 256, 384, 512, 768, 1024};
   for (int ci = 0; ci < 7; ++ci) {
@@ -442,7 +445,7 @@ bool ksmi_wgrad3_geom(const ksmi_wgrad_desc* d, int dtype, ksmi_wgrad3_geom_t* g
     int per_cu = (ns * tiles + 255) / 256;
     if (per_cu > 4) per_cu = 4;
     const int nst = per_cu == 1 ? nst_max : 2;
-    const double e = (per_cu == 1 && nst > 2) ? 0.8 : eff[per_cu];
+    const double e = eff[per_cu];
     double t_main = pps * t_patch * per_cu / e;
     double bw = (double)ns * tiles * g->stage * (nst - 1) / 5.0;     // bytes per microsecond in flight
     if (bw > 4.5e6) bw = 4.5e6;
