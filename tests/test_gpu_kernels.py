@@ -323,12 +323,13 @@ def test_up_weight_gradient_c64(dev, B, H, W):
     F.conv_transpose2d(x.float(), wr, None, stride=2).backward(dy.float())
     ws = torch.empty(lib.ksmi_up_wgrad_workspace(B, H, W, Cc), dtype=torch.uint8, device=dev)
     gw = torch.full((Cc, Cc, 2, 2), 3.0, device=dev)
-    _lib.check(lib.ksmi_up_wgrad(x.permute(0, 2, 3, 1).contiguous().data_ptr(), dy.permute(0, 2, 3, 1).contiguous().data_ptr(), ws.data_ptr(),
-                                 gw.data_ptr(), 0, B, H, W, Cc, stream_ptr()), "wgrad")
+    # (the NHWC copies are held in variables: a temporary's block goes back to the caching allocator the moment data_ptr() returns and
+    # the next temporary may be carved from it -- the launch then reads the wrong tensor, depending on what earlier tests left cached)
+    x_nhwc, dy_nhwc = x.permute(0, 2, 3, 1).contiguous(), dy.permute(0, 2, 3, 1).contiguous()
+    _lib.check(lib.ksmi_up_wgrad(x_nhwc.data_ptr(), dy_nhwc.data_ptr(), ws.data_ptr(), gw.data_ptr(), 0, B, H, W, Cc, stream_ptr()), "wgrad")
     assert float((gw - wr.grad).abs().max() / wr.grad.abs().max()) < 2e-3
     first = gw.clone()
-    _lib.check(lib.ksmi_up_wgrad(x.permute(0, 2, 3, 1).contiguous().data_ptr(), dy.permute(0, 2, 3, 1).contiguous().data_ptr(), ws.data_ptr(),
-                                 gw.data_ptr(), 0, B, H, W, Cc, stream_ptr()), "wgrad")
+    _lib.check(lib.ksmi_up_wgrad(x_nhwc.data_ptr(), dy_nhwc.data_ptr(), ws.data_ptr(), gw.data_ptr(), 0, B, H, W, Cc, stream_ptr()), "wgrad")
     assert torch.equal(gw, first)                 # fixed summation order
 
 
