@@ -447,7 +447,8 @@ bool ksmi_wgrad3_geom(const ksmi_wgrad_desc* d, int dtype, ksmi_wgrad3_geom_t* g
     const int nst = per_cu == 1 ? nst_max : 2;
     const double e = eff[per_cu];
     double t_main = pps * t_patch * per_cu / e;
-    double bw = (double)ns * tiles * g->stage * (nst - 1) / 5.0;     // bytes per microsecond in flight
+    double bw = (double)ns * tiles * g->stage / 5.0;                 // bytes per microsecond in flight (one stage per workgroup: a deeper
+                                                                     // ring measured no faster, and the split count must not depend on it)
     if (bw > 4.5e6) bw = 4.5e6;
     if (t_main < op_bytes / bw) t_main = op_bytes / bw;
     const double t = t_main + 7.0 + 2.0 * ns * tiles * tile_mb / 4.0;
