@@ -74,9 +74,10 @@ class LaunchList:
                 if timed:
                     timer.begin(meta["kind"], meta)
                 if streams is not None and streams.use_side and not timed and meta.get("side"):     # (a timed launch is bracketed by events on its lane's stream)
-                    rc = fn(*args, streams.fork_side())
+                    six = meta.get("side_ix", 0)
+                    rc = fn(*args, streams.fork_side(six))
                     if meta.get("side_tag") is not None:
-                        streams.mark_side(meta["side_tag"])
+                        streams.mark_side(meta["side_tag"], six)
                 else:
                     rc = fn(*args, st)
                 if timed:
@@ -97,6 +98,11 @@ class StepStreams:
 
     def __init__(self, device, lanes=True, side=True):
         self.side = torch.cuda.Stream(device=device)       # (stream priorities measured no better)
+        # KSMI_SIDE2=1 (experiment): a second side stream; the SNUNet plan alternates its weight gradients between the two by parameter
+        # (meta["side_ix"]: launches that accumulate into one gradient stay on one stream), so the slab reducer of one weight gradient
+        # runs beside the main kernel of the next
+        self.side2 = torch.cuda.Stream(device=device) if (side and os.environ.get("KSMI_SIDE2", "0") == "1") else None
+        self.side2_ptr = C.c_void_p(self.side2.cuda_stream) if self.side2 is not None else None
         self.lane1 = torch.cuda.Stream(device=device) if lanes else None
         self.lanes, self.use_side = bool(lanes), bool(side)
         self.side_ptr = C.c_void_p(self.side.cuda_stream)
@@ -121,31 +127,35 @@ class StepStreams:
         self.stream(dst).wait_event(self._event(self.stream(src)))
         self.dirty = True
 
-    def fork_side(self):
-        self.side.wait_event(self._event(torch.cuda.current_stream()))
+    def fork_side(self, ix=0):
+        two = ix and self.side2 is not None
+        (self.side2 if two else self.side).wait_event(self._event(torch.cuda.current_stream()))
         self.dirty = self.side_busy = True
-        return self.side_ptr
+        return self.side2_ptr if two else self.side_ptr
 
-    def mark_side(self, tag):
-        self.events[tag] = self._event(self.side)
+    def mark_side(self, tag, ix=0):
+        self.events[tag] = self._event(self.side2 if (ix and self.side2 is not None) else self.side)
 
     def wait_side(self, tag):
         if tag is None:
             if self.side_busy:                 # (nothing handed to the side stream since the last such wait: nothing to wait for)
                 torch.cuda.current_stream().wait_stream(self.side)
+                if self.side2 is not None:
+                    torch.cuda.current_stream().wait_stream(self.side2)
                 self.side_busy = False
         elif tag in self.events:
             torch.cuda.current_stream().wait_event(self.events.pop(tag))
 
     def all_streams(self):
         """every stream a launch of the step may have run on"""
-        return [s for s in (self.main, self.lane1 if self.lanes else None, self.side if self.use_side else None) if s is not None]
+        return [s for s in (self.main, self.lane1 if self.lanes else None, self.side if self.use_side else None,
+                            self.side2 if self.use_side else None) if s is not None]
 
     def join(self):
         """the current stream waits for every other stream of the step"""
         if self.dirty:
             cur = torch.cuda.current_stream()
-            for s in (self.main, self.lane1, self.side):
+            for s in (self.main, self.lane1, self.side, self.side2):
                 if s is not None and s.cuda_stream != cur.cuda_stream:
                     cur.wait_stream(s)
         if self.main is not None and torch.cuda.current_stream().cuda_stream == self.main.cuda_stream:
@@ -374,11 +384,23 @@ class SNUNetPlan:
         meta["tag"] = f"K={ktot} N={d.N} {d.Hout}x{d.Wout} nsrc={d.nsrc}"
         ll.add("ksmi_conv_forward", lambda: (C.byref(d), self.dt), meta)
 
+    def _side_ix(self, key):
+        """side stream of a parameter's weight gradient (KSMI_SIDE2=1: alternating by first appearance; a parameter keeps its stream, so
+        the two launches of a shared encoder weight stay ordered)"""
+        if os.environ.get("KSMI_SIDE2", "0") != "1":
+            return 0
+        if not hasattr(self, "_side_of"):
+            self._side_of = {}
+        if key not in self._side_of:
+            self._side_of[key] = len(self._side_of) & 1
+        return self._side_of[key]
+
     def _wgrad(self, d, ws, *keys):
         self.keep.append(d)
         # the partial-slab scratch is per compute lane: with the side stream off (or a timed launch) the weight gradients of the two
-        # lanes run concurrently on their lanes' streams
-        sW = self._sname("wgrad")
+        # lanes run concurrently on their lanes' streams (and per side stream: two weight gradients in flight own two slabs)
+        six = self._side_ix(keys[0]) if keys else 0
+        sW = self._sname("wgrad" + ("_s2" if six else ""))
         self.need(sW, ws)
         self.patch(d, "partial", sW)
         taps, es = d.KH * d.KW, self._es()
@@ -388,6 +410,7 @@ class SNUNetPlan:
                 "flops": 2 * pout * d.N * ktot * taps}
         meta["tag"] = f"{keys[0] if keys else '?'} K={ktot} N={d.N} {d.Hout}x{d.Wout}"
         meta["side"] = True                  # off the critical path: eligible for the side stream (LaunchList.run)
+        meta["side_ix"] = six
         self.bwd.add("ksmi_conv_wgrad", lambda: (C.byref(d), self.dt), meta)
         self._mark(*keys)
 
@@ -525,12 +548,13 @@ class SNUNetPlan:
                 d2.wpk = w2.data_ptr()
                 self._conv(self.bwd, d2, "dgrad")
             if up_wgrad_gemm:
-                sW = self._sname("wgrad")
+                six = self._side_ix(wkey)
+                sW = self._sname("wgrad" + ("_s2" if six else ""))
                 self.need(sW, self.lib.ksmi_up_wgrad_workspace(B, H, W, Cc))
                 a_w = self._acc_param(wkey)
                 self.bwd.add("ksmi_up_wgrad", lambda: (x.t.data_ptr(), gy.data_ptr(), self.scr(sW), self.m._g(wkey).data_ptr(), a_w, B, H, W, Cc),
                              {"kind": "up_gemm_wgrad", "bytes": B * H * W * Cc * 5 * es + 16 * Cc * Cc, "flops": 2 * B * H * W * Cc * 4 * Cc,
-                              "tag": f"{wkey} K={Cc} N={4 * Cc} {H}x{W}", "side": True})
+                              "tag": f"{wkey} K={Cc} N={4 * Cc} {H}x{W}", "side": True, "side_ix": six})
                 self._mark(wkey)
             else:
                 # weight gradient: G[tap d][k = n][col = c] -> grad[c*(4C) + n*4 + d]
