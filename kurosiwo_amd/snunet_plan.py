@@ -75,9 +75,9 @@ class LaunchList:
                     timer.begin(meta["kind"], meta)
                 if streams is not None and streams.use_side and not timed and meta.get("side"):     # (a timed launch is bracketed by events on its lane's stream)
                     six = meta.get("side_ix", 0)
-                    rc = fn(*args, streams.fork_side(six))
+                    rc = fn(*args, streams.fork_side(six) if six else streams.fork_side())
                     if meta.get("side_tag") is not None:
-                        streams.mark_side(meta["side_tag"], six)
+                        streams.mark_side(meta["side_tag"], six) if six else streams.mark_side(meta["side_tag"])
                 else:
                     rc = fn(*args, st)
                 if timed:
