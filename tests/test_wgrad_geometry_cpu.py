@@ -66,3 +66,23 @@ def test_square_layers_of_levels_2_to_4_take_two_workgroups_per_cu():
     for H, C in ((56, 128), (28, 256), (14, 512)):
         ns = _nsplit(32, H, [C], C)
         assert 256 < ns * _tiles(C, C) <= 512, (H, C, ns)
+
+
+@pytest.mark.parametrize("B,H,W,C", [(32, 112, 112, 64), (32, 56, 56, 128), (32, 28, 28, 256), (32, 14, 14, 512), (4, 24, 20, 64), (2, 7, 9, 512)])
+def test_up_weight_gradient_workspace_is_whole_slabs(B, H, W, C):
+    """ksmi_up_wgrad_workspace (csrc/gemm2.hip: up_wgrad_geom): whole [C][4C] fp32 slabs, at least 8 reduction steps of 64 rows per
+    split, ~two workgroups per CU at the full-size shapes (models/snunet.py:32-46 backward)"""
+    from kurosiwo_amd import _lib
+    lib = _lib.load()
+    assert lib.ksmi_up_wgrad_supported(B, H, W, C, 1) == 1
+    ws = lib.ksmi_up_wgrad_workspace(B, H, W, C)
+    slab = C * 4 * C * 4
+    assert ws % slab == 0
+    nsplit = ws // slab
+    rows = B * H * W
+    steps = -(-rows // 64)
+    assert 1 <= nsplit <= max(1, steps // 8)
+    tiles = (4 * C // 128) * (C // 64)
+    assert nsplit * tiles <= 512 + tiles
+    if rows >= 32 * 14 * 14 and steps // 8 >= 512 // tiles:
+        assert nsplit * tiles >= 256
