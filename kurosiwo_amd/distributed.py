@@ -86,8 +86,10 @@ def shard_batch(batch, rank=None, world=None, even=True):
 
 
 class RankShardBatchSampler(torch.utils.data.Sampler):
-    """batch_sampler of the DataLoader route under data parallelism: every rank draws the SAME global order (one seeded permutation
-    per epoch when shuffling: what a single process with this seed would iterate) and loads ONLY its contiguous slice
+    """batch_sampler of the DataLoader route under data parallelism: every rank draws the SAME global order (one permutation per
+    epoch seeded with seed + epoch when shuffling; the trainers call set_epoch(epoch) -- see set_loader_epoch -- so a resumed run
+    continues with the permutation of its epoch; a world-1 run keeps the reference's DataLoader(shuffle=True) on torch's global
+    generator, whose order is a different one) and loads ONLY its contiguous slice
     [r*B/W, (r+1)*B/W) of every global batch, instead of every rank decoding all B samples and distributed.shard_batch throwing
     (W-1)/W of them away.  drop_last as utilities/utilities.py:96-103 (train); a ragged last batch (evaluation) is cut the way
     shard_batch(even=False) cuts it: rank r takes [n*r//W, n*(r+1)//W), possibly empty (the loader then skips nothing: an empty
@@ -117,6 +119,13 @@ class RankShardBatchSampler(torch.utils.data.Sampler):
             idx = order[b * self.bs:(b + 1) * self.bs]
             m = len(idx)
             yield idx[m * self.rank // self.world:m * (self.rank + 1) // self.world]
+
+
+def set_loader_epoch(loader, epoch):
+    """tell a rank-sharded loader which epoch's permutation to draw (no-op for loaders without a RankShardBatchSampler)"""
+    bs = getattr(loader, "batch_sampler", None)
+    if isinstance(bs, RankShardBatchSampler):
+        bs.set_epoch(epoch)
 
 
 def sharded_collate(samples):

@@ -103,6 +103,7 @@ def train_change_detection(model, train_loader, val_loader, test_loader, configs
         print(f'===== checkpoint_path: {configs["checkpoint_path"]} ====')
     for epoch in range(0, configs["epochs"]):
         model.train()
+        D.set_loader_epoch(train_loader, epoch)
         metrics.reset()
         loss_acc = torch.zeros(3, dtype=torch.float32, device=dev)
         nb = 0
@@ -172,6 +173,8 @@ def eval_change_detection(model, loader, settype, configs=None, model_configs=No
     with torch.no_grad():
         for batch in loader:
             batch = D.shard_batch(batch, even=False)
+            if len(batch) == 0:        # this rank's slice of a ragged last batch is empty (n % batch < world): nothing to evaluate,
+                continue               # the all-reduce below still runs once on every rank
             if fused:
                 (xA, xB, xdem), mask = _fused_inputs(batch, configs)
             else:

@@ -35,6 +35,7 @@ def train_semantic_segmentation(model, train_loader, val_loader, test_loader, co
     weights = configs.get("class_weights", [1.0, 1.0, 1.0])
     for epoch in range(configs["epochs"]):
         model.train()
+        D.set_loader_epoch(train_loader, epoch)
         metrics.reset()
         loss_acc = torch.zeros(3, dtype=torch.float32, device=dev)
         nb = 0
@@ -85,6 +86,8 @@ def eval_semantic_segmentation(model, loader, configs=None, settype="Test", mode
     with torch.no_grad():
         for batch in loader:
             batch = D.shard_batch(batch, even=False)
+            if len(batch) == 0:        # empty slice of a ragged last batch on this rank (see eval_change_detection)
+                continue
             image, mask = seg_inputs(batch, configs["inputs"], bool(configs["dem"]))
             if image.shape[0] == 0:
                 continue

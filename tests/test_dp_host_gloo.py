@@ -114,3 +114,57 @@ def test_sharded_loader_batches_pass_through_shard_batch():
     assert [b[1].tolist() for b in got] == [[2, 3], [6, 7], [9]]
     assert all(type(b).__name__ == "ShardedBatch" for b in got)
     assert D.shard_batch(got[0], rank=1, world=2) is got[0]
+
+
+def test_eval_loops_skip_an_empty_rank_slice(monkeypatch):
+    """a ragged last evaluation batch with fewer samples than ranks (n % batch < world) gives some ranks an EMPTY slice
+    (ShardedBatch(())): both eval loops skip it before they index the tuple -- ADVICE round 4: it raised IndexError on the empty
+    ranks while the others waited in the all-reduce.  The device-side pieces (metrics, loss) are stubbed: this is the host loop."""
+    from kurosiwo_amd import distributed as D
+    from kurosiwo_amd.synthetic import make_batch
+    from kurosiwo_amd.training import change_detection_trainer as T, segmentation_trainer as S
+    n, bs, W, rank = 11, 8, 8, 0
+
+    class Tiles(torch.utils.data.Dataset):
+        def __init__(self):
+            self.b = make_batch(n, 16, 16, seed=3)
+
+        def __len__(self):
+            return n
+
+        def __getitem__(self, i):
+            return tuple([v[i] for v in t] if isinstance(t, list) else t[i] for t in self.b)
+
+    class CM:
+        def __init__(self, dev):
+            self.cm, self.seen = torch.zeros((4, 4), dtype=torch.int64), 0
+
+        def update(self, out, mask):
+            self.seen += out.shape[0]
+            self.cm[0, 0] += out.shape[0]
+
+        def compute(self):
+            z = torch.zeros(4)
+            return {"accuracy": 0.0, "f1": z, "iou": z, "miou": 0.0, "precision": z, "recall": z}
+
+    class Net(torch.nn.Module):
+        def forward(self, *xs):
+            return torch.zeros((xs[0].shape[0], 3, 16, 16))
+
+    sampler = D.RankShardBatchSampler(n, bs, False, False, rank, W)
+    slices = list(sampler)
+    assert slices == [[0], []]                                       # second (ragged) batch: 3 samples over 8 ranks, rank 0 gets none
+    loader = torch.utils.data.DataLoader(Tiles(), batch_sampler=sampler, collate_fn=D.sharded_collate)
+    cfg = {"device": "cpu", "method": "snunet", "inputs": ["pre_event_1", "post_event"], "dem": False, "loss_function": "cross_entropy"}
+    seen = []
+    for mod in (T, S):
+        monkeypatch.setattr(mod, "ConfusionMetrics", CM)
+        monkeypatch.setattr(mod, "create_loss", lambda configs, mode="val": (lambda out, mask: torch.zeros(())))
+        monkeypatch.setattr(mod, "_print_metrics", lambda *a, **k: None, raising=False)
+    monkeypatch.setattr(T, "_eval_fusion", lambda *a: False)
+    acc, f1, miou = T.eval_change_detection(Net(), loader, "Val", configs=cfg)
+    S.eval_semantic_segmentation(Net(), loader, configs=cfg, settype="Val")
+    # set_loader_epoch reaches the sampler through the loader (and ignores plain loaders)
+    D.set_loader_epoch(loader, 5)
+    assert sampler.epoch == 5
+    D.set_loader_epoch(torch.utils.data.DataLoader(Tiles(), batch_size=4), 2)
