@@ -4,6 +4,23 @@
 int ksmi_fail(int code, const char* msg);          // records msg, returns code
 int ksmi_check_launch(const char* what);           // hipGetLastError() -> 0 or positive hipError_t
 
+// Address of a __device__ symbol (the zero pages the LDS-DMA loaders read padding from) on the CURRENT device, cached per device:
+// a process that drives several GPUs must not hand device 1 the address device 0 resolved.  Concurrent first calls
+// resolve the same value twice at worst.  Defines `static const unsigned char* fn()`; nullptr = lookup failed.
+#define KSMI_MAX_DEVICES 64
+#define KSMI_DEVICE_SYMBOL_GETTER(fn, sym)                                                                          \
+  static const unsigned char* fn() {                                                                                \
+    static void* cache[KSMI_MAX_DEVICES];                                                                           \
+    int dev = 0;                                                                                                    \
+    if (hipGetDevice(&dev) != hipSuccess || (unsigned)dev >= KSMI_MAX_DEVICES) return nullptr;                      \
+    void* p = __atomic_load_n(&cache[dev], __ATOMIC_ACQUIRE);                                                       \
+    if (!p) {                                                                                                       \
+      if (hipGetSymbolAddress(&p, HIP_SYMBOL(sym)) != hipSuccess) return nullptr;                                   \
+      __atomic_store_n(&cache[dev], p, __ATOMIC_RELEASE);                                                           \
+    }                                                                                                               \
+    return (const unsigned char*)p;                                                                                 \
+  }
+
 // igemm2.hip: software-pipelined implicit-GEMM (LDS-DMA double buffering)
 struct ksmi_conv_desc;
 bool ksmi_igemm2_eligible(const ksmi_conv_desc* d, int dtype);

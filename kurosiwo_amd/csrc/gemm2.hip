@@ -334,6 +334,7 @@ struct Gemm2T {
   int map_a, up_H, up_W, up_C;         // A-side rows are the depth rows of a ConvTranspose2d(k2, s2) output gradient (Gemm2P.map_a)
 };
 __device__ __attribute__((aligned(64))) unsigned char gemm2_zero_page[64];
+KSMI_DEVICE_SYMBOL_GETTER(gemm2_zero, gemm2_zero_page)
 
 // SPL = 2 (round 4): the workgroup has two 4-wave groups, each with its own LDS ring, walking one HALF of the workgroup's reduction
 // range; group 1 hands its accumulators to group 0 through LDS at the end (fixed order: deterministic).  A workgroup that is alone on
@@ -589,10 +590,10 @@ bool ksmi_gemm2_tn_enabled(int K, int N, int rows_per_split) {
 int ksmi_gemm2_tn(const void* x, int x_rs, const void* dy, int dy_rs, float* slab, int npad, float* grad, int64_t g_rs, int rows, int K, int N,
                   int Kslab, int nsplit, int rows_per_split, int btile, int accumulate, float* bias_grad, int bias_accumulate, hipStream_t st) {
   if (!ksmi_gemm2_tn_enabled(K, N, rows_per_split)) return 1;
-  static void* zero_page = nullptr;
-  if (!zero_page && hipGetSymbolAddress(&zero_page, HIP_SYMBOL(gemm2_zero_page)) != hipSuccess) return ksmi_fail(KSMI_E_UNSUPPORTED, "gemm2: zero page");
+  const unsigned char* const zero_page = gemm2_zero();
+  if (!zero_page) return ksmi_fail(KSMI_E_UNSUPPORTED, "gemm2: zero page");
   Gemm2T p = {};
-  p.rows = rows; p.rows_per_split = rows_per_split; p.zero = (const unsigned char*)zero_page;
+  p.rows = rows; p.rows_per_split = rows_per_split; p.zero = zero_page;
   if (nsplit == 1 && grad) {        // direct: A = x (k contiguous in grad), B = dy
     p.a = (const bf16_t*)x; p.a_rs = x_rs; p.a_cols = K; p.b = (const bf16_t*)dy; p.b_rs = dy_rs; p.b_cols = N;
     p.out = grad; p.o_rs = g_rs; p.split_stride = 0; p.accumulate = accumulate;
@@ -701,13 +702,13 @@ size_t ksmi_gemm2_up_wgrad_workspace(int B, int H, int W, int C) {
 // dWt[c][n][d] (+)= sum_m x[m][c] dY_depth[m][(d, n)]: slab-mode gemm2_tn (A = the depth rows of d out, B = x) + the permuting reducer
 int ksmi_gemm2_up_wgrad(const void* x, const void* dy, float* slab, float* grad, int accumulate, int B, int H, int W, int C, hipStream_t st) {
   if (C % 64 || C < 64 || B * H * W < 64) return 1;          // (a 128-column A tile stays inside one 2C-element run of the depth row)
-  static void* zero_page = nullptr;
-  if (!zero_page && hipGetSymbolAddress(&zero_page, HIP_SYMBOL(gemm2_zero_page)) != hipSuccess) return ksmi_fail(KSMI_E_UNSUPPORTED, "gemm2: zero page");
+  const unsigned char* const zero_page = gemm2_zero();
+  if (!zero_page) return ksmi_fail(KSMI_E_UNSUPPORTED, "gemm2: zero page");
   const int rows = B * H * W;
   int nsplit, rps;
   up_wgrad_geom(rows, C, &nsplit, &rps);
   Gemm2T p = {};
-  p.rows = rows; p.rows_per_split = rps; p.zero = (const unsigned char*)zero_page;
+  p.rows = rows; p.rows_per_split = rps; p.zero = zero_page;
   p.a = (const bf16_t*)dy; p.a_rs = 0; p.a_cols = 4 * C; p.b = (const bf16_t*)x; p.b_rs = C; p.b_cols = C;
   p.out = slab; p.o_rs = 4 * C; p.split_stride = (int64_t)C * 4 * C; p.accumulate = 0;
   p.map_a = 1; p.up_H = H; p.up_W = W; p.up_C = C;

@@ -25,6 +25,7 @@
 namespace {
 
 __device__ __attribute__((aligned(64))) unsigned char ig3_zero_page[64];      // zero-initialised device memory
+KSMI_DEVICE_SYMBOL_GETTER(ig3_zero, ig3_zero_page)
 
 struct Ig3Args {
   ksmi_conv_desc d;
@@ -447,9 +448,9 @@ int ksmi_igemm3_launch(const ksmi_conv_desc* d, const ksmi_igemm3_geom_t* g, hip
   const char* dbg_env = getenv("KSMI_IG3_DBG");
   ka.dbg = dbg_env ? atoi(dbg_env) : 0;
   ka.tiles = g->tiles; ka.hpb = g->hpb; ka.nslot = g->nslot; ka.stage = g->stage; ka.ns = g->ns;
-  static void* zero_page = nullptr;
-  if (!zero_page && hipGetSymbolAddress(&zero_page, HIP_SYMBOL(ig3_zero_page)) != hipSuccess) return ksmi_fail(KSMI_E_UNSUPPORTED, "igemm3: zero page");
-  ka.zero = (const unsigned char*)zero_page;
+  const unsigned char* const zero_page = ig3_zero();
+  if (!zero_page) return ksmi_fail(KSMI_E_UNSUPPORTED, "igemm3: zero page");
+  ka.zero = zero_page;
   const dim3 grid(g->gx, g->gy);
   const bool aff = d->src[0].scale != nullptr;
   const int taps = d->KH * d->KW;

@@ -39,6 +39,7 @@ template <int N> __device__ __forceinline__ void vm_wait_c() {         // counte
 }
 
 __device__ __attribute__((aligned(64))) unsigned char ig4_zero_page[64];      // zero-initialised device memory
+KSMI_DEVICE_SYMBOL_GETTER(ig4_zero, ig4_zero_page)
 
 struct Ig4Args {
   ksmi_conv_desc d;
@@ -773,9 +774,9 @@ int ksmi_igemm4_launch(const ksmi_conv_desc* d, const ksmi_igemm4_geom_t* g, hip
   ka.rot = rot;
   ka.hslot = g->hslot; ka.nh = g->nh; ka.nhs = g->nhs;
   ka.tiles = g->tiles; ka.gx = g->gx; ka.gy = g->gy;
-  static void* zero_page = nullptr;
-  if (!zero_page && hipGetSymbolAddress(&zero_page, HIP_SYMBOL(ig4_zero_page)) != hipSuccess) return ksmi_fail(KSMI_E_UNSUPPORTED, "igemm4: zero page");
-  ka.zero = (const unsigned char*)zero_page;
+  const unsigned char* const zero_page = ig4_zero();
+  if (!zero_page) return ksmi_fail(KSMI_E_UNSUPPORTED, "igemm4: zero page");
+  ka.zero = zero_page;
   const dim3 grid(g->gx * g->gy);
   const bool aff = d->src[0].scale != nullptr, mask = d->mask_src != nullptr, gate = d->gate_src != nullptr;
 #define KSMI_G4(WM_, NF_, AFF_, MASK_)                                                               \

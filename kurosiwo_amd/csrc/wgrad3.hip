@@ -40,6 +40,7 @@ struct Wg3Args {
 };
 
 __device__ __attribute__((aligned(64))) unsigned char wg3_zero_page[64];     // zero-initialised device memory
+KSMI_DEVICE_SYMBOL_GETTER(wg3_zero, wg3_zero_page)
 
 // LDS-DMA issued from inline asm (dma.h): hipcc (ROCm 7.2) puts `s_waitcnt vmcnt(0)` in front of every ds_read_b64_tr_b16 that
 // follows a __builtin_amdgcn_global_load_lds (the transposed-read intrinsic carries no memory operand, so it may alias the DMA),
@@ -477,9 +478,9 @@ int ksmi_wgrad3_launch(const ksmi_wgrad_desc* d, const ksmi_wgrad3_geom_t* g, hi
   ka.hymask = g->TW == 8 ? 1 : 0;
   ka.lds_bytes = (int)g->lds;
   ka.nst = g->nst;
-  static void* zero_page = nullptr;
-  if (!zero_page && hipGetSymbolAddress(&zero_page, HIP_SYMBOL(wg3_zero_page)) != hipSuccess) return ksmi_fail(KSMI_E_UNSUPPORTED, "wgrad3: zero page");
-  ka.zero = (const unsigned char*)zero_page;
+  const unsigned char* const zero_page = wg3_zero();
+  if (!zero_page) return ksmi_fail(KSMI_E_UNSUPPORTED, "wgrad3: zero page");
+  ka.zero = zero_page;
   if ((size_t)g->patches * 1 >= ((size_t)1 << 31) / 1024) return ksmi_fail(KSMI_E_UNSUPPORTED, "wgrad3: too many patches");
   const dim3 grid(g->nsplit * g->KT * g->NTt);
   const bool aff = d->src[0].scale != nullptr;

@@ -10,6 +10,8 @@ def initialize_cd_model(configs, model_configs, phase="train"):
     if method == "snunet":
         model = SNUNet_ECAM(configs["num_channels"], configs["num_classes"], base_channel=model_configs["base_channel"],
                             precision=configs.get("precision", "bf16" if configs.get("mixed_precision") else "fp32"))
+        if configs.get("sync_bn") is not None:                     # optional key (not in the reference's configs): SyncBN under data parallelism
+            model.sync_bn = bool(configs["sync_bn"])
     elif method == "changeformer":
         from .changeformer import ChangeFormerV6
         if model_configs.get("multi_scale_train"):

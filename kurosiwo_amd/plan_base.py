@@ -35,6 +35,9 @@ class PlanBase:
         # deferred row reductions (LayerNorm dgamma / dbeta, long-axis bias and depthwise weight gradients): one batched launch per
         # `rowsum_batch` producer launches instead of one tiny launch each (single-stream plans pay every launch in full)
         self._rs_entries, self._rs_slots = [], 0
+        # (read per plan, not at import: tests and A/B runs vary them between plans of one process)
+        self.csum_rows = max(1, int(os.environ.get("KSMI_CSUM_ROWS", "512")))
+        self.rowsum_batch = max(1, int(os.environ.get("KSMI_ROWSUM_BATCH", "16")))
         # bf16 mirror of the parameter arena for the token GEMMs (gemm.hip): one cast launch per step
         self.wb = None
         if dtype == torch.bfloat16 and not os.environ.get("KSMI_LINEAR_IGEMM"):
@@ -47,8 +50,7 @@ class PlanBase:
     def _wb_ptr(self, key):
         return self.wb.data_ptr() + 2 * self.m._poff[key]
 
-    csum_rows = max(1, int(os.environ.get("KSMI_CSUM_ROWS", "512")))
-    rowsum_batch = max(1, int(os.environ.get("KSMI_ROWSUM_BATCH", "16")))
+    csum_rows, rowsum_batch = 512, 16          # class defaults; _init_base reads KSMI_CSUM_ROWS / KSMI_ROWSUM_BATCH per plan
 
     def _finish(self):
         self._flush_rowsums()
@@ -112,6 +114,10 @@ class PlanBase:
     def _defer_rowsum(self, key, slot, off, rows, K, k, Cstride, Cc):
         """grad[key][c] (+)= sum_r partial[(r*K + k)*Cstride + c], partial = scratch `slot` + off bytes (written by the launch just
         appended to self.bwd), in the next batched reduction.  Entries of one key inside a batch chain behind the first."""
+        # the recycled slots and the batched reducer rely on list order on ONE stream: a producer handed to the side stream would race
+        # the slot's next owner and the reducer (ADVICE round 4)
+        if self.bwd.pending and self.bwd.pending[-1][2].get("side"):
+            raise AssertionError(f"deferred row sum of {key}: its producer launch is side-stream tagged")
         acc = self._acc_param(key, deferred=True)
         prev = [i for i, e in enumerate(self._rs_entries) if e["key"] == key]
         self._rs_entries.append(dict(key=key, slot=slot, off=off, rows=rows, K=K, k=k, Cstride=Cstride, C=Cc,

@@ -54,6 +54,10 @@ class SNUNet_ECAM(nn.Module):
             raise _lib.KsmiError("SNUNet_ECAM (HIP): out_ch must be 3 (num_classes of the reference configs)")
         self.in_channels, self.out_ch, self.base_channel = in_channels, out_ch, base_channel
         self.precision = precision            # "bf16" (performance) | "fp32" (parity)
+        # optional: BatchNorm statistics over the global batch under data parallelism (snunet_plan.SNUNetPlan.sync_bn; KSMI_SYNC_BN=1 or
+        # configs["sync_bn"]); default = the reference's per-process BatchNorm
+        import os as _os
+        self.sync_bn = _os.environ.get("KSMI_SYNC_BN", "0") == "1"
         n = base_channel
         self._pspec, self._bspec, self._ispec = OrderedDict(), OrderedDict(), OrderedDict()
         for item in _blocks(n, in_channels):
@@ -255,10 +259,11 @@ class SNUNet_ECAM(nn.Module):
         self._ensure_arena()
         # the key carries a version counter, not id(tensor): _raw_ptrs() moves the tensor to the device (a new object), and a freed
         # tensor's id can be handed out again
-        key = (B, H, W, self.act_dtype(), bool(training), bool(with_backward), None if self._raw_norm is None else self._raw_version, tail)
+        key = (B, H, W, self.act_dtype(), bool(training), bool(with_backward), None if self._raw_norm is None else self._raw_version, tail,
+               bool(self.sync_bn))
         if key not in self._plans:
             from .snunet_plan import SNUNetPlan
-            plan = SNUNetPlan(self, B, H, W, self.act_dtype(), training, with_backward, tail=tail)
+            plan = SNUNetPlan(self, B, H, W, self.act_dtype(), training, with_backward, tail=tail, sync_bn=self.sync_bn)
             if self._raw_norm is not None:
                 plan.keep.append(self._raw_norm)   # the plan's launches hold data_ptr()s into it
             self._plans[key] = plan

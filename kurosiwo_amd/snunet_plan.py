@@ -37,6 +37,13 @@ class LaunchList:
     def add_wait(self, src, dst):
         self.pending.append(("@wait", lambda: (src, dst), {"kind": "wait", "bytes": 0, "flops": 0, "lane": dst}))
 
+    def add_allreduce(self, tensor_fn, meta=None):
+        """SyncBN (optional): SUM `tensor_fn()` (a small fp32 statistics tensor) over the ranks, in place, on the stream of
+        the issuing lane, between the launch that wrote it and the launch that reads it"""
+        m = {"kind": "syncbn_allreduce", "bytes": 0, "flops": 0, "lane": self.cur_lane}
+        m.setdefault("stage", self.cur_stage)
+        self.pending.append(("@allreduce", lambda: (tensor_fn(),), m | (meta or {})))
+
     def add_wait_side(self, tag=None):
         """the issuing lane waits for the side-stream launch that carries meta["side_tag"] == tag (None: for everything handed to the
         side stream so far): placed before a launch that overwrites an operand of that weight gradient (plans that recycle buffers)"""
@@ -57,6 +64,16 @@ class LaunchList:
         st, cur = stream_ptr(), 0
         try:
             for idx, (fn, args, name, meta) in enumerate(self.calls):
+                if fn is None and name == "@allreduce":
+                    lane = meta["lane"] if streams is not None and streams.lanes else 0
+                    if lane != cur:
+                        torch.cuda.set_stream(streams.stream(lane))
+                        st, cur = stream_ptr(), lane
+                    from . import distributed as D
+                    D.all_reduce_sum_(args[0])                       # (stream-ordered on RCCL; gloo stages through the host)
+                    if hook is not None:
+                        hook(idx)
+                    continue
                 if fn is None:
                     if name == "@wait_side":
                         if streams is not None and streams.use_side:
@@ -186,8 +203,18 @@ class SNUNetPlan:
     up_wgrad64 = os.environ.get("KSMI_UP_WGRAD64", "1") != "0"     # ... and the level-0 Up weight gradients (C = 64)
     up_wgrad128 = os.environ.get("KSMI_UP_WGRAD128", "1") != "0"   # ... and the level-1 ones (C = 128; after the reducer was parallelised)
 
-    def __init__(self, model, B, H, W, dtype, training, with_backward, tail=0):
+    def __init__(self, model, B, H, W, dtype, training, with_backward, tail=0, sync_bn=False):
         self.m, self.B, self.H, self.W, self.dtype = model, B, H, W, dtype
+        # SyncBN (optional, SURVEY.md §8(e) "second-order items"): BatchNorm statistics of the GLOBAL batch -- the statistics rows of every
+        # BatchNorm call (forward: sum, sum of squares; backward: sum g, sum g * xhat) are summed over the ranks before they are
+        # finished, with the global pixel count.  Data parallelism with it equals one process on the whole batch
+        # (tests/test_gpu_dp.py::test_syncbn_two_ranks_equal_single_process); the default (off) is the reference's per-rank BatchNorm
+        # (models/snunet.py:16,18 under DataParallel-free training).  Uses the unfused statistics passes (one tiny collective per call).
+        from . import distributed as _D
+        self.sync_bn = bool(sync_bn) and training
+        self.bn_world = _D.world_size() if self.sync_bn else 1
+        if self.sync_bn:
+            self.bn_fused = False
         self.training, self.with_backward = training, with_backward
         self.dev = model.flat_params.device
         self.dt = DT[dtype]
@@ -628,9 +655,13 @@ class SNUNetPlan:
                 self.patch(d1, "stats", sS)
             self._conv(self.fwd, d1)
 
+        gcount = float(npix * self.bn_world)                         # pixels the statistics describe (SyncBN: of all ranks)
+
         def bn_fin(bn, sv, rows, cpad):
             nbt = m._c(f"{name}.{bn}.num_batches_tracked").data_ptr()
-            self.fwd.add("ksmi_bn_finalize", lambda: (stats(), rows, cpad, Cc, float(npix), P(f"{bn}.weight"), P(f"{bn}.bias"),
+            if self.sync_bn:                                          # rows of all ranks add up element-wise; the finish sums the rows
+                self.fwd.add_allreduce(lambda rows=rows, cpad=cpad: self._bufs[sS][:rows * 2 * cpad * 4].view(torch.float32))
+            self.fwd.add("ksmi_bn_finalize", lambda: (stats(), rows, cpad, Cc, gcount, P(f"{bn}.weight"), P(f"{bn}.bias"),
                                                       Bf(f"{bn}.running_mean"), Bf(f"{bn}.running_var"), nbt,
                                                       BN_MOMENTUM, BN_EPS, 1 if training else 0,
                                                       sv.mean, sv.rstd, sv.scale, sv.shift))
@@ -695,8 +726,10 @@ class SNUNetPlan:
                 else:
                     self.bwd.add("ksmi_reduce_rows", lambda: (gst.data_ptr(), grows, 2, gpad, Cc, s2p, G("bn2.weight"), G("bn2.bias"), a_bn2))
                     self._mark(f"{name}.bn2.weight", f"{name}.bn2.bias")
+                    if self.sync_bn:          # (the parameter gradients above stay LOCAL sums: the gradient all-reduce adds them; d x needs the global ones)
+                        self.bwd.add_allreduce(lambda: sums2)
                     self.bwd.add("ksmi_bn_bwd_apply_gated", lambda: (gout, z_act.t.data_ptr(), sv2.mean, sv2.rstd, P("bn2.weight"), s2p,
-                                                                     dz.data_ptr(), float(npix), npix, Cc, dt))
+                                                                     dz.data_ptr(), gcount, npix, Cc, dt))
             else:
                 self.bwd.add("ksmi_bnrelu_bwd_reduce", lambda: (gout, out.t.data_ptr(), z_act.t.data_ptr(), sv2.mean, sv2.rstd,
                                                                 self.scr(sR), rows, npix, Cc, dt))
@@ -709,8 +742,10 @@ class SNUNetPlan:
                 else:
                     self.bwd.add("ksmi_reduce_rows", lambda: (self.scr(sR), rows, 2, Cc, Cc, s2p, G("bn2.weight"), G("bn2.bias"), a_bn2))
                     self._mark(f"{name}.bn2.weight", f"{name}.bn2.bias")
+                    if self.sync_bn:
+                        self.bwd.add_allreduce(lambda: sums2)
                     self.bwd.add("ksmi_bnrelu_bwd_apply", lambda: (gout, out.t.data_ptr(), z_act.t.data_ptr(), sv2.mean, sv2.rstd,
-                                                                   P("bn2.weight"), s2p, dz.data_ptr(), float(npix), npix, Cc, dt))
+                                                                   P("bn2.weight"), s2p, dz.data_ptr(), gcount, npix, Cc, dt))
             # conv2.bias feeds a train-mode BatchNorm: its gradient sum(dz) is analytically 0 (the reference holds
             # ~1e-6 of rounding noise there); write exact zeros instead of two reduction launches.
             if training:
@@ -732,6 +767,8 @@ class SNUNetPlan:
             if not fused:
                 self.bwd.add("ksmi_reduce_rows", lambda: (self.scr(sS), rows_g, 2, Npad, Cc, s1p, G("bn1.weight"), G("bn1.bias"), a_bn1))
                 self._mark(f"{name}.bn1.weight", f"{name}.bn1.bias")
+                if self.sync_bn:
+                    self.bwd.add_allreduce(lambda: sums1)
             # weight gradient of conv2: X = relu(bn1(i)) recomputed on load, dY = dz
             dw2, ws2 = make_wgrad(src2, dz, Cc, 0, Cc, m._g(f"{name}.conv2.weight"), 9, Cc * 9, 1,
                                   self._acc_param(f"{name}.conv2.weight"), B, H, W, H, W, 3, 3, 1, 1, dtype)
@@ -751,7 +788,7 @@ class SNUNetPlan:
                 self._defer_rowsum(f"{name}.conv1.bias", pb1, rows_b, 1, 0, Cc, Cc)
             else:
                 self.bwd.add("ksmi_bn_bwd_apply_add", lambda: (r.data_ptr(), gout, i_act.t.data_ptr(), sv1.mean, sv1.rstd,
-                                                               P("bn1.weight"), s1p, pb1.data_ptr(), rows, float(npix), npix, Cc, dt))
+                                                               P("bn1.weight"), s1p, pb1.data_ptr(), rows, gcount, npix, Cc, dt))
                 self._defer_rowsum(f"{name}.conv1.bias", pb1, rows, 1, 0, Cc, Cc)
             a_w1 = self._acc_param(f"{name}.conv1.weight")
             if first:

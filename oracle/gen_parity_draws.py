@@ -71,7 +71,7 @@ def one(mode, pz, path):
 
 def main():
     os.makedirs(CACHE, exist_ok=True)
-    jobs = [(m, p, os.path.join(CACHE, f"{m}_{i}.npz")) for m in MODES for i, p in enumerate(PERTURBS)]
+    jobs = [(m, p, os.path.join(CACHE, f"{m}_{i}.npz")) for m in reversed(MODES) for i, p in enumerate(PERTURBS)]
     todo = [j for j in jobs if not os.path.exists(j[2])]
     procs, nproc = [], int(os.environ.get("DRAW_PROCS", "4"))
     while todo or procs:

@@ -97,3 +97,57 @@ def test_single_process_is_a_noop():
     red.after_launch(0)
     red.wait()
     assert torch.equal(flat, torch.arange(10.0))
+
+
+def _syncbn_worker(rank, world, port, q):
+    """the arithmetic of snunet_plan.SNUNetPlan.sync_bn on plain tensors: statistics rows summed over the ranks, finished with the
+    GLOBAL count; backward sums (sum g, sum g xhat) all-reduced for d x while the BatchNorm parameter gradients stay local sums"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from kurosiwo_amd import distributed as D
+    g = torch.Generator().manual_seed(7)
+    Bt, Cc, H = 4, 6, 5
+    x = torch.randn(Bt, Cc, H, H, generator=g) * 2 + 1
+    w, b = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g)
+    gy = torch.randn(Bt, Cc, H, H, generator=g)
+    # whole batch, autograd (what one process computes)
+    xr = x.clone().requires_grad_(True)
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y = torch.nn.functional.batch_norm(xr, None, None, wr, br, True, 0.1, 1e-5)
+    (y * gy).sum().backward()
+    # this rank's half, statistics through the collective
+    sl = slice(rank * Bt // world, (rank + 1) * Bt // world)
+    xs, gs = x[sl], gy[sl]
+    n_local, n_glob = xs.numel() // Cc, x.numel() // Cc
+    rows = torch.stack([xs.sum((0, 2, 3)), (xs * xs).sum((0, 2, 3))])          # one statistics row of this rank: [2][C]
+    D.all_reduce_sum_(rows)
+    mean = rows[0] / n_glob
+    var = rows[1] / n_glob - mean * mean
+    rstd = (var + 1e-5).rsqrt()
+    xh = (xs - mean.view(1, -1, 1, 1)) * rstd.view(1, -1, 1, 1)
+    ys = xh * w.view(1, -1, 1, 1) + b.view(1, -1, 1, 1)
+    sums = torch.stack([gs.sum((0, 2, 3)), (gs * xh).sum((0, 2, 3))])          # local: these ARE the bias / weight gradients of this rank
+    dw_local, db_local = sums[1].clone(), sums[0].clone()
+    D.all_reduce_sum_(sums)                                                     # global: what d x needs
+    dx = (w * rstd).view(1, -1, 1, 1) * (gs - (sums[0] / n_glob).view(1, -1, 1, 1) - xh * (sums[1] / n_glob).view(1, -1, 1, 1))
+    dwg, dbg = dw_local.clone(), db_local.clone()
+    D.all_reduce_sum_(dwg, dbg)                                                 # the gradient all-reduce of the DP step (SUM)
+    ok = (torch.allclose(ys, y[sl].detach(), atol=1e-5) and torch.allclose(dx, xr.grad[sl], atol=1e-5)
+          and torch.allclose(dwg, wr.grad, atol=1e-4) and torch.allclose(dbg, br.grad, atol=1e-4) and n_local * world == n_glob)
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_syncbn_statistics_arithmetic_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_syncbn_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res), res

@@ -101,6 +101,89 @@ def test_two_rank_step_equals_single_rank_step_on_the_whole_batch():
         assert abs(0.5 * (l0[k] + l1[k]) - losses[k]) < 2e-4 * abs(losses[k]), (k, l0[k], l1[k], losses[k])
 
 
+def _snunet_build(sync_bn):
+    from kurosiwo_amd.snunet import SNUNet_ECAM
+    from oracle import snunet_ref as R
+    from oracle.seeded import seeded_fill_
+    m = SNUNet_ECAM(2, 3, base_channel=16, precision="fp32")
+    m.sync_bn = sync_bn
+    m.load_state_dict(seeded_fill_(R.new_state_dict(2, 3, 16)))
+    return m.cuda().train()
+
+
+def _snunet_data(B):
+    from oracle.seeded import seeded_labels, seeded_tensor
+    xA, xB = seeded_tensor("syncbn.xA", (B, 2, 64, 64)), seeded_tensor("syncbn.xB", (B, 2, 64, 64))
+    lbl = seeded_labels("syncbn.lbl", (B, 64, 64), p_invalid=0.0)       # no ignored pixels: every shard normalises by the same count
+    return xA, xB, lbl
+
+
+def _snunet_steps(model, xA, xB, lbl, n):
+    from kurosiwo_amd.optim import FusedSGD
+    from kurosiwo_amd.trainer import CDTrainStep
+    step = CDTrainStep(model, xA.shape[0], 64, 64, loss_function="ce+dice", class_weights=(1.0, 1.0, 1.0),
+                       optimizer=FusedSGD(model.parameters(), lr=0.05))
+    losses = [float(step.step(xA.cuda(), xB.cuda(), lbl.cuda())[0]) for _ in range(n)]
+    torch.cuda.synchronize()
+    return losses
+
+
+def _syncbn_worker(rank, world, port, q, sync_bn):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from kurosiwo_amd import distributed as D
+    model = _snunet_build(sync_bn)
+    D.broadcast_model_(model)
+    xA, xB, lbl = _snunet_data(4)
+    a, b, l = D.shard_batch((xA, xB, lbl), rank, world)
+    losses = _snunet_steps(model, a, b, l, 2)
+    q.put((rank, losses, model.flat_params.detach().cpu().numpy(), model.flat_buffers.detach().cpu().numpy()))
+    dist.destroy_process_group()
+
+
+def test_syncbn_two_ranks_equal_single_process():
+    """SURVEY.md §8(e) "second-order items": with the optional SyncBN switch (SNUNet_ECAM.sync_bn / KSMI_SYNC_BN=1 / configs["sync_bn"]:
+    every BatchNorm call all-reduces its statistics rows, forward (sum, sum of squares) and backward (sum g, sum g xhat), and finishes
+    them with the global pixel count) two ranks on the two halves of a batch take the optimiser steps ONE process takes on the whole
+    batch: parameters AND BatchNorm running statistics agree to fp32 rounding after two steps.  Without the switch (the reference's
+    per-process BatchNorm, models/snunet.py:16,18) the same run ends somewhere else -- the control that the switch is what is tested.
+    Both ranks share the test box's one GPU, so the group is gloo; the collective calls are the ones RCCL serves on a node."""
+    ctx = mp.get_context("spawn")
+    out = {}
+    for sync_bn in (True, False):
+        q, port = ctx.Queue(), _free_port()
+        procs = [ctx.Process(target=_syncbn_worker, args=(r, 2, port, q, sync_bn)) for r in range(2)]
+        for p in procs:
+            p.start()
+        res = sorted((q.get(timeout=600) for _ in procs), key=lambda t: t[0])
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+        out[sync_bn] = res
+    model = _snunet_build(False)
+    p0 = model.flat_params.detach().cpu().clone()
+    xA, xB, lbl = _snunet_data(4)
+    losses = _snunet_steps(model, xA, xB, lbl, 2)
+    ref_p, ref_b = model.flat_params.detach().cpu(), model.flat_buffers.detach().cpu()
+    upd = float((ref_p - p0).abs().max())
+    (r0, l0, w0, b0), (r1, l1, w1, b1) = out[True]
+    w0, w1, b0, b1 = map(torch.from_numpy, (w0, w1, b0, b1))
+    assert torch.equal(w0, w1) and torch.equal(b0, b1), "ranks diverged under SyncBN"
+    dp, db = float((w0 - ref_p).abs().max()), float((b0 - ref_b).abs().max())
+    print(f"SyncBN two ranks vs one process: max |d param| {dp:.3e} (largest update {upd:.3e}), max |d running stat| {db:.3e}; "
+          f"losses {l0} {l1} vs {losses}")
+    assert dp < 2e-3 * upd + 1e-6, (dp, upd)
+    assert db < 1e-5 * float(ref_b.abs().max()) + 1e-6, db
+    for k in range(2):                                  # mean of the shard losses = loss of the whole batch (same statistics on both sides)
+        assert abs(0.5 * (l0[k] + l1[k]) - losses[k]) < 2e-4 * abs(losses[k]), (k, l0[k], l1[k], losses[k])
+    # control: per-rank BatchNorm (the default) is a different function of the same data
+    (_, _, v0, _), _ = out[False]
+    d_plain = float((torch.from_numpy(v0) - ref_p).abs().max())
+    print(f"per-rank BatchNorm (default) two ranks vs one process: max |d param| {d_plain:.3e}")
+    assert d_plain > 20 * dp, (d_plain, dp)
+
+
 def test_every_parameter_with_a_gradient_has_a_readiness_index():
     """A parameter missing from plan.param_ready would be reduced before (or never after) its writer ran."""
     from kurosiwo_amd.snunet import SNUNet_ECAM

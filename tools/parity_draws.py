@@ -42,6 +42,11 @@ for pz in draws:
             d[k + 1] = float(evaluate(model)["miou"]) - float(gold[f"miou{k + 1}"])
     rel = np.abs(np.array(losses) - gold["losses"]) / gold["losses"]
     rows.append((pz, d[20], d[40], rel.max(), int(rel.argmax())))
+    all_losses = globals().setdefault("all_losses", [])
+    all_losses.append(losses)
     print(f"  perturb {pz:+.0e}: K=20 {d[20]:+.5f}  K=40 {d[40]:+.5f}  max rel loss dev {rel.max():.2f} at step {int(rel.argmax())}", flush=True)
 a = np.array([[r[1], r[2]] for r in rows])
 print(f"  K=20: median {np.median(a[:, 0]):+.5f}  min {a[:, 0].min():+.5f}  max {a[:, 0].max():+.5f}   |   K=40: median {np.median(a[:, 1]):+.5f}  min {a[:, 1].min():+.5f}  max {a[:, 1].max():+.5f}")
+
+if os.environ.get("DRAWS_OUT"):
+    np.savez(os.environ["DRAWS_OUT"], perturbations=np.array(draws), losses=np.array(all_losses), d20=a[:, 0], d40=a[:, 1])
