@@ -69,22 +69,34 @@ __device__ __forceinline__ int swz_h(int hx) { return ((hx >> 2) & 1) << 1; }
 // DIR: 1 = input-gradient launch of the plain variant (ksmi_conv_desc.dir): a name tag for profilers, no code difference
 // ROT: the rotated K-loop schedule (run_tiles_rot) instead of the per-role one (one schedule per instantiation: both in one kernel
 // spill hundreds of registers)
-template <int WM, int NF, bool AFF, int EPI, bool DBG = false, int DIR = 0, bool ROT = false>
-__global__ __launch_bounds__(512, 1) void igemm4_kernel(const Ig4Args ka) {
+// NWV: waves per workgroup.  8 = one 512-thread workgroup per CU (two waves per SIMD in lock step of the step barriers).  4 (round 5) =
+// 256-thread workgroups, TWO per CU, each with its own rings (halo ring of 2 slots): the two workgroups of a CU drift apart, so the
+// epilogue / store acknowledgement / tile prologue / barrier skew of one is covered by the K loop of the other.
+template <int WM, int NF, bool AFF, int EPI, bool DBG = false, int DIR = 0, int ROT = 0, int NWV = 8>
+__global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void igemm4_kernel(const Ig4Args ka) {
   typedef bf16_t T;
   constexpr bool MASK = EPI == 1, GATE = EPI == 2;
   const ksmi_conv_desc& d = ka.d;
-  constexpr int WN = 8 / WM;
+  constexpr int NT = 64 * NWV;                 // threads
+  constexpr int WN = NWV / WM;
   constexpr int BNW = 16 * NF;                 // columns per wave
   constexpr int BN = WN * BNW;                 // columns per workgroup
   constexpr int NG = NF / 2;                   // 32-column groups per wave (epilogue ownership: 8 consecutive channels per lane)
   constexpr int WSLOT = 3 * BN * 64;           // one kernel row of taps
   constexpr int WPIECES = WSLOT / 1024;        // 24 (BN = 128) / 12 (BN = 64) / 6 (BN = 32)
-  constexpr int WK = (WPIECES + 7) / 8;        // pieces per wave (at most)
-  constexpr int NHM = WM == 4 ? 3 : IG4_NHMAX;   // halo pieces per wave and slot: 24 KiB (<= 384 halo pixels) / 40 KiB (<= 640)
-  constexpr int HSLOT = NHM * 8192;
+  constexpr int WK = (WPIECES + NWV - 1) / NWV;   // pieces per wave (at most)
+  constexpr int NHM = NWV == 4 ? 6 : (WM == 4 ? 3 : IG4_NHMAX);   // halo pieces per wave and slot: 24 KiB (<= 384 halo pixels) / 40 KiB (<= 640)
+  constexpr int HSLOT = NHM * NT * 16;
   constexpr int nh = NHM;
-  constexpr int NHS = (WM == 8 && NF == 4) ? 2 : 3;   // halo ring slots (what 160 KiB holds next to the weight ring)
+  constexpr int NHS = (NWV == 4 || (WM == 8 && NF == 4)) ? 2 : 3;   // halo ring slots (what 160 KiB -- 80 KiB for NWV = 4 -- holds next to the weight ring)
+  // DEEP (round 5): weight ring of 5 step slots, weights issued FOUR steps ahead (run_tiles_deep).  vmcnt completes in issue order, so
+  // the wait for the weights of a step also forces every older DMA: with the 3-slot ring (weights two steps ahead) a halo chunk had
+  // ONE chunk time (3 steps) to land however many ring slots it owned, and the 32-column level-0 layers ran their K loop at the
+  // memory latency (cycle stamps: K loop with DMA alone = full K loop = 5.3 k cycles per chunk; with MFMAs alone 4.1 k;
+  // profiles/r05_ig4_phases.txt).  Four steps of weight lead give a halo chunk five steps.
+  constexpr bool DEEP = ROT == 2;              // (launcher: only where !AFF, NHS == 3, NWV == 8, BN <= 64)
+  static_assert(!DEEP || (!AFF && !DBG && NHS == 3 && NWV == 8 && BN <= 64), "deep weight ring: 32 / 64-column tiles with three halo slots");
+  constexpr int NWS = DEEP ? 5 : 3;            // weight ring slots
   constexpr int nhs = NHS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -115,9 +127,9 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Ig4Args ka) {
   const int dbg = DBG ? ka.dbg : 0;                                    // (the switches exist only in the DBG instantiation)
   const unsigned lds0 = (unsigned)(uintptr_t)smem;
   unsigned char* const wring = smem + nhs * HSLOT;
-  constexpr int WPAD = (WPIECES % 8) ? 4096 : 0;                       // landing pad of the dummy weight pieces
-  float* const st_tab = (float*)(wring + 3 * WSLOT + WPAD);                   // [8 waves][2][BNW] statistics of the wave's tiles so far
-  float* const bias_tab = st_tab + 8 * 2 * BNW;                        // [BN] bias of the column tile
+  constexpr int WPAD = (WPIECES % NWV) ? 4096 : 0;                     // landing pad of the dummy weight pieces
+  float* const st_tab = (float*)(wring + NWS * WSLOT + WPAD);                 // [waves][2][BNW] statistics of the wave's tiles so far
+  float* const bias_tab = st_tab + NWV * 2 * BNW;                      // [BN] bias of the column tile
   u32x4* const src_tab = (u32x4*)(bias_tab + BN);                      // [chunk]{pointer of the chunk's first channel, bytes per pixel}
   float* const aff_tab = (float*)(src_tab + KSMI_MAX_CHUNKS);          // AFF: [chunk][k-group]{scale[8], shift[8]}
 
@@ -156,7 +168,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Ig4Args ka) {
   constexpr int nW = WK;
 #pragma unroll
   for (int k = 0; k < WK; ++k) {
-    const int p = wave + 8 * k;
+    const int p = wave + NWV * k;
     const int row = p * 16 + (lane >> 2), sl = lane & 3;
     const int tl = row / BN, n = row - tl * BN;
     const int j = n & 31;
@@ -167,19 +179,19 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Ig4Args ka) {
   int h_qb[NHM];
 #pragma unroll
   for (int k = 0; k < NHM; ++k) {
-    const int pix = (tid + 512 * k) >> 2;
+    const int pix = (tid + NT * k) >> 2;
     const int hy = dHW.div(pix), hx = pix - hy * HW;
-    h_qb[k] = (((tid + 512 * k) & 3) ^ swz_h(hx)) << 4;
+    h_qb[k] = (((tid + NT * k) & 3) ^ swz_h(hx)) << 4;
   }
   // the per-chunk source scalars (virtual concat) go to LDS once: fetched from the kernarg tables inside the K loop they are two
   // dependent scalar loads in front of every halo refill
-  for (int ch = tid; ch < nch && ch < KSMI_MAX_CHUNKS; ch += 512) {
+  for (int ch = tid; ch < nch && ch < KSMI_MAX_CHUNKS; ch += NT) {
     const ksmi_src& sr = d.src[chunk_src_of(d, ch)];
     const uint64_t sp = (uint64_t)(uintptr_t)((const T*)sr.ptr + sr.c_off + chunk_c0_of(d, ch));
     src_tab[ch] = (u32x4){(uint32_t)sp, (uint32_t)(sp >> 32), (uint32_t)sr.C * 2u, 0u};
   }
   if constexpr (AFF) {
-    for (int i = tid; i < nch * 32; i += 512) {
+    for (int i = tid; i < nch * 32; i += NT) {
       const int ch = i >> 5, j = i & 31;
       const int c0 = chunk_c0_of(d, ch);
       aff_tab[(ch * 4 + (j >> 3)) * 16 + (j & 7)] = d.src[0].scale[c0 + j];
@@ -204,7 +216,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Ig4Args ka) {
     asm volatile("" : "+v"(tv));          // opaque per call: keeps hipcc from hoisting the (tile-invariant) halo coordinates into registers
 #pragma unroll
     for (int k = 0; k < NHM; ++k) {
-      const int pix = (tv + 512 * k) >> 2;
+      const int pix = (tv + NT * k) >> 2;
       const int hy = dHW.div(pix), hx = pix - hy * HW;
       const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
       const bool ok = live && pix < HP && (unsigned)iy < (unsigned)d.Hin && (unsigned)ix < (unsigned)d.Win;
@@ -221,7 +233,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Ig4Args ka) {
       const uint64_t av = sp + (uint64_t)(uint32_t)go[k] * e[2] + (uint64_t)(uint32_t)h_qb[k];
       const bool ok = go[k] >= 0;
       const uint32_t lo = ok ? (uint32_t)av : zlo, hi = ok ? (uint32_t)(av >> 32) : zhi;
-      glds16_flat((const unsigned char*)(uintptr_t)(((uint64_t)hi << 32) | lo), lds0 + (unsigned)(slot * HSLOT + (k * 512 + wave * 64) * 16));
+      glds16_flat((const unsigned char*)(uintptr_t)(((uint64_t)hi << 32) | lo), lds0 + (unsigned)(slot * HSLOT + (k * NT + wave * 64) * 16));
     }
   };
   const unsigned char* const wpk = (const unsigned char*)d.wpk;
@@ -232,8 +244,8 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Ig4Args ka) {
       const uint64_t av = (uint64_t)(uintptr_t)base + (uint64_t)(uint32_t)w_off[k];
       const bool ok = w_off[k] >= 0;
       const uint32_t lo = ok ? (uint32_t)av : zlo, hi = ok ? (uint32_t)(av >> 32) : zhi;
-      const int p = wave + 8 * k;                                     // (wave-uniform select of the landing address)
-      const unsigned dst = p < WPIECES ? (unsigned)(nhs * HSLOT + slot * WSLOT + p * 1024) : (unsigned)(nhs * HSLOT + 3 * WSLOT + (wave & 3) * 1024);
+      const int p = wave + NWV * k;                                   // (wave-uniform select of the landing address)
+      const unsigned dst = p < WPIECES ? (unsigned)(nhs * HSLOT + slot * WSLOT + p * 1024) : (unsigned)(nhs * HSLOT + NWS * WSLOT + (wave & 3) * 1024);
       glds16_flat((const unsigned char*)(uintptr_t)(((uint64_t)hi << 32) | lo), lds0 + dst);
     }
   };
@@ -243,7 +255,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Ig4Args ka) {
 #pragma unroll
     for (int k = 0; k < NHM; ++k) {
       {
-        const u32x4 xv = *(const u32x4*)(sb + (tid + 512 * k) * 16);
+        const u32x4 xv = *(const u32x4*)(sb + (tid + NT * k) * 16);
         const int q = h_qb[k] >> 4;
         const f32x4* tab = (const f32x4*)(aff_tab + (ch * 4 + q) * 16);
         const f32x4 s0 = tab[0], s1 = tab[1], h0 = tab[2], h1 = tab[3];
@@ -255,7 +267,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Ig4Args ka) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) x[j] = __builtin_amdgcn_fmed3f(x[j], 0.f, 3.0e38f);
         }
-        if (go[k] >= 0) *(u32x4*)(sb + (tid + 512 * k) * 16) = vec_pack<T>(x);
+        if (go[k] >= 0) *(u32x4*)(sb + (tid + NT * k) * 16) = vec_pack<T>(x);
       }
     }
   };
@@ -268,10 +280,10 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Ig4Args ka) {
   const bool has_resid = EPI == 0 && d.resid != nullptr;
   const bool relu_out = EPI == 0 && d.relu_out != 0;
   // statistics and bias live in LDS (a wave owns its statistics row: plain read-modify-write, fixed order = deterministic)
-  for (int i = tid; i < 8 * 2 * BNW; i += 512) st_tab[i] = 0.f;
+  for (int i = tid; i < NWV * 2 * BNW; i += NT) st_tab[i] = 0.f;
   if (tid < BN) bias_tab[tid] = (d.bias && n0 + tid < d.N) ? d.bias[n0 + tid] : 0.f;
   const bool want_stats = d.stats != nullptr;
-  const bool late = ka.stagger && wave >= 4;                            // (wave-uniform)
+  const bool late = ka.stagger && wave >= NWV / 2;                      // (wave-uniform)
   constexpr int LA = NHS - 1;                                           // halo chunks in flight beyond the current one
 
   // ---- epilogue of one tile (both schedules) --------------------------------------------------------------------------------
@@ -636,10 +648,131 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(const Ig4Args ka) {
     }
     vm_wait_c<0>();
   };
+
+  // DEEP schedule (see the constant): the rotated step body of run_tiles_rot with
+  //   * weight slot = global step index mod 5; at step s the weights of step s + 4 are issued into the slot step s - 1 read;
+  //   * a kernel-row-0 step issues its weights first, then the halo of chunk + 2 (as before: the slot of chunk - 1);
+  //   * waits: the DMA instructions younger than the weights of the step are, in issue order,
+  //       row 0: W(s+1) W(s+2) W(s+3) + the halo issued one chunk ago            -> vmcnt(3 nW + nh)
+  //       row 1: the halo issued in row 0 of the PREVIOUS chunk sits behind these weights as well -> vmcnt(3 nW + 2 nh)
+  //       row 2:                                                                  -> vmcnt(3 nW + nh)
+  //     so a halo chunk issued in step (c, 0) is forced by the wait of step (c + 1, 2): five steps of lead instead of three.
+  //   The prologue issues what the virtual steps -4 .. -1 would have (H0 | W0 | W1 H1 | W2 | W3).
+  auto run_tiles_deep = [&](auto) {
+    int t = pxw;
+    int go_c[NHM], go_n[NHM];
+    tile_goff(t, go_c);
+    tile_goff(t + ka.gx, go_n);
+    __syncthreads();
+    issue_H(go_c, src_tab[0], 0);
+    issue_W(0, 0, 0);
+    {
+      const int c1 = nch > 1 ? 1 : 0;                                 // (a one-chunk tile re-reads chunk 0: the geometry needs nch >= 2 anyway)
+      issue_W(0, 1, 1);
+      issue_H(go_c, src_tab[c1], 1);
+      issue_W(0, 2, 2);
+      issue_W(c1, 0, 3);
+    }
+    int hs = 0;
+    int ws = 0;                                                       // weight slot of the current step
+    int ic = nch > 1 ? 1 : 0, ir = 1;                                 // (chunk, row) of the step whose weights are issued next: step 4
+    for (;;) {
+      f32x4 acc[4][NF];
+#pragma unroll
+      for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      u32x4 fa[2][4], fb[2][NF];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+#pragma unroll
+        for (int mf = 0; mf < 4; ++mf) fa[u][mf] = (u32x4){0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) fb[u][nf] = (u32x4){0u, 0u, 0u, 0u};
+      }
+      bool have = false;
+      auto mma_set = [&](auto set_tag) {
+        constexpr int S = decltype(set_tag)::value;
+#pragma unroll
+        for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+          for (int nf = 0; nf < NF; ++nf) mma16<T>(acc[mf][nf], fb[S][nf], fa[S][mf]);
+      };
+      auto chunk = [&](auto par_tag, int c) {
+        constexpr int PAR = decltype(par_tag)::value;
+        const unsigned char* lds_h = smem + hs * HSLOT;
+        const int hprev = hs == 0 ? NHS - 1 : hs - 1;
+        const int hnext = hs + 1 == NHS ? 0 : hs + 1;
+        int c2 = c + LA;
+        const bool nextt = c2 >= nch;
+        if (nextt) c2 -= nch;
+        const u32x4 ent = src_tab[c2];
+        int go_i[NHM];
+#pragma unroll
+        for (int k = 0; k < NHM; ++k) go_i[k] = nextt ? go_n[k] : go_c[k];
+        auto step = [&](auto r_tag) {
+          constexpr int r = decltype(r_tag)::value;
+          constexpr int Hs = (PAR + r) & 1, Os = Hs ^ 1;
+          if constexpr (r == 1) vm_wait_c<3 * nW + 2 * nh>(); else vm_wait_c<3 * nW + nh>();
+          lds_barrier();
+          const unsigned char* lds_w = wring + ws * WSLOT;
+#pragma unroll
+          for (int mf = 0; mf < 4; ++mf) fa[Os][mf] = *(const u32x4*)(lds_h + r * pitch + a_addr[mf][0]);
+#pragma unroll
+          for (int nf = 0; nf < NF; ++nf) fb[Os][nf] = *(const u32x4*)(lds_w + b_addr[nf]);
+          if (have) mma_set(std::integral_constant<int, Hs>{});
+          __builtin_amdgcn_sched_barrier(0);
+          {
+            const int wslot = ws == 0 ? NWS - 1 : ws - 1;             // the slot step s - 1 read = (s + 4) mod 5
+            issue_W(ic, ir, wslot);
+            if (r == 0) issue_H(go_i, ent, hprev);
+            if (++ir == 3) { ir = 0; ic = ic + 1 == nch ? 0 : ic + 1; }
+          }
+#pragma unroll
+          for (int mf = 0; mf < 4; ++mf) fa[Hs][mf] = *(const u32x4*)(lds_h + r * pitch + a_addr[mf][1]);
+#pragma unroll
+          for (int nf = 0; nf < NF; ++nf) fb[Hs][nf] = *(const u32x4*)(lds_w + 1 * BN * 64 + b_addr[nf]);
+          mma_set(std::integral_constant<int, Os>{});      // tap 0
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int mf = 0; mf < 4; ++mf) fa[Os][mf] = *(const u32x4*)(lds_h + r * pitch + a_addr[mf][2]);
+#pragma unroll
+          for (int nf = 0; nf < NF; ++nf) fb[Os][nf] = *(const u32x4*)(lds_w + 2 * BN * 64 + b_addr[nf]);
+          mma_set(std::integral_constant<int, Hs>{});      // tap 1; set Os now holds tap 2
+          __builtin_amdgcn_sched_barrier(0);
+          have = true;
+          ws = ws + 1 == NWS ? 0 : ws + 1;
+        };
+        step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
+        hs = hnext;
+      };
+      int c = 0;
+      for (; c + 1 < nch; c += 2) {
+        chunk(std::integral_constant<int, 0>{}, c);
+        chunk(std::integral_constant<int, 1>{}, c + 1);
+      }
+      if (c < nch) {
+        chunk(std::integral_constant<int, 0>{}, c);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        mma_set(std::integral_constant<int, 1>{});
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        mma_set(std::integral_constant<int, 0>{});
+      }
+      tile_epilogue(t, acc);
+      if (t + ka.gx >= ka.tiles) break;
+      t += ka.gx;
+#pragma unroll
+      for (int k = 0; k < NHM; ++k) go_c[k] = go_n[k];
+      tile_goff(t + ka.gx, go_n);
+    }
+    vm_wait_c<0>();
+  };
   STAMP();
   if (DBG && (dbg & 32)) return;                                        // (profiling: table setup only)
   if (pxw < ka.tiles) {
-    if constexpr (ROT) run_tiles_rot(0);
+    if constexpr (DEEP) run_tiles_deep(0);
+    else if constexpr (ROT != 0) run_tiles_rot(0);
     else { if (late) run_tiles(std::true_type{}); else run_tiles(std::false_type{}); }
   }
   if (DBG && (dbg & 128)) {
@@ -718,19 +851,27 @@ bool ksmi_igemm4_geom(const ksmi_conv_desc* d, int dtype, ksmi_igemm4_geom_t* g)
   const int cus = cus_env ? atoi(cus_env) : 256;
   // variants (8 waves): WM = 4 pixel groups x 2 column groups of 16 NF columns (256-pixel patch the descriptor chose), or
   // WM = 8 pixel groups x 1 column group (512-pixel patch chosen here): the wider the wave tile, the fewer LDS bytes per MFMA
-  struct Var { int wm, nf; };
-  Var cand[4];
+  struct Var { int wm, nf, nwv; };
+  Var cand[5];
   int nc = 0;
-  if (d->Npad % 128 == 0) cand[nc++] = {4, 4};                      // 256 px x 128 columns, wave 64 x 64
-  if (d->Npad % 64 == 0) { cand[nc++] = {8, 4}; cand[nc++] = {4, 2}; }   // 512 px x 64 (wave 64 x 64) / 256 px x 64 (wave 64 x 32)
-  if (d->Npad == 32) cand[nc++] = {8, 2};                           // 512 px x 32, wave 64 x 32
+  // two 4-wave workgroups per CU for the 32-column layers (KSMI_IG4_NW4: 1 = on, 0 = off; read once)
+  static const int nw4 = getenv("KSMI_IG4_NW4") ? atoi(getenv("KSMI_IG4_NW4")) : 0;
+  if (d->Npad == 32 && nw4) cand[nc++] = {4, 2, 4};                 // 256 px x 32, wave 64 x 32, two workgroups per CU
+  if (d->Npad % 128 == 0) cand[nc++] = {4, 4, 8};                   // 256 px x 128 columns, wave 64 x 64
+  if (d->Npad % 64 == 0) { cand[nc++] = {8, 4, 8}; cand[nc++] = {4, 2, 8}; }   // 512 px x 64 (wave 64 x 64) / 256 px x 64 (wave 64 x 32)
+  if (d->Npad == 32) cand[nc++] = {8, 2, 8};                        // 512 px x 32, wave 64 x 32
   for (int ci = 0; ci < nc; ++ci) {
-    const int wm = cand[ci].wm, nf = cand[ci].nf;
+    const int wm = cand[ci].wm, nf = cand[ci].nf, nwv = cand[ci].nwv;
     if (wm_force && (wm != wm_force || nf != nf_force)) continue;
-    const int bn = (8 / wm) * 16 * nf;
+    const int bn = (nwv / wm) * 16 * nf;
     int th, tw;
     if (wm == 4) { th = d->TH; tw = d->TW; if (th * tw > 256) continue; }
-    else ig4_patch(d->Hout, d->Wout, 512, IG4_NHMAX * 128, &th, &tw);
+    else {
+      ig4_patch(d->Hout, d->Wout, 512, IG4_NHMAX * 128, &th, &tw);
+      const char* pe = getenv("KSMI_IG4_PATCH");                    // probes: "th,tw" of the 512-pixel variants (DRAM-locality experiments)
+      int pth = 0, ptw = 0;
+      if (pe && sscanf(pe, "%d,%d", &pth, &ptw) == 2 && pth > 0 && ptw > 0 && pth * ptw <= 512 && (pth + 2) * (ptw + 2) <= IG4_NHMAX * 128) { th = pth; tw = ptw; }
+    }
     const int hp = (th + 2) * (tw + 2);
     const int tilesX = (d->Wout + tw - 1) / tw, tilesY = (d->Hout + th - 1) / th;
     const int tiles = d->B * tilesX * tilesY;
@@ -738,22 +879,28 @@ bool ksmi_igemm4_geom(const ksmi_conv_desc* d, int dtype, ksmi_igemm4_geom_t* g)
     if (!wm_force && tiles < 64) continue;                          // tiny maps (14 x 14 x batch 32 = 32 patches): igemm2's smaller tiles fill the machine better (measured)
     // the machine has to fill: prefer the wide variants only when they still give (nearly) every CU a workgroup
     if (!wm_force && ci + 1 < nc && (size_t)tiles * gy < 192) continue;
-    g->WM = wm; g->NF = nf; g->th = th; g->tw = tw;
+    g->WM = wm; g->NF = nf; g->nwv = nwv; g->th = th; g->tw = tw;
     g->tiles = tiles; g->gy = gy;
-    g->nh = wm == 4 ? 3 : IG4_NHMAX;
-    g->hslot = g->nh * 8192;
+    g->nh = nwv == 4 ? 6 : (wm == 4 ? 3 : IG4_NHMAX);               // (= the kernel's NHM)
+    g->hslot = g->nh * nwv * 1024;
     if (hp * 64 > g->hslot) continue;
-    const size_t tabs = (size_t)(8 * 2 * 16 * nf + bn) * 4 + (size_t)KSMI_MAX_CHUNKS * 16 + (aff ? (size_t)d->nchunks * 32 * 2 * 4 : 0);
-    const size_t wr = 3 * (size_t)(3 * bn * 64);
-    g->nhs = (wm == 8 && nf == 4) ? 2 : 3;                          // (= the kernel's NHS)
-    g->lds = (size_t)g->nhs * g->hslot + wr + ((3 * bn / 16) % 8 ? 4096 : 0) + tabs;
-    if (g->lds > 160 * 1024) continue;
-    int gx = cus / gy;
+    const size_t tabs = (size_t)(nwv * 2 * 16 * nf + bn) * 4 + (size_t)KSMI_MAX_CHUNKS * 16 + (aff ? (size_t)d->nchunks * 32 * 2 * 4 : 0);
+    static const int rot_on = getenv("KSMI_IG4_ROT") ? atoi(getenv("KSMI_IG4_ROT")) : 1;
+    static const int deep_on = getenv("KSMI_IG4_DEEP") ? atoi(getenv("KSMI_IG4_DEEP")) : 0;   // (the kernel's DEEP: compiled in; the switch forces the per-role schedule instead)
+    const int nhs_ = (nwv == 4 || (wm == 8 && nf == 4)) ? 2 : 3;
+    const bool deep = rot_on && deep_on && !aff && nhs_ == 3 && nwv == 8 && nf == 2;      // <8,2> (32 columns) and <4,2> (64 columns)
+    g->deep = deep ? 1 : 0;
+    const size_t wr = (deep ? 5 : 3) * (size_t)(3 * bn * 64);
+    g->nhs = (nwv == 4 || (wm == 8 && nf == 4)) ? 2 : 3;            // (= the kernel's NHS)
+    g->lds = (size_t)g->nhs * g->hslot + wr + ((3 * bn / 16) % nwv ? 4096 : 0) + tabs;
+    const int per_cu = nwv == 4 ? 2 : 1;
+    if (g->lds * per_cu > 160 * 1024) continue;
+    int gx = cus * per_cu / gy;
     if (gx < 1) gx = 1;
     if (gx > tiles) gx = tiles;
     const int rounds = (tiles + gx - 1) / gx;                       // equalise: the smallest grid with the same number of rounds
     gx = (tiles + rounds - 1) / rounds;
-    if (gx >= 8 && ((gx + 7) / 8 * 8) * gy <= (cus > 8 ? cus : 8)) gx = (gx + 7) / 8 * 8;   // XCD-aware placement wants a multiple of 8
+    if (gx >= 8 && ((gx + 7) / 8 * 8) * gy <= (cus > 8 ? cus : 8) * per_cu) gx = (gx + 7) / 8 * 8;   // XCD-aware placement wants a multiple of 8
     g->gx = gx;
     return true;
   }
@@ -797,7 +944,7 @@ int ksmi_igemm4_launch(const ksmi_conv_desc* d, const ksmi_igemm4_geom_t* g, hip
   } while (0)
 #define KSMI_G4R(WM_, NF_, AFF_, EPI_)                                                               \
   do {                                                                                               \
-    auto kfn = igemm4_kernel<WM_, NF_, AFF_, EPI_, false, 0, true>; KSMI_NOTE(kfn);                                  \
+    auto kfn = igemm4_kernel<WM_, NF_, AFF_, EPI_, false, 0, 1>; KSMI_NOTE(kfn);                                     \
     static bool attr_set = false;                                                                    \
     if (!attr_set) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; } \
     hipLaunchKernelGGL(kfn, grid, dim3(512), g->lds, st, ka);                                        \
@@ -807,7 +954,13 @@ int ksmi_igemm4_launch(const ksmi_conv_desc* d, const ksmi_igemm4_geom_t* g, hip
   do { if (ka.rot) { if (aff) KSMI_G4R(WM_, NF_, true, 0); else if (mask) KSMI_G4R(WM_, NF_, false, 1); else if (gate) KSMI_G4R(WM_, NF_, false, 2); else KSMI_G4R(WM_, NF_, false, 0); } \
        if (aff) KSMI_G4(WM_, NF_, true, 0); else if (mask) KSMI_G4(WM_, NF_, false, 1); else if (gate) KSMI_G4(WM_, NF_, false, 2);   \
        else if (d->dir == 1) KSMI_G4D(WM_, NF_); else KSMI_G4(WM_, NF_, false, 0); } while (0)
-  if (ka.dbg && !aff && !mask && !gate && g->NF == 4) {                       // profiling switches: separate instantiations of the plain kernels
+  if (ka.dbg && !aff && !mask && !gate && g->NF == 2 && g->WM == 8 && g->nwv == 8) {      // (the 32-column level-0 shape)
+    auto kfn = igemm4_kernel<8, 2, false, 0, true>; KSMI_NOTE(kfn);
+    (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(kfn, grid, dim3(512), g->lds, st, ka);
+    return ksmi_check_launch("igemm4");
+  }
+  if (ka.dbg && !aff && !mask && !gate && g->NF == 4 && g->nwv == 8) {        // profiling switches: separate instantiations of the plain kernels
     if (g->WM == 4) {
       auto kfn = igemm4_kernel<4, 4, false, 0, true>; KSMI_NOTE(kfn);
       (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -818,6 +971,34 @@ int ksmi_igemm4_launch(const ksmi_conv_desc* d, const ksmi_igemm4_geom_t* g, hip
       hipLaunchKernelGGL(kfn, grid, dim3(512), g->lds, st, ka);
     }
     return ksmi_check_launch("igemm4");
+  }
+  if (g->nwv == 4) {
+#define KSMI_G4N(AFF_, EPI_, ROT_)                                                                   \
+  do {                                                                                               \
+    auto kfn = igemm4_kernel<4, 2, AFF_, EPI_, false, 0, ROT_ ? 1 : 0, 4>; KSMI_NOTE(kfn);                           \
+    static bool attr_set = false;                                                                    \
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr_set = true; } \
+    hipLaunchKernelGGL(kfn, grid, dim3(256), g->lds, st, ka);                                        \
+    return ksmi_check_launch("igemm4");                                                              \
+  } while (0)
+    if (g->WM != 4 || g->NF != 2) return ksmi_fail(KSMI_E_UNSUPPORTED, "igemm4: no 4-wave instance");
+    if (ka.rot) { if (aff) KSMI_G4N(true, 0, true); else if (mask) KSMI_G4N(false, 1, true); else if (gate) KSMI_G4N(false, 2, true); else KSMI_G4N(false, 0, true); }
+    if (aff) KSMI_G4N(true, 0, false); else if (mask) KSMI_G4N(false, 1, false); else if (gate) KSMI_G4N(false, 2, false); else KSMI_G4N(false, 0, false);
+#undef KSMI_G4N
+  }
+  if (g->deep) {
+#define KSMI_G4DP(WM_, NF_, EPI_)                                                                    \
+  do {                                                                                               \
+    auto kfn = igemm4_kernel<WM_, NF_, false, EPI_, false, 0, 2>; KSMI_NOTE(kfn);                                    \
+    static bool attr_set = false;                                                                    \
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; } \
+    hipLaunchKernelGGL(kfn, grid, dim3(512), g->lds, st, ka);                                        \
+    return ksmi_check_launch("igemm4");                                                              \
+  } while (0)
+    if (aff || g->nwv != 8 || g->NF != 2) return ksmi_fail(KSMI_E_UNSUPPORTED, "igemm4: no deep-ring instance");
+    if (g->WM == 8) { if (mask) KSMI_G4DP(8, 2, 1); else if (gate) KSMI_G4DP(8, 2, 2); else KSMI_G4DP(8, 2, 0); }
+    else { if (mask) KSMI_G4DP(4, 2, 1); else if (gate) KSMI_G4DP(4, 2, 2); else KSMI_G4DP(4, 2, 0); }
+#undef KSMI_G4DP
   }
   if (g->WM == 4 && g->NF == 4) KSMI_G4V(4, 4);
   if (g->WM == 4 && g->NF == 2) KSMI_G4V(4, 2);

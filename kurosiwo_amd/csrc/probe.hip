@@ -16,18 +16,24 @@ namespace {
 
 constexpr int kT = 512;
 
-__global__ __launch_bounds__(kT) void probe_read_dma(const unsigned char* __restrict__ a, size_t nbytes, unsigned* sink) {
+// wmask != 0 (round 5, "LDS fill" probe): the byte offsets wrap inside a window of wmask + 1 bytes (a power of two), so the same
+// nbytes of LDS-DMA traffic is served by the L2 (window <= a few MB) or the memory-side cache (<= 256 MB) instead of HBM: the rate at
+// which a CU's LDS can be FILLED when the data is on chip -- the roof of every LDS-staged kernel that re-reads weights / halo overlap.
+// shared != 0: every workgroup walks the SAME addresses (the weight slab all CUs re-read), else disjoint slices of the window.
+__global__ __launch_bounds__(kT) void probe_read_dma(const unsigned char* __restrict__ a, size_t nbytes, unsigned* sink, size_t wmask, int shared) {
   extern __shared__ unsigned char smem[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = kT / 64;
   const size_t chunk = (size_t)1024 * 8;                                    // bytes per wave per trip: 8 DMA instructions of 1 KB
   const size_t per_wg = chunk * nw;
   const unsigned lds0 = (unsigned)(uintptr_t)smem + wave * 8192;
   const size_t trips = nbytes / (per_wg * gridDim.x);
-  const unsigned char* p = a + (size_t)blockIdx.x * per_wg + (size_t)wave * chunk + lane * 16;
+  size_t off = (shared ? 0 : (size_t)blockIdx.x * per_wg) + (size_t)wave * chunk + lane * 16;
+  const size_t step = shared ? per_wg : per_wg * gridDim.x;
   for (size_t t = 0; t < trips; ++t) {
+    const unsigned char* p = a + (wmask ? (off & wmask) : off);
 #pragma unroll
     for (int k = 0; k < 8; ++k) glds16_flat(p + k * 1024, lds0 + k * 1024);
-    p += per_wg * gridDim.x;
+    off += step;
     vm_wait(8);                                                             // the previous trip has landed; this one stays in flight
   }
   vm_wait(0);
@@ -138,13 +144,18 @@ extern "C" int ksmi_hbm_probe(int mode, const void* a, void* b, void* c, size_t 
     else return ksmi_fail(KSMI_E_ARG, "hbm_probe: the contiguous form has kinds 2, 3, 4");
     return ksmi_check_launch("hbm_probe");
   }
+  // mode bits 8..13 (kind 0 only): log2 of the window the LDS-DMA reads wrap in (0 = no wrap: stream all nbytes); bit 14: every
+  // workgroup reads the same addresses
+  const int wlog = (mode >> 8) & 63, shared = (mode >> 14) & 1;
   mode &= 7;
   switch (mode) {
     case 0: {
       const int grid = 512;                                                  // two workgroups per CU: 16 waves x 8 KB in flight each
       const size_t per = (size_t)1024 * 8 * (kT / 64) * grid;
       if (nbytes % per) return ksmi_fail(KSMI_E_ARG, "hbm_probe: mode 0 needs a multiple of 32 MiB");
-      hipLaunchKernelGGL(probe_read_dma, dim3(grid), dim3(kT), 8192 * (kT / 64), st, (const unsigned char*)a, nbytes, sink);
+      if (wlog && (wlog < 16 || ((size_t)1 << wlog) > nbytes)) return ksmi_fail(KSMI_E_ARG, "hbm_probe: window 64 KiB .. nbytes");
+      hipLaunchKernelGGL(probe_read_dma, dim3(grid), dim3(kT), 8192 * (kT / 64), st, (const unsigned char*)a, nbytes, sink,
+                         wlog ? (((size_t)1 << wlog) - 1) : (size_t)0, shared);
       break;
     }
     case 1: hipLaunchKernelGGL(probe_read_vec, dim3(G), dim3(256), 0, st, (const u32x4*)a, nvec, sink); break;
