@@ -532,7 +532,7 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const float* __rest
       for (int k = 0; k < KTP; k += 4) *(f32x4*)(wr + k) = *(const f32x4*)(wl + j * KTP + k);
 #pragma unroll
       for (int k = 0; k < KT; ++k) a = fmaf(xin[k], wr[k], a);     // (one rounding per tap, in tap order: the first version's v_fmac chain)
-      ot[tid * OP + j] = ok ? a : 0.f;
+      ot[tid * OP + j] = ok ? ElemTraits<T>::cvt(a) : 0.f;         // the STORED value (bf16 mode: rounded here, so the statistics below describe it)
     }
     __syncthreads();
     if (stats) {

@@ -322,16 +322,23 @@ __global__ __launch_bounds__(256 * WN, (WN == 1 && NCH * KH * KW * NTI <= 9) ? 2
           float m[8];
           vec_unpack<T>(mv[MASK ? mf : 0], m);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const float xh = (m[j] - mm[j]) * mr[j];
-            if (!(m[j] * mg[j] + mb[j] > 0.f)) v[j] = 0.f;
-            if (ok[mf]) { ssum[j] += v[j]; ssq[j] += v[j] * xh; }
-          }
+          for (int j = 0; j < 8; ++j) if (!(m[j] * mg[j] + mb[j] > 0.f)) v[j] = 0.f;
+        }
+        // statistics of the value the later passes READ (the stored bf16), as BatchNorm in the reference sees the stored tensor:
+        // sums of the fp32 accumulators describe a tensor nobody normalises (round 5; the gate epilogue of igemm4 always did)
+        const u32x4 pk = vec_pack<T>(v);
+        float q[8];
+        vec_unpack<T>(pk, q);
+        if constexpr (MASK) {
+          float m[8];
+          vec_unpack<T>(mv[MASK ? mf : 0], m);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) if (ok[mf]) { ssum[j] += q[j]; ssq[j] += q[j] * ((m[j] - mm[j]) * mr[j]); }
         } else {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) if (ok[mf]) { ssum[j] += v[j]; ssq[j] += v[j] * v[j]; }
+          for (int j = 0; j < 8; ++j) if (ok[mf]) { ssum[j] += q[j]; ssq[j] += q[j] * q[j]; }
         }
-        if (ok[mf] && !(ka.dbg & 4)) *(u32x4*)(obase + (size_t)opix[mf] * dC) = vec_pack<T>(v);
+        if (ok[mf] && !(ka.dbg & 4)) *(u32x4*)(obase + (size_t)opix[mf] * dC) = pk;
       }
     }
   }

@@ -391,11 +391,16 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void igemm4_kernel(cons
                   for (int j = 0; j < 8; ++j) {
                     const float xh = (m[j] - mm[j]) * mr[j];
                     if (!(m[j] * mg[j] + mb[j] > 0.f)) v[j] = 0.f;
-                    if (ok) { ssum[j] += v[j]; ssq[j] += v[j] * xh; }
+                    const float q = ElemTraits<T>::cvt(v[j]);          // (statistics of the stored value: see the plain branch)
+                    if (ok) { ssum[j] += q; ssq[j] += q * xh; }
                   }
                 } else {
+                  // statistics of the value the BatchNorm passes READ (the stored bf16), as the reference's BatchNorm sees the stored
+                  // tensor; sums of the fp32 accumulators describe a tensor nobody normalises (round 5; the gate branch always did)
+                  float q[8];
+                  vec_unpack<T>(vec_pack<T>(v), q);
 #pragma unroll
-                  for (int j = 0; j < 8; ++j) if (ok) { ssum[j] += v[j]; ssq[j] += v[j] * v[j]; }
+                  for (int j = 0; j < 8; ++j) if (ok) { ssum[j] += q[j]; ssq[j] += q[j] * q[j]; }
                 }
                 if (accum) {
                   float o[8];

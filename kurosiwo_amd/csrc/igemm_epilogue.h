@@ -321,11 +321,12 @@ __device__ __forceinline__ void igemm_epilogue_direct(const ksmi_conv_desc& d, f
           const int n = min(n4 + r, d.N - 1);
           const float xh = (m[r] - d.m_mean[n]) * d.m_rstd[n];
           if (!(m[r] * d.m_scale[n] + d.m_shift[n] > 0.f)) v[nf][r] = 0.f;
-          if (r < nval[nf]) { ssum[nf][r] += v[nf][r]; ssq[nf][r] += v[nf][r] * xh; }
+          const float q = ElemTraits<T>::cvt(v[nf][r]);              // statistics of the STORED value (identity in fp32), round 5
+          if (r < nval[nf]) { ssum[nf][r] += q; ssq[nf][r] += q * xh; }
         }
       } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) if (r < nval[nf]) { ssum[nf][r] += v[nf][r]; ssq[nf][r] += v[nf][r] * v[nf][r]; }
+        for (int r = 0; r < 4; ++r) if (r < nval[nf]) { const float q = ElemTraits<T>::cvt(v[nf][r]); ssum[nf][r] += q; ssq[nf][r] += q * q; }
       }
     }
     // ---- stores -----------------------------------------------------------------------------------
@@ -465,11 +466,12 @@ __device__ __forceinline__ void igemm_epilogue_fast(const ksmi_conv_desc& d, f32
       for (int j = 0; j < 8; ++j) {
         const float xh = (m[j] - mm[j]) * mr[j];
         if (!(m[j] * mg[j] + mb[j] > 0.f)) v[j] = 0.f;
-        if (ok[mf]) { ssum[j] += v[j]; ssq[j] += v[j] * xh; }
+        const float q = ElemTraits<T>::cvt(v[j]);                    // statistics of the STORED value, round 5
+        if (ok[mf]) { ssum[j] += q; ssq[j] += q * xh; }
       }
     } else {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) if (ok[mf]) { ssum[j] += v[j]; ssq[j] += v[j] * v[j]; }
+      for (int j = 0; j < 8; ++j) if (ok[mf]) { const float q = ElemTraits<T>::cvt(v[j]); ssum[j] += q; ssq[j] += q * q; }
     }
     if (accum) {
       float o[8];

@@ -1,6 +1,7 @@
 """Golden vectors for the per-draw K-step parity gate: the protocol of oracle/gen_parity_run.py --reference
 (imported /root/reference SNUNet_ECAM + BCEandDiceLoss + torch.optim.Adam, 40 steps, batches of 4, held-out mIoU after 20 and 40
-steps) repeated under the ELEVEN weight perturbations tools/parity_draws.py uses on the GPU (conv0_0.conv1.weight scaled by 1 + p),
+steps) repeated under the eleven weight perturbations tools/parity_draws.py uses on the GPU (conv0_0.conv1.weight scaled by 1 + p)
+and twelve more,
 
   * in fp32                                     -> how far a 1e-7 perturbation alone moves the CPU fp32 run, and
   * with bf16 STORAGE emulated (oracle/bf16_storage.py: activations / stored gradients / MFMA weight operands rounded to bf16,
@@ -11,7 +12,7 @@ TEST INFRASTRUCTURE, build container only.  Writes tests/golden/snunet_parity_dr
 trajectory, mIoU / per-class IoU at both checkpoints.  Runs are independent processes (DRAW_PROCS at a time, DRAW_THREADS threads each);
 finished draws are cached under /tmp/parity_draws so the script can be resumed.
 
-    python oracle/gen_parity_draws.py            # ~1.5 h on 8 cores
+    python oracle/gen_parity_draws.py            # ~3 h on 8 cores (27 runs of ~25 minutes, four at a time)
 """
 import os
 import subprocess
@@ -21,8 +22,11 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-PERTURBS = (0.0, 1e-7, -1e-7, 2e-7, -2e-7, 3e-7, -3e-7, 5e-7, -5e-7, 1e-6, -1e-6)
+# the eleven perturbations of tools/parity_draws.py / tests/test_gpu_parity_gate.py first, then twelve more for the tail of the distribution
+PERTURBS = (0.0, 1e-7, -1e-7, 2e-7, -2e-7, 3e-7, -3e-7, 5e-7, -5e-7, 1e-6, -1e-6,
+            4e-7, -4e-7, 6e-7, -6e-7, 7e-7, -7e-7, 8e-7, -8e-7, 9e-7, -9e-7, 1.5e-6, -1.5e-6)
 MODES = ("fp32", "bf16emu")
+NDRAWS = {"fp32": 4, "bf16emu": len(PERTURBS)}      # fp32 moves by < 5e-4 under these perturbations: four draws show it
 CACHE = os.environ.get("DRAW_CACHE", "/tmp/parity_draws")
 
 
@@ -71,7 +75,7 @@ def one(mode, pz, path):
 
 def main():
     os.makedirs(CACHE, exist_ok=True)
-    jobs = [(m, p, os.path.join(CACHE, f"{m}_{i}.npz")) for m in reversed(MODES) for i, p in enumerate(PERTURBS)]
+    jobs = [(m, p, os.path.join(CACHE, f"{m}_{i}.npz")) for m in reversed(MODES) for i, p in enumerate(PERTURBS[:NDRAWS[m]])]
     todo = [j for j in jobs if not os.path.exists(j[2])]
     procs, nproc = [], int(os.environ.get("DRAW_PROCS", "4"))
     while todo or procs:
@@ -83,7 +87,7 @@ def main():
             procs[0].wait()
     res = {"perturbations": np.array(PERTURBS)}
     for m in MODES:
-        runs = [np.load(os.path.join(CACHE, f"{m}_{i}.npz")) for i in range(len(PERTURBS))]
+        runs = [np.load(os.path.join(CACHE, f"{m}_{i}.npz")) for i in range(NDRAWS[m])]
         res[f"{m}.losses"] = np.stack([r["losses"] for r in runs])
         for k in (20, 40):
             res[f"{m}.miou{k}"] = np.array([float(r[f"miou{k}"]) for r in runs])

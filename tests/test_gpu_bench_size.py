@@ -246,18 +246,38 @@ def test_snunet_dem_shard_vs_reference_golden(golden_dir, precision):
         assert mism <= 0.01 * am.size, (mism, am.size)
     assert (am[decisive] == gold["train_argmax_sub"][decisive]).all()
     bad, coss = {}, []
-    # bf16: the first block's gradient norms move by +-5-8 % with the rounding realisation (a 1e-7 relative change of one weight
-    # tensor, profiles/r04_bf16_realisation.txt) around a value ~5 % below the fp32 one: 16 % bounds a result, 8 % only bounded a draw
-    tol = 1.6e-1 if precision == "bf16" else 5e-3
+    # bf16: held to the SAME step of the imported reference with bf16 storage emulated (oracle/bf16_storage.py ->
+    # snunet_dem_shard_bf16emu.npz, oracle/gen_bf16emu_golden.py): bf16 storage lowers the first block's gradient norms by 5-9 % on the
+    # reference's own module graph (forward rounding alone does it: LABNOTES.md round 5), so the fp32 vectors would only bound the bf16
+    # path loosely (round 4: 16 %).  Against the emulated reference every norm is within 8 % -- two rounding realisations of one
+    # arithmetic contract (measured: printed below) -- and the deficit against fp32 must be the emulated reference's, not a larger one.
+    emu = np.load(os.path.join(golden_dir, "snunet_dem_shard_bf16emu.npz")) if precision == "bf16" else None
+    tol = 8e-2 if precision == "bf16" else 5e-3
+    ratios = {}
     for k, p in m.named_parameters():
         st = gold[f"gstat.{k}"]
         if k.endswith("conv2.bias"):
             continue                                               # analytically zero (BatchNorm follows)
         nrm = float(p.grad.double().norm())
-        if not abs(nrm - st[0]) < tol * st[0] + 1e-6:
-            bad[k] = (nrm, float(st[0]))
+        ref = float(emu[f"gstat.{k}"][0]) if emu is not None else float(st[0])
+        ratios[k] = nrm / max(ref, 1e-30)
+        if not abs(nrm - ref) < tol * ref + 1e-6:
+            bad[k] = (nrm, ref, float(st[0]))
         if f"grad.{k}" in gold.files:
             coss.append(_cos(p.grad.detach().float().cpu().numpy(), gold[f"grad.{k}"]))
+    if emu is not None:
+        rs = np.array(list(ratios.values()))
+        lo, hi = min(ratios, key=ratios.get), max(ratios, key=ratios.get)
+        print(f"bf16 gradient norms / emulated-reference norms over {rs.size} parameters: median {np.median(rs):.4f}, min {rs.min():.4f} ({lo}), "
+              f"max {rs.max():.4f} ({hi}); first block vs fp32: HIP {float(m.conv0_0.conv1.weight.grad.double().norm()) / float(gold['gstat.conv0_0.conv1.weight'][0]):.4f}, "
+              f"emulated reference {float(emu['gstat.conv0_0.conv1.weight'][0]) / float(gold['gstat.conv0_0.conv1.weight'][0]):.4f}; "
+              f"loss {float(loss):.6f} vs emulated {float(emu['train_loss']):.6f} vs fp32 {float(gold['train_loss']):.6f}")
+        assert abs(np.median(rs) - 1.0) < 1e-2, np.median(rs)          # no systematic offset against the emulated reference
+        assert abs(float(loss) - float(emu["train_loss"])) < 2e-3 * float(emu["train_loss"])
+        ecos = [_cos(m.get_parameter(k).grad.detach().float().cpu().numpy(), emu[f"grad.{k}"]) for k in
+                ("conv0_0.conv1.weight", "conv0_0.conv2.weight", "conv0_4.conv2.weight", "conv_final.weight")]
+        print("cosine with the emulated reference's gradients (first block conv1, conv2, last block conv2, head):", np.round(ecos, 4).tolist())
+        assert min(ecos) > 0.93, ecos
     assert not bad, dict(list(bad.items())[:10])
     assert min(coss) > (0.95 if precision == "bf16" else 0.9999), coss      # (bf16: the first convolution's direction, same realisation spread)
     # the concatenated form of the same inputs is the same function

@@ -135,8 +135,13 @@ def test_conv3x3_forward_dgrad_wgrad(dev, dtype, cfg):
     yn = Fk.to_nchw(y).cpu()
     assert (yn - y_ref.detach()).abs().max() < tol * y_ref.abs().max()
     s = stats.sum(0).cpu()
-    assert (s[0, :N] - y_ref.detach().sum((0, 2, 3))).abs().max() < 1e-3 * max(1.0, float(y_ref.abs().sum((0, 2, 3)).max()))
-    assert (s[1, :N] - (y_ref.detach() ** 2).sum((0, 2, 3))).abs().max() < 1e-3 * float((y_ref.detach() ** 2).sum((0, 2, 3)).max())
+    # the statistics rows describe the STORED output (round 5: what BatchNorm normalises is the tensor in memory, bf16-rounded in the
+    # performance mode; sums of the fp32 accumulators fed a normalisation of values nobody reads and made bf16 training spike)
+    yd = yn.double()
+    assert (s[0, :N].double() - yd.sum((0, 2, 3))).abs().max() < 2e-5 * max(1.0, float(yd.abs().sum((0, 2, 3)).max()))
+    assert (s[1, :N].double() - (yd ** 2).sum((0, 2, 3))).abs().max() < 2e-5 * float((yd ** 2).sum((0, 2, 3)).max())
+    # ... and the stored output is the reference's to the rounding of the activation type
+    assert (s[0, :N] - y_ref.detach().sum((0, 2, 3))).abs().max() < (5e-3 if dtype == torch.bfloat16 else 1e-3) * max(1.0, float(y_ref.abs().sum((0, 2, 3)).max()))
     dyd = Fk.to_nhwc(dy.to(dev), dtype)
     dxs = Fk.conv3x3_dgrad(dyd, w.to(dev), cs)
     dx = torch.cat([Fk.to_nchw(t).cpu() for t in dxs], 1)

@@ -8,7 +8,7 @@ CPU threads, so it is a committed fixture rather than recomputed here).  The ora
 (snunet_parity_run.npz) is held to it in tests/test_oracle_snunet.py (mIoU within 1e-5 at both checkpoints).  The HIP side repeats the protocol through the fused train step in bf16 (the
 benchmarked dtype) and in fp32.
 
-What is asserted, and why two checkpoints (round 4: on the median of seven draws of the HIP run, see DRAWS below).  K = 40 is on the plateau of the learning curve (mIoU 0.986): there the gate is the
+What is asserted, and why two checkpoints (round 5: on EVERY draw of the HIP run, see DRAWS below).  K = 40 is on the plateau of the learning curve (mIoU 0.986): there the gate is the
 survey's +-0.002 for bf16 (fp32: 5e-4).  K = 20 is on the steep part (mIoU rises 0.66 -> 0.97 between steps 10 and 20): fp32 HIP
 still tracks the CPU run to 2e-4, while a bf16 TRAINING trajectory is a slightly different trajectory and sits up to 0.015 lower
 at that step before it rejoins (measured: -0.0144 at 20, +0.0011 at 40, -0.0005 at 80); bf16 INFERENCE is not the cause -- evaluating
@@ -23,15 +23,24 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-# Seven draws of the HIP run.  A 40-step Adam run from seeded weights is a chaotic map: a 1e-7 RELATIVE change of one weight tensor
-# (or a re-ordered fp32 sum in one kernel) moves the K = 20 checkpoint by 1.5e-3 mIoU in fp32 and, in bf16, by up to 0.26 when the run
-# takes one of its loss spikes late (one draw in eleven on the round-4 start tree AND on the current one: profiles/r04_parity_draws.txt,
-# tools/parity_draws.py -- same medians, -0.003 / -0.005 at K = 20 and +0.0007 / +0.0004 at K = 40; a spike at step 16 is still visible
-# at K = 40, one at step 5 is not).  The gate therefore holds the MEDIAN of the draws -- the seeded weights and the same weights with
-# conv0_0.conv1.weight scaled by 1 +- {1, 2, 3}e-7 -- to the survey's bounds and every draw BUT ONE to a wider one; the worst draw is
-# printed.  (Round 4 used three draws and bounded the worst: a re-ordered reducer sum in the last session of the round put the
-# unperturbed draw on a late spike, -0.256 at K = 20, with the median of eleven draws where it was.)
-DRAWS = (0.0, 1e-7, -1e-7, 2e-7, -2e-7, 3e-7, -3e-7)
+# Draws of the HIP run: the seeded weights and the same weights with conv0_0.conv1.weight scaled by 1 + p (float32: p acts in units of
+# 1.19e-7 above 1 and 6e-8 below).  EVERY draw is asserted -- no median-only bound, no dropped sample.
+#
+# Round 5 found why round 4 needed one: the convolution epilogues summed the BatchNorm statistics over their fp32 accumulators while
+# BatchNorm normalised the bf16 values they STORED.  Where the rounding noise of a channel is comparable with its spread the
+# normalised values then have variance > 1, and a 40-step Adam run took loss excursions of 2.6 x ... 16 x in about one draw in
+# eleven (profiles/r04_parity_draws.txt; K = 40 off by -0.033 on the seeded weights).  With the statistics taken over the stored
+# values (what the reference's BatchNorm sees) the eleven draws are K = 40: -0.0002 ... +0.0019, K = 20: -0.0114 ... -0.0010, loss
+# within 0.47 of the fp32 trajectory (profiles/r05_parity_draws.txt).
+#
+# What the bounds are held to: tests/golden/snunet_parity_draws_ref.npz = the same protocol on the IMPORTED reference under 23 such
+# perturbations with bf16 STORAGE emulated (oracle/bf16_storage.py, oracle/gen_parity_draws.py) and 4 in fp32.  The reference's own fp32
+# run moves by <= 5e-4 under a 1e-7 perturbation; its bf16-storage run by -0.040 ... +0.0003 at K = 20 (still on the steep part of the
+# learning curve) and -0.0036 ... +0.0016 at K = 40, loss up to 2.8 x the fp32 trajectory at step 5.  bf16: every HIP draw must be
+# inside that envelope at K = 20, within 0.003 at K = 40 (the survey's +-0.002 is asserted on the median; one emulated-reference draw
+# in eight is outside it) and never more than 1.0 off the fp32 loss trajectory (relative).  fp32: every draw within 1e-3 / 3e-3.
+DRAWS = {"fp32": (0.0, 1e-7, -1e-7, 2e-7, -2e-7, 3e-7, -3e-7),
+         "bf16": (0.0, 1e-7, -1e-7, 2e-7, -2e-7, 3e-7, -3e-7, 5e-7, -5e-7, 1e-6, -1e-6)}
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
@@ -42,7 +51,17 @@ def test_kstep_run_miou_matches_cpu_fp32_reference_run(golden_dir, precision):
     from oracle.gen_parity_run import BATCH, CHECKPOINTS, HELD_OUT, K_STEPS, TRAIN_TILES, protocol_tiles
     from oracle.seeded import seeded_fill_
     gold = np.load(os.path.join(golden_dir, "snunet_parity_run_ref.npz"))
+    env = np.load(os.path.join(golden_dir, "snunet_parity_draws_ref.npz"))
     assert list(gold["protocol"][:4]) == [K_STEPS, TRAIN_TILES, BATCH, HELD_OUT] and CHECKPOINTS == (20, 40)
+    # the emulated reference's envelope (deltas against the same fp32 run)
+    e20 = env["bf16emu.miou20"] - float(gold["miou20"])
+    e40 = env["bf16emu.miou40"] - float(gold["miou40"])
+    f40 = env["fp32.miou40"] - float(gold["miou40"])
+    e_dev = (np.abs(env["bf16emu.losses"] - gold["losses"]) / gold["losses"]).max(1)
+    print(f"imported reference, bf16 storage emulated, {e20.size} draws: K=20 {e20.min():+.5f} ... {e20.max():+.5f} (median {np.median(e20):+.5f}), "
+          f"K=40 {e40.min():+.5f} ... {e40.max():+.5f} (median {np.median(e40):+.5f}), loss deviation up to {e_dev.max():.2f}; "
+          f"fp32 under the perturbations: K=40 {f40.min():+.5f} ... {f40.max():+.5f}")
+    assert e20.size >= 20 and abs(float(env["fp32.miou40"][0]) - float(gold["miou40"])) < 1e-4      # (the fixture is the protocol's)
     dev = torch.device("cuda:0")
     (xA, xB, mask), (eA, eB, emask) = protocol_tiles()
 
@@ -60,7 +79,7 @@ def test_kstep_run_miou_matches_cpu_fp32_reference_run(golden_dir, precision):
     d_iou = {k: [] for k in CHECKPOINTS}
     runs = []
     model = None
-    for pz in DRAWS:
+    for pz in DRAWS[precision]:
         sd = seeded_fill_(R.new_state_dict(2, 3, 32))
         if pz:
             sd["conv0_0.conv1.weight"] = sd["conv0_0.conv1.weight"] * (1.0 + pz)
@@ -81,22 +100,29 @@ def test_kstep_run_miou_matches_cpu_fp32_reference_run(golden_dir, precision):
                       f"{np.array2string(d_iou[k + 1][-1], precision=5)}; pixels in other confusion-matrix cells: {int(np.abs(cm - g_cm).sum()) // 2} of "
                       f"{int(cm.sum())}; loss {losses[-1]:.5f} vs {gold['losses'][k]:.5f}")
         runs.append(np.array(losses))
-    # (K: median |delta mIoU| bound, median per-class IoU bound, |delta mIoU| bound of every draw but the worst)
-    bounds = {"fp32": {20: (2e-3, 5e-3, 6e-3), 40: (5e-4, 1.5e-3, 1.5e-3)}, "bf16": {20: (3e-2, 5e-2, 2e-1), 40: (2e-3, 5e-3, 1e-2)}}[precision]
+    runs = np.stack(runs)
+    rel = np.abs(runs - gold["losses"]) / gold["losses"]
     for k in CHECKPOINTS:
-        med = float(np.median(d_miou[k]))
-        med_iou = np.median(np.stack(d_iou[k]), axis=0)
-        print(f"{precision} K={k}: median delta mIoU {med:+.5f} over draws {np.round(d_miou[k], 5).tolist()}")
-        assert abs(med) <= bounds[k][0], (k, d_miou[k])
-        assert np.abs(med_iou).max() <= bounds[k][1], (k, med_iou)
-        worst = sorted(abs(d) for d in d_miou[k])
-        print(f"{precision} K={k}: worst draw {worst[-1]:.5f}, second worst {worst[-2]:.5f}")
-        assert worst[-2] <= bounds[k][2], (k, d_miou[k])
-    # the loss trajectory follows the oracle's: first step of the seeded weights to rounding, the per-step median of the draws in a band
-    assert abs(runs[0][0] - gold["losses"][0]) < (2e-4 if precision == "fp32" else 2e-2) * gold["losses"][0]
-    rel = np.abs(np.median(np.stack(runs), axis=0) - gold["losses"]) / gold["losses"]
-    assert rel.max() < (0.1 if precision == "fp32" else 0.35), rel
-    if precision == "bf16":
+        print(f"{precision} K={k}: delta mIoU of every draw {np.round(d_miou[k], 5).tolist()}; median {float(np.median(d_miou[k])):+.5f}")
+    print(f"{precision}: largest relative deviation of the loss trajectory per draw {np.round(rel.max(1), 3).tolist()}")
+    a20, a40 = np.abs(d_miou[20]), np.abs(d_miou[40])
+    if precision == "fp32":
+        # every draw: the HIP fp32 run IS the reference's run up to the chaos a 1e-7 perturbation shows on the reference itself (5e-4)
+        assert a40.max() <= 1e-3, d_miou[40]
+        assert a20.max() <= 3e-3, d_miou[20]
+        assert np.abs(np.stack(d_iou[40])).max() <= 3e-3 and np.abs(np.stack(d_iou[20])).max() <= 8e-3
+        assert rel.max() < 0.15, rel.max(1)
+        assert rel[0, 0] < 2e-4                                       # first step of the seeded weights: to rounding
+    else:
+        # every draw inside the emulated reference's envelope at K = 20 ...
+        assert min(d_miou[20]) >= e20.min() and max(d_miou[20]) <= max(e20.max(), 0.002), (d_miou[20], e20.min(), e20.max())
+        # ... within 0.003 at K = 40 (inside the emulated envelope -0.0036 ... +0.0016 widened to the survey's +-0.002), the median within the survey's gate
+        assert a40.max() <= 3e-3, d_miou[40]
+        assert abs(float(np.median(d_miou[40]))) <= 2e-3, d_miou[40]
+        assert np.abs(np.stack(d_iou[40])).max() <= 8e-3, d_iou[40]
+        # ... and no loss excursion: the emulated reference reaches 1.8 (2.8 x the fp32 loss at step 5), round 4's HIP path reached 16
+        assert rel.max() <= 1.0, rel.max(1)
+        assert rel[0, 0] < 2e-2
         # bf16 inference of the trained weights vs fp32 inference of the SAME weights: the eval path is not where bf16 differs
         m32 = SNUNet_ECAM(2, 3, base_channel=32, precision="fp32")
         m32.load_state_dict({k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
