@@ -53,7 +53,7 @@ __device__ __forceinline__ void igemm_epilogue(const ksmi_conv_desc& d, f32x4 (&
   const FastDiv dTW(d.TW);
   // ---- epilogue ---------------------------------------------------------------------------------
   // phase 1: accumulators (+bias) -> LDS tile [P][BN] in T (C layout: col n = l15, row = g*4 + r);
-  //          plain BatchNorm statistics (sum, sumsq) straight from the fp32 registers.
+  //          plain BatchNorm statistics (sum, sumsq) of the values as stored (rounded to T), from registers.
   // phase 2: 16-byte vectors LDS -> (mask, accumulate) -> coalesced global stores.
   constexpr int LDT = BN + 16 / (int)sizeof(T);          // row stride in elements (+16 B pad)
   T* tile = (T*)smem;
@@ -81,7 +81,8 @@ __device__ __forceinline__ void igemm_epilogue(const ksmi_conv_desc& d, f32x4 (&
       for (int r = 0; r < 4; ++r) {
         const int p = wave * 64 + mf * 16 + g * 4 + r;
         const float v = acc[mf][nf][r] + bias;
-        if (rvalid[mf][r] && nvalid) { s_sum[nf] += v; s_sq[nf] += v * v; }
+        const float q = ElemTraits<T>::cvt(v);               // statistics of the STORED value (identity in fp32), round 5
+        if (rvalid[mf][r] && nvalid) { s_sum[nf] += q; s_sq[nf] += q * q; }
         if (p < P) ElemTraits<T>::st(tile + p * LDT + nf * 16 + l15, v);
       }
   }
