@@ -100,15 +100,16 @@ TRAFFIC_KERNELS = {
     "gemm_nn": (r"gemm2_kernel<\d+, true>", r"gemm_nn_kernel"),
 }
 TRAFFIC_FILE = {"snunet": "snunet", "changeformer": "changeformer", "floodvit": "floodvit", "unet": "unet", "mae": "mae"}
-TRAFFIC_ROUND = "r04"
+TRAFFIC_ROUNDS = ("r05", "r04")     # newest committed table first
 
 
 def measured_traffic(kind, model="snunet"):
     """HBM bytes per launch of the dominant kernel class by the PMC counters (None when no table / no mapping): call-weighted mean of
     2 x FETCH_SIZE + WRITE_SIZE over the kernels of the class (x2: the guide's gfx950 FETCH_SIZE correction), plus the rows it used."""
     import re
-    path = os.path.join(ROOT, "profiles", f"{TRAFFIC_ROUND}_{TRAFFIC_FILE.get(model, model)}_traffic.json")
-    if kind not in TRAFFIC_KERNELS or not os.path.exists(path):
+    path = next((q for q in (os.path.join(ROOT, "profiles", f"{r}_{TRAFFIC_FILE.get(model, model)}_traffic.json") for r in TRAFFIC_ROUNDS)
+                 if os.path.exists(q)), None)
+    if kind not in TRAFFIC_KERNELS or path is None:
         return None, []
     tab = json.load(open(path))["kernels"]
     pats = [re.compile(p) for p in TRAFFIC_KERNELS[kind]]
@@ -197,7 +198,7 @@ def measure_hbm_peaks(dev, gib=1):
     return out
 
 
-PROFILE_ROUNDS = ("r04", "r03")
+PROFILE_ROUNDS = ("r05", "r04", "r03")
 
 
 def profile_table(model, solo=True):

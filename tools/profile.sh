@@ -4,7 +4,7 @@
 # (--pmc never together with a trace domain other than --kernel-trace; FETCH_SIZE and WRITE_SIZE do not fit one TCC pass).
 # usage: bash tools/profile.sh <tag> [bench args...]
 set -u
-TAG=${1:-r04}; shift || true
+TAG=${1:-r05}; shift || true
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 5 --warmup 2 --no-cpu-baseline --no-solo $*"

@@ -1,7 +1,7 @@
 #!/bin/bash
 # full evidence set of a round: bench lines (contract form) + rocprofv3 summaries for the model families
 # usage (GPU box): bash tools/profile_all.sh <tag>      -> gpurun_out/<tag>_* ; copy what is to be judged into profiles/
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $R/gpurun_out
 bash $R/tools/profile.sh ${TAG} > $R/gpurun_out/prof_${TAG}.log 2>&1
