@@ -534,6 +534,7 @@ def main():
         marks[i].record()                       # one event per step boundary on the caller's stream (every step joins its streams there)
         step.run()
     marks[args.steps].record()
+    t_issue = time.perf_counter() - t0            # host time to ENQUEUE the K steps (no wait inside): >= dt would mean a host-bound step
     sync()
     dt = time.perf_counter() - t0
     step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
@@ -597,6 +598,7 @@ def main():
             "value": round(B * world * args.steps / dt, 2), "unit": "tiles/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 3), "ms_per_step_p50": round(p50_ms, 3), "ms_per_step_min_max": [round(step_ms[0], 3), round(step_ms[-1], 3)],
+            "host_issue_ms_per_step": round(t_issue / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": workload + ("+RCCL all-reduce" if world > 1 else "") + (" [HIP graph replay]" if graph else ""),

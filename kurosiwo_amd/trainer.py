@@ -35,6 +35,8 @@ class _PlanTrainStep:
         n = model.flat_params.numel()
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         ready = {k: self.plan.param_ready.get(k, -1) for k in model._poff}
+        if os.environ.get("KSMI_DP_BUCKET_MB"):                        # A/B knob: gradient bucket size of the data-parallel all-reduce
+            bucket_mb = float(os.environ["KSMI_DP_BUCKET_MB"])
         buckets = make_buckets(ready, model._poff, None, n, int(bucket_mb * 1e6 / 4))
         self.grad_dtype = grad_dtype or default_grad_dtype(n)          # wire format of the gradient buckets (dp.py)
         self.reducer = BucketedAllReduce(model.flat_grads, buckets, group, self.grad_dtype if self.world > 1 or os.environ.get("KSMI_DP_FORCE") else "fp32",
