@@ -132,7 +132,10 @@ int ksmi_last_kernels(char* buf, int cap);
 /* Device-memory rate probes (measurement aid: bench.py `roofline.measured_peaks`, SURVEY.md §8(d) "measure ... on the box and quote
  * both"): ONE asynchronous pass over `nbytes` of a (and b, c) on `stream`, timed by the caller with HIP events.  mode 0 read by LDS-DMA
  * (nbytes a multiple of 32 MiB), 1 read by 16-byte non-temporal loads, 2 copy a -> b, 3 fp32 triad c = a + s b, 4 fill a; | 8: non-temporal
- * loads / stores, | 16 * g: 8192 >> g workgroups, | 64: one contiguous chunk per workgroup (the caller keeps the best variant).  `sink`: two device words the read probes may write. */
+ * loads / stores, | 16 * g: 8192 >> g workgroups, | 64: one contiguous chunk per workgroup (the caller keeps the best variant).  Mode 0
+ * only: | (w << 8), 16 <= w <= 63: the reads wrap inside a window of 2^w bytes (the same nbytes of LDS-DMA traffic served by the L2 or
+ * the memory-side cache instead of HBM: the LDS fill rate of on-chip data, tools/fill_probe.py), | (1 << 14): every workgroup walks the
+ * same addresses.  `sink`: two device words the read probes may write. */
 int ksmi_hbm_probe(int mode, const void* a, void* b, void* c, size_t nbytes, unsigned* sink, void* stream);
 size_t ksmi_desc_size(int which);
 /* 1: ksmi_conv_forward(d, dtype) runs on a kernel that implements the gate epilogue (gate_src) for this descriptor */
