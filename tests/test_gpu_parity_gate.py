@@ -36,9 +36,15 @@ pytestmark = pytest.mark.gpu
 # What the bounds are held to: tests/golden/snunet_parity_draws_ref.npz = the same protocol on the IMPORTED reference under 23 such
 # perturbations with bf16 STORAGE emulated (oracle/bf16_storage.py, oracle/gen_parity_draws.py) and 4 in fp32.  The reference's own fp32
 # run moves by <= 5e-4 under a 1e-7 perturbation; its bf16-storage run by -0.040 ... +0.0003 at K = 20 (still on the steep part of the
-# learning curve) and -0.0036 ... +0.0016 at K = 40, loss up to 2.8 x the fp32 trajectory at step 5.  bf16: every HIP draw must be
-# inside that envelope at K = 20, within 0.003 at K = 40 (the survey's +-0.002 is asserted on the median; one emulated-reference draw
-# in eight is outside it) and never more than 1.0 off the fp32 loss trajectory (relative).  fp32: every draw within 1e-3 / 3e-3.
+# learning curve) and -0.0036 ... +0.0016 at K = 40 (3 draws of 23 outside the survey's +-0.002), loss up to 2.8 x the fp32 trajectory
+# at step 5 (2 excursions above 1.0).  Sixty further HIP draws (profiles/r05_parity_draws60.txt) have the same shape: 5 of 60 outside
+# +-0.002 at K = 40 (worst -0.0068), 4 excursions above 1.0 (worst 3.4): a 40-step Adam run on batches of 4 in bf16 storage is that
+# noisy on either side.  The gate therefore has two tiers, both over EVERY draw:
+#   bf16, hard bounds (no run of either side has come near them since the fix; round 4's seeded run broke all three):
+#       |d mIoU| <= 0.01 at K = 40, <= 0.08 at K = 20, loss never more than 5.0 off the fp32 trajectory (relative);
+#   bf16, distribution: median within the survey's +-0.002 at K = 40 and within 0.015 at K = 20; at least 9 of the 11 draws within
+#       0.003 at K = 40 and inside the emulated reference's K = 20 envelope (the emulated reference itself: 21 of 23 / all);
+#   fp32: every draw within 1e-3 (K = 40) / 3e-3 (K = 20), loss trajectory within 0.15.
 DRAWS = {"fp32": (0.0, 1e-7, -1e-7, 2e-7, -2e-7, 3e-7, -3e-7),
          "bf16": (0.0, 1e-7, -1e-7, 2e-7, -2e-7, 3e-7, -3e-7, 5e-7, -5e-7, 1e-6, -1e-6)}
 
@@ -114,14 +120,18 @@ def test_kstep_run_miou_matches_cpu_fp32_reference_run(golden_dir, precision):
         assert rel.max() < 0.15, rel.max(1)
         assert rel[0, 0] < 2e-4                                       # first step of the seeded weights: to rounding
     else:
-        # every draw inside the emulated reference's envelope at K = 20 ...
-        assert min(d_miou[20]) >= e20.min() and max(d_miou[20]) <= max(e20.max(), 0.002), (d_miou[20], e20.min(), e20.max())
-        # ... within 0.003 at K = 40 (inside the emulated envelope -0.0036 ... +0.0016 widened to the survey's +-0.002), the median within the survey's gate
-        assert a40.max() <= 3e-3, d_miou[40]
-        assert abs(float(np.median(d_miou[40]))) <= 2e-3, d_miou[40]
-        assert np.abs(np.stack(d_iou[40])).max() <= 8e-3, d_iou[40]
-        # ... and no loss excursion: the emulated reference reaches 1.8 (2.8 x the fp32 loss at step 5), round 4's HIP path reached 16
-        assert rel.max() <= 1.0, rel.max(1)
+        # tier 1, every draw: hard bounds
+        assert a40.max() <= 1e-2, d_miou[40]
+        assert a20.max() <= 8e-2, d_miou[20]
+        assert rel.max() <= 5.0, rel.max(1)
+        assert np.abs(np.stack(d_iou[40])).max() <= 2.5e-2, d_iou[40]
+        # tier 2, the distribution of the draws against the emulated reference's
+        assert abs(float(np.median(d_miou[40]))) <= 2e-3, d_miou[40]                       # the survey's gate, on the median
+        assert abs(float(np.median(d_miou[20]))) <= 1.5e-2, d_miou[20]
+        n = len(d_miou[40])
+        assert int((a40 <= 3e-3).sum()) >= n - 2, d_miou[40]                               # emulated reference: 21 of 23
+        assert int(((np.array(d_miou[20]) >= e20.min()) & (np.array(d_miou[20]) <= max(e20.max(), 0.002))).sum()) >= n - 2, (d_miou[20], e20.min())
+        assert int((rel.max(1) <= 1.0).sum()) >= n - 2, rel.max(1)                         # loss excursions: emulated reference 2 of 23
         assert rel[0, 0] < 2e-2
         # bf16 inference of the trained weights vs fp32 inference of the SAME weights: the eval path is not where bf16 differs
         m32 = SNUNet_ECAM(2, 3, base_channel=32, precision="fp32")
