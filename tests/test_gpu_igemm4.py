@@ -186,3 +186,31 @@ def test_igemm4_matches_igemm2_bitwise_inputs(dev):
     y1, st = Fk.conv3x3([x], w, None, want_stats=True)
     assert torch.equal(y0, y1)
     assert st is not None and torch.isfinite(st).all()
+
+
+@pytest.mark.parametrize("switch", ["KSMI_IG4_NW4", "KSMI_IG4_DEEP"])
+def test_opt_in_schedules_in_their_own_process(switch):
+    """The round-5 variants (4-wave workgroups two per CU; 5-slot weight ring with four steps of lead) are compiled into the library and
+    selected by switches the launcher reads once per process: this file's cases run again in a child process with the switch on --
+    the 32-column cases (plain, mask, gate epilogues; virtual concat; full machine and a 3-workgroup grid) are the ones they serve, the
+    others must be unaffected -- plus a check that the switch really changed the geometry (statistics rows of a level-0 shape)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **{switch: "1"})
+    probe = ("import sys, torch; sys.path.insert(0, %r); from kurosiwo_amd.runtime import make_conv, SrcSpec, conv_stats_rows; "
+             "x = torch.empty(1, dtype=torch.bfloat16); "
+             "d, t = make_conv([SrcSpec(x, 32), SrcSpec(x, 32), SrcSpec(x, 64)], [(x, 32, 0, 0, 32, 0)], x, None, None, 32, 224, 224, 224, 224, 3, 3, 1, 1, 32, torch.bfloat16); "
+             "print('ROWS', conv_stats_rows(d, torch.bfloat16))" % root)
+    rows = {}
+    for tag, e in (("off", dict(os.environ)), ("on", env)):
+        e.pop(switch, None) if tag == "off" else None
+        out = subprocess.run([sys.executable, "-c", probe], env=e, capture_output=True, text=True, timeout=600, cwd=root)
+        assert out.returncode == 0, out.stderr[-2000:]
+        rows[tag] = int(out.stdout.split("ROWS")[1].split()[0])
+    if switch == "KSMI_IG4_NW4":
+        assert rows["on"] > 256 >= rows["off"], rows            # two workgroups per CU: up to 512 persistent workgroups
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-k", "not opt_in"],
+                         env=env, capture_output=True, text=True, timeout=1800, cwd=root)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert " passed" in out.stdout
