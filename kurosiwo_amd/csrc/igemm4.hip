@@ -863,7 +863,11 @@ bool ksmi_igemm4_geom(const ksmi_conv_desc* d, int dtype, ksmi_igemm4_geom_t* g)
   static const int nw4 = getenv("KSMI_IG4_NW4") ? atoi(getenv("KSMI_IG4_NW4")) : 0;
   if (d->Npad == 32 && nw4) cand[nc++] = {4, 2, 4};                 // 256 px x 32, wave 64 x 32, two workgroups per CU
   if (d->Npad % 128 == 0) cand[nc++] = {4, 4, 8};                   // 256 px x 128 columns, wave 64 x 64
-  if (d->Npad % 64 == 0) { cand[nc++] = {8, 4, 8}; cand[nc++] = {4, 2, 8}; }   // 512 px x 64 (wave 64 x 64) / 256 px x 64 (wave 64 x 32)
+  // 64 columns exactly (SNUNet level 1): 256 px x 64 tiles make 7 rounds of 224 workgroups at 112^2 x 32 (88 % of the slots filled) where
+  // the 512 px ones make 4 rounds of 208 (77 %): 2-8 % shorter per launch (profiles/r05_ig4_variants.txt (e)); KSMI_IG4_N64=84 restores the old order
+  static const int n64 = getenv("KSMI_IG4_N64") ? atoi(getenv("KSMI_IG4_N64")) : 42;
+  if (d->Npad == 64 && n64 == 42) { cand[nc++] = {4, 2, 8}; cand[nc++] = {8, 4, 8}; }
+  else if (d->Npad % 64 == 0) { cand[nc++] = {8, 4, 8}; cand[nc++] = {4, 2, 8}; }   // 512 px x 64 (wave 64 x 64) / 256 px x 64 (wave 64 x 32)
   if (d->Npad == 32) cand[nc++] = {8, 2, 8};                        // 512 px x 32, wave 64 x 32
   for (int ci = 0; ci < nc; ++ci) {
     const int wm = cand[ci].wm, nf = cand[ci].nf, nwv = cand[ci].nwv;
