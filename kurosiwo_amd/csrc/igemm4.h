@@ -7,7 +7,7 @@
 struct ksmi_igemm4_geom_t {
   int WM, NF;           // pixel groups of 64 (4 | 8; column groups = nwv / WM); 16-column MFMA fragments per wave (2 | 4)
   int nwv;              // waves per workgroup: 8 (one workgroup per CU) | 4 (two per CU, round 5)
-  int deep;             // 5-slot weight ring, weights four steps ahead (run_tiles_deep, round 5)
+  int deep;             // 1: 5-slot weight ring, weights four steps ahead (run_tiles_deep); 2: one barrier per chunk (run_tiles_chunk); round 5
   int th, tw;           // output patch of a workgroup (the descriptor's for WM = 4, chosen by the kernel for WM = 8)
   int hslot, nh, nhs;   // halo ring: bytes per slot, DMA pieces per wave and slot, slots
   int tiles, gx, gy;    // pixel tiles; persistent workgroups along the pixel axis (= rows of `stats`); column tiles

@@ -88,7 +88,12 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void igemm4_kernel(cons
   constexpr int NHM = NWV == 4 ? 6 : (WM == 4 ? 3 : IG4_NHMAX);   // halo pieces per wave and slot: 24 KiB (<= 384 halo pixels) / 40 KiB (<= 640)
   constexpr int HSLOT = NHM * NT * 16;
   constexpr int nh = NHM;
-  constexpr int NHS = (NWV == 4 || (WM == 8 && NF == 4)) ? 2 : 3;   // halo ring slots (what 160 KiB -- 80 KiB for NWV = 4 -- holds next to the weight ring)
+  // CHUNK (ROT == 3, round 5): ONE wait + barrier per 32-channel chunk instead of one per kernel row.  The weights of a whole chunk
+  // (3 rows) are resident when the chunk starts (weight ring = 2 chunks x 3 rows), so a wave issues 9 taps = 9 * 4 * NF MFMAs between
+  // two barriers: at NF = 2 a row step is 24 MFMAs per wave (384 cycles) against ~520 cycles of wait + barrier + first-fragment latency
+  // (cycle stamps, profiles/r05_ig4_phases.txt) -- the 32 / 64-column kernels were bound by the step skeleton, not by MFMAs or LDS.
+  constexpr bool CHUNK = ROT == 3;
+  constexpr int NHS = (NWV == 4 || (WM == 8 && NF == 4) || (CHUNK && WM == 8)) ? 2 : 3;   // halo ring slots (what 160 KiB -- 80 KiB for NWV = 4 -- holds next to the weight ring)
   // DEEP (round 5): weight ring of 5 step slots, weights issued FOUR steps ahead (run_tiles_deep).  vmcnt completes in issue order, so
   // the wait for the weights of a step also forces every older DMA: with the 3-slot ring (weights two steps ahead) a halo chunk had
   // ONE chunk time (3 steps) to land however many ring slots it owned, and the 32-column level-0 layers ran their K loop at the
@@ -96,7 +101,8 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void igemm4_kernel(cons
   // profiles/r05_ig4_phases.txt).  Four steps of weight lead give a halo chunk five steps.
   constexpr bool DEEP = ROT == 2;              // (launcher: only where !AFF, NHS == 3, NWV == 8, BN <= 64)
   static_assert(!DEEP || (!AFF && !DBG && NHS == 3 && NWV == 8 && BN <= 64), "deep weight ring: 32 / 64-column tiles with three halo slots");
-  constexpr int NWS = DEEP ? 5 : 3;            // weight ring slots
+  static_assert(!CHUNK || (!AFF && !DBG && NWV == 8 && NF == 2), "chunk-granular schedule: the NF = 2 tiles");
+  constexpr int NWS = CHUNK ? 6 : (DEEP ? 5 : 3);   // weight ring slots (one kernel row of taps each)
   constexpr int nhs = NHS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -773,10 +779,85 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void igemm4_kernel(cons
     }
     vm_wait_c<0>();
   };
+
+  // CHUNK schedule (see the constant).  Per chunk c: wait for W(c) (3 rows) and H(c) -> barrier -> issue W(c + 1) into the other half of
+  // the weight ring and the halo of chunk c + LA into the slot chunk c - 1 used -> 9 taps.  Issue order per chunk: weights, then halo:
+  //   LA = 2: the halo issued one chunk ago (for c + 1) is the only DMA younger than W(c)  -> vmcnt(nh);   LA = 1: nothing is -> vmcnt(0).
+  auto run_tiles_chunk = [&](auto) {
+    int t = pxw;
+    int go_c[NHM], go_n[NHM];
+    tile_goff(t, go_c);
+    tile_goff(t + ka.gx, go_n);
+    __syncthreads();
+    issue_H(go_c, src_tab[0], 0);
+    issue_W(0, 0, 0); issue_W(0, 1, 1); issue_W(0, 2, 2);
+    if constexpr (LA > 1) issue_H(go_c, src_tab[1], 1);
+    int hs = 0;
+    int wp = 0;                                                       // half of the weight ring that holds the current chunk
+    for (;;) {
+      f32x4 acc[4][NF];
+#pragma unroll
+      for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int c = 0; c < nch; ++c) {
+        const int c1 = c + 1 == nch ? 0 : c + 1;
+        const unsigned char* lds_h = smem + hs * HSLOT;
+        const int hprev = hs == 0 ? NHS - 1 : hs - 1;
+        const int hnext = hs + 1 == NHS ? 0 : hs + 1;
+        int c2 = c + LA;
+        const bool nextt = c2 >= nch;
+        if (nextt) c2 -= nch;
+        const u32x4 ent = src_tab[c2];
+        int go_i[NHM];
+#pragma unroll
+        for (int k = 0; k < NHM; ++k) go_i[k] = nextt ? go_n[k] : go_c[k];
+        if constexpr (LA > 1) vm_wait_c<nh>(); else vm_wait_c<0>();
+        lds_barrier();
+        const unsigned char* lds_w = wring + wp * 3 * WSLOT;
+        u32x4 fa[2][4], fb[2][NF];
+#pragma unroll
+        for (int mf = 0; mf < 4; ++mf) fa[0][mf] = *(const u32x4*)(lds_h + a_addr[mf][0]);
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) fb[0][nf] = *(const u32x4*)(lds_w + b_addr[nf]);
+        {                                                             // refill behind the first fragment requests (their latency covers the address arithmetic)
+          const int wn_ = (wp ^ 1) * 3;
+          issue_W(c1, 0, wn_); issue_W(c1, 1, wn_ + 1); issue_W(c1, 2, wn_ + 2);
+          issue_H(go_i, ent, LA > 1 ? hprev : hnext);
+        }
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+          const int cur = j & 1, nxt = cur ^ 1;
+          if (j + 1 < 9) {
+            const int r1 = (j + 1) / 3, k1 = (j + 1) % 3;
+#pragma unroll
+            for (int mf = 0; mf < 4; ++mf) fa[nxt][mf] = *(const u32x4*)(lds_h + r1 * pitch + a_addr[mf][k1]);
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) fb[nxt][nf] = *(const u32x4*)(lds_w + (r1 * 3 + k1) * BN * 64 + b_addr[nf]);
+          }
+#pragma unroll
+          for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) mma16<T>(acc[mf][nf], fb[cur][nf], fa[cur][mf]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        hs = hnext;
+        wp ^= 1;
+      }
+      tile_epilogue(t, acc);
+      if (t + ka.gx >= ka.tiles) break;
+      t += ka.gx;
+#pragma unroll
+      for (int k = 0; k < NHM; ++k) go_c[k] = go_n[k];
+      tile_goff(t + ka.gx, go_n);
+    }
+    vm_wait_c<0>();
+  };
   STAMP();
   if (DBG && (dbg & 32)) return;                                        // (profiling: table setup only)
   if (pxw < ka.tiles) {
-    if constexpr (DEEP) run_tiles_deep(0);
+    if constexpr (CHUNK) run_tiles_chunk(0);
+    else if constexpr (DEEP) run_tiles_deep(0);
     else if constexpr (ROT != 0) run_tiles_rot(0);
     else { if (late) run_tiles(std::true_type{}); else run_tiles(std::false_type{}); }
   }
@@ -896,11 +977,14 @@ bool ksmi_igemm4_geom(const ksmi_conv_desc* d, int dtype, ksmi_igemm4_geom_t* g)
     const size_t tabs = (size_t)(nwv * 2 * 16 * nf + bn) * 4 + (size_t)KSMI_MAX_CHUNKS * 16 + (aff ? (size_t)d->nchunks * 32 * 2 * 4 : 0);
     static const int rot_on = getenv("KSMI_IG4_ROT") ? atoi(getenv("KSMI_IG4_ROT")) : 1;
     static const int deep_on = getenv("KSMI_IG4_DEEP") ? atoi(getenv("KSMI_IG4_DEEP")) : 0;   // (the kernel's DEEP: compiled in; the switch forces the per-role schedule instead)
-    const int nhs_ = (nwv == 4 || (wm == 8 && nf == 4)) ? 2 : 3;
-    const bool deep = rot_on && deep_on && !aff && nhs_ == 3 && nwv == 8 && nf == 2;      // <8,2> (32 columns) and <4,2> (64 columns)
-    g->deep = deep ? 1 : 0;
-    const size_t wr = (deep ? 5 : 3) * (size_t)(3 * bn * 64);
-    g->nhs = (nwv == 4 || (wm == 8 && nf == 4)) ? 2 : 3;            // (= the kernel's NHS)
+    // chunk-granular schedule (kernel: CHUNK = ROT == 3) for the NF = 2 tiles: KSMI_IG4_CHUNK (1 = on)
+    static const int chunk_on = getenv("KSMI_IG4_CHUNK") ? atoi(getenv("KSMI_IG4_CHUNK")) : 0;
+    const bool chunk = rot_on && chunk_on && !aff && nwv == 8 && nf == 2;
+    const int nhs_ = (nwv == 4 || (wm == 8 && nf == 4) || (chunk && wm == 8)) ? 2 : 3;
+    const bool deep = !chunk && rot_on && deep_on && !aff && nhs_ == 3 && nwv == 8 && nf == 2;      // <8,2> (32 columns) and <4,2> (64 columns)
+    g->deep = chunk ? 2 : (deep ? 1 : 0);
+    const size_t wr = (chunk ? 6 : (deep ? 5 : 3)) * (size_t)(3 * bn * 64);
+    g->nhs = nhs_;                                                  // (= the kernel's NHS)
     g->lds = (size_t)g->nhs * g->hslot + wr + ((3 * bn / 16) % nwv ? 4096 : 0) + tabs;
     const int per_cu = nwv == 4 ? 2 : 1;
     if (g->lds * per_cu > 160 * 1024) continue;
@@ -995,7 +1079,21 @@ int ksmi_igemm4_launch(const ksmi_conv_desc* d, const ksmi_igemm4_geom_t* g, hip
     if (aff) KSMI_G4N(true, 0, false); else if (mask) KSMI_G4N(false, 1, false); else if (gate) KSMI_G4N(false, 2, false); else KSMI_G4N(false, 0, false);
 #undef KSMI_G4N
   }
-  if (g->deep) {
+  if (g->deep == 2) {
+#define KSMI_G4CH(WM_, NF_, EPI_)                                                                    \
+  do {                                                                                               \
+    auto kfn = igemm4_kernel<WM_, NF_, false, EPI_, false, 0, 3>; KSMI_NOTE(kfn);                                    \
+    static bool attr_set = false;                                                                    \
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; } \
+    hipLaunchKernelGGL(kfn, grid, dim3(512), g->lds, st, ka);                                        \
+    return ksmi_check_launch("igemm4");                                                              \
+  } while (0)
+    if (aff || g->nwv != 8 || g->NF != 2) return ksmi_fail(KSMI_E_UNSUPPORTED, "igemm4: no chunk-schedule instance");
+    if (g->WM == 8) { if (mask) KSMI_G4CH(8, 2, 1); else if (gate) KSMI_G4CH(8, 2, 2); else KSMI_G4CH(8, 2, 0); }
+    else { if (mask) KSMI_G4CH(4, 2, 1); else if (gate) KSMI_G4CH(4, 2, 2); else KSMI_G4CH(4, 2, 0); }
+#undef KSMI_G4CH
+  }
+  if (g->deep == 1) {
 #define KSMI_G4DP(WM_, NF_, EPI_)                                                                    \
   do {                                                                                               \
     auto kfn = igemm4_kernel<WM_, NF_, false, EPI_, false, 0, 2>; KSMI_NOTE(kfn);                                    \
