@@ -188,9 +188,9 @@ def test_igemm4_matches_igemm2_bitwise_inputs(dev):
     assert st is not None and torch.isfinite(st).all()
 
 
-@pytest.mark.parametrize("switch", ["KSMI_IG4_NW4", "KSMI_IG4_DEEP"])
+@pytest.mark.parametrize("switch", ["KSMI_IG4_NW4", "KSMI_IG4_DEEP", "KSMI_IG4_CHUNK"])
 def test_opt_in_schedules_in_their_own_process(switch):
-    """The round-5 variants (4-wave workgroups two per CU; 5-slot weight ring with four steps of lead) are compiled into the library and
+    """The round-5 variants (4-wave workgroups two per CU; 5-slot weight ring with four steps of lead; one barrier per chunk) are compiled into the library and
     selected by switches the launcher reads once per process: this file's cases run again in a child process with the switch on --
     the 32-column cases (plain, mask, gate epilogues; virtual concat; full machine and a 3-workgroup grid) are the ones they serve, the
     others must be unaffected -- plus a check that the switch really changed the geometry (statistics rows of a level-0 shape)."""
