@@ -18,7 +18,10 @@ import os
 import sys
 import time
 
-import torch
+if int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("KSMI_DP_FORCE"):
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "7")     # five streams under data parallelism: see kurosiwo_amd/__init__.py
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
