@@ -41,7 +41,8 @@ pytestmark = pytest.mark.gpu
 # +-0.002 at K = 40 (worst -0.0068), 4 excursions above 1.0 (worst 3.4): a 40-step Adam run on batches of 4 in bf16 storage is that
 # noisy on either side.  The gate therefore has two tiers, both over EVERY draw:
 #   bf16, hard bounds (no run of either side has come near them since the fix; round 4's seeded run broke all three):
-#       |d mIoU| <= 0.01 at K = 40, <= 0.08 at K = 20, loss never more than 5.0 off the fp32 trajectory (relative);
+#       |d mIoU| <= 0.015 at K = 40 (worst of 71 HIP runs: 0.0068; round 4: 0.033), <= 0.1 at K = 20 (0.055; 0.256), loss never more than 5.0 off
+#       the fp32 trajectory, relative (3.4; 16);
 #   bf16, distribution: median within the survey's +-0.002 at K = 40 and within 0.015 at K = 20; at least 9 of the 11 draws within
 #       0.003 at K = 40 and inside the emulated reference's K = 20 envelope (the emulated reference itself: 21 of 23 / all);
 #   fp32: every draw within 1e-3 (K = 40) / 3e-3 (K = 20), loss trajectory within 0.15.
@@ -121,8 +122,8 @@ def test_kstep_run_miou_matches_cpu_fp32_reference_run(golden_dir, precision):
         assert rel[0, 0] < 2e-4                                       # first step of the seeded weights: to rounding
     else:
         # tier 1, every draw: hard bounds
-        assert a40.max() <= 1e-2, d_miou[40]
-        assert a20.max() <= 8e-2, d_miou[20]
+        assert a40.max() <= 1.5e-2, d_miou[40]
+        assert a20.max() <= 1e-1, d_miou[20]
         assert rel.max() <= 5.0, rel.max(1)
         assert np.abs(np.stack(d_iou[40])).max() <= 2.5e-2, d_iou[40]
         # tier 2, the distribution of the draws against the emulated reference's
