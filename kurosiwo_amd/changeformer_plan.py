@@ -14,7 +14,7 @@ import torch
 from . import _lib
 from .changeformer import DEPTHS, EMBED_DIMS, NUM_HEADS, SR_RATIOS
 from .plan_base import PlanBase
-from .runtime import SrcSpec, conv_grid_m, make_conv, make_wgrad
+from .runtime import SrcSpec, conv_grid_m, conv_stats_rows, make_conv, make_wgrad
 from .snunet_plan import _Saved
 
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
@@ -451,7 +451,7 @@ class ChangeFormerPlan(PlanBase):
                 d, table = make_conv(src, [(dx, Cin, 0, 0, Cin, 0 if first else 1)], dx, None, None, B, H, W, H, W, 2, 2, 1, py, Cin, self.dtype,
                                      mask=self._nomask(r, sv), pad_x=px, in_map=(2, 2, py, px, 2 * H, 2 * W))
                 d.wpk = self._packed(wkey, table, 4, Cin, Cin, 16, N * 16, 0, 1, 0, tap_map).data_ptr()
-                rows = conv_grid_m(d)
+                rows = conv_stats_rows(d, self.dtype)               # (one row per persistent workgroup on igemm4's 2 x 2 instance, per M-tile on igemm2)
                 off = rows_total * 2 * d.Npad * 4
                 rows_total += rows
                 self._later.append(lambda d=d, off=off: setattr(d, "stats", self.scr("stats") + off))

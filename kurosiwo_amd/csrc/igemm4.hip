@@ -72,7 +72,10 @@ __device__ __forceinline__ int swz_h(int hx) { return ((hx >> 2) & 1) << 1; }
 // NWV: waves per workgroup.  8 = one 512-thread workgroup per CU (two waves per SIMD in lock step of the step barriers).  4 (round 5) =
 // 256-thread workgroups, TWO per CU, each with its own rings (halo ring of 2 slots): the two workgroups of a CU drift apart, so the
 // epilogue / store acknowledgement / tile prologue / barrier skew of one is covered by the K loop of the other.
-template <int WM, int NF, bool AFF, int EPI, bool DBG = false, int DIR = 0, int ROT = 0, int NWV = 8>
+// KH x KW: taps.  3 x 3 everywhere except the 2 x 2 stride-1 PHASE convolutions of ConvTranspose2d(k4, s2, p1) and of its input gradient
+// (models/changeformer.py:329-336; plan_base._deconv / _deconv_bwd: strided output / input views, per-phase padding 0 | 1), which
+// run on the chunk-granular schedule (ROT == 3) only.
+template <int WM, int NF, bool AFF, int EPI, bool DBG = false, int DIR = 0, int ROT = 0, int NWV = 8, int KH = 3, int KW = 3>
 __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void igemm4_kernel(const Ig4Args ka) {
   typedef bf16_t T;
   constexpr bool MASK = EPI == 1, GATE = EPI == 2;
@@ -82,7 +85,8 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void igemm4_kernel(cons
   constexpr int BNW = 16 * NF;                 // columns per wave
   constexpr int BN = WN * BNW;                 // columns per workgroup
   constexpr int NG = NF / 2;                   // 32-column groups per wave (epilogue ownership: 8 consecutive channels per lane)
-  constexpr int WSLOT = 3 * BN * 64;           // one kernel row of taps
+  static_assert((KH == 3 && KW == 3) || (KH == 2 && KW == 2 && ROT == 3), "taps");
+  constexpr int WSLOT = KW * BN * 64;          // one kernel row of taps
   constexpr int WPIECES = WSLOT / 1024;        // 24 (BN = 128) / 12 (BN = 64) / 6 (BN = 32)
   constexpr int WK = (WPIECES + NWV - 1) / NWV;   // pieces per wave (at most)
   constexpr int NHM = NWV == 4 ? 6 : (WM == 4 ? 3 : IG4_NHMAX);   // halo pieces per wave and slot: 24 KiB (<= 384 halo pixels) / 40 KiB (<= 640)
@@ -101,8 +105,8 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void igemm4_kernel(cons
   // profiles/r05_ig4_phases.txt).  Four steps of weight lead give a halo chunk five steps.
   constexpr bool DEEP = ROT == 2;              // (launcher: only where !AFF, NHS == 3, NWV == 8, BN <= 64)
   static_assert(!DEEP || (!AFF && !DBG && NHS == 3 && NWV == 8 && BN <= 64), "deep weight ring: 32 / 64-column tiles with three halo slots");
-  static_assert(!CHUNK || (!AFF && !DBG && NWV == 8 && NF == 2), "chunk-granular schedule: the NF = 2 tiles");
-  constexpr int NWS = CHUNK ? 6 : (DEEP ? 5 : 3);   // weight ring slots (one kernel row of taps each)
+  static_assert(!CHUNK || (!AFF && !DBG && NWV == 8 && (NF == 2 || KH == 2)), "chunk-granular schedule: the NF = 2 tiles and the 2 x 2 phase convolutions");
+  constexpr int NWS = CHUNK ? 2 * KH : (DEEP ? 5 : 3);   // weight ring slots (one kernel row of taps each)
   constexpr int nhs = NHS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -124,8 +128,8 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void igemm4_kernel(cons
   }
   const int n0 = nt * BN;
   const int TH = ka.th, TW = ka.tw;
-  const int HW = TW + 2;
-  const int HP = (TH + 2) * HW;
+  const int HW = TW + KW - 1;
+  const int HP = (TH + KH - 1) * HW;
   const int P = TH * TW;
   const int tilesX = (d.Wout + TW - 1) / TW, tilesY = (d.Hout + TH - 1) / TH;
   const FastDiv dTX(tilesX, ka.m_tx), dTY(tilesY, ka.m_ty), dHW(HW, ka.m_hw), dTW(TW, ka.m_tw);
@@ -142,14 +146,14 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void igemm4_kernel(cons
   // ---- tile-invariant tables ------------------------------------------------------------------------------------------
   // pixel fragments: the k-group slot of a halo pixel is swizzled by its COLUMN hx only, so the address of tap (ky, kx) is the
   // kx entry plus ky row pitches (12 table registers instead of 36)
-  int a_addr[4][3];
+  int a_addr[4][KW];
 #pragma unroll
   for (int mf = 0; mf < 4; ++mf) {
     int p = wm * 64 + mf * 16 + l15;
     if (p >= P) p = 0;
     const int ly = dTW.div(p), lx = p - ly * TW;
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx) a_addr[mf][kx] = (ly * HW + lx + kx) * 64 + ((g ^ swz_h(lx + kx)) << 4);
+    for (int kx = 0; kx < KW; ++kx) a_addr[mf][kx] = (ly * HW + lx + kx) * 64 + ((g ^ swz_h(lx + kx)) << 4);
   }
   const int pitch = (DBG && (dbg & 8)) ? 0 : HW * 64;
   int b_addr[NF];
@@ -162,7 +166,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void igemm4_kernel(cons
 #pragma unroll
     for (int mf = 0; mf < 4; ++mf)
 #pragma unroll
-      for (int kx = 0; kx < 3; ++kx) a_addr[mf][kx] = 0;
+      for (int kx = 0; kx < KW; ++kx) a_addr[mf][kx] = 0;
 #pragma unroll
     for (int nf = 0; nf < NF; ++nf) b_addr[nf] = 0;
   }
@@ -224,9 +228,11 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void igemm4_kernel(cons
     for (int k = 0; k < NHM; ++k) {
       const int pix = (tv + NT * k) >> 2;
       const int hy = dHW.div(pix), hx = pix - hy * HW;
-      const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+      const int iy = oy0 - d.pad + hy, ix = ox0 - d.pad_x + hx;       // (3 x 3: pad = pad_x = 1, the geometry checks it)
       const bool ok = live && pix < HP && (unsigned)iy < (unsigned)d.Hin && (unsigned)ix < (unsigned)d.Win;
-      go[k] = ok ? (b * d.Hin + iy) * d.Win + ix : -1;
+      // dense source, or (2 x 2 phase convolutions) a strided view of a [B, in_H, in_W, C] tensor (ksmi_conv_desc.in_sy ...)
+      const int gp = d.in_sy == 0 ? (b * d.Hin + iy) * d.Win + ix : (b * d.in_H + (iy * d.in_sy + d.in_oy)) * d.in_W + (ix * d.in_sx + d.in_ox);
+      go[k] = ok ? gp : -1;
     }
   };
   const uint32_t zlo = (uint32_t)(uintptr_t)ka.zero, zhi = (uint32_t)((uint64_t)(uintptr_t)ka.zero >> 32);
@@ -244,7 +250,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void igemm4_kernel(cons
   };
   const unsigned char* const wpk = (const unsigned char*)d.wpk;
   auto issue_W = [&](int ch, int r, int slot) {
-    const unsigned char* base = wpk + (size_t)(ch * 9 + 3 * r) * (size_t)d.Npad * 64;
+    const unsigned char* base = wpk + (size_t)(ch * (KH * KW) + KW * r) * (size_t)d.Npad * 64;
 #pragma unroll
     for (int k = 0; k < WK; ++k) {
       const uint64_t av = (uint64_t)(uintptr_t)base + (uint64_t)(uint32_t)w_off[k];
@@ -306,7 +312,9 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void igemm4_kernel(cons
           const int ly = dTW.div(p), lx = p - ly * TW;
           const int oy = oy0 + ly, ox = ox0 + lx;
           okp[mf] = p < P && oy < d.Hout && ox < d.Wout;
-          opix[mf] = (uint32_t)((b * d.Hout + oy) * d.Wout + ox);
+          // dense destination, or (2 x 2 forward phases) position (oy * out_sy + out_oy, ox * out_sx + out_ox) of a [B, out_H, out_W, C] tensor
+          opix[mf] = d.out_sy == 0 ? (uint32_t)((b * d.Hout + oy) * d.Wout + ox)
+                                   : (uint32_t)((b * d.out_H + (oy * d.out_sy + d.out_oy)) * d.out_W + (ox * d.out_sx + d.out_ox));
         }
 #pragma unroll
         for (int gi = 0; gi < NG; ++gi) {
@@ -790,7 +798,8 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void igemm4_kernel(cons
     tile_goff(t + ka.gx, go_n);
     __syncthreads();
     issue_H(go_c, src_tab[0], 0);
-    issue_W(0, 0, 0); issue_W(0, 1, 1); issue_W(0, 2, 2);
+#pragma unroll
+    for (int r = 0; r < KH; ++r) issue_W(0, r, r);
     if constexpr (LA > 1) issue_H(go_c, src_tab[1], 1);
     int hs = 0;
     int wp = 0;                                                       // half of the weight ring that holds the current chunk
@@ -814,26 +823,27 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void igemm4_kernel(cons
         for (int k = 0; k < NHM; ++k) go_i[k] = nextt ? go_n[k] : go_c[k];
         if constexpr (LA > 1) vm_wait_c<nh>(); else vm_wait_c<0>();
         lds_barrier();
-        const unsigned char* lds_w = wring + wp * 3 * WSLOT;
+        const unsigned char* lds_w = wring + wp * KH * WSLOT;
         u32x4 fa[2][4], fb[2][NF];
 #pragma unroll
         for (int mf = 0; mf < 4; ++mf) fa[0][mf] = *(const u32x4*)(lds_h + a_addr[mf][0]);
 #pragma unroll
         for (int nf = 0; nf < NF; ++nf) fb[0][nf] = *(const u32x4*)(lds_w + b_addr[nf]);
         {                                                             // refill behind the first fragment requests (their latency covers the address arithmetic)
-          const int wn_ = (wp ^ 1) * 3;
-          issue_W(c1, 0, wn_); issue_W(c1, 1, wn_ + 1); issue_W(c1, 2, wn_ + 2);
+          const int wn_ = (wp ^ 1) * KH;
+#pragma unroll
+          for (int r = 0; r < KH; ++r) issue_W(c1, r, wn_ + r);
           issue_H(go_i, ent, LA > 1 ? hprev : hnext);
         }
 #pragma unroll
-        for (int j = 0; j < 9; ++j) {
+        for (int j = 0; j < KH * KW; ++j) {
           const int cur = j & 1, nxt = cur ^ 1;
-          if (j + 1 < 9) {
-            const int r1 = (j + 1) / 3, k1 = (j + 1) % 3;
+          if (j + 1 < KH * KW) {
+            const int r1 = (j + 1) / KW, k1 = (j + 1) % KW;
 #pragma unroll
             for (int mf = 0; mf < 4; ++mf) fa[nxt][mf] = *(const u32x4*)(lds_h + r1 * pitch + a_addr[mf][k1]);
 #pragma unroll
-            for (int nf = 0; nf < NF; ++nf) fb[nxt][nf] = *(const u32x4*)(lds_w + (r1 * 3 + k1) * BN * 64 + b_addr[nf]);
+            for (int nf = 0; nf < NF; ++nf) fb[nxt][nf] = *(const u32x4*)(lds_w + (r1 * KW + k1) * BN * 64 + b_addr[nf]);
           }
 #pragma unroll
           for (int mf = 0; mf < 4; ++mf)
@@ -904,12 +914,21 @@ void ig4_patch(int H, int W, int pmax, int hmax, int* th_o, int* tw_o) {
 bool ksmi_igemm4_geom(const ksmi_conv_desc* d, int dtype, ksmi_igemm4_geom_t* g) {
   static const bool off = getenv("KSMI_IGEMM4_OFF") != nullptr;
   if (off || dtype != KSMI_BF16) return false;
-  if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->pad_x != 1) return false;
+  // 2 x 2 stride-1 phase convolutions of ConvTranspose2d(k4, s2, p1) and its input gradient (round 5): strided views, padding 0 | 1 per
+  // phase, 128-column tiles, the chunk-granular schedule.  KSMI_IG4_K2=0 sends them back to igemm2.
+  static const int k2_on = getenv("KSMI_IG4_K2") ? atoi(getenv("KSMI_IG4_K2")) : 1;
+  const bool k2 = d->KH == 2 && d->KW == 2;
+  if (k2) {
+    if (!k2_on || d->stride != 1 || (unsigned)d->pad > 1u || (unsigned)d->pad_x > 1u) return false;
+    if (d->Npad % 128 || d->src[0].scale || d->gate_src || (d->out_sy && (d->mask_src || d->dst[0].accumulate))) return false;
+    if (d->alpha != 0.f || d->resid || d->relu_out) return false;
+  } else if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->pad_x != 1) return false;
   if (d->Hin != d->Hout || d->Win != d->Wout) return false;
   if (d->nchunks < 2) return false;
   if (d->nchunks > KSMI_MAX_CHUNKS) return false;                   // (source table in LDS)
   if (d->ndst != 1 || d->dst[0].n_begin != 0) return false;
-  if (d->out_sy || d->in_sy || d->ps_cout) return false;
+  if (((d->out_sy || d->in_sy) && !k2) || d->ps_cout) return false;
+  if (d->out_sy && ((size_t)d->B * d->out_H * d->out_W >= ((size_t)1 << 31))) return false;
   if ((d->alpha != 0.f || d->resid || d->relu_out) && (d->mask_src || d->gate_src)) return false;      // extras: plain epilogue only
   if (d->resid && (((uintptr_t)d->resid & 15) || (d->residC % 8))) return false;
   if ((d->N % 8) || (d->dst[0].C % 8) || (d->dst[0].c_off % 8)) return false;
@@ -921,7 +940,8 @@ bool ksmi_igemm4_geom(const ksmi_conv_desc* d, int dtype, ksmi_igemm4_geom_t* g)
     if (d->src[i].c_len % 32) return false;
     if (d->src[i].scale && (i > 0 || d->nsrc != 1)) return false;
     if (!al16(d->src[i].ptr) || (d->src[i].C % 8) || (d->src[i].c_off % 8)) return false;
-    if ((size_t)d->B * d->Hin * d->Win * (size_t)d->src[i].C * 2 >= ((size_t)1 << 32)) return false;
+    const size_t ipx = d->in_sy ? (size_t)d->B * d->in_H * d->in_W : (size_t)d->B * d->Hin * d->Win;
+    if (ipx * (size_t)d->src[i].C * 2 >= ((size_t)1 << 32)) return false;
   }
   if ((size_t)d->B * d->Hout * d->Wout >= ((size_t)1 << 31)) return false;
   const bool aff = d->src[0].scale != nullptr;
@@ -942,8 +962,9 @@ bool ksmi_igemm4_geom(const ksmi_conv_desc* d, int dtype, ksmi_igemm4_geom_t* g)
   int nc = 0;
   // two 4-wave workgroups per CU for the 32-column layers (KSMI_IG4_NW4: 1 = on, 0 = off; read once)
   static const int nw4 = getenv("KSMI_IG4_NW4") ? atoi(getenv("KSMI_IG4_NW4")) : 0;
-  if (d->Npad == 32 && nw4) cand[nc++] = {4, 2, 4};                 // 256 px x 32, wave 64 x 32, two workgroups per CU
+  if (d->Npad == 32 && nw4 && !k2) cand[nc++] = {4, 2, 4};          // 256 px x 32, wave 64 x 32, two workgroups per CU
   if (d->Npad % 128 == 0) cand[nc++] = {4, 4, 8};                   // 256 px x 128 columns, wave 64 x 64
+  if (k2) nc = 1;                                                   // (2 x 2 phase convolutions: that one tile shape)
   // 64 columns exactly (SNUNet level 1): 256 px x 64 tiles make 7 rounds of 224 workgroups at 112^2 x 32 (88 % of the slots filled) where
   // the 512 px ones make 4 rounds of 208 (77 %): 2-8 % shorter per launch (profiles/r05_ig4_variants.txt (e)); KSMI_IG4_N64=84 restores the old order
   static const int n64 = getenv("KSMI_IG4_N64") ? atoi(getenv("KSMI_IG4_N64")) : 42;
@@ -962,7 +983,7 @@ bool ksmi_igemm4_geom(const ksmi_conv_desc* d, int dtype, ksmi_igemm4_geom_t* g)
       int pth = 0, ptw = 0;
       if (pe && sscanf(pe, "%d,%d", &pth, &ptw) == 2 && pth > 0 && ptw > 0 && pth * ptw <= 512 && (pth + 2) * (ptw + 2) <= IG4_NHMAX * 128) { th = pth; tw = ptw; }
     }
-    const int hp = (th + 2) * (tw + 2);
+    const int hp = (th + d->KH - 1) * (tw + d->KW - 1);
     const int tilesX = (d->Wout + tw - 1) / tw, tilesY = (d->Hout + th - 1) / th;
     const int tiles = d->B * tilesX * tilesY;
     const int gy = d->Npad / bn;
@@ -979,13 +1000,13 @@ bool ksmi_igemm4_geom(const ksmi_conv_desc* d, int dtype, ksmi_igemm4_geom_t* g)
     static const int deep_on = getenv("KSMI_IG4_DEEP") ? atoi(getenv("KSMI_IG4_DEEP")) : 0;   // (the kernel's DEEP: compiled in; the switch forces the per-role schedule instead)
     // chunk-granular schedule (kernel: CHUNK = ROT == 3) for the NF = 2 tiles: KSMI_IG4_CHUNK (1 = on)
     static const int chunk_on = getenv("KSMI_IG4_CHUNK") ? atoi(getenv("KSMI_IG4_CHUNK")) : 0;
-    const bool chunk = rot_on && chunk_on && !aff && nwv == 8 && nf == 2;
+    const bool chunk = k2 || (rot_on && chunk_on && !aff && nwv == 8 && nf == 2);
     const int nhs_ = (nwv == 4 || (wm == 8 && nf == 4) || (chunk && wm == 8)) ? 2 : 3;
     const bool deep = !chunk && rot_on && deep_on && !aff && nhs_ == 3 && nwv == 8 && nf == 2;      // <8,2> (32 columns) and <4,2> (64 columns)
     g->deep = chunk ? 2 : (deep ? 1 : 0);
-    const size_t wr = (chunk ? 6 : (deep ? 5 : 3)) * (size_t)(3 * bn * 64);
+    const size_t wr = (chunk ? 2 * d->KH : (deep ? 5 : 3)) * (size_t)(d->KW * bn * 64);
     g->nhs = nhs_;                                                  // (= the kernel's NHS)
-    g->lds = (size_t)g->nhs * g->hslot + wr + ((3 * bn / 16) % nwv ? 4096 : 0) + tabs;
+    g->lds = (size_t)g->nhs * g->hslot + wr + ((d->KW * bn / 16) % nwv ? 4096 : 0) + tabs;
     const int per_cu = nwv == 4 ? 2 : 1;
     if (g->lds * per_cu > 160 * 1024) continue;
     int gx = cus * per_cu / gy;
@@ -1005,7 +1026,7 @@ int ksmi_igemm4_launch(const ksmi_conv_desc* d, const ksmi_igemm4_geom_t* g, hip
   ka.d = *d;
   ka.th = g->th; ka.tw = g->tw;
   const int tilesX = (d->Wout + g->tw - 1) / g->tw, tilesY = (d->Hout + g->th - 1) / g->th;
-  ka.m_tw = fastdiv_magic(g->tw); ka.m_hw = fastdiv_magic(g->tw + 2); ka.m_tx = fastdiv_magic(tilesX); ka.m_ty = fastdiv_magic(tilesY);
+  ka.m_tw = fastdiv_magic(g->tw); ka.m_hw = fastdiv_magic(g->tw + d->KW - 1); ka.m_tx = fastdiv_magic(tilesX); ka.m_ty = fastdiv_magic(tilesY);
   const char* dbg_env = getenv("KSMI_IG4_DBG");
   ka.dbg = dbg_env ? atoi(dbg_env) : 0;
   static const int stag = getenv("KSMI_IG4_STAGGER") ? atoi(getenv("KSMI_IG4_STAGGER")) : 1;
@@ -1078,6 +1099,19 @@ int ksmi_igemm4_launch(const ksmi_conv_desc* d, const ksmi_igemm4_geom_t* g, hip
     if (ka.rot) { if (aff) KSMI_G4N(true, 0, true); else if (mask) KSMI_G4N(false, 1, true); else if (gate) KSMI_G4N(false, 2, true); else KSMI_G4N(false, 0, true); }
     if (aff) KSMI_G4N(true, 0, false); else if (mask) KSMI_G4N(false, 1, false); else if (gate) KSMI_G4N(false, 2, false); else KSMI_G4N(false, 0, false);
 #undef KSMI_G4N
+  }
+  if (g->deep == 2 && d->KH == 2) {                                 // the 2 x 2 phase convolutions: 256 px x 128 columns, chunk schedule
+#define KSMI_G4K2(EPI_)                                                                              \
+  do {                                                                                               \
+    auto kfn = igemm4_kernel<4, 4, false, EPI_, false, 0, 3, 8, 2, 2>; KSMI_NOTE(kfn);                               \
+    static bool attr_set = false;                                                                    \
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; } \
+    hipLaunchKernelGGL(kfn, grid, dim3(512), g->lds, st, ka);                                        \
+    return ksmi_check_launch("igemm4");                                                              \
+  } while (0)
+    if (aff || gate || g->nwv != 8 || g->WM != 4 || g->NF != 4) return ksmi_fail(KSMI_E_UNSUPPORTED, "igemm4: no 2 x 2 instance");
+    if (mask) KSMI_G4K2(1); else KSMI_G4K2(0);
+#undef KSMI_G4K2
   }
   if (g->deep == 2) {
 #define KSMI_G4CH(WM_, NF_, EPI_)                                                                    \

@@ -214,3 +214,89 @@ def test_opt_in_schedules_in_their_own_process(switch):
                          env=env, capture_output=True, text=True, timeout=1800, cwd=root)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert " passed" in out.stdout
+
+
+def _deconv_k4s2_via_phases(x, w, bias, dy, mask_t, dev):
+    """ConvTranspose2d(k4, s2, p1) forward and input gradient the way plan_base._deconv / _deconv_bwd lay them out: four 2x2 stride-1
+    phase convolutions each (strided output view / strided input view, padding 0 | 1 per phase, accumulate + 0/1 mask on the partials).
+    Returns (y NCHW, dx NCHW, kernel names of the launches)."""
+    import ctypes as C
+    from kurosiwo_amd import _lib, functional as Fk
+    from kurosiwo_amd.runtime import DT as DTM, SrcSpec, make_conv, make_pack, packed_weight_numel, stream_ptr
+    lib = _lib.load()
+    dt = torch.bfloat16
+    B, Cin, H, W = x.shape
+    N = w.shape[1]
+    xd = Fk.to_nhwc(x.to(dev), dt)
+    wd = w.to(dev).contiguous()                       # [Cin][N][4][4]
+    bd = bias.to(dev)
+    out = torch.zeros((B, 2 * H, 2 * W, N), dtype=dt, device=dev)
+    keep, names = [], []
+    buf = C.create_string_buffer(4096)
+
+    def launch(d):
+        lib.ksmi_last_kernels(buf, 4096)
+        _lib.check(lib.ksmi_conv_forward(C.byref(d), DTM[dt], stream_ptr()), "conv")
+        if lib.ksmi_last_kernels(buf, 4096):
+            names.append(buf.value.decode())
+
+    def packed(wt, table, n_out, n_mod, sK, sN, tap_map):
+        Npad = (n_out + 15) // 16 * 16
+        o = torch.empty(packed_weight_numel(table, 4, Npad, dt), dtype=dt, device=dev)
+        pd = make_pack(wt, o, table, 4, n_out, Npad, n_mod, sK, sN, 0, 1, 0, tap_map)
+        _lib.check(lib.ksmi_pack_weights(C.byref(pd), DTM[dt], stream_ptr()), "pack")
+        keep.extend([pd, o])
+        return o
+    for py in range(2):
+        for px in range(2):
+            tap_map = [(3 - 2 * a if py == 0 else 2 - 2 * a) * 4 + (3 - 2 * b if px == 0 else 2 - 2 * b) for a in range(2) for b in range(2)]
+            d, table = make_conv([SrcSpec(xd, Cin)], [(out, N, 0, 0, N, 0)], out, bd, None, B, H, W, H, W, 2, 2, 1, 1 - py, N, dt, pad_x=1 - px,
+                                 out_map=(2, 2, py, px, 2 * H, 2 * W))
+            d.wpk = packed(wd, table, N, N, N * 16, 16, tap_map).data_ptr()
+            keep.append(d)
+            launch(d)
+    y = Fk.to_nchw(out).cpu()
+    dyd = Fk.to_nhwc(dy.to(dev), dt)
+    dx = torch.zeros((B, H, W, Cin), dtype=dt, device=dev)
+    md = Fk.to_nhwc(mask_t.to(dev), dt)
+    zero, one = torch.zeros(Cin, device=dev), torch.ones(Cin, device=dev)
+    first = True
+    for py in range(2):
+        for px in range(2):
+            tap_map = [(2 * a if py else 1 + 2 * a) * 4 + (2 * b if px else 1 + 2 * b) for a in range(2) for b in range(2)]
+            d, table = make_conv([SrcSpec(dyd, N)], [(dx, Cin, 0, 0, Cin, 0 if first else 1)], dx, None, None, B, H, W, H, W, 2, 2, 1, py, Cin, dt,
+                                 mask=(md, zero, one, one, zero), pad_x=px, in_map=(2, 2, py, px, 2 * H, 2 * W))
+            d.wpk = packed(wd, table, Cin, Cin, 16, N * 16, tap_map).data_ptr()
+            keep.append(d)
+            launch(d)
+            first = False
+    torch.cuda.synchronize()
+    return y, Fk.to_nchw(dx).cpu(), names
+
+
+@pytest.mark.parametrize("cfg", [dict(B=2, H=24, W=24, Cin=128, N=128), dict(B=1, H=19, W=33, Cin=128, N=256)])
+def test_k4s2_deconv_phases_on_the_ring_kernel(dev, cfg):
+    """models/changeformer.py:329-336 (ConvTranspose2d(k4, s2, p1) of the decoder) as plan_base._deconv / _deconv_bwd launch it:
+    since round 5 the eight 2x2 phase convolutions run on igemm4's 2x2 instance (chunk-granular schedule, strided views).  Against
+    torch's conv_transpose2d and its input gradient on the bf16-quantised operands; the ReLU mask of the input gradient is a 0/1 tensor."""
+    B, H, W, Cin, N = cfg["B"], cfg["H"], cfg["W"], cfg["Cin"], cfg["N"]
+    tag = f"k4s2.{B}{H}{W}{Cin}{N}"
+    x = seeded_tensor(tag + ".x", (B, Cin, H, W))
+    w = seeded_tensor(tag + ".w", (Cin, N, 4, 4)) * (2.0 / (Cin * 4)) ** 0.5
+    bias = seeded_tensor(tag + ".b", (N,)) * 0.1
+    dy = seeded_tensor(tag + ".dy", (B, N, 2 * H, 2 * W))
+    mask_t = (seeded_tensor(tag + ".m", (B, Cin, H, W)) > 0).float()
+    xq = q(x).requires_grad_(True)
+    y_ref = F.conv_transpose2d(xq, q(w), bias, stride=2, padding=1)
+    y_ref.backward(q(dy))
+    dx_ref = xq.grad * mask_t
+    # (maps this small would stay on the tile kernel: the forced variant + a 3-workgroup grid put them on the persistent kernel with
+    # several tiles per workgroup; the second pass is the tile kernel as the cross-check of the harness)
+    for env, want in ((dict(KSMI_IGEMM4_VAR="4,4", KSMI_IGEMM4_CUS="3"), "igemm4_kernel<4, 4, false"), (dict(KSMI_IGEMM4_VAR=None, KSMI_IGEMM4_CUS=None), "igemm2_fwd_kernel")):
+        with _Env(**env):
+            y, dx, names = _deconv_k4s2_via_phases(x, w, bias, dy, mask_t, dev)
+        assert (y - y_ref.detach()).abs().max() < 2.5e-2 * y_ref.abs().max(), env
+        assert (dx - dx_ref).abs().max() < 3e-2 * dx_ref.abs().max(), env
+        assert len(names) == 8 and all(want in n for n in names), names
+        if "igemm4" in want:
+            assert all(n.rstrip(">").endswith("2, 2") for n in names), names
