@@ -10,6 +10,7 @@ struct ksmi_wgrad3_geom_t {
   int patches, pps, nsplit;          // patches, patches per split, splits (= partial slabs)
   int xpl, stage;                    // LDS bytes of one X plane / one stage
   int nst;                           // stages of the LDS ring (2: two workgroups per CU; up to 4 when the workgroup owns the CU)
+  int r0, c0;                        // >= 0: 2 x 2 window of taps (origin inside the 3 x 3 neighbourhood) of a phase gradient; -1: all 9 taps
   size_t lds;
 };
 // false: the descriptor does not qualify (the caller uses igemm_wgrad_kernel)

@@ -64,10 +64,16 @@ __device__ __forceinline__ int wg_chunk_src(const ksmi_wgrad_desc& d, int ch) {
   return (int)((((const uint32_t*)d.chunk_src)[ch >> 2] >> ((ch & 3) * 8)) & 0xffu);
 }
 
-template <int WC, int WN, int NF, bool AFF, bool DEEP>
+// R0, C0 >= 0 (round 5): only the 2 x 2 window of taps (R0 .. R0+1) x (C0 .. C0+1) of the 3 x 3 neighbourhood is computed -- the weight
+// gradient of one 2 x 2 PHASE convolution of ConvTranspose2d(k4, s2, p1) (plan_base._deconv_wgrad: X = a parity sub-image of d out as a
+// strided view, padding p = 0 | 1 per axis <-> window origin 1 - p); slabs hold 4 taps, the reducer scatters through d.tap_off.
+template <int WC, int WN, int NF, bool AFF, bool DEEP, int R0 = -1, int C0 = -1>
 __global__ __launch_bounds__(256, 2) void wgrad3_kernel(const Wg3Args ka) {
   typedef bf16_t T;
   const ksmi_wgrad_desc& d = ka.d;
+  constexpr bool SUB = R0 >= 0;
+  constexpr int NTAP = SUB ? 4 : 9;                // taps computed (and slabs per split)
+  static_assert(!SUB || (R0 <= 1 && C0 >= 0 && C0 <= 1), "2 x 2 window inside the 3 x 3 neighbourhood");
   constexpr int CPT = WC / 2;                      // 32-channel planes of X per tile
   constexpr int NFT = WN * NF;                     // column fragments per tile
   constexpr int NPL = (NFT + 1) / 2;               // 32-column planes of dY per tile
@@ -150,9 +156,9 @@ __global__ __launch_bounds__(256, 2) void wgrad3_kernel(const Wg3Args ka) {
   }
   const unsigned row2 = (unsigned)(2 * HWc * 64);
 
-  f32x4 acc[9][NF];
+  f32x4 acc[NTAP][NF];
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+  for (int t = 0; t < NTAP; ++t)
 #pragma unroll
     for (int nf = 0; nf < NF; ++nf) acc[t][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -187,7 +193,8 @@ __global__ __launch_bounds__(256, 2) void wgrad3_kernel(const Wg3Args ka) {
       const bool inr = v < ka.HPv * 4;
       const bool ok = inr && (unsigned)iy < (unsigned)d.Hin && (unsigned)ix < (unsigned)d.Win;
       const int f = ((hx >> 3) ^ (hy & ka.hymask)) & 1;
-      const uint32_t pix = (uint32_t)((b * d.Hin + iy) * d.Win + ix);
+      const uint32_t pix = d.in_sy == 0 ? (uint32_t)((b * d.Hin + iy) * d.Win + ix)
+                                        : (uint32_t)((b * d.in_H + (iy * d.in_sy + d.in_oy)) * d.in_W + (ix * d.in_sx + d.in_ox));   // (strided view: the phase gradients)
       const uint32_t slb = (uint32_t)((s ^ (f << 1)) * 16);
       if (it * 256 + wave * 64 < ka.HPv * 4) {                       // wave-uniform: this wave has halo slots in this iteration
 #pragma unroll
@@ -280,7 +287,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3_kernel(const Wg3Args ka) {
     // fragments), the dY fragments of the next k-step during the second half of this one (two sets).
     constexpr int AD = !DEEP ? 1 : NF >= 4 ? 4 : (NF == 2 ? 6 : 9);   // (DEEP = false: the one-tap schedule of rounds 2-4, kept for A/B)
     auto a_frag = [&](int q) {
-      const int ks = q / 9, t = q % 9, ty = t / 3, tx = t % 3;
+      const int ks = q / NTAP, t = q % NTAP, ty = SUB ? R0 + t / 2 : t / 3, tx = SUB ? C0 + t % 2 : t % 3;
       const unsigned o = so + (unsigned)(ks * ka.kstride) + (ty == 2 ? row2 : 0u);
       return tr_frag(a_tab[ty & 1][tx][0] + o, a_tab[ty & 1][tx][1] + o);
     };
@@ -293,16 +300,16 @@ __global__ __launch_bounds__(256, 2) void wgrad3_kernel(const Wg3Args ka) {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const int q = ks * 9 + t;
-        if (t == 4 && ks + 1 < 4) {
+      for (int t = 0; t < NTAP; ++t) {
+        const int q = ks * NTAP + t;
+        if (t == NTAP / 2 && ks + 1 < 4) {
           const unsigned bo = so + (unsigned)((ks + 1) * 2048);
 #pragma unroll
           for (int nf = 0; nf < NF; ++nf) bf[(ks + 1) & 1][nf] = tr_frag(b_tab[nf][0] + bo, b_tab[nf][1] + bo);
         }
 #pragma unroll
         for (int nf = 0; nf < NF; ++nf) mma16<T>(acc[t][nf], af[q % AD], bf[ks & 1][nf]);
-        if (q + AD < 36) af[q % AD] = a_frag(q + AD);
+        if (q + AD < 4 * NTAP) af[q % AD] = a_frag(q + AD);
         if constexpr (DEEP) __builtin_amdgcn_sched_barrier(0);        // (the scheduler sinks the requests back to one tap ahead otherwise)
       }
     }
@@ -313,25 +320,25 @@ __global__ __launch_bounds__(256, 2) void wgrad3_kernel(const Wg3Args ka) {
   const int Ktot = d.nchunks * 32;
   const int krow0 = (kt * CPT + (cfi >> 1)) * 32 + (cfi & 1) * 16 + g * 4;
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+  for (int t = 0; t < NTAP; ++t)
 #pragma unroll
     for (int nf = 0; nf < NF; ++nf) {
       const int n = n0 + (wn * NF + nf) * 16 + l15;
       if (n >= Npad) continue;
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        d.partial[(((size_t)split * 9 + t) * Ktot + krow0 + r) * Npad + n] = acc[t][nf][r];
+        d.partial[(((size_t)split * NTAP + t) * Ktot + krow0 + r) * Npad + n] = acc[t][nf][r];
     }
 }
 
 // Sum of the split slabs + scatter into the fp32 gradient (fixed summation tree => deterministic).  A block owns 16 float4
 // (256 contiguous bytes of a slab) x 16 slab lanes: every wave instruction reads four 256-byte runs; slab lane sl walks slabs
 // sl, sl + 16, ...; the 16 lanes of an element are combined by two shuffles (inside a wave) and one LDS step (across the waves).
-__global__ __launch_bounds__(256) void wgrad3_reduce_kernel(const ksmi_wgrad_desc d, int nsplit) {
+__global__ __launch_bounds__(256) void wgrad3_reduce_kernel(const ksmi_wgrad_desc d, int nsplit, int ntaps) {
   __shared__ f32x4 red[4][16];
   const int Npad = (d.N + 15) & ~15;
   const int Ktot = d.nchunks * 32;
-  const size_t total4 = (size_t)9 * Ktot * Npad / 4;
+  const size_t total4 = (size_t)ntaps * Ktot * Npad / 4;
   const int tid = threadIdx.x, e = tid & 15, sl = tid >> 4;
   const size_t i4 = (size_t)blockIdx.x * 16 + e;
   f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
@@ -360,7 +367,7 @@ __global__ __launch_bounds__(256) void wgrad3_reduce_kernel(const ksmi_wgrad_des
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       if (n + j < d.N) {
-        float* gp = d.grad + k * d.gK + (int64_t)(n + j) * d.gN + (int64_t)t * d.gT;
+        float* gp = d.grad + k * d.gK + (int64_t)(n + j) * d.gN + (d.use_tap_off ? (int64_t)d.tap_off[t] : (int64_t)t * d.gT);
         *gp = d.accumulate ? (*gp + v[j]) : v[j];
       }
     }
@@ -373,12 +380,21 @@ __global__ __launch_bounds__(256) void wgrad3_reduce_kernel(const ksmi_wgrad_des
 bool ksmi_wgrad3_geom(const ksmi_wgrad_desc* d, int dtype, ksmi_wgrad3_geom_t* g) {
   static const bool off = getenv("KSMI_WGRAD3_OFF") != nullptr;
   if (off || dtype != KSMI_BF16) return false;
-  if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || (d->pad_x_set && d->pad_x != 1) || d->in_sy != 0 || d->use_tap_off) return false;
+  // 2 x 2 phase gradients (ConvTranspose2d(k4, s2, p1), plan_base._deconv_wgrad): the 2 x 2 window of the 3 x 3 neighbourhood whose
+  // origin is (1 - pad, 1 - pad_x); KSMI_WGRAD3_K2=0 sends them back to igemm_wgrad_kernel
+  static const int k2_on = getenv("KSMI_WGRAD3_K2") ? atoi(getenv("KSMI_WGRAD3_K2")) : 1;
+  const bool k2 = d->KH == 2 && d->KW == 2;
+  g->r0 = g->c0 = -1;
+  if (k2) {
+    if (!k2_on || d->stride != 1 || (unsigned)d->pad > 1u || !d->pad_x_set || (unsigned)d->pad_x > 1u || !d->use_tap_off || d->src[0].scale) return false;
+    g->r0 = 1 - d->pad; g->c0 = 1 - d->pad_x;
+  } else if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || (d->pad_x_set && d->pad_x != 1) || d->in_sy != 0 || d->use_tap_off) return false;
   if (d->Hin != d->Hout || d->Win != d->Wout || (d->N % 8) != 0 || d->N < 16) return false;
   for (int i = 0; i < d->nsrc; ++i) {
     if (d->src[i].c_len % 32) return false;
     if (d->src[i].scale && (i > 0 || d->nsrc != 1)) return false;
-    if ((size_t)d->B * d->Hin * d->Win * (size_t)d->src[i].C * 2 >= ((size_t)1 << 32)) return false;
+    const size_t ipx = d->in_sy ? (size_t)d->B * d->in_H * d->in_W : (size_t)d->B * d->Hin * d->Win;
+    if (ipx * (size_t)d->src[i].C * 2 >= ((size_t)1 << 32)) return false;
   }
   if ((size_t)d->B * d->Hout * d->Wout * (size_t)d->dyC * 2 >= ((size_t)1 << 32)) return false;
   if (d->uniform_kc) { if (d->uniform_kc != 32 || d->k_total != d->nchunks * 32) return false; }
@@ -402,6 +418,7 @@ bool ksmi_wgrad3_geom(const ksmi_wgrad_desc* d, int dtype, ksmi_wgrad3_geom_t* g
   // tile: one chunk -> 32 channels (2 x 2 waves), else 64 channels (4 x 1 waves); 64 columns when there are at least 48
   g->WC = d->nchunks == 1 ? 2 : 4;
   g->NTL = npad >= 48 ? 64 : 32;
+  if (k2 && (g->WC != 4 || g->NTL != 64)) return false;            // (one instance per window: 64 channels x 64 columns)
   g->KT = (d->nchunks + g->WC / 2 - 1) / (g->WC / 2);
   g->NTt = (npad + g->NTL - 1) / g->NTL;
   g->patches = d->B * g->tilesX * g->tilesY;
@@ -424,8 +441,9 @@ bool ksmi_wgrad3_geom(const ksmi_wgrad_desc* d, int dtype, ksmi_wgrad3_geom_t* g
   const int wg_force = wg_env ? atoi(wg_env) : 0;
   const int tiles = g->KT * g->NTt;
   const int nfw = (g->NTL / 16) / (4 / g->WC);                      // column fragments per wave
-  const double t_patch = 4.0 * 9.0 * nfw * 16.0 / 2100.0;           // one 128-pixel patch on one wave at the MFMA rate
-  const double tile_mb = 9.0 * (g->WC * 16) * g->NTL * 4.0 / 1e6;
+  const double ntaps = k2 ? 4.0 : 9.0;
+  const double t_patch = 4.0 * ntaps * nfw * 16.0 / 2100.0;         // one 128-pixel patch on one wave at the MFMA rate
+  const double tile_mb = ntaps * (g->WC * 16) * g->NTL * 4.0 / 1e6;
   const double op_bytes = (double)d->B * H * W * (d->nchunks * 32.0 + npad) * 2.0;
   const size_t lds2 = 2 * (size_t)g->stage + 1024;
   const int max_per_cu = (int)(160 * 1024 / lds2) < 4 ? (int)(160 * 1024 / lds2) : 4;
@@ -460,8 +478,9 @@ bool ksmi_wgrad3_geom(const ksmi_wgrad_desc* d, int dtype, ksmi_wgrad3_geom_t* g
 }
 
 int ksmi_wgrad3_reduce(const ksmi_wgrad_desc* d, const ksmi_wgrad3_geom_t* g, hipStream_t st) {
-  const size_t total4 = (size_t)9 * d->nchunks * 32 * ((d->N + 15) & ~15) / 4;
-  hipLaunchKernelGGL(wgrad3_reduce_kernel, dim3((unsigned)((total4 + 15) / 16)), dim3(256), 0, st, *d, g->nsplit);
+  const int ntaps = g->r0 >= 0 ? 4 : 9;
+  const size_t total4 = (size_t)ntaps * d->nchunks * 32 * ((d->N + 15) & ~15) / 4;
+  hipLaunchKernelGGL(wgrad3_reduce_kernel, dim3((unsigned)((total4 + 15) / 16)), dim3(256), 0, st, *d, g->nsplit, ntaps);
   return ksmi_check_launch("wgrad3_reduce");
 }
 
@@ -496,6 +515,18 @@ int ksmi_wgrad3_launch(const ksmi_wgrad_desc* d, const ksmi_wgrad3_geom_t* g, hi
     if (aff) { if (deep) KSMI_W3_(WC_, WN_, NF_, true, true); else KSMI_W3_(WC_, WN_, NF_, true, false); }   \
     else { if (deep) KSMI_W3_(WC_, WN_, NF_, false, true); else KSMI_W3_(WC_, WN_, NF_, false, false); }     \
   } while (0)
+  if (g->r0 >= 0) {                                                 // 2 x 2 phase gradients: one instance per window origin
+#define KSMI_W3K(R0_, C0_)                                                                           \
+  do {                                                                                               \
+    auto kfn = wgrad3_kernel<4, 1, 4, false, true, R0_, C0_>; KSMI_NOTE(kfn);                        \
+    if (g->lds > 65536) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g->lds); \
+    hipLaunchKernelGGL(kfn, grid, dim3(256), g->lds, st, ka);                                        \
+  } while (0)
+    if (aff || g->WC != 4 || g->NTL != 64) return ksmi_fail(KSMI_E_UNSUPPORTED, "wgrad3: no 2 x 2 instance");
+    if (g->r0 == 0 && g->c0 == 0) KSMI_W3K(0, 0); else if (g->r0 == 0) KSMI_W3K(0, 1); else if (g->c0 == 0) KSMI_W3K(1, 0); else KSMI_W3K(1, 1);
+#undef KSMI_W3K
+    return ksmi_check_launch("wgrad3");
+  }
   if (g->WC == 4 && g->NTL == 64) KSMI_W3(4, 1, 4);
   else if (g->WC == 4) KSMI_W3(4, 1, 2);
   else if (g->NTL == 64) KSMI_W3(2, 2, 2);

@@ -270,8 +270,24 @@ def _deconv_k4s2_via_phases(x, w, bias, dy, mask_t, dev):
             keep.append(d)
             launch(d)
             first = False
+    # weight gradient: four 2x2 phase gradients over the parity sub-images of dy, each writing its 4 of the 16 taps (plan_base._deconv_wgrad)
+    from kurosiwo_amd.runtime import make_wgrad
+    gw = torch.zeros((Cin, N, 4, 4), dtype=torch.float32, device=dev)
+    wnames = []
+    for py in range(2):
+        for px in range(2):
+            tap_off = [(2 * a if py else 1 + 2 * a) * 4 + (2 * b if px else 1 + 2 * b) for a in range(2) for b in range(2)]
+            dw, ws = make_wgrad([SrcSpec(dyd, N)], xd, Cin, 0, Cin, gw, 16, N * 16, 0, 0, B, H, W, H, W, 2, 2, 1, py, dt,
+                                pad_x=px, in_map=(2, 2, py, px, 2 * H, 2 * W), tap_off=tap_off)
+            scratch = torch.empty(max(int(ws), 256), dtype=torch.uint8, device=dev)
+            dw.partial = scratch.data_ptr()
+            keep.extend([dw, scratch])
+            lib.ksmi_last_kernels(buf, 4096)
+            _lib.check(lib.ksmi_conv_wgrad(C.byref(dw), DTM[dt], stream_ptr()), "wgrad")
+            if lib.ksmi_last_kernels(buf, 4096):
+                wnames.append(buf.value.decode())
     torch.cuda.synchronize()
-    return y, Fk.to_nchw(dx).cpu(), names
+    return y, Fk.to_nchw(dx).cpu(), names, gw.cpu(), wnames
 
 
 @pytest.mark.parametrize("cfg", [dict(B=2, H=24, W=24, Cin=128, N=128), dict(B=1, H=19, W=33, Cin=128, N=256)])
@@ -287,16 +303,21 @@ def test_k4s2_deconv_phases_on_the_ring_kernel(dev, cfg):
     dy = seeded_tensor(tag + ".dy", (B, N, 2 * H, 2 * W))
     mask_t = (seeded_tensor(tag + ".m", (B, Cin, H, W)) > 0).float()
     xq = q(x).requires_grad_(True)
-    y_ref = F.conv_transpose2d(xq, q(w), bias, stride=2, padding=1)
+    wq = q(w).requires_grad_(True)
+    y_ref = F.conv_transpose2d(xq, wq, bias, stride=2, padding=1)
     y_ref.backward(q(dy))
     dx_ref = xq.grad * mask_t
     # (maps this small would stay on the tile kernel: the forced variant + a 3-workgroup grid put them on the persistent kernel with
     # several tiles per workgroup; the second pass is the tile kernel as the cross-check of the harness)
     for env, want in ((dict(KSMI_IGEMM4_VAR="4,4", KSMI_IGEMM4_CUS="3"), "igemm4_kernel<4, 4, false"), (dict(KSMI_IGEMM4_VAR=None, KSMI_IGEMM4_CUS=None), "igemm2_fwd_kernel")):
         with _Env(**env):
-            y, dx, names = _deconv_k4s2_via_phases(x, w, bias, dy, mask_t, dev)
+            y, dx, names, gw, wnames = _deconv_k4s2_via_phases(x, w, bias, dy, mask_t, dev)
         assert (y - y_ref.detach()).abs().max() < 2.5e-2 * y_ref.abs().max(), env
         assert (dx - dx_ref).abs().max() < 3e-2 * dx_ref.abs().max(), env
+        # weight gradient: fp32 accumulation of exact bf16 products on both sides
+        assert (gw - wq.grad).abs().max() < 2e-3 * wq.grad.abs().max(), (env, float((gw - wq.grad).abs().max()), float(wq.grad.abs().max()))
+        # ... on the channel-owner kernel's 2x2-window instances (round 5), whatever the convolution switches say
+        assert len(wnames) == 4 and all("wgrad3_kernel<4, 1, 4, false, true, " in n for n in wnames), wnames
         assert len(names) == 8 and all(want in n for n in names), names
         if "igemm4" in want:
             assert all(n.rstrip(">").endswith("2, 2") for n in names), names
