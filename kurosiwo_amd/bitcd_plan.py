@@ -11,7 +11,7 @@ import torch
 
 from .bitcd import LAYERS
 from .changeformer_plan import CS
-from .runtime import SrcSpec, conv_grid_m, make_conv, make_wgrad
+from .runtime import SrcSpec, conv_grid_m, conv_stats_rows, make_conv, make_wgrad
 from .snunet_plan import _Saved
 from .unet_plan import UnetPlan
 
@@ -50,7 +50,7 @@ class BitCDPlan(UnetPlan):
                      self._elt_meta("im2col", 2 * R1 * Kpad))
         d, table = make_conv([SrcSpec(col, Kpad, k_real=Kreal)], [(s0, 64, 0, 0, 64, 0)], s0, None, None, 1, R1, 1, R1, 1, 1, 1, 1, 0, 64, self.dtype)
         d.wpk = self._packed("resnet.conv1.weight", table, 1, 64, 64, 1, Kreal, 0, 0).data_ptr()
-        rows0 = conv_grid_m(d)
+        rows0 = conv_stats_rows(d, self.dtype) if self.training else conv_grid_m(d)   # (rows of the kernel that will run it: see changeformer_plan._conv3)
         if self.training:
             self.need("stats", rows0 * 2 * d.Npad * 4)
             self._later.append(lambda: setattr(d, "stats", self.scr("stats")))

@@ -99,7 +99,10 @@ class ChangeFormerPlan(PlanBase):
             d.wpk = self._packed(wkey, table, 9, N, N, N * 9, 9, 0, 1, 1).data_ptr()
         else:          # element (k = c_in, tap, col = n_out) = W[n][c][tap]
             d.wpk = self._packed(wkey, table, 9, N, N, 9, Ktot * 9, 0, 1, 0).data_ptr()
-        rows = conv_grid_m(d)
+        # statistics rows of the kernel that will run this descriptor (one per persistent workgroup on igemm3 / igemm4, one per M-tile on
+        # igemm2; recorded in d.stats_rows: with the tile kernel's count the dispatch kept every convolution WITH statistics off the ring
+        # kernel -- diff_c1.0 ran at 660 instead of ~1100 TFLOP/s until round 5)
+        rows = conv_stats_rows(d, self.dtype) if stats else conv_grid_m(d)
         if stats:
             self.need("stats", rows * 2 * d.Npad * 4)
             self._later.append(lambda: setattr(d, "stats", self.scr("stats")))
@@ -287,7 +290,7 @@ class ChangeFormerPlan(PlanBase):
         fsrcs = [SrcSpec(scales[i]["up"], E) for i in (4, 3, 2, 1)]
         d, table = make_conv(fsrcs, [(F0, E, 0, 0, E, 0)], F0, m._p(f"{D}.linear_fuse.0.bias"), None, B, H1, W1, H1, W1, 1, 1, 1, 0, E, self.dtype)
         d.wpk = self._packed(f"{D}.linear_fuse.0.weight", table, 1, E, E, 1, 4 * E, 0, 0).data_ptr()
-        rowsF = conv_grid_m(d)
+        rowsF = conv_stats_rows(d, self.dtype) if self.training else conv_grid_m(d)   # (rows of the kernel that will run it: see changeformer_plan._conv3)
         if self.training:
             self.need("stats", rowsF * 2 * d.Npad * 4)
             self._later.append(lambda: setattr(d, "stats", self.scr("stats")))

@@ -232,6 +232,9 @@ def conv_grid_m(d):
 def conv_stats_rows(d, dtype):
     """rows of the `stats` buffer of this descriptor (recorded in d.stats_rows: the persistent short-K kernel writes one row per
     workgroup, every other kernel one per M-tile); call after the descriptor is complete, with d.stats already non-null."""
+    import os
+    if os.environ.get("KSMI_STATS_ROWS_TILE") == "1":       # A/B switch: the tile kernel's row count (keeps a convolution with statistics on igemm2)
+        return conv_grid_m(d)
     rows = _lib.load().ksmi_conv_stats_rows(C.byref(d), DT[dtype])
     d.stats_rows = rows
     return rows

@@ -11,7 +11,7 @@ import torch
 
 from . import _lib
 from .changeformer_plan import BN_EPS, BN_MOMENTUM, CS, ChangeFormerPlan
-from .runtime import SrcSpec, conv_grid_m, make_conv, make_wgrad
+from .runtime import SrcSpec, conv_grid_m, conv_stats_rows, make_conv, make_wgrad
 from .snunet_plan import _Saved
 from .unet import DECODER_CHANNELS, LAYERS
 
@@ -57,7 +57,7 @@ class UnetPlan(ChangeFormerPlan):
         d, table = make_conv(srcs, dsts, dsts[0][0], bias, None, self.B, Hin, Win, Hout, Wout, k, k, stride, pad, N, self.dtype, mask=mask)
         taps = k * k
         d.wpk = self._packed(wkey, table, taps, N, N, taps, Ktot * taps, 0, 1, 0).data_ptr()
-        rows = conv_grid_m(d)
+        rows = conv_stats_rows(d, self.dtype) if stats else conv_grid_m(d)   # (rows of the kernel that will run it: see changeformer_plan._conv3)
         if stats:
             self.need("stats", rows * 2 * d.Npad * 4)
             self._later.append(lambda: setattr(d, "stats", self.scr("stats")))
@@ -236,7 +236,7 @@ class UnetPlan(ChangeFormerPlan):
         self.fwd.add("ksmi_im2col", lambda: (self.x.data_ptr(), col.data_ptr(), B, self.cin, H, W, H1, W1, 7, 7, 2, 3, Kpad, 1, dt), self._elt_meta("im2col", 2 * R1 * Kpad))
         d, table = make_conv([SrcSpec(col, Kpad, k_real=Kreal)], [(s0, 64, 0, 0, 64, 0)], s0, None, None, 1, R1, 1, R1, 1, 1, 1, 1, 0, 64, self.dtype)
         d.wpk = self._packed("encoder.conv1.weight", table, 1, 64, 64, 1, Kreal, 0, 0).data_ptr()
-        rows0 = conv_grid_m(d)
+        rows0 = conv_stats_rows(d, self.dtype) if self.training else conv_grid_m(d)   # (rows of the kernel that will run it: see changeformer_plan._conv3)
         if self.training:
             self.need("stats", rows0 * 2 * d.Npad * 4)
             self._later.append(lambda: setattr(d, "stats", self.scr("stats")))
