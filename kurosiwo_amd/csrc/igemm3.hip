@@ -71,15 +71,20 @@ __global__ __launch_bounds__(256 * WN, (WN == 1 && NCH * KH * KW * NTI <= 9) ? 2
     a_base[mf] = ly * S * HW + lx * S;
   }
   // per-chunk source (virtual concat): base pointer of the chunk's first channel, bytes per pixel
+  // klen: channels of the chunk that exist in the tensor, rounded up to the 16-byte granule (32 except in the last chunk of a source
+  // whose c_len is not a multiple of 32 -- the 16-channel levels of Unet / FC-Siam, 8-channel-stride heads): the granules past it are
+  // read from the zero page like the positions outside the image, and the packed weights hold zeros there
   const unsigned char* sp[NCH];
   uint32_t cb[NCH];
-  int cc0[NCH];
+  int cc0[NCH], klen[NCH], krem[NCH];
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) {
     const ksmi_src& sr = d.src[chunk_src_of(d, ch)];
     cc0[ch] = chunk_c0_of(d, ch);
     sp[ch] = (const unsigned char*)((const T*)sr.ptr + sr.c_off + cc0[ch]);
     cb[ch] = (uint32_t)sr.C * 2u;
+    krem[ch] = sr.c_len - cc0[ch];
+    klen[ch] = krem[ch] >= 32 ? 32 : ((krem[ch] + 7) & ~7);
   }
   // ---- weights -> registers: fragment nf, row j = l15 of the MFMA A operand = output channel 8*(j>>2) + 4*nf + (j&3) of the wave's
   //      32 columns (the lean epilogue's ownership: lane (g, l15) ends up with channels 8g .. 8g+7 of pixel l15) --------------------
@@ -103,8 +108,9 @@ __global__ __launch_bounds__(256 * WN, (WN == 1 && NCH * KH * KW * NTI <= 9) ? 2
     if (tid < NCH * 32) {                                           // layout [chunk][k-group q]{scale[8], shift[8]}
       const int ch = tid >> 5, j = tid & 31;
       const ksmi_src& sr = d.src[0];
-      aff_tab[(ch * 4 + (j >> 3)) * 16 + (j & 7)] = sr.scale[cc0[ch] + j];
-      aff_tab[(ch * 4 + (j >> 3)) * 16 + 8 + (j & 7)] = sr.shift[cc0[ch] + j];
+      const bool kv = j < krem[ch];                                   // (channels past the source: 0 * x + 0 on zero-page granules)
+      aff_tab[(ch * 4 + (j >> 3)) * 16 + (j & 7)] = kv ? sr.scale[cc0[ch] + j] : 0.f;
+      aff_tab[(ch * 4 + (j >> 3)) * 16 + 8 + (j & 7)] = kv ? sr.shift[cc0[ch] + j] : 0.f;
     }
   }
   const bool aff_relu = AFF && d.src[0].relu != 0;
@@ -133,13 +139,15 @@ __global__ __launch_bounds__(256 * WN, (WN == 1 && NCH * KH * KW * NTI <= 9) ? 2
         const int iy = iy0 + hy, ix = ix0 + hx;
         const bool ok = v < HP * 4 && (unsigned)iy < (unsigned)d.Hin && (unsigned)ix < (unsigned)d.Win;
         const uint32_t gpix = (uint32_t)((b * d.Hin + iy) * d.Win + ix);
-        const uint32_t qb = (uint32_t)(((v & 3) ^ swz(pix)) << 4);
+        const int gq = (v & 3) ^ swz(pix);
+        const uint32_t qb = (uint32_t)(gq << 4);
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
           // (two 32-bit selects: a pointer select compiles to two exec-masked DMA instructions)
+          const bool okc = ok && gq * 8 < klen[ch];
           const uint64_t av = (uint64_t)(uintptr_t)sp[ch] + (uint64_t)gpix * cb[ch] + (uint64_t)qb;
           const uint64_t zv = (uint64_t)(uintptr_t)ka.zero;
-          const uint32_t lo = ok ? (uint32_t)av : (uint32_t)zv, hi = ok ? (uint32_t)(av >> 32) : (uint32_t)(zv >> 32);
+          const uint32_t lo = okc ? (uint32_t)av : (uint32_t)zv, hi = okc ? (uint32_t)(av >> 32) : (uint32_t)(zv >> 32);
           const unsigned char* src = (const unsigned char*)(uintptr_t)(((uint64_t)hi << 32) | lo);
           glds16_flat(src, lds0 + (unsigned)(stg * stage + ch * hpb + (s * NTHR + wave * 64) * 16));
         }
@@ -221,10 +229,13 @@ __global__ __launch_bounds__(256 * WN, (WN == 1 && NCH * KH * KW * NTI <= 9) ? 2
     if (d.ps_cout > 0) nn = nc - (nc / d.ps_cout) * d.ps_cout;
 #pragma unroll
     for (int j = 0; j < 8; ++j) biasr[ni][j] = 0.f;
-    if (d.bias && nc < d.N) {
+    if (d.bias && nc + 8 <= d.N) {
       const f32x4 a = *(const f32x4*)(d.bias + nn), c = *(const f32x4*)(d.bias + nn + 4);
 #pragma unroll
       for (int j = 0; j < 4; ++j) { biasr[ni][j] = a[j]; biasr[ni][4 + j] = c[j]; }
+    } else if (d.bias && nc < d.N) {                                // N % 8 != 0 (2- / 3-class heads): the channels past N store zeros
+#pragma unroll
+      for (int j = 0; j < 8; ++j) if (nc + j < d.N) biasr[ni][j] = d.bias[nn + j];
     }
   }
   const int G = gridDim.x, NS = ka.ns, LA = NS - 1;               // lookahead: tiles in flight beyond the current one
@@ -375,7 +386,16 @@ bool ksmi_igemm3_geom(const ksmi_conv_desc* d, int dtype, ksmi_igemm3_geom_t* g)
   if (d->uniform_kc || d->nchunks < 1 || d->nchunks > 8) return false;
   if (d->ndst != 1 || d->dst[0].accumulate || d->dst[0].n_begin != 0) return false;
   if (d->alpha != 0.f || d->resid || d->relu_out || d->out_sy || d->in_sy) return false;
-  if ((d->N % 8) || (d->dst[0].C % 8) || (d->dst[0].c_off % 8) || d->Npad < 32) return false;
+  // KSMI_IGEMM3_PARTIAL=0: the round-4 rule (whole 32-channel chunks, N % 8 == 0, >= 32 padded columns) for same-box A/B runs
+  static const bool partial_on = getenv("KSMI_IGEMM3_PARTIAL") ? atoi(getenv("KSMI_IGEMM3_PARTIAL")) != 0 : true;
+  if (!partial_on) {
+    if ((d->N % 8) || d->Npad < 32) return false;
+    for (int i = 0; i < d->nsrc; ++i) if (d->src[i].c_len % 32) return false;
+  }
+  if ((d->dst[0].C % 8) || (d->dst[0].c_off % 8) || d->Npad < 16) return false;
+  // N % 8 != 0 (the 2- / 3-class heads, destination with a channel stride of 8): the last 8-channel group is stored whole, its pad
+  // channels as zeros (zero weights, no bias) -- plain epilogue only, and the destination row has to hold the whole group
+  if ((d->N % 8) && (d->mask_src || d->ps_cout || d->dst[0].c_off + ((d->N + 7) & ~7) > d->dst[0].C)) return false;
   if (d->ps_cout && (d->ps_cout % 8)) return false;
   // ReLU-mask + BN-backward sums epilogue: instances exist for 3x3 (KSMI_IGEMM3_MASK=1) but measured slower than the tile kernel /
   // igemm4 (K = 32: 154 vs 89 us, the mask loads spill 45 VGPRs next to the register-resident weights; K = 64: 72 vs 64 us): off
@@ -385,7 +405,10 @@ bool ksmi_igemm3_geom(const ksmi_conv_desc* d, int dtype, ksmi_igemm3_geom_t* g)
   auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
   if (!al16(d->dst[0].ptr) || !al16(d->bias)) return false;
   for (int i = 0; i < d->nsrc; ++i) {
-    if (d->src[i].c_len % 32) return false;
+    // whole 16-byte granules of the source row: c_len itself need not be a multiple of 32 (last chunk: zero-page granules) nor of 8
+    // (the row's pad channels are read and meet zero weights: they must exist inside the row)
+    if (d->src[i].c_len < 1 || (d->src[i].C % 8) || (d->src[i].c_off % 8) || d->src[i].c_off + ((d->src[i].c_len + 7) & ~7) > d->src[i].C) return false;
+    if (!al16(d->src[i].ptr)) return false;
     if (d->src[i].scale && (i > 0 || d->nsrc != 1)) return false;
     if ((size_t)d->B * d->Hin * d->Win * (size_t)d->src[i].C * 2 >= ((size_t)1 << 32)) return false;
   }

@@ -50,7 +50,8 @@ def conv3x3(xs, weight, bias=None, affine=None, want_stats=False, alpha=0.0, rel
         srcs[0].scale, srcs[0].shift, srcs[0].relu = affine
     if out is None:
         out = torch.empty((B, H, W, N), dtype=dtype, device=xs[0].device)
-    d, table = make_conv(srcs, [(out, N, 0, 0, N, accumulate)], out, bias, None, B, H, W, H, W, 3, 3, 1, 1, N, dtype,
+    # (a destination whose rows are wider than N -- the 8-channel-stride tensors of the 2- / 3-class heads -- keeps its channel stride)
+    d, table = make_conv(srcs, [(out, out.shape[3], 0, 0, N, accumulate)], out, bias, None, B, H, W, H, W, 3, 3, 1, 1, N, dtype,
                          alpha=alpha, relu_out=relu_out, resid=None if resid is None else (resid, resid.shape[3]), mask=mask)
     wpk = _pack(weight.contiguous(), table, 9, N, N, 9, Ktot * 9, 0, 1, 0, dtype)
     d.wpk = wpk.data_ptr()
