@@ -511,6 +511,10 @@ int ksmi_bn_bwd_apply(const void* dy, const void* r, const float* mean, const fl
  * to the first maximum in window scan order, dx (+)= */
 int ksmi_maxpool3x3s2_forward(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream);
 int ksmi_maxpool3x3s2_backward(const void* x, const void* dy, void* dx, int accumulate, int B, int H, int W, int C, int dtype, void* stream);
+/* training pair: the forward also records the window position (ky * 3 + kx, one byte per output element, [B, Ho, Wo, C]) of the first
+ * maximum -- the element torch.nn.MaxPool2d routes the gradient to -- and the backward compares codes instead of re-reading the windows */
+int ksmi_maxpool3x3s2_forward_idx(const void* x, void* y, void* idx, int B, int H, int W, int C, int dtype, void* stream);
+int ksmi_maxpool3x3s2_backward_idx(const void* idx, const void* dy, void* dx, int accumulate, int B, int H, int W, int C, int dtype, void* stream);
 /* y = alpha * [relu](x*scale[c] + shift[c]) (scale = shift = NULL: plain scaled copy): the materialised BatchNorm output of
  * linear_fuse (:563-567) and the 0.1 branch scale of ResidualBlock (:479-481) in the backward pass */
 int ksmi_affine(const void* x, const float* scale, const float* shift, void* y, int64_t npix, int C, int relu, float alpha, int dtype,

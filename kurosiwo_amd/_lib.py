@@ -193,6 +193,8 @@ SIGNATURES = {
     "ksmi_grad_from_tc": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ksmi_maxpool3x3s2_forward": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ksmi_maxpool3x3s2_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "ksmi_maxpool3x3s2_forward_idx": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "ksmi_maxpool3x3s2_backward_idx": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ksmi_affine": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, C.c_float, _i, _vp]),
     "ksmi_dwconv3x3_gelu_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ksmi_dwconv3x3_backward_input": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

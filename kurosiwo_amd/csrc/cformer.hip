@@ -171,6 +171,89 @@ __global__ void maxpool3s2_bwd_kernel(const T* x, const T* dy, T* dx, int accumu
   }
 }
 
+// Training pair (round 5): the forward also records WHICH element of the window was the first maximum (one byte per output element,
+// code = ky * 3 + kx), and the backward compares codes instead of re-deriving the first maximum from the eight other elements of up to
+// four windows (the gather form above: <= 36 sixteen-byte loads per thread, 325 us at 112 x 112 x 64 x 32 images; this one: <= 4 x
+// (8 + 16) bytes, the gradient of a window still goes to exactly the element torch picks -- ties are common behind a ReLU in bf16).
+template <typename T>
+__global__ void maxpool3s2_fwd_idx_kernel(const T* x, T* y, unsigned char* idx, int B, int H, int W, int C) {
+  constexpr int VEC = ElemTraits<T>::kVec;
+  const int CV = C / VEC, Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  const int64_t n = (int64_t)B * Ho * Wo * CV;
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (int64_t)gridDim.x * blockDim.x) {
+    const int cv = v % CV; int64_t r = v / CV;
+    const int ox = r % Wo; r /= Wo;
+    const int oy = r % Ho; const int b = r / Ho;
+    float m[VEC];
+    unsigned char code[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { m[j] = -3.0e38f; code[j] = 0; }
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = 2 * oy - 1 + ky;
+      if (iy < 0 || iy >= H) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = 2 * ox - 1 + kx;
+        if (ix < 0 || ix >= W) continue;
+        float t[VEC];
+        vec_unpack<T>(*(const u32x4*)(x + (((int64_t)b * H + iy) * W + ix) * C + cv * VEC), t);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) if (t[j] > m[j]) { m[j] = t[j]; code[j] = (unsigned char)(ky * 3 + kx); }   // strict: the FIRST maximum
+      }
+    }
+    *(u32x4*)(y + v * VEC) = vec_pack<T>(m);
+    unsigned char* ip = idx + v * VEC;
+#pragma unroll
+    for (int j = 0; j < VEC; j += 4)
+      *(uint32_t*)(ip + j) = (uint32_t)code[j] | ((uint32_t)code[j + 1] << 8) | ((uint32_t)code[j + 2] << 16) | ((uint32_t)code[j + 3] << 24);
+  }
+}
+template <typename T>
+__global__ void maxpool3s2_bwd_idx_kernel(const unsigned char* idx, const T* dy, T* dx, int accumulate, int B, int H, int W, int C) {
+  constexpr int VEC = ElemTraits<T>::kVec;
+  const int CV = C / VEC, Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  const int64_t n = (int64_t)B * H * W * CV;
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (int64_t)gridDim.x * blockDim.x) {
+    const int cv = v % CV; int64_t r = v / CV;
+    const int ix = r % W; r /= W;
+    const int iy = r % H; const int b = r / H;
+    float s[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) s[j] = 0.f;
+    // windows (oy, ox) with 2*oy - 1 <= iy <= 2*oy + 1: oy in {iy / 2, (iy + 1) / 2} (one window for odd... two for odd rows)
+    const int oy0 = iy / 2, oy1 = (iy + 1) / 2, ox0 = ix / 2, ox1 = (ix + 1) / 2;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int oy = a ? oy1 : oy0;
+      if ((a && oy1 == oy0) || oy >= Ho) continue;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int ox = c ? ox1 : ox0;
+        if ((c && ox1 == ox0) || ox >= Wo) continue;
+        const unsigned mycode = (unsigned)((iy - (2 * oy - 1)) * 3 + (ix - (2 * ox - 1)));
+        const int64_t o = (((int64_t)b * Ho + oy) * Wo + ox) * C + cv * VEC;
+        float g[VEC];
+        vec_unpack<T>(*(const u32x4*)(dy + o), g);
+        const unsigned char* ip = idx + o;
+#pragma unroll
+        for (int j = 0; j < VEC; j += 4) {
+          const uint32_t w4 = *(const uint32_t*)(ip + j);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) if (((w4 >> (8 * q)) & 0xffu) == mycode) s[j + q] += g[j + q];
+        }
+      }
+    }
+    if (accumulate) {
+      float o[VEC];
+      vec_unpack<T>(*(const u32x4*)(dx + v * VEC), o);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) s[j] += o[j];
+    }
+    *(u32x4*)(dx + v * VEC) = vec_pack<T>(s);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // depth-wise 3x3 conv, pad 1 (DWConv, changeformer.py:85-96): z = dw(x) + b ; g = gelu(z) (exact erf).
 // MODE 0: forward (writes z and g) ; MODE 1: adjoint (flipped taps, no bias, writes z only)
@@ -1067,6 +1150,28 @@ int ksmi_maxpool3x3s2_backward(const void* x, const void* dy, void* dx, int accu
           hipLaunchKernelGGL(maxpool3s2_bwd_kernel<bf16_t>, dim3(grid_for(n, 65536)), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, accumulate, B, H, W, C),
           hipLaunchKernelGGL(maxpool3s2_bwd_kernel<float>, dim3(grid_for(n, 65536)), dim3(256), 0, st, (const float*)x, (const float*)dy, (float*)dx, accumulate, B, H, W, C));
   return ksmi_check_launch("maxpool3x3s2_bwd");
+}
+
+int ksmi_maxpool3x3s2_forward_idx(const void* x, void* y, void* idx, int B, int H, int W, int C, int dtype, void* stream) {
+  const int vec = dtype == KSMI_BF16 ? 8 : 4;
+  if (!x || !y || !idx || C % vec) return ksmi_fail(KSMI_E_ARG, "maxpool3x3s2_idx: C must be a multiple of the 16-byte vector");
+  const int64_t n = (int64_t)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / vec);
+  hipStream_t st = (hipStream_t)stream;
+  KSMI_DT(dtype,
+          hipLaunchKernelGGL(maxpool3s2_fwd_idx_kernel<bf16_t>, dim3(grid_for(n, 65536)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, (unsigned char*)idx, B, H, W, C),
+          hipLaunchKernelGGL(maxpool3s2_fwd_idx_kernel<float>, dim3(grid_for(n, 65536)), dim3(256), 0, st, (const float*)x, (float*)y, (unsigned char*)idx, B, H, W, C));
+  return ksmi_check_launch("maxpool3x3s2_fwd_idx");
+}
+
+int ksmi_maxpool3x3s2_backward_idx(const void* idx, const void* dy, void* dx, int accumulate, int B, int H, int W, int C, int dtype, void* stream) {
+  const int vec = dtype == KSMI_BF16 ? 8 : 4;
+  if (!idx || !dy || !dx || C % vec) return ksmi_fail(KSMI_E_ARG, "maxpool3x3s2_idx: C must be a multiple of the 16-byte vector");
+  const int64_t n = (int64_t)B * H * W * (C / vec);
+  hipStream_t st = (hipStream_t)stream;
+  KSMI_DT(dtype,
+          hipLaunchKernelGGL(maxpool3s2_bwd_idx_kernel<bf16_t>, dim3(grid_for(n, 65536)), dim3(256), 0, st, (const unsigned char*)idx, (const bf16_t*)dy, (bf16_t*)dx, accumulate, B, H, W, C),
+          hipLaunchKernelGGL(maxpool3s2_bwd_idx_kernel<float>, dim3(grid_for(n, 65536)), dim3(256), 0, st, (const unsigned char*)idx, (const float*)dy, (float*)dx, accumulate, B, H, W, C));
+  return ksmi_check_launch("maxpool3x3s2_bwd_idx");
 }
 
 int ksmi_affine(const void* x, const float* scale, const float* shift, void* y, int64_t npix, int C, int relu, float alpha, int dtype,

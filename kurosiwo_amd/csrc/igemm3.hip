@@ -215,7 +215,6 @@ __global__ __launch_bounds__(256 * WN, (WN == 1 && NCH * KH * KW * NTI <= 9) ? 2
 
   // ---- epilogue state ---------------------------------------------------------------------------------------------------
   constexpr bool has_mask = MASK;
-  const int dC = d.dst[0].C;
   float ssum[8], ssq[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
@@ -294,7 +293,13 @@ __global__ __launch_bounds__(256 * WN, (WN == 1 && NCH * KH * KW * NTI <= 9) ? 2
       const bool nv = nc < d.N;
       int dd = 0, nn = nc;
       if (d.ps_cout > 0) { dd = nc / d.ps_cout; nn = nc - dd * d.ps_cout; }
-      T* const obase = (T*)d.dst[0].ptr + d.dst[0].c_off + nn;
+      // destination of this lane's 8-channel group: the virtual concat of an input gradient (several destinations, each a whole
+      // number of groups; one destination in every SNUNet launch: the scan is a scalar compare per extra destination)
+      int di = 0;
+#pragma unroll
+      for (int k = 1; k < KSMI_MAX_SRC; ++k) if (k < d.ndst && nc >= d.dst[k].n_begin) di = k;
+      T* const obase = (T*)d.dst[di].ptr + d.dst[di].c_off + (nn - d.dst[di].n_begin);
+      const int dC = d.dst[di].C;
       const T* const mbase = (const T*)d.mask_src + nc;
       float mm[MASK ? 8 : 1], mr[MASK ? 8 : 1], mg[MASK ? 8 : 1], mb[MASK ? 8 : 1];
       const float (&bias)[8] = biasr[ni];
@@ -384,12 +389,23 @@ bool ksmi_igemm3_geom(const ksmi_conv_desc* d, int dtype, ksmi_igemm3_geom_t* g)
   const int taps = d->KH * d->KW;
   if (!((d->KH == 3 && d->KW == 3) || (d->KH == 1 && d->KW == 1) || (d->KH == 2 && d->KW == 2))) return false;
   if (d->uniform_kc || d->nchunks < 1 || d->nchunks > 8) return false;
-  if (d->ndst != 1 || d->dst[0].accumulate || d->dst[0].n_begin != 0) return false;
+  if (d->ndst < 1 || d->ndst > KSMI_MAX_SRC || d->dst[0].accumulate || d->dst[0].n_begin != 0) return false;
+  // several destinations (input gradient of a virtual concat: FC-Siam conv12d -> 3 x 16 channels): whole 8-channel groups each, in order
+  if (d->ndst > 1) {
+    if (d->mask_src || d->ps_cout || (d->N % 8)) return false;
+    int nb = 0;
+    for (int k = 0; k < d->ndst; ++k) {
+      const ksmi_dst& q = d->dst[k];
+      if (q.accumulate || q.n_begin != nb || q.n_len < 8 || (q.n_len % 8) || (q.C % 8) || (q.c_off % 8) || q.c_off + q.n_len > q.C || ((uintptr_t)q.ptr & 15)) return false;
+      nb += q.n_len;
+    }
+    if (nb != d->N) return false;
+  }
   if (d->alpha != 0.f || d->resid || d->relu_out || d->out_sy || d->in_sy) return false;
   // KSMI_IGEMM3_PARTIAL=0: the round-4 rule (whole 32-channel chunks, N % 8 == 0, >= 32 padded columns) for same-box A/B runs
   static const bool partial_on = getenv("KSMI_IGEMM3_PARTIAL") ? atoi(getenv("KSMI_IGEMM3_PARTIAL")) != 0 : true;
   if (!partial_on) {
-    if ((d->N % 8) || d->Npad < 32) return false;
+    if ((d->N % 8) || d->Npad < 32 || d->ndst != 1) return false;
     for (int i = 0; i < d->nsrc; ++i) if (d->src[i].c_len % 32) return false;
   }
   if ((d->dst[0].C % 8) || (d->dst[0].c_off % 8) || d->Npad < 16) return false;
@@ -400,8 +416,12 @@ bool ksmi_igemm3_geom(const ksmi_conv_desc* d, int dtype, ksmi_igemm3_geom_t* g)
   // ReLU-mask + BN-backward sums epilogue: instances exist for 3x3 (KSMI_IGEMM3_MASK=1) but measured slower than the tile kernel /
   // igemm4 (K = 32: 154 vs 89 us, the mask loads spill 45 VGPRs next to the register-resident weights; K = 64: 72 vs 64 us): off
   static const bool mask_on = getenv("KSMI_IGEMM3_MASK") ? atoi(getenv("KSMI_IGEMM3_MASK")) != 0 : false;
-  if (d->mask_src && !(mask_on && taps == 9)) return false;
-  if (d->gate_src) return false;
+  // ... except where the tile kernel cannot run at all (a source that is not whole 32-channel chunks: Unet decoder block 5, 16 channels
+  // at 224 x 224 -- 424 us on the first-generation kernel)
+  bool part_src = false;
+  for (int i = 0; i < d->nsrc; ++i) part_src = part_src || (d->src[i].c_len % 32) != 0;
+  if (d->mask_src && !((mask_on || (part_src && partial_on)) && taps == 9)) return false;
+  if (d->gate_src || (d->mask_src && d->src[0].scale)) return false;
   auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
   if (!al16(d->dst[0].ptr) || !al16(d->bias)) return false;
   for (int i = 0; i < d->nsrc; ++i) {

@@ -12,6 +12,7 @@ the four 2x2 phase convolutions of a stride-2 input gradient; their backward is 
 once per date (its BatchNorm normalises each date on its own, siam_conc.py:100-146); weight gradients of the second pass accumulate.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -180,7 +181,12 @@ class FCSiamPlan(UnetPlan):
     # ---------------------------------------------------------------- the graph
     def _build_fcsiam(self):
         m, B, H, W, dt, nc = self.m, self.B, self.H, self.W, self.dt, self.nc
+        # channel stride of the NHWC image copy: one 16-byte granule is enough since the persistent short-K kernel reads partial chunks
+        # (igemm3.hip klen, round 5: 2 real channels of 8 instead of 32 -- the copy and conv11 move a quarter of the bytes);
+        # KSMI_IGEMM3_PARTIAL=0 (the A/B switch of that rule) restores whole chunks
         kc = 32 if self.dtype == torch.bfloat16 else 16
+        if self.dtype == torch.bfloat16 and os.environ.get("KSMI_IGEMM3_PARTIAL", "1") != "0":
+            kc = 8
         Kpad = -(-self.cin // kc) * kc
         skips = []
         deepest = None

@@ -164,3 +164,62 @@ def test_partial_chunk_switch_in_its_own_process():
                          cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert out.returncode == 0, out.stderr[-2000:]
     assert "KERNELS" in out.stdout and "igemm3_kernel" not in out.stdout, out.stdout[-500:]
+
+
+@pytest.mark.parametrize("cfg", [dict(B=2, H=40, W=36, K=16, N=16), dict(B=1, H=33, W=28, K=24, N=32)])
+def test_igemm3_mask_epilogue_on_partial_chunks(dev, cus, cfg):
+    """ReLU-mask + BatchNorm-backward sums epilogue on a source that is not whole chunks (the input gradient of Unet's decoder block 5,
+    16 channels at 224 x 224: the tile kernel needs whole chunks, the first-generation kernel took 424 us)."""
+    import ctypes as C
+    from kurosiwo_amd import _lib, functional as Fk
+    lib = _lib.load()
+    dtype = torch.bfloat16
+    B, H, W, K, N = cfg["B"], cfg["H"], cfg["W"], cfg["K"], cfg["N"]
+    tag = f"ig3m.{B}{H}{W}{K}{N}"
+    x = seeded_tensor(tag + ".x", (B, K, H, W))
+    w = seeded_tensor(tag + ".w", (N, K, 3, 3)) * (2.0 / (K * 9)) ** 0.5
+    y_ref = F.conv2d(q(x), q(w), None, padding=1)
+    m = q(seeded_tensor(tag + ".m", (B, N, H, W)))
+    mean, rstd = 0.1 * seeded_tensor(tag + ".mm", (N,)), 1.0 + 0.2 * seeded_tensor(tag + ".mr", (N,)).abs()
+    msc, msh = 1.0 + 0.3 * seeded_tensor(tag + ".ms", (N,)), 0.2 * seeded_tensor(tag + ".mh", (N,))
+    keep = (m * msc[None, :, None, None] + msh[None, :, None, None]) > 0
+    y_ref = torch.where(keep, y_ref, torch.zeros_like(y_ref))
+    xh = (m - mean[None, :, None, None]) * rstd[None, :, None, None]
+    mask = (Fk.to_nhwc(m.to(dev), dtype), mean.to(dev), rstd.to(dev), msc.to(dev), msh.to(dev))
+    buf = C.create_string_buffer(4096)
+    lib.ksmi_last_kernels(buf, 4096)
+    y, stats = Fk.conv3x3([Fk.to_nhwc(x.to(dev), dtype)], w.to(dev), None, want_stats=True, mask=mask)
+    torch.cuda.synchronize()
+    assert "igemm3_kernel" in _last_kernels(lib, buf)
+    yn = Fk.to_nchw(y).cpu()
+    assert (yn - y_ref).abs().max() < 2.5e-2 * y_ref.abs().max()
+    s = stats.sum(0).cpu()
+    yq = q(y_ref)
+    assert (s[0, :N] - yq.sum((0, 2, 3))).abs().max() < 2e-3 * max(1.0, float(y_ref.abs().sum((0, 2, 3)).max()))
+    assert (s[1, :N] - (yq * xh).sum((0, 2, 3))).abs().max() < 4e-3 * max(1.0, float((y_ref.abs() * xh.abs()).sum((0, 2, 3)).max()))
+
+
+@pytest.mark.parametrize("cfg", [dict(B=2, H=36, W=44, N=16, splits=[16, 16, 16]), dict(B=1, H=24, W=24, N=32, splits=[32, 16]),
+                                 dict(B=1, H=30, W=20, N=8, splits=[8, 24])])
+def test_igemm3_input_gradient_into_several_destinations(dev, cus, cfg):
+    """dX of y = conv3x3(cat(xs)) written straight into the tensors of the virtual concat (FC-Siam conv12d: 16 -> 3 x 16 channels)."""
+    import ctypes as C
+    from kurosiwo_amd import _lib, functional as Fk
+    lib = _lib.load()
+    dtype = torch.bfloat16
+    B, H, W, N, splits = cfg["B"], cfg["H"], cfg["W"], cfg["N"], cfg["splits"]
+    K = sum(splits)
+    tag = f"ig3d.{B}{H}{W}{N}{splits}"
+    dy = seeded_tensor(tag + ".dy", (B, N, H, W))
+    w = seeded_tensor(tag + ".w", (N, K, 3, 3)) * (2.0 / (N * 9)) ** 0.5
+    dx_ref = F.conv_transpose2d(q(dy), q(w), None, padding=1)
+    buf = C.create_string_buffer(4096)
+    lib.ksmi_last_kernels(buf, 4096)
+    outs = Fk.conv3x3_dgrad(Fk.to_nhwc(dy.to(dev), dtype), w.to(dev), splits)
+    torch.cuda.synchronize()
+    assert "igemm3_kernel" in _last_kernels(lib, buf)
+    c0 = 0
+    for o, c in zip(outs, splits):
+        ref = dx_ref[:, c0:c0 + c]
+        assert (Fk.to_nchw(o).cpu() - ref).abs().max() < 2.5e-2 * dx_ref.abs().max()
+        c0 += c

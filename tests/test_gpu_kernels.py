@@ -390,3 +390,37 @@ def test_up_convtranspose_as_token_gemms(dev, B, H, W, Cc):
     assert float((gw - wr.grad).abs().max() / wr.grad.abs().max()) < 2e-3
     _lib.check(lib.ksmi_up_wgrad(x_nhwc.data_ptr(), dy_nhwc.data_ptr(), ws.data_ptr(), gw.data_ptr(), 1, B, H, W, Cc, st), "wgrad+=")
     assert float((gw - 2 * wr.grad).abs().max() / wr.grad.abs().max()) < 4e-3
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 56, 56), (1, 16, 31, 45), (3, 8, 7, 9)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_maxpool3x3s2_recorded_first_maximum(dev, dtype, shape):
+    """ksmi_maxpool3x3s2_forward_idx / _backward_idx against torch.nn.functional.max_pool2d(3, 2, 1) and against the gather pair:
+    the input is a ReLU output quantised to bf16 (zeros and equal positive values: ties everywhere), the gradient of a window has to go
+    to the FIRST maximum in scan order."""
+    from kurosiwo_amd import _lib, functional as Fk
+    from kurosiwo_amd.functional import DT, stream_ptr
+    lib = _lib.load()
+    B, Cc, H, W = shape
+    x = torch.relu(seeded_tensor(f"mp3.x{shape}", (B, Cc, H, W))).to(torch.bfloat16).float()
+    x = (x * 4).round() / 4                                   # few distinct values: many equal maxima inside a window
+    Ho, Wo = (H + 1) // 2, (W + 1) // 2
+    dy = seeded_tensor(f"mp3.dy{shape}", (B, Cc, Ho, Wo)).to(torch.bfloat16).float()
+    xr = x.clone().requires_grad_(True)
+    y_ref = F.max_pool2d(xr, 3, 2, 1)
+    y_ref.backward(dy)
+    xd = Fk.to_nhwc(x.to(dev), dtype)
+    dyd = Fk.to_nhwc(dy.to(dev), dtype)
+    y = torch.empty((B, Ho, Wo, Cc), dtype=dtype, device=dev)
+    idx = torch.empty(y.numel(), dtype=torch.uint8, device=dev)
+    _lib.check(lib.ksmi_maxpool3x3s2_forward_idx(xd.data_ptr(), y.data_ptr(), idx.data_ptr(), B, H, W, Cc, DT[dtype], stream_ptr()), "fwd_idx")
+    assert torch.equal(Fk.to_nchw(y).cpu(), y_ref.detach())
+    for acc in (0, 1):
+        dx = torch.full((B, H, W, Cc), 0.5, dtype=dtype, device=dev)
+        _lib.check(lib.ksmi_maxpool3x3s2_backward_idx(idx.data_ptr(), dyd.data_ptr(), dx.data_ptr(), acc, B, H, W, Cc, DT[dtype], stream_ptr()), "bwd_idx")
+        dx2 = torch.full((B, H, W, Cc), 0.5, dtype=dtype, device=dev)
+        _lib.check(lib.ksmi_maxpool3x3s2_backward(xd.data_ptr(), dyd.data_ptr(), dx2.data_ptr(), acc, B, H, W, Cc, DT[dtype], stream_ptr()), "bwd")
+        assert torch.equal(dx, dx2)                           # the recorded route == the gather route, bit for bit
+        ref = xr.grad + (0.5 if acc else 0.0)
+        tol = 0.0 if dtype == torch.float32 else 2e-2 * float(ref.abs().max())
+        assert (Fk.to_nchw(dx).cpu() - ref).abs().max() <= tol
