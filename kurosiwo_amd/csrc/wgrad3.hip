@@ -102,7 +102,10 @@ __global__ __launch_bounds__(256, 2) void wgrad3_kernel(const Wg3Args ka) {
   const unsigned char* sp[CPT];
   uint32_t cb[CPT];
   bool cvalid[CPT];
-  int cc0[CPT];
+  int cc0[CPT], klen[CPT], krem[CPT];
+  // klen: channels of the plane that exist in the tensor, rounded up to the 16-byte granule (32 except in the last chunk of a source
+  // whose c_len is not a multiple of 32: the 16-channel levels of Unet / FC-Siam); the granules past it read the zero page, the
+  // reducer skips the rows past k_len
 #pragma unroll
   for (int c = 0; c < CPT; ++c) {
     const int ch = kt * CPT + c;
@@ -112,6 +115,8 @@ __global__ __launch_bounds__(256, 2) void wgrad3_kernel(const Wg3Args ka) {
     cc0[c] = wg_chunk_c0(d, chs);
     sp[c] = (const unsigned char*)((const T*)sr.ptr + sr.c_off + cc0[c]);
     cb[c] = (uint32_t)sr.C * 2u;
+    krem[c] = sr.c_len - cc0[c];
+    klen[c] = krem[c] >= 32 ? 32 : ((krem[c] + 7) & ~7);
   }
   const unsigned char* const dyp = (const unsigned char*)((const T*)d.dy + d.dy_c_off);
   const uint32_t dycb = (uint32_t)d.dyC * 2u;
@@ -124,7 +129,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3_kernel(const Wg3Args ka) {
     if (tid < CPT * 32) {
       const int c = tid >> 5, j = tid & 31;
       const ksmi_src& sr = d.src[0];
-      const bool ok = cvalid[c];
+      const bool ok = cvalid[c] && j < krem[c];
       aff_tab[tid * 2 + 0] = ok ? sr.scale[cc0[c] + j] : 0.f;
       aff_tab[tid * 2 + 1] = ok ? sr.shift[cc0[c] + j] : 0.f;
     }
@@ -195,13 +200,15 @@ __global__ __launch_bounds__(256, 2) void wgrad3_kernel(const Wg3Args ka) {
       const int f = ((hx >> 3) ^ (hy & ka.hymask)) & 1;
       const uint32_t pix = d.in_sy == 0 ? (uint32_t)((b * d.Hin + iy) * d.Win + ix)
                                         : (uint32_t)((b * d.in_H + (iy * d.in_sy + d.in_oy)) * d.in_W + (ix * d.in_sx + d.in_ox));   // (strided view: the phase gradients)
-      const uint32_t slb = (uint32_t)((s ^ (f << 1)) * 16);
+      const int sgr = s ^ (f << 1);                                    // source granule of this slot
+      const uint32_t slb = (uint32_t)(sgr * 16);
       if (it * 256 + wave * 64 < ka.HPv * 4) {                       // wave-uniform: this wave has halo slots in this iteration
 #pragma unroll
         for (int c = 0; c < CPT; ++c) {
           if (!cvalid[c]) continue;
+          const bool okc = ok && sgr * 8 < klen[c];
           const uint64_t av = (uint64_t)(uintptr_t)sp[c] + (uint64_t)(pix * cb[c] + slb);
-          const uint32_t lo = ok ? (uint32_t)av : zlo, hi = ok ? (uint32_t)(av >> 32) : zhi;
+          const uint32_t lo = okc ? (uint32_t)av : zlo, hi = okc ? (uint32_t)(av >> 32) : zhi;
           if (inr) glds16_flat((const unsigned char*)(uintptr_t)(((uint64_t)hi << 32) | lo),
                                lds0 + (unsigned)(stg * stage + c * xpl + (it * 256 + wave * 64) * 16));
         }
@@ -364,9 +371,10 @@ __global__ __launch_bounds__(256) void wgrad3_reduce_kernel(const ksmi_wgrad_des
     const int krow = (int)(r % Ktot), t = (int)(r / Ktot);
     const int ch = krow >> 5;
     const int64_t k = (d.uniform_kc ? ch * d.uniform_kc : d.k_off[ch]) + (krow & 31);
+    const int kl = d.uniform_kc ? min(d.uniform_kc, d.k_total - ch * d.uniform_kc) : d.k_len[ch];   // (rows past it: pad channels of a partial chunk)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      if (n + j < d.N) {
+      if (n + j < d.N && (krow & 31) < kl) {
         float* gp = d.grad + k * d.gK + (int64_t)(n + j) * d.gN + (d.use_tap_off ? (int64_t)d.tap_off[t] : (int64_t)t * d.gT);
         *gp = d.accumulate ? (*gp + v[j]) : v[j];
       }
@@ -390,15 +398,19 @@ bool ksmi_wgrad3_geom(const ksmi_wgrad_desc* d, int dtype, ksmi_wgrad3_geom_t* g
     g->r0 = 1 - d->pad; g->c0 = 1 - d->pad_x;
   } else if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || (d->pad_x_set && d->pad_x != 1) || d->in_sy != 0 || d->use_tap_off) return false;
   if (d->Hin != d->Hout || d->Win != d->Wout || (d->N % 8) != 0 || d->N < 16) return false;
+  // KSMI_WGRAD3_PARTIAL=0: whole 32-channel chunks only (the round-4 rule; same-box A/B)
+  static const bool partial_on = getenv("KSMI_WGRAD3_PARTIAL") ? atoi(getenv("KSMI_WGRAD3_PARTIAL")) != 0 : true;
   for (int i = 0; i < d->nsrc; ++i) {
-    if (d->src[i].c_len % 32) return false;
+    // whole 16-byte granules inside the source row; the last chunk of a source may be partial (zero-page granules, klen in the kernel)
+    if (d->src[i].c_len < 1 || (d->src[i].C % 8) || (d->src[i].c_off % 8) || d->src[i].c_off + ((d->src[i].c_len + 7) & ~7) > d->src[i].C) return false;
+    if ((d->src[i].c_len % 32) && (!partial_on || k2)) return false;
     if (d->src[i].scale && (i > 0 || d->nsrc != 1)) return false;
     const size_t ipx = d->in_sy ? (size_t)d->B * d->in_H * d->in_W : (size_t)d->B * d->Hin * d->Win;
     if (ipx * (size_t)d->src[i].C * 2 >= ((size_t)1 << 32)) return false;
   }
   if ((size_t)d->B * d->Hout * d->Wout * (size_t)d->dyC * 2 >= ((size_t)1 << 32)) return false;
-  if (d->uniform_kc) { if (d->uniform_kc != 32 || d->k_total != d->nchunks * 32) return false; }
-  else for (int i = 0; i < d->nchunks; ++i) if (d->k_len[i] != 32) return false;
+  if (d->uniform_kc) { if (d->uniform_kc != 32 || d->k_total > d->nchunks * 32 || d->k_total <= (d->nchunks - 1) * 32) return false; }
+  else for (int i = 0; i < d->nchunks; ++i) if (d->k_len[i] < 1 || d->k_len[i] > 32 || (d->k_len[i] != 32 && (!partial_on || k2))) return false;
   // patch: width 8 / 16 / 32, at most 128 pixels; fewest patches, then smallest halo
   const int H = d->Hout, W = d->Wout;
   long best = -1;

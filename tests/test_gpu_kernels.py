@@ -159,6 +159,11 @@ def test_conv3x3_forward_dgrad_wgrad(dev, dtype, cfg):
     dict(B=2, H=33, W=19, cs=[64, 32], N=48),         # ragged map, N not a multiple of 32
     dict(B=1, H=40, W=72, cs=[32], N=32, aff=True),   # fused BN-apply + ReLU operand transformed in LDS
     dict(B=2, H=28, W=28, cs=[64], N=64, aff=True),
+    dict(B=2, H=48, W=40, cs=[16], N=16),             # round 5: partial chunks (zero-page granules, the reducer skips the pad rows)
+    dict(B=1, H=33, W=50, cs=[16], N=32, aff=True),
+    dict(B=2, H=24, W=24, cs=[32, 16], N=16),
+    dict(B=1, H=30, W=26, cs=[8], N=16),
+    dict(B=1, H=20, W=44, cs=[16, 16, 16], N=16),     # FC-Siam conv12d: three 16-channel sources
 ])
 def test_wgrad3_channel_owner_kernel(dev, cfg):
     """csrc/wgrad3.hip (bf16 3x3 s1 weight gradient, channel-owner tiling) vs F.conv2d's weight gradient on CPU."""
@@ -179,7 +184,13 @@ def test_wgrad3_channel_owner_kernel(dev, cfg):
     wr = torch.zeros((N, K, 3, 3)).requires_grad_(True)
     F.conv2d(xq, wr, None, padding=1).backward(q(dy))
     xd = [Fk.to_nhwc(x.to(dev), dtype) for x in xs]
+    import ctypes as C
+    from kurosiwo_amd import _lib
+    lib = _lib.load()
+    buf = C.create_string_buffer(4096)
+    lib.ksmi_last_kernels(buf, 4096)
     dw = Fk.conv3x3_wgrad(xd, Fk.to_nhwc(dy.to(dev), dtype), affine=aff).cpu()
+    assert lib.ksmi_last_kernels(buf, 4096) and "wgrad3_kernel" in buf.value.decode(), buf.value.decode()
     err = float((dw - wr.grad).abs().max() / wr.grad.abs().max())
     assert err < 2e-3, err            # operands are identical bf16 values; fp32 accumulation order differs
 
