@@ -931,7 +931,13 @@ bool ksmi_igemm4_geom(const ksmi_conv_desc* d, int dtype, ksmi_igemm4_geom_t* g)
   if (d->out_sy && ((size_t)d->B * d->out_H * d->out_W >= ((size_t)1 << 31))) return false;
   if ((d->alpha != 0.f || d->resid || d->relu_out) && (d->mask_src || d->gate_src)) return false;      // extras: plain epilogue only
   if (d->resid && (((uintptr_t)d->resid & 15) || (d->residC % 8))) return false;
-  if ((d->N % 8) || (d->dst[0].C % 8) || (d->dst[0].c_off % 8)) return false;
+  if ((d->dst[0].C % 8) || (d->dst[0].c_off % 8)) return false;
+  // N % 8 != 0 (2- / 3-class heads into a destination with a channel stride of 8: ChangeFormer's change_probability, 256 -> 2): the last
+  // 8-channel group is stored whole, its pad channels as zeros (zero weights, no bias beyond N) -- plain epilogue only
+  // (KSMI_IG4_THIN=0: back to the tile kernel)
+  static const int thin_on = getenv("KSMI_IG4_THIN") ? atoi(getenv("KSMI_IG4_THIN")) : 1;
+  if ((d->N % 8) && (!thin_on || k2 || d->mask_src || d->gate_src || d->resid || d->dst[0].accumulate || d->alpha != 0.f || d->relu_out ||
+                     d->dst[0].c_off + ((d->N + 7) & ~7) > d->dst[0].C)) return false;
   if (d->Npad != 32 && (d->Npad % 64)) return false;
   auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
   if (!al16(d->dst[0].ptr) || !al16(d->bias) || !al16(d->mask_src) || !al16(d->m_mean) || !al16(d->m_rstd) || !al16(d->m_scale) || !al16(d->m_shift))

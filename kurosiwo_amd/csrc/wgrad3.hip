@@ -385,6 +385,10 @@ __global__ __launch_bounds__(256) void wgrad3_reduce_kernel(const ksmi_wgrad_des
 }  // namespace
 
 // ---- host side --------------------------------------------------------------------------------------------------------
+static bool partial_on_n() {     // KSMI_WGRAD3_PARTIAL=0: whole chunks, N % 8 == 0, N >= 16 only (the round-4 rule; same-box A/B)
+  static const bool on = getenv("KSMI_WGRAD3_PARTIAL") ? atoi(getenv("KSMI_WGRAD3_PARTIAL")) != 0 : true;
+  return on;
+}
 bool ksmi_wgrad3_geom(const ksmi_wgrad_desc* d, int dtype, ksmi_wgrad3_geom_t* g) {
   static const bool off = getenv("KSMI_WGRAD3_OFF") != nullptr;
   if (off || dtype != KSMI_BF16) return false;
@@ -397,7 +401,10 @@ bool ksmi_wgrad3_geom(const ksmi_wgrad_desc* d, int dtype, ksmi_wgrad3_geom_t* g
     if (!k2_on || d->stride != 1 || (unsigned)d->pad > 1u || !d->pad_x_set || (unsigned)d->pad_x > 1u || !d->use_tap_off || d->src[0].scale) return false;
     g->r0 = 1 - d->pad; g->c0 = 1 - d->pad_x;
   } else if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || (d->pad_x_set && d->pad_x != 1) || d->in_sy != 0 || d->use_tap_off) return false;
-  if (d->Hin != d->Hout || d->Win != d->Wout || (d->N % 8) != 0 || d->N < 16) return false;
+  if (d->Hin != d->Hout || d->Win != d->Wout || d->N < 1) return false;
+  // N < 16 or N % 8 != 0 (the weight gradient of a 2- / 3-class head: d out has a channel stride of 8): whole 16-byte granules of the
+  // d out row are read (the pad channels must exist inside the row; their columns are computed and dropped by the reducer)
+  if (((d->N % 8) != 0 || d->N < 16) && (!partial_on_n() || k2 || (d->dyC % 8) || (d->dy_c_off % 8) || d->dy_c_off + ((d->N + 7) & ~7) > d->dyC)) return false;
   // KSMI_WGRAD3_PARTIAL=0: whole 32-channel chunks only (the round-4 rule; same-box A/B)
   static const bool partial_on = getenv("KSMI_WGRAD3_PARTIAL") ? atoi(getenv("KSMI_WGRAD3_PARTIAL")) != 0 : true;
   for (int i = 0; i < d->nsrc; ++i) {

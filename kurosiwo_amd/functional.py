@@ -6,7 +6,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from .runtime import DT, SrcSpec, conv_grid_m, conv_stats_rows, make_conv, make_pack, make_wgrad, packed_weight_numel, require_gpu, stream_ptr
+from .runtime import DT, SrcSpec, conv_grid_m, conv_npad, conv_stats_rows, make_conv, make_pack, make_wgrad, packed_weight_numel, require_gpu, stream_ptr
 
 
 def to_nhwc(x_nchw, dtype):
@@ -26,7 +26,7 @@ def to_nchw(x_nhwc):
 
 
 def _pack(weight, table, taps, N, n_mod, sK, sN, sD, sT, flip, dtype):
-    Npad = (N + 15) // 16 * 16
+    Npad = conv_npad(N)
     out = torch.empty(packed_weight_numel(table, taps, Npad, dtype), dtype=dtype, device=weight.device)
     d = make_pack(weight, out, table, taps, N, Npad, n_mod, sK, sN, sD, sT, flip)
     _lib.check(_lib.load().ksmi_pack_weights(C.byref(d), DT[dtype], stream_ptr()), "pack_weights")
@@ -84,15 +84,17 @@ def conv3x3_dgrad(dy, weight, splits):
     return outs
 
 
-def conv3x3_wgrad(xs, dy, affine=None):
+def conv3x3_wgrad(xs, dy, affine=None, n_real=None):
+    """n_real: output channels that exist when d out is stored with a wider channel stride (the 8-channel-stride 2- / 3-class heads)."""
     dtype = dy.dtype
-    B, H, W, N = dy.shape
+    B, H, W, dyC = dy.shape
+    N = dyC if n_real is None else n_real
     Ktot = sum(x.shape[3] for x in xs)
     srcs = [SrcSpec(x, x.shape[3]) for x in xs]
     if affine is not None:
         srcs[0].scale, srcs[0].shift, srcs[0].relu = affine
     grad = torch.zeros((N, Ktot, 3, 3), dtype=torch.float32, device=dy.device)
-    d, ws = make_wgrad(srcs, dy, N, 0, N, grad, 9, Ktot * 9, 1, 0, B, H, W, H, W, 3, 3, 1, 1, dtype)
+    d, ws = make_wgrad(srcs, dy, dyC, 0, N, grad, 9, Ktot * 9, 1, 0, B, H, W, H, W, 3, 3, 1, 1, dtype)
     wsb = torch.empty(max(ws, 16), dtype=torch.uint8, device=dy.device)
     d.partial = wsb.data_ptr()
     _lib.check(_lib.load().ksmi_conv_wgrad(C.byref(d), DT[dtype], stream_ptr()), "conv_wgrad")

@@ -6,7 +6,7 @@ import os
 import torch
 
 from . import _lib
-from .runtime import DT, SrcSpec, make_conv, make_pack, make_wgrad, packed_weight_numel
+from .runtime import DT, SrcSpec, conv_npad, make_conv, make_pack, make_wgrad, packed_weight_numel
 from .snunet_plan import LaunchList
 
 LN_EPS = 1e-5
@@ -152,7 +152,7 @@ class PlanBase:
         self._mark(*[e["key"] for e in ents])
 
     def _packed(self, key, table, taps, N, n_mod, sK, sN, sD, sT, flip=0, tap_map=None):
-        Npad = (N + 15) // 16 * 16
+        Npad = conv_npad(N)
         out = torch.empty(packed_weight_numel(table, taps, Npad, self.dtype), dtype=self.dtype, device=self.dev)
         d = make_pack(self.m._p(key), out, table, taps, N, Npad, n_mod, sK, sN, sD, sT, flip, tap_map)
         self.keep += [d, out]

@@ -185,6 +185,12 @@ def make_pack(w, out, table, taps, N, Npad, n_mod, sK, sN, sD, sT, flip, tap_map
     return d
 
 
+def conv_npad(N):
+    """Padded column count of a convolution's packed weights / statistics rows: a multiple of 16, and 32 for the thin heads (N < 16) so
+    that the 32-column tiles of the persistent kernels can take them (igemm4.hip <8, 2>: ChangeFormer's 256 -> 2 change_probability)."""
+    return 32 if N < 16 else (N + 15) // 16 * 16
+
+
 def make_conv(srcs, dsts, wpk, bias, stats, B, Hin, Win, Hout, Wout, KH, KW, stride, pad, N, dtype,
               mask=None, ps_cout=0, max_pix=256, pad_x=None, out_map=None, alpha=0.0, relu_out=0, resid=None, in_map=None):
     """dsts: list of (tensor, C, c_off, n_begin, n_len, accumulate).  mask: (tensor, mean, rstd, scale, shift).
@@ -214,7 +220,7 @@ def make_conv(srcs, dsts, wpk, bias, stats, B, Hin, Win, Hout, Wout, KH, KW, str
         d.out_sy, d.out_sx, d.out_oy, d.out_ox, d.out_H, d.out_W = out_map
     mp = max_pix if stride == 1 else min(max_pix, 128)
     d.TH, d.TW = choose_patch(Hout, Wout, stride, KH, KW, mp)
-    d.N, d.Npad = N, (N + 15) // 16 * 16
+    d.N, d.Npad = N, conv_npad(N)
     d.nchunks = len(table)
     d.ps_cout = ps_cout
     if _uniform(table, kc)[0]:

@@ -69,6 +69,8 @@ CFGS = [
     dict(B=4, H=16, W=16, cs=[160], N=64, aff=True),          # odd chunk count through the 3-slot rings
     dict(B=2, H=48, W=40, cs=[32, 64], N=32),                 # 32 output channels: 512-pixel patches, 64 x 32 wave tiles
     dict(B=1, H=64, W=64, cs=[64], N=32, mask=True),
+    dict(B=2, H=48, W=40, cs=[256], N=2, ostride=8),          # 2-class head into a destination with channel stride 8 (ChangeFormer)
+    dict(B=1, H=33, W=50, cs=[64, 32], N=3, ostride=8),
 ]
 
 
@@ -103,6 +105,23 @@ def test_igemm4_conv3x3(dev, cfg):
     old = q(seeded_tensor(tag + ".old", (B, N, H, W))) if cfg.get("acc") else None
     xd = [Fk.to_nhwc(x.to(dev), dtype) for x in xs]
     for cus, var in _variants(N):
+        if cfg.get("ostride"):
+            import ctypes as C
+            from kurosiwo_amd import _lib
+            lib = _lib.load()
+            buf = C.create_string_buffer(4096)
+            lib.ksmi_last_kernels(buf, 4096)
+            outp = torch.full((B, H, W, cfg["ostride"]), 7.0, dtype=dtype, device=dev)
+            with _Env(KSMI_IGEMM4_CUS="3", KSMI_IGEMM4_VAR="8,2"):      # (small maps: force the 512-pixel x 32-column variant, many tiles per workgroup)
+                y, stats = Fk.conv3x3(xd, w.to(dev), bias.to(dev), want_stats=True, out=outp)
+            torch.cuda.synchronize()
+            assert lib.ksmi_last_kernels(buf, 4096) and "igemm4_kernel" in buf.value.decode(), buf.value.decode()
+            yn = Fk.to_nchw(y).cpu()
+            assert (yn[:, :N] - y_ref).abs().max() < 2.5e-2 * y_ref.abs().max()
+            assert float(yn[:, N:].abs().max()) == 0.0
+            s = stats.sum(0).cpu()
+            assert (s[0, :N] - s0_ref).abs().max() < 1e-3 * max(1.0, float(y_ref.abs().sum((0, 2, 3)).max()))
+            continue
         out = Fk.to_nhwc(old.to(dev), dtype) if old is not None else None
         with _Env(KSMI_IGEMM4_CUS=cus, KSMI_IGEMM4_VAR=var):
             y, stats = Fk.conv3x3(xd, w.to(dev), bias.to(dev), affine=aff, want_stats=True, mask=mask, out=out,

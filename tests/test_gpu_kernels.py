@@ -164,6 +164,8 @@ def test_conv3x3_forward_dgrad_wgrad(dev, dtype, cfg):
     dict(B=2, H=24, W=24, cs=[32, 16], N=16),
     dict(B=1, H=30, W=26, cs=[8], N=16),
     dict(B=1, H=20, W=44, cs=[16, 16, 16], N=16),     # FC-Siam conv12d: three 16-channel sources
+    dict(B=2, H=40, W=36, cs=[64], N=2, dyC=8),       # 2- / 3-class heads: d out with a channel stride of 8
+    dict(B=1, H=28, W=50, cs=[32, 32, 32, 32, 32, 32, 32, 32], N=3, dyC=8),
 ])
 def test_wgrad3_channel_owner_kernel(dev, cfg):
     """csrc/wgrad3.hip (bf16 3x3 s1 weight gradient, channel-owner tiling) vs F.conv2d's weight gradient on CPU."""
@@ -189,7 +191,11 @@ def test_wgrad3_channel_owner_kernel(dev, cfg):
     lib = _lib.load()
     buf = C.create_string_buffer(4096)
     lib.ksmi_last_kernels(buf, 4096)
-    dw = Fk.conv3x3_wgrad(xd, Fk.to_nhwc(dy.to(dev), dtype), affine=aff).cpu()
+    if cfg.get("dyC"):
+        dyp = torch.zeros((B, cfg["dyC"], H, W)); dyp[:, :N] = dy
+        dw = Fk.conv3x3_wgrad(xd, Fk.to_nhwc(dyp.to(dev), dtype), affine=aff, n_real=N).cpu()
+    else:
+        dw = Fk.conv3x3_wgrad(xd, Fk.to_nhwc(dy.to(dev), dtype), affine=aff).cpu()
     assert lib.ksmi_last_kernels(buf, 4096) and "wgrad3_kernel" in buf.value.decode(), buf.value.decode()
     err = float((dw - wr.grad).abs().max() / wr.grad.abs().max())
     assert err < 2e-3, err            # operands are identical bf16 values; fp32 accumulation order differs
