@@ -374,6 +374,11 @@ int ksmi_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int6
  * decoupled weight decay p *= 1 - lr * weight_decay, then the Adam update; same state and step counter as ksmi_adam_step */
 int ksmi_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, int64_t* step_count,
                     float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale, void* stream);
+/* ksmi_adam_step / ksmi_adamw_step (decoupled != 0) that ALSO writes the updated parameters as bf16 into mirror_bf16 [n] (8-byte aligned):
+ * the bf16 operand copy of the token GEMMs without a separate cast pass (SURVEY.md K8 "optional bf16 shadow write") */
+int ksmi_adam_step_mirror(float* p, const float* g, float* m, float* v, int64_t n, int64_t* step_count,
+                          float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale, int decoupled,
+                          void* mirror_bf16, void* stream);
 int ksmi_sgd_step(float* p, const float* g, float* mom, int64_t n, int64_t* step_count,
                   float lr, float momentum, float weight_decay, float grad_scale, void* stream);
 

@@ -673,9 +673,12 @@ __global__ void step_increment_kernel(int64_t* step) { if (threadIdx.x == 0 && b
 
 // 16-byte accesses (the arenas are 32-byte aligned; a scalar tail covers n % 4): the 4-byte version moved 2.1 TB/s
 // DECOUPLED: torch.optim.AdamW (p *= 1 - lr * wd before the update); otherwise torch.optim.Adam (wd * p joins the gradient)
-template <bool DECOUPLED>
+// MIRROR (round 5; SURVEY.md K8 "optional bf16 shadow write"): the updated parameter is also written as bf16 into `mirror` (the operand
+// copy of the token GEMMs, plan_base.wb) -- 2 bytes per parameter more here instead of a cast pass that re-reads the fp32 arena
+// (6 bytes per parameter, 0.21 ms per step at the 205 M parameters of FloodViT)
+template <bool DECOUPLED, bool MIRROR = false>
 __global__ void adam_kernel(float* p, const float* g, float* m, float* v, int64_t n, const int64_t* step,
-                            float lr, float b1, float b2, float eps, float wd, float gscale) {
+                            float lr, float b1, float b2, float eps, float wd, float gscale, bf16_t* mirror = nullptr) {
   const double t = (double)*step;
   const float bc1 = (float)(1.0 - pow((double)b1, t));
   const float bc2s = (float)sqrt(1.0 - pow((double)b2, t));
@@ -706,16 +709,29 @@ __global__ void adam_kernel(float* p, const float* g, float* m, float* v, int64_
 #pragma unroll
     for (int j = 0; j < 4; ++j) { float pj = pa[j], mj = ma[j], vj = va[j]; upd(ga[j], pj, mj, vj); pa[j] = pj; ma[j] = mj; va[j] = vj; }
     __builtin_nontemporal_store(pa, (f32x4*)p + i); __builtin_nontemporal_store(ma, (f32x4*)m + i); __builtin_nontemporal_store(va, (f32x4*)v + i);
+    if constexpr (MIRROR) {
+      uint2 w2;
+      w2.x = (uint32_t)f32_to_bf16(pa[0]) | ((uint32_t)f32_to_bf16(pa[1]) << 16);
+      w2.y = (uint32_t)f32_to_bf16(pa[2]) | ((uint32_t)f32_to_bf16(pa[3]) << 16);
+      *((uint2*)mirror + i) = w2;
+    }
     if (two) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) { float pj = pb[j], mj = mb[j], vj = vb[j]; upd(gb[j], pj, mj, vj); pb[j] = pj; mb[j] = mj; vb[j] = vj; }
       __builtin_nontemporal_store(pb, (f32x4*)p + i2); __builtin_nontemporal_store(mb, (f32x4*)m + i2); __builtin_nontemporal_store(vb, (f32x4*)v + i2);
+      if constexpr (MIRROR) {
+        uint2 w2;
+        w2.x = (uint32_t)f32_to_bf16(pb[0]) | ((uint32_t)f32_to_bf16(pb[1]) << 16);
+        w2.y = (uint32_t)f32_to_bf16(pb[2]) | ((uint32_t)f32_to_bf16(pb[3]) << 16);
+        *((uint2*)mirror + i2) = w2;
+      }
     }
   }
   for (int64_t i = nv * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     float pi = p[i], mi = m[i], vi = v[i];
     upd(g[i], pi, mi, vi);
     p[i] = pi; m[i] = mi; v[i] = vi;
+    if constexpr (MIRROR) mirror[i] = f32_to_bf16(pi);
   }
 }
 
@@ -1096,17 +1112,30 @@ int ksmi_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int6
                    float beta2, float eps, float weight_decay, float grad_scale, void* stream) {
   if (!p || !g || !m || !v || !step_count || n < 0) return ksmi_fail(KSMI_E_ARG, "adam: bad args");
   hipLaunchKernelGGL(step_increment_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step_count);
-  hipLaunchKernelGGL(adam_kernel<false>, dim3(grid_for((n + 3) / 4, 8192)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, step_count, lr, beta1,
-                     beta2, eps, weight_decay, grad_scale);
+  hipLaunchKernelGGL((adam_kernel<false, false>), dim3(grid_for((n + 3) / 4, 8192)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, step_count, lr, beta1,
+                     beta2, eps, weight_decay, grad_scale, (bf16_t*)nullptr);
   return ksmi_check_launch("adam");
+}
+
+int ksmi_adam_step_mirror(float* p, const float* g, float* m, float* v, int64_t n, int64_t* step_count, float lr, float beta1,
+                          float beta2, float eps, float weight_decay, float grad_scale, int decoupled, void* mirror_bf16, void* stream) {
+  if (!p || !g || !m || !v || !step_count || !mirror_bf16 || n < 0 || ((uintptr_t)mirror_bf16 & 7)) return ksmi_fail(KSMI_E_ARG, "adam_mirror: bad args");
+  hipLaunchKernelGGL(step_increment_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step_count);
+  if (decoupled)
+    hipLaunchKernelGGL((adam_kernel<true, true>), dim3(grid_for((n + 3) / 4, 8192)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, step_count, lr, beta1,
+                       beta2, eps, weight_decay, grad_scale, (bf16_t*)mirror_bf16);
+  else
+    hipLaunchKernelGGL((adam_kernel<false, true>), dim3(grid_for((n + 3) / 4, 8192)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, step_count, lr, beta1,
+                       beta2, eps, weight_decay, grad_scale, (bf16_t*)mirror_bf16);
+  return ksmi_check_launch("adam_mirror");
 }
 
 int ksmi_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, int64_t* step_count, float lr, float beta1,
                     float beta2, float eps, float weight_decay, float grad_scale, void* stream) {
   if (!p || !g || !m || !v || !step_count || n < 0) return ksmi_fail(KSMI_E_ARG, "adamw: bad args");
   hipLaunchKernelGGL(step_increment_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step_count);
-  hipLaunchKernelGGL(adam_kernel<true>, dim3(grid_for((n + 3) / 4, 8192)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, step_count, lr, beta1,
-                     beta2, eps, weight_decay, grad_scale);
+  hipLaunchKernelGGL((adam_kernel<true, false>), dim3(grid_for((n + 3) / 4, 8192)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, step_count, lr, beta1,
+                     beta2, eps, weight_decay, grad_scale, (bf16_t*)nullptr);
   return ksmi_check_launch("adamw");
 }
 

@@ -73,9 +73,22 @@ class FusedAdam(_FlatOptimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
 
-    def step_arena(self, p_ptr, g_ptr, n, device, grad_scale=1.0):
+    _decoupled = 0
+
+    def step_arena(self, p_ptr, g_ptr, n, device, grad_scale=1.0, mirror=None):
+        """mirror: device pointer of a bf16 copy of the parameter arena that the step refreshes as it writes the parameters
+        (ksmi_adam_step_mirror; the plans' operand copy for the token GEMMs).  Returns True when it did."""
         g = self.param_groups[0]
         st = self.flat_state(n, device)
+        if mirror:
+            _lib.check(_lib.load().ksmi_adam_step_mirror(p_ptr, g_ptr, st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), n,
+                                                         st["step"].data_ptr(), g["lr"], g["betas"][0], g["betas"][1], g["eps"],
+                                                         g["weight_decay"], grad_scale, self._decoupled, mirror, stream_ptr()), "adam_step_mirror")
+            return True
+        self._step_plain(p_ptr, g_ptr, n, st, g, grad_scale)
+        return False
+
+    def _step_plain(self, p_ptr, g_ptr, n, st, g, grad_scale):
         _lib.check(_lib.load().ksmi_adam_step(p_ptr, g_ptr, st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), n,
                                               st["step"].data_ptr(), g["lr"], g["betas"][0], g["betas"][1], g["eps"],
                                               g["weight_decay"], grad_scale, stream_ptr()), "adam_step")
@@ -87,9 +100,9 @@ class FusedAdamW(FusedAdam):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
 
-    def step_arena(self, p_ptr, g_ptr, n, device, grad_scale=1.0):
-        g = self.param_groups[0]
-        st = self.flat_state(n, device)
+    _decoupled = 1
+
+    def _step_plain(self, p_ptr, g_ptr, n, st, g, grad_scale):
         _lib.check(_lib.load().ksmi_adamw_step(p_ptr, g_ptr, st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), n,
                                                st["step"].data_ptr(), g["lr"], g["betas"][0], g["betas"][1], g["eps"],
                                                g["weight_decay"], grad_scale, stream_ptr()), "adamw_step")

@@ -45,7 +45,26 @@ class PlanBase:
             assert n % 8 == 0
             self.wb = torch.empty(n, dtype=torch.bfloat16, device=self.dev)
             fp, wb = model.flat_params, self.wb
-            self.packs.add("ksmi_cast_bf16", lambda: (fp.data_ptr(), wb.data_ptr(), n), {"kind": "cast_bf16", "bytes": 6 * n, "flops": 0})
+            # The cast is skipped for the forward that follows an optimiser step which wrote the mirror itself (ksmi_adam_step_mirror:
+            # trainer -> mirror_written()).  Freshness = the version counter of the fp32 arena at that moment: any in-place torch
+            # operation on a parameter afterwards (load_state_dict, init, .copy_) bumps it and the cast runs again; the mark is
+            # consumed by one forward, so an evaluation pass or a second forward re-casts too.  KSMI_ADAM_MIRROR=0: always cast.
+            self._mirror_version = None
+            self.packs.add("ksmi_cast_bf16", lambda: (fp.data_ptr(), wb.data_ptr(), n),
+                           {"kind": "cast_bf16", "bytes": 6 * n, "flops": 0, "skip_if": self._mirror_is_fresh})
+
+    def mirror_ptr(self):
+        """device pointer of the bf16 operand copy of the parameter arena for an optimiser that writes it (None: this plan has none)"""
+        if self.wb is None or os.environ.get("KSMI_ADAM_MIRROR", "1") == "0" or getattr(self, "_mirror_off", False):
+            return None
+        return self.wb.data_ptr()
+
+    def mirror_written(self):
+        self._mirror_version = self.m.flat_params._version
+
+    def _mirror_is_fresh(self):
+        v, self._mirror_version = getattr(self, "_mirror_version", None), None
+        return v is not None and v == self.m.flat_params._version
 
     def _wb_ptr(self, key):
         return self.wb.data_ptr() + 2 * self.m._poff[key]

@@ -83,6 +83,8 @@ class LaunchList:
                     if hook is not None:
                         hook(idx)
                     continue
+                if meta.get("skip_if") is not None and meta["skip_if"]():      # (plan_base: the bf16 mirror the optimiser just wrote)
+                    continue
                 lane = meta["lane"] if streams is not None and streams.lanes else 0
                 if lane != cur:
                     torch.cuda.set_stream(streams.stream(lane))

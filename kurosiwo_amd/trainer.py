@@ -14,6 +14,18 @@ from .optim import FusedAdam
 from .runtime import stream_ptr
 
 
+def _optimizer_step(step, mf, plan):
+    """optimizer.step on the flat arenas; an Adam-family optimiser also refreshes the plan's bf16 operand copy of the parameters (the
+    next forward then skips its cast pass: plan_base.mirror_written)"""
+    opt = step.optimizer
+    args = (mf.flat_params.data_ptr(), mf.flat_grads.data_ptr(), mf.flat_params.numel(), plan.dev, 1.0 / step.world)
+    mirror = plan.mirror_ptr() if hasattr(plan, "mirror_ptr") and hasattr(opt, "_decoupled") else None
+    if mirror and opt.step_arena(*args, mirror=mirror):
+        plan.mirror_written()
+    elif not mirror:
+        opt.step_arena(*args)
+
+
 class _PlanTrainStep:
     """zero_grad -> forward -> criterion -> backward (+ bucketed all-reduce) -> optimizer.step over a model plan."""
 
@@ -98,6 +110,7 @@ class _PlanTrainStep:
     _graph = None
 
     def capture_graph(self):
+        self.plan._mirror_off = True                 # (a replayed graph cannot re-decide whether the cast pass is needed: keep it in)
         if self.world > 1:
             raise _lib.KsmiError("graph capture of the train step is single-GPU (the bucketed all-reduce hooks run eagerly)")
         if self.timer is not None:
@@ -152,8 +165,7 @@ class _PlanTrainStep:
             ss.end()
         self.reducer.wait()
         mf = self.model
-        self._timed("optimizer", lambda: self.optimizer.step_arena(mf.flat_params.data_ptr(), mf.flat_grads.data_ptr(),
-                                                                   mf.flat_params.numel(), p.dev, 1.0 / self.world))
+        self._timed("optimizer", lambda: _optimizer_step(self, mf, p))
 
     def step(self, *args):
         self.set_batch(*args)
@@ -252,7 +264,7 @@ class MAETrainStep:
         on = t is not None and t.wants("optimizer")
         if on:
             t.begin("optimizer")
-        self.optimizer.step_arena(mf.flat_params.data_ptr(), mf.flat_grads.data_ptr(), mf.flat_params.numel(), p.dev, 1.0 / self.world)
+        _optimizer_step(self, mf, p)
         if on:
             t.end()
 

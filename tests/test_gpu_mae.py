@@ -152,3 +152,34 @@ def test_side_stream_weight_gradients_equal_single_stream(monkeypatch):
     for a, b in zip(out[0][0], out[1][0]):
         assert torch.equal(a, b)
     assert torch.equal(out[0][2], out[1][2]) and torch.equal(out[0][1], out[1][1])
+
+
+def test_adam_bf16_mirror_equals_the_cast_pass(monkeypatch):
+    """ksmi_adam_step_mirror writes the bf16 operand copy of the parameters as it updates them and the next forward skips its cast pass
+    (plan_base.mirror_written / _mirror_is_fresh): the trajectory must equal the one with the cast pass (KSMI_ADAM_MIRROR=0) bit for bit,
+    and an in-place torch operation on a parameter between two steps must bring the cast back for the next forward."""
+    from kurosiwo_amd.trainer import MAETrainStep
+    hp = dict(image_size=224, patch_size=16, dim=256, depth=2, heads=4, mlp_dim=512, channels=2, decoder_dim=128, decoder_depth=1,
+              decoder_heads=4)
+    B = 4
+    g = torch.Generator().manual_seed(11)
+    data = [(torch.randn(B, 2, 224, 224, generator=g), torch.rand(B, 196, generator=g).argsort(dim=-1)) for _ in range(4)]
+    out = []
+    for mirror in ("0", "1"):
+        monkeypatch.setenv("KSMI_ADAM_MIRROR", mirror)
+        model, _ = build(hp, "bf16")
+        st = MAETrainStep(model, B, lr=1e-3)
+        losses = []
+        for i, (x, idx) in enumerate(data):
+            if i == 2:                                       # a torch-side edit of the parameters: the mirror the optimiser wrote is stale
+                with torch.no_grad():
+                    model.flat_params.mul_(0.5)
+            losses.append(st.step(x.cuda(), idx.cuda()).clone())
+        torch.cuda.synchronize()
+        if mirror == "1":
+            assert st.plan._mirror_version is not None      # the last optimiser step marked the mirror
+            assert torch.equal(st.plan.wb.view(torch.int16), model.flat_params.to(torch.bfloat16).view(torch.int16))
+        out.append((losses, model.flat_params.clone()))
+    for a, b in zip(out[0][0], out[1][0]):
+        assert torch.equal(a, b)
+    assert torch.equal(out[0][1], out[1][1])
