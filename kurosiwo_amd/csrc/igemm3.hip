@@ -37,7 +37,10 @@ struct Ig3Args {
 };
 
 // DIR: 1 = input-gradient launch (ksmi_conv_desc.dir): a name tag for profilers, no code difference
-template <int KH, int KW, int NCH, int WN, bool AFF, int NTI, bool MASK, int DIR = 0>
+// PART (round 5): partial chunks (klen), N % 8 != 0 and several destinations.  A template parameter, not run-time tests: with the extra
+// live values in the tile loop the instances that hold 72-144 weight registers ran 6-24 % longer on the SNUNet shapes (same-box,
+// single stream) -- the whole-chunk instances compile exactly as before
+template <int KH, int KW, int NCH, int WN, bool AFF, int NTI, bool MASK, int DIR = 0, bool PART = false>
 __global__ __launch_bounds__(256 * WN, (WN == 1 && NCH * KH * KW * NTI <= 9) ? 2 : 1) void igemm3_kernel(const Ig3Args ka) {
   typedef bf16_t T;
   const ksmi_conv_desc& d = ka.d;
@@ -83,7 +86,7 @@ __global__ __launch_bounds__(256 * WN, (WN == 1 && NCH * KH * KW * NTI <= 9) ? 2
     cc0[ch] = chunk_c0_of(d, ch);
     sp[ch] = (const unsigned char*)((const T*)sr.ptr + sr.c_off + cc0[ch]);
     cb[ch] = (uint32_t)sr.C * 2u;
-    krem[ch] = sr.c_len - cc0[ch];
+    krem[ch] = PART ? sr.c_len - cc0[ch] : 32;
     klen[ch] = krem[ch] >= 32 ? 32 : ((krem[ch] + 7) & ~7);
   }
   // ---- weights -> registers: fragment nf, row j = l15 of the MFMA A operand = output channel 8*(j>>2) + 4*nf + (j&3) of the wave's
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(256 * WN, (WN == 1 && NCH * KH * KW * NTI <= 9) ? 2
     if (tid < NCH * 32) {                                           // layout [chunk][k-group q]{scale[8], shift[8]}
       const int ch = tid >> 5, j = tid & 31;
       const ksmi_src& sr = d.src[0];
-      const bool kv = j < krem[ch];                                   // (channels past the source: 0 * x + 0 on zero-page granules)
+      const bool kv = !PART || j < krem[ch];                                   // (channels past the source: 0 * x + 0 on zero-page granules)
       aff_tab[(ch * 4 + (j >> 3)) * 16 + (j & 7)] = kv ? sr.scale[cc0[ch] + j] : 0.f;
       aff_tab[(ch * 4 + (j >> 3)) * 16 + 8 + (j & 7)] = kv ? sr.shift[cc0[ch] + j] : 0.f;
     }
@@ -144,7 +147,7 @@ __global__ __launch_bounds__(256 * WN, (WN == 1 && NCH * KH * KW * NTI <= 9) ? 2
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
           // (two 32-bit selects: a pointer select compiles to two exec-masked DMA instructions)
-          const bool okc = ok && gq * 8 < klen[ch];
+          const bool okc = PART ? (ok && gq * 8 < klen[ch]) : ok;
           const uint64_t av = (uint64_t)(uintptr_t)sp[ch] + (uint64_t)gpix * cb[ch] + (uint64_t)qb;
           const uint64_t zv = (uint64_t)(uintptr_t)ka.zero;
           const uint32_t lo = okc ? (uint32_t)av : (uint32_t)zv, hi = okc ? (uint32_t)(av >> 32) : (uint32_t)(zv >> 32);
@@ -228,11 +231,11 @@ __global__ __launch_bounds__(256 * WN, (WN == 1 && NCH * KH * KW * NTI <= 9) ? 2
     if (d.ps_cout > 0) nn = nc - (nc / d.ps_cout) * d.ps_cout;
 #pragma unroll
     for (int j = 0; j < 8; ++j) biasr[ni][j] = 0.f;
-    if (d.bias && nc + 8 <= d.N) {
+    if (d.bias && (PART ? nc + 8 <= d.N : nc < d.N)) {
       const f32x4 a = *(const f32x4*)(d.bias + nn), c = *(const f32x4*)(d.bias + nn + 4);
 #pragma unroll
       for (int j = 0; j < 4; ++j) { biasr[ni][j] = a[j]; biasr[ni][4 + j] = c[j]; }
-    } else if (d.bias && nc < d.N) {                                // N % 8 != 0 (2- / 3-class heads): the channels past N store zeros
+    } else if (PART && d.bias && nc < d.N) {                        // N % 8 != 0 (2- / 3-class heads): the channels past N store zeros
 #pragma unroll
       for (int j = 0; j < 8; ++j) if (nc + j < d.N) biasr[ni][j] = d.bias[nn + j];
     }
@@ -296,10 +299,12 @@ __global__ __launch_bounds__(256 * WN, (WN == 1 && NCH * KH * KW * NTI <= 9) ? 2
       // destination of this lane's 8-channel group: the virtual concat of an input gradient (several destinations, each a whole
       // number of groups; one destination in every SNUNet launch: the scan is a scalar compare per extra destination)
       int di = 0;
+      if constexpr (PART) {
 #pragma unroll
-      for (int k = 1; k < KSMI_MAX_SRC; ++k) if (k < d.ndst && nc >= d.dst[k].n_begin) di = k;
-      T* const obase = (T*)d.dst[di].ptr + d.dst[di].c_off + (nn - d.dst[di].n_begin);
-      const int dC = d.dst[di].C;
+        for (int k = 1; k < KSMI_MAX_SRC; ++k) if (k < d.ndst && nc >= d.dst[k].n_begin) di = k;
+      }
+      T* const obase = PART ? (T*)d.dst[di].ptr + d.dst[di].c_off + (nn - d.dst[di].n_begin) : (T*)d.dst[0].ptr + d.dst[0].c_off + nn;
+      const int dC = PART ? d.dst[di].C : d.dst[0].C;
       const T* const mbase = (const T*)d.mask_src + nc;
       float mm[MASK ? 8 : 1], mr[MASK ? 8 : 1], mg[MASK ? 8 : 1], mb[MASK ? 8 : 1];
       const float (&bias)[8] = biasr[ni];
@@ -407,6 +412,11 @@ bool ksmi_igemm3_geom(const ksmi_conv_desc* d, int dtype, ksmi_igemm3_geom_t* g)
   if (!partial_on) {
     if ((d->N % 8) || d->Npad < 32 || d->ndst != 1) return false;
     for (int i = 0; i < d->nsrc; ++i) if (d->src[i].c_len % 32) return false;
+  }
+  {   // what needs the PART instances (3 x 3, and 2 x 2 with <= 2 chunks)
+    bool part = d->ndst > 1 || (d->N % 8) != 0;
+    for (int i = 0; i < d->nsrc; ++i) part = part || (d->src[i].c_len % 32) != 0;
+    if (part && !(taps == 9 || (taps == 4 && d->nchunks <= 2))) return false;
   }
   if ((d->dst[0].C % 8) || (d->dst[0].c_off % 8) || d->Npad < 16) return false;
   // N % 8 != 0 (the 2- / 3-class heads, destination with a channel stride of 8): the last 8-channel group is stored whole, its pad
@@ -520,6 +530,34 @@ int ksmi_igemm3_launch(const ksmi_conv_desc* d, const ksmi_igemm3_geom_t* g, hip
   } while (0)
 #define KSMI_G3W(KH_, KW_, NCH_, AFF_, NTI_)                                                         \
   do { if (g->WN == 2) KSMI_G3(KH_, KW_, NCH_, 2, AFF_, NTI_); else KSMI_G3(KH_, KW_, NCH_, 1, AFF_, NTI_); } while (0)
+  // partial chunks / thin heads / several destinations: their own instances (3 x 3 and 2 x 2 only: ksmi_igemm3_geom)
+  bool part = d->ndst > 1 || (d->N % 8) != 0;
+  for (int i = 0; i < d->nsrc; ++i) part = part || (d->src[i].c_len % 32) != 0;
+#define KSMI_G3P(KH_, KW_, NCH_, WN_, AFF_, MASK_)                                                   \
+  do {                                                                                               \
+    auto kfn = igemm3_kernel<KH_, KW_, NCH_, WN_, AFF_, 1, MASK_, 0, true>; KSMI_NOTE(kfn);                          \
+    if (g->lds > 65536) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g->lds); \
+    hipLaunchKernelGGL(kfn, grid, dim3(256 * WN_), g->lds, st, ka);                                  \
+    return ksmi_check_launch("igemm3");                                                              \
+  } while (0)
+  if (part) {
+    if (taps == 9 && d->mask_src) {
+      if (aff) return ksmi_fail(KSMI_E_UNSUPPORTED, "igemm3: fused operand and mask epilogue together");
+      if (d->nchunks == 1) { if (g->WN == 2) KSMI_G3P(3, 3, 1, 2, false, true); else KSMI_G3P(3, 3, 1, 1, false, true); }
+      if (d->nchunks == 2) KSMI_G3P(3, 3, 2, 1, false, true);
+    } else if (taps == 9) {
+      if (d->nchunks == 1) {
+        if (aff) { if (g->WN == 2) KSMI_G3P(3, 3, 1, 2, true, false); else KSMI_G3P(3, 3, 1, 1, true, false); }
+        else { if (g->WN == 2) KSMI_G3P(3, 3, 1, 2, false, false); else KSMI_G3P(3, 3, 1, 1, false, false); }
+      }
+      if (d->nchunks == 2) { if (aff) KSMI_G3P(3, 3, 2, 1, true, false); else KSMI_G3P(3, 3, 2, 1, false, false); }
+    } else if (taps == 4 && !aff) {
+      if (d->nchunks == 1) { if (g->WN == 2) KSMI_G3P(2, 2, 1, 2, false, false); else KSMI_G3P(2, 2, 1, 1, false, false); }
+      if (d->nchunks == 2) { if (g->WN == 2) KSMI_G3P(2, 2, 2, 2, false, false); else KSMI_G3P(2, 2, 2, 1, false, false); }
+    }
+    return ksmi_fail(KSMI_E_UNSUPPORTED, "igemm3: no partial-chunk instance (geometry / launch mismatch)");
+  }
+#undef KSMI_G3P
   if (taps == 9 && d->mask_src) {
     if (aff) return ksmi_fail(KSMI_E_UNSUPPORTED, "igemm3: fused operand and mask epilogue together");
     if (d->nchunks == 1) { if (g->WN == 2) KSMI_G3M(3, 3, 1, 2, false, 1, true); else KSMI_G3M(3, 3, 1, 1, false, 1, true); }

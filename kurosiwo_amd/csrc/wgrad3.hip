@@ -67,7 +67,9 @@ __device__ __forceinline__ int wg_chunk_src(const ksmi_wgrad_desc& d, int ch) {
 // R0, C0 >= 0 (round 5): only the 2 x 2 window of taps (R0 .. R0+1) x (C0 .. C0+1) of the 3 x 3 neighbourhood is computed -- the weight
 // gradient of one 2 x 2 PHASE convolution of ConvTranspose2d(k4, s2, p1) (plan_base._deconv_wgrad: X = a parity sub-image of d out as a
 // strided view, padding p = 0 | 1 per axis <-> window origin 1 - p); slabs hold 4 taps, the reducer scatters through d.tap_off.
-template <int WC, int WN, int NF, bool AFF, bool DEEP, int R0 = -1, int C0 = -1>
+// PART (round 5): partial chunks (klen).  A template parameter: the run-time form cost the whole-chunk SNUNet launches 6-7 % (same box,
+// single stream: 88 -> 93 us, 202 -> 217 us), so those compile exactly as before.
+template <int WC, int WN, int NF, bool AFF, bool DEEP, int R0 = -1, int C0 = -1, bool PART = false>
 __global__ __launch_bounds__(256, 2) void wgrad3_kernel(const Wg3Args ka) {
   typedef bf16_t T;
   const ksmi_wgrad_desc& d = ka.d;
@@ -115,7 +117,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3_kernel(const Wg3Args ka) {
     cc0[c] = wg_chunk_c0(d, chs);
     sp[c] = (const unsigned char*)((const T*)sr.ptr + sr.c_off + cc0[c]);
     cb[c] = (uint32_t)sr.C * 2u;
-    krem[c] = sr.c_len - cc0[c];
+    krem[c] = PART ? sr.c_len - cc0[c] : 32;
     klen[c] = krem[c] >= 32 ? 32 : ((krem[c] + 7) & ~7);
   }
   const unsigned char* const dyp = (const unsigned char*)((const T*)d.dy + d.dy_c_off);
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3_kernel(const Wg3Args ka) {
     if (tid < CPT * 32) {
       const int c = tid >> 5, j = tid & 31;
       const ksmi_src& sr = d.src[0];
-      const bool ok = cvalid[c] && j < krem[c];
+      const bool ok = cvalid[c] && (!PART || j < krem[c]);
       aff_tab[tid * 2 + 0] = ok ? sr.scale[cc0[c] + j] : 0.f;
       aff_tab[tid * 2 + 1] = ok ? sr.shift[cc0[c] + j] : 0.f;
     }
@@ -198,15 +200,16 @@ __global__ __launch_bounds__(256, 2) void wgrad3_kernel(const Wg3Args ka) {
       const bool inr = v < ka.HPv * 4;
       const bool ok = inr && (unsigned)iy < (unsigned)d.Hin && (unsigned)ix < (unsigned)d.Win;
       const int f = ((hx >> 3) ^ (hy & ka.hymask)) & 1;
-      const uint32_t pix = d.in_sy == 0 ? (uint32_t)((b * d.Hin + iy) * d.Win + ix)
-                                        : (uint32_t)((b * d.in_H + (iy * d.in_sy + d.in_oy)) * d.in_W + (ix * d.in_sx + d.in_ox));   // (strided view: the phase gradients)
+      // (strided view: the phase gradients only -- compile-time, the dense 3 x 3 instances keep the round-4 address arithmetic)
+      const uint32_t pix = (!SUB || d.in_sy == 0) ? (uint32_t)((b * d.Hin + iy) * d.Win + ix)
+                                                  : (uint32_t)((b * d.in_H + (iy * d.in_sy + d.in_oy)) * d.in_W + (ix * d.in_sx + d.in_ox));
       const int sgr = s ^ (f << 1);                                    // source granule of this slot
       const uint32_t slb = (uint32_t)(sgr * 16);
       if (it * 256 + wave * 64 < ka.HPv * 4) {                       // wave-uniform: this wave has halo slots in this iteration
 #pragma unroll
         for (int c = 0; c < CPT; ++c) {
           if (!cvalid[c]) continue;
-          const bool okc = ok && sgr * 8 < klen[c];
+          const bool okc = PART ? (ok && sgr * 8 < klen[c]) : ok;
           const uint64_t av = (uint64_t)(uintptr_t)sp[c] + (uint64_t)(pix * cb[c] + slb);
           const uint32_t lo = okc ? (uint32_t)av : zlo, hi = okc ? (uint32_t)(av >> 32) : zhi;
           if (inr) glds16_flat((const unsigned char*)(uintptr_t)(((uint64_t)hi << 32) | lo),
@@ -544,6 +547,25 @@ int ksmi_wgrad3_launch(const ksmi_wgrad_desc* d, const ksmi_wgrad3_geom_t* g, hi
     if (aff || g->WC != 4 || g->NTL != 64) return ksmi_fail(KSMI_E_UNSUPPORTED, "wgrad3: no 2 x 2 instance");
     if (g->r0 == 0 && g->c0 == 0) KSMI_W3K(0, 0); else if (g->r0 == 0) KSMI_W3K(0, 1); else if (g->c0 == 0) KSMI_W3K(1, 0); else KSMI_W3K(1, 1);
 #undef KSMI_W3K
+    return ksmi_check_launch("wgrad3");
+  }
+  bool part = false;
+  for (int i = 0; i < d->nsrc; ++i) part = part || (d->src[i].c_len % 32) != 0;
+  if (part) {                                                       // partial chunks: their own instances (fragment requests ahead: on)
+#define KSMI_W3P(WC_, WN_, NF_)                                                                      \
+  do {                                                                                               \
+    if (aff) { auto kfn = wgrad3_kernel<WC_, WN_, NF_, true, true, -1, -1, true>; KSMI_NOTE(kfn);    \
+      if (g->lds > 65536) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g->lds); \
+      hipLaunchKernelGGL(kfn, grid, dim3(256), g->lds, st, ka); }                                    \
+    else { auto kfn = wgrad3_kernel<WC_, WN_, NF_, false, true, -1, -1, true>; KSMI_NOTE(kfn);       \
+      if (g->lds > 65536) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g->lds); \
+      hipLaunchKernelGGL(kfn, grid, dim3(256), g->lds, st, ka); }                                    \
+  } while (0)
+    if (g->WC == 4 && g->NTL == 64) KSMI_W3P(4, 1, 4);
+    else if (g->WC == 4) KSMI_W3P(4, 1, 2);
+    else if (g->NTL == 64) KSMI_W3P(2, 2, 2);
+    else KSMI_W3P(2, 2, 1);
+#undef KSMI_W3P
     return ksmi_check_launch("wgrad3");
   }
   if (g->WC == 4 && g->NTL == 64) KSMI_W3(4, 1, 4);
