@@ -213,6 +213,61 @@ def test_launch_list_orders_side_stream_gradients_behind_tagged_waits(monkeypatc
     assert [(k, x) for k, x, _ in log] == [("a", 1), ("w", 2), ("a", 3), ("w", 4)] and all(st != "SIDE" for _, _, st in log)
 
 
+def test_mirror_freshness_and_skip_if_without_a_gpu(monkeypatch):
+    """The bf16 operand copy of the parameters (plan_base.wb): the optimiser that wrote it marks it with the version counter of the
+    fp32 arena; the cast launch of the NEXT forward is skipped iff no in-place torch operation touched a parameter since, and the mark
+    is consumed by that one forward.  LaunchList honours meta["skip_if"].  conv_npad: 32 padded columns for the thin heads."""
+    import torch
+    from kurosiwo_amd import plan_base as pb, snunet_plan as sp
+    from kurosiwo_amd.runtime import conv_npad
+    assert [conv_npad(n) for n in (1, 2, 3, 15, 16, 17, 32, 48, 100)] == [32, 32, 32, 32, 16, 32, 32, 48, 112]
+
+    class M:
+        flat_params = torch.zeros(64)
+
+    class P(pb.PlanBase):
+        def __init__(self):
+            self.m, self.wb = M(), torch.zeros(64, dtype=torch.bfloat16)
+            self._mirror_version = None
+
+    p = P()
+    assert p._mirror_is_fresh() is False                         # nobody wrote the mirror: cast
+    p.mirror_written()
+    assert p._mirror_is_fresh() is True and p._mirror_is_fresh() is False      # consumed by one forward
+    p.mirror_written()
+    view = p.m.flat_params[8:16]
+    with torch.no_grad():
+        view.mul_(2.0)                                           # load_state_dict / init: an in-place op on a view of the arena
+    assert p._mirror_is_fresh() is False
+    monkeypatch.setenv("KSMI_ADAM_MIRROR", "0")
+    assert p.mirror_ptr() is None
+    monkeypatch.delenv("KSMI_ADAM_MIRROR")
+    assert p.mirror_ptr() == p.wb.data_ptr()
+    p._mirror_off = True                                         # (graph capture: the replay cannot re-decide)
+    assert p.mirror_ptr() is None
+
+    monkeypatch.setattr(sp, "stream_ptr", lambda: "MAIN")
+    log, fresh = [], [False]
+
+    class Lib:
+        def ksmi_cast(self, st):
+            log.append("cast")
+            return 0
+
+        def ksmi_fwd(self, st):
+            log.append("fwd")
+            return 0
+
+    ll = sp.LaunchList()
+    ll.add("ksmi_cast", lambda: (), {"kind": "cast_bf16", "bytes": 0, "flops": 0, "skip_if": lambda: fresh[0]})
+    ll.add("ksmi_fwd", lambda: ())
+    ll.resolve(Lib())
+    ll.run()
+    fresh[0] = True
+    ll.run()
+    assert log == ["cast", "fwd", "fwd"]
+
+
 def test_bf16_storage_emulation_contract(golden_dir):
     """oracle/bf16_storage.py (test infrastructure behind tests/golden/snunet_parity_draws_ref.npz and snunet_dem_shard_bf16emu.npz):
     stored tensors and the gradients arriving at them are bf16 values, convolution weights are bf16 operands with an fp32 master
