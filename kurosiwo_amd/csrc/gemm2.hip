@@ -332,6 +332,8 @@ struct Gemm2T {
   const unsigned char* zero;
   float* bias; int bias_acc;           // direct mode: bias[b column] (+)= sum over the rows of B (the nn.Linear bias gradient)
   int map_a, up_H, up_W, up_C;         // A-side rows are the depth rows of a ConvTranspose2d(k2, s2) output gradient (Gemm2P.map_a)
+  float* bias_rows; int64_t bias_rs;   // slab mode (BIASA): bias_rows[split][a column] = sum over the split's rows of A (= dY): the partial
+                                       // column sums of the nn.Linear bias gradient, summed over the splits by the caller
 };
 __device__ __attribute__((aligned(64))) unsigned char gemm2_zero_page[64];
 KSMI_DEVICE_SYMBOL_GETTER(gemm2_zero, gemm2_zero_page)
@@ -340,8 +342,13 @@ KSMI_DEVICE_SYMBOL_GETTER(gemm2_zero, gemm2_zero_page)
 // range; group 1 hands its accumulators to group 0 through LDS at the end (fixed order: deterministic).  A workgroup that is alone on
 // its CU (<= 256 tiles) is a lock-step of DMA wait -> barrier -> fragment reads -> MFMA; the second group doubles the waves per SIMD
 // and halves the serial K loop without partial slabs in memory and without a reducer launch.
-template <int MT, int NS, int SPL>
+// BIASA (round 5): slab mode also emits the column sums of the A side (dY) -- the bias gradient of the layer -- per split: one MFMA per
+// A fragment against an all-ones B fragment in the workgroups of B tile 0 (waves of B-side group 0), instead of a channel_sum pass that
+// re-reads dY from HBM (ChangeFormer: 40 launches, ~0.5 ms per step).  A template parameter: the direct-mode instances of the ViT step
+// compile as before.
+template <int MT, int NS, int SPL, bool BIASA = false>
 __global__ __launch_bounds__(256 * SPL, 1) void gemm2_tn_kernel(const Gemm2T p) {
+  static_assert(!BIASA || SPL == 1, "A-side column sums: one wave group");
   constexpr int TB = 32 * MT, KS = 64, AB = 64 * 256, BROW = TB * 2, BB = 64 * BROW, STAGE = AB + BB;
   constexpr int NQ = STAGE / 1024, NI = NQ / 4, BGM = BROW / 32 - 1, AU = 16, BU = BROW / 16;
   static_assert(NQ % 4 == 0, "whole DMA rounds");
@@ -434,7 +441,11 @@ __global__ __launch_bounds__(256 * SPL, 1) void gemm2_tn_kernel(const Gemm2T p) 
 #pragma unroll
   for (int b = 0; b < MT; ++b) { accb[b] = (f32x4){0.f, 0.f, 0.f, 0.f}; accb2[b] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
   const u32x4 ones = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
-  auto mma_all = [&](f32x4 (&ac)[4][MT], f32x4 (&ab)[MT], const u32x4 (&fa)[4], const u32x4 (&fb)[MT]) {
+  const bool do_biasA = BIASA && p.bias_rows != nullptr && bt == 0 && wm == 0;
+  f32x4 accA[BIASA ? 4 : 1], accA2[BIASA ? 4 : 1];
+#pragma unroll
+  for (int a = 0; a < (BIASA ? 4 : 1); ++a) { accA[a] = (f32x4){0.f, 0.f, 0.f, 0.f}; accA2[a] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  auto mma_all = [&](f32x4 (&ac)[4][MT], f32x4 (&ab)[MT], f32x4 (&aa)[BIASA ? 4 : 1], const u32x4 (&fa)[4], const u32x4 (&fb)[MT]) {
 #pragma unroll
     for (int b = 0; b < MT; ++b)
 #pragma unroll
@@ -442,6 +453,12 @@ __global__ __launch_bounds__(256 * SPL, 1) void gemm2_tn_kernel(const Gemm2T p) 
     if (do_bias) {
 #pragma unroll
       for (int b = 0; b < MT; ++b) mma16<bf16_t>(ab[b], ones, fb[b]);
+    }
+    if constexpr (BIASA) {
+      if (do_biasA) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) mma16<bf16_t>(aa[a], fa[a], ones);         // D[i][j] = sum_k A[i][k]: the same in every column j
+      }
     }
   };
   if (nsteps > 0) {
@@ -457,7 +474,7 @@ __global__ __launch_bounds__(256 * SPL, 1) void gemm2_tn_kernel(const Gemm2T p) 
       __builtin_amdgcn_sched_barrier(0);
       load_frags(cur, 1, faB, fbB);
       __builtin_amdgcn_sched_barrier(0);
-      mma_all(acc, accb, faA, fbA);
+      mma_all(acc, accb, accA, faA, fbA);
       __builtin_amdgcn_sched_barrier(0);
       if (s + NS <= nsteps) vm_wait((NS - 2) * NI); else vm_wait((nsteps - s - 2) * NI);
       lds_barrier();
@@ -465,12 +482,12 @@ __global__ __launch_bounds__(256 * SPL, 1) void gemm2_tn_kernel(const Gemm2T p) 
       cur = cur + 1 == NS ? 0 : cur + 1;
       load_frags(cur, 0, faA, fbA);
       __builtin_amdgcn_sched_barrier(0);
-      mma_all(acc2, accb2, faB, fbB);
+      mma_all(acc2, accb2, accA2, faB, fbB);
       __builtin_amdgcn_sched_barrier(0);
     }
     load_frags(cur, 1, faB, fbB);
-    mma_all(acc, accb, faA, fbA);
-    mma_all(acc2, accb2, faB, fbB);
+    mma_all(acc, accb, accA, faA, fbA);
+    mma_all(acc2, accb2, accA2, faB, fbB);
   }
   if constexpr (SPL == 2) {
     // group 1 -> group 0: [(a * MT + b)][wave * 64 + lane] float4 (+ the bias rows behind them), in the ring memory
@@ -493,6 +510,21 @@ __global__ __launch_bounds__(256 * SPL, 1) void gemm2_tn_kernel(const Gemm2T p) 
       for (int b = 0; b < MT; ++b) { acc[a][b] = (acc[a][b] + acc2[a][b]) + xch[(a * MT + b) * 256 + slot]; acc2[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
     for (int b = 0; b < MT; ++b) { accb[b] = (accb[b] + accb2[b]) + xch[(4 * MT + b) * 256 + slot]; accb2[b] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  }
+  if constexpr (BIASA) {
+    // lane (g, l15 = 0): rows g*4 + r of fragment a <-> A-side columns a0 + wn*64 + g*16 + a*4 + r: 16 consecutive floats
+    if (do_biasA && l15 == 0) {
+      float* br = p.bias_rows + (int64_t)split * p.bias_rs;
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const f32x4 v = accA[a] + accA2[a];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = a0 + wn * 64 + g * 16 + a * 4 + r;
+          if (c < p.a_cols) br[c] = v[r];
+        }
+      }
+    }
   }
   if (do_bias && g == 0) {                                // every accumulator row holds the column sum: take row 0 (g = 0, r = 0)
 #pragma unroll
@@ -557,12 +589,12 @@ int ksmi_gemm2_up_dgrad(const void* dy, const void* wb, void* dx, int accumulate
   return dispatch2<true>(p, st);
 }
 
-template <int MT, int NS, int SPL = 1>
+template <int MT, int NS, int SPL = 1, bool BIASA = false>
 static void launch_tn(dim3 grid, const Gemm2T& p, hipStream_t st) {
   constexpr int lds = SPL * NS * (64 * 256 + 64 * 64 * MT);
   static_assert(lds <= 160 * 1024, "LDS ring");
   static_assert(SPL == 1 || (4 * MT + MT) * 256 * 16 <= lds, "exchange area");
-  auto kfn = gemm2_tn_kernel<MT, NS, SPL>; KSMI_NOTE(kfn);
+  auto kfn = gemm2_tn_kernel<MT, NS, SPL, BIASA>; KSMI_NOTE(kfn);
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
   hipLaunchKernelGGL(kfn, grid, dim3(256 * SPL), lds, st, p);
@@ -601,14 +633,22 @@ int ksmi_gemm2_tn(const void* x, int x_rs, const void* dy, int dy_rs, float* sla
   } else {                          // slabs: A = dy (n contiguous in the slab), B = x
     p.a = (const bf16_t*)dy; p.a_rs = dy_rs; p.a_cols = N; p.b = (const bf16_t*)x; p.b_rs = x_rs; p.b_cols = K;
     p.out = slab; p.o_rs = npad; p.split_stride = (int64_t)Kslab * npad; p.accumulate = 0;
+    p.bias_rows = bias_grad; p.bias_rs = N;      // (slab mode: partial column sums of dY per split, [nsplit][N]: ksmi_conv_wgrad_fuses_bias == 2)
   }
   p.atiles = (p.a_cols + 127) / 128; p.btiles = (p.b_cols + btile - 1) / btile;
   static const int ns = getenv("KSMI_TN_NS") ? atoi(getenv("KSMI_TN_NS")) : 3;      // probes: ring depth of the weight-gradient kernel
   const dim3 grid(p.atiles * p.btiles, nsplit);
-  if (ns <= 3 && ksmi_gemm2_tn_spl((int)(grid.x * grid.y), (rows_per_split + 63) / 64)) {
+  if (!p.bias_rows && ns <= 3 && ksmi_gemm2_tn_spl((int)(grid.x * grid.y), (rows_per_split + 63) / 64)) {
     if (btile == 128) launch_tn<4, 2, 2>(grid, p, st);
     else if (btile == 96) launch_tn<3, 2, 2>(grid, p, st);
     else if (btile == 64) launch_tn<2, 3, 2>(grid, p, st);
+    else return ksmi_fail(KSMI_E_ARG, "gemm2_tn: B-side tile must be 64, 96 or 128");
+    return ksmi_check_launch("gemm2_tn");
+  }
+  if (p.bias_rows) {                // A-side column sums: the three-stage one-group instances
+    if (btile == 128) launch_tn<4, 3, 1, true>(grid, p, st);
+    else if (btile == 96) launch_tn<3, 3, 1, true>(grid, p, st);
+    else if (btile == 64) launch_tn<2, 3, 1, true>(grid, p, st);
     else return ksmi_fail(KSMI_E_ARG, "gemm2_tn: B-side tile must be 64, 96 or 128");
     return ksmi_check_launch("gemm2_tn");
   }

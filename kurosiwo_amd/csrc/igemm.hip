@@ -834,6 +834,12 @@ WgradGeom wgrad_geom(const ksmi_wgrad_desc* d) {
   return g;
 }
 
+// KSMI_SLAB_BIAS=0: the split-mode token weight gradient leaves the bias gradient to a channel_sum pass (the round-4 route; same-box A/B)
+static bool wgrad_slab_bias_on() {
+  static const bool on = getenv("KSMI_SLAB_BIAS") ? atoi(getenv("KSMI_SLAB_BIAS")) != 0 : true;
+  return on;
+}
+
 template <typename T>
 int launch_wgrad(const ksmi_wgrad_desc* d, hipStream_t st) {
   WgradGeom g = wgrad_geom<T>(d);
@@ -852,9 +858,11 @@ int launch_wgrad(const ksmi_wgrad_desc* d, hipStream_t st) {
     {
       const int rows = d->B * d->Hout * d->Wout;
       const bool direct = plain && g.nsplit == 1;
+      // bias_grad: the final gradient in direct mode; in slab mode (plain layers only) the partial column sums of dY per split,
+      // [nsplit][N] (ksmi_conv_wgrad_fuses_bias == 2: the caller sums the rows)
       const int r2 = ksmi_gemm2_tn((const bf16_t*)d->src[0].ptr + d->src[0].c_off, d->src[0].C, (const bf16_t*)d->dy + d->dy_c_off, d->dyC, d->partial,
                                    g.npad, direct ? d->grad : nullptr, d->gN, rows, d->src[0].c_len, d->N, d->nchunks * g.kc, g.nsplit, g.rps,
-                                   g.tbt, d->accumulate, direct ? d->bias_grad : nullptr, d->bias_accumulate, st);
+                                   g.tbt, d->accumulate, (direct || (plain && wgrad_slab_bias_on())) ? d->bias_grad : nullptr, d->bias_accumulate, st);
       if (r2 < 0) return r2;
       if (r2 == 0) {
         if (direct) return 0;
@@ -1026,16 +1034,20 @@ size_t ksmi_conv_wgrad_workspace(const ksmi_wgrad_desc* d, int dtype) {
 }
 
 // 1: ksmi_conv_wgrad(d) also writes d->bias_grad (the token-GEMM path of gemm2.hip in its one-split, direct-write mode)
+// 2 (round 5): the split (slab) mode of the same path writes the PARTIAL column sums of dY, one row per split, to d->bias_grad
+//    [d->nsplit][d->N] floats (overwritten, not accumulated); the caller sums the rows into the bias gradient
 int ksmi_conv_wgrad_fuses_bias(const ksmi_wgrad_desc* d, int dtype) {
   if (!d || dtype != KSMI_BF16 || d->nsrc != 1) return 0;
   static const bool off = getenv("KSMI_NO_FUSED_BIAS_GRAD") != nullptr;
   if (off) return 0;
   WgradGeom g = wgrad_geom<bf16_t>(d);
-  if (!g.tn || g.v3 || g.nsplit != 1) return 0;
+  if (!g.tn || g.v3) return 0;
   bool plain = d->gK == 1 && (!d->use_tap_off || d->tap_off[0] == 0) && d->gN >= d->src[0].c_len && d->gN < ((int64_t)1 << 31);
   if (plain && !d->uniform_kc)
     for (int i = 0; i < d->nchunks; ++i) plain = plain && d->k_off[i] == i * g.kc;
-  return plain && ksmi_gemm2_tn_enabled(d->src[0].c_len, d->N, g.rps) ? 1 : 0;
+  if (!(plain && ksmi_gemm2_tn_enabled(d->src[0].c_len, d->N, g.rps))) return 0;
+  if (g.nsplit == 1) return 1;
+  return wgrad_slab_bias_on() && (g.tbt == 64 || g.tbt == 96 || g.tbt == 128) ? 2 : 0;
 }
 
 int ksmi_conv_wgrad(const ksmi_wgrad_desc* d, int dtype, void* stream) {

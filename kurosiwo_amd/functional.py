@@ -165,8 +165,9 @@ def linear_dgrad(dy, weight, out=None, accumulate=0):
     return out
 
 
-def linear_wgrad(x, dy):
-    """dW[N, Cin] = dy^T @ x (fp32)."""
+def linear_wgrad(x, dy, with_bias=False):
+    """dW[N, Cin] = dy^T @ x (fp32).  with_bias: also returns (db[N] or None, mode): the bias gradient when the weight-gradient launch
+    computes it (ksmi_conv_wgrad_fuses_bias: 1 = written by the launch, 2 = one partial row per split, summed here), else None."""
     dtype = x.dtype
     rows, Cin = x.shape
     N = dy.shape[1]
@@ -174,8 +175,19 @@ def linear_wgrad(x, dy):
     d, ws = make_wgrad([SrcSpec(x, Cin)], dy, N, 0, N, grad, 1, Cin, 0, 0, 1, rows, 1, rows, 1, 1, 1, 1, 0, dtype)
     wsb = torch.empty(max(ws, 16), dtype=torch.uint8, device=x.device)
     d.partial = wsb.data_ptr()
-    _lib.check(_lib.load().ksmi_conv_wgrad(C.byref(d), DT[dtype], stream_ptr()), "linear_wgrad")
-    return grad
+    lib = _lib.load()
+    mode, bias_buf = 0, None
+    if with_bias:
+        bias_buf = torch.full((max(d.nsplit, 1), N), float("nan"), dtype=torch.float32, device=x.device)
+        d.bias_grad = bias_buf.data_ptr()
+        mode = int(lib.ksmi_conv_wgrad_fuses_bias(C.byref(d), DT[dtype]))
+        if mode == 0:
+            d.bias_grad = None
+    _lib.check(lib.ksmi_conv_wgrad(C.byref(d), DT[dtype], stream_ptr()), "linear_wgrad")
+    if not with_bias:
+        return grad
+    db = None if mode == 0 else (bias_buf[0].clone() if mode == 1 else bias_buf[:d.nsplit].sum(0))
+    return grad, db, mode
 
 
 def layernorm(x, gamma, beta, eps=1e-5):

@@ -274,17 +274,27 @@ class PlanBase:
         kr = Cin if k_real is None else k_real
         dw, ws = make_wgrad([SrcSpec(x, Cin, k_real=kr)], dy, N, 0, N, self.m._g(wkey), 1, kr, 0, self._acc_param(wkey),
                             1, rows, 1, rows, 1, 1, 1, 1, 0, self.dtype)
-        fused = False
-        if bkey:       # the bias gradient rides on the weight-gradient GEMM when that launch holds dY in LDS anyway (gemm2.hip, direct mode)
+        fused = 0
+        if bkey:       # the bias gradient rides on the weight-gradient GEMM when that launch holds dY in LDS anyway (gemm2.hip): 1 = direct
+                       # mode writes it; 2 = split mode writes one partial row per split, summed by the next batched row reduction
             dw.bias_grad = self.m._g(bkey).data_ptr()
-            fused = bool(self.lib.ksmi_conv_wgrad_fuses_bias(C.byref(dw), self.dt))
-            if fused:
+            fused = int(self.lib.ksmi_conv_wgrad_fuses_bias(C.byref(dw), self.dt))
+            if fused == 2 and (side_tag is not None or self.side_wgrad):      # (the deferred row sums need their producer on the issuing stream)
+                fused = 0
+            if fused == 1:
                 dw.bias_accumulate = self._acc_param(bkey)
+            elif fused == 2:
+                slot = self._rs_slot(dw.nsplit * N * 4)
+                dw.bias_grad = None
+                self._later.append(lambda: setattr(dw, "bias_grad", self.scr(slot)))
             else:
                 dw.bias_grad = None
         self._wgrad(dw, ws, wkey, side_tag)
-        if bkey and fused:
+        if bkey and fused == 1:
             self._mark(bkey)
+        elif bkey and fused == 2:
+            self._defer_rowsum(bkey, slot, 0, dw.nsplit, 1, 0, N, N)
+            self._rs_tick()
         elif bkey:
             self._bias_grad(dy, rows, N, bkey)
 

@@ -306,3 +306,21 @@ def test_mae_token_shuffles_colsum_mse(dev, dtype):
     d = pred.float() - tgt.float()
     assert abs(float(loss) - float((d * d).mean())) < 1e-5 * float((d * d).mean()) + 1e-7
     assert torch.allclose(dpred.float(), (2 * d * 0.25 / d.numel()).to(dtype).float(), rtol=1e-2, atol=1e-8)
+
+
+@pytest.mark.parametrize("rows,K,N", [(200704, 64, 64), (50176, 128, 512), (12544, 320, 320), (50176, 512, 128), (20000, 256, 64)])
+def test_linear_wgrad_split_mode_emits_bias_rows(dev, rows, K, N):
+    """Round 5: the split (slab) mode of the token weight gradient also writes the partial column sums of d out, one row per split
+    (ksmi_conv_wgrad_fuses_bias == 2; gemm2_tn_kernel<.., BIASA>): the ChangeFormer linears with 12 k - 200 k rows get their bias
+    gradient without a channel_sum pass over d out."""
+    from kurosiwo_amd import functional as Fk
+    g = torch.Generator().manual_seed(rows + K + N)
+    x = (torch.randn(rows, K, generator=g) * 0.5).to(dev).to(torch.bfloat16)
+    dy = (torch.randn(rows, N, generator=g) * 0.5 + 0.05).to(dev).to(torch.bfloat16)
+    dw, db, mode = Fk.linear_wgrad(x, dy, with_bias=True)
+    assert mode == 2, mode
+    ref_w = dy.float().t() @ x.float()
+    ref_b = dy.float().sum(0)
+    assert (dw - ref_w).abs().max() < 2e-3 * ref_w.abs().max()
+    assert torch.isfinite(db).all()
+    assert (db - ref_b).abs().max() < 2e-3 * max(1.0, float(ref_b.abs().max()))
