@@ -130,17 +130,20 @@ class PlanBase:
         self.need(name, nbytes)
         return name
 
-    def _defer_rowsum(self, key, slot, off, rows, K, k, Cstride, Cc):
+    def _defer_rowsum(self, key, slot, off, rows, K, k, Cstride, Cc, side_ok=False):
         """grad[key][c] (+)= sum_r partial[(r*K + k)*Cstride + c], partial = scratch `slot` + off bytes (written by the launch just
         appended to self.bwd), in the next batched reduction.  Entries of one key inside a batch chain behind the first."""
         # the recycled slots and the batched reducer rely on list order on ONE stream: a producer handed to the side stream would race
         # the slot's next owner and the reducer (ADVICE round 4)
-        if self.bwd.pending and self.bwd.pending[-1][2].get("side"):
+        # -- unless the caller says so (side_ok: the split-mode token weight gradient that also writes the bias rows): the batched reducer
+        # of this batch then waits for the whole side stream first, and the slot's next owner is issued behind that reducer either way
+        side = bool(self.bwd.pending and self.bwd.pending[-1][2].get("side"))
+        if side and not side_ok:
             raise AssertionError(f"deferred row sum of {key}: its producer launch is side-stream tagged")
         acc = self._acc_param(key, deferred=True)
         prev = [i for i, e in enumerate(self._rs_entries) if e["key"] == key]
         self._rs_entries.append(dict(key=key, slot=slot, off=off, rows=rows, K=K, k=k, Cstride=Cstride, C=Cc,
-                                     accumulate=0 if prev else acc, head=0 if prev else 1, next=-1))
+                                     accumulate=0 if prev else acc, head=0 if prev else 1, next=-1, side=side))
         if prev:
             self._rs_entries[prev[-1]]["next"] = len(self._rs_entries) - 1
 
@@ -166,6 +169,8 @@ class PlanBase:
             self.keep.append(holder["t"])
         self._later.append(build)
         nbytes = sum(e["rows"] * e["C"] * 4 for e in ents)
+        if any(e.get("side") for e in ents):
+            self.bwd.add_wait_side(None)         # partial rows written on the side stream (split-mode weight gradients with bias rows)
         self.bwd.add("ksmi_reduce_rows_batched_wide", lambda: (holder["t"].data_ptr(), n, max_c),
                      {"kind": "reduce_rows", "bytes": nbytes, "flops": 0})
         self._mark(*[e["key"] for e in ents])
@@ -279,8 +284,8 @@ class PlanBase:
                        # mode writes it; 2 = split mode writes one partial row per split, summed by the next batched row reduction
             dw.bias_grad = self.m._g(bkey).data_ptr()
             fused = int(self.lib.ksmi_conv_wgrad_fuses_bias(C.byref(dw), self.dt))
-            if fused == 2 and (side_tag is not None or self.side_wgrad):      # (the deferred row sums need their producer on the issuing stream)
-                fused = 0
+            if fused == 2 and os.environ.get("KSMI_SLAB_BIAS_SIDE", "1") == "0" and (side_tag is not None or self.side_wgrad):
+                fused = 0                                     # (A/B switch: only producers on the issuing stream, the first form of this route)
             if fused == 1:
                 dw.bias_accumulate = self._acc_param(bkey)
             elif fused == 2:
@@ -293,7 +298,7 @@ class PlanBase:
         if bkey and fused == 1:
             self._mark(bkey)
         elif bkey and fused == 2:
-            self._defer_rowsum(bkey, slot, 0, dw.nsplit, 1, 0, N, N)
+            self._defer_rowsum(bkey, slot, 0, dw.nsplit, 1, 0, N, N, side_ok=True)
             self._rs_tick()
         elif bkey:
             self._bias_grad(dy, rows, N, bkey)
