@@ -100,6 +100,14 @@ class UnetPlan(ChangeFormerPlan):
         dt = self.dt
         self.bwd.add("ksmi_bnrelu_bwd_reduce", lambda: (dout.data_ptr(), out.data_ptr(), z.data_ptr(), sv.mean, sv.rstd, self.scr("bnp"), rows, npix, Cc, dt),
                      self._elt_meta("bnrelu_bwd_reduce", 3 * npix * Cc))
+        # the partial rows finish inside the apply pass (bnfused.hip, as in the SNUNet plan since round 4): one launch less per BatchNorm;
+        # KSMI_BN_FUSED_FAMILIES=0 keeps the separate reduce_rows launch (A/B)
+        if os.environ.get("KSMI_BN_FUSED_FAMILIES", "1") != "0" and self.lib.ksmi_bn_fused_supported(Cc, Cc, dt):
+            self.bwd.add("ksmi_bnrelu_bwd_fin_apply", lambda: (self.scr("bnp"), rows, Cc, self.scr("bnsum"), gw, gb, a1, dout.data_ptr(), out.data_ptr(),
+                                                               z.data_ptr(), sv.mean, sv.rstd, gamma, dz.data_ptr(), float(npix), npix, Cc, dt),
+                         self._elt_meta("bnrelu_bwd_apply", 5 * npix * Cc))
+            self._mark(f"{bnkey}.weight", f"{bnkey}.bias")
+            return
         self.bwd.add("ksmi_reduce_rows", lambda: (self.scr("bnp"), rows, 2, Cc, Cc, self.scr("bnsum"), gw, gb, a1))
         self._mark(f"{bnkey}.weight", f"{bnkey}.bias")
         self.bwd.add("ksmi_bnrelu_bwd_apply", lambda: (dout.data_ptr(), out.data_ptr(), z.data_ptr(), sv.mean, sv.rstd, gamma, self.scr("bnsum"), dz.data_ptr(),
@@ -142,8 +150,14 @@ class UnetPlan(ChangeFormerPlan):
         a1 = [SrcSpec(i1, Cout, scale=sv1.scale_t, shift=sv1.shift_t, relu=1)]
         rows, cpad = self._cv(self.fwd, f"{k}.conv2", a1, [(z2, Cout, 0, 0, Cout, 0)], f"{k}.conv2.weight", Ho, Wo, Ho, Wo, 3, 1, 1, Cout, Cout,
                               stats=self.training)
-        self._bn_finalize(f"{k}.bn2", sv2, rows, cpad, Cout, npix)
+        rows2, cpad2 = rows, cpad
+        # bn2: its statistics finish inside the apply pass below when that is available (bnfused.hip: one launch instead of two; the
+        # downsample branch in between writes other rows of the shared statistics scratch, so it needs its own finalize first)
         down = f"{k}.downsample.0.weight" in self.m._pspec
+        fuse2 = (self.training and not down and os.environ.get("KSMI_BN_FUSED_FAMILIES", "1") != "0"
+                 and bool(self.lib.ksmi_bn_fused_supported(Cout, cpad2, dt)))
+        if not fuse2:
+            self._bn_finalize(f"{k}.bn2", sv2, rows, cpad, Cout, npix)
         if down:
             ds, idn = self.buf(B, Ho, Wo, Cout), self.buf(B, Ho, Wo, Cout)
             svd = _Saved(Cout, self.dev)
@@ -153,8 +167,18 @@ class UnetPlan(ChangeFormerPlan):
             self._affine(self.fwd, ds, svd, idn, npix, Cout, 0)
         else:
             idn = x_in
-        self.fwd.add("ksmi_bn_add_relu", lambda: (z2.data_ptr(), idn.data_ptr(), sv2.scale, sv2.shift, out.data_ptr(), npix, Cout, dt),
-                     self._elt_meta("bn_add_relu", 3 * npix * Cout))
+        if fuse2:
+            m = self.m
+            kb = f"{k}.bn2"
+            g2, b2 = m._p(f"{kb}.weight").data_ptr(), m._p(f"{kb}.bias").data_ptr()
+            rm, rv, nbt = m._b(f"{kb}.running_mean").data_ptr(), m._b(f"{kb}.running_var").data_ptr(), m._c(f"{kb}.num_batches_tracked").data_ptr()
+            st = self._stats_ptr()
+            self.fwd.add("ksmi_bn_fin_add_relu", lambda: (st(), rows2, cpad2, Cout, float(npix), g2, b2, rm, rv, nbt, BN_MOMENTUM, BN_EPS,
+                                                          sv2.mean, sv2.rstd, sv2.scale, sv2.shift, z2.data_ptr(), idn.data_ptr(), out.data_ptr(),
+                                                          None, B, Ho, Wo, dt), self._elt_meta("bn_add_relu", 3 * npix * Cout))
+        else:
+            self.fwd.add("ksmi_bn_add_relu", lambda: (z2.data_ptr(), idn.data_ptr(), sv2.scale, sv2.shift, out.data_ptr(), npix, Cout, dt),
+                         self._elt_meta("bn_add_relu", 3 * npix * Cout))
 
         def bwd():
             dout = self.gbuf(out)
