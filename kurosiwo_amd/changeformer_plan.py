@@ -123,6 +123,14 @@ class ChangeFormerPlan(PlanBase):
         gw, gb = self.m._g(f"{key}.weight").data_ptr(), self.m._g(f"{key}.bias").data_ptr()
         a1, a2 = self._acc_param(f"{key}.weight"), self._acc_param(f"{key}.bias")
         gamma = self.m._p(f"{key}.weight").data_ptr()
+        # the partial rows finish inside the apply pass where the gradient arrives already masked (bnfused.hip MODE 0, as the SNUNet plan
+        # since round 4): one launch instead of two; KSMI_BN_FUSED_FAMILIES=0 keeps the separate reduce_rows launch (A/B)
+        if relu_mask == 0 and os.environ.get("KSMI_BN_FUSED_FAMILIES", "1") != "0" and self.lib.ksmi_bn_fused_supported(Cc, cpad, self.dt):
+            self.bwd.add("ksmi_bn_bwd_fin_apply_gated", lambda: (self.scr("stats"), rows, cpad, self.scr("bnsum"), gw, gb, a1, dy.data_ptr(), r.data_ptr(),
+                                                                 sv.mean, sv.rstd, gamma, dv.data_ptr(), float(count), npix, Cc, self.dt),
+                         self._elt_meta("bn_bwd_apply", 3 * npix * Cc))
+            self._mark(f"{key}.weight", f"{key}.bias")
+            return
         self.bwd.add("ksmi_reduce_rows", lambda: (self.scr("stats"), rows, 2, cpad, Cc, self.scr("bnsum"), gw, gb, a1))
         self._mark(f"{key}.weight", f"{key}.bias")
         self.bwd.add("ksmi_bn_bwd_apply", lambda: (dy.data_ptr(), r.data_ptr(), sv.mean, sv.rstd, gamma, self.scr("bnsum"), dv.data_ptr(),
