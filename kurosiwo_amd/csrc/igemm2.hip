@@ -22,6 +22,8 @@ struct Igemm2Args {            // kernel argument: the public descriptor + launc
   uint32_t m_tw, m_hw, m_tx, m_ty;   // fastdiv magics of TW, halo width, tilesX, tilesY
   int dbg;
   int stages;                        // LDS stages: 2 = double-buffered k-chunks, 1 = single
+  int klen;                          // channels present in EVERY k-chunk (32 bf16 / 16 fp32 unless all sources are one equal partial chunk,
+                                     // round 5): the 16-byte k-groups past it are never fetched and stay zero like the padding positions
 };
 
 // WN = 1: 4 waves, each 64 pixels x BNW = 16*NT channels.  WN = 2: 8 waves = two channel groups sharing ONE halo image
@@ -95,14 +97,14 @@ __global__ __launch_bounds__(256 * WN, LEAN ? 3 : 1) void igemm2_fwd_kernel(cons
     const int pix = v >> 2, sl = v & 3;
     const int hy = dHW.div(pix), hx = pix - hy * HW;
     const int iy = iy0 + hy, ix = ix0 + hx;
-    const bool ok = v < HP * 4 && (unsigned)iy < (unsigned)d.Hin && (unsigned)ix < (unsigned)d.Win;
+    const bool ok = v < HP * 4 && (unsigned)iy < (unsigned)d.Hin && (unsigned)ix < (unsigned)d.Win && (sl ^ swz(pix)) * VEC < ka.klen;
     int gp;
     if constexpr (EX) gp = src_pixel(d, b, iy, ix);
     else gp = (b * d.Hin + iy) * d.Win + ix;
     slot_goff[s] = ok ? gp : -1;
     if constexpr (MP > 1) {
       const int iy2 = toy[1] * S - d.pad + hy, ix2 = tox[1] * S - d.pad_x + hx;
-      const bool ok2 = v < HP * 4 && (unsigned)iy2 < (unsigned)d.Hin && (unsigned)ix2 < (unsigned)d.Win;
+      const bool ok2 = v < HP * 4 && (unsigned)iy2 < (unsigned)d.Hin && (unsigned)ix2 < (unsigned)d.Win && (sl ^ swz(pix)) * VEC < ka.klen;
       int gp2;
       if constexpr (EX) gp2 = src_pixel(d, tb[1], iy2, ix2);
       else gp2 = (tb[1] * d.Hin + iy2) * d.Win + ix2;
@@ -439,6 +441,10 @@ int launch2(const ksmi_conv_desc* d, int dbg, hipStream_t st) {
   ka.m_tw = fastdiv_magic(d->TW); ka.m_hw = fastdiv_magic(HW); ka.m_tx = fastdiv_magic(tilesX); ka.m_ty = fastdiv_magic(tilesY);
   ka.dbg = dbg;
   ka.stages = stages;
+  {
+    constexpr int VEC_ = ElemTraits<T>::kVec, KC_ = VEC_ * 4;
+    ka.klen = d->src[0].c_len % KC_ ? ((d->src[0].c_len % KC_ + VEC_ - 1) / VEC_) * VEC_ : KC_;      // (ksmi_igemm2_eligible: the same in every chunk)
+  }
 #define KSMI_L2W(NT_, KH_, KW_, AFF_, EX_, WN_)                                                     \
   do {                                                                                              \
     auto kfn = igemm2_fwd_kernel<T, NT_, KH_, KW_, AFF_, EX_, WN_>; KSMI_NOTE(kfn);                                 \
@@ -495,10 +501,17 @@ int launch2(const ksmi_conv_desc* d, int dbg, hipStream_t st) {
 // eligibility: every source is a whole number of k-chunks and only source 0 may carry an affine
 bool ksmi_igemm2_eligible(const ksmi_conv_desc* d, int dtype) {
   const int kc = dtype == KSMI_BF16 ? 32 : 16;
+  // whole chunks -- or (round 5, bf16) every source ONE partial chunk of the same width (16 + 16 + 16 channels: FC-Siam conv12d; a
+  // 16-channel input gradient with the mask epilogue): the k-groups past it are never fetched (Igemm2Args.klen); no fused operand then
+  static const bool part_on = getenv("KSMI_IGEMM2_PARTIAL") ? atoi(getenv("KSMI_IGEMM2_PARTIAL")) != 0 : true;
+  bool whole = true, part = dtype == KSMI_BF16 && part_on;
   for (int i = 0; i < d->nsrc; ++i) {
-    if (d->src[i].c_len % kc) return false;
-    if (i > 0 && d->src[i].scale) return false;
+    const ksmi_src& q = d->src[i];
+    if (q.c_len % kc) whole = false;
+    if (q.c_len >= kc || q.c_len != d->src[0].c_len || (q.C % 8) || (q.c_off % 8) || q.c_off + ((q.c_len + 7) & ~7) > q.C || q.scale) part = false;
+    if (i > 0 && q.scale) return false;
   }
+  if (!whole && !part) return false;
   if (d->src[0].scale && d->nsrc != 1) return false;
   return true;
 }

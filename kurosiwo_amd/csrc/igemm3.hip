@@ -430,7 +430,9 @@ bool ksmi_igemm3_geom(const ksmi_conv_desc* d, int dtype, ksmi_igemm3_geom_t* g)
   // at 224 x 224 -- 424 us on the first-generation kernel)
   bool part_src = false;
   for (int i = 0; i < d->nsrc; ++i) part_src = part_src || (d->src[i].c_len % 32) != 0;
-  if (d->mask_src && !((mask_on || (part_src && partial_on)) && taps == 9)) return false;
+  // (KSMI_IGEMM3_MASK_PART=0: leave those to the tile kernel's uniform-partial-chunk route, igemm2.hip klen)
+  static const bool mask_part_on = getenv("KSMI_IGEMM3_MASK_PART") ? atoi(getenv("KSMI_IGEMM3_MASK_PART")) != 0 : true;
+  if (d->mask_src && !((mask_on || (part_src && partial_on && mask_part_on)) && taps == 9)) return false;
   if (d->gate_src || (d->mask_src && d->src[0].scale)) return false;
   auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
   if (!al16(d->dst[0].ptr) || !al16(d->bias)) return false;

@@ -223,3 +223,35 @@ def test_igemm3_input_gradient_into_several_destinations(dev, cus, cfg):
         ref = dx_ref[:, c0:c0 + c]
         assert (Fk.to_nchw(o).cpu() - ref).abs().max() < 2.5e-2 * dx_ref.abs().max()
         c0 += c
+
+
+@pytest.mark.parametrize("cfg", [dict(B=2, H=36, W=44, cs=[16, 16, 16], N=16), dict(B=1, H=30, W=28, cs=[8, 8, 8, 8], N=32),
+                                 dict(B=2, H=20, W=24, cs=[24, 24, 24], N=64, mask=True)])
+def test_tile_kernel_takes_uniform_partial_chunks(dev, cfg):
+    """igemm2.hip (round 5): every source one partial chunk of the same width (FC-Siam conv12d: 16 + 16 + 16 channels = three chunks,
+    more than the register-resident kernel holds): the k-groups past the width are never fetched and stay zero like the padding."""
+    import ctypes as C
+    from kurosiwo_amd import _lib, functional as Fk
+    lib = _lib.load()
+    dtype = torch.bfloat16
+    B, H, W, cs, N = cfg["B"], cfg["H"], cfg["W"], cfg["cs"], cfg["N"]
+    tag = f"ig2p.{B}{H}{W}{cs}{N}"
+    xs = [seeded_tensor(f"{tag}.x{i}", (B, c, H, W)) for i, c in enumerate(cs)]
+    K = sum(cs)
+    w = seeded_tensor(tag + ".w", (N, K, 3, 3)) * (2.0 / (K * 9)) ** 0.5
+    bias = seeded_tensor(tag + ".b", (N,)) * 0.1
+    y_ref = F.conv2d(torch.cat([q(x) for x in xs], 1), q(w), bias, padding=1)
+    mask = None
+    if cfg.get("mask"):
+        m = q(seeded_tensor(tag + ".m", (B, N, H, W)))
+        one, zero = torch.ones(N), torch.zeros(N)
+        y_ref = torch.where(m > 0, y_ref, torch.zeros_like(y_ref))
+        mask = (Fk.to_nhwc(m.to(dev), dtype), zero.to(dev), one.to(dev), one.to(dev), zero.to(dev))
+    buf = C.create_string_buffer(4096)
+    lib.ksmi_last_kernels(buf, 4096)
+    y, stats = Fk.conv3x3([Fk.to_nhwc(x.to(dev), dtype) for x in xs], w.to(dev), bias.to(dev), want_stats=True, mask=mask)
+    torch.cuda.synchronize()
+    assert "igemm2_fwd_kernel" in _last_kernels(lib, buf), _last_kernels(lib, buf)
+    assert (Fk.to_nchw(y).cpu() - y_ref).abs().max() < 2.5e-2 * y_ref.abs().max()
+    s = stats.sum(0).cpu()
+    assert (s[0, :N] - q(y_ref).sum((0, 2, 3))).abs().max() < 2e-3 * max(1.0, float(y_ref.abs().sum((0, 2, 3)).max()))
