@@ -38,6 +38,7 @@ class ChangeFormerPlan(PlanBase):
     # the encoder's nn.Linear / sr-conv weight gradients on the train step's side stream (plan_base.PlanBase.side_tokens; waits in
     # _encoder_stage_bwd).  KSMI_CF_SIDE_TOKENS=0: the single-stream list.
     side_tokens = os.environ.get("KSMI_CF_SIDE_TOKENS", "1") != "0"
+    slab_bias_side = True      # (plan_base._linear_wgrad: +1.1 % here, profiles/r05_ab_slab_bias.txt)
 
     def __init__(self, model, B, H, W, dtype, training, with_backward):
         self._init_base(model, dtype, with_backward)

@@ -21,6 +21,7 @@ class PlanBase:
     # The token plans instead name the weight gradients that may leave the critical path one by one (side_tokens; _linear_bwd side_tag)
     # and place a wait (LaunchList.add_wait_side) before every launch that overwrites an operand of one of them.
     side_tokens = False
+    slab_bias_side = False     # bias rows of split-mode token weight gradients also from side-stream launches (_linear_wgrad)
 
     def _init_base(self, model, dtype, with_backward):
         self.m, self.dtype, self.with_backward = model, dtype, with_backward
@@ -284,8 +285,13 @@ class PlanBase:
                        # mode writes it; 2 = split mode writes one partial row per split, summed by the next batched row reduction
             dw.bias_grad = self.m._g(bkey).data_ptr()
             fused = int(self.lib.ksmi_conv_wgrad_fuses_bias(C.byref(dw), self.dt))
-            if fused == 2 and os.environ.get("KSMI_SLAB_BIAS_SIDE", "1") == "0" and (side_tag is not None or self.side_wgrad):
-                fused = 0                                     # (A/B switch: only producers on the issuing stream, the first form of this route)
+            # ... from a side-stream producer only in the plans that gain from it (slab_bias_side): the batched reducer then waits for
+            # the side stream -- ChangeFormer + 1.1 % (51 channel_sum passes leave the critical stream), FloodViT - 1.4 % (its only split
+            # layer is the 2-split proj gradient: 24 waits per step for 24 colsum launches of 10 us).  KSMI_SLAB_BIAS_SIDE=0 / 1 forces.
+            if fused == 2 and (side_tag is not None or self.side_wgrad):
+                force = os.environ.get("KSMI_SLAB_BIAS_SIDE")
+                if not (self.slab_bias_side if force is None else force != "0"):
+                    fused = 0
             if fused == 1:
                 dw.bias_accumulate = self._acc_param(bkey)
             elif fused == 2:

@@ -19,6 +19,7 @@ from .unet import DECODER_CHANNELS, LAYERS
 
 
 class UnetPlan(ChangeFormerPlan):
+    slab_bias_side = False     # (measured on ChangeFormer only: plan_base._linear_wgrad)
     input_names = ("x",)
 
     side_tokens = False        # (ChangeFormerPlan's encoder switch: no MiT encoder here)
