@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define KSMI_ABI_VERSION 5   /* 5: round 4 (BatchNorm statistics finished inside the consuming pass: ksmi_bn_fin_*, ksmi_bn*_bwd_fin_*); 2: round 2 (stats_rows, stochastic layers, bias_grad in ksmi_wgrad_desc, ...); 3: round 3 (gate epilogue, ksmi_desc_size); 4: first conv on raw tiles, tile reader, BIT token path */
+#define KSMI_ABI_VERSION 6   /* 6: round 5 (ksmi_adam_step_mirror, ksmi_maxpool3x3s2_forward_idx / _backward_idx, ksmi_conv_wgrad_fuses_bias == 2: partial bias rows in ksmi_wgrad_desc.bias_grad, hbm probe window bits); 5: round 4 (BatchNorm statistics finished inside the consuming pass: ksmi_bn_fin_*, ksmi_bn*_bwd_fin_*); 2: round 2 (stats_rows, stochastic layers, bias_grad in ksmi_wgrad_desc, ...); 3: round 3 (gate epilogue, ksmi_desc_size); 4: first conv on raw tiles, tile reader, BIT token path */
 #define KSMI_F32 0
 #define KSMI_BF16 1
 #define KSMI_E_ARG (-1)

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libksmi.so")
 
 KSMI_F32, KSMI_BF16 = 0, 1
 MAX_SRC, MAX_CHUNKS = 6, 72
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class KsmiError(RuntimeError):
