@@ -190,9 +190,12 @@ typedef struct ksmi_wgrad_desc {
   int32_t pad_x_set, pad_x;
   int32_t use_tap_off;
   int32_t tap_off[16];
-  /* optional fused bias gradient of a plain nn.Linear (1x1, one source): bias_grad[n] (+)= sum over rows of dY[row][n].  Only the
-   * launches for which ksmi_conv_wgrad_fuses_bias() returns 1 compute it (the token-GEMM weight gradient that writes the gradient
-   * in one split: dY is already in LDS there); otherwise the field is ignored and the caller runs ksmi_colsum. */
+  /* optional fused bias gradient of a plain nn.Linear (1x1, one source), by the return value of ksmi_conv_wgrad_fuses_bias():
+   *   1: bias_grad[n] (+)= sum over rows of dY[row][n] (the token-GEMM weight gradient that writes the gradient in one split: dY is
+   *      already in LDS there);
+   *   2 (ABI 6): the split mode of the same path OVERWRITES bias_grad[split * N + n] = sum over the split's rows of dY[row][n] for
+   *      split < nsplit -- the caller sums the nsplit rows (bias_accumulate is not used);
+   *   0: the field is ignored and the caller runs ksmi_colsum / ksmi_channel_sum. */
   float* bias_grad; int32_t bias_accumulate;
 } ksmi_wgrad_desc;
 size_t ksmi_conv_wgrad_workspace(const ksmi_wgrad_desc* d, int dtype);
