@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define KSMI_ABI_VERSION 6   /* 6: round 5 (ksmi_adam_step_mirror, ksmi_maxpool3x3s2_forward_idx / _backward_idx, ksmi_conv_wgrad_fuses_bias == 2: partial bias rows in ksmi_wgrad_desc.bias_grad, hbm probe window bits); 5: round 4 (BatchNorm statistics finished inside the consuming pass: ksmi_bn_fin_*, ksmi_bn*_bwd_fin_*); 2: round 2 (stats_rows, stochastic layers, bias_grad in ksmi_wgrad_desc, ...); 3: round 3 (gate epilogue, ksmi_desc_size); 4: first conv on raw tiles, tile reader, BIT token path */
+#define KSMI_ABI_VERSION 7   /* 7: round 6 (ksmi_set_knob, ksmi_conv_dispatch_info, ksmi_argmax_confusion_grouped, ksmi_run_list, fused SR-attention block, stream-K token GEMMs); 6: round 5 (ksmi_adam_step_mirror, ksmi_maxpool3x3s2_forward_idx / _backward_idx, ksmi_conv_wgrad_fuses_bias == 2: partial bias rows in ksmi_wgrad_desc.bias_grad, hbm probe window bits); 5: round 4 (BatchNorm statistics finished inside the consuming pass: ksmi_bn_fin_*, ksmi_bn*_bwd_fin_*); 2: round 2 (stats_rows, stochastic layers, bias_grad in ksmi_wgrad_desc, ...); 3: round 3 (gate epilogue, ksmi_desc_size); 4: first conv on raw tiles, tile reader, BIT token path */
 #define KSMI_F32 0
 #define KSMI_BF16 1
 #define KSMI_E_ARG (-1)
@@ -35,6 +35,12 @@ extern "C" {
 
 int ksmi_abi_version(void);
 const char* ksmi_last_error(void);
+/* Test / probe hook (ABI 7).  The launchers read their switches (KSMI_* environment variables) ONCE: the start-up switches at their first
+ * use, the run-time knobs -- KSMI_IGEMM3_CUS, KSMI_IGEMM4_CUS, KSMI_IGEMM4_VAR, KSMI_IG4_PATCH, KSMI_IG3_DBG, KSMI_IG4_DBG, KSMI_WGRAD3_NST,
+ * KSMI_WGRAD3_WGS: grid shrinkers, forced tile variants and profiling switches of the tests and probes -- at their first look-up, after
+ * which only this call changes them (value NULL: back to the built-in default).  No launch path calls getenv per launch.  Not part of
+ * the reference's operator surface; production code never calls it. */
+int ksmi_set_knob(const char* name, const char* value);
 /* bytes of K per packed k-chunk / elements per chunk for a dtype (32 bf16, 16 fp32) */
 int ksmi_chunk_elems(int dtype);
 
@@ -145,6 +151,10 @@ int ksmi_conv_grid_m(const ksmi_conv_desc* d);
 /* rows of `stats` ksmi_conv_forward(d, dtype) will write when d->stats_rows is set to the returned value */
 int ksmi_conv_stats_rows(const ksmi_conv_desc* d, int dtype);
 int ksmi_conv_forward(const ksmi_conv_desc* d, int dtype, void* stream);
+/* (ABI 7, test / tooling hook) which kernel ksmi_conv_forward(d, dtype) starts, decided on the host without launching: info[0] = kernel
+ * generation (4 = persistent long-K igemm4, 3 = persistent short-K igemm3, 2 = igemm2, 1 = first generation), info[1] = 1 when the chosen
+ * launcher has a compiled instance for the geometry it picked, igemm4: info[2..7] = WM, NF, waves, schedule, gx, gy.  `info`: 8 ints. */
+int ksmi_conv_dispatch_info(const ksmi_conv_desc* d, int dtype, int32_t* info);
 
 /* Weight packing fp32 parameter -> `dtype` [nchunks][taps][Npad][chunk_elems].
  * element (chunk, tap, j, kk) = w[ k*sK + (j % n_mod)*sN + (j / n_mod)*sD + tap'*sT ],

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libksmi.so")
 
 KSMI_F32, KSMI_BF16 = 0, 1
 MAX_SRC, MAX_CHUNKS = 6, 72
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class KsmiError(RuntimeError):
@@ -93,6 +93,8 @@ SIGNATURES = {
     "ksmi_last_kernels": (_i, [C.c_char_p, _i]),
     "ksmi_hbm_probe": (_i, [_i, _vp, _vp, _vp, C.c_size_t, _vp, _vp]),
     "ksmi_last_error": (C.c_char_p, []),
+    "ksmi_set_knob": (_i, [C.c_char_p, C.c_char_p]),
+    "ksmi_conv_dispatch_info": (_i, [C.POINTER(ConvDesc), _i, C.POINTER(C.c_int32)]),
     "ksmi_chunk_elems": (_i, [_i]),
     "ksmi_conv_grid_m": (_i, [C.POINTER(ConvDesc)]),
     "ksmi_conv_forward": (_i, [C.POINTER(ConvDesc), _i, _vp]),
@@ -268,6 +270,30 @@ def load():
             raise KsmiError(f"libksmi {cls.__name__}: {lib.ksmi_desc_size(which)} bytes in the library, {C.sizeof(cls)} in the binding")
     _lib = lib
     return lib
+
+
+def set_knob(name, value):
+    """ksmi_set_knob (include/ksmi.h): a run-time switch of the launchers (tests / probes only); value None = built-in default"""
+    rc = load().ksmi_set_knob(name.encode(), None if value is None else str(value).encode())
+    if rc != 0:
+        check(rc, "ksmi_set_knob")
+
+
+class knobs:
+    """with knobs(KSMI_IGEMM4_CUS="3", KSMI_IGEMM4_VAR="8,2"): ...  -- restores the built-in defaults on exit"""
+
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        for k, v in self.kv.items():
+            set_knob(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k in self.kv:
+            set_knob(k, None)
+        return False
 
 
 def check(rc, what=""):

@@ -65,7 +65,43 @@ static const std::string& kernel_name(const void* fn) {
   return cache.emplace(fn, out).first->second;
 }
 
+// ---- knobs: the test / probe switches that must be changeable WHILE a process runs (the launchers' start-up switches stay
+// `static const ... getenv` reads: evaluated once).  A knob starts as the environment variable of its name read ONCE, at its first
+// look-up; afterwards only ksmi_set_knob changes it -- no launcher calls getenv per launch.
+static std::mutex g_knob_mu;
+static std::map<std::string, std::pair<bool, std::string>> g_knobs;     // name -> (set?, value)
+
+static std::pair<bool, std::string>& knob_slot(const char* name) {
+  auto it = g_knobs.find(name);
+  if (it == g_knobs.end()) {
+    const char* e = getenv(name);
+    it = g_knobs.emplace(name, std::make_pair(e != nullptr, std::string(e ? e : ""))).first;
+  }
+  return it->second;
+}
+int ksmi_knob_int(const char* name, int dflt) {
+  std::lock_guard<std::mutex> lk(g_knob_mu);
+  const auto& k = knob_slot(name);
+  return k.first ? atoi(k.second.c_str()) : dflt;
+}
+bool ksmi_knob_str(const char* name, char* out, int cap) {
+  std::lock_guard<std::mutex> lk(g_knob_mu);
+  const auto& k = knob_slot(name);
+  if (!k.first || cap < 1) return false;
+  strncpy(out, k.second.c_str(), (size_t)cap - 1);
+  out[cap - 1] = 0;
+  return true;
+}
+
 extern "C" {
+int ksmi_set_knob(const char* name, const char* value) {
+  if (!name || strncmp(name, "KSMI_", 5)) return ksmi_fail(KSMI_E_ARG, "set_knob: names start with KSMI_");
+  std::lock_guard<std::mutex> lk(g_knob_mu);
+  auto& k = knob_slot(name);
+  k.first = value != nullptr;
+  k.second = value ? value : "";
+  return 0;
+}
 int ksmi_last_kernels(char* buf, int cap) {
   const int n = g_nnotes < 8 ? g_nnotes : 8;
   int pos = 0;

@@ -3,6 +3,9 @@
 #include <hip/hip_runtime.h>
 int ksmi_fail(int code, const char* msg);          // records msg, returns code
 int ksmi_check_launch(const char* what);           // hipGetLastError() -> 0 or positive hipError_t
+// run-time knobs (api.hip): the environment variable `name` as read at the knob's FIRST look-up, or what ksmi_set_knob stored since
+int ksmi_knob_int(const char* name, int dflt);
+bool ksmi_knob_str(const char* name, char* out, int cap);      // false: unset
 
 // Address of a __device__ symbol (the zero pages the LDS-DMA loaders read padding from) on the CURRENT device, cached per device:
 // a process that drives several GPUs must not hand device 1 the address device 0 resolved.  Concurrent first calls

@@ -750,11 +750,12 @@ __global__ void tn_reduce_kernel(const ksmi_wgrad_desc d, int KC, int K) {
   }
 }
 
+static bool wgrad_generic_forced() { static const bool on = getenv("KSMI_WGRAD_GENERIC") != nullptr; return on; }
 // eligibility of the token-GEMM path and its split geometry
 static bool gemm_tn_eligible(const ksmi_wgrad_desc* d, int es) {
   return es == 2 && d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && d->nsrc == 1 && d->src[0].scale == nullptr &&
          d->Hin == d->Hout && d->Win == d->Wout && (d->src[0].c_len % 8) == 0 && (d->N % 8) == 0 && d->N >= 64 && d->src[0].c_len >= 64 &&
-         getenv("KSMI_WGRAD_GENERIC") == nullptr;
+         !wgrad_generic_forced();
 }
 // tile and split choice of the token-GEMM weight gradient (gemm2.hip: 128 A-side columns x `bt` B-side columns per workgroup).
 // direct (one split, row-major gradient): A = k, B = n; slabs: A = n, B = k.  Cost = whole rounds of the 256 CUs x 64-row steps
@@ -977,6 +978,30 @@ int ksmi_conv_stats_rows(const ksmi_conv_desc* d, int dtype) {
   ksmi_igemm4_geom_t g4;
   if (ksmi_igemm4_geom(&c, dtype, &g4)) return g4.gx;
   return ksmi_conv_grid_m(d);
+}
+
+// Which kernel ksmi_conv_forward(d, dtype) starts, decided on the host (nothing is launched): info[0] = kernel generation (4 igemm4, 3 igemm3,
+// 2 igemm2, 1 first generation), info[1] = 1 when that launcher has an instantiated kernel for the geometry it chose (a geometry function
+// that accepts a descriptor its launcher cannot start makes the forward raise instead of falling through: ADVICE round 5), igemm4 only:
+// info[2..7] = WM, NF, waves per workgroup, schedule (0 row steps, 1 deep ring, 2 chunk), gx, gy.  Test / tooling hook.
+int ksmi_conv_dispatch_info(const ksmi_conv_desc* d, int dtype, int32_t* info) {
+  if (!d || !info) return ksmi_fail(KSMI_E_ARG, "conv_dispatch_info: null argument");
+  for (int i = 0; i < 8; ++i) info[i] = 0;
+  static const bool force_v1 = getenv("KSMI_IGEMM_V1") != nullptr;
+  ksmi_igemm3_geom_t g3;
+  if (!force_v1 && !d->gate_src && ksmi_igemm3_geom(d, dtype, &g3) && (d->stats == nullptr || d->stats_rows == g3.gx)) {
+    info[0] = 3; info[1] = 1; info[6] = g3.gx; info[7] = g3.gy;
+    return 0;
+  }
+  ksmi_igemm4_geom_t g4;
+  if (!force_v1 && ksmi_igemm4_geom(d, dtype, &g4) && (d->stats == nullptr || d->stats_rows == g4.gx)) {
+    info[0] = 4; info[1] = ksmi_igemm4_launchable(d, &g4) ? 1 : 0;
+    info[2] = g4.WM; info[3] = g4.NF; info[4] = g4.nwv; info[5] = g4.deep; info[6] = g4.gx; info[7] = g4.gy;
+    return 0;
+  }
+  info[0] = (!force_v1 && ksmi_igemm2_eligible(d, dtype)) ? 2 : 1;
+  info[1] = 1;
+  return 0;
 }
 
 int ksmi_conv_forward(const ksmi_conv_desc* d, int dtype, void* stream) {

@@ -488,8 +488,7 @@ bool ksmi_igemm3_geom(const ksmi_conv_desc* d, int dtype, ksmi_igemm3_geom_t* g)
   g->tiles = d->B * tilesX * tilesY;
   int per_cu = (int)(LDS_CU / g->lds);
   if (per_cu > cap) per_cu = cap;
-  const char* cus_env = getenv("KSMI_IGEMM3_CUS");            // (read per call: the tests shrink the grid to force many rounds)
-  const int cus = cus_env ? atoi(cus_env) : 256;
+  const int cus = ksmi_knob_int("KSMI_IGEMM3_CUS", 256);      // (a knob: the tests shrink the grid to force many rounds)
   const int gy = ntiles / g->NTI;
   int gx = cus * per_cu / gy;
   if (gx < 1) gx = 1;
@@ -507,8 +506,7 @@ int ksmi_igemm3_launch(const ksmi_conv_desc* d, const ksmi_igemm3_geom_t* g, hip
   const int HW = (d->TW - 1) * d->stride + d->KW;
   const int tilesX = (d->Wout + d->TW - 1) / d->TW, tilesY = (d->Hout + d->TH - 1) / d->TH;
   ka.m_tw = fastdiv_magic(d->TW); ka.m_hw = fastdiv_magic(HW); ka.m_tx = fastdiv_magic(tilesX); ka.m_ty = fastdiv_magic(tilesY);
-  const char* dbg_env = getenv("KSMI_IG3_DBG");
-  ka.dbg = dbg_env ? atoi(dbg_env) : 0;
+  ka.dbg = ksmi_knob_int("KSMI_IG3_DBG", 0);
   ka.tiles = g->tiles; ka.hpb = g->hpb; ka.nslot = g->nslot; ka.stage = g->stage; ka.ns = g->ns;
   const unsigned char* const zero_page = ig3_zero();
   if (!zero_page) return ksmi_fail(KSMI_E_UNSUPPORTED, "igemm3: zero page");

@@ -16,3 +16,5 @@ struct ksmi_igemm4_geom_t {
 // false: the descriptor does not qualify (the caller uses igemm2)
 bool ksmi_igemm4_geom(const ksmi_conv_desc* d, int dtype, ksmi_igemm4_geom_t* g);
 int ksmi_igemm4_launch(const ksmi_conv_desc* d, const ksmi_igemm4_geom_t* g, hipStream_t st);
+// true: ksmi_igemm4_launch has an instantiated kernel for this geometry (host only, nothing is launched; ksmi_conv_dispatch_info)
+bool ksmi_igemm4_launchable(const ksmi_conv_desc* d, const ksmi_igemm4_geom_t* g);

@@ -958,11 +958,10 @@ bool ksmi_igemm4_geom(const ksmi_conv_desc* d, int dtype, ksmi_igemm4_geom_t* g)
   if (d->gate_src && (!d->xhat_src || !d->g_mean || !d->g_rstd || !al16(d->gate_src) || !al16(d->xhat_src) || !al16(d->g_mean) || !al16(d->g_rstd)))
     return false;
   if (aff && d->nchunks > 64) return false;                         // affine table: 8 KB
-  const char* v_env = getenv("KSMI_IGEMM4_VAR");                    // (read per call: the tests force each variant) "wm,nf"
+  char v_env[32];                                                   // (a knob: the tests force each variant) "wm,nf"
   int wm_force = 0, nf_force = 0;
-  if (v_env) sscanf(v_env, "%d,%d", &wm_force, &nf_force);
-  const char* cus_env = getenv("KSMI_IGEMM4_CUS");                  // (read per call: the tests shrink the grid to force many rounds)
-  const int cus = cus_env ? atoi(cus_env) : 256;
+  if (ksmi_knob_str("KSMI_IGEMM4_VAR", v_env, sizeof(v_env))) sscanf(v_env, "%d,%d", &wm_force, &nf_force);
+  const int cus = ksmi_knob_int("KSMI_IGEMM4_CUS", 256);            // (a knob: the tests shrink the grid to force many rounds)
   // variants (8 waves): WM = 4 pixel groups x 2 column groups of 16 NF columns (256-pixel patch the descriptor chose), or
   // WM = 8 pixel groups x 1 column group (512-pixel patch chosen here): the wider the wave tile, the fewer LDS bytes per MFMA
   struct Var { int wm, nf, nwv; };
@@ -972,24 +971,28 @@ bool ksmi_igemm4_geom(const ksmi_conv_desc* d, int dtype, ksmi_igemm4_geom_t* g)
   static const int nw4 = getenv("KSMI_IG4_NW4") ? atoi(getenv("KSMI_IG4_NW4")) : 0;
   if (d->Npad == 32 && nw4 && !k2) cand[nc++] = {4, 2, 4};          // 256 px x 32, wave 64 x 32, two workgroups per CU
   if (d->Npad % 128 == 0) cand[nc++] = {4, 4, 8};                   // 256 px x 128 columns, wave 64 x 64
-  if (k2) nc = 1;                                                   // (2 x 2 phase convolutions: that one tile shape)
   // 64 columns exactly (SNUNet level 1): 256 px x 64 tiles make 7 rounds of 224 workgroups at 112^2 x 32 (88 % of the slots filled) where
   // the 512 px ones make 4 rounds of 208 (77 %): 2-8 % shorter per launch (profiles/r05_ig4_variants.txt (e)); KSMI_IG4_N64=84 restores the old order
   static const int n64 = getenv("KSMI_IG4_N64") ? atoi(getenv("KSMI_IG4_N64")) : 42;
-  if (d->Npad == 64 && n64 == 42) { cand[nc++] = {4, 2, 8}; cand[nc++] = {8, 4, 8}; }
-  else if (d->Npad % 64 == 0) { cand[nc++] = {8, 4, 8}; cand[nc++] = {4, 2, 8}; }   // 512 px x 64 (wave 64 x 64) / 256 px x 64 (wave 64 x 32)
-  if (d->Npad == 32) cand[nc++] = {8, 2, 8};                        // 512 px x 32, wave 64 x 32
+  // (2 x 2 phase convolutions: the 256 px x 128 shape is the ONLY instance that exists -- no 64-column candidates for them, so a geometry
+  // this function accepts is always launchable; a shape the fill rule below would have skipped simply stays on that one tile)
+  if (!k2) {
+    if (d->Npad == 64 && n64 == 42) { cand[nc++] = {4, 2, 8}; cand[nc++] = {8, 4, 8}; }
+    else if (d->Npad % 64 == 0) { cand[nc++] = {8, 4, 8}; cand[nc++] = {4, 2, 8}; }   // 512 px x 64 (wave 64 x 64) / 256 px x 64 (wave 64 x 32)
+    if (d->Npad == 32) cand[nc++] = {8, 2, 8};                        // 512 px x 32, wave 64 x 32
+  }
   for (int ci = 0; ci < nc; ++ci) {
     const int wm = cand[ci].wm, nf = cand[ci].nf, nwv = cand[ci].nwv;
     if (wm_force && (wm != wm_force || nf != nf_force)) continue;
+    if (k2 && !(wm == 4 && nf == 4 && nwv == 8)) continue;          // (belt and braces: the one 2 x 2 instance, ksmi_igemm4_launch)
     const int bn = (nwv / wm) * 16 * nf;
     int th, tw;
     if (wm == 4) { th = d->TH; tw = d->TW; if (th * tw > 256) continue; }
     else {
       ig4_patch(d->Hout, d->Wout, 512, IG4_NHMAX * 128, &th, &tw);
-      const char* pe = getenv("KSMI_IG4_PATCH");                    // probes: "th,tw" of the 512-pixel variants (DRAM-locality experiments)
+      char pe[32];                                                  // probes: "th,tw" of the 512-pixel variants (DRAM-locality experiments)
       int pth = 0, ptw = 0;
-      if (pe && sscanf(pe, "%d,%d", &pth, &ptw) == 2 && pth > 0 && ptw > 0 && pth * ptw <= 512 && (pth + 2) * (ptw + 2) <= IG4_NHMAX * 128) { th = pth; tw = ptw; }
+      if (ksmi_knob_str("KSMI_IG4_PATCH", pe, sizeof(pe)) && sscanf(pe, "%d,%d", &pth, &ptw) == 2 && pth > 0 && ptw > 0 && pth * ptw <= 512 && (pth + 2) * (ptw + 2) <= IG4_NHMAX * 128) { th = pth; tw = ptw; }
     }
     const int hp = (th + d->KH - 1) * (tw + d->KW - 1);
     const int tilesX = (d->Wout + tw - 1) / tw, tilesY = (d->Hout + th - 1) / th;
@@ -1029,28 +1032,38 @@ bool ksmi_igemm4_geom(const ksmi_conv_desc* d, int dtype, ksmi_igemm4_geom_t* g)
   return false;
 }
 
+// dry run (ksmi_igemm4_launchable): walk the instance selection of ksmi_igemm4_launch without touching the device
+static thread_local bool ig4_dry = false;
+#define KSMI_IG4_DRY_RETURN do { if (ig4_dry) return 0; } while (0)
+
+bool ksmi_igemm4_launchable(const ksmi_conv_desc* d, const ksmi_igemm4_geom_t* g) {
+  ig4_dry = true;
+  const int rc = ksmi_igemm4_launch(d, g, nullptr);
+  ig4_dry = false;
+  return rc == 0;
+}
+
 int ksmi_igemm4_launch(const ksmi_conv_desc* d, const ksmi_igemm4_geom_t* g, hipStream_t st) {
   Ig4Args ka;
   ka.d = *d;
   ka.th = g->th; ka.tw = g->tw;
   const int tilesX = (d->Wout + g->tw - 1) / g->tw, tilesY = (d->Hout + g->th - 1) / g->th;
   ka.m_tw = fastdiv_magic(g->tw); ka.m_hw = fastdiv_magic(g->tw + d->KW - 1); ka.m_tx = fastdiv_magic(tilesX); ka.m_ty = fastdiv_magic(tilesY);
-  const char* dbg_env = getenv("KSMI_IG4_DBG");
-  ka.dbg = dbg_env ? atoi(dbg_env) : 0;
+  ka.dbg = ksmi_knob_int("KSMI_IG4_DBG", 0);
   static const int stag = getenv("KSMI_IG4_STAGGER") ? atoi(getenv("KSMI_IG4_STAGGER")) : 1;
   ka.stagger = stag;
   static const int rot = getenv("KSMI_IG4_ROT") ? atoi(getenv("KSMI_IG4_ROT")) : 1;      // (rotated schedule: +3-7 % on the long-K shapes)
   ka.rot = rot;
   ka.hslot = g->hslot; ka.nh = g->nh; ka.nhs = g->nhs;
   ka.tiles = g->tiles; ka.gx = g->gx; ka.gy = g->gy;
-  const unsigned char* const zero_page = ig4_zero();
-  if (!zero_page) return ksmi_fail(KSMI_E_UNSUPPORTED, "igemm4: zero page");
+  const unsigned char* const zero_page = ig4_dry ? nullptr : ig4_zero();
+  if (!zero_page && !ig4_dry) return ksmi_fail(KSMI_E_UNSUPPORTED, "igemm4: zero page");
   ka.zero = zero_page;
   const dim3 grid(g->gx * g->gy);
   const bool aff = d->src[0].scale != nullptr, mask = d->mask_src != nullptr, gate = d->gate_src != nullptr;
 #define KSMI_G4(WM_, NF_, AFF_, MASK_)                                                               \
   do {                                                                                               \
-    auto kfn = igemm4_kernel<WM_, NF_, AFF_, MASK_>; KSMI_NOTE(kfn);                                                 \
+    auto kfn = igemm4_kernel<WM_, NF_, AFF_, MASK_>; KSMI_IG4_DRY_RETURN; KSMI_NOTE(kfn);                                                 \
     static bool attr_set = false;        /* (one driver call per instantiation, not per launch) */  \
     if (!attr_set) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; } \
     hipLaunchKernelGGL(kfn, grid, dim3(512), g->lds, st, ka);                                        \
@@ -1058,7 +1071,7 @@ int ksmi_igemm4_launch(const ksmi_conv_desc* d, const ksmi_igemm4_geom_t* g, hip
   } while (0)
 #define KSMI_G4D(WM_, NF_)                                                                           \
   do {                                                                                               \
-    auto kfn = igemm4_kernel<WM_, NF_, false, 0, false, 1>; KSMI_NOTE(kfn);                                          \
+    auto kfn = igemm4_kernel<WM_, NF_, false, 0, false, 1>; KSMI_IG4_DRY_RETURN; KSMI_NOTE(kfn);                                          \
     static bool attr_set = false;                                                                    \
     if (!attr_set) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; } \
     hipLaunchKernelGGL(kfn, grid, dim3(512), g->lds, st, ka);                                        \
@@ -1066,7 +1079,7 @@ int ksmi_igemm4_launch(const ksmi_conv_desc* d, const ksmi_igemm4_geom_t* g, hip
   } while (0)
 #define KSMI_G4R(WM_, NF_, AFF_, EPI_)                                                               \
   do {                                                                                               \
-    auto kfn = igemm4_kernel<WM_, NF_, AFF_, EPI_, false, 0, 1>; KSMI_NOTE(kfn);                                     \
+    auto kfn = igemm4_kernel<WM_, NF_, AFF_, EPI_, false, 0, 1>; KSMI_IG4_DRY_RETURN; KSMI_NOTE(kfn);                                     \
     static bool attr_set = false;                                                                    \
     if (!attr_set) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; } \
     hipLaunchKernelGGL(kfn, grid, dim3(512), g->lds, st, ka);                                        \
@@ -1077,18 +1090,18 @@ int ksmi_igemm4_launch(const ksmi_conv_desc* d, const ksmi_igemm4_geom_t* g, hip
        if (aff) KSMI_G4(WM_, NF_, true, 0); else if (mask) KSMI_G4(WM_, NF_, false, 1); else if (gate) KSMI_G4(WM_, NF_, false, 2);   \
        else if (d->dir == 1) KSMI_G4D(WM_, NF_); else KSMI_G4(WM_, NF_, false, 0); } while (0)
   if (ka.dbg && !aff && !mask && !gate && g->NF == 2 && g->WM == 8 && g->nwv == 8) {      // (the 32-column level-0 shape)
-    auto kfn = igemm4_kernel<8, 2, false, 0, true>; KSMI_NOTE(kfn);
+    auto kfn = igemm4_kernel<8, 2, false, 0, true>; KSMI_IG4_DRY_RETURN; KSMI_NOTE(kfn);
     (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL(kfn, grid, dim3(512), g->lds, st, ka);
     return ksmi_check_launch("igemm4");
   }
   if (ka.dbg && !aff && !mask && !gate && g->NF == 4 && g->nwv == 8) {        // profiling switches: separate instantiations of the plain kernels
     if (g->WM == 4) {
-      auto kfn = igemm4_kernel<4, 4, false, 0, true>; KSMI_NOTE(kfn);
+      auto kfn = igemm4_kernel<4, 4, false, 0, true>; KSMI_IG4_DRY_RETURN; KSMI_NOTE(kfn);
       (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       hipLaunchKernelGGL(kfn, grid, dim3(512), g->lds, st, ka);
     } else {
-      auto kfn = igemm4_kernel<8, 4, false, 0, true>; KSMI_NOTE(kfn);
+      auto kfn = igemm4_kernel<8, 4, false, 0, true>; KSMI_IG4_DRY_RETURN; KSMI_NOTE(kfn);
       (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       hipLaunchKernelGGL(kfn, grid, dim3(512), g->lds, st, ka);
     }
@@ -1097,7 +1110,7 @@ int ksmi_igemm4_launch(const ksmi_conv_desc* d, const ksmi_igemm4_geom_t* g, hip
   if (g->nwv == 4) {
 #define KSMI_G4N(AFF_, EPI_, ROT_)                                                                   \
   do {                                                                                               \
-    auto kfn = igemm4_kernel<4, 2, AFF_, EPI_, false, 0, ROT_ ? 1 : 0, 4>; KSMI_NOTE(kfn);                           \
+    auto kfn = igemm4_kernel<4, 2, AFF_, EPI_, false, 0, ROT_ ? 1 : 0, 4>; KSMI_IG4_DRY_RETURN; KSMI_NOTE(kfn);                           \
     static bool attr_set = false;                                                                    \
     if (!attr_set) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr_set = true; } \
     hipLaunchKernelGGL(kfn, grid, dim3(256), g->lds, st, ka);                                        \
@@ -1111,7 +1124,7 @@ int ksmi_igemm4_launch(const ksmi_conv_desc* d, const ksmi_igemm4_geom_t* g, hip
   if (g->deep == 2 && d->KH == 2) {                                 // the 2 x 2 phase convolutions: 256 px x 128 columns, chunk schedule
 #define KSMI_G4K2(EPI_)                                                                              \
   do {                                                                                               \
-    auto kfn = igemm4_kernel<4, 4, false, EPI_, false, 0, 3, 8, 2, 2>; KSMI_NOTE(kfn);                               \
+    auto kfn = igemm4_kernel<4, 4, false, EPI_, false, 0, 3, 8, 2, 2>; KSMI_IG4_DRY_RETURN; KSMI_NOTE(kfn);                               \
     static bool attr_set = false;                                                                    \
     if (!attr_set) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; } \
     hipLaunchKernelGGL(kfn, grid, dim3(512), g->lds, st, ka);                                        \
@@ -1124,7 +1137,7 @@ int ksmi_igemm4_launch(const ksmi_conv_desc* d, const ksmi_igemm4_geom_t* g, hip
   if (g->deep == 2) {
 #define KSMI_G4CH(WM_, NF_, EPI_)                                                                    \
   do {                                                                                               \
-    auto kfn = igemm4_kernel<WM_, NF_, false, EPI_, false, 0, 3>; KSMI_NOTE(kfn);                                    \
+    auto kfn = igemm4_kernel<WM_, NF_, false, EPI_, false, 0, 3>; KSMI_IG4_DRY_RETURN; KSMI_NOTE(kfn);                                    \
     static bool attr_set = false;                                                                    \
     if (!attr_set) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; } \
     hipLaunchKernelGGL(kfn, grid, dim3(512), g->lds, st, ka);                                        \
@@ -1138,7 +1151,7 @@ int ksmi_igemm4_launch(const ksmi_conv_desc* d, const ksmi_igemm4_geom_t* g, hip
   if (g->deep == 1) {
 #define KSMI_G4DP(WM_, NF_, EPI_)                                                                    \
   do {                                                                                               \
-    auto kfn = igemm4_kernel<WM_, NF_, false, EPI_, false, 0, 2>; KSMI_NOTE(kfn);                                    \
+    auto kfn = igemm4_kernel<WM_, NF_, false, EPI_, false, 0, 2>; KSMI_IG4_DRY_RETURN; KSMI_NOTE(kfn);                                    \
     static bool attr_set = false;                                                                    \
     if (!attr_set) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; } \
     hipLaunchKernelGGL(kfn, grid, dim3(512), g->lds, st, ka);                                        \

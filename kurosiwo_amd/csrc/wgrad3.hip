@@ -450,8 +450,8 @@ bool ksmi_wgrad3_geom(const ksmi_wgrad_desc* d, int dtype, ksmi_wgrad3_geom_t* g
   if (2 * (size_t)g->stage + 1024 > 160 * 1024) return false;
   // LDS ring: KSMI_WGRAD3_NST = 3 / 4 lets a workgroup that owns its CU (at most 256 workgroups) keep up to that many stages
   // (patches i+1 .. i+nst-1 in flight during the MFMAs of patch i); the default is two stages and two workgroups per CU.
-  const char* nst_env = getenv("KSMI_WGRAD3_NST");                  // (read per call: the tests force each depth)
-  const int nst_want = nst_env && atoi(nst_env) >= 2 ? atoi(nst_env) : 2;
+  const int nst_knob = ksmi_knob_int("KSMI_WGRAD3_NST", 2);         // (a knob: the tests force each depth)
+  const int nst_want = nst_knob >= 2 ? nst_knob : 2;
   int nst_max = (int)((160 * 1024 - 1024) / g->stage);
   if (nst_max > 4) nst_max = 4;
   if (nst_want < nst_max) nst_max = nst_want;
@@ -459,8 +459,7 @@ bool ksmi_wgrad3_geom(const ksmi_wgrad_desc* d, int dtype, ksmi_wgrad3_geom_t* g
   // traffic (K = N = 64 at 512 workgroups: 75 MB of slabs against 103 MB of operands), while too few workgroups cannot keep
   // HBM busy.  Pick the count that minimises, in microseconds with coarse measured constants,
   //   max(MFMA time, operand bytes / min(4.5 TB/s, workgroups x stages in flight / 5 us)) + slab write + slab read.
-  const char* wg_env = getenv("KSMI_WGRAD3_WGS");                   // (read per call: the tests shrink the grid so that the ring wraps)
-  const int wg_force = wg_env ? atoi(wg_env) : 0;
+  const int wg_force = ksmi_knob_int("KSMI_WGRAD3_WGS", 0);         // (a knob: the tests shrink the grid so that the ring wraps)
   const int tiles = g->KT * g->NTt;
   const int nfw = (g->NTL / 16) / (4 / g->WC);                      // column fragments per wave
   const double ntaps = k2 ? 4.0 : 9.0;

@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), name
     assert set(_lib.SIGNATURES) == declared
-    assert lib.ksmi_abi_version() == 6
+    assert lib.ksmi_abi_version() == _lib.ABI_VERSION == 7
     assert lib.ksmi_chunk_elems(_lib.KSMI_BF16) == 32 and lib.ksmi_chunk_elems(_lib.KSMI_F32) == 16
 
 

@@ -83,3 +83,50 @@ def test_bias_gradient_modes_of_the_token_weight_gradient(rows, K, N, mode):
     dw.bias_grad = g.data_ptr()
     assert lib.ksmi_conv_wgrad_fuses_bias(C.byref(dw), DT[BF]) == mode
     assert (dw.nsplit == 1) == (mode == 1)
+
+
+def _phase_desc(B, H, W, Cin, N):
+    """one 2 x 2 stride-1 phase convolution of ConvTranspose2d(k4, s2, p1) as plan_base._deconv builds it: strided output view"""
+    x = torch.empty((16,), dtype=BF)
+    src = SrcSpec(x, Cin)
+    src.C = Cin
+    out = torch.empty((16,), dtype=BF)
+    d, _ = make_conv([src], [(out, N, 0, 0, N, 0)], out, None, None, B, H, W, H, W, 2, 2, 1, 1, N, BF, pad_x=1,
+                     out_map=(2, 2, 0, 0, 2 * H, 2 * W))
+    d._keep = (x, out)
+    return d
+
+
+@pytest.mark.parametrize("H,N", [(56, 256), (64, 256), (28, 128), (14, 128), (112, 128)])
+def test_every_accepted_phase_geometry_has_an_instance(H, N):
+    """for the 2 x 2 phase convolutions ksmi_igemm4_geom listed 64-column tile candidates that have no compiled
+    2 x 2 instance; in the window 64 <= tiles < 192 / gy (ragged last batches, small data-parallel shards) the forward raised
+    KSMI_E_UNSUPPORTED instead of falling back.  Sweep the batch: whatever kernel the dispatcher picks must be launchable, and a
+    persistent-kernel choice for a phase convolution is the <4, 4> x 8-wave instance."""
+    lib = _lib.load()
+    info = (C.c_int32 * 8)()
+    seen = set()
+    for B in range(1, 49):
+        d = _phase_desc(B, H, H, 256, N)
+        assert lib.ksmi_conv_dispatch_info(C.byref(d), DT[BF], info) == 0
+        gen, ok = info[0], info[1]
+        assert ok == 1, (B, H, N, list(info))
+        if gen == 4:
+            assert (info[2], info[3], info[4]) == (4, 4, 8), (B, list(info))
+        seen.add(gen)
+    assert seen <= {2, 4}
+
+
+def test_every_accepted_3x3_geometry_has_an_instance():
+    """the same sweep over the 3 x 3 layers of the plans: batch 1 .. 40 at every SNUNet level and column count, plain / mask / long-K"""
+    lib = _lib.load()
+    info = (C.c_int32 * 8)()
+    for H, cs, N in ((224, [32, 32, 64], 32), (112, [64, 64, 128], 64), (56, [128, 128, 256], 128), (28, [256, 256, 512], 256),
+                     (14, [512], 512), (224, [256], 256), (224, [256], 2), (56, [64], 128), (112, [64], 64)):
+        for B in (1, 2, 3, 4, 5, 6, 8, 12, 16, 24, 32, 40):
+            for mask in (False, True):
+                if mask and N < 16:
+                    continue
+                d = _desc(B, H, H, cs, N, out_c=(8 if N < 8 else None), mask=mask)
+                assert lib.ksmi_conv_dispatch_info(C.byref(d), DT[BF], info) == 0
+                assert info[1] == 1, (B, H, cs, N, mask, list(info))

@@ -22,13 +22,10 @@ def dev():
 
 @pytest.fixture(params=["256", "3"])
 def cus(request):
-    old = os.environ.get("KSMI_IGEMM3_CUS")
-    os.environ["KSMI_IGEMM3_CUS"] = request.param
+    from kurosiwo_amd import _lib
+    _lib.set_knob("KSMI_IGEMM3_CUS", request.param)      # (a run-time knob of the launcher: include/ksmi.h ksmi_set_knob)
     yield request.param
-    if old is None:
-        os.environ.pop("KSMI_IGEMM3_CUS", None)
-    else:
-        os.environ["KSMI_IGEMM3_CUS"] = old
+    _lib.set_knob("KSMI_IGEMM3_CUS", None)
 
 
 def q(t):

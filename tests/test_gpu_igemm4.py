@@ -39,23 +39,20 @@ def _variants(N):
 
 
 class _Env:
+    """run-time knobs of the launchers (include/ksmi.h ksmi_set_knob): set for the block, back to the built-in defaults after it"""
+
     def __init__(self, **kv):
         self.kv = kv
 
     def __enter__(self):
-        self.old = {k: os.environ.get(k) for k in self.kv}
+        from kurosiwo_amd import _lib
         for k, v in self.kv.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+            _lib.set_knob(k, v)
 
     def __exit__(self, *a):
-        for k, v in self.old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+        from kurosiwo_amd import _lib
+        for k in self.kv:
+            _lib.set_knob(k, None)
 
 
 CFGS = [

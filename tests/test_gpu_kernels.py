@@ -233,13 +233,9 @@ def test_wgrad3_ring_depths(dev, cfg, nst):
     dyd = Fk.to_nhwc(dy.to(dev), dtype)
 
     def run(depth):
-        old = {k: os.environ.get(k) for k in ("KSMI_WGRAD3_NST", "KSMI_WGRAD3_WGS")}
-        os.environ["KSMI_WGRAD3_NST"], os.environ["KSMI_WGRAD3_WGS"] = depth, cfg["wgs"]
-        try:
+        from kurosiwo_amd import _lib
+        with _lib.knobs(KSMI_WGRAD3_NST=depth, KSMI_WGRAD3_WGS=cfg["wgs"]):      # (run-time knobs: include/ksmi.h ksmi_set_knob)
             return Fk.conv3x3_wgrad(xd, dyd, affine=aff).cpu()
-        finally:
-            for k, v in old.items():
-                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
 
     dw = run(nst)
     err = float((dw - wr.grad).abs().max() / wr.grad.abs().max())

@@ -10,8 +10,9 @@ from kurosiwo_amd.runtime import SrcSpec, make_wgrad
 
 
 def _nsplit(B, H, cs, N, **env):
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update({k: str(v) for k, v in env.items()})
+    from kurosiwo_amd import _lib
+    for k, v in env.items():
+        _lib.set_knob(k, v)                                       # (run-time knobs of the launcher: include/ksmi.h ksmi_set_knob)
     try:
         dt = torch.bfloat16
         xs = [torch.empty((1,), dtype=dt) for _ in cs]          # (pointers only: the geometry reads shapes from the descriptor)
@@ -26,8 +27,8 @@ def _nsplit(B, H, cs, N, **env):
         assert ws % (9 * K * npad * 4) == 0
         return d.nsplit
     finally:
-        for k, v in old.items():
-            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+        for k in env:
+            _lib.set_knob(k, None)
 
 
 def _tiles(K, N):
