@@ -19,7 +19,7 @@ import sys
 import time
 
 if int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("KSMI_DP_FORCE"):
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "7")     # five streams under data parallelism: see kurosiwo_amd/__init__.py
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "7")     # five streams under data parallelism: kurosiwo_amd/distributed.py set_hw_queues (before the HIP runtime starts)
 
 import torch  # noqa: E402
 

@@ -19,6 +19,23 @@ def env_world():
     return int(os.environ.get("WORLD_SIZE", "1"))
 
 
+def set_hw_queues():
+    """Data-parallel runs add two streams to the three of the train step (the bucket issue stream and ProcessGroupNCCL's own).  The HIP
+    runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4): with five streams on four queues two streams of the step
+    share a queue and lose their concurrency -- measured on MI355X, SNUNet bs 32, ONE-rank RCCL (no collective in flight, so a guess
+    until two ranks have run): +7 % step time at 4 or 5 queues, +2 % at 6 or 7, +14 % at 8 (profiles/r05_dp_hw_queues.txt).
+    Called by the entry points (main.py through init_distributed, bench.py), not at package import: it only defaults the variable
+    (an explicit setting wins), and says so when the HIP runtime is already up and the setting can no longer take effect."""
+    if "GPU_MAX_HW_QUEUES" in os.environ:
+        return
+    if torch.cuda.is_available() and torch.cuda.is_initialized():
+        import warnings
+        warnings.warn("kurosiwo_amd: the HIP runtime was initialised before init_distributed(); GPU_MAX_HW_QUEUES=7 (five streams under "
+                      "data parallelism) cannot be applied any more -- export it in the launcher's environment")
+        return
+    os.environ["GPU_MAX_HW_QUEUES"] = "7"
+
+
 def init_distributed(configs=None):
     """Join the process group described by the torchrun environment (no-op for a single process).  Returns (rank, local_rank, world)
     and, when `configs` is given, records them and points configs['device'] at this rank's GPU."""
@@ -27,6 +44,7 @@ def init_distributed(configs=None):
     # KSMI_DP_FORCE=1: join a ONE-rank group as well, so that the collective path (RCCL communicator, device_id binding, bucket hooks,
     # stream joins) runs on a single GPU -- tests/test_gpu_dp.py::test_main_entry_on_the_rccl_backend_one_rank
     if (world > 1 or os.environ.get("KSMI_DP_FORCE")) and not dist.is_initialized():
+        set_hw_queues()
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         # KSMI_DIST_BACKEND=gloo: several ranks on ONE GPU (the single-GPU test box; RCCL refuses duplicate devices)

@@ -13,6 +13,22 @@ from . import _lib
 from .runtime import stream_ptr
 
 
+# Generation of every parameter arena a fused optimiser has written (keyed by the arena's base pointer): EVERY step_arena call bumps
+# it, mirror or not, whichever plan or train step drove it.  The plans' bf16 operand copies (plan_base.mirror_written /
+# _mirror_is_fresh) are fresh only while the generation still has the value their own mirrored step recorded: the optimiser writes the
+# parameters through raw pointers, which torch's version counter never sees, so a second plan of the same model that steps in between
+# would otherwise leave the first plan's copy one step stale.
+_ARENA_GEN = {}
+
+
+def arena_generation(p_ptr):
+    return _ARENA_GEN.get(int(p_ptr), 0)
+
+
+def _bump_generation(p_ptr):
+    _ARENA_GEN[int(p_ptr)] = _ARENA_GEN.get(int(p_ptr), 0) + 1
+
+
 def _arena_of(params):
     """(base_ptr, numel) of the flat fp32 arena the tensors are views of, in order, else None.  The arena is taken from the
     views' common storage (model.flat_params / flat_grads), so its numel is the model's own (SNUNet aligns its views to 4
@@ -80,6 +96,7 @@ class FusedAdam(_FlatOptimizer):
         (ksmi_adam_step_mirror; the plans' operand copy for the token GEMMs).  Returns True when it did."""
         g = self.param_groups[0]
         st = self.flat_state(n, device)
+        _bump_generation(p_ptr)
         if mirror:
             _lib.check(_lib.load().ksmi_adam_step_mirror(p_ptr, g_ptr, st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), n,
                                                          st["step"].data_ptr(), g["lr"], g["betas"][0], g["betas"][1], g["eps"],
@@ -117,5 +134,6 @@ class FusedSGD(_FlatOptimizer):
     def step_arena(self, p_ptr, g_ptr, n, device, grad_scale=1.0):
         g = self.param_groups[0]
         st = self.flat_state(n, device)
+        _bump_generation(p_ptr)
         _lib.check(_lib.load().ksmi_sgd_step(p_ptr, g_ptr, st["momentum_buffer"].data_ptr(), n, st["step"].data_ptr(),
                                              g["lr"], g["momentum"], g["weight_decay"], grad_scale, stream_ptr()), "sgd_step")

@@ -61,11 +61,20 @@ class PlanBase:
         return self.wb.data_ptr()
 
     def mirror_written(self):
-        self._mirror_version = self.m.flat_params._version
+        """the optimiser step that just ran wrote THIS plan's operand copy: record the arena's generation (optim.arena_generation: bumped by
+        every fused optimiser step on the arena, whichever plan drove it) and torch's version counter (bumped by in-place torch edits)"""
+        from .optim import arena_generation
+        fp = self.m.flat_params
+        self._mirror_version = (arena_generation(fp.data_ptr()), fp._version)
 
     def _mirror_is_fresh(self):
+        """True once: the last write of the parameters was this plan's own mirrored step.  A step of ANOTHER plan of the same model (a
+        different batch shape: trainers rebuild their step when B changes, the plans stay cached in model._plans) bumps the generation
+        and writes only ITS copy, so this plan casts again; so does any in-place torch edit of a parameter."""
+        from .optim import arena_generation
         v, self._mirror_version = getattr(self, "_mirror_version", None), None
-        return v is not None and v == self.m.flat_params._version
+        fp = self.m.flat_params
+        return v is not None and v == (arena_generation(fp.data_ptr()), fp._version)
 
     def _wb_ptr(self, key):
         return self.wb.data_ptr() + 2 * self.m._poff[key]

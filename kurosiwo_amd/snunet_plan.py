@@ -13,7 +13,7 @@ import os
 import torch
 
 from . import _lib
-from .runtime import DT, Act, SrcSpec, conv_grid_m, conv_stats_rows, make_conv, make_pack, make_wgrad, packed_weight_numel, stream_ptr
+from .runtime import DT, Act, SrcSpec, conv_grid_m, conv_npad, conv_stats_rows, make_conv, make_pack, make_wgrad, packed_weight_numel, stream_ptr
 from .snunet import BN_EPS, BN_MOMENTUM
 
 
@@ -366,7 +366,7 @@ class SNUNetPlan:
         return acc
 
     def _packed(self, key, table, taps, N, n_mod, sK, sN, sD, sT, flip):
-        Npad = (N + 15) // 16 * 16
+        Npad = conv_npad(N)                          # (= ksmi_conv_desc.Npad of the layer: 32 columns below 16 channels, runtime.conv_npad)
         out = torch.empty(packed_weight_numel(table, taps, Npad, self.dtype), dtype=self.dtype, device=self.dev)
         d = make_pack(self.m._p(key), out, table, taps, N, Npad, n_mod, sK, sN, sD, sT, flip)
         self.keep += [d, out]
@@ -457,7 +457,7 @@ class SNUNetPlan:
         srcs = [SrcSpec(r, cj) for (r, cj, _, _, _) in cons]
         acc = act.take_acc_flag()
         d, table = make_conv(srcs, [(act.grad(), Cc, 0, 0, Cc, acc)], act.grad(), None, None, B, H, W, H, W, 3, 3, 1, 1, Cc, self.dtype)
-        Npad = (Cc + 15) // 16 * 16
+        Npad = conv_npad(Cc)
         wpk = torch.empty(packed_weight_numel(table, 9, Npad, self.dtype), dtype=self.dtype, device=self.dev)
         kc = 32 if self.dtype == torch.bfloat16 else 16
         slab = 9 * Npad * kc
@@ -614,7 +614,7 @@ class SNUNetPlan:
         P = lambda s: m._p(f"{name}.{s}").data_ptr()
         G = lambda s: m._g(f"{name}.{s}").data_ptr()
         Bf = lambda s: m._b(f"{name}.{s}").data_ptr()
-        Npad = (Cc + 15) // 16 * 16
+        Npad = conv_npad(Cc)
         sS, sR = self._sname("stats"), self._sname("red")             # per-lane scratch (this block's lane, forward and backward)
         stats = (lambda: self.scr(sS)) if training else (lambda: None)
 

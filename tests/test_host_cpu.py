@@ -239,6 +239,20 @@ def test_mirror_freshness_and_skip_if_without_a_gpu(monkeypatch):
     with torch.no_grad():
         view.mul_(2.0)                                           # load_state_dict / init: an in-place op on a view of the arena
     assert p._mirror_is_fresh() is False
+    # two cached plans of ONE model (a batch-shape change rebuilds the train step, the plans stay in model._plans): the optimiser writes
+    # the parameters through raw pointers, which torch's version counter never sees -- the arena generation every fused step bumps
+    # does (plan A must cast again after plan B stepped, or it runs one optimiser step stale)
+    from kurosiwo_amd import optim
+    a, b = P(), P()
+    b.m = a.m                                                    # the same arena
+    optim._bump_generation(a.m.flat_params.data_ptr()); a.mirror_written()          # step on A (mirrored)
+    assert a._mirror_is_fresh() is True
+    optim._bump_generation(a.m.flat_params.data_ptr()); a.mirror_written()          # step on A again ...
+    optim._bump_generation(a.m.flat_params.data_ptr()); b.mirror_written()          # ... then a step on B: only wb_B was written
+    assert a._mirror_is_fresh() is False and b._mirror_is_fresh() is True
+    optim._bump_generation(a.m.flat_params.data_ptr()); a.mirror_written()          # an UNMIRRORED step of anything else afterwards (SGD, the autograd path)
+    optim._bump_generation(a.m.flat_params.data_ptr())
+    assert a._mirror_is_fresh() is False
     monkeypatch.setenv("KSMI_ADAM_MIRROR", "0")
     assert p.mirror_ptr() is None
     monkeypatch.delenv("KSMI_ADAM_MIRROR")
