@@ -375,6 +375,13 @@ int ksmi_ce_dice_backward(const float* logits, const int64_t* labels, const floa
  * utilities/utilities.py:228-265. */
 int ksmi_argmax_confusion(const float* logits, const int64_t* labels, int64_t* pred /* or NULL */, int64_t* cm,
                           int B, int C, int HW, int ignore_index, void* stream);
+/* (ABI 7) the same pass with per-sample GROUP tables -- the per-AOI and per-climate-zone metrics of the evaluation loops
+ * (training/change_detection_trainer.py:331-337, 437-472: one torchmetrics object per activation id / zone, updated sample by sample):
+ * sample b also adds its counts to cms_a[slot_a[b]][4][4] and cms_b[slot_b[b]][4][4] (device int32 slots, < 0: the sample belongs to
+ * no group of that table; a NULL table is skipped; cm may be NULL).  One launch per batch whatever the number of groups. */
+int ksmi_argmax_confusion_grouped(const float* logits, const int64_t* labels, int64_t* pred /* or NULL */, int64_t* cm /* or NULL */,
+                                  const int32_t* slot_a, int64_t* cms_a, const int32_t* slot_b, int64_t* cms_b,
+                                  int B, int C, int HW, int ignore_index, void* stream);
 
 /* ---------------------------------------------------------------------------------
  * Optimisers: torch.optim.Adam(lr) / SGD(momentum, weight_decay) as used at

@@ -150,6 +150,7 @@ SIGNATURES = {
     "ksmi_ce_dice_forward": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp]),
     "ksmi_ce_dice_backward": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "ksmi_argmax_confusion": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "ksmi_argmax_confusion_grouped": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ksmi_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _f, _f, _f, _f, _f, _f, _vp]),
     "ksmi_adamw_step": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _f, _f, _f, _f, _f, _f, _vp]),
     "ksmi_adam_step_mirror": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _f, _f, _f, _f, _f, _f, _i, _vp, _vp]),

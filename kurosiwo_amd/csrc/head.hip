@@ -610,6 +610,34 @@ __global__ __launch_bounds__(256) void argmax_confusion_kernel(const float* logi
   if (threadIdx.x < 16 && hist[threadIdx.x]) atomicAdd(&cm[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
 }
 
+// the same pass with per-sample group tables (per-AOI / per-climate-zone metrics of the eval loops, change_detection_trainer.py:331-337,
+// 437-472): sample b also adds its counts to cms_a[slot_a[b]] and cms_b[slot_b[b]] (slot < 0 or table null: no such group) -- one launch per
+// batch instead of one per sample and group
+__global__ __launch_bounds__(256) void argmax_confusion_grouped_kernel(const float* logits, const int64_t* labels, int64_t* pred,
+                                                                       unsigned long long* cm, const int32_t* slot_a, unsigned long long* cms_a,
+                                                                       const int32_t* slot_b, unsigned long long* cms_b, int C, int HW,
+                                                                       int ignore_index) {
+  __shared__ unsigned int hist[16];
+  if (threadIdx.x < 16) hist[threadIdx.x] = 0;
+  __syncthreads();
+  const int b = blockIdx.y;
+  const float* lg = logits + (int64_t)b * C * HW;
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += gridDim.x * blockDim.x) {
+    float m = lg[p]; int am = 0;
+    for (int k = 1; k < C; ++k) { const float v = lg[(int64_t)k * HW + p]; if (v > m) { m = v; am = k; } }
+    if (pred) pred[(int64_t)b * HW + p] = am;
+    const int64_t t = labels[(int64_t)b * HW + p];
+    if (t != ignore_index && t >= 0 && t < 4 && am < 4) atomicAdd(&hist[t * 4 + am], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < 16 && hist[threadIdx.x]) {
+    const unsigned long long v = hist[threadIdx.x];
+    if (cm) atomicAdd(&cm[threadIdx.x], v);
+    if (cms_a && slot_a[b] >= 0) atomicAdd(&cms_a[(int64_t)slot_a[b] * 16 + threadIdx.x], v);
+    if (cms_b && slot_b[b] >= 0) atomicAdd(&cms_b[(int64_t)slot_b[b] * 16 + threadIdx.x], v);
+  }
+}
+
 bool ecam_c_ok(int C, int dtype) {
   const int vec = dtype == KSMI_BF16 ? 8 : 4;
   return C % 16 == 0 && (4 * C) / vec <= kThreads && kThreads % (C / vec) == 0;
@@ -772,6 +800,17 @@ int ksmi_argmax_confusion(const float* logits, const int64_t* labels, int64_t* p
   const dim3 grid((HW + 255) / 256 > 128 ? 128 : (HW + 255) / 256, B);
   hipLaunchKernelGGL(argmax_confusion_kernel, grid, dim3(256), 0, (hipStream_t)stream, logits, labels, pred, (unsigned long long*)cm, C, HW, ignore_index);
   return ksmi_check_launch("argmax_confusion");
+}
+
+int ksmi_argmax_confusion_grouped(const float* logits, const int64_t* labels, int64_t* pred, int64_t* cm, const int32_t* slot_a,
+                                  int64_t* cms_a, const int32_t* slot_b, int64_t* cms_b, int B, int C, int HW, int ignore_index,
+                                  void* stream) {
+  if (!logits || !labels || C < 1 || C > 4) return ksmi_fail(KSMI_E_ARG, "argmax_confusion_grouped: 1 <= C <= 4");
+  if ((cms_a && !slot_a) || (cms_b && !slot_b)) return ksmi_fail(KSMI_E_ARG, "argmax_confusion_grouped: a group table without its slot array");
+  const dim3 grid((HW + 255) / 256 > 128 ? 128 : (HW + 255) / 256, B);
+  hipLaunchKernelGGL(argmax_confusion_grouped_kernel, grid, dim3(256), 0, (hipStream_t)stream, logits, labels, pred, (unsigned long long*)cm,
+                     slot_a, (unsigned long long*)cms_a, slot_b, (unsigned long long*)cms_b, C, HW, ignore_index);
+  return ksmi_check_launch("argmax_confusion_grouped");
 }
 
 }  // extern "C"

@@ -77,6 +77,7 @@ class BucketedAllReduce:
         self.handles = []
         self.issued = []
         self.issue_stream = None
+        self._events = {}                  # writer stream handle -> its reusable event (_issue)
         self.writer_streams = None         # callable -> streams whose work a ready bucket may depend on
 
     def world(self):
@@ -109,7 +110,12 @@ class BucketedAllReduce:
         if self.issue_stream is None:
             self.issue_stream = torch.cuda.Stream(device=self.flat.device)
         for s in streams:
-            ev = torch.cuda.Event()
+            # one event per writer stream for the life of the reducer: hipStreamWaitEvent captures the record it finds when it is
+            # enqueued, so the event may be re-recorded for the next bucket as soon as this call returns (no create / destroy per
+            # bucket per stream per step)
+            ev = self._events.get(s.cuda_stream)
+            if ev is None:
+                ev = self._events[s.cuda_stream] = torch.cuda.Event()
             ev.record(s)
             self.issue_stream.wait_event(ev)
         with torch.cuda.stream(self.issue_stream):

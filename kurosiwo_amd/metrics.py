@@ -37,6 +37,58 @@ class ConfusionMetrics:
         return metrics_from_cm(self.cm)
 
 
+class GroupedConfusion:
+    """The overall confusion matrix of an evaluation loop plus up to two families of per-group matrices (per activation id, per climate
+    zone: training/change_detection_trainer.py:331-337, 437-472 keep one torchmetrics object per group and update it sample by sample),
+    all accumulated by ONE launch per batch (ksmi_argmax_confusion_grouped): the per-sample group keys arrive with the batch on the host
+    (Dataset.py: `clz`, `activ`), become int32 slot indices there, and ride to the device in one small asynchronous copy -- no
+    per-sample launch, slice or host synchronisation.  `families` = [keys of family a, keys of family b]; groups[f][key] is a
+    ConfusionMetrics whose .cm is a VIEW of the family's [G, 4, 4] table, so compute() / all-reduce code is unchanged."""
+
+    def __init__(self, device, families=(), ignore_index=3):
+        if len(families) > 2:
+            raise _lib.KsmiError("GroupedConfusion: at most two group families per launch")
+        self.total = ConfusionMetrics(device, ignore_index=ignore_index)
+        self.ignore_index = ignore_index
+        self.tables, self.index, self.groups = [], [], []
+        for keys in families:
+            keys = list(keys)
+            t = torch.zeros((max(len(keys), 1), 4, 4), dtype=torch.int64, device=device)
+            self.tables.append(t)
+            self.index.append({k: i for i, k in enumerate(keys)})
+            g = {}
+            for i, k in enumerate(keys):
+                cmx = ConfusionMetrics(device, ignore_index=ignore_index)
+                cmx.cm = t[i]
+                g[k] = cmx
+            self.groups.append(g)
+
+    def update(self, logits, target, keys=()):
+        """keys[f] = the per-sample group key of family f (host sequence / CPU tensor of length B; unknown keys belong to no group)"""
+        require_gpu(logits)
+        B, Cc, H, W = logits.shape
+        logits = logits.contiguous().float()
+        if target.dtype != torch.int64:
+            target = target.long()
+        slots = []
+        for f, table in enumerate(self.tables):
+            if f < len(keys) and keys[f] is not None and self.index[f]:
+                host = torch.tensor([self.index[f].get(int(k), -1) for k in keys[f]], dtype=torch.int32)
+                if host.numel() != B:
+                    raise _lib.KsmiError(f"GroupedConfusion: {host.numel()} group keys for a batch of {B}")
+                slots.append((host.to(logits.device, non_blocking=True), table))
+            else:
+                slots.append((None, None))
+        while len(slots) < 2:
+            slots.append((None, None))
+        (sa, ta), (sb, tb) = slots
+        P = lambda t: t.data_ptr() if t is not None else None
+        _lib.check(_lib.load().ksmi_argmax_confusion_grouped(logits.data_ptr(), target.contiguous().data_ptr(), None, self.total.cm.data_ptr(),
+                                                             P(sa), P(ta), P(sb), P(tb), B, Cc, H * W, self.ignore_index, stream_ptr()),
+                   "argmax_confusion_grouped")
+        self._keep = (sa, sb, logits, target)      # (alive until the next update: the launch is asynchronous)
+
+
 def metrics_from_cm(cm):
     cm = cm.to(torch.float64).cpu()
     tp = cm.diag()

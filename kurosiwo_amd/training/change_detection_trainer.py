@@ -16,7 +16,7 @@ import torch
 from .. import distributed as D
 from ..config import init_lr_scheduler
 from ..loss import create_loss
-from ..metrics import ConfusionMetrics, metrics_from_cm
+from ..metrics import ConfusionMetrics, GroupedConfusion, metrics_from_cm
 from ..optim import FusedAdam, FusedAdamW, FusedSGD
 from ..synthetic import cd_inputs
 from ..trainer import CDTrainStep
@@ -161,9 +161,9 @@ def _rng_words(model):
 
 def eval_change_detection(model, loader, settype, configs=None, model_configs=None):
     dev = torch.device(configs["device"])
-    metrics = ConfusionMetrics(dev)
-    per_aoi = {a: ConfusionMetrics(dev) for a in getattr(loader.dataset, "activations", [])} if configs.get("log_AOI_metrics") else {}
-    per_zone = {z: ConfusionMetrics(dev) for z in (1, 2, 3)} if configs.get("log_zone_metrics") else {}
+    grouped = GroupedConfusion(dev, [list(getattr(loader.dataset, "activations", [])) if configs.get("log_AOI_metrics") else [],
+                                     [1, 2, 3] if configs.get("log_zone_metrics") else []])
+    metrics, (per_aoi, per_zone) = grouped.total, grouped.groups
     criterion = create_loss(configs, mode="val")
     model.to(dev)
     model.eval()
@@ -188,13 +188,9 @@ def eval_change_detection(model, loader, settype, configs=None, model_configs=No
                 output = output[-1]
             total_loss += criterion(output, mask) * xA.size(0)
             nsamples += xA.size(0)
-            metrics.update(output, mask)
-            for group, key in ((per_aoi, activ), (per_zone, clz)):
-                if group:
-                    for i in range(xA.size(0)):
-                        k = int(key[i])
-                        if k in group:
-                            group[k].update(output[i:i + 1], mask[i:i + 1])
+            # overall + per-AOI + per-zone confusion matrices in ONE launch (metrics.GroupedConfusion): the group keys of the batch are
+            # host data, turned into device slot indices without a synchronisation
+            grouped.update(output, mask, (activ if per_aoi else None, clz if per_zone else None))
     ns = torch.tensor([float(nsamples)], dtype=torch.float64, device=dev)
     D.all_reduce_sum_(metrics.cm, total_loss, ns, *[g.cm for g in list(per_aoi.values()) + list(per_zone.values())])
     nsamples = int(ns.item())

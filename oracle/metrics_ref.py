@@ -10,7 +10,8 @@ PARITY UNPINNED BY IMPORT: torchmetrics (0.11.4, requirements.txt:3) is a
 third-party dependency absent from /root/reference and from this image; the
 formulas below restate its documented multiclass stat-scores semantics
 (target == ignore_index pixels are dropped; 0/0 -> 0) and are pinned by
-hand-computed cases in tests/test_metrics_oracle.py.  Pure numpy integers.
+hand-computed cases in tests/test_host_cpu.py (test_metrics_*; the per-group
+kernel is held to these functions in tests/test_gpu_eval.py).  Pure numpy integers.
 """
 import numpy as np
 

@@ -147,6 +147,13 @@ def test_eval_loops_skip_an_empty_rank_slice(monkeypatch):
             z = torch.zeros(4)
             return {"accuracy": 0.0, "f1": z, "iou": z, "miou": 0.0, "precision": z, "recall": z}
 
+    class GC:                                                            # (metrics.GroupedConfusion's surface: total + two group families)
+        def __init__(self, dev, families=()):
+            self.total, self.groups = CM(dev), [{}, {}]
+
+        def update(self, out, mask, keys=()):
+            self.total.update(out, mask)
+
     class Net(torch.nn.Module):
         def forward(self, *xs):
             return torch.zeros((xs[0].shape[0], 3, 16, 16))
@@ -159,6 +166,7 @@ def test_eval_loops_skip_an_empty_rank_slice(monkeypatch):
     seen = []
     for mod in (T, S):
         monkeypatch.setattr(mod, "ConfusionMetrics", CM)
+        monkeypatch.setattr(mod, "GroupedConfusion", GC)
         monkeypatch.setattr(mod, "create_loss", lambda configs, mode="val": (lambda out, mask: torch.zeros(())))
         monkeypatch.setattr(mod, "_print_metrics", lambda *a, **k: None, raising=False)
     monkeypatch.setattr(T, "_eval_fusion", lambda *a: False)

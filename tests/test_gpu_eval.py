@@ -33,7 +33,7 @@ def test_eval_change_detection_returns_the_oracle_metrics(tmp_path, monkeypatch,
     class A:
         inputs, dem, slope = ["pre_event_1", "post_event"], False, False
     configs = update_config(configs, A)
-    configs.update(batch_size=4, precision="fp32", evaluate_water=True, log_AOI_metrics=True, device="cuda:0")
+    configs.update(batch_size=4, precision="fp32", evaluate_water=True, log_AOI_metrics=True, log_zone_metrics=True, device="cuda:0")
     _, val_loader, _ = prepare_loaders(configs)
     sd = seeded_fill_(R.new_state_dict(2, 3, 32))
     model = SNUNet_ECAM(2, 3, base_channel=32, precision="fp32")
@@ -43,7 +43,7 @@ def test_eval_change_detection_returns_the_oracle_metrics(tmp_path, monkeypatch,
     printed = capsys.readouterr().out
     # ---- oracle: same tiles, same order
     cm = np.zeros((4, 4), np.int64)
-    per_aoi = {}
+    per_aoi, per_zone = {}, {}
     for batch in val_loader:
         (xA, xB), mask = cd_inputs(batch, configs["inputs"], False)
         with torch.no_grad():
@@ -52,6 +52,8 @@ def test_eval_change_detection_returns_the_oracle_metrics(tmp_path, monkeypatch,
         cm += metrics_ref.confusion_matrix(pred, mask.numpy())
         for i, a in enumerate(batch[-1].tolist()):
             per_aoi[a] = per_aoi.get(a, 0) + metrics_ref.confusion_matrix(pred[i], mask[i].numpy())
+        for i, z in enumerate(batch[-2].tolist()):
+            per_zone[z] = per_zone.get(z, 0) + metrics_ref.confusion_matrix(pred[i], mask[i].numpy())
     ref = metrics_ref.metrics_from_cm(cm)
     # fp32 logits agree to ~1e-6: a handful of near-tie pixels may flip -> a few 1e-4 percentage points
     assert np.abs(acc.numpy() - 100 * ref["accuracy"]).max() < 2e-3
@@ -69,3 +71,48 @@ def test_eval_change_detection_returns_the_oracle_metrics(tmp_path, monkeypatch,
         mo = re.search(rf"Validation AOI {a}: mIoU ([0-9.]+)", printed)
         assert mo, (a, printed)
         assert abs(float(mo.group(1)) - 100 * metrics_ref.metrics_from_cm(c)["miou"]) < 6e-3
+    for z, c in per_zone.items():
+        if z in (1, 2, 3) and int(c.sum()) > 0:
+            mo = re.search(rf"Validation climate zone {z}: mIoU ([0-9.]+)", printed)
+            assert mo, (z, printed)
+            assert abs(float(mo.group(1)) - 100 * metrics_ref.metrics_from_cm(c)["miou"]) < 6e-3
+
+
+def test_grouped_confusion_one_launch_equals_per_sample_oracle():
+    """ksmi_argmax_confusion_grouped (metrics.GroupedConfusion): the overall matrix and two families of per-group matrices from ONE launch
+    per batch equal the integer oracle applied sample by sample (the reference keeps one torchmetrics object per activation id / zone:
+    cd_trainer:331-337, 437-472); keys that name no group, ties (lowest index wins) and ignored pixels included.  Bit-exact (integers)."""
+    from kurosiwo_amd.metrics import GroupedConfusion
+    from oracle import metrics_ref
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(7)
+    B, C, H, W = 7, 3, 33, 41
+    aoi_keys, zone_keys = [130, 321, 470], [1, 2, 3]
+    gc = GroupedConfusion(dev, [aoi_keys, zone_keys])
+    want_total = np.zeros((4, 4), np.int64)
+    want_a = {k: np.zeros((4, 4), np.int64) for k in aoi_keys}
+    want_z = {k: np.zeros((4, 4), np.int64) for k in zone_keys}
+    for it in range(3):
+        logits = torch.randn((B, C, H, W), generator=g)
+        logits[:, :, ::5, ::3] = 0.25                                           # ties across all classes: argmax = class 0
+        mask = torch.randint(0, 4, (B, H, W), generator=g)
+        activ = torch.tensor([130, 321, 999, 470, 130, 130, 321])               # 999: no such group
+        clz = torch.tensor([1, 2, 3, 0, 2, 2, 1])                               # 0: no such zone
+        gc.update(logits.to(dev), mask.to(dev), (activ, clz))
+        pred = metrics_ref.argmax_lowest_index(logits.numpy())
+        for i in range(B):
+            c = metrics_ref.confusion_matrix(pred[i], mask[i].numpy())
+            want_total += c
+            if int(activ[i]) in want_a:
+                want_a[int(activ[i])] += c
+            if int(clz[i]) in want_z:
+                want_z[int(clz[i])] += c
+    assert np.array_equal(gc.total.cm.cpu().numpy(), want_total)
+    for k in aoi_keys:
+        assert np.array_equal(gc.groups[0][k].cm.cpu().numpy(), want_a[k]), k
+    for k in zone_keys:
+        assert np.array_equal(gc.groups[1][k].cm.cpu().numpy(), want_z[k]), k
+    # one family only / none: the same entry point
+    gc1 = GroupedConfusion(dev, [[], zone_keys])
+    gc1.update(logits.to(dev), mask.to(dev), (None, clz))
+    assert int(gc1.total.cm.sum()) == int((mask != 3).sum()) and int(gc1.tables[1].sum()) == int((mask[clz != 0] != 3).sum())
