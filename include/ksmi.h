@@ -45,6 +45,34 @@ int ksmi_set_knob(const char* name, const char* value);
 int ksmi_chunk_elems(int dtype);
 
 /* ---------------------------------------------------------------------------------
+ * Launch-list executor (ABI 7, csrc/runlist.hip).  No reference counterpart: the reference's step is an autograd graph walked by
+ * torch; here a step is a static list of prepared entry-point calls (the plan modules of kurosiwo_amd), and one ksmi_run_list call issues a
+ * whole segment of it on the streams of the step instead of one host-language call per launch.
+ *   ksmi_op.kind CALL: fn(args..., stream) through the typed thunk `sig` (ksmi_thunk_id of its signature string: one letter per
+ *     argument without the trailing stream -- p pointer, i int, u unsigned, l int64, z size_t, f float, d double); args = nargs 64-bit
+ *     slots (integers / pointers by value, float in the low 32 bits, double by bit pattern).  lane 0 | 1 = compute lane; side 1 | 2 =
+ *     the launch goes to that weight-gradient stream behind an event recorded on its lane's stream; tag >= 0 = record an event
+ *     behind it that KSMI_OP_WAIT_SIDE(tag) consumes.
+ *   ORDER: lane b waits for everything lane a was handed.  WAIT_SIDE: lane waits for the tagged side launch (tag < 0: the whole side stream).
+ * `skip` (or NULL): one byte per op, non-zero = leave that CALL out this time.  On failure *failed_at = index of the op. */
+#define KSMI_OP_CALL 0
+#define KSMI_OP_ORDER 1
+#define KSMI_OP_WAIT_SIDE 2
+typedef struct ksmi_op {
+  int32_t kind, sig, lane, side, tag, a, b, nargs;
+  const void* fn;
+  const uint64_t* args;
+} ksmi_op;
+int ksmi_thunk_id(const char* signature);                       /* -1: no thunk for that signature */
+void* ksmi_runner_create(void);
+int ksmi_runner_destroy(void* runner);
+/* lane1 NULL: one compute lane; side NULL: weight gradients stay on their lane's stream */
+int ksmi_runner_set_streams(void* runner, void* main_stream, void* lane1, void* side, void* side2);
+int ksmi_run_list(void* runner, const ksmi_op* ops, int first, int last, const uint8_t* skip, int32_t* failed_at);
+/* end of a step: main waits for every other stream that was handed work; tagged events are forgotten */
+int ksmi_runner_join(void* runner);
+
+/* ---------------------------------------------------------------------------------
  * Implicit-GEMM convolution family (MFMA).  Replaces nn.Conv2d / nn.ConvTranspose2d
  * forward + input-gradient + weight-gradient:
  *   models/snunet.py:15-17 (3x3 convs), :41 (ConvTranspose2d k2 s2), :132-146

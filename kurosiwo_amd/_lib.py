@@ -84,6 +84,13 @@ class WgradDesc(C.Structure):
                 ("bias_grad", C.c_void_p), ("bias_accumulate", C.c_int32)]
 
 
+class Op(C.Structure):
+    """ksmi_op (include/ksmi.h): one entry of a compiled launch list"""
+    _fields_ = [(k, C.c_int32) for k in ("kind", "sig", "lane", "side", "tag", "a", "b", "nargs")] + [("fn", C.c_void_p), ("args", C.c_void_p)]
+
+
+OP_CALL, OP_ORDER, OP_WAIT_SIDE = 0, 1, 2
+
 _vp, _i, _i64, _f, _d, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_size_t
 _P4 = C.c_void_p * 4
 
@@ -94,6 +101,12 @@ SIGNATURES = {
     "ksmi_hbm_probe": (_i, [_i, _vp, _vp, _vp, C.c_size_t, _vp, _vp]),
     "ksmi_last_error": (C.c_char_p, []),
     "ksmi_set_knob": (_i, [C.c_char_p, C.c_char_p]),
+    "ksmi_thunk_id": (_i, [C.c_char_p]),
+    "ksmi_runner_create": (_vp, []),
+    "ksmi_runner_destroy": (_i, [_vp]),
+    "ksmi_runner_set_streams": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "ksmi_run_list": (_i, [_vp, _vp, _i, _i, _vp, C.POINTER(C.c_int32)]),
+    "ksmi_runner_join": (_i, [_vp]),
     "ksmi_conv_dispatch_info": (_i, [C.POINTER(ConvDesc), _i, C.POINTER(C.c_int32)]),
     "ksmi_chunk_elems": (_i, [_i]),
     "ksmi_conv_grid_m": (_i, [C.POINTER(ConvDesc)]),

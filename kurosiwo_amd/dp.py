@@ -121,6 +121,11 @@ class BucketedAllReduce:
         with torch.cuda.stream(self.issue_stream):
             return fn()
 
+    def hook_indices(self):
+        """indices of the backward launch list at which after_launch has a bucket to issue (none while no collective is active: the
+        compiled launch list then runs in one piece, snunet_plan.LaunchList.run)"""
+        return sorted(k for k in self.by_launch if k >= 0) if self.active() else []
+
     def after_launch(self, idx):
         for (s, e, _) in self.by_launch.get(idx, ()):
             self.issued.append((s, e))

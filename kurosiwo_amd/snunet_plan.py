@@ -17,6 +17,62 @@ from .runtime import DT, Act, SrcSpec, conv_grid_m, conv_npad, conv_stats_rows, 
 from .snunet import BN_EPS, BN_MOMENTUM
 
 
+_TAG_IDS = {}
+
+
+def _tag_id(tag):
+    """side-stream tags of the plans (arbitrary hashables) as the small integers ksmi_op carries"""
+    return _TAG_IDS.setdefault(tag, len(_TAG_IDS))
+
+
+def _sig_codes(argtypes):
+    """signature string of tools/gen_thunks.py: one letter per argument (p pointer, i int, u unsigned, l int64, z size_t, f float, d double)"""
+    out = []
+    for t in argtypes:
+        if t in (C.c_void_p, C.c_char_p) or (isinstance(t, type) and (issubclass(t, C._Pointer) or issubclass(t, C.Array))):
+            out.append("p")
+        else:
+            out.append({C.c_int: "i", C.c_int32: "i", C.c_uint32: "u", C.c_int64: "l", C.c_size_t: "z", C.c_float: "f", C.c_double: "d"}[t])
+    return "".join(out)
+
+
+def _slot(code, v, struct):
+    """one prepared argument as the 64-bit slot the call thunks read (include/ksmi.h ksmi_op)"""
+    if hasattr(v, "value") and not hasattr(v, "_obj"):        # a ctypes scalar (c_void_p, c_int, ...)
+        v = v.value
+    if code == "p":
+        if v is None:
+            return 0
+        if isinstance(v, int):
+            return v
+        if hasattr(v, "_obj"):                                # ctypes.byref(x)
+            return C.addressof(v._obj)
+        if isinstance(v, (C.Array, C.Structure)):
+            return C.addressof(v)
+        if isinstance(v, C._Pointer):
+            return C.cast(v, C.c_void_p).value or 0
+        raise _lib.KsmiError(f"launch list: cannot take the address of a {type(v).__name__} argument")
+    if code == "f":
+        return struct.unpack("<I", struct.pack("<f", float(v)))[0]
+    if code == "d":
+        return struct.unpack("<Q", struct.pack("<d", float(v)))[0]
+    return int(v) & 0xFFFFFFFFFFFFFFFF
+
+
+_PLAIN_RUNNERS = {}
+
+
+def _plain_runner(st):
+    """the executor state of single-stream runs (model(x) outside a train step): everything on the caller's current stream"""
+    dev = torch.cuda.current_device() if torch.cuda.is_available() else -1
+    lib = _lib.load()
+    r = _PLAIN_RUNNERS.get(dev)
+    if r is None:
+        r = _PLAIN_RUNNERS[dev] = C.c_void_p(lib.ksmi_runner_create())
+    lib.ksmi_runner_set_streams(r, st, None, None, None)
+    return r
+
+
 class LaunchList:
     """(name, argfn, meta) triples; argfn() is evaluated once, after all scratch buffers exist.
     meta = {"kind": kernel class, "bytes": algorithmic HBM bytes, "flops": 2*MAC} for the roofline, plus the scheduling tags
@@ -52,13 +108,95 @@ class LaunchList:
     def resolve(self, lib):
         self.calls = [(None if name.startswith("@") else getattr(lib, name), tuple(argfn()), name, meta) for name, argfn, meta in self.pending]
 
-    def run(self, timer=None, hook=None, streams=None):
-        """streams = StepStreams or None.  None: every launch on the current stream, in list order (always a valid order; the
+    # ---- compiled form (round 6): the list as an array of ksmi_op walked by ONE C-ABI call per segment (csrc/runlist.hip) instead of one
+    # ctypes call + stream switch + up to three torch event calls per launch in Python (host_issue_ms_per_step: 9 ms of a 14 ms SNUNet
+    # step, 29 of 34 ms for ChangeFormer).  The Python walk below stays for timed runs (a kernel timer brackets single launches), for hooks
+    # without an index list, for SyncBN's collectives, and as the cross-check (KSMI_RUN_LIST=0; tests/test_gpu_graph.py).
+    fast = os.environ.get("KSMI_RUN_LIST", "1") != "0"
+    _compiled = None
+
+    def _compile(self):
+        import struct
+        lib = _lib.load()
+        n = len(self.calls)
+        ops = (_lib.Op * max(n, 1))()
+        slots, where, skips, names, ok = [], [], [], [], True
+        for i, (fn, args, name, meta) in enumerate(self.calls):
+            op = ops[i]
+            op.tag, op.sig = -1, -1
+            op.lane = int(meta.get("lane", 0))
+            names.append(name)
+            if fn is None:
+                if name == "@wait":
+                    op.kind, op.a, op.b = _lib.OP_ORDER, int(args[0]), int(args[1])
+                elif name == "@wait_side":
+                    op.kind, op.tag = _lib.OP_WAIT_SIDE, (-1 if args[0] is None else _tag_id(args[0]))
+                else:
+                    ok = False                   # ("@allreduce": SyncBN's collectives are issued by torch.distributed)
+                continue
+            if name not in _lib.SIGNATURES:       # (a stubbed library in the host-only tests: the Python walk)
+                ok = False
+                continue
+            restype, argtypes = _lib.SIGNATURES[name]
+            codes = _sig_codes(argtypes[:-1])
+            sig = lib.ksmi_thunk_id(codes.encode())
+            if sig < 0 or len(codes) != len(args):
+                raise _lib.KsmiError(f"launch list: no call thunk for {name} ({codes!r}, {len(args)} arguments): re-run tools/gen_thunks.py")
+            op.kind, op.sig, op.nargs = _lib.OP_CALL, sig, len(args)
+            op.fn = C.cast(fn, C.c_void_p).value
+            op.side = (2 if meta.get("side_ix", 0) else 1) if meta.get("side") else 0
+            if op.side and meta.get("side_tag") is not None:
+                op.tag = _tag_id(meta["side_tag"])
+            where.append((i, len(slots)))
+            slots += [_slot(c, v, struct) for c, v in zip(codes, args)]
+            if meta.get("skip_if") is not None:
+                skips.append((i, meta["skip_if"]))
+        arr = (C.c_uint64 * max(len(slots), 1))(*slots)
+        base = C.addressof(arr)
+        for i, off in where:
+            ops[i].args = base + 8 * off
+        self._compiled = {"ops": ops, "slots": arr, "n": n, "skips": skips, "names": names, "ok": ok, "failed": C.c_int32(-1),
+                          "skipbuf": (C.c_uint8 * max(n, 1))() if skips else None}
+        return self._compiled
+
+    def _run_fast(self, hook, hook_at, streams):
+        cp = self._compiled
+        lib = _lib.load()
+        if streams is not None:
+            streams.begin()
+            runner = streams.runner()
+        else:
+            runner = _plain_runner(stream_ptr())
+        skip = None
+        if cp["skips"]:
+            skip = cp["skipbuf"]
+            for i, fn in cp["skips"]:
+                skip[i] = 1 if fn() else 0
+        n = cp["n"]
+        cuts = sorted({i + 1 for i in hook_at if 0 <= i < n} | {n}) if hook is not None else [n]
+        a = 0
+        for b in cuts:
+            rc = lib.ksmi_run_list(runner, cp["ops"], a, b, skip, C.byref(cp["failed"]))
+            if rc != 0:
+                at = cp["failed"].value
+                _lib.check(rc, cp["names"][at] if 0 <= at < n else "ksmi_run_list")
+            if hook is not None and (b - 1) in hook_at:
+                hook(b - 1)
+            a = b
+
+    def run(self, timer=None, hook=None, streams=None, hook_at=None):
+        """hook_at: the list indices at which `hook` has work to do (dp.BucketedAllReduce.hook_indices); with it (or without a hook) and
+        without a timer the compiled list runs (see above).
+        streams = StepStreams or None.  None: every launch on the current stream, in list order (always a valid order; the
         "@wait" entries are no-ops).  With streams: launches of lane 1 go to the second compute stream, launches tagged "side" (the
         weight gradients: nothing on the critical path of the backward pass reads them) to the side stream behind an event recorded
         on the issuing lane's stream at that point of the list, so that independent work fills the machine next to the
         bandwidth-bound BatchNorm / elementwise launches of the critical path; the caller joins (StepStreams.join) before
         anything outside the lists reads the results."""
+        if timer is None and self.fast and self.calls and (hook is None or hook_at is not None):
+            cp = self._compiled or self._compile()
+            if cp["ok"]:
+                return self._run_fast(hook, hook_at or (), streams)
         if streams is not None:
             streams.begin()
         st, cur = stream_ptr(), 0
@@ -130,9 +268,32 @@ class StepStreams:
         self.side_busy = False
         self.events = {}           # side_tag -> event recorded behind that launch on the side stream (LaunchList.add_wait_side)
 
+    _runner = None
+
     def begin(self):
         if self.main is None:
             self.main = torch.cuda.current_stream()
+            if self._runner is not None:
+                self._bind_runner()
+
+    def _bind_runner(self):
+        _lib.load().ksmi_runner_set_streams(self._runner, C.c_void_p(self.main.cuda_stream),
+                                            C.c_void_p(self.lane1.cuda_stream) if self.lanes else None,
+                                            self.side_ptr if self.use_side else None, self.side2_ptr if self.use_side else None)
+
+    def runner(self):
+        """executor state of the compiled launch lists (csrc/runlist.hip) bound to this step's streams; call after begin()"""
+        if self._runner is None:
+            self._runner = C.c_void_p(_lib.load().ksmi_runner_create())
+            self._bind_runner()
+        return self._runner
+
+    def __del__(self):
+        try:
+            if self._runner is not None:
+                _lib.load().ksmi_runner_destroy(self._runner)
+        except Exception:
+            pass
 
     def stream(self, lane):
         return self.main if lane == 0 else self.lane1
@@ -182,6 +343,8 @@ class StepStreams:
 
     def end(self):
         self.join()
+        if self._runner is not None:                 # (the compiled lists keep their own dirty / tag state: main joins the other streams)
+            _lib.check(_lib.load().ksmi_runner_join(self._runner), "ksmi_runner_join")
         self.main = None
         self.events.clear()
         self.side_busy = False

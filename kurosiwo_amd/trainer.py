@@ -160,7 +160,7 @@ class _PlanTrainStep:
             p.logits.data_ptr(), self.labels.data_ptr(), self.cw.data_ptr(), self.with_dice, self.loss_ws.data_ptr(), None,
             p.dlogits.data_ptr(), B, HW, 3, st), "ce_dice_backward"))
         ss = self._streams()
-        p.bwd.run(t, self._after_launch if ss is not None else self.reducer.after_launch, ss)
+        p.bwd.run(t, self._after_launch if ss is not None else self.reducer.after_launch, ss, hook_at=self.reducer.hook_indices())
         if ss is not None:
             ss.end()
         self.reducer.wait()
@@ -256,7 +256,7 @@ class MAETrainStep:
         p.packs.run(t)
         p.fwd.run(t)
         ss = self._streams()
-        p.bwd.run(t, self._after_launch if ss is not None else self.reducer.after_launch, ss)
+        p.bwd.run(t, self._after_launch if ss is not None else self.reducer.after_launch, ss, hook_at=self.reducer.hook_indices())
         if ss is not None:
             ss.end()
         self.reducer.wait()

@@ -159,3 +159,27 @@ def test_lanes_without_the_side_stream_equal_single_stream():
     for a, b in zip(out[0][0], out[1][0]):
         assert torch.equal(a, b), (a.tolist(), b.tolist())
     assert torch.equal(out[0][2], out[1][2]) and torch.equal(out[0][1], out[1][1])
+
+
+@pytest.mark.parametrize("family", ["snunet", "floodvit", "changeformer", "unet"])
+def test_compiled_launch_list_equals_the_python_walk(family, monkeypatch):
+    """snunet_plan.LaunchList: the compiled list (ONE ksmi_run_list call per segment, csrc/runlist.hip: typed call thunks, event ring,
+    tagged side-stream events) issues the same launches on the same streams behind the same dependency edges as the Python walk
+    (KSMI_RUN_LIST=0): multi-stream trajectories equal bit for bit, losses, gradients and parameters."""
+    from kurosiwo_amd import snunet_plan as sp
+    B, S = (16, 224) if family == "floodvit" else (4, 224)
+    data = _batches(4, B, 2, S, 47)
+    out = []
+    for fast in (False, True):
+        monkeypatch.setattr(sp.LaunchList, "fast", fast)
+        m, st = _lane_case(family, B, S, True, False)
+        losses = []
+        for xA, xB, y in data:
+            args = (xA.cuda(), y.cuda()) if family in ("unet", "floodvit") else (xA.cuda(), xB.cuda(), y.cuda())
+            losses.append(st.step(*args).clone())
+        torch.cuda.synchronize()
+        assert (st.plan.bwd._compiled is not None) == fast and (st._ss._runner is not None) == fast
+        out.append((losses, m.flat_params.clone(), m.flat_grads.clone()))
+    for a, b in zip(out[0][0], out[1][0]):
+        assert torch.equal(a, b), (a.tolist(), b.tolist())
+    assert torch.equal(out[0][2], out[1][2]) and torch.equal(out[0][1], out[1][1])
