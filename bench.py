@@ -582,11 +582,16 @@ def main():
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     sync()
     t0 = time.perf_counter()
+    issue_marks = [t0]
     for i in range(args.steps):
         marks[i].record()                       # one event per step boundary on the caller's stream (every step joins its streams there)
         step.run()
+        issue_marks.append(time.perf_counter())
     marks[args.steps].record()
     t_issue = time.perf_counter() - t0            # host time to ENQUEUE the K steps (no wait inside): >= dt would mean a host-bound step
+    # ... but once the runtime's queues are full the host is paced by the GPU, so the K-step average approaches the step time whatever the
+    # host costs: the first steps after the sync (empty queues) are the host's own issue time
+    issue_first = sorted(issue_marks[i + 1] - issue_marks[i] for i in range(min(3, args.steps)))[0]
     sync()
     dt = time.perf_counter() - t0
     step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
@@ -651,6 +656,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 3), "ms_per_step_p50": round(p50_ms, 3), "ms_per_step_min_max": [round(step_ms[0], 3), round(step_ms[-1], 3)],
             "host_issue_ms_per_step": round(t_issue / args.steps * 1e3, 3),
+            "host_issue_ms_first_steps": round(issue_first * 1e3, 3),
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": workload + ("+RCCL all-reduce" if world > 1 else "") + (" [HIP graph replay]" if graph else ""),

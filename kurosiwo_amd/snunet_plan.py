@@ -193,7 +193,7 @@ class LaunchList:
         on the issuing lane's stream at that point of the list, so that independent work fills the machine next to the
         bandwidth-bound BatchNorm / elementwise launches of the critical path; the caller joins (StepStreams.join) before
         anything outside the lists reads the results."""
-        if timer is None and self.fast and self.calls and (hook is None or hook_at is not None):
+        if (timer is None or not getattr(timer, "active", True)) and self.fast and self.calls and (hook is None or hook_at is not None):
             cp = self._compiled or self._compile()
             if cp["ok"]:
                 return self._run_fast(hook, hook_at or (), streams)

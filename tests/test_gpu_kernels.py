@@ -437,3 +437,35 @@ def test_maxpool3x3s2_recorded_first_maximum(dev, dtype, shape):
         ref = xr.grad + (0.5 if acc else 0.0)
         tol = 0.0 if dtype == torch.float32 else 2e-2 * float(ref.abs().max())
         assert (Fk.to_nchw(dx).cpu() - ref).abs().max() <= tol
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(B=2, H=48, W=40, cs=[32], N=32),                       # igemm3 (short K, weights in registers)
+    dict(B=4, H=96, W=96, cs=[32, 32, 64], N=32),               # igemm4 <8, 2> (long K, 32 columns; >= 64 tiles so that it is chosen)
+    dict(B=4, H=96, W=96, cs=[64, 64], N=128),                  # igemm4 <4, 4>
+    dict(B=1, H=14, W=14, cs=[256], N=256),                     # igemm2 (tiny map: the tile kernel)
+])
+def test_conv_statistics_are_sums_over_the_stored_bf16_values(dev, cfg):
+    """the BatchNorm statistics rows of every convolution epilogue are the sum and the sum of squares of the values AS
+    STORED (bf16), not of the fp32 accumulators -- BatchNorm normalises the stored tensor (round 5 found loss excursions of 2.6 x ... 16 x
+    in bf16 K-step runs when the two differed).  Direct check per kernel generation: reduce the stats rows and compare with fp64 sums over
+    the output tensor the launch stored; the fp32-accumulator sums differ from those by the rounding noise this test would catch."""
+    from kurosiwo_amd import functional as Fk
+    B, H, W, cs, N = cfg["B"], cfg["H"], cfg["W"], cfg["cs"], cfg["N"]
+    tag = f"stats.{H}.{sum(cs)}.{N}"
+    xs = [seeded_tensor(f"{tag}.x{i}", (B, c, H, W)) for i, c in enumerate(cs)]
+    w = seeded_tensor(tag + ".w", (N, sum(cs), 3, 3)) * (2.0 / (9 * sum(cs))) ** 0.5 * 3.0
+    xd = [Fk.to_nhwc(x.to(dev), torch.bfloat16) for x in xs]
+    out, stats = Fk.conv3x3(xd, w.to(dev), want_stats=True)
+    torch.cuda.synchronize()
+    y = out.float().double().reshape(-1, out.shape[-1])[:, :N]          # the stored values
+    s1, s2 = y.sum(0), (y * y).sum(0)
+    g1, g2 = stats[:, 0, :N].double().sum(0), stats[:, 1, :N].double().sum(0)
+    # fp32 partial sums per workgroup row: relative 1e-5 of the absolute mass
+    tol1 = 2e-5 * y.abs().sum(0) + 1e-6
+    assert ((g1 - s1).abs() <= tol1).all(), float(((g1 - s1).abs() / tol1).max())
+    assert ((g2 - s2).abs() <= 2e-5 * s2 + 1e-6).all(), float(((g2 - s2).abs() / (2e-5 * s2 + 1e-6)).max())
+    # ... and the test has teeth: sums over the UNROUNDED convolution differ by more than that tolerance in most channels
+    ref = torch.nn.functional.conv2d(torch.cat([x.to(torch.bfloat16).float() for x in xs], 1).double(), w.to(torch.bfloat16).double(), padding=1)
+    r2 = (ref * ref).sum((0, 2, 3))
+    assert ((r2.to(dev) - s2).abs() > 2e-5 * s2 + 1e-6).float().mean() > 0.5

@@ -122,9 +122,11 @@ def test_kstep_run_miou_matches_cpu_fp32_reference_run(golden_dir, precision):
         assert rel[0, 0] < 2e-4                                       # first step of the seeded weights: to rounding
     else:
         # tier 1, every draw: hard bounds
-        assert a40.max() <= 1.5e-2, d_miou[40]
-        assert a20.max() <= 1e-1, d_miou[20]
-        assert rel.max() <= 5.0, rel.max(1)
+        # (round 6, ADVICE round 5: tightened from 0.015 / 0.1 / 5.0 towards the observed worst cases -- worst of 71 HIP runs 0.0068 / 0.055 /
+        # 3.4, the eleven draws here 0.0019 / 0.0114 / 0.47 -- so that a moderate numerical regression fails the hard tier too)
+        assert a40.max() <= 8e-3, d_miou[40]
+        assert a20.max() <= 6e-2, d_miou[20]
+        assert rel.max() <= 3.5, rel.max(1)
         assert np.abs(np.stack(d_iou[40])).max() <= 2.5e-2, d_iou[40]
         # tier 2, the distribution of the draws against the emulated reference's
         assert abs(float(np.median(d_miou[40]))) <= 2e-3, d_miou[40]                       # the survey's gate, on the median
@@ -194,3 +196,64 @@ def test_changeformer_kstep_run_matches_cpu_fp32_reference_run(golden_dir, preci
     rel = np.abs(np.array(losses) - gold["losses"]) / gold["losses"]
     print(f"changeformer {precision}: loss trajectory max relative deviation {rel.max():.5f}")
     assert rel.max() < bound_loss, rel
+
+
+PLATEAU_DRAWS = (0.0, 1e-7, -1e-7, 2e-7, -2e-7, 5e-7, -5e-7, 1e-6, -1e-6)
+
+
+def test_plateau_protocol_every_bf16_draw_within_the_surveys_gate(golden_dir):
+    """the +-0.002 mIoU gate asserted on EVERY draw where the protocol itself is not the noise source.  The
+    40-step / batch-4 protocol above is noisy on the reference itself under bf16 storage (3 of 23 emulated draws outside +-0.002); this one
+    runs 80 Adam steps on batches of 16 (half the benchmarked per-GPU batch: what an fp32 run of the imported reference fits into the
+    build container) and evaluates the 64 held-out tiles after 60 and 80 steps, both far onto the plateau (reference mIoU 0.9892 /
+    0.9904, rising 7e-4 per 10 steps).  CPU side = the IMPORTED reference (oracle/gen_parity_run.py --reference-plateau ->
+    tests/golden/snunet_parity_plateau_ref.npz; training/change_detection_trainer.py:135-189).  Asserted: every bf16 draw within 0.002
+    of the reference's fp32 run at both checkpoints, every fp32 draw within 5e-4."""
+    from kurosiwo_amd.snunet import SNUNet_ECAM
+    from kurosiwo_amd.synthetic import cd_inputs, make_batch
+    from kurosiwo_amd.trainer import CDTrainStep
+    from oracle import metrics_ref, snunet_ref as R
+    from oracle.gen_parity_run import HELD_OUT, HELD_OUT_SEED, P_BATCH, P_CHECKPOINTS, P_K_STEPS, P_TRAIN_TILES, TRAIN_SEED
+    from oracle.seeded import seeded_fill_
+    gold = np.load(os.path.join(golden_dir, "snunet_parity_plateau_ref.npz"))
+    assert list(gold["protocol"][:4]) == [P_K_STEPS, P_TRAIN_TILES, P_BATCH, HELD_OUT] and P_CHECKPOINTS == (60, 80)
+    dev = torch.device("cuda:0")
+    (xA, xB), mask = cd_inputs(make_batch(P_TRAIN_TILES, seed=TRAIN_SEED), ("pre_event_1", "post_event"))
+    (eA, eB), emask = cd_inputs(make_batch(HELD_OUT, seed=HELD_OUT_SEED), ("pre_event_1", "post_event"))
+
+    def evaluate(m):
+        m.eval()
+        cm = np.zeros((4, 4), np.int64)
+        with torch.no_grad():
+            for s in range(0, HELD_OUT, 8):
+                logits = m(eA[s:s + 8].to(dev), eB[s:s + 8].to(dev)).float().cpu().numpy()
+                cm += metrics_ref.confusion_matrix(metrics_ref.argmax_lowest_index(logits), emask[s:s + 8].numpy())
+        m.train()
+        return metrics_ref.metrics_from_cm(cm)
+
+    worst = {}
+    for precision, draws, bound in (("fp32", PLATEAU_DRAWS[:3], 5e-4), ("bf16", PLATEAU_DRAWS, 2e-3)):
+        deltas = {k: [] for k in P_CHECKPOINTS}
+        dev_loss = []
+        for pz in draws:
+            sd = seeded_fill_(R.new_state_dict(2, 3, 32))
+            if pz:
+                sd["conv0_0.conv1.weight"] = sd["conv0_0.conv1.weight"] * (1.0 + pz)
+            model = SNUNet_ECAM(2, 3, base_channel=32, precision=precision)
+            model.load_state_dict(sd)
+            model = model.to(dev).train()
+            step = CDTrainStep(model, P_BATCH, 224, 224, loss_function="ce+dice", class_weights=(1.0, 1.0, 1.0), lr=1e-3)
+            losses = []
+            for k in range(P_K_STEPS):
+                s = (k % (P_TRAIN_TILES // P_BATCH)) * P_BATCH
+                losses.append(float(step.step(xA[s:s + P_BATCH].to(dev), xB[s:s + P_BATCH].to(dev), mask[s:s + P_BATCH].to(dev))[0]))
+                if k + 1 in P_CHECKPOINTS:
+                    m = evaluate(model)
+                    deltas[k + 1].append(float(m["miou"]) - float(gold[f"miou{k + 1}"]))
+            dev_loss.append(float((np.abs(np.array(losses) - gold["losses"]) / gold["losses"]).max()))
+        for k in P_CHECKPOINTS:
+            print(f"plateau protocol, {precision}, K={k}: delta mIoU of every draw {np.round(deltas[k], 5).tolist()} (reference {float(gold[f'miou{k}']):.5f})")
+        print(f"plateau protocol, {precision}: largest relative deviation of the loss trajectory per draw {np.round(dev_loss, 3).tolist()}")
+        worst[precision] = max(max(abs(x) for x in deltas[k]) for k in P_CHECKPOINTS)
+        for k in P_CHECKPOINTS:
+            assert max(abs(x) for x in deltas[k]) <= bound, (precision, k, deltas[k])
