@@ -342,3 +342,112 @@ def test_two_gpus_other_bucket_modes(mode, wire):
     else:
         for x, y in zip(chk["rank_losses"], ref["config"]["dp_check"]["rank_losses"]):
             assert abs(x - y) < 0.05 * abs(y) + 1e-3, (chk, ref["config"]["dp_check"])
+
+
+# ---- the FULL fused train step under data parallelism for the other two bucket plans (FloodViT: 280 keys,
+# ChangeFormer: 373 keys, BatchNorm in the decoder), with the opt-in wire settings -- mode "rs_ag" (gloo has no reduce-scatter: the mode
+# degrades to all-reduce, the bucket bookkeeping is the same) and the bf16 wire -- two ranks on the halves of a batch, both on the test
+# box's one GPU over gloo, three optimiser steps, multi-stream step (side-stream weight gradients) and the compiled launch list.
+def _family_build(family, precision):
+    torch.manual_seed(11)
+    if family == "floodvit":
+        from kurosiwo_amd.floodvit import FinetunerSegmentation, ViT
+        hp = SMALL
+        enc = ViT(image_size=hp["image_size"], patch_size=hp["patch_size"], num_classes=1000, dim=hp["dim"], depth=hp["depth"],
+                  heads=hp["heads"], mlp_dim=hp["mlp_dim"], channels=hp["channels"])
+        return FinetunerSegmentation(enc, CFG, precision=precision).cuda().train()
+    from kurosiwo_amd.changeformer import ChangeFormerV6
+    m = ChangeFormerV6(input_nc=2, output_nc=3, decoder_softmax=True, embed_dim=64, precision=precision)
+    for k in ("drop_rate", "attn_drop", "drop_path_rate"):             # (regulariser-free: the ranks would draw from one counter-based stream anyway)
+        if hasattr(m, k):
+            setattr(m, k, 0.0)
+    return m.cuda().train()
+
+
+def _family_steps(family, model, B, rank, world, wire, mode, n):
+    from kurosiwo_amd import distributed as D
+    from kurosiwo_amd.optim import FusedSGD
+    from kurosiwo_amd.trainer import CDTrainStep, SegTrainStep
+    from oracle.seeded import seeded_labels, seeded_tensor
+    S = 224                                                              # (ChangeFormer's SR attention is specialised for 224 x 224 tiles)
+    lbl = seeded_labels("dp2.lbl", (B, S, S), p_invalid=0.0)
+    opt = FusedSGD(model.parameters(), lr=0.02)
+    kw = dict(optimizer=opt, bucket_mb=2.0, grad_dtype=wire, dp_mode=mode)
+    if family == "floodvit":
+        x = seeded_tensor("dp2.x", (B, 6, S, S)).clamp_(-2.23, 5.75)
+        (xs, ls) = D.shard_batch((x, lbl), rank, world) if world > 1 else (x, lbl)
+        step = SegTrainStep(model, xs.shape[0], "cross_entropy", [1.0, 1.0, 1.0], **kw)
+        args = (xs.cuda(), ls.cuda())
+    else:
+        xA, xB = seeded_tensor("dp2.xA", (B, 2, S, S)), seeded_tensor("dp2.xB", (B, 2, S, S))
+        (a, b, ls) = D.shard_batch((xA, xB, lbl), rank, world) if world > 1 else (xA, xB, lbl)
+        step = CDTrainStep(model, a.shape[0], S, S, "ce+dice", (1.0, 1.0, 1.0), **kw)
+        args = (a.cuda(), b.cuda(), ls.cuda())
+    losses = [float(step.step(*args)[0]) for _ in range(n)]
+    torch.cuda.synchronize()
+    return losses, step
+
+
+def _family_worker(rank, world, port, q, family, precision, wire, mode):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from kurosiwo_amd import distributed as D
+    model = _family_build(family, precision)
+    if rank == 1:
+        model.flat_params.mul_(1.25)
+    D.broadcast_model_(model)
+    losses, step = _family_steps(family, model, 4, rank, world, wire, mode, 3)
+    missing = [k for k in model._poff if k not in step.plan.param_ready]
+    covered = sum(e - s for s, e, _ in step.reducer.buckets) == model.flat_params.numel()
+    q.put((rank, losses, model.flat_params.detach().cpu().numpy(), covered, missing, len(step.reducer.buckets), step.reducer.hook_indices(),
+           step._ss is not None and step._ss._runner is not None))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("family,precision,wire,mode", [("floodvit", "fp32", "fp32", "rs_ag"), ("floodvit", "bf16", "bf16", "all_reduce"),
+                                                        ("changeformer", "fp32", "fp32", "rs_ag"), ("changeformer", "bf16", "bf16", "all_reduce")])
+def test_two_ranks_full_train_step_other_bucket_plans(family, precision, wire, mode):
+    ctx = mp.get_context("spawn")
+    q, port = ctx.Queue(), _free_port()
+    procs = [ctx.Process(target=_family_worker, args=(r, 2, port, q, family, precision, wire, mode)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = []
+    import queue as _queue
+    import time as _time
+    t_end = _time.time() + 600
+    while len(res) < 2:                                                  # (a worker that died must fail the test at once, not after the queue time-out)
+        try:
+            res.append(q.get(timeout=2))
+        except _queue.Empty:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            if dead or _time.time() > t_end:
+                for p in procs:
+                    p.kill()
+                pytest.fail(f"worker exit codes {dead or 'time-out'}")
+    res.sort(key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (r0, l0, w0, c0, m0, nb0, hooks0, fast0), (r1, l1, w1, c1, m1, nb1, hooks1, fast1) = res
+    w0, w1 = torch.from_numpy(w0), torch.from_numpy(w1)
+    assert c0 and c1 and not m0 and not m1, (c0, c1, m0[:5], m1[:5])          # buckets cover the arena; every parameter has a readiness index
+    assert nb0 == nb1 >= 2 and hooks0 == hooks1 and len(hooks0) >= 2            # several buckets issued DURING the backward list ...
+    assert fast0 and fast1                                                      # ... from the compiled launch list, cut at the bucket indices
+    assert torch.equal(w0, w1), f"ranks diverged: max |d| {float((w0 - w1).abs().max()):.3e}"
+    assert all(abs(x) < 1e6 for x in l0 + l1) and torch.isfinite(w0).all()
+    if precision == "fp32" and family == "floodvit":
+        # BN-free model, fp32 sums on the wire: the two ranks took the step ONE process takes on the whole batch
+        model = _family_build(family, precision)
+        p0 = model.flat_params.detach().cpu().clone()
+        losses, _ = _family_steps(family, model, 4, 0, 1, "fp32", None, 3)
+        ref = model.flat_params.detach().cpu()
+        upd = float((ref - p0).abs().max())
+        assert float((w0 - ref).abs().max()) < 2e-3 * upd + 1e-7, (float((w0 - ref).abs().max()), upd)
+        for k in range(3):
+            assert abs(0.5 * (l0[k] + l1[k]) - losses[k]) < 3e-4 * abs(losses[k]), (k, l0[k], l1[k], losses[k])
+    else:
+        # per-rank BatchNorm (ChangeFormer's decoder) and / or bf16 sums: a different function of the same data by design; the losses of the
+        # shards still descend together
+        assert 0.5 * (l0[-1] + l1[-1]) < 0.5 * (l0[0] + l1[0]) * 1.05, (l0, l1)
