@@ -445,6 +445,9 @@ int ksmi_layernorm_backward(const void* dy, const void* x, const float* mean, co
 /* nn.GELU() exact-erf (vision_transformer.py:24), elementwise helpers */
 int ksmi_gelu_forward(const void* x, void* y, int64_t n, int dtype, void* stream);
 int ksmi_gelu_backward(const void* dy, const void* x, void* dx, int64_t n, int dtype, void* stream);
+/* (ABI 7) dx = (dy * Dropout(site; element)) * gelu'(x): the backward of act -> drop (models/changeformer.py:129-130) in one pass */
+int ksmi_gelu_backward_drop(const void* dy, const void* x, void* dx, int64_t n, uint32_t thr, float inv_keep, uint32_t site,
+                            const uint32_t* rng_state, int dtype, void* stream);
 int ksmi_add(const void* a, const void* b, void* out, int64_t n, int dtype, void* stream);
 int ksmi_relu_backward(const void* dy, const void* x, void* dx, int64_t n, int dtype, void* stream);
 int ksmi_relu_forward(const void* x, void* y, int64_t n, int dtype, void* stream);   /* Decoder.relu, model_utilities.py:44 */
@@ -509,6 +512,10 @@ int ksmi_col2im(const void* dcol, void* dx, int accumulate, int B, int Cin, int 
  * gradient partials partial[rows][10*C] (columns c*9+t, then 9C+c) for ksmi_reduce_rows */
 int ksmi_dwconv3x3_gelu_forward(const void* x, const float* w, const float* bias, void* z, void* g, int B, int H, int W, int C,
                                 int dtype, void* stream);
+/* (ABI 7) ... with Mlp.drop (:130) behind the activation applied to g as it is stored: the draw of ksmi_dropout_apply(g, site) on element
+ * (token * C + c), product formed on the rounded activation (bit-identical to the two passes); thr = 0: the plain forward */
+int ksmi_dwconv3x3_gelu_forward_drop(const void* x, const float* w, const float* bias, void* z, void* g, int B, int H, int W, int C,
+                                     uint32_t thr, float inv_keep, uint32_t site, const uint32_t* rng_state, int dtype, void* stream);
 int ksmi_dwconv3x3_backward_input(const void* dz, const float* w, void* dx, int B, int H, int W, int C, int dtype, void* stream);
 int ksmi_dwconv3x3_wgrad(const void* x, const void* dz, float* partial, int rows, int B, int H, int W, int C, int dtype, void* stream);
 /* Attention against the spatially reduced keys (:190-207): q [B*Nq][C], kv [B*Nk][2C] "(2 h d)", out [B*Nq][C]; Nk = 49,

@@ -214,6 +214,8 @@ SIGNATURES = {
     "ksmi_maxpool3x3s2_backward_idx": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ksmi_affine": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, C.c_float, _i, _vp]),
     "ksmi_dwconv3x3_gelu_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "ksmi_dwconv3x3_gelu_forward_drop": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, C.c_uint32, C.c_float, C.c_uint32, _vp, _i, _vp]),
+    "ksmi_gelu_backward_drop": (_i, [_vp, _vp, _vp, _i64, C.c_uint32, C.c_float, C.c_uint32, _vp, _i, _vp]),
     "ksmi_dwconv3x3_backward_input": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ksmi_dwconv3x3_wgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ksmi_sr_attention_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, C.c_float, _i, _vp]),

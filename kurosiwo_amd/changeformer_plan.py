@@ -61,6 +61,7 @@ class ChangeFormerPlan(PlanBase):
         # train mode only, exactly as nn.Dropout / DropPath
         nblk = sum(DEPTHS)
         self.p_drop = float(model.drop_rate) if training else 0.0
+        self.fuse_drop = os.environ.get("KSMI_CF_FUSE_DROP", "1") != "0"     # Mlp.drop inside the depth-wise / gelu' passes (round 6)
         self.p_attn = float(model.attn_drop) if training else 0.0
         dp = float(model.drop_path_rate) if training else 0.0
         self.dpr = [dp * i / (nblk - 1) for i in range(nblk)]
@@ -220,10 +221,19 @@ class ChangeFormerPlan(PlanBase):
                 rec["st2"] = self._ln(t_mid, f"{k}.norm2.weight", f"{k}.norm2.bias", h2, R, Cc, 1e-6)
                 self._linear(f"{k}.fc1", h2, Cc, f"{k}.mlp.fc1.weight", f"{k}.mlp.fc1.bias", u, 4 * Cc, R)
                 wd, bd = m._p(f"{k}.mlp.dwconv.dwconv.weight").data_ptr(), m._p(f"{k}.mlp.dwconv.dwconv.bias").data_ptr()
-                self.fwd.add("ksmi_dwconv3x3_gelu_forward", lambda u=u, z=z, g=g, wd=wd, bd=bd, Hs=Hs, Ws=Ws, Cc=Cc: (
-                    u.data_ptr(), wd, bd, z.data_ptr(), g.data_ptr(), B2, Hs, Ws, 4 * Cc, dt), self._elt_meta("dwconv_gelu", 3 * R * 4 * Cc))
+                # Mlp.drop after the activation (:130) rides on the depth-wise kernel's store of g (round 6; fc2 and its weight gradient read
+                # the dropped g): one launch and two passes over the 4C-wide tensor less per block; KSMI_CF_FUSE_DROP=0: the separate pass
+                fuse_d = self.fuse_drop and self._branch_active(gi) and self.p_drop > 0
+                if fuse_d:
+                    ds = self._site(gi, SITE_MLP1, self.p_drop)
+                    self.fwd.add("ksmi_dwconv3x3_gelu_forward_drop", lambda u=u, z=z, g=g, wd=wd, bd=bd, Hs=Hs, Ws=Ws, Cc=Cc, ds=ds: (
+                        u.data_ptr(), wd, bd, z.data_ptr(), g.data_ptr(), B2, Hs, Ws, 4 * Cc, ds[0], ds[1], ds[2], self.rng_ptr, dt),
+                        self._elt_meta("dwconv_gelu", 3 * R * 4 * Cc))
+                else:
+                    self.fwd.add("ksmi_dwconv3x3_gelu_forward", lambda u=u, z=z, g=g, wd=wd, bd=bd, Hs=Hs, Ws=Ws, Cc=Cc: (
+                        u.data_ptr(), wd, bd, z.data_ptr(), g.data_ptr(), B2, Hs, Ws, 4 * Cc, dt), self._elt_meta("dwconv_gelu", 3 * R * 4 * Cc))
                 if self._branch_active(gi):
-                    if self.p_drop > 0:                            # Mlp.drop after the activation (:130): in place, fc2 and its wgrad read it
+                    if self.p_drop > 0 and not fuse_d:             # Mlp.drop after the activation (:130): in place, fc2 and its wgrad read it
                         self._drop(self.fwd, g, None, g, R, 4 * Cc, Hs * Ws, self._site(gi, SITE_MLP1, self.p_drop), NO_SITE)
                     self._linear(f"{k}.fc2", g, 4 * Cc, f"{k}.mlp.fc2.weight", f"{k}.mlp.fc2.bias", ptmp, Cc, R)
                     self._drop(self.fwd, ptmp, t_mid, t_out, R, Cc, Hs * Ws, self._site(gi, SITE_MLP2, self.p_drop), self._site(gi, SITE_PATH_MLP, self.dpr[gi]))
@@ -509,10 +519,16 @@ class ChangeFormerPlan(PlanBase):
                 gy = tD
             self._linear_bwd(f"{k}.fc2", rec["g"], 4 * Cc, f"{k}.mlp.fc2.weight", f"{k}.mlp.fc2.bias", gy, Cc, R, t4,
                              side_tag=f"{k}.fc2" if sd else None)
-            if active and self.p_drop > 0:
-                self._drop(self.bwd, t4, None, t4, R, 4 * Cc, N, self._site(gi, SITE_MLP1, self.p_drop), NO_SITE)
-            self.bwd.add("ksmi_gelu_backward", lambda z=rec["z"]: (t4.data_ptr(), z.data_ptr(), t4.data_ptr(), R * 4 * Cc, dt),
-                         self._elt_meta("gelu_bwd", 3 * R * 4 * Cc))
+            if active and self.p_drop > 0 and self.fuse_drop:       # the mask of Mlp.drop and gelu' in one pass over the gradient (round 6)
+                ds = self._site(gi, SITE_MLP1, self.p_drop)
+                self.bwd.add("ksmi_gelu_backward_drop", lambda z=rec["z"], ds=ds: (t4.data_ptr(), z.data_ptr(), t4.data_ptr(), R * 4 * Cc,
+                                                                                 ds[0], ds[1], ds[2], self.rng_ptr, dt),
+                             self._elt_meta("gelu_bwd", 3 * R * 4 * Cc))
+            else:
+                if active and self.p_drop > 0:
+                    self._drop(self.bwd, t4, None, t4, R, 4 * Cc, N, self._site(gi, SITE_MLP1, self.p_drop), NO_SITE)
+                self.bwd.add("ksmi_gelu_backward", lambda z=rec["z"]: (t4.data_ptr(), z.data_ptr(), t4.data_ptr(), R * 4 * Cc, dt),
+                             self._elt_meta("gelu_bwd", 3 * R * 4 * Cc))
             wd = m._p(f"{k}.mlp.dwconv.dwconv.weight").data_ptr()
             du = rec["z"]                                         # z is dead after gelu_backward: reuse as d(fc1 output)
             self.bwd.add("ksmi_dwconv3x3_backward_input", lambda du=du, wd=wd: (t4.data_ptr(), wd, du.data_ptr(), B2, Hs, Ws, 4 * Cc, dt),

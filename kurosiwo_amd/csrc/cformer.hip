@@ -361,9 +361,13 @@ __device__ __forceinline__ DwCol<T> dw_load_col(const T* const* rp, const bool* 
   return c;
 }
 
-template <typename T, int MODE>
+// DROP (round 6): Mlp.drop behind the activation (models/changeformer.py:130) applied to g as it is stored -- element index = the flat
+// index of the [tokens][C] matrix, the same draw ksmi_dropout_apply(g, site) makes in a pass of its own (13 launches and 2 x the
+// 4C-wide tensor per ChangeFormer step); the product is formed on the ROUNDED activation like that pass did: bit-identical
+template <typename T, int MODE, bool DROP = false>
 __global__ __launch_bounds__(256) void dwconv3x3_row_kernel(const T* x, const float* w, const float* bias, T* z, T* g, int B, int H, int W, int C,
-                                                            int seg, int nseg, int64_t units) {
+                                                            int seg, int nseg, int64_t units, uint32_t thr = 0, float inv = 1.f,
+                                                            uint32_t site = 0, const uint32_t* __restrict__ rng = nullptr) {
   constexpr int VEC = ElemTraits<T>::kVec;
   const int CV = C / VEC;
   const int cv = blockIdx.y * 32 + (threadIdx.x & 31), pl = threadIdx.x >> 5;
@@ -372,6 +376,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_row_kernel(const T* x, const fl
   // consecutive units are neighbouring rows of one image (shared halo rows): keep them on ONE XCD (gridDim.x is a multiple of 8)
   const int64_t u = ((int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) * 8 + pl;
   if (u >= units) return;
+  const uint32_t dkey = DROP ? ksmi_rng_key(rng, site) : 0u;
   float wr[9][VEC], br[VEC];
 #pragma unroll
   for (int j = 0; j < VEC; ++j) {
@@ -411,6 +416,11 @@ __global__ __launch_bounds__(256) void dwconv3x3_row_kernel(const T* x, const fl
     *(u32x4*)(zo + (int64_t)px * C) = vec_pack<T>(acc);                                                          \
     if (MODE == 0) {                                                                                             \
       _Pragma("unroll") for (int j = 0; j < VEC; ++j) acc[j] = gelu_f(ElemTraits<T>::cvt(acc[j]));               \
+      if (DROP) {                                                                                                \
+        const uint32_t e0 = (uint32_t)((row * W + px) * (int64_t)C + c0);                                        \
+        _Pragma("unroll") for (int j = 0; j < VEC; ++j)                                                          \
+          acc[j] = ksmi_rng_keep(dkey, e0 + j, thr) ? ElemTraits<T>::cvt(acc[j]) * inv : 0.f;                    \
+      }                                                                                                          \
       *(u32x4*)(go + (int64_t)px * C) = vec_pack<T>(acc);                                                        \
     }                                                                                                            \
     ++px;                                                                                                        \
@@ -1281,6 +1291,29 @@ int ksmi_dwconv3x3_gelu_forward(const void* x, const float* w, const float* bias
           hipLaunchKernelGGL((dwconv3x3_kernel<bf16_t, 0>), grid, dim3(256), 0, st, (const bf16_t*)x, w, bias, (bf16_t*)z, (bf16_t*)g, B, H, W, C, ppb),
           hipLaunchKernelGGL((dwconv3x3_kernel<float, 0>), grid, dim3(256), 0, st, (const float*)x, w, bias, (float*)z, (float*)g, B, H, W, C, ppb));
   return ksmi_check_launch("dwconv3x3_gelu_fwd");
+}
+
+int ksmi_dropout_apply(const void* x, const void* resid, void* y, int64_t rows, int cols, int rows_per_sample, uint32_t thr, float inv_keep,
+                       uint32_t site, uint32_t dp_thr, float dp_inv_keep, uint32_t dp_site, const uint32_t* rng_state, int dtype, void* stream);
+
+int ksmi_dwconv3x3_gelu_forward_drop(const void* x, const float* w, const float* bias, void* z, void* g, int B, int H, int W, int C, uint32_t thr,
+                                     float inv_keep, uint32_t site, const uint32_t* rng_state, int dtype, void* stream) {
+  if (!thr) return ksmi_dwconv3x3_gelu_forward(x, w, bias, z, g, B, H, W, C, dtype, stream);
+  if (!rng_state) return ksmi_fail(KSMI_E_ARG, "dwconv3x3_gelu_forward_drop: the rng state is required");
+  const int vec = dtype == KSMI_BF16 ? 8 : 4;
+  if (C % vec) return ksmi_fail(KSMI_E_ARG, "dwconv: C must be a multiple of the 16-byte vector");
+  if ((int64_t)B * H * W * C >= ((int64_t)1 << 32)) return ksmi_fail(KSMI_E_ARG, "dwconv3x3_gelu_forward_drop: element index exceeds 32 bits");
+  if (!dw_row_form()) {            // (the per-pixel form of KSMI_DW_ROW=0: the two passes it replaces)
+    if (int rc = ksmi_dwconv3x3_gelu_forward(x, w, bias, z, g, B, H, W, C, dtype, stream)) return rc;
+    return ksmi_dropout_apply(g, nullptr, g, (int64_t)B * H * W, C, H * W, thr, inv_keep, site, 0, 1.f, 0, rng_state, dtype, stream);
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const DwRowGeom q = dw_row_geom(B, H, W);
+  const dim3 grid((unsigned)(((q.units + 7) / 8 + 7) / 8 * 8), (C / vec + 31) / 32);
+  KSMI_DT(dtype,
+          hipLaunchKernelGGL((dwconv3x3_row_kernel<bf16_t, 0, true>), grid, dim3(256), 0, st, (const bf16_t*)x, w, bias, (bf16_t*)z, (bf16_t*)g, B, H, W, C, q.seg, q.nseg, q.units, thr, inv_keep, site, rng_state),
+          hipLaunchKernelGGL((dwconv3x3_row_kernel<float, 0, true>), grid, dim3(256), 0, st, (const float*)x, w, bias, (float*)z, (float*)g, B, H, W, C, q.seg, q.nseg, q.units, thr, inv_keep, site, rng_state));
+  return ksmi_check_launch("dwconv3x3_gelu_fwd_drop");
 }
 
 int ksmi_dwconv3x3_backward_input(const void* dz, const float* w, void* dx, int B, int H, int W, int C, int dtype, void* stream) {

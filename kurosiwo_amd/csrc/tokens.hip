@@ -201,6 +201,27 @@ __global__ void eltwise_kernel(const T* a, const T* b, T* out, int64_t nvec) {
   }
 }
 
+// dx = (dy * Dropout(site; element)) * gelu'(x): the backward of act -> drop (models/changeformer.py:129-130) in one pass; the masked
+// gradient is rounded to the storage type before the product, as the two passes it replaces did (bit-identical)
+template <typename T>
+__global__ void gelu_bwd_drop_kernel(const T* dy, const T* x, T* dx, int64_t nvec, uint32_t thr, float inv, uint32_t site,
+                                     const uint32_t* __restrict__ rng) {
+  constexpr int VEC = ElemTraits<T>::kVec;
+  const uint32_t key = ksmi_rng_key(rng, site);
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * blockDim.x) {
+    float g[VEC], y[VEC];
+    vec_unpack<T>(*(const u32x4*)(dy + v * VEC), g);
+    vec_unpack<T>(*(const u32x4*)(x + v * VEC), y);
+    const uint32_t e0 = (uint32_t)(v * VEC);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const float m = ksmi_rng_keep(key, e0 + j, thr) ? ElemTraits<T>::cvt(g[j] * inv) : 0.f;
+      g[j] = m * gelu_df(y[j]);
+    }
+    *(u32x4*)(dx + v * VEC) = vec_pack<T>(g);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // patchify: "b c (h p1) (w p2) -> b (h w) (p1 p2 c)"  (vision_transformer.py:122); image NCHW fp32
 // ------------------------------------------------------------------------------------------------
@@ -693,6 +714,18 @@ int ksmi_layernorm_backward(const void* dy, const void* x, const float* mean, co
 
 int ksmi_gelu_forward(const void* x, void* y, int64_t n, int dtype, void* stream) { KSMI_ELT(0, x, x, y, n, "gelu_fwd") }
 int ksmi_gelu_backward(const void* dy, const void* x, void* dx, int64_t n, int dtype, void* stream) { KSMI_ELT(1, dy, x, dx, n, "gelu_bwd") }
+int ksmi_gelu_backward_drop(const void* dy, const void* x, void* dx, int64_t n, uint32_t thr, float inv_keep, uint32_t site, const uint32_t* rng_state,
+                            int dtype, void* stream) {
+  if (!thr) return ksmi_gelu_backward(dy, x, dx, n, dtype, stream);
+  if (!rng_state) return ksmi_fail(KSMI_E_ARG, "gelu_backward_drop: the rng state is required");
+  const int vec = dtype == KSMI_BF16 ? 8 : 4;
+  if (n % vec || n >= ((int64_t)1 << 32)) return ksmi_fail(KSMI_E_ARG, "gelu_backward_drop: element count must be a multiple of the 16-byte vector and < 2^32");
+  const int64_t nvec = n / vec;
+  KSMI_DT(dtype,
+          hipLaunchKernelGGL(gelu_bwd_drop_kernel<bf16_t>, dim3(grid_for(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x, (bf16_t*)dx, nvec, thr, inv_keep, site, rng_state),
+          hipLaunchKernelGGL(gelu_bwd_drop_kernel<float>, dim3(grid_for(nvec)), dim3(256), 0, (hipStream_t)stream, (const float*)dy, (const float*)x, (float*)dx, nvec, thr, inv_keep, site, rng_state));
+  return ksmi_check_launch("gelu_bwd_drop");
+}
 int ksmi_add(const void* a, const void* b, void* out, int64_t n, int dtype, void* stream) { KSMI_ELT(2, a, b, out, n, "add") }
 int ksmi_relu_backward(const void* dy, const void* x, void* dx, int64_t n, int dtype, void* stream) { KSMI_ELT(3, dy, x, dx, n, "relu_bwd") }
 

@@ -304,3 +304,29 @@ def test_channel_fastest_im2col_family(dtype, cin, cout, k, s, p, hw):
     grad = torch.ones(cout, cin, k, k, device="cuda")
     _lib.check(lib.ksmi_grad_from_tc(gt.data_ptr(), grad.data_ptr(), cout, cin, T, K, 1, stream_ptr()), "grad_from_tc")
     assert torch.equal(grad, 1 + gt.reshape(cout, T, cin).transpose(1, 2).reshape(cout, cin, k, k))
+
+
+def test_fused_mlp_dropout_is_bit_identical_to_the_separate_passes(monkeypatch):
+    """Round 6: Mlp.drop (models/changeformer.py:130) rides on the depth-wise kernel's store of the activation and on the gelu' pass of the
+    backward (ksmi_dwconv3x3_gelu_forward_drop, ksmi_gelu_backward_drop) instead of two passes of ksmi_dropout_apply: same draws (site,
+    flat element index), products formed on the rounded values -- three train steps equal bit for bit, 26 launches fewer per step."""
+    import torch
+    from kurosiwo_amd.changeformer import ChangeFormerV6
+    from kurosiwo_amd.trainer import CDTrainStep
+    g = torch.Generator().manual_seed(3)
+    data = [(torch.randn(2, 2, 224, 224, generator=g), torch.randn(2, 2, 224, 224, generator=g), torch.randint(0, 3, (2, 224, 224), generator=g)) for _ in range(3)]
+    out = []
+    for fuse in ("0", "1"):
+        monkeypatch.setenv("KSMI_CF_FUSE_DROP", fuse)
+        torch.manual_seed(5)
+        m = ChangeFormerV6(input_nc=2, output_nc=3, decoder_softmax=True, embed_dim=64, precision="bf16").cuda().train()
+        m.manual_seed(11, 0)
+        st = CDTrainStep(m, 2, 224, 224, "ce+dice", (1.0, 1.0, 1.0), lr=1e-3)
+        names = [n for _, _, n, _ in st.plan.fwd.calls + st.plan.bwd.calls]
+        losses = [st.step(a.cuda(), b.cuda(), y.cuda()).clone() for a, b, y in data]
+        torch.cuda.synchronize()
+        out.append((losses, m.flat_params.clone(), m.flat_grads.clone(), names.count("ksmi_dropout_apply"),
+                    names.count("ksmi_dwconv3x3_gelu_forward_drop") + names.count("ksmi_gelu_backward_drop")))
+    assert out[0][4] == 0 and out[1][4] == 26 and out[0][3] - out[1][3] == 26, (out[0][3:], out[1][3:])
+    assert all(torch.equal(a, b) for a, b in zip(out[0][0], out[1][0]))
+    assert torch.equal(out[0][2], out[1][2]) and torch.equal(out[0][1], out[1][1])
