@@ -365,8 +365,11 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kv_kernel(AttnP p, int kchu
 // one workgroup with no slab loop and no partial sums: phase A (waves over query tiles, S^T orientation) writes dq and delta, phase B
 // (waves over key tiles, S orientation) walks all query tiles from LDS and writes dk, dv.  One launch of B*H workgroups (256 for the
 // FloodViT batch = one per CU) replaces bwd_q + bwd_kv (+ finish): 71 -> ~25 us per layer.
-template <int D, int NKT>
-__global__ __launch_bounds__(512) void attn_mfma_bwd_fused_kernel(AttnP p) {
+// NW (round 6): waves per workgroup.  8 = two rounds of query / key tiles per phase at 13 tiles (the second with 5 of 8 waves); 16 = one
+// round per phase: the kernel is a chain of LDS / MFMA / exp latencies (3.4 k MFMAs per head = ~3 us of issue against 40-50 us measured),
+// so halving the serial rounds matters more than the idle three waves.
+template <int D, int NKT, int NW = 8>
+__global__ __launch_bounds__(64 * NW) void attn_mfma_bwd_fused_kernel(AttnP p) {
   using G = Geo<D>;
   constexpr int ROWS = NKT * 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -378,14 +381,14 @@ __global__ __launch_bounds__(512) void attn_mfma_bwd_fused_kernel(AttnP p) {
   float* Ds = Ls + ROWS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
   const int b = blockIdx.y, h = blockIdx.x;
-  stage_rows<D, 512>(Ks, p.k + (size_t)b * p.Nk * p.k_rs + h * D, p.k_rs, ROWS, p.Nk, tid);
-  stage_rows<D, 512>(Vs, p.v + (size_t)b * p.Nk * p.v_rs + h * D, p.v_rs, ROWS, p.Nk, tid);
-  stage_rows<D, 512>(Qs, p.q + (size_t)b * p.Nq * p.q_rs + h * D, p.q_rs, ROWS, p.Nq, tid);
-  stage_rows<D, 512>(Gs, p.dout + (size_t)b * p.Nq * p.o_rs + h * D, p.o_rs, ROWS, p.Nq, tid);
-  for (int i = tid; i < ROWS; i += 512) Ls[i] = i < p.Nq ? p.lse[((size_t)b * p.H + h) * p.Nq + i] : 3.0e38f;   // exp(s - 3e38) = 0: padded queries
+  stage_rows<D, 64 * NW>(Ks, p.k + (size_t)b * p.Nk * p.k_rs + h * D, p.k_rs, ROWS, p.Nk, tid);
+  stage_rows<D, 64 * NW>(Vs, p.v + (size_t)b * p.Nk * p.v_rs + h * D, p.v_rs, ROWS, p.Nk, tid);
+  stage_rows<D, 64 * NW>(Qs, p.q + (size_t)b * p.Nq * p.q_rs + h * D, p.q_rs, ROWS, p.Nq, tid);
+  stage_rows<D, 64 * NW>(Gs, p.dout + (size_t)b * p.Nq * p.o_rs + h * D, p.o_rs, ROWS, p.Nq, tid);
+  for (int i = tid; i < ROWS; i += 64 * NW) Ls[i] = i < p.Nq ? p.lse[((size_t)b * p.H + h) * p.Nq + i] : 3.0e38f;   // exp(s - 3e38) = 0: padded queries
   __syncthreads();
   // ---- phase A: dq and delta, wave = query tile ------------------------------------------------------------------
-  for (int qt = wave; qt * 16 < p.Nq; qt += 8) {             // 8 waves: 13 tiles = at most 2 per wave
+  for (int qt = wave; qt * 16 < p.Nq; qt += NW) {            // 8 waves: 13 tiles = at most 2 per wave; 16: one
     const int qrow = qt * 16 + l15;
     const bool qok = qrow < p.Nq;
     const bf16_t* op = p.o + ((size_t)b * p.Nq + qrow) * p.o_rs + h * D;
@@ -445,7 +448,7 @@ __global__ __launch_bounds__(512) void attn_mfma_bwd_fused_kernel(AttnP p) {
   }
   __syncthreads();                                        // delta of every query is in LDS
   // ---- phase B: dk and dv, wave = key tile -----------------------------------------------------------------------
-  for (int kt = wave; kt * 16 < p.Nk; kt += 8) {
+  for (int kt = wave; kt * 16 < p.Nk; kt += NW) {
     const int key = kt * 16 + l15;
     const bool kok = key < p.Nk;
     u32x4 Kf[G::KS], Vf[G::KS];
@@ -458,7 +461,7 @@ __global__ __launch_bounds__(512) void attn_mfma_bwd_fused_kernel(AttnP p) {
     f32x4 dK[G::DT], dV[G::DT];
 #pragma unroll
     for (int dt = 0; dt < G::DT; ++dt) { dK[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dV[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll 1
+#pragma unroll 1                  // (unrolled by 2: neutral, profiles/r06_ab_attn_waves.txt)
     for (int t = 0; t * 16 < p.Nq; ++t) {
       f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -590,7 +593,11 @@ int ksmi_attn_mfma_vit(int backward, const void* qkv, void* out, float* lse, con
   p.Nq = p.Nk = N; p.H = H; p.B = B; p.scale = scale;
   if (!backward) {
     // one 8-wave workgroup per head measured the same as the 64-query workgroups (FloodViT 1011 vs 1016 tiles/s): kept as a switch
-    static const bool one_wg = getenv("KSMI_ATTN_FWD_ONE_WG") != nullptr;
+    // One 8-wave workgroup per head (K and V staged once for the 13 query tiles) against four 4-wave workgroups of 64 queries that stage
+    // them four times.  Round 2 measured the two the same inside the step; re-measured in round 6 (same box, FloodViT step): 27.7 -> 18.6 us
+    // per layer, 1235 -> 1260 tiles/s (profiles/r06_ab_attn_waves.txt).  A 16-wave instance (one round of tiles) spills at 128 VGPRs: 49 us.
+    // KSMI_ATTN_FWD_ONE_WG=0: the 64-query workgroups.
+    static const int one_wg = getenv("KSMI_ATTN_FWD_ONE_WG") ? atoi(getenv("KSMI_ATTN_FWD_ONE_WG")) : 1;
     if (!one_wg) return launch_fwd<64, 13>(p, (hipStream_t)stream);
     const size_t lds = 2 * (size_t)13 * 16 * Geo<64>::RS;
     auto kfn = attn_mfma_fwd_kernel<64, 13, 8>; KSMI_NOTE(kfn);
@@ -604,6 +611,15 @@ int ksmi_attn_mfma_vit(int backward, const void* qkv, void* out, float* lse, con
   static const bool split = getenv("KSMI_ATTN_SPLIT") != nullptr;      // A/B: the two-kernel backward
   if (!split && lse) {
     constexpr size_t lds = 4 * (size_t)13 * 16 * Geo<64>::RS + 2 * 13 * 16 * sizeof(float);
+    // 16 waves = one round of tiles per phase: 39.8 -> 31.1 us per layer in the FloodViT step, 1217 -> 1250 tiles/s same box
+    // (profiles/r06_ab_attn_waves.txt); KSMI_ATTN_BWD_NW=8: the round-2 form
+    static const int nw = getenv("KSMI_ATTN_BWD_NW") ? atoi(getenv("KSMI_ATTN_BWD_NW")) : 16;
+    if (nw == 16) {
+      auto kfn = attn_mfma_bwd_fused_kernel<64, 13, 16>; KSMI_NOTE(kfn);
+      set_lds(kfn, lds);
+      hipLaunchKernelGGL(kfn, dim3(H, B), dim3(1024), lds, (hipStream_t)stream, p);
+      return ksmi_check_launch("attn_mfma_bwd_fused");
+    }
     auto kfn = attn_mfma_bwd_fused_kernel<64, 13>; KSMI_NOTE(kfn);
     set_lds(kfn, lds);
     hipLaunchKernelGGL(kfn, dim3(H, B), dim3(512), lds, (hipStream_t)stream, p);
