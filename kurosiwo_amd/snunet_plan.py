@@ -107,6 +107,7 @@ class LaunchList:
 
     def resolve(self, lib):
         self.calls = [(None if name.startswith("@") else getattr(lib, name), tuple(argfn()), name, meta) for name, argfn, meta in self.pending]
+        self._compiled = None          # (the compiled form holds the argument values of the previous resolution)
 
     # ---- compiled form (round 6): the list as an array of ksmi_op walked by ONE C-ABI call per segment (csrc/runlist.hip) instead of one
     # ctypes call + stream switch + up to three torch event calls per launch in Python (host_issue_ms_per_step: 9 ms of a 14 ms SNUNet
