@@ -330,3 +330,26 @@ def test_fused_mlp_dropout_is_bit_identical_to_the_separate_passes(monkeypatch):
     assert out[0][4] == 0 and out[1][4] == 26 and out[0][3] - out[1][3] == 26, (out[0][3:], out[1][3:])
     assert all(torch.equal(a, b) for a, b in zip(out[0][0], out[1][0]))
     assert torch.equal(out[0][2], out[1][2]) and torch.equal(out[0][1], out[1][1])
+
+
+@pytest.mark.parametrize("B", [5, 6])
+def test_decoder_phase_convolutions_at_ragged_batch_sizes(B):
+    """at per-rank batches of 5 / 6 the 56 x 56 phase convolutions of the k4 s2 transposed convolutions fell into a
+    window where ksmi_igemm4_geom returned a tile shape without a compiled 2 x 2 instance and the forward raised instead of falling back
+    (ragged last validation batches, small data-parallel shards).  A whole train step and an evaluation forward at those sizes."""
+    import torch
+    from kurosiwo_amd.changeformer import ChangeFormerV6
+    from kurosiwo_amd.trainer import CDTrainStep
+    torch.manual_seed(1)
+    m = ChangeFormerV6(input_nc=2, output_nc=3, decoder_softmax=True, embed_dim=256, precision="bf16").cuda().train()
+    st = CDTrainStep(m, B, 224, 224, "ce+dice", (1.0, 1.0, 1.0), lr=1e-4)
+    g = torch.Generator().manual_seed(B)
+    xa, xb = torch.randn(B, 2, 224, 224, generator=g), torch.randn(B, 2, 224, 224, generator=g)
+    y = torch.randint(0, 3, (B, 224, 224), generator=g)
+    loss = st.step(xa.cuda(), xb.cuda(), y.cuda())
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss).all() and torch.isfinite(m.flat_grads).all()
+    m.eval()
+    with torch.no_grad():
+        out = m(xa.cuda(), xb.cuda())
+    assert out[-1].shape == (B, 3, 224, 224) and torch.isfinite(out[-1]).all()
