@@ -35,7 +35,8 @@ extern "C" {
 
 int ksmi_abi_version(void);
 const char* ksmi_last_error(void);
-/* Test / probe hook (ABI 7).  The launchers read their switches (KSMI_* environment variables) ONCE: the start-up switches at their first
+/* Test / probe hook (ABI 7).  Every launcher switch goes through ONE registry (csrc/api.hip: ksmi_knob_int / _str / _is_set; no other
+ * translation unit calls getenv).  The launchers read their switches (KSMI_* environment variables) ONCE: the start-up switches at their first
  * use, the run-time knobs -- KSMI_IGEMM3_CUS, KSMI_IGEMM4_CUS, KSMI_IGEMM4_VAR, KSMI_IG4_PATCH, KSMI_IG3_DBG, KSMI_IG4_DBG, KSMI_WGRAD3_NST,
  * KSMI_WGRAD3_WGS: grid shrinkers, forced tile variants and profiling switches of the tests and probes -- at their first look-up, after
  * which only this call changes them (value NULL: back to the built-in default).  No launch path calls getenv per launch.  Not part of

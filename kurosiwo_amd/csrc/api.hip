@@ -84,6 +84,10 @@ int ksmi_knob_int(const char* name, int dflt) {
   const auto& k = knob_slot(name);
   return k.first ? atoi(k.second.c_str()) : dflt;
 }
+bool ksmi_knob_is_set(const char* name) {
+  std::lock_guard<std::mutex> lk(g_knob_mu);
+  return knob_slot(name).first;
+}
 bool ksmi_knob_str(const char* name, char* out, int cap) {
   std::lock_guard<std::mutex> lk(g_knob_mu);
   const auto& k = knob_slot(name);

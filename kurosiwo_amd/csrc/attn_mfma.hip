@@ -597,7 +597,7 @@ int ksmi_attn_mfma_vit(int backward, const void* qkv, void* out, float* lse, con
     // them four times.  Round 2 measured the two the same inside the step; re-measured in round 6 (same box, FloodViT step): 27.7 -> 18.6 us
     // per layer, 1235 -> 1260 tiles/s (profiles/r06_ab_attn_waves.txt).  A 16-wave instance (one round of tiles) spills at 128 VGPRs: 49 us.
     // KSMI_ATTN_FWD_ONE_WG=0: the 64-query workgroups.
-    static const int one_wg = getenv("KSMI_ATTN_FWD_ONE_WG") ? atoi(getenv("KSMI_ATTN_FWD_ONE_WG")) : 1;
+    static const int one_wg = ksmi_knob_int("KSMI_ATTN_FWD_ONE_WG", 1);
     if (!one_wg) return launch_fwd<64, 13>(p, (hipStream_t)stream);
     const size_t lds = 2 * (size_t)13 * 16 * Geo<64>::RS;
     auto kfn = attn_mfma_fwd_kernel<64, 13, 8>; KSMI_NOTE(kfn);
@@ -608,12 +608,12 @@ int ksmi_attn_mfma_vit(int backward, const void* qkv, void* out, float* lse, con
   p.dout = (const bf16_t*)dout;
   p.dq = (bf16_t*)dqkv; p.dk = p.dq + H * 64; p.dv = p.dq + 2 * H * 64;
   p.dq_rs = p.dk_rs = p.dv_rs = C3;
-  static const bool split = getenv("KSMI_ATTN_SPLIT") != nullptr;      // A/B: the two-kernel backward
+  static const bool split = ksmi_knob_is_set("KSMI_ATTN_SPLIT");      // A/B: the two-kernel backward
   if (!split && lse) {
     constexpr size_t lds = 4 * (size_t)13 * 16 * Geo<64>::RS + 2 * 13 * 16 * sizeof(float);
     // 16 waves = one round of tiles per phase: 39.8 -> 31.1 us per layer in the FloodViT step, 1217 -> 1250 tiles/s same box
     // (profiles/r06_ab_attn_waves.txt); KSMI_ATTN_BWD_NW=8: the round-2 form
-    static const int nw = getenv("KSMI_ATTN_BWD_NW") ? atoi(getenv("KSMI_ATTN_BWD_NW")) : 16;
+    static const int nw = ksmi_knob_int("KSMI_ATTN_BWD_NW", 16);
     if (nw == 16) {
       auto kfn = attn_mfma_bwd_fused_kernel<64, 13, 16>; KSMI_NOTE(kfn);
       set_lds(kfn, lds);

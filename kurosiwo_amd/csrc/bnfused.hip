@@ -284,7 +284,7 @@ bool fused_ok(int C, int dtype, int Cstride) {
 }
 
 int fat_grid(int64_t work_items) {
-  static const int cap = getenv("KSMI_BN_FAT_GRID") ? atoi(getenv("KSMI_BN_FAT_GRID")) : 256;     // (A/B switch: workgroups of the fused passes)
+  static const int cap = ksmi_knob_int("KSMI_BN_FAT_GRID", 256);     // (A/B switch: workgroups of the fused passes)
   int64_t b = (work_items + kFat - 1) / kFat;
   return (int)(b < 1 ? 1 : (b > cap ? cap : b));
 }

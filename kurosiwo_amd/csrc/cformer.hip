@@ -1164,7 +1164,7 @@ int ksmi_im2col(const void* x, void* out, int B, int Cin, int H, int W, int Ho, 
   const int64_t n = (int64_t)B * Ho * Wo * Kpad;
   hipStream_t st = (hipStream_t)stream;
   const int vec = dtype == KSMI_BF16 ? 8 : 4;
-  static const bool scalar_only = getenv("KSMI_IM2COL_SCALAR") != nullptr;      // A/B switch
+  static const bool scalar_only = ksmi_knob_is_set("KSMI_IM2COL_SCALAR");      // A/B switch
   if (Kpad % vec == 0 && !scalar_only && ((uintptr_t)out & 15) == 0) {
     const int64_t nv = n / vec;
     if (src_nchw_f32) {
@@ -1258,7 +1258,7 @@ int ksmi_col2im(const void* dcol, void* dx, int accumulate, int B, int Cin, int 
 
 struct DwRowGeom { int seg, nseg; int64_t units; };
 static DwRowGeom dw_row_geom(int B, int H, int W) {
-  static const int want = getenv("KSMI_DW_SEG") ? atoi(getenv("KSMI_DW_SEG")) : 14;
+  static const int want = ksmi_knob_int("KSMI_DW_SEG", 14);
   DwRowGeom q;
   q.nseg = W <= want ? 1 : (W + want / 2) / want;
   q.seg = (W + q.nseg - 1) / q.nseg;
@@ -1267,7 +1267,7 @@ static DwRowGeom dw_row_geom(int B, int H, int W) {
   return q;
 }
 static bool dw_row_form() {
-  static const bool on = !(getenv("KSMI_DW_ROW") && atoi(getenv("KSMI_DW_ROW")) == 0);
+  static const bool on = (ksmi_knob_int("KSMI_DW_ROW", 1) != 0);
   return on;
 }
 
@@ -1284,7 +1284,7 @@ int ksmi_dwconv3x3_gelu_forward(const void* x, const float* w, const float* bias
             hipLaunchKernelGGL((dwconv3x3_row_kernel<float, 0>), grid, dim3(256), 0, st, (const float*)x, w, bias, (float*)z, (float*)g, B, H, W, C, q.seg, q.nseg, q.units));
     return ksmi_check_launch("dwconv3x3_gelu_fwd");
   }
-  static const int ppb_env = getenv("KSMI_DW_PPB") ? atoi(getenv("KSMI_DW_PPB")) : 0;
+  static const int ppb_env = ksmi_knob_int("KSMI_DW_PPB", 0);
   const int ppb = ppb_env > 0 ? ppb_env : 32;       // measured (KSMI_DW_PPB sweep): 128 -> 110 / 69 us, 32 -> 90 / 49 us (forward / adjoint)
   const dim3 grid((unsigned)((((int64_t)B * H * W + ppb - 1) / ppb + 7) / 8 * 8), (C / vec + 31) / 32);
   KSMI_DT(dtype,
@@ -1328,7 +1328,7 @@ int ksmi_dwconv3x3_backward_input(const void* dz, const float* w, void* dx, int 
             hipLaunchKernelGGL((dwconv3x3_row_kernel<float, 1>), grid, dim3(256), 0, st, (const float*)dz, w, (const float*)nullptr, (float*)dx, (float*)nullptr, B, H, W, C, q.seg, q.nseg, q.units));
     return ksmi_check_launch("dwconv3x3_bwd_input");
   }
-  static const int ppb_env = getenv("KSMI_DW_PPB") ? atoi(getenv("KSMI_DW_PPB")) : 0;
+  static const int ppb_env = ksmi_knob_int("KSMI_DW_PPB", 0);
   const int ppb = ppb_env > 0 ? ppb_env : 32;       // measured (KSMI_DW_PPB sweep): 128 -> 110 / 69 us, 32 -> 90 / 49 us (forward / adjoint)
   const dim3 grid((unsigned)((((int64_t)B * H * W + ppb - 1) / ppb + 7) / 8 * 8), (C / vec + 31) / 32);
   KSMI_DT(dtype,
@@ -1367,7 +1367,7 @@ int ksmi_dwconv3x3_wgrad(const void* x, const void* dz, float* partial, int rows
 }
 
 static bool sr_mfma(int dtype, int Nk, int C, int H) {
-  static const bool valu = getenv("KSMI_ATTN_VALU") != nullptr;
+  static const bool valu = ksmi_knob_is_set("KSMI_ATTN_VALU");
   return dtype == KSMI_BF16 && Nk <= 64 && H > 0 && (C / H == 64 || C / H == 80) && !valu;
 }
 

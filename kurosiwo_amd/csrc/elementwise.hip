@@ -112,7 +112,7 @@ __global__ void rows_fold_kernel(float* partial, int rows, int K, int Cstride, i
 
 static int fold_rows(float* partial, int rows, int K, int Cstride, int C, hipStream_t st) {
   constexpr int R = 32;
-  static const int fold_min = getenv("KSMI_FOLD_MIN") ? atoi(getenv("KSMI_FOLD_MIN")) : 8 * R;
+  static const int fold_min = ksmi_knob_int("KSMI_FOLD_MIN", 8) * R;
   if (rows <= fold_min) return rows;              // up to 256 rows: the finishing kernel's 64 row lanes walk 4 rows each, no extra launch
   hipLaunchKernelGGL(rows_fold_kernel, dim3((C + 15) / 16, R), dim3(256), 0, st, partial, rows, K, Cstride, C, R);
   return R;

@@ -6,6 +6,9 @@ int ksmi_check_launch(const char* what);           // hipGetLastError() -> 0 or 
 // run-time knobs (api.hip): the environment variable `name` as read at the knob's FIRST look-up, or what ksmi_set_knob stored since
 int ksmi_knob_int(const char* name, int dflt);
 bool ksmi_knob_str(const char* name, char* out, int cap);      // false: unset
+bool ksmi_knob_is_set(const char* name);
+// (every launcher switch goes through these: the start-up switches as `static const` reads -- evaluated once, at first use --, the
+// run-time knobs of the tests per call; no translation unit calls getenv itself)
 
 // Address of a __device__ symbol (the zero pages the LDS-DMA loaders read padding from) on the CURRENT device, cached per device:
 // a process that drives several GPUs must not hand device 1 the address device 0 resolved.  Concurrent first calls

@@ -276,8 +276,8 @@ int launch2n(const Gemm2P& p, hipStream_t st) {
 // Cost = whole rounds of the 256 x occupancy slots x the measured round time in us at K = 1024 (only the ratios matter).
 struct Tile2 { int mt, ns; };
 inline Tile2 pick_tile(int rows, int ntiles) {
-  static const int f_mt = getenv("KSMI_GEMM2_MT") ? atoi(getenv("KSMI_GEMM2_MT")) : 0;     // probes / tests: pin the instance
-  static const int f_ns = getenv("KSMI_GEMM2_NS") ? atoi(getenv("KSMI_GEMM2_NS")) : 0;
+  static const int f_mt = ksmi_knob_int("KSMI_GEMM2_MT", 0);     // probes / tests: pin the instance
+  static const int f_ns = ksmi_knob_int("KSMI_GEMM2_NS", 0);
   static const struct { int mt, ns, slots; double round_us; } cand[] = {
       {2, 3, 512, 13.0}, {4, 3, 256, 13.8}, {2, 2, 768, 15.5}, {3, 2, 512, 16.0}, {5, 3, 256, 16.3}, {6, 3, 256, 18.0},
       {4, 2, 512, 19.0}, {7, 3, 256, 21.0}, {8, 3, 256, 23.0}};
@@ -561,7 +561,7 @@ __global__ __launch_bounds__(256 * SPL, 1) void gemm2_tn_kernel(const Gemm2T p) 
 // 0 = launched, 1 = shape not covered (the caller falls back to gemm.hip), < 0 = error
 int ksmi_gemm2_nt(const void* x, int x_rs, const void* w, int w_rs, const float* bias, const void* resid, int r_rs, void* y, int y_rs,
                   int rows, int K, int N, hipStream_t st) {
-  static const bool off = getenv("KSMI_GEMM2_OFF") != nullptr;
+  static const bool off = ksmi_knob_is_set("KSMI_GEMM2_OFF");
   if (off || K % 64 || N % 128 || rows < 64 || K < 128) return 1;
   Gemm2P p = {(const bf16_t*)x, x_rs, (const bf16_t*)w, w_rs, bias, (const bf16_t*)resid, r_rs, (bf16_t*)y, y_rs, rows, K, N, 0, 0, 0};
   return dispatch2<false>(p, st);
@@ -569,7 +569,7 @@ int ksmi_gemm2_nt(const void* x, int x_rs, const void* w, int w_rs, const float*
 
 int ksmi_gemm2_nn(const void* dy, int dy_rs, const void* w, int w_rs, void* dx, int dx_rs, int rows, int K, int N, int accumulate,
                   hipStream_t st) {
-  static const bool off = getenv("KSMI_GEMM2_OFF") != nullptr;
+  static const bool off = ksmi_knob_is_set("KSMI_GEMM2_OFF");
   if (off || N % 64 || K % 128 || rows < 64 || N < 128) return 1;
   Gemm2P p = {(const bf16_t*)dy, dy_rs, (const bf16_t*)w, w_rs, nullptr, nullptr, 0, (bf16_t*)dx, dx_rs, rows, N, K, accumulate, 0, 0};
   return dispatch2<true>(p, st);
@@ -606,14 +606,14 @@ bool ksmi_gemm2_tn_spl(int tiles_times_splits, int steps_per_split) {
   // (profiles/r04_tn_spl.txt) the two-group kernels are 11-14 % shorter (38.9 -> 33.4 us, 61.8 -> 54.7 us) and the step is 3.6 % SLOWER
   // (13.81 -> 14.31 ms): a 512-thread workgroup with 144 KB of LDS owns its CU, while the one-group instance (72 KB) shares it with a
   // token GEMM of the main stream -- on the side stream co-residency is worth more than the shorter kernel (MAE: +0.9 %).
-  static const int f = getenv("KSMI_TN_SPL") ? atoi(getenv("KSMI_TN_SPL")) : 0;
+  static const int f = ksmi_knob_int("KSMI_TN_SPL", 0);
   if (f <= 0) return false;
   if (f == 1) return steps_per_split >= 2;
   return tiles_times_splits <= 256 && steps_per_split >= 12;
 }
 
 bool ksmi_gemm2_tn_enabled(int K, int N, int rows_per_split) {
-  static const bool off = getenv("KSMI_GEMM2_OFF") != nullptr || getenv("KSMI_GEMM2_TN_OFF") != nullptr;
+  static const bool off = ksmi_knob_is_set("KSMI_GEMM2_OFF") || ksmi_knob_is_set("KSMI_GEMM2_TN_OFF");
   return !(off || K % 8 || N % 8 || K < 64 || N < 64 || rows_per_split % 64);
 }
 
@@ -636,7 +636,7 @@ int ksmi_gemm2_tn(const void* x, int x_rs, const void* dy, int dy_rs, float* sla
     p.bias_rows = bias_grad; p.bias_rs = N;      // (slab mode: partial column sums of dY per split, [nsplit][N]: ksmi_conv_wgrad_fuses_bias == 2)
   }
   p.atiles = (p.a_cols + 127) / 128; p.btiles = (p.b_cols + btile - 1) / btile;
-  static const int ns = getenv("KSMI_TN_NS") ? atoi(getenv("KSMI_TN_NS")) : 3;      // probes: ring depth of the weight-gradient kernel
+  static const int ns = ksmi_knob_int("KSMI_TN_NS", 3);      // probes: ring depth of the weight-gradient kernel
   const dim3 grid(p.atiles * p.btiles, nsplit);
   if (!p.bias_rows && ns <= 3 && ksmi_gemm2_tn_spl((int)(grid.x * grid.y), (rows_per_split + 63) / 64)) {
     if (btile == 128) launch_tn<4, 2, 2>(grid, p, st);
@@ -762,11 +762,11 @@ int ksmi_gemm2_up_wgrad(const void* x, const void* dy, float* slab, float* grad,
 
 extern "C" {
 int ksmi_up_gemm_supported(int B, int H, int W, int C, int dtype) {
-  static const bool off = getenv("KSMI_GEMM2_OFF") != nullptr;
+  static const bool off = ksmi_knob_is_set("KSMI_GEMM2_OFF");
   return !off && dtype == KSMI_BF16 && C >= 128 && C % 128 == 0 && (int64_t)B * H * W >= 64 && (int64_t)B * H * W * 112 < ((int64_t)1 << 32) ? 1 : 0;
 }
 int ksmi_up_wgrad_supported(int B, int H, int W, int C, int dtype) {
-  static const bool off = getenv("KSMI_GEMM2_OFF") != nullptr;
+  static const bool off = ksmi_knob_is_set("KSMI_GEMM2_OFF");
   return !off && dtype == KSMI_BF16 && C >= 64 && C % 64 == 0 && (int64_t)B * H * W >= 64 && (int64_t)B * H * W * 112 < ((int64_t)1 << 32) ? 1 : 0;
 }
 int ksmi_up_pack_weight(const float* wt, void* wb, int C, void* stream) { return ksmi_gemm2_up_pack(wt, wb, C, (hipStream_t)stream); }

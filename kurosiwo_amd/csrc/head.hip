@@ -655,7 +655,7 @@ bool ecam_c_ok(int C, int dtype) {
 extern "C" {
 
 static int pool_split() {
-  static const int s = getenv("KSMI_ECAM_POOL_SPLIT") ? atoi(getenv("KSMI_ECAM_POOL_SPLIT")) : 16;
+  static const int s = ksmi_knob_int("KSMI_ECAM_POOL_SPLIT", 16);
   return s < 1 ? 1 : (s > kPoolSplit ? kPoolSplit : s);
 }
 

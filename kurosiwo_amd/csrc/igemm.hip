@@ -750,7 +750,7 @@ __global__ void tn_reduce_kernel(const ksmi_wgrad_desc d, int KC, int K) {
   }
 }
 
-static bool wgrad_generic_forced() { static const bool on = getenv("KSMI_WGRAD_GENERIC") != nullptr; return on; }
+static bool wgrad_generic_forced() { static const bool on = ksmi_knob_is_set("KSMI_WGRAD_GENERIC"); return on; }
 // eligibility of the token-GEMM path and its split geometry
 static bool gemm_tn_eligible(const ksmi_wgrad_desc* d, int es) {
   return es == 2 && d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && d->nsrc == 1 && d->src[0].scale == nullptr &&
@@ -771,7 +771,7 @@ static void gemm_tn_geom(const ksmi_wgrad_desc* d, int kc, int& nsplit, int& rps
     for (int i = 0; i < d->nchunks; ++i) plain = plain && d->k_off[i] == i * kc;
   const int steps_all = (rows + 63) / 64;
   double best = 1e30; int bs = 1; bt = 128;
-  static const int f_bt = getenv("KSMI_TN_BT") ? atoi(getenv("KSMI_TN_BT")) : 0, f_s = getenv("KSMI_TN_SPLIT") ? atoi(getenv("KSMI_TN_SPLIT")) : 0;   // probes
+  static const int f_bt = ksmi_knob_int("KSMI_TN_BT", 0), f_s = ksmi_knob_int("KSMI_TN_SPLIT", 0);   // probes
   for (int b = 128; b >= 64; b -= 32) {
     if (f_bt && b != f_bt) continue;
     const double step_us = b == 128 ? 0.95 : b == 96 ? 0.78 : 0.6;
@@ -804,19 +804,19 @@ WgradGeom wgrad_geom(const ksmi_wgrad_desc* d) {
   g.kc = ElemTraits<T>::kVec * 4;
   g.npad = (d->N + 15) & ~15;
   g.nt = g.npad >= 64 ? 4 : (g.npad >= 32 ? 2 : 1);
-  static const int wnt_cap = getenv("KSMI_WGRAD_NT") ? atoi(getenv("KSMI_WGRAD_NT")) : 4;
+  static const int wnt_cap = ksmi_knob_int("KSMI_WGRAD_NT", 4);
   if (g.nt > wnt_cap) g.nt = wnt_cap;
   // 3x3 / 4x4: the 64-column tile (96+ accumulators beside the prefetch registers of the patch pipeline) spills at 256 VGPRs and is
   // latency-starved at 512; two 32-column workgroups re-read X from L2 instead and run the same speed or better
-  static const bool wnt4 = getenv("KSMI_WGRAD_NT4") != nullptr;
+  static const bool wnt4 = ksmi_knob_is_set("KSMI_WGRAD_NT4");
   if (g.taps >= 9 && g.nt > 2 && !wnt4) g.nt = 2;
   g.bn = g.nt * 16;
   g.ntiles = (g.npad + g.bn - 1) / g.bn;
   const int tilesX = (d->Wout + d->TW - 1) / d->TW, tilesY = (d->Hout + d->TH - 1) / d->TH;
   g.patches = d->B * tilesX * tilesY;
   // aim at ~1024 workgroups in total; at most 512 splits
-  static const int wg_target = getenv("KSMI_WGRAD_WGS") ? atoi(getenv("KSMI_WGRAD_WGS")) : 1024;
-  static const int split_cap = getenv("KSMI_WGRAD_SPLITS") ? atoi(getenv("KSMI_WGRAD_SPLITS")) : 512;   // single-chunk gradients (K <= 32) otherwise run one workgroup per CU
+  static const int wg_target = ksmi_knob_int("KSMI_WGRAD_WGS", 1024);
+  static const int split_cap = ksmi_knob_int("KSMI_WGRAD_SPLITS", 512);   // single-chunk gradients (K <= 32) otherwise run one workgroup per CU
   int want = wg_target / (d->nchunks * g.ntiles);
   if (want < 1) want = 1;
   if (want > split_cap) want = split_cap;
@@ -837,7 +837,7 @@ WgradGeom wgrad_geom(const ksmi_wgrad_desc* d) {
 
 // KSMI_SLAB_BIAS=0: the split-mode token weight gradient leaves the bias gradient to a channel_sum pass (the round-4 route; same-box A/B)
 static bool wgrad_slab_bias_on() {
-  static const bool on = getenv("KSMI_SLAB_BIAS") ? atoi(getenv("KSMI_SLAB_BIAS")) != 0 : true;
+  static const bool on = (ksmi_knob_int("KSMI_SLAB_BIAS", 1) != 0);
   return on;
 }
 
@@ -900,10 +900,10 @@ int launch_wgrad(const ksmi_wgrad_desc* d, hipStream_t st) {
     const size_t pmax = pin > (size_t)d->B * d->Hout * d->Wout ? pin : (size_t)d->B * d->Hout * d->Wout;
     if (pmax * cmax * sizeof(T) >= ((size_t)1 << 32)) return ksmi_fail(KSMI_E_UNSUPPORTED, "wgrad: a tensor of 4 GiB or more is not supported");
   }
-  static const int wdbg = getenv("KSMI_WDBG") ? atoi(getenv("KSMI_WDBG")) : 0;   // profiling switches: 1 no MFMA, 2 no global loads, 4 no LDS stores
+  static const int wdbg = ksmi_knob_int("KSMI_WDBG", 0);   // profiling switches: 1 no MFMA, 2 no global loads, 4 no LDS stores
   const dim3 grid(g.nsplit, d->nchunks, g.ntiles);
   // LIN: bf16, patch width divides 16 and the patch is a whole number of 32-pixel k-steps (see the kernel)
-  static const bool lin_off = getenv("KSMI_WGRAD_NOLIN") != nullptr;
+  static const bool lin_off = ksmi_knob_is_set("KSMI_WGRAD_NOLIN");
   const bool lin = !lin_off && sizeof(T) == 2 && (16 % d->TW) == 0 && ((d->TH * d->TW) % 32) == 0;
 #define KSMI_LAUNCH_WG(NT_, KH_, KW_)                                                               \
   do {                                                                                              \
@@ -987,7 +987,7 @@ int ksmi_conv_stats_rows(const ksmi_conv_desc* d, int dtype) {
 int ksmi_conv_dispatch_info(const ksmi_conv_desc* d, int dtype, int32_t* info) {
   if (!d || !info) return ksmi_fail(KSMI_E_ARG, "conv_dispatch_info: null argument");
   for (int i = 0; i < 8; ++i) info[i] = 0;
-  static const bool force_v1 = getenv("KSMI_IGEMM_V1") != nullptr;
+  static const bool force_v1 = ksmi_knob_is_set("KSMI_IGEMM_V1");
   ksmi_igemm3_geom_t g3;
   if (!force_v1 && !d->gate_src && ksmi_igemm3_geom(d, dtype, &g3) && (d->stats == nullptr || d->stats_rows == g3.gx)) {
     info[0] = 3; info[1] = 1; info[6] = g3.gx; info[7] = g3.gy;
@@ -1009,7 +1009,7 @@ int ksmi_conv_forward(const ksmi_conv_desc* d, int dtype, void* stream) {
       (d->nchunks > KSMI_MAX_CHUNKS && !(d->uniform_kc && d->nsrc == 1)))
     return ksmi_fail(KSMI_E_ARG, "conv: bad descriptor");
   if (dtype != KSMI_BF16 && dtype != KSMI_F32) return ksmi_fail(KSMI_E_ARG, "conv: bad dtype");
-  static const bool force_v1 = getenv("KSMI_IGEMM_V1") != nullptr;      // A/B switch for profiling
+  static const bool force_v1 = ksmi_knob_is_set("KSMI_IGEMM_V1");      // A/B switch for profiling
   {   // short K, bf16: persistent workgroups with register-resident weights (its statistics rows = workgroups, not tiles)
     ksmi_igemm3_geom_t g3;
     if (!force_v1 && !d->gate_src && ksmi_igemm3_geom(d, dtype, &g3) && (d->stats == nullptr || d->stats_rows == g3.gx))
@@ -1044,7 +1044,7 @@ int ksmi_pack_weights_batched(const ksmi_pack_desc* descs_device, int n, int dty
   // x = workgroups per descriptor: the large tensors (512 x 512 x 9: 295 k vectors) decide the duration, so they get enough to fill
   // the machine on their own; workgroups beyond a small tensor's vectors fall through the loop at once (48 per descriptor: 108 us
   // per SNUNet step with ~200 workgroups alive in the tail)
-  static const int gx = getenv("KSMI_PACK_GRID") ? atoi(getenv("KSMI_PACK_GRID")) : 512;
+  static const int gx = ksmi_knob_int("KSMI_PACK_GRID", 512);
   const dim3 grid(gx < 1 ? 1 : gx, n);
   if (dtype == KSMI_BF16) hipLaunchKernelGGL(pack_weights_batched_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, descs_device);
   else if (dtype == KSMI_F32) hipLaunchKernelGGL(pack_weights_batched_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, descs_device);
@@ -1063,7 +1063,7 @@ size_t ksmi_conv_wgrad_workspace(const ksmi_wgrad_desc* d, int dtype) {
 //    [d->nsplit][d->N] floats (overwritten, not accumulated); the caller sums the rows into the bias gradient
 int ksmi_conv_wgrad_fuses_bias(const ksmi_wgrad_desc* d, int dtype) {
   if (!d || dtype != KSMI_BF16 || d->nsrc != 1) return 0;
-  static const bool off = getenv("KSMI_NO_FUSED_BIAS_GRAD") != nullptr;
+  static const bool off = ksmi_knob_is_set("KSMI_NO_FUSED_BIAS_GRAD");
   if (off) return 0;
   WgradGeom g = wgrad_geom<bf16_t>(d);
   if (!g.tn || g.v3) return 0;

@@ -397,29 +397,29 @@ int launch2(const ksmi_conv_desc* d, int dbg, hipStream_t st) {
     const size_t px = d->in_sy ? (size_t)d->B * d->in_H * d->in_W : (size_t)d->B * d->Hin * d->Win;
     if (px * (size_t)d->src[i].C * sizeof(T) >= ((size_t)1 << 32)) return ksmi_fail(KSMI_E_UNSUPPORTED, "conv: a source tensor of 4 GiB or more is not supported");
   }
-  static const int nt_cap = getenv("KSMI_NT_CAP") ? atoi(getenv("KSMI_NT_CAP")) : 2;      // BN=32: 80 KB of LDS = 2 workgroups per CU beats the BN=64 tile (1 per CU) by 15-35 %
+  static const int nt_cap = ksmi_knob_int("KSMI_NT_CAP", 2);      // BN=32: 80 KB of LDS = 2 workgroups per CU beats the BN=64 tile (1 per CU) by 15-35 %
   int nt = d->Npad >= 64 ? 4 : (d->Npad >= 32 ? 2 : 1);
   // token GEMMs (1x1) keep both a small halo (16 KB) and a small weight slab: BN = 64 still leaves 2 workgroups per CU
-  static const int nt_cap11 = getenv("KSMI_NT_CAP_1X1") ? atoi(getenv("KSMI_NT_CAP_1X1")) : 2;
+  static const int nt_cap11 = ksmi_knob_int("KSMI_NT_CAP_1X1", 2);
   if (nt > (taps == 1 ? nt_cap11 : nt_cap)) nt = taps == 1 ? nt_cap11 : nt_cap;
   // two channel groups per workgroup (8 waves, one halo image): 3x3 / 2x2 / 1x1 with at least 64 output channels
-  static const bool wn_off = getenv("KSMI_WN1") != nullptr;
-  static const bool lean_off = getenv("KSMI_NO_LEAN") != nullptr;
+  static const bool wn_off = ksmi_knob_is_set("KSMI_WN1");
+  static const bool lean_off = ksmi_knob_is_set("KSMI_NO_LEAN");
   const bool lean = !lean_off && d->nchunks == 1 && taps == 9 && nt == 2 && HP * 64 <= 24576 && d->src[0].scale == nullptr;   // (the AFF path spills at 168 VGPRs)
-  static const int wn_min = getenv("KSMI_WN_MIN") ? atoi(getenv("KSMI_WN_MIN")) : 64;
+  static const int wn_min = ksmi_knob_int("KSMI_WN_MIN", 64);
   const int wn = (!lean && !wn_off && nt == 2 && d->Npad >= wn_min && taps <= 9) ? 2 : 1;
   const int bn = nt * 16 * wn;
   const int gy = (d->Npad + bn - 1) / bn;
   const size_t hpb = ((size_t)HP * 64 + 1023) & ~(size_t)1023;
   // single-chunk convolutions (K <= 32 bf16 channels) need one stage only: 40 KB -> 3-4 workgroups per CU
-  static const int stage_cap = getenv("KSMI_STAGES") ? atoi(getenv("KSMI_STAGES")) : 2;
+  static const int stage_cap = ksmi_knob_int("KSMI_STAGES", 2);
   const int stages = (d->nchunks > 1 && stage_cap > 1) ? 2 : 1;
   const bool aff = d->src[0].scale != nullptr;
   // two pixel tiles per workgroup and weight slab (MP = 2): long-K 3x3 convolutions on the 8-wave tile with >= 256 output channels
   // (ChangeFormer's 256-channel 224^2 / 112^2 layers: +1.8 % on its step; neutral to -0.5 % on SNUNet's 64..128-channel layers, which
   // keep one tile), when the halved grid still gives every CU >= 1.5 workgroups and two stages of (2 halos + slab) fit 160 KB of LDS
-  static const bool mp_off = getenv("KSMI_IGEMM2_MP1") != nullptr;
-  static const int mp_min_k = getenv("KSMI_IGEMM2_MP_MINK") ? atoi(getenv("KSMI_IGEMM2_MP_MINK")) : 4;
+  static const bool mp_off = ksmi_knob_is_set("KSMI_IGEMM2_MP1");
+  static const int mp_min_k = ksmi_knob_int("KSMI_IGEMM2_MP_MINK", 4);
   const bool mp2 = !mp_off && sizeof(T) == 2 && wn == 2 && nt == 2 && !aff && stages == 2 && taps == 9 && d->nchunks >= mp_min_k &&
                    2 * (2 * hpb + (size_t)taps * bn * 64) <= (size_t)160 * 1024 && gy >= 4 && (size_t)((gm + 1) / 2) * gy >= 384;
   const dim3 grid(mp2 ? (gm + 1) / 2 : gm, gy);
@@ -503,7 +503,7 @@ bool ksmi_igemm2_eligible(const ksmi_conv_desc* d, int dtype) {
   const int kc = dtype == KSMI_BF16 ? 32 : 16;
   // whole chunks -- or (round 5, bf16) every source ONE partial chunk of the same width (16 + 16 + 16 channels: FC-Siam conv12d; a
   // 16-channel input gradient with the mask epilogue): the k-groups past it are never fetched (Igemm2Args.klen); no fused operand then
-  static const bool part_on = getenv("KSMI_IGEMM2_PARTIAL") ? atoi(getenv("KSMI_IGEMM2_PARTIAL")) != 0 : true;
+  static const bool part_on = (ksmi_knob_int("KSMI_IGEMM2_PARTIAL", 1) != 0);
   bool whole = true, part = dtype == KSMI_BF16 && part_on;
   for (int i = 0; i < d->nsrc; ++i) {
     const ksmi_src& q = d->src[i];
@@ -517,7 +517,7 @@ bool ksmi_igemm2_eligible(const ksmi_conv_desc* d, int dtype) {
 }
 
 int ksmi_igemm2_launch(const ksmi_conv_desc* d0, int dtype, hipStream_t st) {
-  static const int dbg = getenv("KSMI_DBG") ? atoi(getenv("KSMI_DBG")) : 0;
+  static const int dbg = ksmi_knob_int("KSMI_DBG", 0);
   if (dtype == KSMI_BF16) return launch2<bf16_t>(d0, dbg, st);
   return launch2<float>(d0, dbg, st);
 }

@@ -389,7 +389,7 @@ __global__ __launch_bounds__(256 * WN, (WN == 1 && NCH * KH * KW * NTI <= 9) ? 2
 
 // ---- host side --------------------------------------------------------------------------------------------------------------
 bool ksmi_igemm3_geom(const ksmi_conv_desc* d, int dtype, ksmi_igemm3_geom_t* g) {
-  static const bool off = getenv("KSMI_IGEMM3_OFF") != nullptr;
+  static const bool off = ksmi_knob_is_set("KSMI_IGEMM3_OFF");
   if (off || dtype != KSMI_BF16) return false;
   const int taps = d->KH * d->KW;
   if (!((d->KH == 3 && d->KW == 3) || (d->KH == 1 && d->KW == 1) || (d->KH == 2 && d->KW == 2))) return false;
@@ -408,7 +408,7 @@ bool ksmi_igemm3_geom(const ksmi_conv_desc* d, int dtype, ksmi_igemm3_geom_t* g)
   }
   if (d->alpha != 0.f || d->resid || d->relu_out || d->out_sy || d->in_sy) return false;
   // KSMI_IGEMM3_PARTIAL=0: the round-4 rule (whole 32-channel chunks, N % 8 == 0, >= 32 padded columns) for same-box A/B runs
-  static const bool partial_on = getenv("KSMI_IGEMM3_PARTIAL") ? atoi(getenv("KSMI_IGEMM3_PARTIAL")) != 0 : true;
+  static const bool partial_on = (ksmi_knob_int("KSMI_IGEMM3_PARTIAL", 1) != 0);
   if (!partial_on) {
     if ((d->N % 8) || d->Npad < 32 || d->ndst != 1) return false;
     for (int i = 0; i < d->nsrc; ++i) if (d->src[i].c_len % 32) return false;
@@ -425,13 +425,13 @@ bool ksmi_igemm3_geom(const ksmi_conv_desc* d, int dtype, ksmi_igemm3_geom_t* g)
   if (d->ps_cout && (d->ps_cout % 8)) return false;
   // ReLU-mask + BN-backward sums epilogue: instances exist for 3x3 (KSMI_IGEMM3_MASK=1) but measured slower than the tile kernel /
   // igemm4 (K = 32: 154 vs 89 us, the mask loads spill 45 VGPRs next to the register-resident weights; K = 64: 72 vs 64 us): off
-  static const bool mask_on = getenv("KSMI_IGEMM3_MASK") ? atoi(getenv("KSMI_IGEMM3_MASK")) != 0 : false;
+  static const bool mask_on = (ksmi_knob_int("KSMI_IGEMM3_MASK", 0) != 0);
   // ... except where the tile kernel cannot run at all (a source that is not whole 32-channel chunks: Unet decoder block 5, 16 channels
   // at 224 x 224 -- 424 us on the first-generation kernel)
   bool part_src = false;
   for (int i = 0; i < d->nsrc; ++i) part_src = part_src || (d->src[i].c_len % 32) != 0;
   // (KSMI_IGEMM3_MASK_PART=0: leave those to the tile kernel's uniform-partial-chunk route, igemm2.hip klen)
-  static const bool mask_part_on = getenv("KSMI_IGEMM3_MASK_PART") ? atoi(getenv("KSMI_IGEMM3_MASK_PART")) != 0 : true;
+  static const bool mask_part_on = (ksmi_knob_int("KSMI_IGEMM3_MASK_PART", 1) != 0);
   if (d->mask_src && !((mask_on || (part_src && partial_on && mask_part_on)) && taps == 9)) return false;
   if (d->gate_src || (d->mask_src && d->src[0].scale)) return false;
   auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
@@ -457,7 +457,7 @@ bool ksmi_igemm3_geom(const ksmi_conv_desc* d, int dtype, ksmi_igemm3_geom_t* g)
   if (taps == 9) {
     if (d->nchunks > 2) return false;
     // (fused-operand K = 64 on this kernel, KSMI_IGEMM3_AFF2=1: 99 us against 68 us on igemm4, one 4-wave workgroup per CU)
-    static const bool aff2_on = getenv("KSMI_IGEMM3_AFF2") ? atoi(getenv("KSMI_IGEMM3_AFF2")) != 0 : false;
+    static const bool aff2_on = (ksmi_knob_int("KSMI_IGEMM3_AFF2", 0) != 0);
     if (d->nchunks == 2) { if (aff && !aff2_on) return false; g->WN = 1; }
   } else if (taps == 4) {
     if (aff || (d->nchunks != 1 && d->nchunks != 2 && d->nchunks != 4)) return false;

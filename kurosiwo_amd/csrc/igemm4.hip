@@ -914,11 +914,11 @@ void ig4_patch(int H, int W, int pmax, int hmax, int* th_o, int* tw_o) {
 }  // namespace
 
 bool ksmi_igemm4_geom(const ksmi_conv_desc* d, int dtype, ksmi_igemm4_geom_t* g) {
-  static const bool off = getenv("KSMI_IGEMM4_OFF") != nullptr;
+  static const bool off = ksmi_knob_is_set("KSMI_IGEMM4_OFF");
   if (off || dtype != KSMI_BF16) return false;
   // 2 x 2 stride-1 phase convolutions of ConvTranspose2d(k4, s2, p1) and its input gradient (round 5): strided views, padding 0 | 1 per
   // phase, 128-column tiles, the chunk-granular schedule.  KSMI_IG4_K2=0 sends them back to igemm2.
-  static const int k2_on = getenv("KSMI_IG4_K2") ? atoi(getenv("KSMI_IG4_K2")) : 1;
+  static const int k2_on = ksmi_knob_int("KSMI_IG4_K2", 1);
   const bool k2 = d->KH == 2 && d->KW == 2;
   if (k2) {
     if (!k2_on || d->stride != 1 || (unsigned)d->pad > 1u || (unsigned)d->pad_x > 1u) return false;
@@ -937,7 +937,7 @@ bool ksmi_igemm4_geom(const ksmi_conv_desc* d, int dtype, ksmi_igemm4_geom_t* g)
   // N % 8 != 0 (2- / 3-class heads into a destination with a channel stride of 8: ChangeFormer's change_probability, 256 -> 2): the last
   // 8-channel group is stored whole, its pad channels as zeros (zero weights, no bias beyond N) -- plain epilogue only
   // (KSMI_IG4_THIN=0: back to the tile kernel)
-  static const int thin_on = getenv("KSMI_IG4_THIN") ? atoi(getenv("KSMI_IG4_THIN")) : 1;
+  static const int thin_on = ksmi_knob_int("KSMI_IG4_THIN", 1);
   if ((d->N % 8) && (!thin_on || k2 || d->mask_src || d->gate_src || d->resid || d->dst[0].accumulate || d->alpha != 0.f || d->relu_out ||
                      d->dst[0].c_off + ((d->N + 7) & ~7) > d->dst[0].C)) return false;
   if (d->Npad != 32 && (d->Npad % 64)) return false;
@@ -968,12 +968,12 @@ bool ksmi_igemm4_geom(const ksmi_conv_desc* d, int dtype, ksmi_igemm4_geom_t* g)
   Var cand[5];
   int nc = 0;
   // two 4-wave workgroups per CU for the 32-column layers (KSMI_IG4_NW4: 1 = on, 0 = off; read once)
-  static const int nw4 = getenv("KSMI_IG4_NW4") ? atoi(getenv("KSMI_IG4_NW4")) : 0;
+  static const int nw4 = ksmi_knob_int("KSMI_IG4_NW4", 0);
   if (d->Npad == 32 && nw4 && !k2) cand[nc++] = {4, 2, 4};          // 256 px x 32, wave 64 x 32, two workgroups per CU
   if (d->Npad % 128 == 0) cand[nc++] = {4, 4, 8};                   // 256 px x 128 columns, wave 64 x 64
   // 64 columns exactly (SNUNet level 1): 256 px x 64 tiles make 7 rounds of 224 workgroups at 112^2 x 32 (88 % of the slots filled) where
   // the 512 px ones make 4 rounds of 208 (77 %): 2-8 % shorter per launch (profiles/r05_ig4_variants.txt (e)); KSMI_IG4_N64=84 restores the old order
-  static const int n64 = getenv("KSMI_IG4_N64") ? atoi(getenv("KSMI_IG4_N64")) : 42;
+  static const int n64 = ksmi_knob_int("KSMI_IG4_N64", 42);
   // (2 x 2 phase convolutions: the 256 px x 128 shape is the ONLY instance that exists -- no 64-column candidates for them, so a geometry
   // this function accepts is always launchable; a shape the fill rule below would have skipped simply stays on that one tile)
   if (!k2) {
@@ -1007,10 +1007,10 @@ bool ksmi_igemm4_geom(const ksmi_conv_desc* d, int dtype, ksmi_igemm4_geom_t* g)
     g->hslot = g->nh * nwv * 1024;
     if (hp * 64 > g->hslot) continue;
     const size_t tabs = (size_t)(nwv * 2 * 16 * nf + bn) * 4 + (size_t)KSMI_MAX_CHUNKS * 16 + (aff ? (size_t)d->nchunks * 32 * 2 * 4 : 0);
-    static const int rot_on = getenv("KSMI_IG4_ROT") ? atoi(getenv("KSMI_IG4_ROT")) : 1;
-    static const int deep_on = getenv("KSMI_IG4_DEEP") ? atoi(getenv("KSMI_IG4_DEEP")) : 0;   // (the kernel's DEEP: compiled in; the switch forces the per-role schedule instead)
+    static const int rot_on = ksmi_knob_int("KSMI_IG4_ROT", 1);
+    static const int deep_on = ksmi_knob_int("KSMI_IG4_DEEP", 0);   // (the kernel's DEEP: compiled in; the switch forces the per-role schedule instead)
     // chunk-granular schedule (kernel: CHUNK = ROT == 3) for the NF = 2 tiles: KSMI_IG4_CHUNK (1 = on)
-    static const int chunk_on = getenv("KSMI_IG4_CHUNK") ? atoi(getenv("KSMI_IG4_CHUNK")) : 0;
+    static const int chunk_on = ksmi_knob_int("KSMI_IG4_CHUNK", 0);
     const bool chunk = k2 || (rot_on && chunk_on && !aff && nwv == 8 && nf == 2);
     const int nhs_ = (nwv == 4 || (wm == 8 && nf == 4) || (chunk && wm == 8)) ? 2 : 3;
     const bool deep = !chunk && rot_on && deep_on && !aff && nhs_ == 3 && nwv == 8 && nf == 2;      // <8,2> (32 columns) and <4,2> (64 columns)
@@ -1050,9 +1050,9 @@ int ksmi_igemm4_launch(const ksmi_conv_desc* d, const ksmi_igemm4_geom_t* g, hip
   const int tilesX = (d->Wout + g->tw - 1) / g->tw, tilesY = (d->Hout + g->th - 1) / g->th;
   ka.m_tw = fastdiv_magic(g->tw); ka.m_hw = fastdiv_magic(g->tw + d->KW - 1); ka.m_tx = fastdiv_magic(tilesX); ka.m_ty = fastdiv_magic(tilesY);
   ka.dbg = ksmi_knob_int("KSMI_IG4_DBG", 0);
-  static const int stag = getenv("KSMI_IG4_STAGGER") ? atoi(getenv("KSMI_IG4_STAGGER")) : 1;
+  static const int stag = ksmi_knob_int("KSMI_IG4_STAGGER", 1);
   ka.stagger = stag;
-  static const int rot = getenv("KSMI_IG4_ROT") ? atoi(getenv("KSMI_IG4_ROT")) : 1;      // (rotated schedule: +3-7 % on the long-K shapes)
+  static const int rot = ksmi_knob_int("KSMI_IG4_ROT", 1);      // (rotated schedule: +3-7 % on the long-K shapes)
   ka.rot = rot;
   ka.hslot = g->hslot; ka.nh = g->nh; ka.nhs = g->nhs;
   ka.tiles = g->tiles; ka.gx = g->gx; ka.gy = g->gy;

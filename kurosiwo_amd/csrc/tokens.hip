@@ -686,7 +686,7 @@ int ksmi_layernorm_forward(const void* x, const float* gamma, const float* beta,
 int ksmi_layernorm_bwd_blocks(int rows) {
   // 256 workgroups (one per CU) up to ViT-sized token matrices (measured faster there than 512 / 1024); the 200 k-row maps of the MiT
   // encoder's first stage need more waves in flight to stream (1024: ChangeFormer +0.5 %)
-  static const int env = getenv("KSMI_LN_BWD_BLOCKS") ? atoi(getenv("KSMI_LN_BWD_BLOCKS")) : 0;
+  static const int env = ksmi_knob_int("KSMI_LN_BWD_BLOCKS", 0);
   const int cap = env > 0 ? env : (rows >= 100000 ? 1024 : 256);
   int b = (rows + 7) / 8;
   return b > cap ? cap : (b < 1 ? 1 : b);
@@ -830,7 +830,7 @@ int ksmi_vit_embed_backward(const void* dx0, void* demb, float* dcls, float* dpo
 
 int ksmi_attention_forward(const void* qkv, void* out, float* lse, int B, int N, int H, int D, float scale, int dtype, void* stream) {
   if (D != 64) return ksmi_fail(KSMI_E_UNSUPPORTED, "attention: dim_head must be 64");
-  static const bool valu = getenv("KSMI_ATTN_VALU") != nullptr;       // A/B switch
+  static const bool valu = ksmi_knob_is_set("KSMI_ATTN_VALU");       // A/B switch
   if (dtype == KSMI_BF16 && N <= 208 && !valu) return ksmi_attn_mfma_vit(0, qkv, out, lse, nullptr, nullptr, nullptr, B, N, H, scale, stream);
   const size_t es = dtype == KSMI_BF16 ? 2 : 4;
   const size_t lds = 2 * (size_t)N * D * es;
@@ -848,7 +848,7 @@ size_t ksmi_attention_bwd_workspace(int B, int N, int H, int D, int dtype) {
 int ksmi_attention_backward(const void* qkv, const void* out, const float* lse, const void* dout, void* dqkv, void* workspace, int B, int N,
                             int H, int D, float scale, int dtype, void* stream) {
   if (D != 64) return ksmi_fail(KSMI_E_UNSUPPORTED, "attention: dim_head must be 64");
-  static const bool valu = getenv("KSMI_ATTN_VALU") != nullptr;
+  static const bool valu = ksmi_knob_is_set("KSMI_ATTN_VALU");
   if (dtype == KSMI_BF16 && N <= 208 && !valu) {
     if (!workspace) return ksmi_fail(KSMI_E_ARG, "attention_bwd: workspace required (ksmi_attention_bwd_workspace)");
     return ksmi_attn_mfma_vit(1, qkv, (void*)out, (float*)lse, dout, dqkv, workspace, B, N, H, scale, stream);

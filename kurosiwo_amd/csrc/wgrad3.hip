@@ -389,15 +389,15 @@ __global__ __launch_bounds__(256) void wgrad3_reduce_kernel(const ksmi_wgrad_des
 
 // ---- host side --------------------------------------------------------------------------------------------------------
 static bool partial_on_n() {     // KSMI_WGRAD3_PARTIAL=0: whole chunks, N % 8 == 0, N >= 16 only (the round-4 rule; same-box A/B)
-  static const bool on = getenv("KSMI_WGRAD3_PARTIAL") ? atoi(getenv("KSMI_WGRAD3_PARTIAL")) != 0 : true;
+  static const bool on = (ksmi_knob_int("KSMI_WGRAD3_PARTIAL", 1) != 0);
   return on;
 }
 bool ksmi_wgrad3_geom(const ksmi_wgrad_desc* d, int dtype, ksmi_wgrad3_geom_t* g) {
-  static const bool off = getenv("KSMI_WGRAD3_OFF") != nullptr;
+  static const bool off = ksmi_knob_is_set("KSMI_WGRAD3_OFF");
   if (off || dtype != KSMI_BF16) return false;
   // 2 x 2 phase gradients (ConvTranspose2d(k4, s2, p1), plan_base._deconv_wgrad): the 2 x 2 window of the 3 x 3 neighbourhood whose
   // origin is (1 - pad, 1 - pad_x); KSMI_WGRAD3_K2=0 sends them back to igemm_wgrad_kernel
-  static const int k2_on = getenv("KSMI_WGRAD3_K2") ? atoi(getenv("KSMI_WGRAD3_K2")) : 1;
+  static const int k2_on = ksmi_knob_int("KSMI_WGRAD3_K2", 1);
   const bool k2 = d->KH == 2 && d->KW == 2;
   g->r0 = g->c0 = -1;
   if (k2) {
@@ -409,7 +409,7 @@ bool ksmi_wgrad3_geom(const ksmi_wgrad_desc* d, int dtype, ksmi_wgrad3_geom_t* g
   // d out row are read (the pad channels must exist inside the row; their columns are computed and dropped by the reducer)
   if (((d->N % 8) != 0 || d->N < 16) && (!partial_on_n() || k2 || (d->dyC % 8) || (d->dy_c_off % 8) || d->dy_c_off + ((d->N + 7) & ~7) > d->dyC)) return false;
   // KSMI_WGRAD3_PARTIAL=0: whole 32-channel chunks only (the round-4 rule; same-box A/B)
-  static const bool partial_on = getenv("KSMI_WGRAD3_PARTIAL") ? atoi(getenv("KSMI_WGRAD3_PARTIAL")) != 0 : true;
+  static const bool partial_on = (ksmi_knob_int("KSMI_WGRAD3_PARTIAL", 1) != 0);
   for (int i = 0; i < d->nsrc; ++i) {
     // whole 16-byte granules inside the source row; the last chunk of a source may be partial (zero-page granules, klen in the kernel)
     if (d->src[i].c_len < 1 || (d->src[i].C % 8) || (d->src[i].c_off % 8) || d->src[i].c_off + ((d->src[i].c_len + 7) & ~7) > d->src[i].C) return false;
@@ -524,7 +524,7 @@ int ksmi_wgrad3_launch(const ksmi_wgrad_desc* d, const ksmi_wgrad3_geom_t* g, hi
   if ((size_t)g->patches * 1 >= ((size_t)1 << 31) / 1024) return ksmi_fail(KSMI_E_UNSUPPORTED, "wgrad3: too many patches");
   const dim3 grid(g->nsplit * g->KT * g->NTt);
   const bool aff = d->src[0].scale != nullptr;
-  static const bool deep = !(getenv("KSMI_WGRAD3_DEEP") && atoi(getenv("KSMI_WGRAD3_DEEP")) == 0);   // fragment requests AD taps ahead (default)
+  static const bool deep = (ksmi_knob_int("KSMI_WGRAD3_DEEP", 1) != 0);   // fragment requests AD taps ahead (default)
 #define KSMI_W3_(WC_, WN_, NF_, AFF_, DEEP_)                                                          \
   do {                                                                                               \
     auto kfn = wgrad3_kernel<WC_, WN_, NF_, AFF_, DEEP_>; KSMI_NOTE(kfn);                            \
