@@ -750,6 +750,36 @@ __global__ void tn_reduce_kernel(const ksmi_wgrad_desc d, int KC, int K) {
   }
 }
 
+// ... for a PLAIN row-major nn.Linear gradient grad[n][k] (gK == 1): the slabs have n contiguous, the gradient k contiguous, so the
+// element-wise reducer above writes every 4-byte value of the gradient into a cache line of its own (4 MB of gradient = one million
+// scattered stores: 15.8 us for the 1024 x 1024 layers of the ViT, 0.76 TB/s).  Here a workgroup sums a 32 (k) x 32 (n) tile of the
+// slabs with coalesced reads (same split order: bit-identical sums), turns it through LDS and writes 128-byte runs of the gradient.
+__global__ __launch_bounds__(256) void tn_reduce_tr_kernel(const float* __restrict__ partial, int nsplit, size_t slab, int Npad, int N, int Kreal,
+                                                           float* __restrict__ grad, int64_t gN, int accumulate) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int k0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) {
+    const int k = k0 + r, n = n0 + tx;
+    float sum = 0.f;
+    if (k < Kreal && n < Npad) {
+      const float* p = partial + (size_t)k * Npad + n;
+      for (int sp = 0; sp < nsplit; ++sp) sum += p[(size_t)sp * slab];
+    }
+    tile[r][tx] = sum;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) {
+    const int n = n0 + r, k = k0 + tx;
+    if (n < N && k < Kreal) {
+      float* g = grad + (int64_t)n * gN + k;
+      *g = accumulate ? *g + tile[tx][r] : tile[tx][r];
+    }
+  }
+}
+
 static bool wgrad_generic_forced() { static const bool on = ksmi_knob_is_set("KSMI_WGRAD_GENERIC"); return on; }
 // eligibility of the token-GEMM path and its split geometry
 static bool gemm_tn_eligible(const ksmi_wgrad_desc* d, int es) {
@@ -872,6 +902,14 @@ int launch_wgrad(const ksmi_wgrad_desc* d, hipStream_t st) {
           int blocksr = (int)((totalr * 8 + 255) / 256); if (blocksr > 4096) blocksr = 4096;
           hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocksr), dim3(256), 0, st, *d, 1, g.kc);
           return ksmi_check_launch("wgrad_reduce");
+        }
+        static const int tr_on = ksmi_knob_int("KSMI_TN_REDUCE_TR", 1);      // 0: the element-wise reducer (round 1)
+        if (tr_on && plain) {
+          const int Kreal = d->uniform_kc ? d->k_total : d->k_off[d->nchunks - 1] + d->k_len[d->nchunks - 1];
+          const dim3 gridr((g.npad + 31) / 32, (Kreal + 31) / 32);
+          hipLaunchKernelGGL(tn_reduce_tr_kernel, gridr, dim3(256), 0, st, d->partial, g.nsplit, (size_t)d->nchunks * g.kc * g.npad, g.npad, d->N, Kreal,
+                             d->grad, d->gN, d->accumulate);
+          return ksmi_check_launch("tn_reduce_tr");
         }
         const size_t total0 = (size_t)d->nchunks * g.kc * g.npad / 4;
         int blocks0 = (int)((total0 + 255) / 256); if (blocks0 > 8192) blocks0 = 8192;
